@@ -1,0 +1,267 @@
+"""c_lwe_snarks_amd -- thin ctypes binding over libmfhip.so (the C ABI in include/mfhip.h).
+
+The product is the HIP library and its C ABI; this module only exists so that pytest, bench.py and
+__graft_entry__.py can drive that ABI with torch-owned device memory.  There is no CPU fallback: if the
+shared library is missing, or no HIP device is usable, construction fails loudly.
+
+(The directory is named ``c-lwe-snarks_amd``; ``c_lwe_snarks_amd.py`` at the repo root loads it under an
+importable name.)
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmfhip.so")
+P = 0xFFFFFFFB  # GAMMA_P, reference src/lwe.h:25
+
+
+class MfhError(RuntimeError):
+    pass
+
+
+@dataclass(frozen=True)
+class Params:
+    """GAMMA_* of reference src/lwe.h:14-31 as runtime values."""
+
+    n: int = 1470
+    logq: int = 736
+    d: int = 1 << 15
+    m: int = 21845
+
+    @property
+    def L(self):  # limbs per value
+        return (self.logq + 63) // 64
+
+    @property
+    def K(self):  # limbs surviving modq
+        return self.logq // 64
+
+    @property
+    def ctb(self):  # CT_BYTES
+        return self.logq // 8
+
+    @property
+    def ctr_ct(self):  # CTR_CT, src/snark.h:8
+        return self.ctb * self.n
+
+    @property
+    def ctr_s(self):
+        return 0
+
+    @property
+    def ctr_as(self):
+        return self.ctr_ct * self.d
+
+    @property
+    def ctr_bt(self):
+        return 2 * self.ctr_ct * self.d
+
+    @property
+    def ctr_bv(self):
+        return 2 * self.ctr_ct * self.d + self.ctr_ct
+
+    @property
+    def ct_limbs(self):
+        return (self.n + 1) * self.L
+
+
+DEBUG = Params(d=256, m=64)  # the reference's !NDEBUG parameters (src/lwe.h:18-21)
+DEFAULT = Params()  # NDEBUG parameters (src/lwe.h:14-17)
+
+
+class _CParams(ctypes.Structure):
+    _fields_ = [("n", ctypes.c_uint32), ("logq", ctypes.c_uint32), ("d", ctypes.c_uint32), ("m", ctypes.c_uint32)]
+
+
+_lib = None
+
+EXPORTS = [
+    "mfh_ctx_create", "mfh_ctx_destroy", "mfh_set_stream", "mfh_sync", "mfh_last_error", "mfh_set_seed",
+    "mfh_keystream", "mfh_sample_rows", "mfh_ct_add", "mfh_ct_mul_ui", "mfh_ct_addmul_ui", "mfh_eval_rows",
+    "mfh_encrypt_rows", "mfh_decrypt", "mfh_ct_smudge", "mfh_ssp_upload", "mfh_witness_poly", "mfh_version",
+    "mfh_workspace_bytes", "mfh_last_kernel_ms", "mfh_set_timing",
+]
+
+
+def load_library():
+    """dlopen libmfhip.so; raises MfhError (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MfhError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, u64, sz, i32, u32 = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint32
+    sig = {
+        "mfh_ctx_create": (i32, [ctypes.POINTER(vp), i32, ctypes.POINTER(_CParams)]),
+        "mfh_ctx_destroy": (None, [vp]),
+        "mfh_set_stream": (i32, [vp, vp]),
+        "mfh_sync": (i32, [vp]),
+        "mfh_last_error": (ctypes.c_char_p, [vp]),
+        "mfh_set_seed": (i32, [vp, ctypes.c_char_p]),
+        "mfh_keystream": (i32, [vp, u64, vp, sz]),
+        "mfh_sample_rows": (i32, [vp, u64, sz, vp]),
+        "mfh_ct_add": (i32, [vp, vp, vp, vp, sz]),
+        "mfh_ct_mul_ui": (i32, [vp, vp, vp, u32, sz]),
+        "mfh_ct_addmul_ui": (i32, [vp, vp, vp, u32, sz]),
+        "mfh_eval_rows": (i32, [vp, u64, sz, vp, vp, vp, vp, vp, i32]),
+        "mfh_encrypt_rows": (i32, [vp, u64, sz, vp, vp, vp, vp]),
+        "mfh_decrypt": (i32, [vp, vp, vp, sz, vp]),
+        "mfh_ct_smudge": (i32, [vp, vp, sz, ctypes.c_char_p, sz, ctypes.c_char_p]),
+        "mfh_ssp_upload": (i32, [vp, vp, vp, sz, sz]),
+        "mfh_witness_poly": (i32, [vp, vp, ctypes.c_char_p, u32, vp]),
+        "mfh_version": (ctypes.c_char_p, []),
+        "mfh_workspace_bytes": (sz, [vp]),
+        "mfh_last_kernel_ms": (ctypes.c_float, [vp, ctypes.c_char_p]),
+        "mfh_set_timing": (i32, [vp, i32]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export what the header declares
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+class Context:
+    """One prover context on one GPU (one process per GPU).  Mirrors the reference's implicit global state:
+    an `rng_t` seeded from the CRS seed (src/snark.c:59,119) plus the parameter macros."""
+
+    def __init__(self, params: Params = DEFAULT, device: int = 0):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise MfhError("no HIP device visible: the MI355X path has no CPU fallback")
+        self.torch = torch
+        self.lib = load_library()
+        self.params = params
+        self.device = torch.device("cuda", device)
+        self._h = ctypes.c_void_p()
+        cp = _CParams(params.n, params.logq, params.d, params.m)
+        rc = self.lib.mfh_ctx_create(ctypes.byref(self._h), device, ctypes.byref(cp))
+        if rc != 0:
+            raise MfhError(f"mfh_ctx_create failed ({rc})")
+        # run on torch's current stream so torch allocations/copies and our kernels are ordered
+        self._chk(self.lib.mfh_set_stream(self._h, ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+
+    def close(self):
+        if self._h:
+            self.lib.mfh_ctx_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise MfhError(f"libmfhip error {rc}: {self.lib.mfh_last_error(self._h).decode()}")
+
+    # -- helpers ---------------------------------------------------------------------------------------
+    def empty(self, nbytes):
+        return self.torch.empty(int(nbytes), dtype=self.torch.uint8, device=self.device)
+
+    def zeros(self, nbytes):
+        return self.torch.zeros(int(nbytes), dtype=self.torch.uint8, device=self.device)
+
+    def to_device(self, arr):
+        a = np.ascontiguousarray(arr)
+        return self.torch.from_numpy(a.view(np.uint8).reshape(-1)).to(self.device)
+
+    def to_host(self, t, dtype=np.uint8):
+        return t.cpu().numpy().view(dtype)
+
+    def sync(self):
+        self._chk(self.lib.mfh_sync(self._h))
+
+    def set_timing(self, on=True):
+        self._chk(self.lib.mfh_set_timing(self._h, 1 if on else 0))
+
+    def last_kernel_ms(self, which):
+        return float(self.lib.mfh_last_kernel_ms(self._h, which.encode()))
+
+    # -- reference-shaped operations ----------------------------------------------------------------------
+    def set_seed(self, seed: bytes):
+        """rng_init(rng, seed) -- src/entropy.c:58-61."""
+        assert len(seed) == 40
+        self._chk(self.lib.mfh_set_seed(self._h, bytes(seed)))
+
+    def keystream(self, off, nbytes, out=None):
+        """rng_seek(off); rng_gen(nbytes) -- src/entropy.c:46-56, src/aes.c:104-144."""
+        out = self.empty(nbytes) if out is None else out
+        self._chk(self.lib.mfh_keystream(self._h, off, _ptr(out), nbytes))
+        return out
+
+    def sample_rows(self, off, nrows):
+        """mpz2_urandommv for nrows rows -- src/entropy.h:62-66.  Returns uint8 tensor of nrows*n*L*8 bytes."""
+        p = self.params
+        out = self.empty(nrows * p.n * p.L * 8)
+        self._chk(self.lib.mfh_sample_rows(self._h, off, nrows, _ptr(out)))
+        return out
+
+    def ct_add(self, a, b, count=1, out=None):
+        out = self.empty(a.numel()) if out is None else out
+        self._chk(self.lib.mfh_ct_add(self._h, _ptr(out), _ptr(a), _ptr(b), count))
+        return out
+
+    def ct_mul_ui(self, a, x, count=1, out=None):
+        out = self.empty(a.numel()) if out is None else out
+        self._chk(self.lib.mfh_ct_mul_ui(self._h, _ptr(out), _ptr(a), x, count))
+        return out
+
+    def ct_addmul_ui(self, rop, a, x, count=1):
+        self._chk(self.lib.mfh_ct_addmul_ui(self._h, _ptr(rop), _ptr(a), x, count))
+        return rop
+
+    def eval_rows(self, off, nrows, c8, coeff0, coeff1=None, rop0=None, rop1=None, accumulate=False):
+        """eval_poly (src/lwe.c:176-186) for one or two coefficient vectors; returns (rop0, rop1)."""
+        p = self.params
+        if rop0 is None:
+            rop0 = self.empty(p.ct_limbs * 8)
+        if coeff1 is not None and rop1 is None:
+            rop1 = self.empty(p.ct_limbs * 8)
+        self._chk(self.lib.mfh_eval_rows(self._h, off, nrows, _ptr(c8), _ptr(coeff0), _ptr(coeff1), _ptr(rop0), _ptr(rop1),
+                                         1 if accumulate else 0))
+        return rop0, rop1
+
+    def encrypt_rows(self, off, nrows, sk, msg, err, out=None):
+        """regev_encrypt2 + ct_export batch (src/lwe.c:78-97,115-119)."""
+        p = self.params
+        out = self.empty(nrows * p.ctb) if out is None else out
+        self._chk(self.lib.mfh_encrypt_rows(self._h, off, nrows, _ptr(sk), _ptr(msg), _ptr(err), _ptr(out)))
+        return out
+
+    def decrypt(self, sk, cts, count):
+        out = self.empty(4 * count)
+        self._chk(self.lib.mfh_decrypt(self._h, _ptr(sk), _ptr(cts), count, _ptr(out)))
+        return out
+
+    def ct_smudge(self, cts, count, mag: bytes, maglen, sign: bytes):
+        self._chk(self.lib.mfh_ct_smudge(self._h, _ptr(cts), count, bytes(mag), maglen, bytes(sign)))
+        return cts
+
+    def ssp_upload(self, ssp_host_u64: np.ndarray, d_ssp=None, first_slot=0, nslots=None):
+        p = self.params
+        nslots = p.m + 3 if nslots is None else nslots
+        if d_ssp is None:
+            d_ssp = self.empty((p.m + 3) * p.d * 4)
+        a = np.ascontiguousarray(ssp_host_u64)
+        self._chk(self.lib.mfh_ssp_upload(self._h, ctypes.c_void_p(a.ctypes.data), _ptr(d_ssp), first_slot, nslots))
+        return d_ssp
+
+    def witness_poly(self, d_ssp, witness_bits: bytes, delta):
+        out = self.empty(self.params.d * 4)
+        self._chk(self.lib.mfh_witness_poly(self._h, _ptr(d_ssp), bytes(witness_bits), delta, _ptr(out)))
+        return out

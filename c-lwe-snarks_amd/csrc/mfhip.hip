@@ -1,0 +1,852 @@
+// mfhip.hip -- MI355X (gfx950) kernels and the C ABI of include/mfhip.h.
+//
+// Hot path of mmaker/c-lwe-snarks re-designed for CDNA4 (citations: reference file:line):
+//   eval_poly  (src/lwe.c:176-186)  = ct_import (regenerate 1470 x 92 B of AES-256-CTR per row, src/lwe.c:122-126)
+//                                     + ct_addmul_ui (1471 x [704-bit += 736-bit x 32-bit], src/lwe.c:141-149)
+//   regev_encrypt2 (src/lwe.c:78-97) = same row expansion + <sk, a> (1470 truncated 704x704-bit products)
+// The reference spends ~97 % of a prover row in the keystream.  Here the keystream never leaves the CU:
+// a workgroup expands a 512-coordinate tile of one ciphertext row into LDS (T-table AES, table replicated
+// 32x in LDS so lookups are bank-conflict free), then every thread multiply-accumulates "its" coordinate
+// into register-resident 32-bit limbs.  HBM sees only the 92-byte b's, the coefficients and one partial
+// accumulator per workgroup.
+#include <hip/hip_runtime.h>
+
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "aes_dev.hpp"
+#include "mfhip.h"
+
+using mf::AesKey;
+
+// ------------------------------------------------------------------------------------------------------
+// Compile-time parameter sets.  logq = 736 is the reference's (src/lwe.h:24); 1472 is BASELINE config 5.
+// ------------------------------------------------------------------------------------------------------
+template <int LOGQ>
+struct PS {
+  static constexpr int CTB = LOGQ / 8;         // CT_BYTES
+  static constexpr int EW = CTB / 4;           // stream words per element (23 | 46)
+  static constexpr int L = (LOGQ + 63) / 64;   // limbs of a value (12 | 23)
+  static constexpr int K = LOGQ / 64;          // limbs surviving modq (11 | 23)
+  static constexpr int KW = 2 * K;             // 32-bit words surviving modq (22 | 46)
+  static constexpr int TILE = LOGQ == 736 ? 512 : 256;  // coordinates (= threads) per workgroup
+  static constexpr int KS_BYTES = TILE * CTB + 16;      // one row tile of keystream (+1 block when misaligned)
+};
+
+#define HIP_TRY(ctx, expr)                                                        \
+  do {                                                                            \
+    hipError_t e_ = (expr);                                                       \
+    if (e_ != hipSuccess) {                                                       \
+      (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);             \
+      return MFH_EDEVICE;                                                         \
+    }                                                                             \
+  } while (0)
+
+struct mfh_ctx {
+  mfh_params P{};
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  AesKey key{};
+  bool have_seed = false;
+  uint32_t *d_t0 = nullptr;  // 256 words
+  void *ws = nullptr;        // scratch (partials etc.)
+  size_t ws_bytes = 0;
+  std::string err;
+  bool timing = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  float ms_eval = -1.f, ms_encrypt = -1.f, ms_keystream = -1.f;
+};
+
+static int ws_reserve(mfh_ctx *c, size_t bytes) {
+  if (bytes <= c->ws_bytes) return MFH_OK;
+  if (c->ws) {
+    hipStreamSynchronize(c->stream);
+    hipFree(c->ws);
+    c->ws = nullptr;
+    c->ws_bytes = 0;
+  }
+  bytes = (bytes + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
+  if (hipMalloc(&c->ws, bytes) != hipSuccess) {
+    c->err = "hipMalloc(workspace) failed";
+    return MFH_ENOMEM;
+  }
+  c->ws_bytes = bytes;
+  return MFH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// keystream kernel: aesctr_prg / rng_seek (src/aes.c:104-144, src/entropy.c:46-56), stateless form
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_keystream(AesKey key, const uint32_t *__restrict__ g_t0, uint64_t off,
+                                                   uint8_t *__restrict__ out, uint64_t nbytes) {
+  __shared__ uint32_t lt[mf::kT0Words];
+  mf::lds_fill_t0(lt, g_t0);
+  __syncthreads();
+  const uint32_t *tl = lt + (threadIdx.x & 31);
+  const uint64_t cb0 = off >> 4;
+  const uint32_t head = (uint32_t)(off & 15);
+  const uint64_t nblk = (head + nbytes + 15) >> 4;
+  const bool aligned = head == 0 && (((uintptr_t)out) & 15) == 0;
+  for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nblk; b += (uint64_t)gridDim.x * blockDim.x) {
+    uint32_t w[4];
+    mf::aes256_ctr_block(tl, key, cb0 + b, w);
+    int64_t o = (int64_t)(b * 16) - head;  // output index of this block's byte 0
+    if (aligned && (uint64_t)o + 16 <= nbytes) {
+      *reinterpret_cast<uint4 *>(out + o) = make_uint4(w[0], w[1], w[2], w[3]);
+    } else {
+      for (int i = 0; i < 16; i++) {
+        int64_t idx = o + i;
+        if (idx >= 0 && (uint64_t)idx < nbytes) out[idx] = (uint8_t)(w[i >> 2] >> (8 * (i & 3)));
+      }
+    }
+  }
+}
+
+// repack raw stream elements (CTB bytes each) into L-limb values, masked to logq bits
+template <int LOGQ>
+__global__ void k_repack_values(const uint32_t *__restrict__ ks, uint32_t *__restrict__ out, uint64_t nelem) {
+  using S = PS<LOGQ>;
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t total = nelem * (2 * S::L);
+  if (i >= total) return;
+  uint64_t e = i / (2 * S::L);
+  uint32_t w = (uint32_t)(i % (2 * S::L));
+  out[i] = w < S::EW ? ks[e * S::EW + w] : 0u;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Row-tile expansion into LDS, shared by eval and encrypt.
+// Tile = coordinates [j0, j0+TILE) of the row whose element 0 sits at stream byte `rowoff`.
+// Whole waves take whole 64-block rounds (block b -> thread b % TILE of round b / TILE), so a round in which
+// a wave has no block is skipped by that wave entirely: no half-empty issue slots.
+// ------------------------------------------------------------------------------------------------------
+template <int LOGQ>
+__device__ __forceinline__ uint32_t expand_tile_to_lds(const uint32_t *tl, const AesKey &key, uint8_t *ks, uint64_t rowoff,
+                                                       uint32_t j0, uint32_t nelem) {
+  using S = PS<LOGQ>;
+  const uint64_t B0 = rowoff + (uint64_t)j0 * S::CTB;
+  const uint64_t cb0 = B0 >> 4;
+  const uint32_t head = (uint32_t)(B0 & 15);
+  const uint32_t nblk = (head + nelem * S::CTB + 15) >> 4;
+  for (uint32_t b = threadIdx.x; b < nblk; b += S::TILE) {
+    uint32_t w[4];
+    mf::aes256_ctr_block(tl, key, cb0 + b, w);
+    *reinterpret_cast<uint4 *>(ks + 16 * b) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  return head;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// eval kernel: fused ct_import + ct_addmul_ui over a chunk of rows, 1 or 2 coefficient vectors.
+// grid = (ntiles, nchunks); block = TILE threads; thread t owns coordinate j0 + t.
+// partials: part[((chunk*NACC + a)*KW + l)*NJ + j]  (uint32), NJ = ntiles*TILE
+// ------------------------------------------------------------------------------------------------------
+template <int LOGQ, int NACC>
+__global__ __launch_bounds__(PS<LOGQ>::TILE) void k_eval(AesKey key, const uint32_t *__restrict__ g_t0, uint64_t off, uint32_t n,
+                                                         uint32_t nrows, uint32_t rows_per_chunk,
+                                                         const uint8_t *__restrict__ c8, const uint32_t *__restrict__ coeff0,
+                                                         const uint32_t *__restrict__ coeff1, uint32_t *__restrict__ part) {
+  using S = PS<LOGQ>;
+  __shared__ uint32_t lt[mf::kT0Words];
+  __shared__ __attribute__((aligned(16))) uint8_t ks[S::KS_BYTES];
+  mf::lds_fill_t0(lt, g_t0);
+  const uint32_t *tl = lt + (threadIdx.x & 31);
+  const uint32_t j0 = blockIdx.x * S::TILE;
+  const uint32_t j = j0 + threadIdx.x;
+  const uint32_t nelem = j0 >= n ? 0u : min((uint32_t)S::TILE, n - j0);  // keystream-backed coordinates in this tile
+  const uint32_t r0 = blockIdx.y * rows_per_chunk;
+  const uint32_t r1 = min(nrows, r0 + rows_per_chunk);
+  const uint32_t NJ = gridDim.x * S::TILE;
+
+  uint32_t acc[NACC][S::KW];
+#pragma unroll
+  for (int a = 0; a < NACC; a++)
+#pragma unroll
+    for (int l = 0; l < S::KW; l++) acc[a][l] = 0;
+
+  __syncthreads();
+  for (uint32_t row = r0; row < r1; row++) {
+    uint32_t c[NACC];
+    c[0] = coeff0[row];
+    if (NACC > 1) c[1] = coeff1[row];
+    bool any = c[0] != 0;
+    if (NACC > 1) any = any || c[1] != 0;
+    if (!any) continue;  // wave-uniform: the reference expands such rows only to advance its stream
+
+    const uint64_t rowoff = off + (uint64_t)row * n * S::CTB;
+    const uint32_t head = expand_tile_to_lds<LOGQ>(tl, key, ks, rowoff, j0, nelem);
+    __syncthreads();
+
+    if (j <= n) {
+      uint32_t a[S::KW];
+      if (j < n) {
+        const uint32_t *kw = reinterpret_cast<const uint32_t *>(ks + head) + threadIdx.x * S::EW;
+#pragma unroll
+        for (int l = 0; l < S::KW; l++) a[l] = kw[l];
+      } else {
+        const uint32_t *bw = reinterpret_cast<const uint32_t *>(c8 + (uint64_t)row * S::CTB);
+#pragma unroll
+        for (int l = 0; l < S::KW; l++) a[l] = bw[l];
+      }
+#pragma unroll
+      for (int q = 0; q < NACC; q++) {
+        uint32_t carry = 0;
+#pragma unroll
+        for (int l = 0; l < S::KW; l++) {
+          uint64_t t = (uint64_t)a[l] * c[q] + acc[q][l] + carry;
+          acc[q][l] = (uint32_t)t;
+          carry = (uint32_t)(t >> 32);
+        }
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int a = 0; a < NACC; a++)
+#pragma unroll
+    for (int l = 0; l < S::KW; l++) part[(((uint64_t)blockIdx.y * NACC + a) * S::KW + l) * NJ + j] = acc[a][l];
+}
+
+// sum partials over chunks, propagate carries, write natural-layout values (optionally += previous)
+template <int LOGQ>
+__global__ void k_eval_reduce(const uint32_t *__restrict__ part, uint32_t nchunks, uint32_t nacc, uint32_t NJ, uint32_t n,
+                              uint64_t *__restrict__ rop0, uint64_t *__restrict__ rop1, int accumulate) {
+  using S = PS<LOGQ>;
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t a = blockIdx.y;
+  if (j > n) return;
+  uint64_t *rop = a == 0 ? rop0 : rop1;
+  uint32_t *out = reinterpret_cast<uint32_t *>(rop + (uint64_t)j * S::L);
+  uint64_t carry = 0;
+  for (int l = 0; l < S::KW; l++) {
+    uint64_t s = carry;
+    for (uint32_t ch = 0; ch < nchunks; ch++) s += part[(((uint64_t)ch * nacc + a) * S::KW + l) * NJ + j];
+    if (accumulate) s += out[l];
+    out[l] = (uint32_t)s;
+    carry = s >> 32;
+  }
+  for (int l = S::KW; l < 2 * S::L; l++) out[l] = 0;  // modq: limbs >= K dropped (src/lwe.h:107-118)
+}
+
+// ------------------------------------------------------------------------------------------------------
+// encrypt kernel: per row, <sk, a> over a coordinate tile (truncated KW-word products), reduced in LDS.
+// pb[(row*ntiles + tile)*KW + l] = tile partial of <sk,a> mod 2^(32 KW)
+// ------------------------------------------------------------------------------------------------------
+template <int LOGQ>
+__global__ __launch_bounds__(PS<LOGQ>::TILE) void k_encrypt(AesKey key, const uint32_t *__restrict__ g_t0, uint64_t off, uint32_t n,
+                                                            uint32_t nrows, uint32_t rows_per_chunk,
+                                                            const uint64_t *__restrict__ sk, uint32_t *__restrict__ pb) {
+  using S = PS<LOGQ>;
+  constexpr int NW = S::TILE / 64;
+  __shared__ uint32_t lt[mf::kT0Words];
+  __shared__ __attribute__((aligned(16))) uint8_t ks[S::KS_BYTES];
+  __shared__ uint64_t sums[S::KW];
+  mf::lds_fill_t0(lt, g_t0);
+  const uint32_t *tl = lt + (threadIdx.x & 31);
+  const uint32_t j0 = blockIdx.x * S::TILE;
+  const uint32_t j = j0 + threadIdx.x;
+  const uint32_t nelem = j0 >= n ? 0u : min((uint32_t)S::TILE, n - j0);
+  const uint32_t r0 = blockIdx.y * rows_per_chunk;
+  const uint32_t r1 = min(nrows, r0 + rows_per_chunk);
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+  uint32_t s[S::KW];
+  {
+    const uint32_t *sw = reinterpret_cast<const uint32_t *>(sk + (uint64_t)(j < n ? j : 0) * S::L);
+#pragma unroll
+    for (int l = 0; l < S::KW; l++) s[l] = j < n ? sw[l] : 0u;
+  }
+  uint32_t *red = reinterpret_cast<uint32_t *>(ks);  // [KW][TILE] words, reuses the keystream tile
+
+  __syncthreads();
+  for (uint32_t row = r0; row < r1; row++) {
+    const uint64_t rowoff = off + (uint64_t)row * n * S::CTB;
+    const uint32_t head = expand_tile_to_lds<LOGQ>(tl, key, ks, rowoff, j0, nelem);
+    __syncthreads();
+    uint32_t a[S::KW];
+    {
+      const uint32_t *kw = reinterpret_cast<const uint32_t *>(ks + head) + threadIdx.x * S::EW;
+#pragma unroll
+      for (int l = 0; l < S::KW; l++) a[l] = j < n ? kw[l] : 0u;
+    }
+    // prod = low KW words of a * s (operand scanning, carries dropped beyond KW)
+    uint32_t prod[S::KW];
+#pragma unroll
+    for (int l = 0; l < S::KW; l++) prod[l] = 0;
+#pragma unroll
+    for (int u = 0; u < S::KW; u++) {
+      uint32_t carry = 0;
+#pragma unroll
+      for (int v = 0; u + v < S::KW; v++) {
+        uint64_t t = (uint64_t)a[u] * s[v] + prod[u + v] + carry;
+        prod[u + v] = (uint32_t)t;
+        carry = (uint32_t)(t >> 32);
+      }
+    }
+    __syncthreads();  // everyone has read its keystream words
+#pragma unroll
+    for (int l = 0; l < S::KW; l++) red[l * S::TILE + threadIdx.x] = prod[l];
+    __syncthreads();
+    for (int l = wave; l < S::KW; l += NW) {
+      uint64_t t = 0;
+#pragma unroll
+      for (int k = 0; k < NW; k++) t += red[l * S::TILE + k * 64 + lane];
+#pragma unroll
+      for (int o = 32; o; o >>= 1) t += __shfl_xor(t, o);
+      if (lane == 0) sums[l] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint64_t carry = 0;
+      uint32_t *o = pb + ((uint64_t)row * gridDim.x + blockIdx.x) * S::KW;
+      for (int l = 0; l < S::KW; l++) {
+        uint64_t t = sums[l] + carry;
+        o[l] = (uint32_t)t;
+        carry = t >> 32;
+      }
+    }
+    // next iteration's expansion overwrites ks/red: all reads of red finished before the barrier above;
+    // sums[] is rewritten only after three more barriers.
+  }
+}
+
+// b = (e*p + sum_tiles pb + m) mod 2^(64K)  ->  CT_BYTES little-endian bytes (ct_export, src/lwe.c:115-119)
+template <int LOGQ>
+__global__ void k_encrypt_finish(const uint32_t *__restrict__ pb, uint32_t ntiles, uint32_t nrows, const uint32_t *__restrict__ msg,
+                                 const uint64_t *__restrict__ err, uint8_t *__restrict__ c8) {
+  using S = PS<LOGQ>;
+  uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= nrows) return;
+  const uint32_t *e = reinterpret_cast<const uint32_t *>(err + (uint64_t)row * S::L);
+  uint32_t *o = reinterpret_cast<uint32_t *>(c8 + (uint64_t)row * S::CTB);
+  uint64_t carry = msg[row];
+  uint64_t mulc = 0;
+  for (int l = 0; l < S::KW; l++) {
+    uint64_t ep = (uint64_t)e[l] * MFH_P + mulc;  // e*p, word l
+    mulc = ep >> 32;
+    uint64_t t = carry + (uint32_t)ep;
+    for (uint32_t k = 0; k < ntiles; k++) t += pb[((uint64_t)row * ntiles + k) * S::KW + l];
+    o[l] = (uint32_t)t;
+    carry = t >> 32;
+  }
+  for (int l = S::KW; l < S::EW; l++) o[l] = 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// small kernels: ct_add / ct_mul_ui / ct_addmul_ui (src/lwe.c:131-157), decrypt (src/lwe.c:105-111), smudge
+// ------------------------------------------------------------------------------------------------------
+template <int LOGQ, int OP>  // 0 add, 1 mul_ui, 2 addmul_ui
+__global__ void k_ct_elementwise(uint64_t *rop, const uint64_t *a, const uint64_t *b, uint32_t x, uint64_t nvalues) {
+  using S = PS<LOGQ>;
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nvalues) return;
+  const uint32_t *aw = reinterpret_cast<const uint32_t *>(a + i * S::L);
+  uint32_t *rw = reinterpret_cast<uint32_t *>(rop + i * S::L);
+  uint64_t carry = 0;
+  if (OP == 0) {
+    const uint32_t *bw = reinterpret_cast<const uint32_t *>(b + i * S::L);
+    for (int l = 0; l < S::KW; l++) {
+      uint64_t t = (uint64_t)aw[l] + bw[l] + carry;
+      rw[l] = (uint32_t)t;
+      carry = t >> 32;
+    }
+  } else {
+    for (int l = 0; l < S::KW; l++) {
+      uint64_t t = (uint64_t)aw[l] * x + carry + (OP == 2 ? rw[l] : 0u);
+      rw[l] = (uint32_t)t;
+      carry = t >> 32;
+    }
+  }
+  for (int l = S::KW; l < 2 * S::L; l++) rw[l] = 0;
+}
+
+__device__ __forceinline__ uint32_t words_mod_p(const uint32_t *w, int nw) {
+  // 2^32 = 5 (mod p): Horner from the top word
+  uint64_t r = 0;
+  for (int l = nw - 1; l >= 0; l--) r = (r * 5 + w[l]) % MFH_P;  // r < p, r*5 + w < 2^35: no overflow... (r<2^32)*5+2^32 fits
+  return (uint32_t)r;
+}
+
+// one workgroup (256 threads) per ciphertext
+template <int LOGQ>
+__global__ __launch_bounds__(256) void k_decrypt(const uint64_t *__restrict__ sk, const uint64_t *__restrict__ cts, uint32_t n,
+                                                 uint32_t *__restrict__ out) {
+  using S = PS<LOGQ>;
+  __shared__ uint32_t red[S::KW * 256];
+  __shared__ uint64_t sums[S::KW];
+  const uint64_t *ct = cts + (uint64_t)blockIdx.x * (n + 1) * S::L;
+  uint32_t acc[S::KW];
+#pragma unroll
+  for (int l = 0; l < S::KW; l++) acc[l] = 0;
+  for (uint32_t j = threadIdx.x; j < n; j += 256) {
+    const uint32_t *a = reinterpret_cast<const uint32_t *>(ct + (uint64_t)j * S::L);
+    const uint32_t *s = reinterpret_cast<const uint32_t *>(sk + (uint64_t)j * S::L);
+    uint32_t sw[S::KW];
+#pragma unroll
+    for (int l = 0; l < S::KW; l++) sw[l] = s[l];
+#pragma unroll
+    for (int u = 0; u < S::KW; u++) {
+      uint32_t au = a[u], carry = 0;
+#pragma unroll
+      for (int v = 0; u + v < S::KW; v++) {
+        uint64_t t = (uint64_t)au * sw[v] + acc[u + v] + carry;
+        acc[u + v] = (uint32_t)t;
+        carry = (uint32_t)(t >> 32);
+      }
+    }
+  }
+#pragma unroll
+  for (int l = 0; l < S::KW; l++) red[l * 256 + threadIdx.x] = acc[l];
+  __syncthreads();
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int l = wave; l < S::KW; l += 4) {
+    uint64_t t = 0;
+    for (int k = 0; k < 4; k++) t += red[l * 256 + k * 64 + lane];
+    for (int o = 32; o; o >>= 1) t += __shfl_xor(t, o);
+    if (lane == 0) sums[l] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t dot[S::KW];
+    uint64_t carry = 0;
+    for (int l = 0; l < S::KW; l++) {
+      uint64_t t = sums[l] + carry;
+      dot[l] = (uint32_t)t;
+      carry = t >> 32;
+    }
+    // b is taken at full L limbs (ct_import does not reduce it, src/lwe.c:125)
+    const uint32_t *b = reinterpret_cast<const uint32_t *>(ct + (uint64_t)n * S::L);
+    uint32_t bm = words_mod_p(b, 2 * S::L), dm = words_mod_p(dot, S::KW);
+    out[blockIdx.x] = (uint32_t)(((uint64_t)bm + MFH_P - dm) % MFH_P);
+  }
+}
+
+template <int LOGQ>
+__global__ void k_smudge(uint64_t *cts, uint32_t n, const uint32_t *__restrict__ up /*count x KW words*/, const uint8_t *__restrict__ sign,
+                         uint32_t count) {
+  using S = PS<LOGQ>;
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  uint32_t *b = reinterpret_cast<uint32_t *>(cts + ((uint64_t)i * (n + 1) + n) * S::L);
+  const uint32_t *u = up + (uint64_t)i * S::KW;
+  if (sign[i] & 1) {
+    uint32_t borrow = 0;
+    for (int l = 0; l < S::KW; l++) {
+      uint64_t t = (uint64_t)b[l] - u[l] - borrow;
+      b[l] = (uint32_t)t;
+      borrow = (uint32_t)(t >> 63);
+    }
+  } else {
+    uint32_t carry = 0;
+    for (int l = 0; l < S::KW; l++) {
+      uint64_t t = (uint64_t)b[l] + u[l] + carry;
+      b[l] = (uint32_t)t;
+      carry = (uint32_t)(t >> 32);
+    }
+  }
+  for (int l = S::KW; l < 2 * S::L; l++) b[l] = 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// SSP: layout conversion and the witness polynomial (src/ssp.c:28-34, src/snark.c:141,147-155)
+// ------------------------------------------------------------------------------------------------------
+__global__ void k_ssp_reduce(const uint64_t *__restrict__ in, uint32_t *__restrict__ out, uint64_t ncoef) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ncoef; i += (uint64_t)gridDim.x * blockDim.x)
+    out[i] = (uint32_t)(in[i] % MFH_P);
+}
+
+// partial[g][k] = sum over the g-th share of selected rows of v_row[k]   (uint64, no reduction needed: < 2^32 * rows)
+__global__ __launch_bounds__(256) void k_witness_partial(const uint32_t *__restrict__ ssp, const uint32_t *__restrict__ rows, uint32_t nsel,
+                                                         uint32_t d, uint64_t *__restrict__ partial) {
+  const uint32_t k4 = blockIdx.x * blockDim.x + threadIdx.x;  // group of 4 coefficients
+  if (k4 * 4 >= d) return;
+  const uint32_t G = gridDim.y, g = blockIdx.y;
+  uint64_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  for (uint32_t i = g; i < nsel; i += G) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(ssp + (uint64_t)rows[i] * d + (uint64_t)k4 * 4);
+    s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
+  }
+  uint64_t *o = partial + (uint64_t)g * d + (uint64_t)k4 * 4;
+  o[0] = s0; o[1] = s1; o[2] = s2; o[3] = s3;
+}
+
+__global__ void k_witness_finish(const uint32_t *__restrict__ ssp, const uint64_t *__restrict__ partial, uint32_t G, uint32_t d, uint32_t delta,
+                                 uint32_t *__restrict__ w) {
+  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= d) return;
+  uint64_t s = ((uint64_t)ssp[k] * delta) % MFH_P;  // slot 0 = t
+  for (uint32_t g = 0; g < G; g++) s = (s + partial[(uint64_t)g * d + k] % MFH_P) % MFH_P;
+  w[k] = (uint32_t)s;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------
+struct Timer {
+  mfh_ctx *c;
+  float *dst;
+  Timer(mfh_ctx *c_, float *d) : c(c_), dst(d) {
+    if (c->timing) hipEventRecord(c->ev0, c->stream);
+  }
+  ~Timer() {
+    if (c->timing) {
+      hipEventRecord(c->ev1, c->stream);
+      hipEventSynchronize(c->ev1);
+      hipEventElapsedTime(dst, c->ev0, c->ev1);
+    }
+  }
+};
+
+extern "C" {
+
+const char *mfh_version(void) { return "mfhip 0.1 (gfx950)"; }
+
+int mfh_ctx_create(mfh_ctx **out, int device, const mfh_params *P) {
+  if (!out || !P) return MFH_EINVAL;
+  *out = nullptr;
+  if (P->logq != 736 && P->logq != 1472) return MFH_EUNSUPPORTED;
+  if (P->n == 0 || P->n > (1u << 20)) return MFH_EINVAL;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return MFH_EDEVICE;
+  if (hipSetDevice(device) != hipSuccess) return MFH_EDEVICE;
+  mfh_ctx *c = new mfh_ctx();
+  c->P = *P;
+  c->device = device;
+  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    return MFH_EDEVICE;
+  }
+  c->stream = c->own_stream;
+  uint32_t t0[256];
+  mf::make_t0_le(t0);
+  if (hipMalloc(&c->d_t0, sizeof t0) != hipSuccess || hipMemcpy(c->d_t0, t0, sizeof t0, hipMemcpyHostToDevice) != hipSuccess ||
+      hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+    mfh_ctx_destroy(c);
+    return MFH_EDEVICE;
+  }
+  *out = c;
+  return MFH_OK;
+}
+
+void mfh_ctx_destroy(mfh_ctx *c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  if (c->stream) hipStreamSynchronize(c->stream);
+  if (c->ws) hipFree(c->ws);
+  if (c->d_t0) hipFree(c->d_t0);
+  if (c->ev0) hipEventDestroy(c->ev0);
+  if (c->ev1) hipEventDestroy(c->ev1);
+  if (c->own_stream) hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+int mfh_set_stream(mfh_ctx *c, void *s) {
+  if (!c) return MFH_EINVAL;
+  c->stream = (hipStream_t)s;  // NULL is HIP's default (null) stream, which torch uses by default
+  return MFH_OK;
+}
+
+int mfh_sync(mfh_ctx *c) {
+  if (!c) return MFH_EINVAL;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return MFH_OK;
+}
+
+const char *mfh_last_error(const mfh_ctx *c) { return c ? c->err.c_str() : "null context"; }
+size_t mfh_workspace_bytes(const mfh_ctx *c) { return c ? c->ws_bytes : 0; }
+int mfh_set_timing(mfh_ctx *c, int en) {
+  if (!c) return MFH_EINVAL;
+  c->timing = en != 0;
+  return MFH_OK;
+}
+float mfh_last_kernel_ms(mfh_ctx *c, const char *which) {
+  if (!c || !which) return -1.f;
+  if (!strcmp(which, "eval")) return c->ms_eval;
+  if (!strcmp(which, "encrypt")) return c->ms_encrypt;
+  if (!strcmp(which, "keystream")) return c->ms_keystream;
+  return -1.f;
+}
+
+int mfh_set_seed(mfh_ctx *c, const uint8_t seed[40]) {
+  if (!c || !seed) return MFH_EINVAL;
+  mf::expand_key(c->key, seed);
+  c->have_seed = true;
+  return MFH_OK;
+}
+
+#define NEED_SEED(c)                                  \
+  do {                                                \
+    if (!(c)->have_seed) {                            \
+      (c)->err = "mfh_set_seed has not been called";  \
+      return MFH_EINVAL;                              \
+    }                                                 \
+  } while (0)
+
+#define DISPATCH_LOGQ(c, CALL736, CALL1472) \
+  do {                                      \
+    if ((c)->P.logq == 736) {               \
+      CALL736;                              \
+    } else {                                \
+      CALL1472;                             \
+    }                                       \
+  } while (0)
+
+int mfh_keystream(mfh_ctx *c, uint64_t off, void *d_out, size_t nbytes) {
+  if (!c || (!d_out && nbytes)) return MFH_EINVAL;
+  NEED_SEED(c);
+  if (!nbytes) return MFH_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  uint64_t nblk = ((off & 15) + nbytes + 15) >> 4;
+  uint32_t grid = (uint32_t)std::min<uint64_t>((nblk + 255) / 256, 256 * 8);
+  {
+    Timer t(c, &c->ms_keystream);
+    hipLaunchKernelGGL(k_keystream, dim3(grid), dim3(256), 0, c->stream, c->key, c->d_t0, off, (uint8_t *)d_out, (uint64_t)nbytes);
+  }
+  HIP_TRY(c, hipGetLastError());
+  return MFH_OK;
+}
+
+int mfh_sample_rows(mfh_ctx *c, uint64_t off, size_t nrows, uint64_t *d_out) {
+  if (!c || (!d_out && nrows)) return MFH_EINVAL;
+  NEED_SEED(c);
+  if (!nrows) return MFH_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint64_t nelem = (uint64_t)nrows * c->P.n;
+  const uint64_t bytes = nelem * (c->P.logq / 8);
+  void *tmp = nullptr;
+  HIP_TRY(c, hipMalloc(&tmp, bytes));
+  int rc = mfh_keystream(c, off, tmp, bytes);
+  if (rc == MFH_OK) {
+    const uint64_t total = nelem * 2 * ((c->P.logq + 63) / 64);
+    dim3 grid((uint32_t)((total + 255) / 256));
+    DISPATCH_LOGQ(c, hipLaunchKernelGGL(k_repack_values<736>, grid, dim3(256), 0, c->stream, (const uint32_t *)tmp, (uint32_t *)d_out, nelem),
+                  hipLaunchKernelGGL(k_repack_values<1472>, grid, dim3(256), 0, c->stream, (const uint32_t *)tmp, (uint32_t *)d_out, nelem));
+    if (hipGetLastError() != hipSuccess) rc = MFH_EDEVICE;
+  }
+  hipStreamSynchronize(c->stream);
+  hipFree(tmp);
+  return rc;
+}
+
+}  // extern "C"
+
+template <int LOGQ, int OP>
+static int ct_elementwise(mfh_ctx *c, uint64_t *rop, const uint64_t *a, const uint64_t *b, uint32_t x, size_t count) {
+  const uint64_t nvalues = (uint64_t)count * (c->P.n + 1);
+  if (!nvalues) return MFH_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  hipLaunchKernelGGL((k_ct_elementwise<LOGQ, OP>), dim3((uint32_t)((nvalues + 255) / 256)), dim3(256), 0, c->stream, rop, a, b, x, nvalues);
+  HIP_TRY(c, hipGetLastError());
+  return MFH_OK;
+}
+
+extern "C" {
+
+int mfh_ct_add(mfh_ctx *c, uint64_t *rop, const uint64_t *a, const uint64_t *b, size_t count) {
+  if (!c || !rop || !a || !b) return MFH_EINVAL;
+  DISPATCH_LOGQ(c, return (ct_elementwise<736, 0>(c, rop, a, b, 0, count)), return (ct_elementwise<1472, 0>(c, rop, a, b, 0, count)));
+}
+int mfh_ct_mul_ui(mfh_ctx *c, uint64_t *rop, const uint64_t *a, uint32_t x, size_t count) {
+  if (!c || !rop || !a) return MFH_EINVAL;
+  if (x >= MFH_P) { c->err = "ct_mul_ui: scalar must be < p (src/lwe.c:133)"; return MFH_EINVAL; }
+  DISPATCH_LOGQ(c, return (ct_elementwise<736, 1>(c, rop, a, nullptr, x, count)), return (ct_elementwise<1472, 1>(c, rop, a, nullptr, x, count)));
+}
+int mfh_ct_addmul_ui(mfh_ctx *c, uint64_t *rop, const uint64_t *a, uint32_t x, size_t count) {
+  if (!c || !rop || !a) return MFH_EINVAL;
+  if (x >= MFH_P) { c->err = "ct_addmul_ui: scalar must be < p (src/lwe.c:143)"; return MFH_EINVAL; }
+  DISPATCH_LOGQ(c, return (ct_elementwise<736, 2>(c, rop, a, nullptr, x, count)), return (ct_elementwise<1472, 2>(c, rop, a, nullptr, x, count)));
+}
+
+static void chunking(uint32_t nrows, uint32_t ntiles, uint32_t &nchunks, uint32_t &rpc) {
+  // ~4 workgroups per CU's worth of chunks, at least 8 rows each so the table fill amortises
+  uint32_t target = std::max(1u, (256u * 4u) / ntiles);
+  rpc = std::max(8u, (nrows + target - 1) / target);
+  nchunks = (nrows + rpc - 1) / rpc;
+}
+
+}  // extern "C"
+
+template <int LOGQ>
+static int eval_rows(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *c8, const uint32_t *c0, const uint32_t *c1, uint64_t *rop0,
+                     uint64_t *rop1, int accumulate) {
+  using S = PS<LOGQ>;
+  const uint32_t n = c->P.n;
+  const uint32_t ntiles = (n + 1 + S::TILE - 1) / S::TILE;
+  const int nacc = c1 ? 2 : 1;
+  uint32_t nchunks, rpc;
+  chunking((uint32_t)nrows, ntiles, nchunks, rpc);
+  const uint32_t NJ = ntiles * S::TILE;
+  const size_t part_bytes = (size_t)nchunks * nacc * S::KW * NJ * 4;
+  int rc = ws_reserve(c, part_bytes);
+  if (rc) return rc;
+  uint32_t *part = (uint32_t *)c->ws;
+  {
+    Timer t(c, &c->ms_eval);
+    if (nacc == 2)
+      hipLaunchKernelGGL((k_eval<LOGQ, 2>), dim3(ntiles, nchunks), dim3(S::TILE), 0, c->stream, c->key, c->d_t0, off, n, (uint32_t)nrows, rpc,
+                         c8, c0, c1, part);
+    else
+      hipLaunchKernelGGL((k_eval<LOGQ, 1>), dim3(ntiles, nchunks), dim3(S::TILE), 0, c->stream, c->key, c->d_t0, off, n, (uint32_t)nrows, rpc,
+                         c8, c0, c1, part);
+  }
+  HIP_TRY(c, hipGetLastError());
+  hipLaunchKernelGGL(k_eval_reduce<LOGQ>, dim3((n + 1 + 255) / 256, nacc), dim3(256), 0, c->stream, part, nchunks, (uint32_t)nacc, NJ, n, rop0,
+                     rop1, accumulate);
+  HIP_TRY(c, hipGetLastError());
+  return MFH_OK;
+}
+
+extern "C" {
+
+int mfh_eval_rows(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d_c8, const uint32_t *d_coeff0, const uint32_t *d_coeff1,
+                  uint64_t *d_rop0, uint64_t *d_rop1, int accumulate) {
+  if (!c || !d_rop0 || (nrows && (!d_c8 || !d_coeff0)) || ((d_coeff1 == nullptr) != (d_rop1 == nullptr))) return MFH_EINVAL;
+  NEED_SEED(c);
+  if (nrows > 0xffffffffu) return MFH_EINVAL;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (nrows == 0) {
+    if (!accumulate) {
+      size_t bytes = (size_t)(c->P.n + 1) * ((c->P.logq + 63) / 64) * 8;
+      HIP_TRY(c, hipMemsetAsync(d_rop0, 0, bytes, c->stream));
+      if (d_rop1) HIP_TRY(c, hipMemsetAsync(d_rop1, 0, bytes, c->stream));
+    }
+    return MFH_OK;
+  }
+  DISPATCH_LOGQ(c, return eval_rows<736>(c, off, nrows, d_c8, d_coeff0, d_coeff1, d_rop0, d_rop1, accumulate),
+                return eval_rows<1472>(c, off, nrows, d_c8, d_coeff0, d_coeff1, d_rop0, d_rop1, accumulate));
+}
+
+}  // extern "C"
+
+template <int LOGQ>
+static int encrypt_rows(mfh_ctx *c, uint64_t off, size_t nrows, const uint64_t *sk, const uint32_t *msg, const uint64_t *err, uint8_t *c8) {
+  using S = PS<LOGQ>;
+  const uint32_t n = c->P.n;
+  const uint32_t ntiles = (n + S::TILE - 1) / S::TILE;
+  uint32_t nchunks, rpc;
+  chunking((uint32_t)nrows, ntiles, nchunks, rpc);
+  rpc = std::max(1u, std::min(rpc, ((uint32_t)nrows + 255u) / 256u));  // rows are independent: prefer many small chunks
+  nchunks = ((uint32_t)nrows + rpc - 1) / rpc;
+  const size_t pb_bytes = (size_t)nrows * ntiles * S::KW * 4;
+  int rc = ws_reserve(c, pb_bytes);
+  if (rc) return rc;
+  uint32_t *pb = (uint32_t *)c->ws;
+  {
+    Timer t(c, &c->ms_encrypt);
+    hipLaunchKernelGGL(k_encrypt<LOGQ>, dim3(ntiles, nchunks), dim3(S::TILE), 0, c->stream, c->key, c->d_t0, off, n, (uint32_t)nrows, rpc, sk, pb);
+  }
+  HIP_TRY(c, hipGetLastError());
+  hipLaunchKernelGGL(k_encrypt_finish<LOGQ>, dim3(((uint32_t)nrows + 255) / 256), dim3(256), 0, c->stream, pb, ntiles, (uint32_t)nrows, msg, err, c8);
+  HIP_TRY(c, hipGetLastError());
+  return MFH_OK;
+}
+
+extern "C" {
+
+int mfh_encrypt_rows(mfh_ctx *c, uint64_t off, size_t nrows, const uint64_t *d_sk, const uint32_t *d_msg, const uint64_t *d_err,
+                     uint8_t *d_c8_out) {
+  if (!c || (nrows && (!d_sk || !d_msg || !d_err || !d_c8_out))) return MFH_EINVAL;
+  NEED_SEED(c);
+  if (!nrows) return MFH_OK;
+  if (nrows > 0xffffffffu) return MFH_EINVAL;
+  HIP_TRY(c, hipSetDevice(c->device));
+  DISPATCH_LOGQ(c, return encrypt_rows<736>(c, off, nrows, d_sk, d_msg, d_err, d_c8_out),
+                return encrypt_rows<1472>(c, off, nrows, d_sk, d_msg, d_err, d_c8_out));
+}
+
+int mfh_decrypt(mfh_ctx *c, const uint64_t *d_sk, const uint64_t *d_cts, size_t count, uint32_t *d_out) {
+  if (!c || (count && (!d_sk || !d_cts || !d_out))) return MFH_EINVAL;
+  if (!count) return MFH_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  DISPATCH_LOGQ(c, hipLaunchKernelGGL(k_decrypt<736>, dim3((uint32_t)count), dim3(256), 0, c->stream, d_sk, d_cts, c->P.n, d_out),
+                hipLaunchKernelGGL(k_decrypt<1472>, dim3((uint32_t)count), dim3(256), 0, c->stream, d_sk, d_cts, c->P.n, d_out));
+  HIP_TRY(c, hipGetLastError());
+  return MFH_OK;
+}
+
+int mfh_ct_smudge(mfh_ctx *c, uint64_t *d_cts, size_t count, const uint8_t *h_mag, size_t maglen, const uint8_t *h_sign) {
+  if (!c || (count && (!d_cts || !h_mag || !h_sign))) return MFH_EINVAL;
+  if (!count) return MFH_OK;
+  const uint32_t KW = 2 * (c->P.logq / 64);
+  if (maglen + 4 > (size_t)KW * 4) { c->err = "smudge magnitude too wide"; return MFH_EINVAL; }
+  HIP_TRY(c, hipSetDevice(c->device));
+  // u*p on the host (count is 5 per proof): schoolbook by 32-bit words
+  std::vector<uint32_t> up((size_t)count * KW, 0);
+  for (size_t i = 0; i < count; i++) {
+    std::vector<uint8_t> m(((maglen + 3) / 4) * 4, 0);
+    memcpy(m.data(), h_mag + i * maglen, maglen);
+    uint64_t carry = 0;
+    for (uint32_t l = 0; l < KW; l++) {
+      uint32_t w = 0;
+      if ((size_t)l * 4 < m.size()) memcpy(&w, m.data() + (size_t)l * 4, 4);
+      uint64_t t = (uint64_t)w * MFH_P + carry;
+      up[i * KW + l] = (uint32_t)t;
+      carry = t >> 32;
+    }
+  }
+  const size_t ub = up.size() * 4;
+  int rc = ws_reserve(c, ub + count);
+  if (rc) return rc;
+  HIP_TRY(c, hipMemcpyAsync(c->ws, up.data(), ub, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync((uint8_t *)c->ws + ub, h_sign, count, hipMemcpyHostToDevice, c->stream));
+  DISPATCH_LOGQ(c, hipLaunchKernelGGL(k_smudge<736>, dim3(((uint32_t)count + 63) / 64), dim3(64), 0, c->stream, d_cts, c->P.n, (const uint32_t *)c->ws,
+                                      (const uint8_t *)c->ws + ub, (uint32_t)count),
+                hipLaunchKernelGGL(k_smudge<1472>, dim3(((uint32_t)count + 63) / 64), dim3(64), 0, c->stream, d_cts, c->P.n, (const uint32_t *)c->ws,
+                                   (const uint8_t *)c->ws + ub, (uint32_t)count));
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipStreamSynchronize(c->stream));  // host vectors go out of scope
+  return MFH_OK;
+}
+
+int mfh_ssp_upload(mfh_ctx *c, const void *h_ssp_u64, uint32_t *d_ssp, size_t first_slot, size_t nslots) {
+  if (!c || !h_ssp_u64 || !d_ssp) return MFH_EINVAL;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t d = c->P.d;
+  const size_t chunk_slots = std::max<size_t>(1, (64u << 20) / (8 * d));
+  void *stage = nullptr;
+  HIP_TRY(c, hipMalloc(&stage, chunk_slots * d * 8));
+  int rc = MFH_OK;
+  for (size_t s = 0; s < nslots && rc == MFH_OK; s += chunk_slots) {
+    size_t ns = std::min(chunk_slots, nslots - s);
+    const uint8_t *src = (const uint8_t *)h_ssp_u64 + (first_slot + s) * d * 8;
+    if (hipMemcpyAsync(stage, src, ns * d * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = MFH_EDEVICE; break; }
+    hipLaunchKernelGGL(k_ssp_reduce, dim3(2048), dim3(256), 0, c->stream, (const uint64_t *)stage, d_ssp + (first_slot + s) * d, (uint64_t)ns * d);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) rc = MFH_EDEVICE;
+  }
+  hipFree(stage);
+  if (rc) c->err = "ssp upload failed";
+  return rc;
+}
+
+int mfh_witness_poly(mfh_ctx *c, const uint32_t *d_ssp, const uint8_t *h_bits, uint32_t delta, uint32_t *d_w) {
+  if (!c || !d_ssp || !h_bits || !d_w) return MFH_EINVAL;
+  if (delta >= MFH_P) { c->err = "delta must be < p"; return MFH_EINVAL; }
+  const uint32_t d = c->P.d, m = c->P.m;
+  if (d % 4) { c->err = "d must be a multiple of 4"; return MFH_EINVAL; }
+  HIP_TRY(c, hipSetDevice(c->device));
+  std::vector<uint32_t> rows;
+  for (uint32_t i = 1; i < m; i++)
+    if ((h_bits[(i - 1) >> 3] >> ((i - 1) & 7)) & 1) rows.push_back(i + 1);  // slot of v_i
+  const uint32_t nsel = (uint32_t)rows.size();
+  const uint32_t G = std::max(1u, std::min(64u, nsel / 8 + 1));
+  const size_t rows_b = ((size_t)nsel * 4 + 255) & ~(size_t)255;
+  int rc = ws_reserve(c, rows_b + (size_t)G * d * 8);
+  if (rc) return rc;
+  uint32_t *d_rows = (uint32_t *)c->ws;
+  uint64_t *partial = (uint64_t *)((uint8_t *)c->ws + rows_b);
+  if (nsel) HIP_TRY(c, hipMemcpyAsync(d_rows, rows.data(), (size_t)nsel * 4, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_witness_partial, dim3((d / 4 + 255) / 256, G), dim3(256), 0, c->stream, d_ssp, d_rows, nsel, d, partial);
+  HIP_TRY(c, hipGetLastError());
+  hipLaunchKernelGGL(k_witness_finish, dim3((d + 255) / 256), dim3(256), 0, c->stream, d_ssp, partial, G, d, delta, d_w);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipStreamSynchronize(c->stream));  // `rows` goes out of scope
+  return MFH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,123 @@
+/*
+ * mfhip.h -- C ABI of the MI355X-native LWE/SSP-SNARK prover core (libmfhip.so).
+ *
+ * This is the drop-in boundary for the hot path of mmaker/c-lwe-snarks ("mangiafuoco"):
+ * every entry point is `extern "C"`, takes plain pointers and sizes, and cites the reference
+ * interface it replaces (file:line relative to the reference tree).  The reference API is
+ * one-ciphertext-at-a-time over GMP `mpz_t`; these are the batched, dense-limb equivalents that
+ * the reference-signature shim (c-lwe-snarks_amd/host/) calls underneath.
+ *
+ * Data conventions
+ *   value      : L = ceil(logq/64) little-endian uint64 limbs (12 @ logq=736, 23 @ 1472).  Results are
+ *                reduced the way the reference's modq() reduces (src/lwe.h:107-118): only the low
+ *                K = logq/64 limbs survive (effective modulus 2^704 @ 736, 2^1472 @ 1472).
+ *   ciphertext : (n+1) values, coordinate-major: ct[j*L .. j*L+L), j = n is `b`   (ct_t, src/lwe.h:44)
+ *   c8         : CT_BYTES = logq/8 little-endian bytes of `b` per ciphertext       (ct_export, src/lwe.c:115-119)
+ *   seed       : 40 bytes: [0,8) nonce, [8,40) AES-256 key                         (rseed_t, src/entropy.h:35)
+ *   stream     : byte x of the public stream = byte (x&15) of AES256_K(nonce_le64 || le64(x>>4))
+ *                (src/aes.c:104-144, src/entropy.c:46-61)
+ *   Pointers named d_* are DEVICE pointers (HBM); h_* are host pointers.  All launches go to the
+ *   context's HIP stream and are asynchronous unless stated; mfh_sync() waits.
+ *
+ * Error behaviour: the reference API is void and asserts preconditions (debug builds only).  Here every
+ * function returns 0 on success or a negative MFH_E* code; mfh_last_error() gives the text.  There is no
+ * CPU fallback anywhere in the library: without a usable HIP device mfh_ctx_create fails.
+ */
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MFH_P 0xfffffffbu /* GAMMA_P, src/lwe.h:25 */
+
+enum {
+  MFH_OK = 0,
+  MFH_EINVAL = -1,  /* bad argument (the reference would assert or misbehave) */
+  MFH_EDEVICE = -2, /* HIP runtime error / no device */
+  MFH_ENOMEM = -3,
+  MFH_EUNSUPPORTED = -4 /* parameter set not compiled in (logq must be 736 or 1472) */
+};
+
+typedef struct {
+  uint32_t n;    /* GAMMA_N,    src/lwe.h:23 (1470) */
+  uint32_t logq; /* GAMMA_LOGQ, src/lwe.h:24 (736; 1472 for the doubled-modulus stress config) */
+  uint32_t d;    /* GAMMA_D,    src/lwe.h:15,19 */
+  uint32_t m;    /* GAMMA_M,    src/lwe.h:17,20 */
+} mfh_params;
+
+typedef struct mfh_ctx mfh_ctx;
+
+/* ---- context ------------------------------------------------------------------------------------ */
+int mfh_ctx_create(mfh_ctx **out, int device, const mfh_params *P);
+void mfh_ctx_destroy(mfh_ctx *ctx);
+/* run on an existing hipStream_t (e.g. torch's current stream).  NULL means HIP's default (null) stream,
+ * NOT the context's own stream (a fresh context runs on its own non-blocking stream until this is called). */
+int mfh_set_stream(mfh_ctx *ctx, void *hip_stream);
+int mfh_sync(mfh_ctx *ctx);
+const char *mfh_last_error(const mfh_ctx *ctx);
+/* rng_init (src/entropy.c:58-61) + aesctr_init (src/aes.c:49-95): expand the AES-256 key of `seed`
+ * and make it the context's current public stream. */
+int mfh_set_seed(mfh_ctx *ctx, const uint8_t h_seed[40]);
+
+/* ---- L0/L1: keystream and sampler ---------------------------------------------------------------- */
+/* rng_seek + rng_gen / aesctr_prg (src/entropy.c:46-56, src/aes.c:104-144): bytes [off, off+nbytes)
+ * of the current stream into d_out. */
+int mfh_keystream(mfh_ctx *ctx, uint64_t off, void *d_out, size_t nbytes);
+/* mpz2_urandommv(c, rs, GAMMA_LOGQ, GAMMA_N) for `nrows` consecutive ciphertext rows starting at stream
+ * offset `off` (src/entropy.h:62-66, src/lwe.c:90,101,124): d_out[row][j][L] limbs, j < n, masked to logq bits. */
+int mfh_sample_rows(mfh_ctx *ctx, uint64_t off, size_t nrows, uint64_t *d_out);
+
+/* ---- L2: ciphertext algebra ---------------------------------------------------------------------- */
+/* ct_add / ct_mul_ui / ct_addmul_ui on `count` ciphertexts (src/lwe.c:131-157).  In-place allowed. */
+int mfh_ct_add(mfh_ctx *ctx, uint64_t *d_rop, const uint64_t *d_a, const uint64_t *d_b, size_t count);
+int mfh_ct_mul_ui(mfh_ctx *ctx, uint64_t *d_rop, const uint64_t *d_a, uint32_t b, size_t count);
+int mfh_ct_addmul_ui(mfh_ctx *ctx, uint64_t *d_rop, const uint64_t *d_a, uint32_t b, size_t count);
+
+/* eval_poly (src/lwe.c:176-186), fused over one or two coefficient vectors:
+ *   rop_k (+)= sum_{i<nrows} coeff_k[i] * Import(c8[i])   with the stream pre-seeked to `off`
+ * i.e. row i is expanded from stream bytes [off + i*n*CT_BYTES, ...) exactly as ct_import does
+ * (src/lwe.c:122-126), once, and multiply-accumulated into both outputs.  Rows whose coefficients are
+ * all zero are not expanded (the reference expands them only to advance its stream).
+ * d_coeff1/d_rop1 may be NULL.  accumulate != 0 keeps the previous contents of d_rop* (the reference
+ * always accumulates into rop); 0 overwrites.  Coefficients must be < p (the reference asserts). */
+int mfh_eval_rows(mfh_ctx *ctx, uint64_t off, size_t nrows, const uint8_t *d_c8, const uint32_t *d_coeff0,
+                  const uint32_t *d_coeff1, uint64_t *d_rop0, uint64_t *d_rop1, int accumulate);
+
+/* Batched regev_encrypt2 + ct_export (src/lwe.c:78-97,115-119): for i < nrows
+ *   b_i = (e_i*p + <sk, a_i> + m_i) mod 2^(64K),  a_i = row at stream offset off + i*n*CT_BYTES
+ * d_sk: n values; d_msg: nrows uint32 (< p); d_err: nrows values (the sampled error e, any L-limb value;
+ * the reference draws 559 bits from getrandom, src/lwe.c:60-63); d_c8_out: nrows*CT_BYTES bytes. */
+int mfh_encrypt_rows(mfh_ctx *ctx, uint64_t off, size_t nrows, const uint64_t *d_sk, const uint32_t *d_msg,
+                     const uint64_t *d_err, uint8_t *d_c8_out);
+
+/* Batched regev_decrypt (src/lwe.c:105-111) of `count` explicit ciphertexts: d_out[i] = (b - <a,sk> mod 2^(64K)) mod p */
+int mfh_decrypt(mfh_ctx *ctx, const uint64_t *d_sk, const uint64_t *d_cts, size_t count, uint32_t *d_out);
+
+/* ct_smudge (src/lwe.c:65-76) with caller-supplied entropy: b += (+/-) u*p on coordinate n of each of `count`
+ * ciphertexts; h_mag = count * maglen little-endian bytes of u, h_sign[i]&1 selects the minus sign. */
+int mfh_ct_smudge(mfh_ctx *ctx, uint64_t *d_cts, size_t count, const uint8_t *h_mag, size_t maglen, const uint8_t *h_sign);
+
+/* ---- L3: SSP witness polynomial ------------------------------------------------------------------- */
+/* Device SSP layout: uint32 d_ssp[(m+3)][d], slot 0 = t, slot i+1 = v_i, coefficients reduced mod p
+ * (reference host layout: uint64 little-endian, src/ssp.h:6-9; mfh_ssp_upload converts and reduces as
+ * nmod_poly_import does, src/ssp.c:28-34). */
+int mfh_ssp_upload(mfh_ctx *ctx, const void *h_ssp_u64, uint32_t *d_ssp, size_t first_slot, size_t nslots);
+/* w(x) = delta*t(x) + sum_{i=1..m-1, witness bit i-1 set} v_i(x) mod p   (src/snark.c:141,147-155);
+ * h_witness_bits: little-endian bit string, bit i-1 <-> v_i (mpz_tstbit).  d_w: d uint32. */
+int mfh_witness_poly(mfh_ctx *ctx, const uint32_t *d_ssp, const uint8_t *h_witness_bits, uint32_t delta, uint32_t *d_w);
+
+/* ---- library info -------------------------------------------------------------------------------- */
+const char *mfh_version(void);
+/* size in bytes the context's scratch currently occupies on the device */
+size_t mfh_workspace_bytes(const mfh_ctx *ctx);
+/* duration in ms of the most recent launch of the named hot kernel ("eval", "encrypt", "keystream"),
+ * measured with HIP events on the context's stream (bench.py's roofline leg); < 0 if none */
+float mfh_last_kernel_ms(mfh_ctx *ctx, const char *which);
+int mfh_set_timing(mfh_ctx *ctx, int enabled);
+
+#ifdef __cplusplus
+}
+#endif

@@ -1,0 +1,226 @@
+"""GPU parity tests: the HIP path (through the C ABI of include/mfhip.h) against the CPU oracle, bit-exact.
+
+Sizes here are ones the oracle finishes in seconds; the properties the reference's own tests pin
+(src/test_entropy.c, src/test_lwe.c) are restated against the C ABI.  Full-size checks live in
+test_gpu_fullsize.py.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+SEED = bytes(range(40))
+SEED2 = bytes((7 * i + 3) & 0xFF for i in range(40))
+
+
+@pytest.fixture(scope="module")
+def mf():
+    import c_lwe_snarks_amd as m
+
+    return m
+
+
+@pytest.fixture(scope="module")
+def ctx(gpu_ctx_factory, mf):
+    c = gpu_ctx_factory(mf.DEBUG)
+    c.set_seed(SEED)
+    return c
+
+
+# ---------------------------------------------------------------- L0/L1: keystream, seek, sampler
+@pytest.mark.parametrize("off,n", [(0, 48), (0, 16), (92, 8), (5, 1), (15, 2), (16, 4096), (135240, 135240),
+                                    (8863223880, 92 * 7), ((1 << 36) + 3, 1000), (12, 92 * 1470 + 5), (0, 1 << 20)])
+def test_keystream_matches_oracle(ctx, oracle, off, n):
+    got = ctx.to_host(ctx.keystream(off, n)).tobytes()
+    assert got == oracle.keystream(SEED, off, n)
+
+
+def test_keystream_kat(ctx):
+    # seed bytes 0..39, verified there against `openssl enc -aes-256-ecb`
+    assert ctx.to_host(ctx.keystream(0, 16)).tobytes().hex() == "8477f45516027713a26a881ae67882bf"
+    assert ctx.to_host(ctx.keystream(92, 8)).tobytes().hex() == "ed29f6cae21f9e67"
+
+
+def test_keystream_seek_and_chunking(ctx):
+    # src/test_entropy.c:111-156: bulk == chunked generation; seek(512) == reading past 512 bytes
+    bulk = ctx.to_host(ctx.keystream(0, 92 * 1470 * 3)).tobytes()
+    for k in (0, 1, 1469, 1470, 2 * 1470 + 17):
+        assert ctx.to_host(ctx.keystream(92 * k, 92)).tobytes() == bulk[92 * k: 92 * k + 92]
+    assert ctx.to_host(ctx.keystream(512, 8)).tobytes() == bulk[512:520]
+
+
+def test_other_seed(gpu_ctx_factory, mf, oracle):
+    c = gpu_ctx_factory(mf.DEBUG)
+    c.set_seed(SEED2)
+    assert c.to_host(c.keystream(1234567, 333)).tobytes() == oracle.keystream(SEED2, 1234567, 333)
+
+
+@pytest.mark.parametrize("off,nrows", [(0, 1), (135240, 2), (8863223880, 1)])
+def test_sample_rows(ctx, oracle, mf, off, nrows):
+    p = mf.DEBUG
+    got = ctx.to_host(ctx.sample_rows(off, nrows), np.uint64).reshape(nrows, p.n, p.L)
+    exp = oracle.sample_rows(p, SEED, off, nrows)
+    assert np.array_equal(got, exp)
+
+
+# ---------------------------------------------------------------- L2: ciphertext algebra
+def _rand_ct(rng, p, count=1, bits=None):
+    bits = p.logq if bits is None else bits
+    return ol.rand_values(rng, count * (p.n + 1), p.L, bits).reshape(count, p.n + 1, p.L)
+
+
+def test_ct_elementwise(ctx, oracle, mf):
+    p = mf.DEBUG
+    rng = np.random.default_rng(1)
+    a, b = _rand_ct(rng, p)[0], _rand_ct(rng, p)[0]
+    da, db = ctx.to_device(a), ctx.to_device(b)
+    assert np.array_equal(ctx.to_host(ctx.ct_add(da, db), np.uint64).reshape(a.shape), oracle.ct_add(p, a, b))
+    for x in (0, 1, 5, 0xFFFFFFFA):
+        assert np.array_equal(ctx.to_host(ctx.ct_mul_ui(da, x), np.uint64).reshape(a.shape), oracle.ct_mul_ui(p, a, x))
+        r0 = oracle.modq(p, b[0])  # accumulators are always reduced values
+        bb = b.copy()
+        bb[:, p.K:] = 0
+        drop = ctx.to_device(bb)
+        ctx.ct_addmul_ui(drop, da, x)
+        assert np.array_equal(ctx.to_host(drop, np.uint64).reshape(a.shape), oracle.ct_addmul_ui(p, bb, a, x))
+    # modq quirk: effective modulus is 2^704, not 2^736: 2^720 + 5 -> 5
+    v = np.zeros_like(a)
+    v[0] = ol.int_to_limbs((1 << 720) + 5, p.L)
+    got = ctx.to_host(ctx.ct_mul_ui(ctx.to_device(v), 1), np.uint64).reshape(a.shape)
+    assert ol.limbs_to_int(got[0]) == 5
+
+
+def test_ct_mul_ui_rejects_scalar_ge_p(ctx, mf):
+    p = mf.DEBUG
+    d = ctx.zeros(p.ct_limbs * 8)
+    with pytest.raises(mf.MfhError):
+        ctx.ct_mul_ui(d, 0xFFFFFFFB)  # the reference asserts b < GAMMA_P (src/lwe.c:133)
+
+
+@pytest.mark.parametrize("nrows,nacc,off_kind", [(1, 1, "s"), (2, 1, "s"), (37, 2, "s"), (100, 1, "as"), (9, 2, "bv"), (64, 2, "odd")])
+def test_eval_rows_matches_oracle(ctx, oracle, mf, nrows, nacc, off_kind):
+    p = mf.DEBUG
+    off = {"s": p.ctr_s, "as": p.ctr_as, "bv": p.ctr_bv, "odd": p.ctr_ct * 3 + 0}[off_kind]
+    rng = np.random.default_rng(nrows * 10 + nacc)
+    c8 = rng.integers(0, 256, size=nrows * p.ctb, dtype=np.uint8)
+    coeffs = [rng.integers(0, ol.P, size=nrows, dtype=np.uint64) for _ in range(nacc)]
+    if nrows > 4:
+        coeffs[0][1] = 0
+        coeffs[0][3] = 0
+        if nacc > 1:
+            coeffs[1][3] = 0  # row 3 has all-zero coefficients: skipped on the GPU, expanded-and-ignored in the reference
+            coeffs[1][2] = ol.P - 1
+    d_c8 = ctx.to_device(c8)
+    d_co = [ctx.to_device(c.astype(np.uint32)) for c in coeffs]
+    r0, r1 = ctx.eval_rows(off, nrows, d_c8, d_co[0], d_co[1] if nacc > 1 else None)
+    exp0 = oracle.eval_poly(p, SEED, off, c8.tobytes(), coeffs[0])
+    assert np.array_equal(ctx.to_host(r0, np.uint64).reshape(exp0.shape), exp0)
+    if nacc > 1:
+        exp1 = oracle.eval_poly(p, SEED, off, c8.tobytes(), coeffs[1])
+        assert np.array_equal(ctx.to_host(r1, np.uint64).reshape(exp1.shape), exp1)
+
+
+def test_eval_rows_accumulates_like_reference(ctx, oracle, mf):
+    # eval_poly accumulates into rop (src/lwe.c:183): two half calls == one full call
+    p = mf.DEBUG
+    rng = np.random.default_rng(5)
+    nrows = 20
+    c8 = rng.integers(0, 256, size=nrows * p.ctb, dtype=np.uint8)
+    co = rng.integers(0, ol.P, size=nrows, dtype=np.uint64)
+    d_c8, d_co = ctx.to_device(c8), ctx.to_device(co.astype(np.uint32))
+    full, _ = ctx.eval_rows(0, nrows, d_c8, d_co)
+    half, _ = ctx.eval_rows(0, 10, d_c8, d_co)
+    ctx.eval_rows(10 * p.ctr_ct, 10, d_c8[10 * p.ctb:], d_co[40:], rop0=half, accumulate=True)
+    assert np.array_equal(ctx.to_host(full), ctx.to_host(half))
+    assert np.array_equal(ctx.to_host(full, np.uint64).reshape(p.n + 1, p.L), oracle.eval_poly(p, SEED, 0, c8.tobytes(), co))
+
+
+def test_eval_rows_empty(ctx, mf):
+    p = mf.DEBUG
+    r0, _ = ctx.eval_rows(0, 0, ctx.zeros(16), ctx.zeros(16))
+    assert not ctx.to_host(r0).any()
+
+
+@pytest.mark.parametrize("nrows,off_kind", [(1, "s"), (3, "s"), (5, "bv"), (33, "as")])
+def test_encrypt_rows_matches_oracle(ctx, oracle, mf, nrows, off_kind):
+    p = mf.DEBUG
+    off = {"s": p.ctr_s, "as": p.ctr_as, "bv": p.ctr_bv}[off_kind]
+    rng = np.random.default_rng(nrows)
+    sk = ol.rand_values(rng, p.n, p.L, p.logq)
+    msg = rng.integers(0, ol.P, size=nrows, dtype=np.uint64)
+    err = ol.rand_values(rng, nrows, p.L, 559)  # GAMMA_LOG_SIGMA + 3 bits (src/lwe.c:62)
+    got = ctx.to_host(ctx.encrypt_rows(off, nrows, ctx.to_device(sk), ctx.to_device(msg.astype(np.uint32)), ctx.to_device(err)))
+    r = oracle.rng(SEED, off)
+    exp = b"".join(oracle.ct_export(p, oracle.encrypt(p, r, sk, int(msg[i]), err[i])) for i in range(nrows))
+    assert got.tobytes() == exp
+
+
+def test_encrypt_decrypt_roundtrip_and_homomorphism(ctx, oracle, mf):
+    # src/test_lwe.c:74-95 (dec(enc(m)) == m) and :105-181 (eval_poly of unit coefficients decrypts to sum m)
+    p = mf.DEBUG
+    rng = np.random.default_rng(11)
+    nrows = 100
+    sk = ol.rand_values(rng, p.n, p.L, p.logq)
+    msg = rng.integers(0, ol.P, size=nrows, dtype=np.uint64)
+    err = ol.rand_values(rng, nrows, p.L, 559)
+    d_sk = ctx.to_device(sk)
+    c8 = ctx.encrypt_rows(0, nrows, d_sk, ctx.to_device(msg.astype(np.uint32)), ctx.to_device(err))
+    ones = ctx.to_device(np.ones(nrows, dtype=np.uint32))
+    ev, _ = ctx.eval_rows(0, nrows, c8, ones)
+    got = int(ctx.to_host(ctx.decrypt(d_sk, ev, 1), np.uint32)[0])
+    assert got == int(msg.sum() % ol.P)
+    # single-row: import + decrypt each of the first 5
+    for i in range(5):
+        unit = np.zeros(nrows, dtype=np.uint32)
+        unit[i] = 1
+        ct, _ = ctx.eval_rows(0, nrows, c8, ctx.to_device(unit))
+        assert int(ctx.to_host(ctx.decrypt(d_sk, ct, 1), np.uint32)[0]) == int(msg[i])
+        # and the oracle agrees on the decryption of the GPU ciphertext
+        assert oracle.decrypt(p, sk, ctx.to_host(ct, np.uint64).reshape(p.n + 1, p.L)) == int(msg[i])
+
+
+def test_decrypt_matches_oracle_on_unreduced_b(ctx, oracle, mf):
+    p = mf.DEBUG
+    rng = np.random.default_rng(3)
+    sk = ol.rand_values(rng, p.n, p.L, p.logq)
+    cts = _rand_ct(rng, p, count=3)  # b up to 736 bits, as after a raw ct_import (src/lwe.c:125)
+    got = ctx.to_host(ctx.decrypt(ctx.to_device(sk), ctx.to_device(cts), 3), np.uint32)
+    for i in range(3):
+        assert int(got[i]) == oracle.decrypt(p, sk, cts[i])
+
+
+def test_smudge(ctx, oracle, mf):
+    # src/test_lwe.c:183-205: smudging preserves decryption; and bit-exact against the oracle
+    p = mf.DEBUG
+    rng = np.random.default_rng(4)
+    cts = _rand_ct(rng, p, count=4, bits=704)
+    cts[:, :, p.K:] = 0
+    mags = rng.integers(0, 256, size=4 * 80, dtype=np.uint8)
+    signs = bytes([0, 1, 1, 0])
+    d = ctx.to_device(cts)
+    ctx.ct_smudge(d, 4, mags.tobytes(), 80, signs)
+    got = ctx.to_host(d, np.uint64).reshape(cts.shape)
+    for i in range(4):
+        exp, neg = oracle.ct_smudge(p, cts[i], mags[80 * i: 80 * i + 80].tobytes(), signs[i])
+        assert not neg
+        assert np.array_equal(got[i], exp)
+
+
+# ---------------------------------------------------------------- L3: witness polynomial
+def test_witness_poly(ctx, oracle, mf):
+    p = mf.DEBUG
+    rng = np.random.default_rng(6)
+    ssp = rng.integers(0, 1 << 63, size=(p.m + 3) * p.d, dtype=np.uint64)  # arbitrary u64: import reduces mod p
+    bits = rng.integers(0, 256, size=(p.m + 7) // 8, dtype=np.uint8).tobytes()
+    delta = 0xDEADBEE
+    d_ssp = ctx.ssp_upload(ssp)
+    got = ctx.to_host(ctx.witness_poly(d_ssp, bits, delta), np.uint32)
+    red = (ssp % np.uint64(ol.P)).reshape(p.m + 3, p.d)
+    assert np.array_equal(ctx.to_host(d_ssp, np.uint32).reshape(p.m + 3, p.d), red.astype(np.uint32))
+    w = (red[0].astype(object) * delta) % ol.P
+    for i in range(1, p.m):
+        if (bits[(i - 1) >> 3] >> ((i - 1) & 7)) & 1:
+            w = (w + red[i + 1].astype(object)) % ol.P
+    assert np.array_equal(got.astype(np.uint64), np.array(w, dtype=np.uint64))
