@@ -3,12 +3,12 @@
 // Replaces the reference's L0 layer: aesctr_init / aesctr_prg (src/aes.c:49-144), which call
 // OpenSSL one block at a time.  gfx950 has no AES instruction, so a block is 13 T-table rounds
 // + 1 S-box round.  Design for the CU:
-//   * ONE table, T0 (little-endian column convention: T0[a] = {2S, S, S, 3S} as bytes 0..3), the
-//     other three are rotations (v_alignbit_b32): 1 KiB of distinct data.
-//   * The table is replicated 32x in LDS, entry-major: word a*32 + r holds T0[a].  Lane l reads
-//     replica r = l & 31, so the 32 lanes of each ds_read_b32 lane group hit 32 distinct banks
-//     whatever bytes they look up: every lookup is conflict-free (a single 1 KiB copy is ~3.5-way
-//     conflicted on random data).  32 KiB of the CU's 160 KiB.
+//   * Two tables, T0 (little-endian column convention: T0[a] = {2S, S, S, 3S} as bytes 0..3) and
+//     T2 = rotl16(T0); T1/T3 are rotl8 of those (one v_alignbit_b32 per output column).
+//   * Each is replicated 32x in LDS, entry-major (256-byte entries: 32 x T0[a], then 32 x T2[a]).
+//     Lane l reads replica l & 31, so the 32 lanes of each ds_read_b32 lane group hit 32 distinct
+//     banks whatever bytes they look up: every lookup is conflict-free (a single 1 KiB copy is
+//     ~3.5-way conflicted on random data).  64 KiB of the CU's 160 KiB.
 //   * Columns are little-endian words, so the nonce/counter words are the input columns as they
 //     stand and the output words are the keystream's uint32 words as they stand.
 #pragma once
@@ -22,7 +22,6 @@ struct AesKey {
   uint32_t nonce_lo, nonce_hi;
 };
 
-constexpr int kT0Words = 256 * 32;  // replicated table, words
 
 // ---- host: S-box, T0, key schedule (FIPS-197) ----------------------------------------------------
 inline uint8_t gf_mul2(uint8_t a) { return (uint8_t)((a << 1) ^ ((a & 0x80) ? 0x1b : 0)); }
@@ -84,38 +83,73 @@ inline void expand_key(AesKey &k, const uint8_t seed[40]) {
 }
 
 // ---- device ----------------------------------------------------------------------------------------
-__device__ __forceinline__ void lds_fill_t0(uint32_t *lt, const uint32_t *__restrict__ g_t0) {
-  for (int i = threadIdx.x; i < kT0Words; i += blockDim.x) lt[i] = g_t0[i >> 5];
+// LDS table image (64 KiB): word a*64 + r holds T0[a] for r < 32 and T2[a] = rotl16(T0[a]) for r >= 32.
+// A lane uses replica r = lane & 31 (+32 for T2): bank = r for every entry, so the 32 lanes of each
+// ds_read_b32 lane group never conflict, and the byte address is (a << 8) | (r << 2): the entry index sits in
+// byte 1 of the address, so one v_perm_b32 (or, for state byte 1, one v_bitop3 and-or) forms it.
+// T1 = rotl8(T0) and T3 = rotl8(T2) share one v_alignbit per output column:
+//   t_j = T0[b0(s_j)] ^ T2[b2(s_j+2)] ^ rotl8(T0[b1(s_j+1)] ^ T2[b3(s_j+3)]) ^ rk
+// Measured on MI355X (tools/rate*_ubench.hip): ds_read_b32 ~2.15 CU-clk per wave-instruction, v_xor/v_bitop3 ~2.5
+// and v_perm/v_alignbit ~4.3 SIMD-clk: 27 SIMD-clk of VALU per column against 34 of LDS: the round is LDS-bound.
+constexpr int kTabBytes = 256 * 64 * 4;
+
+__device__ __forceinline__ void lds_fill_tab(uint32_t *lt, const uint32_t *__restrict__ g_t0) {
+  for (int i = threadIdx.x; i < 256 * 64; i += blockDim.x) {
+    uint32_t v = g_t0[i >> 6];
+    lt[i] = (i & 32) ? ((v << 16) | (v >> 16)) : v;
+  }
 }
 
-__device__ __forceinline__ uint32_t rotl8(uint32_t x) { return __builtin_amdgcn_alignbit(x, x, 24); }
-__device__ __forceinline__ uint32_t rotl16(uint32_t x) { return __builtin_amdgcn_alignbit(x, x, 16); }
-__device__ __forceinline__ uint32_t rotl24(uint32_t x) { return __builtin_amdgcn_alignbit(x, x, 8); }
+struct AesLane {
+  uint32_t lo0, lo2;  // byte offsets of this lane's T0 / T2 replica inside a 256-byte entry
+  uint32_t m1;        // 0x0000ff00, kept in a VGPR so v_bitop3 runs at full rate
+};
+__device__ __forceinline__ AesLane aes_lane() {
+  AesLane l;
+  l.lo0 = (threadIdx.x & 31) * 4;
+  l.lo2 = l.lo0 + 128;
+  l.m1 = 0xff00u;
+  asm volatile("" : "+v"(l.m1));  // keep it a VGPR
+  return l;
+}
 
-// tl = replicated table base + (lane & 31); entry a lives at tl[a << 5]
-#define MF_T(x) tl[(x) << 5]
+#define MF_XOR3(a, b, c) __builtin_amdgcn_bitop3_b32((a), (b), (c), 0x96)
+#define MF_ANDOR(a, m, c) __builtin_amdgcn_bitop3_b32((a), (m), (c), 0xEA) /* (a & m) | c */
+#define MF_LD(addr) (*reinterpret_cast<const uint32_t *>(tab + (addr)))
+// address of entry byte_k(s) in the T0 (lo0) or T2 (lo2) half
+#define MF_A(s, lo, k) ((k) == 1 ? MF_ANDOR((s), L.m1, (lo)) : __builtin_amdgcn_perm((s), (lo), 0x0c0c0400u + ((k) << 8)))
+
+__device__ __forceinline__ uint32_t aes_col(const uint8_t *tab, const AesLane &L, uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t rk) {
+  uint32_t x0 = MF_LD(MF_A(a, L.lo0, 0)), x1 = MF_LD(MF_A(b, L.lo0, 1));
+  uint32_t x2 = MF_LD(MF_A(c, L.lo2, 2)), x3 = MF_LD(MF_A(d, L.lo2, 3));
+  uint32_t y = x1 ^ x3;
+  return MF_XOR3(x0 ^ rk, x2, __builtin_amdgcn_alignbit(y, y, 24));
+}
+// last round (SubBytes+ShiftRows+AddRoundKey): S = T2.byte0 = T0.byte1 = T0.byte2 = T2.byte3
+__device__ __forceinline__ uint32_t aes_last(const uint8_t *tab, const AesLane &L, uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t rk) {
+  uint32_t x0 = MF_LD(MF_A(a, L.lo2, 0)), x1 = MF_LD(MF_A(b, L.lo0, 1));
+  uint32_t x2 = MF_LD(MF_A(c, L.lo0, 2)), x3 = MF_LD(MF_A(d, L.lo2, 3));
+  uint32_t lo = __builtin_amdgcn_perm(x1, x0, 0x0c0c0500u);  // {x0.b0, x1.b1, 0, 0}
+  uint32_t hi = __builtin_amdgcn_perm(x3, x2, 0x07020c0cu);  // {0, 0, x2.b2, x3.b3}
+  return MF_XOR3(lo, hi, rk);
+}
 
 // One stream block: AES256_K(nonce_le64 || le64(ctr)) as 4 little-endian words.
-__device__ __forceinline__ void aes256_ctr_block(const uint32_t *tl, const AesKey &k, uint64_t ctr, uint32_t out[4]) {
+__device__ __forceinline__ void aes256_ctr_block(const uint8_t *tab, const AesLane &L, const AesKey &k, uint64_t ctr, uint32_t out[4]) {
   uint32_t s0 = k.nonce_lo ^ k.rk[0], s1 = k.nonce_hi ^ k.rk[1];
   uint32_t s2 = (uint32_t)ctr ^ k.rk[2], s3 = (uint32_t)(ctr >> 32) ^ k.rk[3];
 #pragma unroll
   for (int r = 1; r < 14; r++) {
-    uint32_t t0 = MF_T(s0 & 255) ^ rotl8(MF_T((s1 >> 8) & 255)) ^ rotl16(MF_T((s2 >> 16) & 255)) ^ rotl24(MF_T(s3 >> 24)) ^ k.rk[4 * r];
-    uint32_t t1 = MF_T(s1 & 255) ^ rotl8(MF_T((s2 >> 8) & 255)) ^ rotl16(MF_T((s3 >> 16) & 255)) ^ rotl24(MF_T(s0 >> 24)) ^ k.rk[4 * r + 1];
-    uint32_t t2 = MF_T(s2 & 255) ^ rotl8(MF_T((s3 >> 8) & 255)) ^ rotl16(MF_T((s0 >> 16) & 255)) ^ rotl24(MF_T(s1 >> 24)) ^ k.rk[4 * r + 2];
-    uint32_t t3 = MF_T(s3 & 255) ^ rotl8(MF_T((s0 >> 8) & 255)) ^ rotl16(MF_T((s1 >> 16) & 255)) ^ rotl24(MF_T(s2 >> 24)) ^ k.rk[4 * r + 3];
+    uint32_t t0 = aes_col(tab, L, s0, s1, s2, s3, k.rk[4 * r]);
+    uint32_t t1 = aes_col(tab, L, s1, s2, s3, s0, k.rk[4 * r + 1]);
+    uint32_t t2 = aes_col(tab, L, s2, s3, s0, s1, k.rk[4 * r + 2]);
+    uint32_t t3 = aes_col(tab, L, s3, s0, s1, s2, k.rk[4 * r + 3]);
     s0 = t0; s1 = t1; s2 = t2; s3 = t3;
   }
-  // last round: SubBytes + ShiftRows + AddRoundKey.  S[a] is byte 1 (and byte 2) of T0[a].
-#define MF_LAST(a, b, c, d)                                                                                      \
-  (((MF_T((a) & 255) >> 8) & 0xffu) | (MF_T(((b) >> 8) & 255) & 0xff00u) | (MF_T(((c) >> 16) & 255) & 0xff0000u) | \
-   ((MF_T((d) >> 24) << 8) & 0xff000000u))
-  out[0] = MF_LAST(s0, s1, s2, s3) ^ k.rk[56];
-  out[1] = MF_LAST(s1, s2, s3, s0) ^ k.rk[57];
-  out[2] = MF_LAST(s2, s3, s0, s1) ^ k.rk[58];
-  out[3] = MF_LAST(s3, s0, s1, s2) ^ k.rk[59];
-#undef MF_LAST
+  out[0] = aes_last(tab, L, s0, s1, s2, s3, k.rk[56]);
+  out[1] = aes_last(tab, L, s1, s2, s3, s0, k.rk[57]);
+  out[2] = aes_last(tab, L, s2, s3, s0, s1, k.rk[58]);
+  out[3] = aes_last(tab, L, s3, s0, s1, s2, k.rk[59]);
 }
 
 }  // namespace mf

@@ -34,7 +34,9 @@ struct PS {
   static constexpr int L = (LOGQ + 63) / 64;   // limbs of a value (12 | 23)
   static constexpr int K = LOGQ / 64;          // limbs surviving modq (11 | 23)
   static constexpr int KW = 2 * K;             // 32-bit words surviving modq (22 | 46)
-  static constexpr int TILE = LOGQ == 736 ? 512 : 256;  // coordinates (= threads) per workgroup
+  static constexpr int TILE = LOGQ == 736 ? 512 : 256;  // coordinates per row tile
+  static constexpr int ROWS = 2;                        // rows a workgroup expands per iteration
+  static constexpr int THREADS = TILE * ROWS;           // 1024 | 512
   static constexpr int KS_BYTES = TILE * CTB + 16;      // one row tile of keystream (+1 block when misaligned)
 };
 
@@ -83,19 +85,20 @@ static int ws_reserve(mfh_ctx *c, size_t bytes) {
 // ------------------------------------------------------------------------------------------------------
 // keystream kernel: aesctr_prg / rng_seek (src/aes.c:104-144, src/entropy.c:46-56), stateless form
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_keystream(AesKey key, const uint32_t *__restrict__ g_t0, uint64_t off,
-                                                   uint8_t *__restrict__ out, uint64_t nbytes) {
-  __shared__ uint32_t lt[mf::kT0Words];
-  mf::lds_fill_t0(lt, g_t0);
+__global__ __launch_bounds__(1024) void k_keystream(AesKey key, const uint32_t *__restrict__ g_t0, uint64_t off,
+                                                    uint8_t *__restrict__ out, uint64_t nbytes) {
+  __shared__ __attribute__((aligned(16))) uint32_t lt[mf::kTabBytes / 4];
+  mf::lds_fill_tab(lt, g_t0);
   __syncthreads();
-  const uint32_t *tl = lt + (threadIdx.x & 31);
+  const uint8_t *tab = reinterpret_cast<const uint8_t *>(lt);
+  const mf::AesLane L = mf::aes_lane();
   const uint64_t cb0 = off >> 4;
   const uint32_t head = (uint32_t)(off & 15);
   const uint64_t nblk = (head + nbytes + 15) >> 4;
   const bool aligned = head == 0 && (((uintptr_t)out) & 15) == 0;
   for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nblk; b += (uint64_t)gridDim.x * blockDim.x) {
     uint32_t w[4];
-    mf::aes256_ctr_block(tl, key, cb0 + b, w);
+    mf::aes256_ctr_block(tab, L, key, cb0 + b, w);
     int64_t o = (int64_t)(b * 16) - head;  // output index of this block's byte 0
     if (aligned && (uint64_t)o + 16 <= nbytes) {
       *reinterpret_cast<uint4 *>(out + o) = make_uint4(w[0], w[1], w[2], w[3]);
@@ -121,47 +124,88 @@ __global__ void k_repack_values(const uint32_t *__restrict__ ks, uint32_t *__res
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Active-row compaction: idx[] = rows with a non-zero coefficient, cnt[0] = how many.  One workgroup.
+// (The reference expands zero-coefficient rows only to advance its stream, src/snark.c:147-155.)
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_compact_rows(const uint32_t *__restrict__ c0, const uint32_t *__restrict__ c1, uint32_t nrows,
+                                                       uint32_t *__restrict__ idx, uint32_t *__restrict__ cnt) {
+  __shared__ uint32_t wsum[16];
+  __shared__ uint32_t base;
+  if (threadIdx.x == 0) base = 0;
+  __syncthreads();
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (uint32_t r0 = 0; r0 < nrows; r0 += 1024) {
+    uint32_t r = r0 + threadIdx.x;
+    bool act = r < nrows && (c0[r] != 0 || (c1 && c1[r] != 0));
+    unsigned long long m = __ballot(act);
+    uint32_t before = __popcll(m & ((1ull << lane) - 1));
+    if (lane == 0) wsum[wave] = __popcll(m);
+    __syncthreads();
+    uint32_t wbase = base;
+    for (uint32_t w = 0; w < wave; w++) wbase += wsum[w];
+    if (act) idx[wbase + before] = r;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t t = 0;
+      for (int w = 0; w < 16; w++) t += wsum[w];
+      base += t;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) cnt[0] = base;
+}
+
+// ------------------------------------------------------------------------------------------------------
 // Row-tile expansion into LDS, shared by eval and encrypt.
-// Tile = coordinates [j0, j0+TILE) of the row whose element 0 sits at stream byte `rowoff`.
-// Whole waves take whole 64-block rounds (block b -> thread b % TILE of round b / TILE), so a round in which
-// a wave has no block is skipped by that wave entirely: no half-empty issue slots.
+// Tile = coordinates [j0, j0+TILE) of the row whose element 0 sits at stream byte `rowoff`; `t` is the
+// thread's index inside the TILE threads that serve this row.  Whole waves take whole 64-block rounds
+// (block b -> thread b % TILE of round b / TILE), so a round in which a wave has no block is skipped by
+// that wave entirely: no half-empty issue slots.
 // ------------------------------------------------------------------------------------------------------
 template <int LOGQ>
-__device__ __forceinline__ uint32_t expand_tile_to_lds(const uint32_t *tl, const AesKey &key, uint8_t *ks, uint64_t rowoff,
-                                                       uint32_t j0, uint32_t nelem) {
+__device__ __forceinline__ uint32_t expand_tile_to_lds(const uint8_t *tab, const mf::AesLane &L, const AesKey &key, uint8_t *ks,
+                                                       uint64_t rowoff, uint32_t j0, uint32_t nelem, uint32_t t) {
   using S = PS<LOGQ>;
   const uint64_t B0 = rowoff + (uint64_t)j0 * S::CTB;
   const uint64_t cb0 = B0 >> 4;
   const uint32_t head = (uint32_t)(B0 & 15);
   const uint32_t nblk = (head + nelem * S::CTB + 15) >> 4;
-  for (uint32_t b = threadIdx.x; b < nblk; b += S::TILE) {
+  for (uint32_t b = t; b < nblk; b += S::TILE) {
     uint32_t w[4];
-    mf::aes256_ctr_block(tl, key, cb0 + b, w);
+    mf::aes256_ctr_block(tab, L, key, cb0 + b, w);
     *reinterpret_cast<uint4 *>(ks + 16 * b) = make_uint4(w[0], w[1], w[2], w[3]);
   }
   return head;
 }
 
 // ------------------------------------------------------------------------------------------------------
-// eval kernel: fused ct_import + ct_addmul_ui over a chunk of rows, 1 or 2 coefficient vectors.
-// grid = (ntiles, nchunks); block = TILE threads; thread t owns coordinate j0 + t.
-// partials: part[((chunk*NACC + a)*KW + l)*NJ + j]  (uint32), NJ = ntiles*TILE
+// eval kernel: fused ct_import + ct_addmul_ui over the active rows, 1 or 2 coefficient vectors.
+// grid = (ntiles, nchunks); block = ROWS x TILE threads; thread (rs, t) owns coordinate j0 + t for the rows
+// idx[k], k = k0 + rs, k0 + rs + ROWS, ... of its chunk.
+// partials: part[(((chunk*ROWS + rs)*NACC + a)*KW + l)*NJ + j]  (uint32), NJ = ntiles*TILE
 // ------------------------------------------------------------------------------------------------------
 template <int LOGQ, int NACC>
-__global__ __launch_bounds__(PS<LOGQ>::TILE) void k_eval(AesKey key, const uint32_t *__restrict__ g_t0, uint64_t off, uint32_t n,
-                                                         uint32_t nrows, uint32_t rows_per_chunk,
-                                                         const uint8_t *__restrict__ c8, const uint32_t *__restrict__ coeff0,
-                                                         const uint32_t *__restrict__ coeff1, uint32_t *__restrict__ part) {
+__global__ __launch_bounds__(PS<LOGQ>::THREADS) void k_eval(AesKey key, const uint32_t *__restrict__ g_t0, uint64_t off, uint32_t n,
+                                                            const uint32_t *__restrict__ idx, const uint32_t *__restrict__ cnt,
+                                                            const uint8_t *__restrict__ c8, const uint32_t *__restrict__ coeff0,
+                                                            const uint32_t *__restrict__ coeff1, uint32_t *__restrict__ part) {
   using S = PS<LOGQ>;
-  __shared__ uint32_t lt[mf::kT0Words];
-  __shared__ __attribute__((aligned(16))) uint8_t ks[S::KS_BYTES];
-  mf::lds_fill_t0(lt, g_t0);
-  const uint32_t *tl = lt + (threadIdx.x & 31);
+  __shared__ __attribute__((aligned(16))) uint32_t lt[mf::kTabBytes / 4];
+  __shared__ __attribute__((aligned(16))) uint8_t ksbuf[S::ROWS][S::KS_BYTES];
+  mf::lds_fill_tab(lt, g_t0);
+  const uint8_t *tab = reinterpret_cast<const uint8_t *>(lt);
+  const mf::AesLane L = mf::aes_lane();
+  const uint32_t rs = threadIdx.x / S::TILE, t = threadIdx.x % S::TILE;
+  uint8_t *ks = ksbuf[rs];
   const uint32_t j0 = blockIdx.x * S::TILE;
-  const uint32_t j = j0 + threadIdx.x;
+  const uint32_t j = j0 + t;
   const uint32_t nelem = j0 >= n ? 0u : min((uint32_t)S::TILE, n - j0);  // keystream-backed coordinates in this tile
-  const uint32_t r0 = blockIdx.y * rows_per_chunk;
-  const uint32_t r1 = min(nrows, r0 + rows_per_chunk);
+  const uint32_t nact = cnt[0];
+  // chunks of a multiple of ROWS active rows
+  uint32_t per = (nact + gridDim.y - 1) / gridDim.y;
+  per = (per + S::ROWS - 1) / S::ROWS * S::ROWS;
+  const uint32_t k0 = blockIdx.y * per;
+  const uint32_t k1 = min(nact, k0 + per);
   const uint32_t NJ = gridDim.x * S::TILE;
 
   uint32_t acc[NACC][S::KW];
@@ -171,22 +215,22 @@ __global__ __launch_bounds__(PS<LOGQ>::TILE) void k_eval(AesKey key, const uint3
     for (int l = 0; l < S::KW; l++) acc[a][l] = 0;
 
   __syncthreads();
-  for (uint32_t row = r0; row < r1; row++) {
+  for (uint32_t kk = k0; kk < k1; kk += S::ROWS) {  // uniform trip count for the whole workgroup (barriers inside)
+    const uint32_t k = kk + rs;
+    const bool have = k < k1;  // uniform per row-half (a half is whole waves)
+    uint32_t row = 0, head = 0;
     uint32_t c[NACC];
-    c[0] = coeff0[row];
-    if (NACC > 1) c[1] = coeff1[row];
-    bool any = c[0] != 0;
-    if (NACC > 1) any = any || c[1] != 0;
-    if (!any) continue;  // wave-uniform: the reference expands such rows only to advance its stream
-
-    const uint64_t rowoff = off + (uint64_t)row * n * S::CTB;
-    const uint32_t head = expand_tile_to_lds<LOGQ>(tl, key, ks, rowoff, j0, nelem);
+    if (have) {
+      row = idx[k];
+      c[0] = coeff0[row];
+      if (NACC > 1) c[1] = coeff1[row];
+      head = expand_tile_to_lds<LOGQ>(tab, L, key, ks, off + (uint64_t)row * n * S::CTB, j0, nelem, t);
+    }
     __syncthreads();
-
-    if (j <= n) {
+    if (have && j <= n) {
       uint32_t a[S::KW];
       if (j < n) {
-        const uint32_t *kw = reinterpret_cast<const uint32_t *>(ks + head) + threadIdx.x * S::EW;
+        const uint32_t *kw = reinterpret_cast<const uint32_t *>(ks + head) + t * S::EW;
 #pragma unroll
         for (int l = 0; l < S::KW; l++) a[l] = kw[l];
       } else {
@@ -199,9 +243,9 @@ __global__ __launch_bounds__(PS<LOGQ>::TILE) void k_eval(AesKey key, const uint3
         uint32_t carry = 0;
 #pragma unroll
         for (int l = 0; l < S::KW; l++) {
-          uint64_t t = (uint64_t)a[l] * c[q] + acc[q][l] + carry;
-          acc[q][l] = (uint32_t)t;
-          carry = (uint32_t)(t >> 32);
+          uint64_t tt = (uint64_t)a[l] * c[q] + acc[q][l] + carry;
+          acc[q][l] = (uint32_t)tt;
+          carry = (uint32_t)(tt >> 32);
         }
       }
     }
@@ -210,12 +254,13 @@ __global__ __launch_bounds__(PS<LOGQ>::TILE) void k_eval(AesKey key, const uint3
 #pragma unroll
   for (int a = 0; a < NACC; a++)
 #pragma unroll
-    for (int l = 0; l < S::KW; l++) part[(((uint64_t)blockIdx.y * NACC + a) * S::KW + l) * NJ + j] = acc[a][l];
+    for (int l = 0; l < S::KW; l++)
+      part[((((uint64_t)blockIdx.y * S::ROWS + rs) * NACC + a) * S::KW + l) * NJ + j] = acc[a][l];
 }
 
-// sum partials over chunks, propagate carries, write natural-layout values (optionally += previous)
+// sum partials over slabs (chunks x row-halves), propagate carries, write natural-layout values (optionally += previous)
 template <int LOGQ>
-__global__ void k_eval_reduce(const uint32_t *__restrict__ part, uint32_t nchunks, uint32_t nacc, uint32_t NJ, uint32_t n,
+__global__ void k_eval_reduce(const uint32_t *__restrict__ part, uint32_t nslabs, uint32_t nacc, uint32_t NJ, uint32_t n,
                               uint64_t *__restrict__ rop0, uint64_t *__restrict__ rop1, int accumulate) {
   using S = PS<LOGQ>;
   uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -226,7 +271,7 @@ __global__ void k_eval_reduce(const uint32_t *__restrict__ part, uint32_t nchunk
   uint64_t carry = 0;
   for (int l = 0; l < S::KW; l++) {
     uint64_t s = carry;
-    for (uint32_t ch = 0; ch < nchunks; ch++) s += part[(((uint64_t)ch * nacc + a) * S::KW + l) * NJ + j];
+    for (uint32_t ch = 0; ch < nslabs; ch++) s += part[(((uint64_t)ch * nacc + a) * S::KW + l) * NJ + j];
     if (accumulate) s += out[l];
     out[l] = (uint32_t)s;
     carry = s >> 32;
@@ -236,25 +281,29 @@ __global__ void k_eval_reduce(const uint32_t *__restrict__ part, uint32_t nchunk
 
 // ------------------------------------------------------------------------------------------------------
 // encrypt kernel: per row, <sk, a> over a coordinate tile (truncated KW-word products), reduced in LDS.
+// grid = (ntiles, nchunks); thread (rs, t): rows r0 + rs, r0 + rs + ROWS, ...
 // pb[(row*ntiles + tile)*KW + l] = tile partial of <sk,a> mod 2^(32 KW)
 // ------------------------------------------------------------------------------------------------------
 template <int LOGQ>
-__global__ __launch_bounds__(PS<LOGQ>::TILE) void k_encrypt(AesKey key, const uint32_t *__restrict__ g_t0, uint64_t off, uint32_t n,
-                                                            uint32_t nrows, uint32_t rows_per_chunk,
-                                                            const uint64_t *__restrict__ sk, uint32_t *__restrict__ pb) {
+__global__ __launch_bounds__(PS<LOGQ>::THREADS) void k_encrypt(AesKey key, const uint32_t *__restrict__ g_t0, uint64_t off, uint32_t n,
+                                                               uint32_t nrows, uint32_t rows_per_chunk,
+                                                               const uint64_t *__restrict__ sk, uint32_t *__restrict__ pb) {
   using S = PS<LOGQ>;
   constexpr int NW = S::TILE / 64;
-  __shared__ uint32_t lt[mf::kT0Words];
-  __shared__ __attribute__((aligned(16))) uint8_t ks[S::KS_BYTES];
-  __shared__ uint64_t sums[S::KW];
-  mf::lds_fill_t0(lt, g_t0);
-  const uint32_t *tl = lt + (threadIdx.x & 31);
+  __shared__ __attribute__((aligned(16))) uint32_t lt[mf::kTabBytes / 4];
+  __shared__ __attribute__((aligned(16))) uint8_t ksbuf[S::ROWS][S::KS_BYTES];
+  __shared__ uint64_t sums[S::ROWS][S::KW];
+  mf::lds_fill_tab(lt, g_t0);
+  const uint8_t *tab = reinterpret_cast<const uint8_t *>(lt);
+  const mf::AesLane L = mf::aes_lane();
+  const uint32_t rs = threadIdx.x / S::TILE, t = threadIdx.x % S::TILE;
+  uint8_t *ks = ksbuf[rs];
   const uint32_t j0 = blockIdx.x * S::TILE;
-  const uint32_t j = j0 + threadIdx.x;
+  const uint32_t j = j0 + t;
   const uint32_t nelem = j0 >= n ? 0u : min((uint32_t)S::TILE, n - j0);
   const uint32_t r0 = blockIdx.y * rows_per_chunk;
   const uint32_t r1 = min(nrows, r0 + rows_per_chunk);
-  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t lane = t & 63, wave = t >> 6;
 
   uint32_t s[S::KW];
   {
@@ -262,56 +311,58 @@ __global__ __launch_bounds__(PS<LOGQ>::TILE) void k_encrypt(AesKey key, const ui
 #pragma unroll
     for (int l = 0; l < S::KW; l++) s[l] = j < n ? sw[l] : 0u;
   }
-  uint32_t *red = reinterpret_cast<uint32_t *>(ks);  // [KW][TILE] words, reuses the keystream tile
+  uint32_t *red = reinterpret_cast<uint32_t *>(ks);  // [KW][TILE] words, reuses this half's keystream tile
 
   __syncthreads();
-  for (uint32_t row = r0; row < r1; row++) {
-    const uint64_t rowoff = off + (uint64_t)row * n * S::CTB;
-    const uint32_t head = expand_tile_to_lds<LOGQ>(tl, key, ks, rowoff, j0, nelem);
+  for (uint32_t rr = r0; rr < r1; rr += S::ROWS) {
+    const uint32_t row = rr + rs;
+    const bool have = row < r1;
+    uint32_t head = 0;
+    if (have) head = expand_tile_to_lds<LOGQ>(tab, L, key, ks, off + (uint64_t)row * n * S::CTB, j0, nelem, t);
     __syncthreads();
-    uint32_t a[S::KW];
-    {
-      const uint32_t *kw = reinterpret_cast<const uint32_t *>(ks + head) + threadIdx.x * S::EW;
-#pragma unroll
-      for (int l = 0; l < S::KW; l++) a[l] = j < n ? kw[l] : 0u;
-    }
-    // prod = low KW words of a * s (operand scanning, carries dropped beyond KW)
     uint32_t prod[S::KW];
 #pragma unroll
     for (int l = 0; l < S::KW; l++) prod[l] = 0;
+    if (have && j < n) {
+      uint32_t a[S::KW];
+      const uint32_t *kw = reinterpret_cast<const uint32_t *>(ks + head) + t * S::EW;
 #pragma unroll
-    for (int u = 0; u < S::KW; u++) {
-      uint32_t carry = 0;
+      for (int l = 0; l < S::KW; l++) a[l] = kw[l];
+      // prod = low KW words of a * s (operand scanning, carries dropped beyond KW)
 #pragma unroll
-      for (int v = 0; u + v < S::KW; v++) {
-        uint64_t t = (uint64_t)a[u] * s[v] + prod[u + v] + carry;
-        prod[u + v] = (uint32_t)t;
-        carry = (uint32_t)(t >> 32);
+      for (int u = 0; u < S::KW; u++) {
+        uint32_t carry = 0;
+#pragma unroll
+        for (int v = 0; u + v < S::KW; v++) {
+          uint64_t tt = (uint64_t)a[u] * s[v] + prod[u + v] + carry;
+          prod[u + v] = (uint32_t)tt;
+          carry = (uint32_t)(tt >> 32);
+        }
       }
     }
     __syncthreads();  // everyone has read its keystream words
 #pragma unroll
-    for (int l = 0; l < S::KW; l++) red[l * S::TILE + threadIdx.x] = prod[l];
+    for (int l = 0; l < S::KW; l++) red[l * S::TILE + t] = prod[l];
     __syncthreads();
     for (int l = wave; l < S::KW; l += NW) {
-      uint64_t t = 0;
+      uint64_t tt = 0;
 #pragma unroll
-      for (int k = 0; k < NW; k++) t += red[l * S::TILE + k * 64 + lane];
+      for (int k = 0; k < NW; k++) tt += red[l * S::TILE + k * 64 + lane];
 #pragma unroll
-      for (int o = 32; o; o >>= 1) t += __shfl_xor(t, o);
-      if (lane == 0) sums[l] = t;
+      for (int o = 32; o; o >>= 1) tt += __shfl_xor(tt, o);
+      if (lane == 0) sums[rs][l] = tt;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (have && t == 0) {
       uint64_t carry = 0;
       uint32_t *o = pb + ((uint64_t)row * gridDim.x + blockIdx.x) * S::KW;
       for (int l = 0; l < S::KW; l++) {
-        uint64_t t = sums[l] + carry;
-        o[l] = (uint32_t)t;
-        carry = t >> 32;
+        uint64_t tt = sums[rs][l] + carry;
+        o[l] = (uint32_t)tt;
+        carry = tt >> 32;
       }
     }
-    // next iteration's expansion overwrites ks/red: all reads of red finished before the barrier above;
+    // the next iteration's expansion overwrites ks/red: every read of red finished before the barrier above;
     // sums[] is rewritten only after three more barriers.
   }
 }
@@ -603,10 +654,10 @@ int mfh_keystream(mfh_ctx *c, uint64_t off, void *d_out, size_t nbytes) {
   if (!nbytes) return MFH_OK;
   HIP_TRY(c, hipSetDevice(c->device));
   uint64_t nblk = ((off & 15) + nbytes + 15) >> 4;
-  uint32_t grid = (uint32_t)std::min<uint64_t>((nblk + 255) / 256, 256 * 8);
+  uint32_t grid = (uint32_t)std::min<uint64_t>((nblk + 1023) / 1024, 256 * 2);
   {
     Timer t(c, &c->ms_keystream);
-    hipLaunchKernelGGL(k_keystream, dim3(grid), dim3(256), 0, c->stream, c->key, c->d_t0, off, (uint8_t *)d_out, (uint64_t)nbytes);
+    hipLaunchKernelGGL(k_keystream, dim3(grid), dim3(1024), 0, c->stream, c->key, c->d_t0, off, (uint8_t *)d_out, (uint64_t)nbytes);
   }
   HIP_TRY(c, hipGetLastError());
   return MFH_OK;
@@ -663,14 +714,14 @@ int mfh_ct_addmul_ui(mfh_ctx *c, uint64_t *rop, const uint64_t *a, uint32_t x, s
   DISPATCH_LOGQ(c, return (ct_elementwise<736, 2>(c, rop, a, nullptr, x, count)), return (ct_elementwise<1472, 2>(c, rop, a, nullptr, x, count)));
 }
 
-static void chunking(uint32_t nrows, uint32_t ntiles, uint32_t &nchunks, uint32_t &rpc) {
-  // ~4 workgroups per CU's worth of chunks, at least 8 rows each so the table fill amortises
-  uint32_t target = std::max(1u, (256u * 4u) / ntiles);
-  rpc = std::max(8u, (nrows + target - 1) / target);
-  nchunks = (nrows + rpc - 1) / rpc;
-}
-
 }  // extern "C"
+
+// number of row chunks: one workgroup per CU per tile row is the sweet spot (64 KiB table + 2 keystream tiles fill the LDS)
+static uint32_t pick_chunks(uint32_t nrows, uint32_t ntiles, uint32_t rows_per_iter) {
+  uint32_t target = std::max(1u, (256u * 2u) / ntiles);  // ~2 workgroups per CU in flight over the launch
+  uint32_t maxc = std::max(1u, (nrows + rows_per_iter * 4 - 1) / (rows_per_iter * 4));  // >= 4 iterations per chunk to amortise the table fill
+  return std::min(target, maxc);
+}
 
 template <int LOGQ>
 static int eval_rows(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *c8, const uint32_t *c0, const uint32_t *c1, uint64_t *rop0,
@@ -679,24 +730,29 @@ static int eval_rows(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *c8, 
   const uint32_t n = c->P.n;
   const uint32_t ntiles = (n + 1 + S::TILE - 1) / S::TILE;
   const int nacc = c1 ? 2 : 1;
-  uint32_t nchunks, rpc;
-  chunking((uint32_t)nrows, ntiles, nchunks, rpc);
+  const uint32_t nchunks = pick_chunks((uint32_t)nrows, ntiles, S::ROWS);
+  const uint32_t nslabs = nchunks * S::ROWS;
   const uint32_t NJ = ntiles * S::TILE;
-  const size_t part_bytes = (size_t)nchunks * nacc * S::KW * NJ * 4;
-  int rc = ws_reserve(c, part_bytes);
+  const size_t part_bytes = (size_t)nslabs * nacc * S::KW * NJ * 4;
+  const size_t idx_bytes = (((size_t)nrows + 1) * 4 + 255) & ~(size_t)255;
+  int rc = ws_reserve(c, part_bytes + idx_bytes);
   if (rc) return rc;
   uint32_t *part = (uint32_t *)c->ws;
+  uint32_t *idx = (uint32_t *)((uint8_t *)c->ws + part_bytes);
+  uint32_t *cnt = idx + nrows;
+  hipLaunchKernelGGL(k_compact_rows, dim3(1), dim3(1024), 0, c->stream, c0, c1, (uint32_t)nrows, idx, cnt);
+  HIP_TRY(c, hipGetLastError());
   {
     Timer t(c, &c->ms_eval);
     if (nacc == 2)
-      hipLaunchKernelGGL((k_eval<LOGQ, 2>), dim3(ntiles, nchunks), dim3(S::TILE), 0, c->stream, c->key, c->d_t0, off, n, (uint32_t)nrows, rpc,
-                         c8, c0, c1, part);
+      hipLaunchKernelGGL((k_eval<LOGQ, 2>), dim3(ntiles, nchunks), dim3(S::THREADS), 0, c->stream, c->key, c->d_t0, off, n, idx, cnt, c8, c0, c1,
+                         part);
     else
-      hipLaunchKernelGGL((k_eval<LOGQ, 1>), dim3(ntiles, nchunks), dim3(S::TILE), 0, c->stream, c->key, c->d_t0, off, n, (uint32_t)nrows, rpc,
-                         c8, c0, c1, part);
+      hipLaunchKernelGGL((k_eval<LOGQ, 1>), dim3(ntiles, nchunks), dim3(S::THREADS), 0, c->stream, c->key, c->d_t0, off, n, idx, cnt, c8, c0, c1,
+                         part);
   }
   HIP_TRY(c, hipGetLastError());
-  hipLaunchKernelGGL(k_eval_reduce<LOGQ>, dim3((n + 1 + 255) / 256, nacc), dim3(256), 0, c->stream, part, nchunks, (uint32_t)nacc, NJ, n, rop0,
+  hipLaunchKernelGGL(k_eval_reduce<LOGQ>, dim3((n + 1 + 255) / 256, nacc), dim3(256), 0, c->stream, part, nslabs, (uint32_t)nacc, NJ, n, rop0,
                      rop1, accumulate);
   HIP_TRY(c, hipGetLastError());
   return MFH_OK;
@@ -729,17 +785,17 @@ static int encrypt_rows(mfh_ctx *c, uint64_t off, size_t nrows, const uint64_t *
   using S = PS<LOGQ>;
   const uint32_t n = c->P.n;
   const uint32_t ntiles = (n + S::TILE - 1) / S::TILE;
-  uint32_t nchunks, rpc;
-  chunking((uint32_t)nrows, ntiles, nchunks, rpc);
-  rpc = std::max(1u, std::min(rpc, ((uint32_t)nrows + 255u) / 256u));  // rows are independent: prefer many small chunks
-  nchunks = ((uint32_t)nrows + rpc - 1) / rpc;
+  const uint32_t nchunks = pick_chunks((uint32_t)nrows, ntiles, S::ROWS);
+  uint32_t rpc = ((uint32_t)nrows + nchunks - 1) / nchunks;
+  rpc = (rpc + S::ROWS - 1) / S::ROWS * S::ROWS;
+  const uint32_t gy = ((uint32_t)nrows + rpc - 1) / rpc;
   const size_t pb_bytes = (size_t)nrows * ntiles * S::KW * 4;
   int rc = ws_reserve(c, pb_bytes);
   if (rc) return rc;
   uint32_t *pb = (uint32_t *)c->ws;
   {
     Timer t(c, &c->ms_encrypt);
-    hipLaunchKernelGGL(k_encrypt<LOGQ>, dim3(ntiles, nchunks), dim3(S::TILE), 0, c->stream, c->key, c->d_t0, off, n, (uint32_t)nrows, rpc, sk, pb);
+    hipLaunchKernelGGL(k_encrypt<LOGQ>, dim3(ntiles, gy), dim3(S::THREADS), 0, c->stream, c->key, c->d_t0, off, n, (uint32_t)nrows, rpc, sk, pb);
   }
   HIP_TRY(c, hipGetLastError());
   hipLaunchKernelGGL(k_encrypt_finish<LOGQ>, dim3(((uint32_t)nrows + 255) / 256), dim3(256), 0, c->stream, pb, ntiles, (uint32_t)nrows, msg, err, c8);
