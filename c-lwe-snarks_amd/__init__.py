@@ -84,7 +84,8 @@ EXPORTS = [
     "mfh_ctx_create", "mfh_ctx_destroy", "mfh_set_stream", "mfh_sync", "mfh_last_error", "mfh_set_seed",
     "mfh_keystream", "mfh_sample_rows", "mfh_ct_add", "mfh_ct_mul_ui", "mfh_ct_addmul_ui", "mfh_eval_rows",
     "mfh_encrypt_rows", "mfh_decrypt", "mfh_ct_smudge", "mfh_ssp_upload", "mfh_witness_poly", "mfh_version",
-    "mfh_workspace_bytes", "mfh_last_kernel_ms", "mfh_set_timing",
+    "mfh_workspace_bytes", "mfh_last_kernel_ms", "mfh_set_timing", "mfh_poly_mul", "mfh_poly_add", "mfh_poly_prepare_t",
+    "mfh_ssp_prepare", "mfh_poly_h", "mfh_setup_messages", "mfh_setup", "mfh_prove",
 ]
 
 
@@ -120,6 +121,14 @@ def load_library():
         "mfh_workspace_bytes": (sz, [vp]),
         "mfh_last_kernel_ms": (ctypes.c_float, [vp, ctypes.c_char_p]),
         "mfh_set_timing": (i32, [vp, i32]),
+        "mfh_poly_mul": (i32, [vp, vp, sz, vp, sz, vp]),
+        "mfh_poly_add": (i32, [vp, vp, vp, sz, vp]),
+        "mfh_poly_prepare_t": (i32, [vp, vp]),
+        "mfh_ssp_prepare": (i32, [vp, vp]),
+        "mfh_poly_h": (i32, [vp, vp, vp]),
+        "mfh_setup_messages": (i32, [vp, vp, u32, u32, u32, vp]),
+        "mfh_setup": (i32, [vp, vp, u32, u32, u32, vp, vp, vp]),
+        "mfh_prove": (i32, [vp, vp, vp, ctypes.c_char_p, u32, ctypes.c_char_p, sz, ctypes.c_char_p, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export what the header declares
@@ -264,4 +273,44 @@ class Context:
     def witness_poly(self, d_ssp, witness_bits: bytes, delta):
         out = self.empty(self.params.d * 4)
         self._chk(self.lib.mfh_witness_poly(self._h, _ptr(d_ssp), bytes(witness_bits), delta, _ptr(out)))
+        return out
+
+    # -- polynomial step, setup, prover ---------------------------------------------------------------------
+    def poly_mul(self, a, la, b, lb):
+        out = self.empty((la + lb - 1) * 4)
+        self._chk(self.lib.mfh_poly_mul(self._h, _ptr(a), la, _ptr(b), lb, _ptr(out)))
+        return out
+
+    def ssp_prepare(self, d_ssp):
+        """per-SSP precomputation for the division by t(x) (src/snark.c:169)"""
+        self._chk(self.lib.mfh_ssp_prepare(self._h, _ptr(d_ssp)))
+
+    def poly_prepare_t(self, d_t):
+        self._chk(self.lib.mfh_poly_prepare_t(self._h, _ptr(d_t)))
+
+    def poly_h(self, d_v):
+        out = self.empty(self.params.d * 4)
+        self._chk(self.lib.mfh_poly_h(self._h, _ptr(d_v), _ptr(out)))
+        return out
+
+    def setup_messages(self, d_ssp, alpha, beta, s):
+        p = self.params
+        out = self.empty((2 * p.d + p.m) * 4)
+        self._chk(self.lib.mfh_setup_messages(self._h, _ptr(d_ssp), alpha, beta, s, _ptr(out)))
+        return out
+
+    def setup(self, d_ssp, alpha, beta, s, d_sk, d_err, out=None):
+        """setup() (src/snark.c:57-115): returns the device CRS, (2d+m)*CT_BYTES bytes in stream order."""
+        p = self.params
+        out = self.empty((2 * p.d + p.m) * p.ctb) if out is None else out
+        self._chk(self.lib.mfh_setup(self._h, _ptr(d_ssp), alpha, beta, s, _ptr(d_sk), _ptr(d_err), _ptr(out)))
+        return out
+
+    def prove(self, d_crs, d_ssp, witness_bits: bytes, delta, smudge_mag: bytes, smudge_sign: bytes, maglen=80, out=None):
+        """prover() (src/snark.c:117-190): returns 5 ciphertexts h | hat_h | hat_v | v_w | b_w."""
+        p = self.params
+        out = self.empty(5 * p.ct_limbs * 8) if out is None else out
+        assert len(smudge_mag) == 5 * maglen and len(smudge_sign) == 5
+        self._chk(self.lib.mfh_prove(self._h, _ptr(d_crs), _ptr(d_ssp), bytes(witness_bits), delta, bytes(smudge_mag), maglen,
+                                     bytes(smudge_sign), _ptr(out)))
         return out

@@ -1,0 +1,67 @@
+// ctx.hpp -- internal: the context object behind include/mfhip.h and helpers shared by the .hip files.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "aes_dev.hpp"
+#include "mfhip.h"
+
+#define HIP_TRY(ctx, expr)                                                        \
+  do {                                                                            \
+    hipError_t e_ = (expr);                                                       \
+    if (e_ != hipSuccess) {                                                       \
+      (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);             \
+      return MFH_EDEVICE;                                                         \
+    }                                                                             \
+  } while (0)
+
+struct PolyState;
+
+struct mfh_ctx {
+  mfh_params P{};
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  mf::AesKey key{};
+  bool have_seed = false;
+  uint32_t *d_t0 = nullptr;  // 256 words
+  void *ws = nullptr;        // scratch (partials etc.)
+  size_t ws_bytes = 0;
+  std::string err;
+  bool timing = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  float ms_eval = -1.f, ms_encrypt = -1.f, ms_keystream = -1.f;
+  PolyState *poly = nullptr;  // NTT tables and per-SSP precomputation (poly.hip)
+  void *aux = nullptr;        // small scratch that must survive an eval/encrypt launch (snark.hip)
+  size_t aux_bytes = 0;
+  uint32_t *d_msg = nullptr;  // setup messages
+  size_t msg_rows = 0;
+  uint32_t *d_prover = nullptr;  // prover polynomials w, v, h and the b_w coefficient vector
+  size_t prover_words = 0;
+  std::vector<uint32_t> h_cw;
+};
+
+void mfh_poly_destroy(mfh_ctx *c);
+int aux_reserve(mfh_ctx *c, size_t bytes);
+
+inline int ws_reserve(mfh_ctx *c, size_t bytes) {
+  if (bytes <= c->ws_bytes) return MFH_OK;
+  if (c->ws) {
+    hipStreamSynchronize(c->stream);
+    hipFree(c->ws);
+    c->ws = nullptr;
+    c->ws_bytes = 0;
+  }
+  bytes = (bytes + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
+  if (hipMalloc(&c->ws, bytes) != hipSuccess) {
+    c->err = "hipMalloc(workspace) failed";
+    return MFH_ENOMEM;
+  }
+  c->ws_bytes = bytes;
+  return MFH_OK;
+}
+

@@ -40,47 +40,7 @@ struct PS {
   static constexpr int KS_BYTES = TILE * CTB + 16;      // one row tile of keystream (+1 block when misaligned)
 };
 
-#define HIP_TRY(ctx, expr)                                                        \
-  do {                                                                            \
-    hipError_t e_ = (expr);                                                       \
-    if (e_ != hipSuccess) {                                                       \
-      (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);             \
-      return MFH_EDEVICE;                                                         \
-    }                                                                             \
-  } while (0)
-
-struct mfh_ctx {
-  mfh_params P{};
-  int device = 0;
-  hipStream_t own_stream = nullptr;
-  hipStream_t stream = nullptr;
-  AesKey key{};
-  bool have_seed = false;
-  uint32_t *d_t0 = nullptr;  // 256 words
-  void *ws = nullptr;        // scratch (partials etc.)
-  size_t ws_bytes = 0;
-  std::string err;
-  bool timing = false;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  float ms_eval = -1.f, ms_encrypt = -1.f, ms_keystream = -1.f;
-};
-
-static int ws_reserve(mfh_ctx *c, size_t bytes) {
-  if (bytes <= c->ws_bytes) return MFH_OK;
-  if (c->ws) {
-    hipStreamSynchronize(c->stream);
-    hipFree(c->ws);
-    c->ws = nullptr;
-    c->ws_bytes = 0;
-  }
-  bytes = (bytes + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
-  if (hipMalloc(&c->ws, bytes) != hipSuccess) {
-    c->err = "hipMalloc(workspace) failed";
-    return MFH_ENOMEM;
-  }
-  c->ws_bytes = bytes;
-  return MFH_OK;
-}
+#include "ctx.hpp"
 
 // ------------------------------------------------------------------------------------------------------
 // keystream kernel: aesctr_prg / rng_seek (src/aes.c:104-144, src/entropy.c:46-56), stateless form
@@ -589,7 +549,11 @@ void mfh_ctx_destroy(mfh_ctx *c) {
   if (!c) return;
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
+  mfh_poly_destroy(c);
   if (c->ws) hipFree(c->ws);
+  if (c->aux) hipFree(c->aux);
+  if (c->d_msg) hipFree(c->d_msg);
+  if (c->d_prover) hipFree(c->d_prover);
   if (c->d_t0) hipFree(c->d_t0);
   if (c->ev0) hipEventDestroy(c->ev0);
   if (c->ev1) hipEventDestroy(c->ev1);

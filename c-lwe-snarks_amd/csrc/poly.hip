@@ -1,0 +1,402 @@
+// poly.hip -- polynomial arithmetic over F_p, p = 2^32 - 5, on the GPU.
+//
+// The prover's only non-streaming step is  h = (v^2 - 1) / t  (reference src/snark.c:166-169, FLINT's
+// nmod_poly_pow / nmod_poly_sub / nmod_poly_div).  p - 1 = 2 * 2147483645 has 2-adicity 1, so there is no NTT mod p;
+// products are computed exactly over the integers with three NTT-friendly 31-bit primes + CRT (coefficients < 2^32,
+// length <= 2^22: every convolution coefficient is < 2^86 < p1*p2*p3 ~ 2^92.6) and reduced mod p afterwards.  Because every
+// result is the canonical representative in [0, p), it is bit-identical to FLINT's whatever algorithm FLINT picks.
+// Division is a multiplication by the power-series inverse of rev(t), computed once per SSP by Newton iteration
+// (mfh_poly_prepare_t): q = rev( rev(A)[:n] * rev(t)^-1 mod x^n ), n = deg A - deg t + 1.
+#include <algorithm>
+
+#include "ctx.hpp"
+
+namespace {
+
+constexpr uint32_t P32 = 0xfffffffbu;
+
+struct NttPrime {
+  uint32_t p, ninv, r2;  // modulus, -p^-1 mod 2^32, 2^64 mod p
+};
+struct Primes3 {
+  NttPrime q[3];
+};
+
+__host__ __device__ __forceinline__ uint32_t mont_mul(uint32_t a, uint32_t b, uint32_t p, uint32_t ninv) {
+  uint64_t t = (uint64_t)a * b;
+  uint32_t m = (uint32_t)t * ninv;
+  uint32_t u = (uint32_t)((t + (uint64_t)m * p) >> 32);
+  return u >= p ? u - p : u;
+}
+__host__ __device__ __forceinline__ uint32_t add_mod(uint32_t a, uint32_t b, uint32_t p) {
+  uint32_t s = a + b;  // p < 2^31: no overflow
+  return s >= p ? s - p : s;
+}
+__host__ __device__ __forceinline__ uint32_t sub_mod(uint32_t a, uint32_t b, uint32_t p) { return a >= b ? a - b : a + p - b; }
+
+// x mod (2^32 - 5) for x < 2^64:  2^32 = 5
+__host__ __device__ __forceinline__ uint32_t red_p32(uint64_t x) {
+  x = (x >> 32) * 5 + (uint32_t)x;  // < 5*2^32 + 2^32
+  x = (x >> 32) * 5 + (uint32_t)x;  // < 30 + 2^32
+  if (x >= P32) x -= P32;
+  if (x >= P32) x -= P32;
+  return (uint32_t)x;
+}
+
+uint64_t h_powmod(uint64_t a, uint64_t e, uint64_t p) {
+  uint64_t r = 1;
+  a %= p;
+  while (e) {
+    if (e & 1) r = (unsigned __int128)r * a % p;
+    a = (unsigned __int128)a * a % p;
+    e >>= 1;
+  }
+  return r;
+}
+
+// ---- kernels -------------------------------------------------------------------------------------------
+// load `len` coefficients (mod p32) into [3][N] Montgomery residues, zero padded
+__global__ void k_ntt_load(const uint32_t *__restrict__ in, uint32_t len, uint32_t N, Primes3 P, uint32_t *__restrict__ out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const NttPrime q = P.q[blockIdx.y];
+  uint32_t x = i < len ? in[i] : 0u;
+  out[(size_t)blockIdx.y * N + i] = mont_mul(x, q.r2, q.p, q.ninv);  // x * R mod p (x < 2^32, r2 < p: product < p * 2^32)
+}
+
+// decimation-in-frequency stage (natural -> bit-reversed order overall)
+__global__ void k_ntt_dif(uint32_t *__restrict__ a, uint32_t N, uint32_t len, const uint32_t *__restrict__ tw, uint32_t tw_stride_n, Primes3 P) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N / 2) return;
+  const NttPrime q = P.q[blockIdx.y];
+  const uint32_t half = len >> 1;
+  const uint32_t j = i & (half - 1);
+  const uint32_t s = (i - j) * 2;
+  uint32_t *x = a + (size_t)blockIdx.y * N + s + j;
+  const uint32_t w = tw[(size_t)blockIdx.y * tw_stride_n + (size_t)j * (tw_stride_n * 2 / len)];
+  uint32_t u = x[0], v = x[half];
+  x[0] = add_mod(u, v, q.p);
+  x[half] = mont_mul(sub_mod(u, v, q.p), w, q.p, q.ninv);
+}
+// decimation-in-time stage with inverse twiddles (bit-reversed -> natural)
+__global__ void k_ntt_dit(uint32_t *__restrict__ a, uint32_t N, uint32_t len, const uint32_t *__restrict__ tw, uint32_t tw_stride_n, Primes3 P) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N / 2) return;
+  const NttPrime q = P.q[blockIdx.y];
+  const uint32_t half = len >> 1;
+  const uint32_t j = i & (half - 1);
+  const uint32_t s = (i - j) * 2;
+  uint32_t *x = a + (size_t)blockIdx.y * N + s + j;
+  const uint32_t w = tw[(size_t)blockIdx.y * tw_stride_n + (size_t)j * (tw_stride_n * 2 / len)];
+  uint32_t u = x[0], v = mont_mul(x[half], w, q.p, q.ninv);
+  x[0] = add_mod(u, v, q.p);
+  x[half] = sub_mod(u, v, q.p);
+}
+__global__ void k_pointwise(uint32_t *__restrict__ a, const uint32_t *__restrict__ b, uint32_t N, Primes3 P) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const NttPrime q = P.q[blockIdx.y];
+  size_t o = (size_t)blockIdx.y * N + i;
+  a[o] = mont_mul(a[o], b[o], q.p, q.ninv);
+}
+struct Crt {
+  uint32_t ninv_std[3];  // N^-1 mod p_i (standard form): mont_mul(xR, ninv_std) = x / N in standard form
+  uint32_t inv_p1_p2, inv_p1_p3, inv_p2_p3;  // Montgomery form of p1^-1 mod p2, p1^-1 mod p3, p2^-1 mod p3
+  uint32_t p1_mod, p1p2_mod;                 // p1 mod p32, p1*p2 mod p32
+};
+// residues (Montgomery, unscaled inverse transform) -> coefficient mod p32, first `count` coefficients
+__global__ void k_crt(const uint32_t *__restrict__ r, uint32_t N, uint32_t count, Primes3 P, Crt C, uint32_t *__restrict__ out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const NttPrime q1 = P.q[0], q2 = P.q[1], q3 = P.q[2];
+  uint32_t x1 = mont_mul(r[i], C.ninv_std[0], q1.p, q1.ninv);
+  uint32_t r2 = mont_mul(r[(size_t)N + i], C.ninv_std[1], q2.p, q2.ninv);
+  uint32_t r3 = mont_mul(r[(size_t)2 * N + i], C.ninv_std[2], q3.p, q3.ninv);
+  // Garner: X = x1 + x2 p1 + x3 p1 p2
+  uint32_t x1m2 = x1 >= q2.p ? x1 - q2.p : x1;  // x1 < p1 < 2 p2
+  uint32_t x2 = mont_mul(sub_mod(r2, x1m2, q2.p), C.inv_p1_p2, q2.p, q2.ninv);
+  uint32_t x1m3 = x1 >= q3.p ? x1 - q3.p : x1;
+  uint32_t x2m3 = x2 >= q3.p ? x2 - q3.p : x2;
+  uint32_t t3 = mont_mul(sub_mod(r3, x1m3, q3.p), C.inv_p1_p3, q3.p, q3.ninv);
+  uint32_t x3 = mont_mul(sub_mod(t3, x2m3, q3.p), C.inv_p2_p3, q3.p, q3.ninv);
+  uint64_t acc = (uint64_t)red_p32(x1) + red_p32((uint64_t)x2 * C.p1_mod) + red_p32((uint64_t)x3 * C.p1p2_mod);
+  out[i] = red_p32(acc);
+}
+
+__global__ void k_reverse(const uint32_t *__restrict__ in, int64_t top, uint32_t count, uint32_t *__restrict__ out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;  // out[i] = in[top - i] (0 if top - i < 0)
+  if (i >= count) return;
+  int64_t s = top - (int64_t)i;
+  out[i] = s >= 0 ? in[s] : 0u;
+}
+__global__ void k_two_minus(uint32_t *__restrict__ e, uint32_t count) {  // e <- 2 - e  (mod p32)
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  uint32_t v = e[i];
+  uint32_t neg = v ? P32 - v : 0u;
+  e[i] = i == 0 ? red_p32((uint64_t)neg + 2) : neg;
+}
+__global__ void k_sub_const0(uint32_t *__restrict__ a, uint32_t c) {  // a[0] -= c
+  if (threadIdx.x == 0 && blockIdx.x == 0) a[0] = red_p32((uint64_t)a[0] + P32 - c);
+}
+__global__ void k_add_vec(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, uint32_t count, uint32_t *__restrict__ out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) out[i] = red_p32((uint64_t)a[i] + b[i]);
+}
+// out[i] = q[n-1-i] for i < min(n, d), zero above (quotient reversed back, first d coefficients)
+__global__ void k_unreverse_pad(const uint32_t *__restrict__ qrev, uint32_t n, uint32_t d, uint32_t *__restrict__ out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d) return;
+  out[i] = i < n ? qrev[n - 1 - i] : 0u;
+}
+
+inline dim3 g1(uint32_t n) { return dim3((n + 255) / 256); }
+
+}  // namespace
+
+struct PolyState {
+  Primes3 P{};
+  uint32_t root[3]{};  // generator of the 2^logmax subgroup is derived from these primitive roots
+  uint32_t logmax = 0;
+  uint32_t *d_tw = nullptr;   // [3][Nmax/2] forward twiddles (Montgomery)
+  uint32_t *d_twi = nullptr;  // [3][Nmax/2] inverse twiddles
+  uint32_t *d_bufA = nullptr, *d_bufB = nullptr;  // [3][Nmax] transform buffers
+  uint32_t *d_tmp = nullptr;  // Nmax coefficients
+  uint32_t *d_tmp2 = nullptr;
+  // per-SSP quotient precomputation
+  bool have_t = false;
+  uint32_t d = 0, dt = 0, n = 0, logN2 = 0;
+  uint32_t *d_G = nullptr;     // n coefficients of rev(t)^-1
+  uint32_t *d_Ghat = nullptr;  // [3][N2] forward transform of G
+  uint32_t *d_f = nullptr;     // rev(t), dt+1 coefficients
+  ~PolyState() {
+    for (uint32_t *p : {d_tw, d_twi, d_bufA, d_bufB, d_tmp, d_tmp2, d_G, d_Ghat, d_f})
+      if (p) hipFree(p);
+  }
+};
+
+namespace {
+
+const uint32_t kPrimes[3] = {2013265921u, 1811939329u, 2113929217u};  // 15*2^27+1, 27*2^26+1, 63*2^25+1
+const uint32_t kRoots[3] = {31u, 13u, 5u};                             // primitive roots (checked at init)
+
+uint32_t to_mont(uint64_t x, const NttPrime &q) { return (uint32_t)(((unsigned __int128)(x % q.p) << 32) % q.p); }
+
+int poly_init(mfh_ctx *c, uint32_t logmax) {
+  if (c->poly && c->poly->logmax >= logmax) return MFH_OK;
+  if (logmax > 24) {
+    c->err = "polynomial too long for the NTT primes (max 2^24)";
+    return MFH_EUNSUPPORTED;
+  }
+  delete c->poly;
+  c->poly = nullptr;
+  PolyState *S = new PolyState();
+  S->logmax = logmax;
+  const size_t Nmax = (size_t)1 << logmax;
+  for (int k = 0; k < 3; k++) {
+    NttPrime &q = S->P.q[k];
+    q.p = kPrimes[k];
+    uint32_t inv = 1;  // Newton for p^-1 mod 2^32
+    for (int it = 0; it < 6; it++) inv *= 2 - q.p * inv;
+    q.ninv = (uint32_t)(0u - inv);
+    q.r2 = (uint32_t)(((unsigned __int128)1 << 64) % q.p);
+    // primitive root check: g^((p-1)/f) != 1 for every prime factor f of p-1
+    uint64_t pm1 = q.p - 1, rest = pm1;
+    for (uint64_t f = 2; f * f <= rest; f++)
+      if (rest % f == 0) {
+        if (h_powmod(kRoots[k], pm1 / f, q.p) == 1) { c->err = "NTT root is not primitive"; delete S; return MFH_EINVAL; }
+        while (rest % f == 0) rest /= f;
+      }
+    if (rest > 1 && h_powmod(kRoots[k], pm1 / rest, q.p) == 1) { c->err = "NTT root is not primitive"; delete S; return MFH_EINVAL; }
+  }
+  std::vector<uint32_t> tw(3 * Nmax / 2), twi(3 * Nmax / 2);
+  for (int k = 0; k < 3; k++) {
+    const NttPrime &q = S->P.q[k];
+    uint64_t w = h_powmod(kRoots[k], (q.p - 1) >> logmax, q.p), wi = h_powmod(w, q.p - 2, q.p);
+    uint64_t a = 1, b = 1;
+    for (size_t i = 0; i < Nmax / 2; i++) {
+      tw[k * (Nmax / 2) + i] = to_mont(a, q);
+      twi[k * (Nmax / 2) + i] = to_mont(b, q);
+      a = a * w % q.p;
+      b = b * wi % q.p;
+    }
+  }
+  bool ok = hipMalloc(&S->d_tw, tw.size() * 4) == hipSuccess && hipMalloc(&S->d_twi, twi.size() * 4) == hipSuccess &&
+            hipMalloc(&S->d_bufA, 3 * Nmax * 4) == hipSuccess && hipMalloc(&S->d_bufB, 3 * Nmax * 4) == hipSuccess &&
+            hipMalloc(&S->d_tmp, Nmax * 4) == hipSuccess && hipMalloc(&S->d_tmp2, Nmax * 4) == hipSuccess &&
+            hipMemcpy(S->d_tw, tw.data(), tw.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
+            hipMemcpy(S->d_twi, twi.data(), twi.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+  if (!ok) {
+    delete S;
+    c->err = "poly_init: device allocation failed";
+    return MFH_ENOMEM;
+  }
+  c->poly = S;
+  return MFH_OK;
+}
+
+uint32_t ceil_log2(size_t x) {
+  uint32_t l = 0;
+  while (((size_t)1 << l) < x) l++;
+  return l;
+}
+
+void forward(mfh_ctx *c, uint32_t *buf, uint32_t logN) {
+  PolyState *S = c->poly;
+  const uint32_t N = 1u << logN, half_max = 1u << (S->logmax - 1);
+  for (uint32_t len = N; len >= 2; len >>= 1)
+    hipLaunchKernelGGL(k_ntt_dif, dim3((N / 2 + 255) / 256, 3), dim3(256), 0, c->stream, buf, N, len, S->d_tw, half_max, S->P);
+}
+void inverse(mfh_ctx *c, uint32_t *buf, uint32_t logN) {
+  PolyState *S = c->poly;
+  const uint32_t N = 1u << logN, half_max = 1u << (S->logmax - 1);
+  for (uint32_t len = 2; len <= N; len <<= 1)
+    hipLaunchKernelGGL(k_ntt_dit, dim3((N / 2 + 255) / 256, 3), dim3(256), 0, c->stream, buf, N, len, S->d_twi, half_max, S->P);
+}
+Crt make_crt(const PolyState *S, uint32_t logN) {
+  Crt C{};
+  const NttPrime *q = S->P.q;
+  for (int k = 0; k < 3; k++) C.ninv_std[k] = (uint32_t)h_powmod((uint64_t)1 << logN, q[k].p - 2, q[k].p);
+  C.inv_p1_p2 = to_mont(h_powmod(q[0].p, q[1].p - 2, q[1].p), q[1]);
+  C.inv_p1_p3 = to_mont(h_powmod(q[0].p, q[2].p - 2, q[2].p), q[2]);
+  C.inv_p2_p3 = to_mont(h_powmod(q[1].p, q[2].p - 2, q[2].p), q[2]);
+  C.p1_mod = (uint32_t)(q[0].p % P32);
+  C.p1p2_mod = (uint32_t)(((uint64_t)q[0].p * q[1].p) % P32);
+  return C;
+}
+
+// c[0..keep) = (a * b)[0..keep) mod p32.  bhat != null: use that precomputed forward transform (size 2^logN) instead of b.
+int poly_mul(mfh_ctx *c, const uint32_t *a, uint32_t la, const uint32_t *b, uint32_t lb, const uint32_t *bhat, uint32_t logN_hat,
+             uint32_t *out, uint32_t keep) {
+  PolyState *S = c->poly;
+  uint32_t logN = bhat ? logN_hat : ceil_log2((size_t)la + lb - 1);
+  if (logN < 1) logN = 1;
+  if (logN > S->logmax || ((size_t)la + lb - 1) > ((size_t)1 << logN)) {
+    c->err = "poly_mul: size exceeds the prepared NTT length";
+    return MFH_EINVAL;
+  }
+  const uint32_t N = 1u << logN;
+  hipLaunchKernelGGL(k_ntt_load, dim3((N + 255) / 256, 3), dim3(256), 0, c->stream, a, la, N, S->P, S->d_bufA);
+  forward(c, S->d_bufA, logN);
+  const uint32_t *rhs = bhat;
+  if (!bhat) {
+    if (b == a && lb == la) {
+      rhs = S->d_bufA;
+    } else {
+      hipLaunchKernelGGL(k_ntt_load, dim3((N + 255) / 256, 3), dim3(256), 0, c->stream, b, lb, N, S->P, S->d_bufB);
+      forward(c, S->d_bufB, logN);
+      rhs = S->d_bufB;
+    }
+  }
+  hipLaunchKernelGGL(k_pointwise, dim3((N + 255) / 256, 3), dim3(256), 0, c->stream, S->d_bufA, rhs, N, S->P);
+  inverse(c, S->d_bufA, logN);
+  hipLaunchKernelGGL(k_crt, g1(keep), dim3(256), 0, c->stream, S->d_bufA, N, keep, S->P, make_crt(S, logN), out);
+  HIP_TRY(c, hipGetLastError());
+  return MFH_OK;
+}
+
+}  // namespace
+
+void mfh_poly_destroy(mfh_ctx *c) {
+  delete c->poly;
+  c->poly = nullptr;
+}
+
+extern "C" {
+
+int mfh_poly_mul(mfh_ctx *c, const uint32_t *d_a, size_t la, const uint32_t *d_b, size_t lb, uint32_t *d_c) {
+  if (!c || !d_a || !d_b || !d_c || !la || !lb) return MFH_EINVAL;
+  HIP_TRY(c, hipSetDevice(c->device));
+  int rc = poly_init(c, std::max(ceil_log2(la + lb - 1), 1u));
+  if (rc) return rc;
+  return poly_mul(c, d_a, (uint32_t)la, d_b, (uint32_t)lb, nullptr, 0, d_c, (uint32_t)(la + lb - 1));
+}
+
+int mfh_poly_prepare_t(mfh_ctx *c, const uint32_t *d_t) {
+  if (!c || !d_t) return MFH_EINVAL;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint32_t d = c->P.d;
+  std::vector<uint32_t> t(d);
+  HIP_TRY(c, hipMemcpyAsync(t.data(), d_t, (size_t)d * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  int64_t dt = -1;
+  for (int64_t i = (int64_t)d - 1; i >= 0; i--)
+    if (t[i]) { dt = i; break; }
+  if (dt < 0) {
+    c->err = "t(x) is the zero polynomial: (v^2-1)/t is undefined (nmod_poly_div would raise)";
+    return MFH_EINVAL;
+  }
+  const uint32_t n = 2 * d - 1 - (uint32_t)dt;  // quotient length for the nominal degree 2d-2 numerator
+  // products: v*v (2d-1 coeffs) and rev(A)[:n] * G[:n] (2n-1 coeffs); Newton steps never exceed 2n
+  uint32_t logmax = std::max(ceil_log2((size_t)2 * d), ceil_log2((size_t)2 * n + dt + 2));
+  int rc = poly_init(c, logmax);
+  if (rc) return rc;
+  PolyState *S = c->poly;
+  for (uint32_t **p : {&S->d_G, &S->d_Ghat, &S->d_f})
+    if (*p) { hipFree(*p); *p = nullptr; }
+  S->have_t = false;
+  S->d = d; S->dt = (uint32_t)dt; S->n = n;
+  S->logN2 = std::max(ceil_log2((size_t)2 * n - 1), 1u);
+  const uint32_t N2 = 1u << S->logN2;
+  HIP_TRY(c, hipMalloc(&S->d_G, (size_t)std::max(n, 2u) * 4 * 2));
+  HIP_TRY(c, hipMalloc(&S->d_Ghat, (size_t)3 * N2 * 4));
+  HIP_TRY(c, hipMalloc(&S->d_f, (size_t)(dt + 1) * 4));
+  hipLaunchKernelGGL(k_reverse, g1((uint32_t)dt + 1), dim3(256), 0, c->stream, d_t, dt, (uint32_t)dt + 1, S->d_f);  // f = rev(t)
+  // Newton: g <- g (2 - f g) mod x^(2k)
+  uint32_t g0 = (uint32_t)h_powmod(t[dt], (uint64_t)P32 - 2, P32);
+  HIP_TRY(c, hipMemsetAsync(S->d_G, 0, (size_t)std::max(n, 2u) * 4 * 2, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(S->d_G, &g0, 4, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (uint32_t k = 1; k < n;) {
+    const uint32_t k2 = std::min(2 * k, n);
+    const uint32_t lf = std::min(k2, (uint32_t)dt + 1);
+    rc = poly_mul(c, S->d_f, lf, S->d_G, k, nullptr, 0, S->d_tmp, std::min(k2, lf + k - 1));  // e = f g mod x^k2
+    if (rc) return rc;
+    if (lf + k - 1 < k2) HIP_TRY(c, hipMemsetAsync(S->d_tmp + (lf + k - 1), 0, (size_t)(k2 - (lf + k - 1)) * 4, c->stream));
+    hipLaunchKernelGGL(k_two_minus, g1(k2), dim3(256), 0, c->stream, S->d_tmp, k2);
+    rc = poly_mul(c, S->d_G, k, S->d_tmp, k2, nullptr, 0, S->d_tmp2, k2);  // g (2 - e) mod x^k2
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(S->d_G, S->d_tmp2, (size_t)k2 * 4, hipMemcpyDeviceToDevice, c->stream));
+    k = k2;
+  }
+  // forward transform of G at the size used per proof
+  hipLaunchKernelGGL(k_ntt_load, dim3((N2 + 255) / 256, 3), dim3(256), 0, c->stream, S->d_G, n, N2, S->P, S->d_Ghat);
+  forward(c, S->d_Ghat, S->logN2);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  S->have_t = true;
+  return MFH_OK;
+}
+
+int mfh_poly_h(mfh_ctx *c, const uint32_t *d_v, uint32_t *d_h) {
+  if (!c || !d_v || !d_h) return MFH_EINVAL;
+  PolyState *S = c->poly;
+  if (!S || !S->have_t) {
+    c->err = "mfh_poly_prepare_t has not been called for this SSP";
+    return MFH_EINVAL;
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint32_t d = S->d, n = S->n;
+  // A = v^2 - 1 : 2d-1 coefficients (nominal degree 2d-2)
+  int rc = poly_mul(c, d_v, d, d_v, d, nullptr, 0, S->d_tmp, 2 * d - 1);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_sub_const0, dim3(1), dim3(64), 0, c->stream, S->d_tmp, 1u);
+  // rev(A)[:n]
+  hipLaunchKernelGGL(k_reverse, g1(n), dim3(256), 0, c->stream, S->d_tmp, (int64_t)(2 * d - 2), n, S->d_tmp2);
+  // qrev = rev(A)[:n] * G mod x^n
+  rc = poly_mul(c, S->d_tmp2, n, nullptr, n, S->d_Ghat, S->logN2, S->d_tmp, n);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_unreverse_pad, g1(d), dim3(256), 0, c->stream, S->d_tmp, n, d, d_h);
+  HIP_TRY(c, hipGetLastError());
+  return MFH_OK;
+}
+
+int mfh_poly_add(mfh_ctx *c, const uint32_t *d_a, const uint32_t *d_b, size_t count, uint32_t *d_out) {
+  if (!c || !d_a || !d_b || !d_out) return MFH_EINVAL;
+  HIP_TRY(c, hipSetDevice(c->device));
+  hipLaunchKernelGGL(k_add_vec, g1((uint32_t)count), dim3(256), 0, c->stream, d_a, d_b, (uint32_t)count, d_out);
+  HIP_TRY(c, hipGetLastError());
+  return MFH_OK;
+}
+
+}  // extern "C"

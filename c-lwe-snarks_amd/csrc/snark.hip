@@ -1,0 +1,171 @@
+// snark.hip -- setup() and prover() of the reference (src/snark.c:57-190) as sequences of device launches.
+//
+// CRS device layout: ONE contiguous array of (2d + m) compressed ciphertexts (CT_BYTES each) in public-stream
+// order -- s[0..d) | as[0..d) | t | v[0..m-1) -- which is exactly the order setup() encrypts them in and the order
+// of the stream offsets CTR_S / CTR_AS / CTR_BT / CTR_BV (src/snark.h:8-12).  The reference keeps four mallocs
+// (struct crs, src/snark.h:27-33); the host shim copies between the two.
+#include <algorithm>
+
+#include "ctx.hpp"
+
+namespace {
+
+constexpr uint32_t P32 = 0xfffffffbu;
+
+__device__ __forceinline__ uint32_t red_p32(uint64_t x) {
+  x = (x >> 32) * 5 + (uint32_t)x;
+  x = (x >> 32) * 5 + (uint32_t)x;
+  if (x >= P32) x -= P32;
+  if (x >= P32) x -= P32;
+  return (uint32_t)x;
+}
+__device__ __forceinline__ uint32_t mulmod(uint32_t a, uint32_t b) { return red_p32((uint64_t)a * b); }
+
+// pw[k] = s^k mod p
+__global__ void k_powers(uint32_t s, uint32_t d, uint32_t *__restrict__ pw) {
+  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= d) return;
+  uint32_t r = 1, b = s, e = k;
+  while (e) {
+    if (e & 1) r = mulmod(r, b);
+    b = mulmod(b, b);
+    e >>= 1;
+  }
+  pw[k] = r;
+}
+// msg[i] = pw[i], msg[d+i] = alpha * pw[i]      (src/snark.c:73-91)
+__global__ void k_msg_powers(const uint32_t *__restrict__ pw, uint32_t d, uint32_t alpha, uint32_t *__restrict__ msg) {
+  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= d) return;
+  msg[k] = pw[k];
+  msg[d + k] = mulmod(alpha, pw[k]);
+}
+// msg[2d + r] = beta * <slot(r), pw>, slot(0) = t (slot 0), slot(r) = v_r (slot r+1) for r = 1..m-1: Horner's value
+// nmod_poly_evaluate_nmod(v_i, s) * beta (src/snark.c:97-98,105-106), computed as a dot product with the powers of s.
+__global__ __launch_bounds__(256) void k_msg_evals(const uint32_t *__restrict__ ssp, const uint32_t *__restrict__ pw, uint32_t d, uint32_t beta,
+                                                   uint32_t *__restrict__ msg) {
+  __shared__ uint64_t red[4];
+  const uint32_t r = blockIdx.x;
+  const uint32_t slot = r == 0 ? 0 : r + 1;
+  const uint32_t *row = ssp + (uint64_t)slot * d;
+  uint64_t acc = 0;
+  for (uint32_t k = threadIdx.x * 4; k < d; k += 256 * 4) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(row + k);
+    const uint4 w = *reinterpret_cast<const uint4 *>(pw + k);
+    uint64_t p0 = (uint64_t)v.x * w.x, p1 = (uint64_t)v.y * w.y, p2 = (uint64_t)v.z * w.z, p3 = (uint64_t)v.w * w.w;
+    acc += (p0 >> 32) * 5 + (uint32_t)p0;  // each < 2^35: > 2^28 terms before overflow
+    acc += (p1 >> 32) * 5 + (uint32_t)p1;
+    acc += (p2 >> 32) * 5 + (uint32_t)p2;
+    acc += (p3 >> 32) * 5 + (uint32_t)p3;
+  }
+  acc = red_p32(acc);
+  for (int o = 32; o; o >>= 1) acc += __shfl_xor(acc, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) msg[2 * d + r] = mulmod(red_p32(red[0] + red[1] + red[2] + red[3]), beta);
+}
+
+inline dim3 g1(uint32_t n) { return dim3((n + 255) / 256); }
+
+}  // namespace
+
+int aux_reserve(mfh_ctx *c, size_t bytes) {
+  if (bytes <= c->aux_bytes) return MFH_OK;
+  if (c->aux) {
+    hipStreamSynchronize(c->stream);
+    hipFree(c->aux);
+    c->aux = nullptr;
+    c->aux_bytes = 0;
+  }
+  if (hipMalloc(&c->aux, bytes) != hipSuccess) {
+    c->err = "hipMalloc(aux) failed";
+    return MFH_ENOMEM;
+  }
+  c->aux_bytes = bytes;
+  return MFH_OK;
+}
+
+extern "C" {
+
+int mfh_ssp_prepare(mfh_ctx *c, const uint32_t *d_ssp) {
+  if (!c || !d_ssp) return MFH_EINVAL;
+  return mfh_poly_prepare_t(c, d_ssp);  // slot 0 = t
+}
+
+int mfh_setup_messages(mfh_ctx *c, const uint32_t *d_ssp, uint32_t alpha, uint32_t beta, uint32_t s, uint32_t *d_msg) {
+  if (!c || !d_ssp || !d_msg) return MFH_EINVAL;
+  if (alpha >= P32 || beta >= P32 || s >= P32) { c->err = "alpha, beta, s must be < p"; return MFH_EINVAL; }
+  const uint32_t d = c->P.d, m = c->P.m;
+  if (d % 4) { c->err = "d must be a multiple of 4"; return MFH_EINVAL; }
+  HIP_TRY(c, hipSetDevice(c->device));
+  int rc = aux_reserve(c, (size_t)d * 4);
+  if (rc) return rc;
+  uint32_t *pw = (uint32_t *)c->aux;
+  hipLaunchKernelGGL(k_powers, g1(d), dim3(256), 0, c->stream, s, d, pw);
+  hipLaunchKernelGGL(k_msg_powers, g1(d), dim3(256), 0, c->stream, pw, d, alpha, d_msg);
+  hipLaunchKernelGGL(k_msg_evals, dim3(m), dim3(256), 0, c->stream, d_ssp, pw, d, beta, d_msg);
+  HIP_TRY(c, hipGetLastError());
+  return MFH_OK;
+}
+
+int mfh_setup(mfh_ctx *c, const uint32_t *d_ssp, uint32_t alpha, uint32_t beta, uint32_t s, const uint64_t *d_sk, const uint64_t *d_err,
+              uint8_t *d_crs_c8) {
+  if (!c || !d_ssp || !d_sk || !d_err || !d_crs_c8) return MFH_EINVAL;
+  const size_t rows = (size_t)2 * c->P.d + c->P.m;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (!c->d_msg || c->msg_rows < rows) {
+    if (c->d_msg) { hipStreamSynchronize(c->stream); hipFree(c->d_msg); c->d_msg = nullptr; }
+    HIP_TRY(c, hipMalloc(&c->d_msg, rows * 4));
+    c->msg_rows = rows;
+  }
+  int rc = mfh_setup_messages(c, d_ssp, alpha, beta, s, c->d_msg);
+  if (rc) return rc;
+  // all 2d+m encryptions are consecutive rows of the stream starting at CTR_S = 0 (src/snark.c:75-110)
+  return mfh_encrypt_rows(c, 0, rows, d_sk, c->d_msg, d_err, d_crs_c8);
+}
+
+int mfh_prove(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, const uint8_t *h_witness_bits, uint32_t delta,
+              const uint8_t *h_smudge_mag, size_t maglen, const uint8_t *h_smudge_sign, uint64_t *d_proof) {
+  if (!c || !d_crs_c8 || !d_ssp || !h_witness_bits || !h_smudge_mag || !h_smudge_sign || !d_proof) return MFH_EINVAL;
+  if (delta >= P32) { c->err = "delta must be < p"; return MFH_EINVAL; }
+  const uint32_t d = c->P.d, m = c->P.m, n = c->P.n;
+  const uint32_t L = (c->P.logq + 63) / 64, ctb = c->P.logq / 8;
+  const size_t ctl = (size_t)(n + 1) * L;
+  HIP_TRY(c, hipSetDevice(c->device));
+  // prover scratch: w, v, h (d each), cw (m)
+  if (!c->d_prover || c->prover_words < (size_t)3 * d + m) {
+    if (c->d_prover) { hipStreamSynchronize(c->stream); hipFree(c->d_prover); c->d_prover = nullptr; }
+    HIP_TRY(c, hipMalloc(&c->d_prover, ((size_t)3 * d + m) * 4));
+    c->prover_words = (size_t)3 * d + m;
+  }
+  uint32_t *w = c->d_prover, *v = w + d, *h = v + d, *cw = h + d;
+  uint64_t *pi_h = d_proof, *pi_hat_h = d_proof + ctl, *pi_hat_v = d_proof + 2 * ctl, *pi_v_w = d_proof + 3 * ctl, *pi_b_w = d_proof + 4 * ctl;
+
+  // w(x) = delta t + sum_{bit} v_i   (src/snark.c:141,147-155)
+  int rc = mfh_witness_poly(c, d_ssp, h_witness_bits, delta, w);
+  if (rc) return rc;
+  // b_w = delta * ct_t + sum_{bit} ct_{v_i}: rows BT, BV.. are m consecutive stream rows (src/snark.c:143-155)
+  c->h_cw.resize(m);
+  c->h_cw[0] = delta;
+  for (uint32_t i = 1; i < m; i++) c->h_cw[i] = (h_witness_bits[(i - 1) >> 3] >> ((i - 1) & 7)) & 1;
+  HIP_TRY(c, hipMemcpyAsync(cw, c->h_cw.data(), (size_t)m * 4, hipMemcpyHostToDevice, c->stream));
+  const uint64_t ctr_ct = (uint64_t)ctb * n;
+  rc = mfh_eval_rows(c, 2 * ctr_ct * d, m, d_crs_c8 + (size_t)2 * d * ctb, cw, nullptr, pi_b_w, nullptr, 0);
+  if (rc) return rc;
+  // v = w + v_0 ; h = (v^2 - 1) / t   (src/snark.c:161-169)
+  rc = mfh_poly_add(c, w, d_ssp + (size_t)d, d, v);
+  if (rc) return rc;
+  rc = mfh_poly_h(c, v, h);
+  if (rc) return rc;
+  // S rows: (w, h) -> (v_w, h);  AS rows: (v, h) -> (hat_v, hat_h)   (src/snark.c:157-158,163-164,171-174, each row expanded once)
+  rc = mfh_eval_rows(c, 0, d, d_crs_c8, w, h, pi_v_w, pi_h, 0);
+  if (rc) return rc;
+  rc = mfh_eval_rows(c, ctr_ct * d, d, d_crs_c8 + (size_t)d * ctb, v, h, pi_hat_v, pi_hat_h, 0);
+  if (rc) return rc;
+  // smudging: h, hat_h, hat_v, v_w, then v_w AGAIN; b_w is never smudged (src/snark.c:185-189)
+  rc = mfh_ct_smudge(c, d_proof, 4, h_smudge_mag, maglen, h_smudge_sign);
+  if (rc) return rc;
+  return mfh_ct_smudge(c, pi_v_w, 1, h_smudge_mag + 4 * maglen, maglen, h_smudge_sign + 4);
+}
+
+}  // extern "C"

@@ -109,6 +109,34 @@ int mfh_ssp_upload(mfh_ctx *ctx, const void *h_ssp_u64, uint32_t *d_ssp, size_t 
  * h_witness_bits: little-endian bit string, bit i-1 <-> v_i (mpz_tstbit).  d_w: d uint32. */
 int mfh_witness_poly(mfh_ctx *ctx, const uint32_t *d_ssp, const uint8_t *h_witness_bits, uint32_t delta, uint32_t *d_w);
 
+/* ---- L3/L4: polynomial step, setup, prover ------------------------------------------------------------ */
+/* c = a*b over F_p[x] (la+lb-1 canonical coefficients).  What nmod_poly_mul/pow compute (src/snark.c:167). */
+int mfh_poly_mul(mfh_ctx *ctx, const uint32_t *d_a, size_t la, const uint32_t *d_b, size_t lb, uint32_t *d_c);
+int mfh_poly_add(mfh_ctx *ctx, const uint32_t *d_a, const uint32_t *d_b, size_t count, uint32_t *d_out);
+/* Per-SSP precomputation for the quotient by t(x): power-series inverse of rev(t) (and its transform).
+ * d_t = d coefficients (slot 0 of the device SSP).  Fails (MFH_EINVAL) for t = 0, where nmod_poly_div raises. */
+int mfh_poly_prepare_t(mfh_ctx *ctx, const uint32_t *d_t);
+int mfh_ssp_prepare(mfh_ctx *ctx, const uint32_t *d_ssp); /* = mfh_poly_prepare_t(slot 0) */
+/* h = floor((v^2 - 1) / t), first d coefficients (nmod_poly_pow/sub/div, src/snark.c:166-169).  v: d coefficients. */
+int mfh_poly_h(mfh_ctx *ctx, const uint32_t *d_v, uint32_t *d_h);
+
+/* The 2d+m plaintexts setup() encrypts, in stream order: s^i | alpha s^i | beta t(s) | beta v_i(s), i=1..m-1
+ * (src/snark.c:73-110; the Horner values nmod_poly_evaluate_nmod are computed as dot products with the powers of s). */
+int mfh_setup_messages(mfh_ctx *ctx, const uint32_t *d_ssp, uint32_t alpha, uint32_t beta, uint32_t s, uint32_t *d_msg);
+/* setup() (src/snark.c:57-115) with caller-supplied secrets: d_sk = n values (key_gen, src/lwe.c:30-34),
+ * d_err = (2d+m) error values in encryption order (errdist_uniform, src/lwe.c:60-63).  The public seed is the one
+ * given to mfh_set_seed (crs->seed).  Output: the device CRS, (2d+m)*CT_BYTES bytes in stream order
+ * s[0..d) | as[0..d) | t | v[0..m-1)  (struct crs, src/snark.h:27-33, keeps them in four arrays). */
+int mfh_setup(mfh_ctx *ctx, const uint32_t *d_ssp, uint32_t alpha, uint32_t beta, uint32_t s, const uint64_t *d_sk,
+              const uint64_t *d_err, uint8_t *d_crs_c8);
+/* prover() (src/snark.c:117-190) with caller-supplied entropy: delta (< p; the reference draws 8 bytes % p) and the
+ * five smudging draws in call order h, hat_h, hat_v, v_w, v_w (sic: v_w twice, b_w never; src/snark.c:185-189):
+ * h_smudge_mag = 5*maglen bytes, h_smudge_sign = 5 bytes.  Needs mfh_set_seed(crs seed) and mfh_ssp_prepare.
+ * d_proof = 5 ciphertexts in struct order h | hat_h | hat_v | v_w | b_w (struct proof, src/snark.h:14-20).
+ * Every CRS row is expanded once: S rows feed v_w and h, AS rows feed hat_v and hat_h (the reference expands each twice). */
+int mfh_prove(mfh_ctx *ctx, const uint8_t *d_crs_c8, const uint32_t *d_ssp, const uint8_t *h_witness_bits, uint32_t delta,
+              const uint8_t *h_smudge_mag, size_t maglen, const uint8_t *h_smudge_sign, uint64_t *d_proof);
+
 /* ---- library info -------------------------------------------------------------------------------- */
 const char *mfh_version(void);
 /* size in bytes the context's scratch currently occupies on the device */

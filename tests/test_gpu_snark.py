@@ -1,0 +1,164 @@
+"""GPU parity for the SNARK layer: polynomial step, setup(), prover() against the oracle, bit-exact, at the
+reference's debug parameters (D=256, M=64: what src/test_snark.c runs) plus the properties that test pins."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+SEED = bytes((11 * i + 5) & 0xFF for i in range(40))
+
+
+@pytest.fixture(scope="module")
+def mf():
+    import c_lwe_snarks_amd as m
+
+    return m
+
+
+@pytest.fixture(scope="module")
+def ctx(gpu_ctx_factory, mf):
+    c = gpu_ctx_factory(mf.DEBUG)
+    c.set_seed(SEED)
+    return c
+
+
+def _u32(ctx, arr):
+    return ctx.to_device(np.ascontiguousarray(arr, dtype=np.uint32))
+
+
+# ------------------------------------------------------------------ polynomial arithmetic
+@pytest.mark.parametrize("la,lb", [(1, 1), (2, 3), (256, 256), (100, 511), (1000, 1)])
+def test_poly_mul(ctx, la, lb):
+    rng = np.random.default_rng(la * 1000 + lb)
+    a = rng.integers(0, ol.P, size=la, dtype=np.uint64)
+    b = rng.integers(0, ol.P, size=lb, dtype=np.uint64)
+    a[0] = ol.P - 1
+    b[-1] = ol.P - 1
+    got = ctx.to_host(ctx.poly_mul(_u32(ctx, a), la, _u32(ctx, b), lb), np.uint32)
+    exp = [0] * (la + lb - 1)
+    for i, x in enumerate(a.tolist()):
+        for j, y in enumerate(b.tolist()):
+            exp[i + j] = (exp[i + j] + x * y) % ol.P
+    assert got.tolist() == exp
+
+
+@pytest.mark.parametrize("case", ["dense", "low_deg_t", "small_v", "valid_ssp"])
+def test_poly_h_matches_oracle(ctx, oracle, mf, case):
+    p = mf.DEBUG
+    rng = np.random.default_rng(hash(case) & 0xFFFF)
+    v = rng.integers(0, ol.P, size=p.d, dtype=np.uint64)
+    t = rng.integers(0, ol.P, size=p.d, dtype=np.uint64)
+    if case == "low_deg_t":
+        t[p.d - 5:] = 0  # deg t = d-6: the quotient has more than d coefficients; the first d are kept
+    if case == "small_v":
+        v[10:] = 0  # deg(v^2-1) < deg t: quotient 0
+    if case == "valid_ssp":
+        bits = rng.integers(0, 256, size=(p.m + 7) // 8, dtype=np.uint8).tobytes()
+        tape = rng.integers(0, 256, size=p.m * 8 * p.d, dtype=np.uint8)
+        ssp = oracle.ssp_from_tape(p, tape, bits).reshape(p.m + 3, p.d)
+        t = ssp[0].copy()
+        v = ssp[1].copy()
+        for i in range(1, p.m):
+            if (bits[(i - 1) >> 3] >> ((i - 1) & 7)) & 1:
+                v = (v + ssp[i + 1]) % np.uint64(ol.P)
+        assert oracle.poly_divides(v, t)
+    ctx.poly_prepare_t(_u32(ctx, t))
+    got = ctx.to_host(ctx.poly_h(_u32(ctx, v)), np.uint32).astype(np.uint64)
+    assert np.array_equal(got, oracle.poly_h(v, t))
+
+
+def test_poly_prepare_rejects_zero_t(ctx, mf):
+    with pytest.raises(mf.MfhError):
+        ctx.poly_prepare_t(ctx.zeros(mf.DEBUG.d * 4))
+
+
+# ------------------------------------------------------------------ a full debug-size instance
+@pytest.fixture(scope="module")
+def instance(ctx, oracle, mf):
+    p = mf.DEBUG
+    rng = np.random.default_rng(2024)
+    bits = bytearray(rng.integers(0, 256, size=(p.m + 7) // 8, dtype=np.uint8).tobytes())
+    tape = rng.integers(0, 256, size=p.m * 8 * p.d, dtype=np.uint8)
+    ssp = oracle.ssp_from_tape(p, tape, bytes(bits))
+    alpha, beta, s = (int(x) for x in rng.integers(1, ol.P, size=3, dtype=np.uint64))
+    sk = ol.rand_values(rng, p.n, p.L, p.logq)
+    etape = ol.rand_values(rng, 2 * p.d + p.m, p.L, 559)
+    crs = oracle.setup(p, SEED, ssp, alpha, beta, s, sk, etape)
+    d_ssp = ctx.ssp_upload(ssp)
+    ctx.ssp_prepare(d_ssp)
+    return dict(p=p, bits=bytes(bits), ssp=ssp, alpha=alpha, beta=beta, s=s, sk=sk, etape=etape, crs=crs, d_ssp=d_ssp)
+
+
+def _crs_stream_order(p, crs):
+    return np.concatenate([crs["s"], crs["as_"], crs["t"], crs["v"][: (p.m - 1) * p.ctb]])
+
+
+def test_setup_messages(ctx, oracle, instance):
+    I = instance
+    p = I["p"]
+    got = ctx.to_host(ctx.setup_messages(I["d_ssp"], I["alpha"], I["beta"], I["s"]), np.uint32)
+    ssp = I["ssp"].reshape(p.m + 3, p.d)
+    exp = []
+    x = 1
+    for _ in range(p.d):
+        exp.append(x)
+        x = x * I["s"] % ol.P
+    exp += [e * I["alpha"] % ol.P for e in exp[: p.d]]
+    exp.append(oracle.poly_eval(ssp[0], I["s"]) * I["beta"] % ol.P)
+    exp += [oracle.poly_eval(ssp[i + 1], I["s"]) * I["beta"] % ol.P for i in range(1, p.m)]
+    assert got.tolist() == exp
+
+
+def test_setup_matches_oracle(ctx, instance):
+    I = instance
+    p = I["p"]
+    d_crs = ctx.setup(I["d_ssp"], I["alpha"], I["beta"], I["s"], ctx.to_device(I["sk"]), ctx.to_device(I["etape"]))
+    got = ctx.to_host(d_crs)
+    assert np.array_equal(got, _crs_stream_order(p, I["crs"]))
+    I["d_crs"] = d_crs
+
+
+def test_crs_structure_properties(ctx, instance):
+    # src/test_snark.c:35-70: dec(s[0]) = 1, dec(as[0]) = alpha, alpha*dec(s[i]) = dec(as[i]) for i = 1, D-1
+    I = instance
+    p = I["p"]
+    d_crs = I["d_crs"] if "d_crs" in I else ctx.to_device(_crs_stream_order(p, I["crs"]))
+    d_sk = ctx.to_device(I["sk"])
+
+    def dec_row(region_off, region_row0, i):
+        unit = np.zeros(1, dtype=np.uint32) + 1
+        ct, _ = ctx.eval_rows(region_off + i * p.ctr_ct, 1, d_crs[(region_row0 + i) * p.ctb:], ctx.to_device(unit))
+        return int(ctx.to_host(ctx.decrypt(d_sk, ct, 1), np.uint32)[0])
+
+    assert dec_row(p.ctr_s, 0, 0) == 1
+    assert dec_row(p.ctr_as, p.d, 0) == I["alpha"]
+    for i in (1, p.d - 1):
+        assert dec_row(p.ctr_s, 0, i) * I["alpha"] % ol.P == dec_row(p.ctr_as, p.d, i)
+
+
+def test_prover_matches_oracle_and_verifies(ctx, oracle, instance):
+    I = instance
+    p = I["p"]
+    rng = np.random.default_rng(7)
+    delta = int(rng.integers(0, ol.P, dtype=np.uint64))
+    mags = rng.integers(0, 256, size=5 * 80, dtype=np.uint8).tobytes()
+    signs = bytes([1, 0, 1, 0, 1])
+    tape = b"".join(mags[80 * k: 80 * k + 80] + signs[k: k + 1] for k in range(5))
+    ref = oracle.prover(p, I["crs"], I["ssp"], I["bits"], delta, tape, 80)
+    d_crs = ctx.to_device(_crs_stream_order(p, I["crs"]))
+    got = ctx.to_host(ctx.prove(d_crs, I["d_ssp"], I["bits"], delta, mags, signs), np.uint64).reshape(5, p.n + 1, p.L)
+    names = ["h", "hat_h", "hat_v", "v_w", "b_w"]
+    for k in range(5):
+        assert np.array_equal(got[k], ref["proof"][k]), f"proof element {names[k]} differs from the oracle"
+    # acceptance: the reference-semantics verifier (oracle) accepts the GPU proof (src/test_snark.c:105-107)
+    assert oracle.verifier(p, I["ssp"], I["alpha"], I["beta"], I["s"], I["sk"], got)
+    # src/test_snark.c:81-89: alpha*dec(h) == dec(hat_h), 0 < dec(h) < p  -- decrypted on the GPU
+    dec = ctx.to_host(ctx.decrypt(ctx.to_device(I["sk"]), ctx.to_device(got), 5), np.uint32)
+    assert 0 < int(dec[0]) < ol.P and int(dec[0]) * I["alpha"] % ol.P == int(dec[1])
+    # a wrong witness bit must be rejected
+    bad = bytearray(I["bits"])
+    bad[0] ^= 1
+    got_bad = ctx.to_host(ctx.prove(d_crs, I["d_ssp"], bytes(bad), delta, mags, signs), np.uint64).reshape(5, p.n + 1, p.L)
+    assert not oracle.verifier(p, I["ssp"], I["alpha"], I["beta"], I["s"], I["sk"], got_bad)
