@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""bench.py -- proofs/s of the reference's benchmark_snark prover (src/benchmark_snark.c:70-74) on MI355X.
+
+One "step" = one complete prover() call (src/snark.c:117-190) on the NDEBUG default SSP instance
+(D = 2^15 constraints, M = 21845 wires, N = 1470, log q = 736; src/lwe.h:14-31), starting from the COMPRESSED CRS
+exactly as the reference's prover does: all (2D+M) x 135 240 B of AES-256-CTR keystream are regenerated inside the
+timed region (fused into the multiply-accumulate kernel), the witness polynomial, h = (v^2-1)/t, the five
+homomorphic evaluations and the smudging are all inside it.  Inputs (CRS bytes, SSP, witness) are resident in HBM
+when the clock starts.  Nothing is cached between steps except per-circuit constants (the AES tables and the
+power-series inverse of rev(t), which depends on the SSP only, like the SSP itself).
+
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL).  The CRS rows of every region are sharded
+across the ranks, each proof is one cooperative step with ONE all-reduce of 1.3 MB of uint64 lanes:
+total work is fixed as N grows => "scaling": "strong".
+
+Prints ONE JSON line on rank 0 (driver contract), with "roofline" and "cpu_baseline" objects.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+ROW_BYTES = 1471 * 92  # algorithmic bytes of one expanded ciphertext row (keystream + b)
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def build_instance(mf, ctx, torch, p, seed_int):
+    """Synthetic, VALID default-size instance, deterministic in seed_int (identical on every rank)."""
+    dev = ctx.device
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed_int)
+    P = mf.P
+    # SSP: (m+3) x d uint32 coefficients in [0, p)
+    d_ssp = ctx.empty((p.m + 3) * p.d * 4)
+    ssp32 = d_ssp.view(torch.int32).view(p.m + 3, p.d)
+    step = 2048
+    for r0 in range(0, p.m + 3, step):
+        r1 = min(p.m + 3, r0 + step)
+        x = torch.randint(0, P, (r1 - r0, p.d), dtype=torch.int64, device=dev, generator=g)
+        ssp32[r0:r1] = x.to(torch.int32)  # keeps the low 32 bits
+    ssp32[p.m + 1:] = 0  # slots m+1, m+2 are unused padding in the reference layout (src/ssp.h:6)
+    rng = np.random.default_rng(seed_int)
+    bits = bytearray(rng.integers(0, 256, size=(p.m + 7) // 8, dtype=np.uint8).tobytes())
+    # t = v_0 + sum_{bit} v_i - 1  (random_ssp, src/ssp.c:59-71) so that t | v^2 - 1
+    ssp32[0] = 0
+    acc = ctx.witness_poly(d_ssp, bytes(bits), 0).view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+    v0 = ssp32[1].to(torch.int64) & 0xFFFFFFFF
+    t = (acc + v0) % P
+    t[0] = (t[0] + (P - 1)) % P  # minus the constant polynomial 1 (nmod_poly_sub(t, t, one), src/ssp.c:71)
+    ssp32[0] = t.to(torch.int32)
+    alpha, beta, s = (int(x) for x in rng.integers(1, P, size=3, dtype=np.uint64))
+    # secret key: n uniform 736-bit values; errors: 559-bit (src/lwe.c:30-34,60-63)
+    sk = torch.randint(-(2 ** 63), 2 ** 63 - 1, (p.n, p.L), dtype=torch.int64, device=dev, generator=g)
+    sk[:, p.L - 1] &= (1 << (p.logq - 64 * (p.L - 1))) - 1
+    rows = 2 * p.d + p.m
+    err = torch.randint(-(2 ** 63), 2 ** 63 - 1, (rows, p.L), dtype=torch.int64, device=dev, generator=g)
+    err[:, 8] &= (1 << (559 - 512)) - 1
+    err[:, 9:] = 0
+    return dict(d_ssp=d_ssp, bits=bytes(bits), alpha=alpha, beta=beta, s=s, sk=sk.view(torch.uint8).reshape(-1),
+                err=err.view(torch.uint8).reshape(-1), t_host=t.cpu().numpy(), v0_host=v0.cpu().numpy())
+
+
+def horner(coeffs, x, P):
+    r = 0
+    for c in reversed(coeffs.tolist()):
+        r = (r * x + c) % P
+    return r
+
+
+def verify_on_gpu(mf, ctx, inst, proof):
+    """verifier() (src/snark.c:192-250) with the five decryptions on the GPU; returns True iff it accepts."""
+    P = mf.P
+    dec = [int(x) for x in ctx.to_host(ctx.decrypt(inst["sk"], proof, 5), np.uint32)]
+    h_s, hath_s, hatv_s, w_s, b_s = dec
+    t_s = horner(inst["t_host"], inst["s"], P)
+    v_s = (horner(inst["v0_host"], inst["s"], P) + w_s) % P
+    ok = (h_s * inst["alpha"] % P == hath_s and v_s * inst["alpha"] % P == hatv_s and (v_s * v_s - 1 - h_s * t_s) % P == 0
+          and w_s * inst["beta"] % P == b_s)
+    return ok
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=20000, help="rows of the CPU baseline sample (~0.65 ms each on one core)")
+    args = ap.parse_args()
+
+    import torch
+
+    import c_lwe_snarks_amd as mf
+    from c_lwe_snarks_amd import dist as mfdist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+    if world != args.gpus and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+
+    p = mf.DEFAULT
+    ctx = mf.Context(p, local_rank)
+    seed = bytes((37 * i + 11) & 0xFF for i in range(40))
+    ctx.set_seed(seed)
+    inst = build_instance(mf, ctx, torch, p, 20260101)
+    ctx.ssp_prepare(inst["d_ssp"])  # per-circuit constant: rev(t)^-1 (depends on the SSP only)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- setup(): 2D+M encryptions -> compressed CRS (also the "LWE encryptions/s" figure at scale)
+    rows_crs = 2 * p.d + p.m
+    d_crs = ctx.setup(inst["d_ssp"], inst["alpha"], inst["beta"], inst["s"], inst["sk"], inst["err"])
+    barrier()
+    t0 = time.perf_counter()
+    ctx.setup(inst["d_ssp"], inst["alpha"], inst["beta"], inst["s"], inst["sk"], inst["err"], out=d_crs)
+    torch.cuda.synchronize()
+    setup_s = time.perf_counter() - t0
+
+    rng = np.random.default_rng(99)
+    delta = int(rng.integers(0, mf.P, dtype=np.uint64))
+    mags = rng.integers(0, 256, size=5 * 80, dtype=np.uint8).tobytes()
+    signs = bytes(rng.integers(0, 2, size=5, dtype=np.uint8).tolist())
+    bufs = {}
+
+    def step():
+        return mfdist.prove_sharded(ctx, d_crs, inst["d_ssp"], inst["bits"], delta, mags, signs, rank, world, bufs=bufs)
+
+    for _ in range(args.warmup):
+        proof = step()
+    ctx.set_timing(True)
+    ctx.timing_drain("eval")
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        proof = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ctx.set_timing(False)
+    n2, ms2, rows2 = ctx.timing_drain("eval2")
+    n1, ms1, rows1 = ctx.timing_drain("eval1")
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=ctx.device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    accepted = verify_on_gpu(mf, ctx, inst, proof) if rank == 0 else True
+
+    # ---- LWE batch (BASELINE config 1/2: one batch of 65 536 encryptions, rows at stream offset k*135240)
+    enc_per_s = None
+    if rank == 0:
+        B = 65536
+        msg = ctx.to_device(np.random.default_rng(5).integers(0, mf.P, size=B, dtype=np.uint64).astype(np.uint32))
+        errB = inst["err"][: B * p.L * 8]
+        outB = ctx.empty(B * p.ctb)
+        ctx.encrypt_rows(0, B, inst["sk"], msg, errB, out=outB)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        ctx.encrypt_rows(0, B, inst["sk"], msg, errB, out=outB)
+        torch.cuda.synchronize()
+        enc_per_s = B / (time.perf_counter() - t1)
+
+    # ---- CPU baseline: the oracle's reference-faithful row touch (ct_import + ct_addmul_ui), one thread
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle_lib as ol
+
+        o = ol.Oracle()
+        o.bench_eval_rows(p, seed, 200)  # warm tables
+        c0 = time.perf_counter()
+        o.bench_eval_rows(p, seed, args.cpu_rows)
+        cpu_s = time.perf_counter() - c0
+        rows_per_s = args.cpu_rows / cpu_s
+        ref_rows = 4 * p.d + p.m  # row touches of the reference prover: (M-1)+1 + 4D (src/snark.c:143-174)
+        cpu = {"value": rows_per_s / ref_rows, "unit": "proofs/s", "cores": 1, "kind": "port",
+               "sample": f"{args.cpu_rows} prover row-touches (ct_import + ct_addmul_ui, one AES block per call) of the oracle in {cpu_s:.1f} s "
+                         f"= {rows_per_s:.0f} rows/s, scaled to the reference prover's {ref_rows} row-touches; h=(v^2-1)/t excluded",
+               "rows_per_s": rows_per_s}
+
+    if rank == 0:
+        ms_step = elapsed / args.steps * 1e3
+        launch_rows = rows2 / max(n2, 1)
+        avg_ms = ms2 / max(n2, 1)
+        achieved = launch_rows * ROW_BYTES / (avg_ms * 1e-3) / 1e9 if n2 else None
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "traffic_eval2.json")
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "snark_proofs_per_sec",
+            "value": args.steps / elapsed,
+            "unit": "proofs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "u32 limbs (704-bit integers mod 2^704) + AES-256 bytes",
+            "data": "synthetic (valid random SSP, random witness, seeded secrets)",
+            "config": {"workload": "benchmark_snark default SSP instance (NDEBUG): D=32768, M=21845, N=1470, logq=736; full prover() "
+                                   "from the compressed CRS, keystream regenerated in the timed region",
+                       "rows_per_proof": rows_crs, "sharding": f"CRS rows over {world} rank(s), 1 all-reduce/proof" if world > 1 else "single GPU"},
+            "proof_accepted": bool(accepted),
+            "lwe_enc_per_s": enc_per_s,
+            "setup_s": setup_s,
+            "setup_enc_per_s": rows_crs / setup_s,
+            "roofline": {"bound": "hbm", "kernel": "k_eval<736,2> (fused AES-256-CTR expansion + 2x MAC, S and AS regions)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+                         "traffic": traffic, "launches": n2, "avg_launch_ms": avg_ms, "rows_per_launch": launch_rows,
+                         "bytes_per_row": ROW_BYTES,
+                         "note": "algorithmic bytes = expanded row bytes; the kernel regenerates them with AES on the CU (LDS T-tables), "
+                                 "it is LDS-lookup/VALU bound and moves ~0 HBM bytes: see DESIGN.md",
+                         "aes_gblocks_per_s": (launch_rows * 8452.5 / (avg_ms * 1e-3) / 1e9) if n2 else None},
+            "eval1": {"launches": n1, "avg_launch_ms": ms1 / max(n1, 1), "rows_per_launch": rows1 / max(n1, 1)},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if accepted else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -86,6 +86,7 @@ EXPORTS = [
     "mfh_encrypt_rows", "mfh_decrypt", "mfh_ct_smudge", "mfh_ssp_upload", "mfh_witness_poly", "mfh_version",
     "mfh_workspace_bytes", "mfh_last_kernel_ms", "mfh_set_timing", "mfh_poly_mul", "mfh_poly_add", "mfh_poly_prepare_t",
     "mfh_ssp_prepare", "mfh_poly_h", "mfh_setup_messages", "mfh_setup", "mfh_prove",
+    "mfh_prove_partial", "mfh_prove_finish", "mfh_ct_to_lanes", "mfh_ct_from_lanes", "mfh_timing_drain",
 ]
 
 
@@ -129,6 +130,12 @@ def load_library():
         "mfh_setup_messages": (i32, [vp, vp, u32, u32, u32, vp]),
         "mfh_setup": (i32, [vp, vp, u32, u32, u32, vp, vp, vp]),
         "mfh_prove": (i32, [vp, vp, vp, ctypes.c_char_p, u32, ctypes.c_char_p, sz, ctypes.c_char_p, vp]),
+        "mfh_prove_partial": (i32, [vp, vp, vp, ctypes.c_char_p, u32, u32, u32, vp]),
+        "mfh_prove_finish": (i32, [vp, vp, ctypes.c_char_p, sz, ctypes.c_char_p]),
+        "mfh_ct_to_lanes": (i32, [vp, vp, sz, vp]),
+        "mfh_ct_from_lanes": (i32, [vp, vp, sz, vp]),
+        "mfh_timing_drain": (i32, [vp, ctypes.c_char_p, ctypes.POINTER(u64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(u64),
+                                   ctypes.POINTER(ctypes.c_float)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export what the header declares
@@ -197,6 +204,12 @@ class Context:
 
     def set_timing(self, on=True):
         self._chk(self.lib.mfh_set_timing(self._h, 1 if on else 0))
+
+    def timing_drain(self, which):
+        """(launch count, total ms, total rows) of the launches of kind `which` since the last drain"""
+        n, rows, ms, last = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_double(), ctypes.c_float()
+        self._chk(self.lib.mfh_timing_drain(self._h, which.encode(), ctypes.byref(n), ctypes.byref(ms), ctypes.byref(rows), ctypes.byref(last)))
+        return n.value, ms.value, rows.value
 
     def last_kernel_ms(self, which):
         return float(self.lib.mfh_last_kernel_ms(self._h, which.encode()))
@@ -313,4 +326,27 @@ class Context:
         assert len(smudge_mag) == 5 * maglen and len(smudge_sign) == 5
         self._chk(self.lib.mfh_prove(self._h, _ptr(d_crs), _ptr(d_ssp), bytes(witness_bits), delta, bytes(smudge_mag), maglen,
                                      bytes(smudge_sign), _ptr(out)))
+        return out
+
+    # -- row-sharded prover (one process per GPU; see dist.py) ------------------------------------------------
+    def prove_partial(self, d_crs, d_ssp, witness_bits: bytes, delta, rank, world, out=None):
+        p = self.params
+        out = self.empty(5 * p.ct_limbs * 8) if out is None else out
+        self._chk(self.lib.mfh_prove_partial(self._h, _ptr(d_crs), _ptr(d_ssp), bytes(witness_bits), delta, rank, world, _ptr(out)))
+        return out
+
+    def prove_finish(self, d_proof, smudge_mag: bytes, smudge_sign: bytes, maglen=80):
+        self._chk(self.lib.mfh_prove_finish(self._h, _ptr(d_proof), bytes(smudge_mag), maglen, bytes(smudge_sign)))
+        return d_proof
+
+    def ct_to_lanes(self, d_cts, count, out=None):
+        p = self.params
+        out = self.torch.empty(count * (p.n + 1) * 2 * p.K, dtype=self.torch.int64, device=self.device) if out is None else out
+        self._chk(self.lib.mfh_ct_to_lanes(self._h, _ptr(d_cts), count, _ptr(out)))
+        return out
+
+    def ct_from_lanes(self, d_lanes, count, out=None):
+        p = self.params
+        out = self.empty(count * p.ct_limbs * 8) if out is None else out
+        self._chk(self.lib.mfh_ct_from_lanes(self._h, _ptr(d_lanes), count, _ptr(out)))
         return out

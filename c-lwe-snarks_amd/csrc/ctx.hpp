@@ -32,9 +32,15 @@ struct mfh_ctx {
   void *ws = nullptr;        // scratch (partials etc.)
   size_t ws_bytes = 0;
   std::string err;
+  // kernel timing (bench.py's roofline leg): HIP events recorded on the launch stream, resolved lazily
   bool timing = false;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  float ms_eval = -1.f, ms_encrypt = -1.f, ms_keystream = -1.f;
+  struct Timed {
+    hipEvent_t e0, e1;
+    int kind;        // 0 keystream, 1 eval (1 coeff vector), 2 eval (2 vectors), 3 encrypt
+    uint64_t rows;   // rows handed to the launch
+  };
+  std::vector<Timed> timed;
+  std::vector<hipEvent_t> ev_pool;
   PolyState *poly = nullptr;  // NTT tables and per-SSP precomputation (poly.hip)
   void *aux = nullptr;        // small scratch that must survive an eval/encrypt launch (snark.hip)
   size_t aux_bytes = 0;
@@ -43,6 +49,28 @@ struct mfh_ctx {
   uint32_t *d_prover = nullptr;  // prover polynomials w, v, h and the b_w coefficient vector
   size_t prover_words = 0;
   std::vector<uint32_t> h_cw;
+};
+
+struct Timer {  // brackets one launch with events when timing is on; never synchronises
+  mfh_ctx *c;
+  mfh_ctx::Timed t{};
+  bool on;
+  Timer(mfh_ctx *c_, int kind, uint64_t rows) : c(c_), on(c_->timing) {
+    if (!on) return;
+    auto get = [&]() {
+      hipEvent_t e;
+      if (!c->ev_pool.empty()) { e = c->ev_pool.back(); c->ev_pool.pop_back(); }
+      else hipEventCreate(&e);
+      return e;
+    };
+    t.e0 = get(); t.e1 = get(); t.kind = kind; t.rows = rows;
+    hipEventRecord(t.e0, c->stream);
+  }
+  ~Timer() {
+    if (!on) return;
+    hipEventRecord(t.e1, c->stream);
+    c->timed.push_back(t);
+  }
 };
 
 void mfh_poly_destroy(mfh_ctx *c);

@@ -183,7 +183,7 @@ __global__ __launch_bounds__(PS<LOGQ>::THREADS) void k_eval(AesKey key, const ui
     if (have) {
       row = idx[k];
       c[0] = coeff0[row];
-      if (NACC > 1) c[1] = coeff1[row];
+      if constexpr (NACC > 1) c[1] = coeff1[row];
       head = expand_tile_to_lds<LOGQ>(tab, L, key, ks, off + (uint64_t)row * n * S::CTB, j0, nelem, t);
     }
     __syncthreads();
@@ -499,21 +499,6 @@ __global__ void k_witness_finish(const uint32_t *__restrict__ ssp, const uint64_
 // ------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------
-struct Timer {
-  mfh_ctx *c;
-  float *dst;
-  Timer(mfh_ctx *c_, float *d) : c(c_), dst(d) {
-    if (c->timing) hipEventRecord(c->ev0, c->stream);
-  }
-  ~Timer() {
-    if (c->timing) {
-      hipEventRecord(c->ev1, c->stream);
-      hipEventSynchronize(c->ev1);
-      hipEventElapsedTime(dst, c->ev0, c->ev1);
-    }
-  }
-};
-
 extern "C" {
 
 const char *mfh_version(void) { return "mfhip 0.1 (gfx950)"; }
@@ -536,8 +521,7 @@ int mfh_ctx_create(mfh_ctx **out, int device, const mfh_params *P) {
   c->stream = c->own_stream;
   uint32_t t0[256];
   mf::make_t0_le(t0);
-  if (hipMalloc(&c->d_t0, sizeof t0) != hipSuccess || hipMemcpy(c->d_t0, t0, sizeof t0, hipMemcpyHostToDevice) != hipSuccess ||
-      hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+  if (hipMalloc(&c->d_t0, sizeof t0) != hipSuccess || hipMemcpy(c->d_t0, t0, sizeof t0, hipMemcpyHostToDevice) != hipSuccess) {
     mfh_ctx_destroy(c);
     return MFH_EDEVICE;
   }
@@ -555,8 +539,8 @@ void mfh_ctx_destroy(mfh_ctx *c) {
   if (c->d_msg) hipFree(c->d_msg);
   if (c->d_prover) hipFree(c->d_prover);
   if (c->d_t0) hipFree(c->d_t0);
-  if (c->ev0) hipEventDestroy(c->ev0);
-  if (c->ev1) hipEventDestroy(c->ev1);
+  for (auto &t : c->timed) { hipEventDestroy(t.e0); hipEventDestroy(t.e1); }
+  for (auto e : c->ev_pool) hipEventDestroy(e);
   if (c->own_stream) hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -580,12 +564,44 @@ int mfh_set_timing(mfh_ctx *c, int en) {
   c->timing = en != 0;
   return MFH_OK;
 }
+static int timing_kind(const char *which) {
+  if (!strcmp(which, "keystream")) return 0;
+  if (!strcmp(which, "eval1")) return 1;
+  if (!strcmp(which, "eval2")) return 2;
+  if (!strcmp(which, "encrypt")) return 3;
+  if (!strcmp(which, "eval")) return 12;  // either eval flavour
+  return -1;
+}
+
+int mfh_timing_drain(mfh_ctx *c, const char *which, uint64_t *count, double *total_ms, uint64_t *total_rows, float *last_ms) {
+  if (!c || !which) return MFH_EINVAL;
+  const int kind = timing_kind(which);
+  if (kind < 0) return MFH_EINVAL;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  uint64_t n = 0, rows = 0;
+  double tot = 0;
+  float last = -1.f;
+  std::vector<mfh_ctx::Timed> keep;
+  for (auto &t : c->timed) {
+    const bool match = t.kind == kind || (kind == 12 && (t.kind == 1 || t.kind == 2));
+    if (!match) { keep.push_back(t); continue; }
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, t.e0, t.e1) == hipSuccess) { n++; tot += ms; rows += t.rows; last = ms; }
+    c->ev_pool.push_back(t.e0);
+    c->ev_pool.push_back(t.e1);
+  }
+  c->timed.swap(keep);
+  if (count) *count = n;
+  if (total_ms) *total_ms = tot;
+  if (total_rows) *total_rows = rows;
+  if (last_ms) *last_ms = last;
+  return MFH_OK;
+}
+
 float mfh_last_kernel_ms(mfh_ctx *c, const char *which) {
-  if (!c || !which) return -1.f;
-  if (!strcmp(which, "eval")) return c->ms_eval;
-  if (!strcmp(which, "encrypt")) return c->ms_encrypt;
-  if (!strcmp(which, "keystream")) return c->ms_keystream;
-  return -1.f;
+  float last = -1.f;
+  if (mfh_timing_drain(c, which, nullptr, nullptr, nullptr, &last) != MFH_OK) return -1.f;
+  return last;
 }
 
 int mfh_set_seed(mfh_ctx *c, const uint8_t seed[40]) {
@@ -620,7 +636,7 @@ int mfh_keystream(mfh_ctx *c, uint64_t off, void *d_out, size_t nbytes) {
   uint64_t nblk = ((off & 15) + nbytes + 15) >> 4;
   uint32_t grid = (uint32_t)std::min<uint64_t>((nblk + 1023) / 1024, 256 * 2);
   {
-    Timer t(c, &c->ms_keystream);
+    Timer t(c, 0, nblk);
     hipLaunchKernelGGL(k_keystream, dim3(grid), dim3(1024), 0, c->stream, c->key, c->d_t0, off, (uint8_t *)d_out, (uint64_t)nbytes);
   }
   HIP_TRY(c, hipGetLastError());
@@ -707,7 +723,7 @@ static int eval_rows(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *c8, 
   hipLaunchKernelGGL(k_compact_rows, dim3(1), dim3(1024), 0, c->stream, c0, c1, (uint32_t)nrows, idx, cnt);
   HIP_TRY(c, hipGetLastError());
   {
-    Timer t(c, &c->ms_eval);
+    Timer t(c, nacc, nrows);
     if (nacc == 2)
       hipLaunchKernelGGL((k_eval<LOGQ, 2>), dim3(ntiles, nchunks), dim3(S::THREADS), 0, c->stream, c->key, c->d_t0, off, n, idx, cnt, c8, c0, c1,
                          part);
@@ -758,7 +774,7 @@ static int encrypt_rows(mfh_ctx *c, uint64_t off, size_t nrows, const uint64_t *
   if (rc) return rc;
   uint32_t *pb = (uint32_t *)c->ws;
   {
-    Timer t(c, &c->ms_encrypt);
+    Timer t(c, 3, nrows);
     hipLaunchKernelGGL(k_encrypt<LOGQ>, dim3(ntiles, gy), dim3(S::THREADS), 0, c->stream, c->key, c->d_t0, off, n, (uint32_t)nrows, rpc, sk, pb);
   }
   HIP_TRY(c, hipGetLastError());

@@ -65,6 +65,30 @@ __global__ __launch_bounds__(256) void k_msg_evals(const uint32_t *__restrict__ 
   if (threadIdx.x == 0) msg[2 * d + r] = mulmod(red_p32(red[0] + red[1] + red[2] + red[3]), beta);
 }
 
+// ciphertext values (KW significant 32-bit words each) <-> one uint64 "lane" per 32-bit word.  Lanes of several
+// partial ciphertexts can be added word-wise (RCCL sum on uint64, 2^32 ranks of headroom) and the carries propagated
+// once afterwards: sums mod 2^(32 KW) do not depend on the order.
+__global__ void k_ct_to_lanes(const uint64_t *__restrict__ cts, uint64_t nvalues, uint32_t L, uint32_t KW, uint64_t *__restrict__ lanes) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nvalues * KW) return;
+  const uint64_t v = i / KW;
+  const uint32_t w = (uint32_t)(i % KW);
+  lanes[i] = reinterpret_cast<const uint32_t *>(cts + v * L)[w];
+}
+__global__ void k_ct_from_lanes(const uint64_t *__restrict__ lanes, uint64_t nvalues, uint32_t L, uint32_t KW, uint64_t *__restrict__ cts) {
+  uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= nvalues) return;
+  uint32_t *o = reinterpret_cast<uint32_t *>(cts + v * L);
+  uint64_t carry = 0;
+  for (uint32_t w = 0; w < KW; w++) {
+    const uint64_t x = lanes[v * KW + w];
+    const uint64_t lo = (x & 0xffffffffu) + (carry & 0xffffffffu);
+    o[w] = (uint32_t)lo;
+    carry = (x >> 32) + (carry >> 32) + (lo >> 32);
+  }
+  for (uint32_t w = KW; w < 2 * L; w++) o[w] = 0;  // modq
+}
+
 inline dim3 g1(uint32_t n) { return dim3((n + 255) / 256); }
 
 }  // namespace
@@ -124,9 +148,29 @@ int mfh_setup(mfh_ctx *c, const uint32_t *d_ssp, uint32_t alpha, uint32_t beta, 
   return mfh_encrypt_rows(c, 0, rows, d_sk, c->d_msg, d_err, d_crs_c8);
 }
 
-int mfh_prove(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, const uint8_t *h_witness_bits, uint32_t delta,
-              const uint8_t *h_smudge_mag, size_t maglen, const uint8_t *h_smudge_sign, uint64_t *d_proof) {
-  if (!c || !d_crs_c8 || !d_ssp || !h_witness_bits || !h_smudge_mag || !h_smudge_sign || !d_proof) return MFH_EINVAL;
+int mfh_ct_to_lanes(mfh_ctx *c, const uint64_t *d_cts, size_t count, uint64_t *d_lanes) {
+  if (!c || !d_cts || !d_lanes) return MFH_EINVAL;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint32_t L = (c->P.logq + 63) / 64, KW = 2 * (c->P.logq / 64);
+  const uint64_t nvalues = (uint64_t)count * (c->P.n + 1);
+  hipLaunchKernelGGL(k_ct_to_lanes, dim3((uint32_t)((nvalues * KW + 255) / 256)), dim3(256), 0, c->stream, d_cts, nvalues, L, KW, d_lanes);
+  HIP_TRY(c, hipGetLastError());
+  return MFH_OK;
+}
+
+int mfh_ct_from_lanes(mfh_ctx *c, const uint64_t *d_lanes, size_t count, uint64_t *d_cts) {
+  if (!c || !d_cts || !d_lanes) return MFH_EINVAL;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint32_t L = (c->P.logq + 63) / 64, KW = 2 * (c->P.logq / 64);
+  const uint64_t nvalues = (uint64_t)count * (c->P.n + 1);
+  hipLaunchKernelGGL(k_ct_from_lanes, dim3((uint32_t)((nvalues + 255) / 256)), dim3(256), 0, c->stream, d_lanes, nvalues, L, KW, d_cts);
+  HIP_TRY(c, hipGetLastError());
+  return MFH_OK;
+}
+
+int mfh_prove_partial(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, const uint8_t *h_witness_bits, uint32_t delta,
+                      uint32_t rank, uint32_t world, uint64_t *d_partial) {
+  if (!c || !d_crs_c8 || !d_ssp || !h_witness_bits || !d_partial || world == 0 || rank >= world) return MFH_EINVAL;
   if (delta >= P32) { c->err = "delta must be < p"; return MFH_EINVAL; }
   const uint32_t d = c->P.d, m = c->P.m, n = c->P.n;
   const uint32_t L = (c->P.logq + 63) / 64, ctb = c->P.logq / 8;
@@ -139,9 +183,15 @@ int mfh_prove(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, const 
     c->prover_words = (size_t)3 * d + m;
   }
   uint32_t *w = c->d_prover, *v = w + d, *h = v + d, *cw = h + d;
-  uint64_t *pi_h = d_proof, *pi_hat_h = d_proof + ctl, *pi_hat_v = d_proof + 2 * ctl, *pi_v_w = d_proof + 3 * ctl, *pi_b_w = d_proof + 4 * ctl;
+  uint64_t *pi_h = d_partial, *pi_hat_h = d_partial + ctl, *pi_hat_v = d_partial + 2 * ctl, *pi_v_w = d_partial + 3 * ctl,
+           *pi_b_w = d_partial + 4 * ctl;
+  // this rank's contiguous share of each region's rows
+  auto share = [&](uint32_t rows, uint32_t &lo, uint32_t &cnt) {
+    lo = (uint32_t)((uint64_t)rows * rank / world);
+    cnt = (uint32_t)((uint64_t)rows * (rank + 1) / world) - lo;
+  };
 
-  // w(x) = delta t + sum_{bit} v_i   (src/snark.c:141,147-155)
+  // w(x) = delta t + sum_{bit} v_i   (src/snark.c:141,147-155); every rank needs all of w for the polynomial step
   int rc = mfh_witness_poly(c, d_ssp, h_witness_bits, delta, w);
   if (rc) return rc;
   // b_w = delta * ct_t + sum_{bit} ct_{v_i}: rows BT, BV.. are m consecutive stream rows (src/snark.c:143-155)
@@ -150,7 +200,9 @@ int mfh_prove(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, const 
   for (uint32_t i = 1; i < m; i++) c->h_cw[i] = (h_witness_bits[(i - 1) >> 3] >> ((i - 1) & 7)) & 1;
   HIP_TRY(c, hipMemcpyAsync(cw, c->h_cw.data(), (size_t)m * 4, hipMemcpyHostToDevice, c->stream));
   const uint64_t ctr_ct = (uint64_t)ctb * n;
-  rc = mfh_eval_rows(c, 2 * ctr_ct * d, m, d_crs_c8 + (size_t)2 * d * ctb, cw, nullptr, pi_b_w, nullptr, 0);
+  uint32_t lo, cnt;
+  share(m, lo, cnt);
+  rc = mfh_eval_rows(c, 2 * ctr_ct * d + ctr_ct * lo, cnt, d_crs_c8 + ((size_t)2 * d + lo) * ctb, cw + lo, nullptr, pi_b_w, nullptr, 0);
   if (rc) return rc;
   // v = w + v_0 ; h = (v^2 - 1) / t   (src/snark.c:161-169)
   rc = mfh_poly_add(c, w, d_ssp + (size_t)d, d, v);
@@ -158,14 +210,27 @@ int mfh_prove(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, const 
   rc = mfh_poly_h(c, v, h);
   if (rc) return rc;
   // S rows: (w, h) -> (v_w, h);  AS rows: (v, h) -> (hat_v, hat_h)   (src/snark.c:157-158,163-164,171-174, each row expanded once)
-  rc = mfh_eval_rows(c, 0, d, d_crs_c8, w, h, pi_v_w, pi_h, 0);
+  share(d, lo, cnt);
+  rc = mfh_eval_rows(c, ctr_ct * lo, cnt, d_crs_c8 + (size_t)lo * ctb, w + lo, h + lo, pi_v_w, pi_h, 0);
   if (rc) return rc;
-  rc = mfh_eval_rows(c, ctr_ct * d, d, d_crs_c8 + (size_t)d * ctb, v, h, pi_hat_v, pi_hat_h, 0);
-  if (rc) return rc;
+  return mfh_eval_rows(c, ctr_ct * ((uint64_t)d + lo), cnt, d_crs_c8 + ((size_t)d + lo) * ctb, v + lo, h + lo, pi_hat_v, pi_hat_h, 0);
+}
+
+int mfh_prove_finish(mfh_ctx *c, uint64_t *d_proof, const uint8_t *h_smudge_mag, size_t maglen, const uint8_t *h_smudge_sign) {
+  if (!c || !d_proof || !h_smudge_mag || !h_smudge_sign) return MFH_EINVAL;
+  const size_t ctl = (size_t)(c->P.n + 1) * ((c->P.logq + 63) / 64);
   // smudging: h, hat_h, hat_v, v_w, then v_w AGAIN; b_w is never smudged (src/snark.c:185-189)
-  rc = mfh_ct_smudge(c, d_proof, 4, h_smudge_mag, maglen, h_smudge_sign);
+  int rc = mfh_ct_smudge(c, d_proof, 4, h_smudge_mag, maglen, h_smudge_sign);
   if (rc) return rc;
-  return mfh_ct_smudge(c, pi_v_w, 1, h_smudge_mag + 4 * maglen, maglen, h_smudge_sign + 4);
+  return mfh_ct_smudge(c, d_proof + 3 * ctl, 1, h_smudge_mag + 4 * maglen, maglen, h_smudge_sign + 4);
+}
+
+int mfh_prove(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, const uint8_t *h_witness_bits, uint32_t delta,
+              const uint8_t *h_smudge_mag, size_t maglen, const uint8_t *h_smudge_sign, uint64_t *d_proof) {
+  if (!h_smudge_mag || !h_smudge_sign) return MFH_EINVAL;
+  int rc = mfh_prove_partial(c, d_crs_c8, d_ssp, h_witness_bits, delta, 0, 1, d_proof);
+  if (rc) return rc;
+  return mfh_prove_finish(c, d_proof, h_smudge_mag, maglen, h_smudge_sign);
 }
 
 }  // extern "C"

@@ -137,14 +137,29 @@ int mfh_setup(mfh_ctx *ctx, const uint32_t *d_ssp, uint32_t alpha, uint32_t beta
 int mfh_prove(mfh_ctx *ctx, const uint8_t *d_crs_c8, const uint32_t *d_ssp, const uint8_t *h_witness_bits, uint32_t delta,
               const uint8_t *h_smudge_mag, size_t maglen, const uint8_t *h_smudge_sign, uint64_t *d_proof);
 
+/* ---- multi-GPU: row-sharded prover -------------------------------------------------------------
+ * Every proof element is sum_i coeff_i * row_i and the public stream is seekable, so the CRS rows of each region are
+ * split into `world` contiguous shares.  mfh_prove_partial computes rank `rank`'s share of the five (un-smudged)
+ * ciphertexts; the shares are summed with ONE all-reduce of uint64 lanes (mfh_ct_to_lanes -> RCCL sum ->
+ * mfh_ct_from_lanes propagates the carries and applies modq), then mfh_prove_finish smudges.  world = 1 is mfh_prove. */
+int mfh_prove_partial(mfh_ctx *ctx, const uint8_t *d_crs_c8, const uint32_t *d_ssp, const uint8_t *h_witness_bits, uint32_t delta,
+                      uint32_t rank, uint32_t world, uint64_t *d_partial);
+int mfh_prove_finish(mfh_ctx *ctx, uint64_t *d_proof, const uint8_t *h_smudge_mag, size_t maglen, const uint8_t *h_smudge_sign);
+/* count ciphertexts <-> count*(n+1)*2K uint64 lanes (one per surviving 32-bit word) */
+int mfh_ct_to_lanes(mfh_ctx *ctx, const uint64_t *d_cts, size_t count, uint64_t *d_lanes);
+int mfh_ct_from_lanes(mfh_ctx *ctx, const uint64_t *d_lanes, size_t count, uint64_t *d_cts);
+
 /* ---- library info -------------------------------------------------------------------------------- */
 const char *mfh_version(void);
 /* size in bytes the context's scratch currently occupies on the device */
 size_t mfh_workspace_bytes(const mfh_ctx *ctx);
-/* duration in ms of the most recent launch of the named hot kernel ("eval", "encrypt", "keystream"),
- * measured with HIP events on the context's stream (bench.py's roofline leg); < 0 if none */
-float mfh_last_kernel_ms(mfh_ctx *ctx, const char *which);
+/* Kernel timing for the roofline leg of bench.py.  With timing enabled every launch of a hot kernel is bracketed by
+ * HIP events on the context's stream (no synchronisation is added).  mfh_timing_drain waits for the stream, then
+ * reports and forgets the launches of kind `which`: "eval2" / "eval1" (k_eval with 2 / 1 coefficient vectors),
+ * "eval" (both), "encrypt", "keystream".  total_rows = rows handed to those launches (AES blocks for "keystream"). */
 int mfh_set_timing(mfh_ctx *ctx, int enabled);
+int mfh_timing_drain(mfh_ctx *ctx, const char *which, uint64_t *count, double *total_ms, uint64_t *total_rows, float *last_ms);
+float mfh_last_kernel_ms(mfh_ctx *ctx, const char *which); /* = last_ms of mfh_timing_drain; < 0 if none */
 
 #ifdef __cplusplus
 }

@@ -162,3 +162,36 @@ def test_prover_matches_oracle_and_verifies(ctx, oracle, instance):
     bad[0] ^= 1
     got_bad = ctx.to_host(ctx.prove(d_crs, I["d_ssp"], bytes(bad), delta, mags, signs), np.uint64).reshape(5, p.n + 1, p.L)
     assert not oracle.verifier(p, I["ssp"], I["alpha"], I["beta"], I["s"], I["sk"], got_bad)
+
+
+def test_sharded_prover_equals_single(ctx, oracle, instance, mf):
+    """partial proofs over row shares, summed as uint64 lanes, equal the single-GPU proof bit for bit.
+    (world = 3 emulated on one GPU: the all-reduce is a plain tensor sum here; tests/test_dist_cpu.py runs the real
+    collective with gloo.)"""
+    from c_lwe_snarks_amd import dist as mfdist
+
+    I = instance
+    p = I["p"]
+    rng = np.random.default_rng(8)
+    delta = int(rng.integers(0, ol.P, dtype=np.uint64))
+    mags = rng.integers(0, 256, size=5 * 80, dtype=np.uint8).tobytes()
+    signs = bytes([0, 1, 1, 0, 0])
+    d_crs = ctx.to_device(_crs_stream_order(p, I["crs"]))
+    single = ctx.to_host(ctx.prove(d_crs, I["d_ssp"], I["bits"], delta, mags, signs)).copy()
+    one = ctx.to_host(mfdist.prove_sharded(ctx, d_crs, I["d_ssp"], I["bits"], delta, mags, signs, 0, 1)).copy()
+    assert np.array_equal(single, one)
+    world = 3
+    lanes = None
+    for r in range(world):
+        part = ctx.prove_partial(d_crs, I["d_ssp"], I["bits"], delta, r, world)
+        ln = ctx.ct_to_lanes(part, 5).clone()
+        lanes = ln if lanes is None else lanes + ln
+    proof = ctx.ct_from_lanes(lanes, 5)
+    ctx.prove_finish(proof, mags, signs)
+    assert np.array_equal(ctx.to_host(proof), single)
+    # the CPU restatements used by the gloo test agree with the device kernels
+    part = ctx.prove_partial(d_crs, I["d_ssp"], I["bits"], delta, 1, world)
+    limbs = ctx.to_host(part, np.uint64).reshape(5, p.n + 1, p.L)
+    assert np.array_equal(mfdist.lanes_from_limbs_cpu(limbs, p.K).reshape(-1), ctx.to_host(ctx.ct_to_lanes(part, 5), np.int64))
+    assert np.array_equal(mfdist.limbs_from_lanes_cpu(ctx.to_host(lanes, np.int64).reshape(5, p.n + 1, 2 * p.K), p.L, p.K).reshape(-1),
+                          ctx.to_host(ctx.ct_from_lanes(lanes, 5), np.uint64))
