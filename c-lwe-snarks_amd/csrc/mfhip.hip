@@ -218,10 +218,32 @@ __global__ __launch_bounds__(PS<LOGQ>::THREADS) void k_eval(AesKey key, const ui
       part[((((uint64_t)blockIdx.y * S::ROWS + rs) * NACC + a) * S::KW + l) * NJ + j] = acc[a][l];
 }
 
-// sum partials over slabs (chunks x row-halves), propagate carries, write natural-layout values (optionally += previous)
+// Partial-sum reduction, stage 1: lazy[(a*KW + l)*NJ + j] = sum over slabs of the 32-bit partial words (uint64, no carries yet).
+// grid = (NJ/256, KW, nacc): every load is a coalesced run over j.
 template <int LOGQ>
-__global__ void k_eval_reduce(const uint32_t *__restrict__ part, uint32_t nslabs, uint32_t nacc, uint32_t NJ, uint32_t n,
-                              uint64_t *__restrict__ rop0, uint64_t *__restrict__ rop1, int accumulate) {
+__global__ __launch_bounds__(256) void k_eval_reduce_sum(const uint32_t *__restrict__ part, uint32_t nslabs, uint32_t nacc, uint32_t NJ,
+                                                         uint64_t *__restrict__ lazy) {
+  using S = PS<LOGQ>;
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t l = blockIdx.y, a = blockIdx.z;
+  if (j >= NJ) return;
+  const uint32_t *p = part + ((uint64_t)a * S::KW + l) * NJ + j;
+  const uint64_t stride = (uint64_t)nacc * S::KW * NJ;
+  uint64_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  uint32_t ch = 0;
+  for (; ch + 4 <= nslabs; ch += 4) {
+    s0 += p[(uint64_t)ch * stride];
+    s1 += p[(uint64_t)(ch + 1) * stride];
+    s2 += p[(uint64_t)(ch + 2) * stride];
+    s3 += p[(uint64_t)(ch + 3) * stride];
+  }
+  for (; ch < nslabs; ch++) s0 += p[(uint64_t)ch * stride];
+  lazy[((uint64_t)a * S::KW + l) * NJ + j] = s0 + s1 + s2 + s3;
+}
+// stage 2: propagate carries over the KW words of each coordinate, write natural-layout values (optionally += previous)
+template <int LOGQ>
+__global__ void k_eval_reduce_carry(const uint64_t *__restrict__ lazy, uint32_t NJ, uint32_t n, uint64_t *__restrict__ rop0,
+                                    uint64_t *__restrict__ rop1, int accumulate) {
   using S = PS<LOGQ>;
   uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t a = blockIdx.y;
@@ -230,8 +252,7 @@ __global__ void k_eval_reduce(const uint32_t *__restrict__ part, uint32_t nslabs
   uint32_t *out = reinterpret_cast<uint32_t *>(rop + (uint64_t)j * S::L);
   uint64_t carry = 0;
   for (int l = 0; l < S::KW; l++) {
-    uint64_t s = carry;
-    for (uint32_t ch = 0; ch < nslabs; ch++) s += part[(((uint64_t)ch * nacc + a) * S::KW + l) * NJ + j];
+    uint64_t s = lazy[((uint64_t)a * S::KW + l) * NJ + j] + carry;  // < 2^32 * slabs + carry: no overflow
     if (accumulate) s += out[l];
     out[l] = (uint32_t)s;
     carry = s >> 32;
@@ -714,11 +735,13 @@ static int eval_rows(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *c8, 
   const uint32_t nslabs = nchunks * S::ROWS;
   const uint32_t NJ = ntiles * S::TILE;
   const size_t part_bytes = (size_t)nslabs * nacc * S::KW * NJ * 4;
+  const size_t lazy_bytes = (size_t)nacc * S::KW * NJ * 8;
   const size_t idx_bytes = (((size_t)nrows + 1) * 4 + 255) & ~(size_t)255;
-  int rc = ws_reserve(c, part_bytes + idx_bytes);
+  int rc = ws_reserve(c, part_bytes + lazy_bytes + idx_bytes);
   if (rc) return rc;
   uint32_t *part = (uint32_t *)c->ws;
-  uint32_t *idx = (uint32_t *)((uint8_t *)c->ws + part_bytes);
+  uint64_t *lazy = (uint64_t *)((uint8_t *)c->ws + part_bytes);
+  uint32_t *idx = (uint32_t *)((uint8_t *)c->ws + part_bytes + lazy_bytes);
   uint32_t *cnt = idx + nrows;
   hipLaunchKernelGGL(k_compact_rows, dim3(1), dim3(1024), 0, c->stream, c0, c1, (uint32_t)nrows, idx, cnt);
   HIP_TRY(c, hipGetLastError());
@@ -732,8 +755,8 @@ static int eval_rows(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *c8, 
                          part);
   }
   HIP_TRY(c, hipGetLastError());
-  hipLaunchKernelGGL(k_eval_reduce<LOGQ>, dim3((n + 1 + 255) / 256, nacc), dim3(256), 0, c->stream, part, nslabs, (uint32_t)nacc, NJ, n, rop0,
-                     rop1, accumulate);
+  hipLaunchKernelGGL(k_eval_reduce_sum<LOGQ>, dim3((NJ + 255) / 256, S::KW, nacc), dim3(256), 0, c->stream, part, nslabs, (uint32_t)nacc, NJ, lazy);
+  hipLaunchKernelGGL(k_eval_reduce_carry<LOGQ>, dim3((n + 1 + 255) / 256, nacc), dim3(256), 0, c->stream, lazy, NJ, n, rop0, rop1, accumulate);
   HIP_TRY(c, hipGetLastError());
   return MFH_OK;
 }
