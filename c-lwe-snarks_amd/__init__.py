@@ -86,7 +86,7 @@ EXPORTS = [
     "mfh_encrypt_rows", "mfh_decrypt", "mfh_ct_smudge", "mfh_ssp_upload", "mfh_witness_poly", "mfh_version",
     "mfh_workspace_bytes", "mfh_last_kernel_ms", "mfh_set_timing", "mfh_poly_mul", "mfh_poly_add", "mfh_poly_prepare_t",
     "mfh_ssp_prepare", "mfh_poly_h", "mfh_setup_messages", "mfh_setup", "mfh_prove",
-    "mfh_prove_partial", "mfh_prove_finish", "mfh_ct_to_lanes", "mfh_ct_from_lanes", "mfh_timing_drain",
+    "mfh_prove_partial", "mfh_prove_finish", "mfh_ct_to_lanes", "mfh_ct_from_lanes", "mfh_timing_drain", "mfh_add_dotp",
 ]
 
 
@@ -134,6 +134,7 @@ def load_library():
         "mfh_prove_finish": (i32, [vp, vp, ctypes.c_char_p, sz, ctypes.c_char_p]),
         "mfh_ct_to_lanes": (i32, [vp, vp, sz, vp]),
         "mfh_ct_from_lanes": (i32, [vp, vp, sz, vp]),
+        "mfh_add_dotp": (i32, [vp, vp, vp, vp, sz]),
         "mfh_timing_drain": (i32, [vp, ctypes.c_char_p, ctypes.POINTER(u64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(u64),
                                    ctypes.POINTER(ctypes.c_float)]),
     }
@@ -350,3 +351,8 @@ class Context:
         out = self.empty(count * p.ct_limbs * 8) if out is None else out
         self._chk(self.lib.mfh_ct_from_lanes(self._h, _ptr(d_lanes), count, _ptr(out)))
         return out
+
+    def add_dotp(self, rop, a, b, length):
+        """mpz_add_dotp (src/lwe.c:20-28) on device values"""
+        self._chk(self.lib.mfh_add_dotp(self._h, _ptr(rop), _ptr(a), _ptr(b), length))
+        return rop

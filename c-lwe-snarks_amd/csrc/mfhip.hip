@@ -459,6 +459,56 @@ __global__ __launch_bounds__(256) void k_decrypt(const uint64_t *__restrict__ sk
   }
 }
 
+// rop = (rop + sum_j a[j]*b[j]) mod 2^(64K): mpz_add_dotp (src/lwe.c:20-28).  One workgroup of 256 threads.
+template <int LOGQ>
+__global__ __launch_bounds__(256) void k_add_dotp(uint64_t *__restrict__ rop, const uint64_t *__restrict__ a, const uint64_t *__restrict__ b,
+                                                  uint32_t len) {
+  using S = PS<LOGQ>;
+  __shared__ uint32_t red[S::KW * 256];
+  __shared__ uint64_t sums[S::KW];
+  uint32_t acc[S::KW];
+#pragma unroll
+  for (int l = 0; l < S::KW; l++) acc[l] = 0;
+  for (uint32_t j = threadIdx.x; j < len; j += 256) {
+    const uint32_t *x = reinterpret_cast<const uint32_t *>(a + (uint64_t)j * S::L);
+    const uint32_t *y = reinterpret_cast<const uint32_t *>(b + (uint64_t)j * S::L);
+    uint32_t yw[S::KW];
+#pragma unroll
+    for (int l = 0; l < S::KW; l++) yw[l] = y[l];
+#pragma unroll
+    for (int u = 0; u < S::KW; u++) {
+      uint32_t xu = x[u], carry = 0;
+#pragma unroll
+      for (int v = 0; u + v < S::KW; v++) {
+        uint64_t t = (uint64_t)xu * yw[v] + acc[u + v] + carry;
+        acc[u + v] = (uint32_t)t;
+        carry = (uint32_t)(t >> 32);
+      }
+    }
+  }
+#pragma unroll
+  for (int l = 0; l < S::KW; l++) red[l * 256 + threadIdx.x] = acc[l];
+  __syncthreads();
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int l = wave; l < S::KW; l += 4) {
+    uint64_t t = 0;
+    for (int k = 0; k < 4; k++) t += red[l * 256 + k * 64 + lane];
+    for (int o = 32; o; o >>= 1) t += __shfl_xor(t, o);
+    if (lane == 0) sums[l] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t *r = reinterpret_cast<uint32_t *>(rop);
+    uint64_t carry = 0;
+    for (int l = 0; l < S::KW; l++) {
+      uint64_t t = sums[l] + carry + r[l];
+      r[l] = (uint32_t)t;
+      carry = t >> 32;
+    }
+    for (int l = S::KW; l < 2 * S::L; l++) r[l] = 0;
+  }
+}
+
 template <int LOGQ>
 __global__ void k_smudge(uint64_t *cts, uint32_t n, const uint32_t *__restrict__ up /*count x KW words*/, const uint8_t *__restrict__ sign,
                          uint32_t count) {
@@ -825,6 +875,15 @@ int mfh_decrypt(mfh_ctx *c, const uint64_t *d_sk, const uint64_t *d_cts, size_t 
   HIP_TRY(c, hipSetDevice(c->device));
   DISPATCH_LOGQ(c, hipLaunchKernelGGL(k_decrypt<736>, dim3((uint32_t)count), dim3(256), 0, c->stream, d_sk, d_cts, c->P.n, d_out),
                 hipLaunchKernelGGL(k_decrypt<1472>, dim3((uint32_t)count), dim3(256), 0, c->stream, d_sk, d_cts, c->P.n, d_out));
+  HIP_TRY(c, hipGetLastError());
+  return MFH_OK;
+}
+
+int mfh_add_dotp(mfh_ctx *c, uint64_t *d_rop, const uint64_t *d_a, const uint64_t *d_b, size_t len) {
+  if (!c || !d_rop || (len && (!d_a || !d_b)) || len > 0xffffffffu) return MFH_EINVAL;
+  HIP_TRY(c, hipSetDevice(c->device));
+  DISPATCH_LOGQ(c, hipLaunchKernelGGL(k_add_dotp<736>, dim3(1), dim3(256), 0, c->stream, d_rop, d_a, d_b, (uint32_t)len),
+                hipLaunchKernelGGL(k_add_dotp<1472>, dim3(1), dim3(256), 0, c->stream, d_rop, d_a, d_b, (uint32_t)len));
   HIP_TRY(c, hipGetLastError());
   return MFH_OK;
 }

@@ -1,0 +1,117 @@
+/*
+ * mangiafuoco_api.h -- the C interface libmfuoco_gpu.so exports: the same function names, argument meaning and
+ * ownership rules as the reference library's five headers (src/aes.h, src/entropy.h, src/lwe.h, src/ssp.h,
+ * src/snark.h), so that a program written against those headers links against libmfuoco_gpu.so instead of the
+ * reference objects.  One combined header, our own text; programs that already include the reference's headers do
+ * not need it (the layouts below are the ones those headers define).
+ *
+ * Everything that the reference computes with AES/GMP on the CPU on this path is computed on the GPU through
+ * libmfhip.so (include/mfhip.h); host code only marshals mpz_t <-> dense limbs and draws OS entropy.
+ * Parameters follow the reference's compile-time switch: -DNDEBUG => D = 2^15, M = 21845, else D = 256, M = 64.
+ */
+#ifndef MANGIAFUOCO_API_H
+#define MANGIAFUOCO_API_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include <gmp.h>
+#include <flint/nmod_poly.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- parameters (src/lwe.h:14-31) ---- */
+#ifdef NDEBUG
+#define GAMMA_D (1UL << 15)
+#define GAMMA_M (21845)
+#else
+#define GAMMA_D (1UL << 8)
+#define GAMMA_M (1UL << 6)
+#endif
+#define GAMMA_N 1470
+#define GAMMA_LOGQ 736
+#define GAMMA_P 0xfffffffbUL
+#define GAMMA_LOG_SMUDGING 640
+#define GAMMA_LOG_SIGMA 556
+#define LOGQ_BYTES 92UL
+#define CT_BYTES (LOGQ_BYTES)
+
+/* ---- stream (src/aes.h:21-40, src/entropy.h:35-60) ---- */
+struct aesctr {
+  uint64_t nonce;
+  void *key; /* opaque to callers (the reference stores an AES_KEY* here) */
+  uint64_t ctr;
+  uint8_t remb[16];
+  size_t rem;
+};
+typedef struct aesctr *aesctr_ptr;
+typedef struct aesctr aesctr_t[1];
+typedef uint8_t rseed_t[32 + 8];
+typedef aesctr_t rng_t[1];
+
+void aesctr_init(aesctr_ptr stream, const uint8_t *key, const uint64_t nonce);
+void aesctr_prg(aesctr_ptr stream, void *out, size_t count);
+void aesctr_clear(aesctr_ptr stream);
+void rng_init(rng_t rs, uint8_t *rseed);
+void rng_clear(rng_t rs);
+void rng_seek(rng_t rs, size_t count);
+void mpz2_urandomb(mpz_ptr rop, rng_t rs, size_t nbits);
+void mpz2_urandomb2(mpz_ptr rop, size_t nbits);
+
+/* ---- LWE (src/lwe.h:33-74, src/lwe.c:141,160) ---- */
+typedef mpz_t sk_t[GAMMA_N];
+typedef mpz_t ct_t[GAMMA_N + 1];
+void key_gen(sk_t sk);
+void key_clear(sk_t sk);
+void errdist_uniform(mpz_t e);
+void ct_init(ct_t ct);
+void ct_clear(ct_t ct);
+void ct_export(uint8_t *buf, ct_t ct);
+void ct_import(ct_t ct, rng_t rng, uint8_t *buf);
+void decompress_encryption(ct_t c, rng_t rs, mpz_t b);
+void regev_encrypt2(ct_t c, rng_t rs, sk_t sk, mpz_t m, void (*chi)(mpz_t));
+void regev_decrypt(mpz_t m, sk_t sk, ct_t ct);
+void mpz_add_dotp(mpz_t rop, mpz_t a[], mpz_t b[], size_t len);
+void ct_smudge(ct_t ct);
+void ct_add(ct_t rop, ct_t a, ct_t b);
+void ct_mul_ui(ct_t rop, ct_t a, uint64_t b);
+void ct_addmul_ui(ct_t rop, ct_t a, uint64_t b);
+void ct_zero(ct_t rop);
+void eval_poly(ct_t rop, rng_t rng, uint8_t (*c8)[CT_BYTES], nmod_poly_t coeffs, size_t d);
+
+/* ---- SSP (src/ssp.h:6-14) ---- */
+#define SSP_SIZE (GAMMA_D * 8 * (GAMMA_M + 3))
+void nmod_poly_import(nmod_poly_t *pp, void *buf, size_t degree);
+void nmod_poly_export(void *buf, nmod_poly_t *pp, size_t degree);
+void random_ssp(mpz_t input, uint8_t *circuit);
+
+/* ---- SNARK (src/snark.h:6-51) ---- */
+struct proof { ct_t h, hat_h, hat_v, v_w, b_w; };
+struct vrs { uint64_t alpha, beta, s; sk_t sk; };
+struct crs { rseed_t seed; uint8_t (*s)[CT_BYTES]; uint8_t (*as)[CT_BYTES]; uint8_t (*v)[CT_BYTES]; uint8_t *t; };
+typedef uint8_t *ssp_t;
+typedef struct crs crs_t[1];
+typedef struct proof proof_t[1];
+typedef struct vrs vrs_t[1];
+void crs_init(crs_t crs);
+void crs_clear(crs_t crs);
+void proof_init(proof_t pi);
+void proof_clear(proof_t pi);
+void setup(crs_t crs, vrs_t vrs, ssp_t ssp);
+void prover(proof_t pi, crs_t crs, ssp_t ssp, mpz_t witness);
+bool verifier(ssp_t ssp, vrs_t vrs, proof_t pi);
+
+/* ---- additions (not in the reference) ---- */
+/* The shim keeps the last SSP it uploaded (keyed by host pointer) resident in HBM; call this after changing the
+ * bytes of an SSP buffer in place. */
+void mfuoco_gpu_invalidate(void);
+/* select the GPU (default 0, or $MFUOCO_GPU); must precede the first call */
+void mfuoco_gpu_set_device(int device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

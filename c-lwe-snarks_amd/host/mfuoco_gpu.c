@@ -1,0 +1,508 @@
+/*
+ * mfuoco_gpu.c -- libmfuoco_gpu.so: the reference library's C interface (names, argument meaning, ownership and error
+ * behaviour of src/aes.h, src/entropy.h, src/lwe.h, src/ssp.h, src/snark.h) implemented on top of the MI355X C ABI
+ * (include/mfhip.h).  Host code here only (a) converts mpz_t <-> dense little-endian limbs, (b) moves bytes across
+ * PCIe, (c) draws OS entropy where the reference calls getrandom(2).  All arithmetic on the path -- AES-CTR expansion,
+ * big-integer multiply-accumulate, dot products, the polynomial step -- runs on the GPU.  No CPU fallback: if the GPU
+ * context cannot be created the first call aborts with a message.
+ *
+ * Error behaviour mirrors the reference: functions return void, preconditions the reference asserts (message < p,
+ * scalar < p, non-negative values) abort() here in every build, allocation failures perror() and continue where the
+ * reference does.
+ */
+#define _GNU_SOURCE
+#include <stdbool.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <strings.h>
+#include <sys/random.h>
+
+#include <gmp.h>
+
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+
+#include "mfhip.h"
+#include "mfuoco/mangiafuoco_api.h"
+
+#define L_LIMBS 12
+#define K_LIMBS 11
+#define CTL ((size_t)(GAMMA_N + 1) * L_LIMBS)
+#define CTR_CT ((uint64_t)CT_BYTES * GAMMA_N)
+#define CTR_S 0ULL
+#define CTR_AS (CTR_CT * GAMMA_D)
+#define CTR_BT (2 * CTR_CT * GAMMA_D)
+
+static struct {
+  mfh_ctx *ctx;
+  int device;
+  uint8_t seed[40];
+  bool have_seed;
+  /* persistent device scratch */
+  uint64_t *d_ct[3];  /* three ciphertexts */
+  uint64_t *d_sk;     /* n values */
+  uint8_t *d_c8;      /* up to max(D, M) * CT_BYTES, or the whole CRS */
+  uint32_t *d_co;     /* coefficients */
+  uint64_t *d_proof;  /* 5 ciphertexts */
+  uint32_t *d_ssp;    /* (M+3) * D uint32 */
+  const void *ssp_host; /* host pointer the resident SSP was uploaded from */
+  uint8_t *d_crs;     /* (2D+M) * CT_BYTES */
+  uint64_t *d_err;
+} G = { .device = -1 };
+
+static void die(const char *what)
+{
+  fprintf(stderr, "libmfuoco_gpu: %s%s%s\n", what, G.ctx ? ": " : "", G.ctx ? mfh_last_error(G.ctx) : "");
+  abort();
+}
+#define CK(call) do { if ((call) != MFH_OK) die(#call); } while (0)
+#define HK(call) do { if ((call) != hipSuccess) die(#call); } while (0)
+
+void mfuoco_gpu_set_device(int device) { G.device = device; }
+void mfuoco_gpu_invalidate(void) { G.ssp_host = NULL; }
+
+static mfh_ctx *gpu(void)
+{
+  if (G.ctx) return G.ctx;
+  if (G.device < 0) {
+    const char *e = getenv("MFUOCO_GPU");
+    G.device = e ? atoi(e) : 0;
+  }
+  mfh_params P = { GAMMA_N, GAMMA_LOGQ, (uint32_t)GAMMA_D, (uint32_t)GAMMA_M };
+  if (mfh_ctx_create(&G.ctx, G.device, &P) != MFH_OK) {
+    fprintf(stderr, "libmfuoco_gpu: no usable HIP device %d (there is no CPU fallback)\n", G.device);
+    abort();
+  }
+  CK(mfh_set_stream(G.ctx, NULL)); /* default stream: hipMemcpy below is ordered with the kernels */
+  size_t rows = 2 * (size_t)GAMMA_D + GAMMA_M;
+  for (int i = 0; i < 3; i++) HK(hipMalloc((void **)&G.d_ct[i], CTL * 8));
+  HK(hipMalloc((void **)&G.d_sk, (size_t)GAMMA_N * L_LIMBS * 8));
+  HK(hipMalloc((void **)&G.d_c8, rows * CT_BYTES));
+  HK(hipMalloc((void **)&G.d_co, rows * 4));
+  HK(hipMalloc((void **)&G.d_proof, 5 * CTL * 8));
+  HK(hipMalloc((void **)&G.d_crs, rows * CT_BYTES));
+  return G.ctx;
+}
+
+static void use_seed(const uint8_t seed[40])
+{
+  mfh_ctx *c = gpu();
+  if (!G.have_seed || memcmp(G.seed, seed, 40)) {
+    CK(mfh_set_seed(c, seed));
+    memcpy(G.seed, seed, 40);
+    G.have_seed = true;
+  }
+}
+
+/* ---- mpz <-> limbs -------------------------------------------------------------------------------------- */
+static void to_limbs(uint64_t *out, const mpz_t z)
+{
+  if (mpz_sgn(z) < 0) die("negative value (the reference asserts SIZ >= 0, src/lwe.h:109)");
+  if (mpz_sizeinbase(z, 2) > 64 * L_LIMBS) die("value wider than 768 bits");
+  memset(out, 0, L_LIMBS * 8);
+  mpz_export(out, NULL, -1, 8, 0, 0, z);
+}
+static void from_limbs(mpz_t z, const uint64_t *in) { mpz_import(z, L_LIMBS, -1, 8, 0, 0, in); }
+
+static void ct_to_dev(uint64_t *d, mpz_t *ct, size_t count)
+{
+  uint64_t *h = malloc(count * L_LIMBS * 8);
+  for (size_t j = 0; j < count; j++) to_limbs(h + j * L_LIMBS, ct[j]);
+  HK(hipMemcpy(d, h, count * L_LIMBS * 8, hipMemcpyHostToDevice));
+  free(h);
+}
+static void ct_from_dev(mpz_t *ct, const uint64_t *d, size_t count)
+{
+  uint64_t *h = malloc(count * L_LIMBS * 8);
+  HK(hipMemcpy(h, d, count * L_LIMBS * 8, hipMemcpyDeviceToHost));
+  for (size_t j = 0; j < count; j++) from_limbs(ct[j], h + j * L_LIMBS);
+  free(h);
+}
+
+/* ---- L0/L1: stream -------------------------------------------------------------------------------------- */
+typedef struct { uint8_t seed[40]; } shim_key;
+
+void aesctr_init(aesctr_ptr s, const uint8_t *key, const uint64_t nonce)
+{
+  s->rem = 0;
+  s->ctr = 0;
+  shim_key *k = malloc(sizeof *k);
+  if (!k) { perror("Failed malloc"); return; }
+  memcpy(k->seed, &nonce, 8);
+  memcpy(k->seed + 8, key, 32);
+  s->key = k;
+  s->nonce = nonce;
+}
+
+void aesctr_clear(aesctr_ptr s)
+{
+  if (!s) return;
+  if (s->key) { memset(s->key, 0, sizeof(shim_key)); free(s->key); }
+  memset(s, 0, sizeof(struct aesctr));
+}
+
+/* absolute stream position of the next byte */
+static uint64_t stream_pos(const struct aesctr *s) { return s->ctr * 16 - s->rem; }
+static void stream_set_pos(struct aesctr *s, uint64_t pos)
+{
+  s->ctr = (pos + 15) / 16;
+  s->rem = (size_t)(s->ctr * 16 - pos);
+  /* remb mirrors the reference: the unread tail of the last generated block (src/aes.c:135-142) */
+  if (s->rem) {
+    uint8_t blk[16], *d;
+    use_seed(((shim_key *)s->key)->seed);
+    HK(hipMalloc((void **)&d, 16));
+    CK(mfh_keystream(G.ctx, (s->ctr - 1) * 16, d, 16));
+    HK(hipMemcpy(blk, d, 16, hipMemcpyDeviceToHost));
+    HK(hipFree(d));
+    memcpy(s->remb, blk + 16 - s->rem, s->rem);
+  }
+}
+
+void aesctr_prg(aesctr_ptr s, void *out, size_t bytes)
+{
+  if (!bytes) return;
+  use_seed(((shim_key *)s->key)->seed);
+  uint64_t pos = stream_pos(s);
+  uint8_t *d;
+  HK(hipMalloc((void **)&d, bytes));
+  CK(mfh_keystream(G.ctx, pos, d, bytes));
+  HK(hipMemcpy(out, d, bytes, hipMemcpyDeviceToHost));
+  HK(hipFree(d));
+  stream_set_pos(s, pos + bytes);
+}
+
+void rng_init(rng_t rs, uint8_t *rseed)
+{
+  uint64_t nonce;
+  memcpy(&nonce, rseed, 8);
+  aesctr_init((aesctr_ptr)rs, rseed + 8, nonce);
+}
+void rng_clear(rng_t rs) { aesctr_clear((aesctr_ptr)rs); }
+void rng_seek(rng_t rs, size_t count) { stream_set_pos((aesctr_ptr)rs, count); }
+
+void mpz2_urandomb(mpz_ptr rop, rng_t rs, size_t nbits)
+{
+  size_t limbs = (nbits + 63) / 64, bytes = nbits / 8;
+  uint64_t *buf = calloc(limbs ? limbs : 1, 8);
+  aesctr_prg((aesctr_ptr)rs, buf, bytes);
+  if (limbs) buf[limbs - 1] &= ~0ULL >> (limbs * 64 - nbits);
+  mpz_import(rop, limbs, -1, 8, 0, 0, buf);
+  free(buf);
+}
+void mpz2_urandomb2(mpz_ptr rop, size_t nbits)
+{
+  size_t limbs = (nbits + 63) / 64, bytes = nbits / 8;
+  uint64_t *buf = calloc(limbs ? limbs : 1, 8);
+  if (getrandom(buf, bytes, GRND_NONBLOCK) < 0) perror("getrandom");
+  if (limbs) buf[limbs - 1] &= ~0ULL >> (limbs * 64 - nbits);
+  mpz_import(rop, limbs, -1, 8, 0, 0, buf);
+  free(buf);
+}
+
+/* ---- L2: LWE -------------------------------------------------------------------------------------------- */
+static void initv(mpz_t *v, size_t n) { for (size_t i = 0; i < n; i++) mpz_init2(v[i], GAMMA_LOGQ); }
+static void clearv(mpz_t *v, size_t n) { for (size_t i = 0; i < n; i++) mpz_clear(v[i]); }
+void key_gen(sk_t sk) { initv(sk, GAMMA_N); for (size_t i = 0; i < GAMMA_N; i++) mpz2_urandomb2(sk[i], GAMMA_LOGQ); }
+void key_clear(sk_t sk) { clearv(sk, GAMMA_N); }
+void ct_init(ct_t ct) { initv(ct, GAMMA_N + 1); }
+void ct_clear(ct_t ct) { clearv(ct, GAMMA_N + 1); }
+void errdist_uniform(mpz_t e) { mpz2_urandomb2(e, GAMMA_LOG_SIGMA + 3); }
+void ct_zero(ct_t rop) { for (size_t i = 0; i <= GAMMA_N; i++) mpz_set_ui(rop[i], 0); }
+
+void ct_export(uint8_t *buf, ct_t ct)
+{
+  bzero(buf, CT_BYTES);
+  if (mpz_sizeinbase(ct[GAMMA_N], 2) > 8 * CT_BYTES) die("ct_export: b does not fit CT_BYTES");
+  mpz_export(buf, NULL, -1, 1, -1, 0, ct[GAMMA_N]);
+}
+
+/* a-part of a row at the rng's position, advancing it by CTR_CT (mpz2_urandommv, src/lwe.c:90,101,124) */
+static void sample_a(ct_t ct, rng_t rng)
+{
+  struct aesctr *s = (struct aesctr *)rng;
+  use_seed(((shim_key *)s->key)->seed);
+  uint64_t pos = stream_pos(s);
+  CK(mfh_sample_rows(G.ctx, pos, 1, G.d_ct[0]));
+  ct_from_dev(ct, G.d_ct[0], GAMMA_N);
+  stream_set_pos(s, pos + CTR_CT);
+}
+
+void ct_import(ct_t ct, rng_t rng, uint8_t *buf)
+{
+  sample_a(ct, rng);
+  mpz_import(ct[GAMMA_N], LOGQ_BYTES, -1, 1, -1, 0, buf);
+}
+void decompress_encryption(ct_t c, rng_t rng, mpz_t b)
+{
+  sample_a(c, rng);
+  mpz_set(c[GAMMA_N], b);
+}
+
+void regev_encrypt2(ct_t c, rng_t rs, sk_t sk, mpz_t m, void (*chi)(mpz_t))
+{
+  if (mpz_sgn(m) < 0 || mpz_cmp_ui(m, GAMMA_P) >= 0) die("regev_encrypt2: message must be < p (src/lwe.c:80)");
+  struct aesctr *s = (struct aesctr *)rs;
+  mpz_t e;
+  mpz_init(e);
+  (*chi)(e);
+  uint8_t sign;
+  if (getrandom(&sign, 1, GRND_NONBLOCK) < 0) perror("getrandom"); /* the reference burns one byte here (src/lwe.c:87) */
+  uint64_t eh[L_LIMBS];
+  to_limbs(eh, e);
+  mpz_clear(e);
+  use_seed(((shim_key *)s->key)->seed);
+  uint64_t pos = stream_pos(s);
+  uint32_t mh = (uint32_t)mpz_get_ui(m);
+  uint8_t c8[CT_BYTES];
+  ct_to_dev(G.d_sk, sk, GAMMA_N);
+  HK(hipMemcpy(G.d_co, &mh, 4, hipMemcpyHostToDevice));
+  HK(hipMemcpy(G.d_ct[1], eh, sizeof eh, hipMemcpyHostToDevice));
+  CK(mfh_encrypt_rows(G.ctx, pos, 1, G.d_sk, G.d_co, G.d_ct[1], G.d_c8));
+  HK(hipMemcpy(c8, G.d_c8, CT_BYTES, hipMemcpyDeviceToHost));
+  sample_a(c, rs); /* the caller receives the a's too; advances the stream */
+  mpz_import(c[GAMMA_N], LOGQ_BYTES, -1, 1, -1, 0, c8);
+}
+
+void regev_decrypt(mpz_t m, sk_t sk, ct_t ct)
+{
+  gpu();
+  uint32_t out;
+  ct_to_dev(G.d_sk, sk, GAMMA_N);
+  ct_to_dev(G.d_ct[0], ct, GAMMA_N + 1);
+  CK(mfh_decrypt(G.ctx, G.d_sk, G.d_ct[0], 1, G.d_co));
+  HK(hipMemcpy(&out, G.d_co, 4, hipMemcpyDeviceToHost));
+  mpz_set_ui(m, out);
+}
+
+void mpz_add_dotp(mpz_t rop, mpz_t a[], mpz_t b[], size_t len)
+{
+  gpu();
+  uint64_t r[L_LIMBS], *da, *db, *dr;
+  /* rop may be an unreduced accumulator in the reference; only its value mod 2^704 survives the final modq */
+  mpz_t t;
+  mpz_init(t);
+  mpz_fdiv_r_2exp(t, rop, 64 * K_LIMBS);
+  to_limbs(r, t);
+  mpz_clear(t);
+  HK(hipMalloc((void **)&da, len * L_LIMBS * 8 + 8));
+  HK(hipMalloc((void **)&db, len * L_LIMBS * 8 + 8));
+  HK(hipMalloc((void **)&dr, L_LIMBS * 8));
+  ct_to_dev(da, a, len);
+  ct_to_dev(db, b, len);
+  HK(hipMemcpy(dr, r, sizeof r, hipMemcpyHostToDevice));
+  CK(mfh_add_dotp(G.ctx, dr, da, db, len));
+  HK(hipMemcpy(r, dr, sizeof r, hipMemcpyDeviceToHost));
+  from_limbs(rop, r);
+  HK(hipFree(da)); HK(hipFree(db)); HK(hipFree(dr));
+}
+
+void ct_smudge(ct_t ct)
+{
+  gpu();
+  uint8_t mag[GAMMA_LOG_SMUDGING / 8], sign;
+  if (getrandom(mag, sizeof mag, GRND_NONBLOCK) < 0 || getrandom(&sign, 1, GRND_NONBLOCK) < 0) perror("getrandom");
+  ct_to_dev(G.d_ct[0], ct, GAMMA_N + 1);
+  CK(mfh_ct_smudge(G.ctx, G.d_ct[0], 1, mag, sizeof mag, &sign));
+  ct_from_dev(ct + GAMMA_N, G.d_ct[0] + (size_t)GAMMA_N * L_LIMBS, 1);
+}
+
+void ct_add(ct_t rop, ct_t a, ct_t b)
+{
+  gpu();
+  ct_to_dev(G.d_ct[0], a, GAMMA_N + 1);
+  ct_to_dev(G.d_ct[1], b, GAMMA_N + 1);
+  CK(mfh_ct_add(G.ctx, G.d_ct[2], G.d_ct[0], G.d_ct[1], 1));
+  ct_from_dev(rop, G.d_ct[2], GAMMA_N + 1);
+}
+void ct_mul_ui(ct_t rop, ct_t a, uint64_t b)
+{
+  gpu();
+  if (b >= GAMMA_P) die("ct_mul_ui: scalar must be < p (src/lwe.c:133)");
+  ct_to_dev(G.d_ct[0], a, GAMMA_N + 1);
+  CK(mfh_ct_mul_ui(G.ctx, G.d_ct[2], G.d_ct[0], (uint32_t)b, 1));
+  ct_from_dev(rop, G.d_ct[2], GAMMA_N + 1);
+}
+void ct_addmul_ui(ct_t rop, ct_t a, uint64_t b)
+{
+  gpu();
+  if (b >= GAMMA_P) die("ct_addmul_ui: scalar must be < p (src/lwe.c:143)");
+  ct_to_dev(G.d_ct[0], a, GAMMA_N + 1);
+  ct_to_dev(G.d_ct[2], rop, GAMMA_N + 1);
+  CK(mfh_ct_addmul_ui(G.ctx, G.d_ct[2], G.d_ct[0], (uint32_t)b, 1));
+  ct_from_dev(rop, G.d_ct[2], GAMMA_N + 1);
+}
+
+void eval_poly(ct_t rop, rng_t rng, uint8_t (*c8)[CT_BYTES], nmod_poly_t p, size_t d)
+{
+  struct aesctr *s = (struct aesctr *)rng;
+  use_seed(((shim_key *)s->key)->seed);
+  if (d > 2 * (size_t)GAMMA_D + GAMMA_M) die("eval_poly: more rows than a CRS holds");
+  uint32_t *co = malloc(d * 4 + 4);
+  for (size_t i = 0; i < d; i++) {
+    mp_limb_t c = nmod_poly_get_coeff_ui(p, i);
+    if (c >= GAMMA_P) die("eval_poly: coefficient must be < p (src/lwe.c:143)");
+    co[i] = (uint32_t)c;
+  }
+  uint64_t pos = stream_pos(s);
+  HK(hipMemcpy(G.d_co, co, d * 4, hipMemcpyHostToDevice));
+  HK(hipMemcpy(G.d_c8, c8, d * CT_BYTES, hipMemcpyHostToDevice));
+  free(co);
+  ct_to_dev(G.d_ct[2], rop, GAMMA_N + 1); /* eval_poly accumulates into rop (src/lwe.c:183) */
+  CK(mfh_eval_rows(G.ctx, pos, d, G.d_c8, G.d_co, NULL, G.d_ct[2], NULL, 1));
+  ct_from_dev(rop, G.d_ct[2], GAMMA_N + 1);
+  stream_set_pos(s, pos + d * CTR_CT);
+}
+
+/* ---- L3: SSP (host harness, src/ssp.c) --------------------------------------------------------------------- */
+void nmod_poly_export(void *buf_, nmod_poly_t *pp, size_t degree)
+{
+  uint64_t *buf = buf_;
+  for (size_t i = 0; i < degree; i++) buf[i] = nmod_poly_get_coeff_ui(*pp, i);
+}
+void nmod_poly_import(nmod_poly_t *pp, void *buf_, size_t degree)
+{
+  uint64_t *buf = buf_;
+  for (size_t i = 0; i < degree; i++) nmod_poly_set_coeff_ui(*pp, i, buf[i]);
+}
+void random_ssp(mpz_t input, uint8_t *circuit)
+{
+  const size_t buflen = 8 * GAMMA_D;
+  uint8_t *buf = malloc(buflen);
+  uint64_t *t = calloc(GAMMA_D, 8), *out;
+  mpz2_urandomb2(input, GAMMA_M);
+  for (size_t i = 0; i < GAMMA_M; i++) {
+    if (getrandom(buf, buflen, GRND_NONBLOCK) < 0) perror("getrandom");
+    out = (uint64_t *)(circuit + 8 * GAMMA_D * (i + 1));
+    int take = i == 0 || mpz_tstbit(input, i - 1);
+    for (size_t k = 0; k < GAMMA_D; k++) {
+      uint64_t x;
+      memcpy(&x, buf + 8 * k, 8);
+      out[k] = x % GAMMA_P;
+      if (take) t[k] = (t[k] + out[k]) % GAMMA_P;
+    }
+  }
+  t[0] = (t[0] + GAMMA_P - 1) % GAMMA_P;
+  memcpy(circuit, t, buflen);
+  free(buf); free(t);
+}
+
+/* ---- L4: SNARK -------------------------------------------------------------------------------------------- */
+void proof_init(proof_t pi) { ct_init(pi->h); ct_init(pi->hat_h); ct_init(pi->hat_v); ct_init(pi->v_w); ct_init(pi->b_w); }
+void proof_clear(proof_t pi) { ct_clear(pi->h); ct_clear(pi->hat_h); ct_clear(pi->hat_v); ct_clear(pi->v_w); ct_clear(pi->b_w); }
+void crs_init(struct crs *crs)
+{
+  if (getrandom(crs->seed, sizeof(rseed_t), GRND_NONBLOCK) < 0) perror("getrandom");
+  crs->s = malloc(CT_BYTES * GAMMA_D);
+  crs->as = malloc(CT_BYTES * GAMMA_D);
+  crs->v = malloc(CT_BYTES * GAMMA_M);
+  crs->t = malloc(CT_BYTES);
+  if (!crs->s || !crs->as || !crs->v || !crs->t) perror("Error allocating memory");
+}
+void crs_clear(struct crs *crs) { free(crs->s); free(crs->as); free(crs->v); free(crs->t); }
+
+static uint64_t rand_modp_(void)
+{
+  uint64_t r;
+  if (getrandom(&r, 8, GRND_NONBLOCK) < 0) perror("getrandom");
+  return r % GAMMA_P;
+}
+
+static void ssp_resident(ssp_t ssp)
+{
+  if (G.ssp_host == ssp && G.d_ssp) return;
+  if (!G.d_ssp) HK(hipMalloc((void **)&G.d_ssp, (size_t)(GAMMA_M + 3) * GAMMA_D * 4));
+  CK(mfh_ssp_upload(G.ctx, ssp, G.d_ssp, 0, GAMMA_M + 3));
+  CK(mfh_ssp_prepare(G.ctx, G.d_ssp));
+  G.ssp_host = ssp;
+}
+
+void setup(crs_t crs, vrs_t vrs, ssp_t ssp)
+{
+  gpu();
+  use_seed(crs->seed);
+  vrs->alpha = rand_modp_();
+  vrs->beta = rand_modp_();
+  vrs->s = rand_modp_();
+  key_gen(vrs->sk);
+  const size_t rows = 2 * (size_t)GAMMA_D + GAMMA_M;
+  /* errors: 559-bit draws (errdist_uniform) + the ineffective sign byte per encryption (src/lwe.c:85-87) */
+  uint64_t *err = calloc(rows * L_LIMBS, 8);
+  for (size_t i = 0; i < rows; i++) {
+    uint8_t sign;
+    if (getrandom(err + i * L_LIMBS, (GAMMA_LOG_SIGMA + 3) / 8, GRND_NONBLOCK) < 0 || getrandom(&sign, 1, GRND_NONBLOCK) < 0) perror("getrandom");
+  }
+  if (!G.d_err) HK(hipMalloc((void **)&G.d_err, rows * L_LIMBS * 8));
+  HK(hipMemcpy(G.d_err, err, rows * L_LIMBS * 8, hipMemcpyHostToDevice));
+  free(err);
+  ct_to_dev(G.d_sk, vrs->sk, GAMMA_N);
+  G.ssp_host = NULL;
+  ssp_resident(ssp);
+  CK(mfh_setup(G.ctx, G.d_ssp, (uint32_t)vrs->alpha, (uint32_t)vrs->beta, (uint32_t)vrs->s, G.d_sk, G.d_err, G.d_crs));
+  HK(hipMemcpy(crs->s, G.d_crs, CT_BYTES * GAMMA_D, hipMemcpyDeviceToHost));
+  HK(hipMemcpy(crs->as, G.d_crs + CT_BYTES * GAMMA_D, CT_BYTES * GAMMA_D, hipMemcpyDeviceToHost));
+  HK(hipMemcpy(crs->t, G.d_crs + 2 * CT_BYTES * GAMMA_D, CT_BYTES, hipMemcpyDeviceToHost));
+  HK(hipMemcpy(crs->v, G.d_crs + (2 * GAMMA_D + 1) * CT_BYTES, CT_BYTES * (GAMMA_M - 1), hipMemcpyDeviceToHost));
+}
+
+void prover(proof_t pi, crs_t crs, ssp_t ssp, mpz_t witness)
+{
+  gpu();
+  use_seed(crs->seed);
+  ssp_resident(ssp);
+  HK(hipMemcpy(G.d_crs, crs->s, CT_BYTES * GAMMA_D, hipMemcpyHostToDevice));
+  HK(hipMemcpy(G.d_crs + CT_BYTES * GAMMA_D, crs->as, CT_BYTES * GAMMA_D, hipMemcpyHostToDevice));
+  HK(hipMemcpy(G.d_crs + 2 * CT_BYTES * GAMMA_D, crs->t, CT_BYTES, hipMemcpyHostToDevice));
+  HK(hipMemcpy(G.d_crs + (2 * GAMMA_D + 1) * CT_BYTES, crs->v, CT_BYTES * (GAMMA_M - 1), hipMemcpyHostToDevice));
+  uint8_t bits[(GAMMA_M + 7) / 8 + 8] = { 0 };
+  if (mpz_sizeinbase(witness, 2) > GAMMA_M + 8) die("prover: witness wider than M bits");
+  mpz_export(bits, NULL, -1, 1, -1, 0, witness);
+  /* entropy in the reference's order: delta (8 B), then 5 x [80 B magnitude, 1 B sign] (src/snark.c:140,185-189) */
+  uint32_t delta = (uint32_t)rand_modp_();
+  uint8_t mag[5 * (GAMMA_LOG_SMUDGING / 8)], sign[5];
+  for (int k = 0; k < 5; k++)
+    if (getrandom(mag + k * (GAMMA_LOG_SMUDGING / 8), GAMMA_LOG_SMUDGING / 8, GRND_NONBLOCK) < 0 || getrandom(sign + k, 1, GRND_NONBLOCK) < 0)
+      perror("getrandom");
+  CK(mfh_prove(G.ctx, G.d_crs, G.d_ssp, bits, delta, mag, GAMMA_LOG_SMUDGING / 8, sign, G.d_proof));
+  ct_from_dev(pi->h, G.d_proof, GAMMA_N + 1);
+  ct_from_dev(pi->hat_h, G.d_proof + CTL, GAMMA_N + 1);
+  ct_from_dev(pi->hat_v, G.d_proof + 2 * CTL, GAMMA_N + 1);
+  ct_from_dev(pi->v_w, G.d_proof + 3 * CTL, GAMMA_N + 1);
+  ct_from_dev(pi->b_w, G.d_proof + 4 * CTL, GAMMA_N + 1);
+}
+
+static uint64_t horner_modp(const uint8_t *slot, uint64_t x)
+{
+  unsigned __int128 r = 0;
+  for (size_t i = GAMMA_D; i-- > 0;) {
+    uint64_t c;
+    memcpy(&c, slot + 8 * i, 8);
+    r = (r * x + c % GAMMA_P) % GAMMA_P;
+  }
+  return (uint64_t)r;
+}
+
+bool verifier(ssp_t ssp, vrs_t vrs, proof_t pi)
+{
+  gpu();
+  uint32_t dec[5];
+  ct_to_dev(G.d_sk, vrs->sk, GAMMA_N);
+  ct_to_dev(G.d_proof, pi->h, GAMMA_N + 1);
+  ct_to_dev(G.d_proof + CTL, pi->hat_h, GAMMA_N + 1);
+  ct_to_dev(G.d_proof + 2 * CTL, pi->hat_v, GAMMA_N + 1);
+  ct_to_dev(G.d_proof + 3 * CTL, pi->v_w, GAMMA_N + 1);
+  ct_to_dev(G.d_proof + 4 * CTL, pi->b_w, GAMMA_N + 1);
+  CK(mfh_decrypt(G.ctx, G.d_sk, G.d_proof, 5, G.d_co)); /* the five regev_decrypt of src/snark.c:204-208 */
+  HK(hipMemcpy(dec, G.d_co, sizeof dec, hipMemcpyDeviceToHost));
+  const unsigned __int128 P = GAMMA_P;
+  uint64_t h_s = dec[0], hath_s = dec[1], hatv_s = dec[2], w_s = dec[3], b_s = dec[4];
+  uint64_t t_s = horner_modp(ssp, vrs->s);
+  uint64_t v_s = (horner_modp(ssp + 8 * GAMMA_D, vrs->s) + w_s) % GAMMA_P;
+  if ((uint64_t)((unsigned __int128)h_s * vrs->alpha % P) != hath_s) return false;               /* eq-pke */
+  if ((uint64_t)((unsigned __int128)v_s * vrs->alpha % P) != hatv_s) return false;
+  if ((uint64_t)(((unsigned __int128)v_s * v_s + P - 1) % P) != (uint64_t)((unsigned __int128)h_s * t_s % P)) return false; /* eq-div */
+  if ((uint64_t)((unsigned __int128)w_s * vrs->beta % P) != b_s) return false;                    /* eq-lin */
+  /* the reference's "test-error" bound (src/snark.c:238-241) can never reject: SIZ of a non-positive value is <= 0 */
+  return true;
+}

@@ -96,6 +96,9 @@ int mfh_encrypt_rows(mfh_ctx *ctx, uint64_t off, size_t nrows, const uint64_t *d
 /* Batched regev_decrypt (src/lwe.c:105-111) of `count` explicit ciphertexts: d_out[i] = (b - <a,sk> mod 2^(64K)) mod p */
 int mfh_decrypt(mfh_ctx *ctx, const uint64_t *d_sk, const uint64_t *d_cts, size_t count, uint32_t *d_out);
 
+/* mpz_add_dotp (src/lwe.c:20-28): rop = (rop + sum_{j<len} a[j]*b[j]) mod 2^(64K); rop is one value, a and b are len values */
+int mfh_add_dotp(mfh_ctx *ctx, uint64_t *d_rop, const uint64_t *d_a, const uint64_t *d_b, size_t len);
+
 /* ct_smudge (src/lwe.c:65-76) with caller-supplied entropy: b += (+/-) u*p on coordinate n of each of `count`
  * ciphertexts; h_mag = count * maglen little-endian bytes of u, h_sign[i]&1 selects the minus sign. */
 int mfh_ct_smudge(mfh_ctx *ctx, uint64_t *d_cts, size_t count, const uint8_t *h_mag, size_t maglen, const uint8_t *h_sign);
