@@ -1,0 +1,59 @@
+"""Condense rocprofv3 outputs under gpurun_out/ into the small summaries committed under profiles/."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+out_dir = os.path.join(ROOT, "profiles")
+os.makedirs(out_dir, exist_ok=True)
+
+
+def one(pattern):
+    g = glob.glob(os.path.join(ROOT, "gpurun_out", pattern))
+    return g[0] if g else None
+
+
+# kernel stats
+f = one(f"{tag}_stats/*/*_kernel_stats.csv")
+if f:
+    rows = list(csv.DictReader(open(f)))
+    with open(os.path.join(out_dir, f"{tag}_kernel_stats.csv"), "w") as o:
+        o.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline   (MI355X, 1 GPU)\n")
+        o.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
+        for r in rows:
+            o.write(",".join(['"' + r["Name"][:110].replace('"', "'") + '"', r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]]) + "\n")
+    log = one(f"{tag}_stats.log")
+    if log:
+        for line in open(log):
+            if line.startswith("{"):
+                open(os.path.join(out_dir, f"{tag}_bench_under_rocprof.json"), "w").write(line)
+
+# PMC
+res = {}
+for name in ("fetch", "write", "sq"):
+    f = one(f"{tag}_pmc_{name}/*/*_counter_collection.csv")
+    if not f:
+        continue
+    agg = defaultdict(lambda: defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        agg[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, cs in agg.items():
+        for c, v in cs.items():
+            res.setdefault(k, {})[c] = {"launches": len(v), "mean": sum(v) / len(v), "max": max(v)}
+json.dump(res, open(os.path.join(out_dir, f"{tag}_pmc_by_kernel.json"), "w"), indent=1)
+ev2 = next((v for k, v in res.items() if k.startswith("void k_eval<736, 2>")), None)
+if ev2 and "FETCH_SIZE" in ev2 and "WRITE_SIZE" in ev2:
+    # MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are in KiB-like units (x1024 -> bytes); on gfx950 FETCH_SIZE reports 1/2 of a wide
+    # coalesced read stream -> doubled (upper bound for this kernel, whose reads are 4-byte gathers of the CRS b's and coefficients).
+    fetch = ev2["FETCH_SIZE"]["mean"] * 1024 * 2
+    write = ev2["WRITE_SIZE"]["mean"] * 1024
+    json.dump({"kernel": "k_eval<736,2>", "fetch_bytes_x2_corrected": fetch, "write_bytes": write, "hbm_bytes_per_launch": fetch + write,
+               "note": "separate --pmc passes; FETCH_SIZE doubled per the gfx950 correction"}, open(os.path.join(out_dir, "traffic_eval2.json"), "w"), indent=1)
+    print("traffic", fetch + write)
+for k, v in res.items():
+    if "k_eval<736, 2>" in k or "k_encrypt<736>" in k or "k_keystream" in k:
+        print(k, {c: round(x["mean"]) for c, x in v.items()})
