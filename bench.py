@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-resident", action="store_true", help="skip the resident-CRS regime")
     ap.add_argument("--cpu-rows", type=int, default=20000, help="rows of the CPU baseline sample (~0.65 ms each on one core)")
     args = ap.parse_args()
 
@@ -166,6 +167,48 @@ def main():
 
     accepted = verify_on_gpu(mf, ctx, inst, proof) if rank == 0 else True
 
+    # ---- second regime: the expanded CRS resident in HBM (11.3 GB), streamed at HBM speed
+    resident = None
+    if not args.no_resident:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        image = ctx.crs_expand(0, rows_crs, d_crs)
+        torch.cuda.synchronize()
+        expand_s = time.perf_counter() - t1
+        ctx.set_resident(image)
+        for _ in range(args.warmup):
+            proof_r = step()
+        ctx.set_timing(True)
+        ctx.timing_drain("mac2")
+        ctx.timing_drain("mac1")
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            proof_r = step()
+        barrier()
+        el_r = time.perf_counter() - t1
+        ctx.set_timing(False)
+        m2n, m2ms, m2rows = ctx.timing_drain("mac2")
+        m1n, m1ms, m1rows = ctx.timing_drain("mac1")
+        if dist is not None:
+            tt = torch.tensor([el_r], dtype=torch.float64, device=ctx.device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el_r = float(tt.item())
+        same = bool(torch.equal(proof_r, proof))
+        ctx.set_resident(None)
+        rb = ctx.resident_row_bytes()
+        avg = m2ms / max(m2n, 1)
+        lr = m2rows / max(m2n, 1)
+        resident = {"value": args.steps / el_r, "unit": "proofs/s", "ms_per_step": el_r / args.steps * 1e3, "proof_identical_to_regenerated": same,
+                    "crs_expand_s": expand_s, "image_bytes": rows_crs * rb,
+                    "roofline": {"bound": "hbm", "kernel": "k_mac_resident<736,2> (streaming 2x MAC over the expanded S / AS rows)",
+                                 "achieved": lr * ROW_BYTES / (avg * 1e-3) / 1e9 if m2n else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": (lr * ROW_BYTES / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS) if m2n else None,
+                                 "bytes_read_per_row": rb, "read_gbs": lr * rb / (avg * 1e-3) / 1e9 if m2n else None,
+                                 "launches": m2n, "avg_launch_ms": avg, "rows_per_launch": lr},
+                    "mac1": {"launches": m1n, "avg_launch_ms": m1ms / max(m1n, 1), "rows_per_launch": m1rows / max(m1n, 1)}}
+        del image
+
     # ---- LWE batch (BASELINE config 1/2: one batch of 65 536 encryptions, rows at stream offset k*135240)
     enc_per_s = None
     if rank == 0:
@@ -237,6 +280,7 @@ def main():
                                  "it is LDS-lookup/VALU bound and moves ~0 HBM bytes: see DESIGN.md",
                          "aes_gblocks_per_s": (launch_rows * 8452.5 / (avg_ms * 1e-3) / 1e9) if n2 else None},
             "eval1": {"launches": n1, "avg_launch_ms": ms1 / max(n1, 1), "rows_per_launch": rows1 / max(n1, 1)},
+            "resident_crs": resident,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

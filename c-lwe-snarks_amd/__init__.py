@@ -87,6 +87,7 @@ EXPORTS = [
     "mfh_workspace_bytes", "mfh_last_kernel_ms", "mfh_set_timing", "mfh_poly_mul", "mfh_poly_add", "mfh_poly_prepare_t",
     "mfh_ssp_prepare", "mfh_poly_h", "mfh_setup_messages", "mfh_setup", "mfh_prove",
     "mfh_prove_partial", "mfh_prove_finish", "mfh_ct_to_lanes", "mfh_ct_from_lanes", "mfh_timing_drain", "mfh_add_dotp",
+    "mfh_resident_row_bytes", "mfh_crs_expand", "mfh_eval_rows_resident", "mfh_crs_set_resident",
 ]
 
 
@@ -135,6 +136,10 @@ def load_library():
         "mfh_ct_to_lanes": (i32, [vp, vp, sz, vp]),
         "mfh_ct_from_lanes": (i32, [vp, vp, sz, vp]),
         "mfh_add_dotp": (i32, [vp, vp, vp, vp, sz]),
+        "mfh_resident_row_bytes": (sz, [vp]),
+        "mfh_crs_expand": (i32, [vp, u64, sz, vp, vp]),
+        "mfh_eval_rows_resident": (i32, [vp, vp, sz, sz, vp, vp, vp, vp, i32]),
+        "mfh_crs_set_resident": (i32, [vp, vp]),
         "mfh_timing_drain": (i32, [vp, ctypes.c_char_p, ctypes.POINTER(u64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(u64),
                                    ctypes.POINTER(ctypes.c_float)]),
     }
@@ -356,3 +361,27 @@ class Context:
         """mpz_add_dotp (src/lwe.c:20-28) on device values"""
         self._chk(self.lib.mfh_add_dotp(self._h, _ptr(rop), _ptr(a), _ptr(b), length))
         return rop
+
+    # -- resident (materialised) CRS ------------------------------------------------------------------------------
+    def resident_row_bytes(self):
+        return int(self.lib.mfh_resident_row_bytes(self._h))
+
+    def crs_expand(self, off, nrows, c8, out=None):
+        """expand rows (a-vectors from the stream + b from c8) once into the streaming layout"""
+        out = self.empty(nrows * self.resident_row_bytes()) if out is None else out
+        self._chk(self.lib.mfh_crs_expand(self._h, off, nrows, _ptr(c8), _ptr(out)))
+        return out
+
+    def eval_rows_resident(self, rows, first_row, nrows, coeff0, coeff1=None, rop0=None, rop1=None, accumulate=False):
+        p = self.params
+        if rop0 is None:
+            rop0 = self.empty(p.ct_limbs * 8)
+        if coeff1 is not None and rop1 is None:
+            rop1 = self.empty(p.ct_limbs * 8)
+        self._chk(self.lib.mfh_eval_rows_resident(self._h, _ptr(rows), first_row, nrows, _ptr(coeff0), _ptr(coeff1), _ptr(rop0), _ptr(rop1),
+                                                  1 if accumulate else 0))
+        return rop0, rop1
+
+    def set_resident(self, rows):
+        self._resident = rows  # keep the tensor alive
+        self._chk(self.lib.mfh_crs_set_resident(self._h, _ptr(rows)))

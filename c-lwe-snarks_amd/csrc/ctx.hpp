@@ -36,7 +36,7 @@ struct mfh_ctx {
   bool timing = false;
   struct Timed {
     hipEvent_t e0, e1;
-    int kind;        // 0 keystream, 1 eval (1 coeff vector), 2 eval (2 vectors), 3 encrypt
+    int kind;        // 0 keystream, 1/2 eval (1/2 coeff vectors), 3 encrypt, 4 expand, 5/6 resident MAC (1/2 vectors)
     uint64_t rows;   // rows handed to the launch
   };
   std::vector<Timed> timed;
@@ -49,6 +49,7 @@ struct mfh_ctx {
   uint32_t *d_prover = nullptr;  // prover polynomials w, v, h and the b_w coefficient vector
   size_t prover_words = 0;
   std::vector<uint32_t> h_cw;
+  const uint8_t *resident_rows = nullptr;  // expanded CRS (mfh_crs_expand layout) or null: regenerate the keystream
 };
 
 struct Timer {  // brackets one launch with events when timing is on; never synchronises

@@ -218,6 +218,129 @@ __global__ __launch_bounds__(PS<LOGQ>::THREADS) void k_eval(AesKey key, const ui
       part[((((uint64_t)blockIdx.y * S::ROWS + rs) * NACC + a) * S::KW + l) * NJ + j] = acc[a][l];
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Resident (materialised) CRS: SURVEY 8(d)'s second regime.  mfh_crs_expand writes every row once in a limb-plane
+// layout that the streaming MAC kernel reads with fully coalesced 16-byte loads:
+//   row r = [plane 0..NP16) of RS x uint4 | last plane of RS x uint2 (736) ]   RS = row stride in coordinates (n+1 rounded to 64)
+//   plane k holds words 4k..4k+3 of every coordinate; only the KW words that survive modq are stored (88 of 92 bytes).
+// Coordinate n of a row is its `b` (copied from the compressed CRS) so the MAC kernel has no special case.
+// ------------------------------------------------------------------------------------------------------
+template <int LOGQ>
+struct RL {  // resident layout
+  using S = PS<LOGQ>;
+  static constexpr int NP16 = S::KW / 4;           // full 16-byte planes (5 | 11)
+  static constexpr int TAIL = S::KW % 4;           // words in the last partial plane (2 | 2)
+  __host__ __device__ static constexpr uint32_t rs(uint32_t n) { return (n + 1 + 63) / 64 * 64; }
+  __host__ __device__ static constexpr uint64_t row_bytes(uint32_t n) { return (uint64_t)rs(n) * S::KW * 4; }
+};
+
+template <int LOGQ>
+__global__ __launch_bounds__(PS<LOGQ>::THREADS) void k_expand(AesKey key, const uint32_t *__restrict__ g_t0, uint64_t off, uint32_t n,
+                                                              uint32_t nrows, uint32_t rows_per_chunk, const uint8_t *__restrict__ c8,
+                                                              uint8_t *__restrict__ out) {
+  using S = PS<LOGQ>;
+  using R = RL<LOGQ>;
+  __shared__ __attribute__((aligned(16))) uint32_t lt[mf::kTabBytes / 4];
+  __shared__ __attribute__((aligned(16))) uint8_t ksbuf[S::ROWS][S::KS_BYTES];
+  mf::lds_fill_tab(lt, g_t0);
+  const uint8_t *tab = reinterpret_cast<const uint8_t *>(lt);
+  const mf::AesLane L = mf::aes_lane();
+  const uint32_t rs = threadIdx.x / S::TILE, t = threadIdx.x % S::TILE;
+  uint8_t *ks = ksbuf[rs];
+  const uint32_t j0 = blockIdx.x * S::TILE, j = j0 + t;
+  const uint32_t nelem = j0 >= n ? 0u : min((uint32_t)S::TILE, n - j0);
+  const uint32_t r0 = blockIdx.y * rows_per_chunk, r1 = min(nrows, r0 + rows_per_chunk);
+  const uint32_t RS = R::rs(n);
+  __syncthreads();
+  for (uint32_t rr = r0; rr < r1; rr += S::ROWS) {
+    const uint32_t row = rr + rs;
+    const bool have = row < r1;
+    uint32_t head = 0;
+    if (have) head = expand_tile_to_lds<LOGQ>(tab, L, key, ks, off + (uint64_t)row * n * S::CTB, j0, nelem, t);
+    __syncthreads();
+    if (have && j < RS) {
+      uint32_t a[S::KW];
+      if (j < n) {
+        const uint32_t *kw = reinterpret_cast<const uint32_t *>(ks + head) + t * S::EW;
+#pragma unroll
+        for (int l = 0; l < S::KW; l++) a[l] = kw[l];
+      } else if (j == n) {
+        const uint32_t *bw = reinterpret_cast<const uint32_t *>(c8 + (uint64_t)row * S::CTB);
+#pragma unroll
+        for (int l = 0; l < S::KW; l++) a[l] = bw[l];
+      } else {
+#pragma unroll
+        for (int l = 0; l < S::KW; l++) a[l] = 0;
+      }
+      uint8_t *rowp = out + (uint64_t)row * R::row_bytes(n);
+#pragma unroll
+      for (int k = 0; k < R::NP16; k++)
+        reinterpret_cast<uint4 *>(rowp + (uint64_t)k * RS * 16)[j] = make_uint4(a[4 * k], a[4 * k + 1], a[4 * k + 2], a[4 * k + 3]);
+      if (R::TAIL == 2)
+        reinterpret_cast<uint2 *>(rowp + (uint64_t)R::NP16 * RS * 16)[j] = make_uint2(a[4 * R::NP16], a[4 * R::NP16 + 1]);
+    }
+    __syncthreads();
+  }
+}
+
+// streaming MAC over resident rows: grid = (RS/64 column groups x nchunks), 256 threads = 4 waves; each wave owns 64
+// coordinates and walks its share of the active rows, two rows in flight.
+// part layout as k_eval's: part[((slab*NACC + a)*KW + l)*NJ + j], slab = chunk*4 + wave-in-block ... here one slab per block row-share.
+template <int LOGQ, int NACC>
+__global__ __launch_bounds__(256) void k_mac_resident(const uint8_t *__restrict__ rows, uint32_t n, const uint32_t *__restrict__ idx,
+                                                      const uint32_t *__restrict__ cnt, uint32_t row_base, const uint32_t *__restrict__ coeff0,
+                                                      const uint32_t *__restrict__ coeff1, uint32_t *__restrict__ part, uint32_t NJ) {
+  using S = PS<LOGQ>;
+  using R = RL<LOGQ>;
+  const uint32_t RS = R::rs(n);
+  const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t nact = cnt[0];
+  const uint32_t per = (nact + gridDim.y - 1) / gridDim.y;
+  const uint32_t k0 = blockIdx.y * per, k1 = min(nact, k0 + per);
+  uint32_t acc[NACC][S::KW];
+#pragma unroll
+  for (int a = 0; a < NACC; a++)
+#pragma unroll
+    for (int l = 0; l < S::KW; l++) acc[a][l] = 0;
+  if (j < RS) {
+    for (uint32_t k = k0; k < k1; k++) {
+      const uint32_t row = idx[k];
+      uint32_t c[NACC];
+      c[0] = coeff0[row];
+      if constexpr (NACC > 1) c[1] = coeff1[row];
+      const uint8_t *rowp = rows + (uint64_t)(row_base + row) * R::row_bytes(n);
+      uint32_t a[S::KW];
+#pragma unroll
+      for (int q = 0; q < R::NP16; q++) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(rowp + (uint64_t)q * RS * 16) + j);
+        a[4 * q] = v[0]; a[4 * q + 1] = v[1]; a[4 * q + 2] = v[2]; a[4 * q + 3] = v[3];
+      }
+      if (R::TAIL == 2) {
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(rowp + (uint64_t)R::NP16 * RS * 16) + j);
+        a[4 * R::NP16] = v[0]; a[4 * R::NP16 + 1] = v[1];
+      }
+#pragma unroll
+      for (int q = 0; q < NACC; q++) {
+        uint32_t carry = 0;
+#pragma unroll
+        for (int l = 0; l < S::KW; l++) {
+          uint64_t tt = (uint64_t)a[l] * c[q] + acc[q][l] + carry;
+          acc[q][l] = (uint32_t)tt;
+          carry = (uint32_t)(tt >> 32);
+        }
+      }
+    }
+  }
+  if (j < NJ) {
+#pragma unroll
+    for (int a = 0; a < NACC; a++)
+#pragma unroll
+      for (int l = 0; l < S::KW; l++) part[(((uint64_t)blockIdx.y * NACC + a) * S::KW + l) * NJ + j] = j < RS ? acc[a][l] : 0u;
+  }
+}
+
 // Partial-sum reduction, stage 1: lazy[(a*KW + l)*NJ + j] = sum over slabs of the 32-bit partial words (uint64, no carries yet).
 // grid = (NJ/256, KW, nacc): every load is a coalesced run over j.
 template <int LOGQ>
@@ -641,6 +764,9 @@ static int timing_kind(const char *which) {
   if (!strcmp(which, "eval2")) return 2;
   if (!strcmp(which, "encrypt")) return 3;
   if (!strcmp(which, "eval")) return 12;  // either eval flavour
+  if (!strcmp(which, "expand")) return 4;
+  if (!strcmp(which, "mac1")) return 5;
+  if (!strcmp(which, "mac2")) return 6;
   return -1;
 }
 
@@ -811,6 +937,59 @@ static int eval_rows(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *c8, 
   return MFH_OK;
 }
 
+template <int LOGQ>
+static int crs_expand(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *c8, uint8_t *out) {
+  using S = PS<LOGQ>;
+  const uint32_t n = c->P.n;
+  const uint32_t RS = RL<LOGQ>::rs(n);
+  const uint32_t ntiles = (RS + S::TILE - 1) / S::TILE;
+  const uint32_t nchunks = pick_chunks((uint32_t)nrows, ntiles, S::ROWS);
+  uint32_t rpc = ((uint32_t)nrows + nchunks - 1) / nchunks;
+  rpc = (rpc + S::ROWS - 1) / S::ROWS * S::ROWS;
+  const uint32_t gy = ((uint32_t)nrows + rpc - 1) / rpc;
+  {
+    Timer t(c, 4, nrows);
+    hipLaunchKernelGGL(k_expand<LOGQ>, dim3(ntiles, gy), dim3(S::THREADS), 0, c->stream, c->key, c->d_t0, off, n, (uint32_t)nrows, rpc, c8, out);
+  }
+  HIP_TRY(c, hipGetLastError());
+  return MFH_OK;
+}
+
+template <int LOGQ>
+static int eval_rows_resident(mfh_ctx *c, const uint8_t *rows, size_t row_base, size_t nrows, const uint32_t *c0, const uint32_t *c1,
+                              uint64_t *rop0, uint64_t *rop1, int accumulate) {
+  using S = PS<LOGQ>;
+  const uint32_t n = c->P.n;
+  const uint32_t RS = RL<LOGQ>::rs(n);
+  const int nacc = c1 ? 2 : 1;
+  const uint32_t gx = (RS + 255) / 256;
+  const uint32_t NJ = gx * 256;
+  const uint32_t nchunks = std::max(1u, std::min((uint32_t)nrows, (256u * 8u) / gx));  // ~8 workgroups of 4 waves per CU
+  const size_t part_bytes = (size_t)nchunks * nacc * S::KW * NJ * 4;
+  const size_t lazy_bytes = (size_t)nacc * S::KW * NJ * 8;
+  const size_t idx_bytes = (((size_t)nrows + 1) * 4 + 255) & ~(size_t)255;
+  int rc = ws_reserve(c, part_bytes + lazy_bytes + idx_bytes);
+  if (rc) return rc;
+  uint32_t *part = (uint32_t *)c->ws;
+  uint64_t *lazy = (uint64_t *)((uint8_t *)c->ws + part_bytes);
+  uint32_t *idx = (uint32_t *)((uint8_t *)c->ws + part_bytes + lazy_bytes);
+  uint32_t *cnt = idx + nrows;
+  hipLaunchKernelGGL(k_compact_rows, dim3(1), dim3(1024), 0, c->stream, c0, c1, (uint32_t)nrows, idx, cnt);
+  HIP_TRY(c, hipGetLastError());
+  {
+    Timer t(c, 4 + nacc, nrows);
+    if (nacc == 2)
+      hipLaunchKernelGGL((k_mac_resident<LOGQ, 2>), dim3(gx, nchunks), dim3(256), 0, c->stream, rows, n, idx, cnt, (uint32_t)row_base, c0, c1, part, NJ);
+    else
+      hipLaunchKernelGGL((k_mac_resident<LOGQ, 1>), dim3(gx, nchunks), dim3(256), 0, c->stream, rows, n, idx, cnt, (uint32_t)row_base, c0, c1, part, NJ);
+  }
+  HIP_TRY(c, hipGetLastError());
+  hipLaunchKernelGGL(k_eval_reduce_sum<LOGQ>, dim3((NJ + 255) / 256, S::KW, nacc), dim3(256), 0, c->stream, part, nchunks, (uint32_t)nacc, NJ, lazy);
+  hipLaunchKernelGGL(k_eval_reduce_carry<LOGQ>, dim3((n + 1 + 255) / 256, nacc), dim3(256), 0, c->stream, lazy, NJ, n, rop0, rop1, accumulate);
+  HIP_TRY(c, hipGetLastError());
+  return MFH_OK;
+}
+
 extern "C" {
 
 int mfh_eval_rows(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d_c8, const uint32_t *d_coeff0, const uint32_t *d_coeff1,
@@ -829,6 +1008,43 @@ int mfh_eval_rows(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d_c8, c
   }
   DISPATCH_LOGQ(c, return eval_rows<736>(c, off, nrows, d_c8, d_coeff0, d_coeff1, d_rop0, d_rop1, accumulate),
                 return eval_rows<1472>(c, off, nrows, d_c8, d_coeff0, d_coeff1, d_rop0, d_rop1, accumulate));
+}
+
+size_t mfh_resident_row_bytes(const mfh_ctx *c) {
+  if (!c) return 0;
+  return c->P.logq == 736 ? (size_t)RL<736>::row_bytes(c->P.n) : (size_t)RL<1472>::row_bytes(c->P.n);
+}
+
+int mfh_crs_expand(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d_c8, void *d_rows_out) {
+  if (!c || (nrows && (!d_c8 || !d_rows_out)) || nrows > 0xffffffffu) return MFH_EINVAL;
+  NEED_SEED(c);
+  if (!nrows) return MFH_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  DISPATCH_LOGQ(c, return crs_expand<736>(c, off, nrows, d_c8, (uint8_t *)d_rows_out), return crs_expand<1472>(c, off, nrows, d_c8, (uint8_t *)d_rows_out));
+}
+
+int mfh_eval_rows_resident(mfh_ctx *c, const void *d_rows, size_t first_row, size_t nrows, const uint32_t *d_coeff0, const uint32_t *d_coeff1,
+                           uint64_t *d_rop0, uint64_t *d_rop1, int accumulate) {
+  if (!c || !d_rop0 || (nrows && (!d_rows || !d_coeff0)) || ((d_coeff1 == nullptr) != (d_rop1 == nullptr)) || nrows > 0xffffffffu ||
+      first_row > 0xffffffffu)
+    return MFH_EINVAL;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (nrows == 0) {
+    if (!accumulate) {
+      size_t bytes = (size_t)(c->P.n + 1) * ((c->P.logq + 63) / 64) * 8;
+      HIP_TRY(c, hipMemsetAsync(d_rop0, 0, bytes, c->stream));
+      if (d_rop1) HIP_TRY(c, hipMemsetAsync(d_rop1, 0, bytes, c->stream));
+    }
+    return MFH_OK;
+  }
+  DISPATCH_LOGQ(c, return eval_rows_resident<736>(c, (const uint8_t *)d_rows, first_row, nrows, d_coeff0, d_coeff1, d_rop0, d_rop1, accumulate),
+                return eval_rows_resident<1472>(c, (const uint8_t *)d_rows, first_row, nrows, d_coeff0, d_coeff1, d_rop0, d_rop1, accumulate));
+}
+
+int mfh_crs_set_resident(mfh_ctx *c, const void *d_rows) {
+  if (!c) return MFH_EINVAL;
+  c->resident_rows = (const uint8_t *)d_rows;
+  return MFH_OK;
 }
 
 }  // extern "C"

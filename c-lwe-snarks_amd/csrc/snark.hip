@@ -202,7 +202,9 @@ int mfh_prove_partial(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp
   const uint64_t ctr_ct = (uint64_t)ctb * n;
   uint32_t lo, cnt;
   share(m, lo, cnt);
-  rc = mfh_eval_rows(c, 2 * ctr_ct * d + ctr_ct * lo, cnt, d_crs_c8 + ((size_t)2 * d + lo) * ctb, cw + lo, nullptr, pi_b_w, nullptr, 0);
+  const void *res = c->resident_rows;
+  rc = res ? mfh_eval_rows_resident(c, res, (size_t)2 * d + lo, cnt, cw + lo, nullptr, pi_b_w, nullptr, 0)
+           : mfh_eval_rows(c, 2 * ctr_ct * d + ctr_ct * lo, cnt, d_crs_c8 + ((size_t)2 * d + lo) * ctb, cw + lo, nullptr, pi_b_w, nullptr, 0);
   if (rc) return rc;
   // v = w + v_0 ; h = (v^2 - 1) / t   (src/snark.c:161-169)
   rc = mfh_poly_add(c, w, d_ssp + (size_t)d, d, v);
@@ -211,6 +213,11 @@ int mfh_prove_partial(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp
   if (rc) return rc;
   // S rows: (w, h) -> (v_w, h);  AS rows: (v, h) -> (hat_v, hat_h)   (src/snark.c:157-158,163-164,171-174, each row expanded once)
   share(d, lo, cnt);
+  if (res) {
+    rc = mfh_eval_rows_resident(c, res, lo, cnt, w + lo, h + lo, pi_v_w, pi_h, 0);
+    if (rc) return rc;
+    return mfh_eval_rows_resident(c, res, (size_t)d + lo, cnt, v + lo, h + lo, pi_hat_v, pi_hat_h, 0);
+  }
   rc = mfh_eval_rows(c, ctr_ct * lo, cnt, d_crs_c8 + (size_t)lo * ctb, w + lo, h + lo, pi_v_w, pi_h, 0);
   if (rc) return rc;
   return mfh_eval_rows(c, ctr_ct * ((uint64_t)d + lo), cnt, d_crs_c8 + ((size_t)d + lo) * ctb, v + lo, h + lo, pi_hat_v, pi_hat_h, 0);

@@ -86,6 +86,19 @@ int mfh_ct_addmul_ui(mfh_ctx *ctx, uint64_t *d_rop, const uint64_t *d_a, uint32_
 int mfh_eval_rows(mfh_ctx *ctx, uint64_t off, size_t nrows, const uint8_t *d_c8, const uint32_t *d_coeff0,
                   const uint32_t *d_coeff1, uint64_t *d_rop0, uint64_t *d_rop1, int accumulate);
 
+/* ---- resident (materialised) CRS: SURVEY 8(d)'s second regime ---------------------------------------------------
+ * The reference regenerates the a-vectors of every CRS row from the seed on every use (ct_import, src/lwe.c:122-126).
+ * With 288 GB of HBM they can instead be expanded ONCE (11.3 GB for the default CRS) and streamed at HBM speed:
+ * mfh_crs_expand writes rows [off/CTR_CT ...) in a limb-plane layout (mfh_resident_row_bytes() per row: only the words that
+ * survive modq, coordinate n = the row's b); mfh_eval_rows_resident is eval_poly over rows [first_row, first_row+nrows)
+ * of such an image (coefficient i belongs to row first_row + i).  mfh_crs_set_resident(ctx, image) makes
+ * mfh_prove / mfh_prove_partial use the image (row index = position in stream order from CTR_S); NULL reverts. */
+size_t mfh_resident_row_bytes(const mfh_ctx *ctx);
+int mfh_crs_expand(mfh_ctx *ctx, uint64_t off, size_t nrows, const uint8_t *d_c8, void *d_rows_out);
+int mfh_eval_rows_resident(mfh_ctx *ctx, const void *d_rows, size_t first_row, size_t nrows, const uint32_t *d_coeff0,
+                           const uint32_t *d_coeff1, uint64_t *d_rop0, uint64_t *d_rop1, int accumulate);
+int mfh_crs_set_resident(mfh_ctx *ctx, const void *d_rows);
+
 /* Batched regev_encrypt2 + ct_export (src/lwe.c:78-97,115-119): for i < nrows
  *   b_i = (e_i*p + <sk, a_i> + m_i) mod 2^(64K),  a_i = row at stream offset off + i*n*CT_BYTES
  * d_sk: n values; d_msg: nrows uint32 (< p); d_err: nrows values (the sampled error e, any L-limb value;
@@ -159,7 +172,7 @@ size_t mfh_workspace_bytes(const mfh_ctx *ctx);
 /* Kernel timing for the roofline leg of bench.py.  With timing enabled every launch of a hot kernel is bracketed by
  * HIP events on the context's stream (no synchronisation is added).  mfh_timing_drain waits for the stream, then
  * reports and forgets the launches of kind `which`: "eval2" / "eval1" (k_eval with 2 / 1 coefficient vectors),
- * "eval" (both), "encrypt", "keystream".  total_rows = rows handed to those launches (AES blocks for "keystream"). */
+ * "eval" (both), "encrypt", "keystream", "expand", "mac2" / "mac1" (resident MAC).  total_rows = rows handed to those launches (AES blocks for "keystream"). */
 int mfh_set_timing(mfh_ctx *ctx, int enabled);
 int mfh_timing_drain(mfh_ctx *ctx, const char *which, uint64_t *count, double *total_ms, uint64_t *total_rows, float *last_ms);
 float mfh_last_kernel_ms(mfh_ctx *ctx, const char *which); /* = last_ms of mfh_timing_drain; < 0 if none */

@@ -195,3 +195,39 @@ def test_sharded_prover_equals_single(ctx, oracle, instance, mf):
     assert np.array_equal(mfdist.lanes_from_limbs_cpu(limbs, p.K).reshape(-1), ctx.to_host(ctx.ct_to_lanes(part, 5), np.int64))
     assert np.array_equal(mfdist.limbs_from_lanes_cpu(ctx.to_host(lanes, np.int64).reshape(5, p.n + 1, 2 * p.K), p.L, p.K).reshape(-1),
                           ctx.to_host(ctx.ct_from_lanes(lanes, 5), np.uint64))
+
+
+def test_resident_crs_matches_regenerated(ctx, oracle, instance, mf):
+    """SURVEY 8(d) second regime: rows expanded once into the streaming layout give the same eval_poly results and the
+    same proof as regenerating the keystream."""
+    I = instance
+    p = I["p"]
+    d_crs = ctx.to_device(_crs_stream_order(p, I["crs"]))
+    nrows_all = 2 * p.d + p.m
+    image = ctx.crs_expand(0, nrows_all, d_crs)
+    assert image.numel() == nrows_all * ctx.resident_row_bytes()
+    rng = np.random.default_rng(21)
+    for first, nrows in [(0, 37), (p.d, 64), (2 * p.d, p.m), (5, 1)]:
+        co = [rng.integers(0, ol.P, size=nrows, dtype=np.uint64) for _ in range(2)]
+        co[0][0] = 0
+        if nrows > 3:
+            co[1][3] = 0
+            co[0][3] = 0
+        d_co = [ctx.to_device(c.astype(np.uint32)) for c in co]
+        r0, r1 = ctx.eval_rows_resident(image, first, nrows, d_co[0], d_co[1])
+        e0, e1 = ctx.eval_rows(first * p.ctr_ct, nrows, d_crs[first * p.ctb:], d_co[0], d_co[1])
+        assert np.array_equal(ctx.to_host(r0), ctx.to_host(e0)) and np.array_equal(ctx.to_host(r1), ctx.to_host(e1))
+        exp = oracle.eval_poly(p, SEED, first * p.ctr_ct, ctx.to_host(d_crs)[first * p.ctb:(first + nrows) * p.ctb].tobytes(), co[0])
+        assert np.array_equal(ctx.to_host(r0, np.uint64).reshape(exp.shape), exp)
+        s0, _ = ctx.eval_rows_resident(image, first, nrows, d_co[1])
+        assert np.array_equal(ctx.to_host(s0), ctx.to_host(r1))
+    delta = 777
+    mags = rng.integers(0, 256, size=400, dtype=np.uint8).tobytes()
+    signs = bytes([1, 1, 0, 0, 1])
+    regen = ctx.to_host(ctx.prove(d_crs, I["d_ssp"], I["bits"], delta, mags, signs)).copy()
+    ctx.set_resident(image)
+    try:
+        res = ctx.to_host(ctx.prove(d_crs, I["d_ssp"], I["bits"], delta, mags, signs)).copy()
+    finally:
+        ctx.set_resident(None)
+    assert np.array_equal(regen, res)
