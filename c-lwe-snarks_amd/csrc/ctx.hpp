@@ -21,6 +21,14 @@
 
 struct PolyState;
 
+// pinned host staging buffer whose previous async copy is awaited only when the buffer is reused
+struct PinBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  hipEvent_t ev = nullptr;
+  bool pending = false;
+};
+
 struct mfh_ctx {
   mfh_params P{};
   int device = 0;
@@ -49,6 +57,7 @@ struct mfh_ctx {
   uint32_t *d_prover = nullptr;  // prover polynomials w, v, h and the b_w coefficient vector
   size_t prover_words = 0;
   std::vector<uint32_t> h_cw;
+  PinBuf pin_rows, pin_cw, pin_smudge;
   const uint8_t *resident_rows = nullptr;  // expanded CRS (mfh_crs_expand layout) or null: regenerate the keystream
 };
 
@@ -73,6 +82,27 @@ struct Timer {  // brackets one launch with events when timing is on; never sync
     c->timed.push_back(t);
   }
 };
+
+inline void *pin_acquire(mfh_ctx *c, PinBuf &b, size_t bytes) {
+  if (b.pending) { hipEventSynchronize(b.ev); b.pending = false; }
+  if (bytes > b.cap) {
+    if (b.p) hipHostFree(b.p);
+    b.cap = (bytes + 4095) & ~(size_t)4095;
+    if (hipHostMalloc(&b.p, b.cap, hipHostMallocDefault) != hipSuccess) { b.p = nullptr; b.cap = 0; c->err = "hipHostMalloc failed"; return nullptr; }
+  }
+  if (!b.ev) hipEventCreateWithFlags(&b.ev, hipEventDisableTiming);
+  return b.p;
+}
+inline void pin_release(mfh_ctx *c, PinBuf &b) {
+  hipEventRecord(b.ev, c->stream);
+  b.pending = true;
+}
+inline void pin_free(PinBuf &b) {
+  if (b.pending) hipEventSynchronize(b.ev);
+  if (b.p) hipHostFree(b.p);
+  if (b.ev) hipEventDestroy(b.ev);
+  b = PinBuf();
+}
 
 void mfh_poly_destroy(mfh_ctx *c);
 int aux_reserve(mfh_ctx *c, size_t bytes);

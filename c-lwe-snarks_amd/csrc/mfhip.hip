@@ -87,32 +87,19 @@ __global__ void k_repack_values(const uint32_t *__restrict__ ks, uint32_t *__res
 // Active-row compaction: idx[] = rows with a non-zero coefficient, cnt[0] = how many.  One workgroup.
 // (The reference expands zero-coefficient rows only to advance its stream, src/snark.c:147-155.)
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_compact_rows(const uint32_t *__restrict__ c0, const uint32_t *__restrict__ c1, uint32_t nrows,
-                                                       uint32_t *__restrict__ idx, uint32_t *__restrict__ cnt) {
-  __shared__ uint32_t wsum[16];
-  __shared__ uint32_t base;
-  if (threadIdx.x == 0) base = 0;
-  __syncthreads();
-  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (uint32_t r0 = 0; r0 < nrows; r0 += 1024) {
-    uint32_t r = r0 + threadIdx.x;
-    bool act = r < nrows && (c0[r] != 0 || (c1 && c1[r] != 0));
-    unsigned long long m = __ballot(act);
-    uint32_t before = __popcll(m & ((1ull << lane) - 1));
-    if (lane == 0) wsum[wave] = __popcll(m);
-    __syncthreads();
-    uint32_t wbase = base;
-    for (uint32_t w = 0; w < wave; w++) wbase += wsum[w];
-    if (act) idx[wbase + before] = r;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      uint32_t t = 0;
-      for (int w = 0; w < 16; w++) t += wsum[w];
-      base += t;
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) cnt[0] = base;
+__global__ __launch_bounds__(256) void k_compact_rows(const uint32_t *__restrict__ c0, const uint32_t *__restrict__ c1, uint32_t nrows,
+                                                      uint32_t *__restrict__ idx, uint32_t *__restrict__ cnt) {
+  // cnt[0] must be zero on entry.  The order of idx[] depends on scheduling; every consumer only sums over it, and the sums
+  // are exact integers mod 2^(64K), so results do not.
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t lane = threadIdx.x & 63;
+  const bool act = r < nrows && (c0[r] != 0 || (c1 && c1[r] != 0));
+  const unsigned long long m = __ballot(act);
+  if (!m) return;
+  uint32_t base = 0;
+  if (lane == 0) base = atomicAdd(cnt, (uint32_t)__popcll(m));
+  base = __shfl(base, 0);
+  if (act) idx[base + __popcll(m & ((1ull << lane) - 1))] = r;
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -346,27 +333,29 @@ __global__ __launch_bounds__(256) void k_mac_resident(const uint8_t *__restrict_
 template <int LOGQ>
 __global__ __launch_bounds__(256) void k_eval_reduce_sum(const uint32_t *__restrict__ part, uint32_t nslabs, uint32_t nacc, uint32_t NJ,
                                                          uint64_t *__restrict__ lazy) {
+  // grid = (NJ/256, KW * nacc, NG): slab group g sums slabs g, g+NG, ... ; lazy[g][(a*KW + l)*NJ + j]
   using S = PS<LOGQ>;
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t l = blockIdx.y, a = blockIdx.z;
+  const uint32_t l = blockIdx.y % S::KW, a = blockIdx.y / S::KW;
+  const uint32_t g = blockIdx.z, NG = gridDim.z;
   if (j >= NJ) return;
   const uint32_t *p = part + ((uint64_t)a * S::KW + l) * NJ + j;
   const uint64_t stride = (uint64_t)nacc * S::KW * NJ;
   uint64_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-  uint32_t ch = 0;
-  for (; ch + 4 <= nslabs; ch += 4) {
+  uint32_t ch = g;
+  for (; ch + 3 * NG < nslabs; ch += 4 * NG) {
     s0 += p[(uint64_t)ch * stride];
-    s1 += p[(uint64_t)(ch + 1) * stride];
-    s2 += p[(uint64_t)(ch + 2) * stride];
-    s3 += p[(uint64_t)(ch + 3) * stride];
+    s1 += p[(uint64_t)(ch + NG) * stride];
+    s2 += p[(uint64_t)(ch + 2 * NG) * stride];
+    s3 += p[(uint64_t)(ch + 3 * NG) * stride];
   }
-  for (; ch < nslabs; ch++) s0 += p[(uint64_t)ch * stride];
-  lazy[((uint64_t)a * S::KW + l) * NJ + j] = s0 + s1 + s2 + s3;
+  for (; ch < nslabs; ch += NG) s0 += p[(uint64_t)ch * stride];
+  lazy[((uint64_t)g * nacc * S::KW + (uint64_t)a * S::KW + l) * NJ + j] = s0 + s1 + s2 + s3;
 }
 // stage 2: propagate carries over the KW words of each coordinate, write natural-layout values (optionally += previous)
 template <int LOGQ>
-__global__ void k_eval_reduce_carry(const uint64_t *__restrict__ lazy, uint32_t NJ, uint32_t n, uint64_t *__restrict__ rop0,
-                                    uint64_t *__restrict__ rop1, int accumulate) {
+__global__ void k_eval_reduce_carry(const uint64_t *__restrict__ lazy, uint32_t NG, uint32_t nacc, uint32_t NJ, uint32_t n,
+                                    uint64_t *__restrict__ rop0, uint64_t *__restrict__ rop1, int accumulate) {
   using S = PS<LOGQ>;
   uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t a = blockIdx.y;
@@ -375,7 +364,8 @@ __global__ void k_eval_reduce_carry(const uint64_t *__restrict__ lazy, uint32_t 
   uint32_t *out = reinterpret_cast<uint32_t *>(rop + (uint64_t)j * S::L);
   uint64_t carry = 0;
   for (int l = 0; l < S::KW; l++) {
-    uint64_t s = lazy[((uint64_t)a * S::KW + l) * NJ + j] + carry;  // < 2^32 * slabs + carry: no overflow
+    uint64_t s = carry;  // < 2^32 * slabs + carry: no overflow
+    for (uint32_t g = 0; g < NG; g++) s += lazy[((uint64_t)g * nacc * S::KW + (uint64_t)a * S::KW + l) * NJ + j];
     if (accumulate) s += out[l];
     out[l] = (uint32_t)s;
     carry = s >> 32;
@@ -728,6 +718,9 @@ void mfh_ctx_destroy(mfh_ctx *c) {
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
   mfh_poly_destroy(c);
+  pin_free(c->pin_rows);
+  pin_free(c->pin_cw);
+  pin_free(c->pin_smudge);
   if (c->ws) hipFree(c->ws);
   if (c->aux) hipFree(c->aux);
   if (c->d_msg) hipFree(c->d_msg);
@@ -911,7 +904,8 @@ static int eval_rows(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *c8, 
   const uint32_t nslabs = nchunks * S::ROWS;
   const uint32_t NJ = ntiles * S::TILE;
   const size_t part_bytes = (size_t)nslabs * nacc * S::KW * NJ * 4;
-  const size_t lazy_bytes = (size_t)nacc * S::KW * NJ * 8;
+  const uint32_t NG = 8;  // slab groups of the first reduction stage
+  const size_t lazy_bytes = (size_t)NG * nacc * S::KW * NJ * 8;
   const size_t idx_bytes = (((size_t)nrows + 1) * 4 + 255) & ~(size_t)255;
   int rc = ws_reserve(c, part_bytes + lazy_bytes + idx_bytes);
   if (rc) return rc;
@@ -919,7 +913,8 @@ static int eval_rows(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *c8, 
   uint64_t *lazy = (uint64_t *)((uint8_t *)c->ws + part_bytes);
   uint32_t *idx = (uint32_t *)((uint8_t *)c->ws + part_bytes + lazy_bytes);
   uint32_t *cnt = idx + nrows;
-  hipLaunchKernelGGL(k_compact_rows, dim3(1), dim3(1024), 0, c->stream, c0, c1, (uint32_t)nrows, idx, cnt);
+  HIP_TRY(c, hipMemsetAsync(cnt, 0, 4, c->stream));
+  hipLaunchKernelGGL(k_compact_rows, dim3(((uint32_t)nrows + 255) / 256), dim3(256), 0, c->stream, c0, c1, (uint32_t)nrows, idx, cnt);
   HIP_TRY(c, hipGetLastError());
   {
     Timer t(c, nacc, nrows);
@@ -931,8 +926,9 @@ static int eval_rows(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *c8, 
                          part);
   }
   HIP_TRY(c, hipGetLastError());
-  hipLaunchKernelGGL(k_eval_reduce_sum<LOGQ>, dim3((NJ + 255) / 256, S::KW, nacc), dim3(256), 0, c->stream, part, nslabs, (uint32_t)nacc, NJ, lazy);
-  hipLaunchKernelGGL(k_eval_reduce_carry<LOGQ>, dim3((n + 1 + 255) / 256, nacc), dim3(256), 0, c->stream, lazy, NJ, n, rop0, rop1, accumulate);
+  hipLaunchKernelGGL(k_eval_reduce_sum<LOGQ>, dim3((NJ + 255) / 256, S::KW * nacc, NG), dim3(256), 0, c->stream, part, nslabs, (uint32_t)nacc, NJ, lazy);
+  hipLaunchKernelGGL(k_eval_reduce_carry<LOGQ>, dim3((n + 1 + 255) / 256, nacc), dim3(256), 0, c->stream, lazy, NG, (uint32_t)nacc, NJ, n, rop0, rop1,
+                     accumulate);
   HIP_TRY(c, hipGetLastError());
   return MFH_OK;
 }
@@ -966,7 +962,8 @@ static int eval_rows_resident(mfh_ctx *c, const uint8_t *rows, size_t row_base, 
   const uint32_t NJ = gx * 256;
   const uint32_t nchunks = std::max(1u, std::min((uint32_t)nrows, (256u * 8u) / gx));  // ~8 workgroups of 4 waves per CU
   const size_t part_bytes = (size_t)nchunks * nacc * S::KW * NJ * 4;
-  const size_t lazy_bytes = (size_t)nacc * S::KW * NJ * 8;
+  const uint32_t NG = 8;  // slab groups of the first reduction stage
+  const size_t lazy_bytes = (size_t)NG * nacc * S::KW * NJ * 8;
   const size_t idx_bytes = (((size_t)nrows + 1) * 4 + 255) & ~(size_t)255;
   int rc = ws_reserve(c, part_bytes + lazy_bytes + idx_bytes);
   if (rc) return rc;
@@ -974,7 +971,8 @@ static int eval_rows_resident(mfh_ctx *c, const uint8_t *rows, size_t row_base, 
   uint64_t *lazy = (uint64_t *)((uint8_t *)c->ws + part_bytes);
   uint32_t *idx = (uint32_t *)((uint8_t *)c->ws + part_bytes + lazy_bytes);
   uint32_t *cnt = idx + nrows;
-  hipLaunchKernelGGL(k_compact_rows, dim3(1), dim3(1024), 0, c->stream, c0, c1, (uint32_t)nrows, idx, cnt);
+  HIP_TRY(c, hipMemsetAsync(cnt, 0, 4, c->stream));
+  hipLaunchKernelGGL(k_compact_rows, dim3(((uint32_t)nrows + 255) / 256), dim3(256), 0, c->stream, c0, c1, (uint32_t)nrows, idx, cnt);
   HIP_TRY(c, hipGetLastError());
   {
     Timer t(c, 4 + nacc, nrows);
@@ -984,8 +982,9 @@ static int eval_rows_resident(mfh_ctx *c, const uint8_t *rows, size_t row_base, 
       hipLaunchKernelGGL((k_mac_resident<LOGQ, 1>), dim3(gx, nchunks), dim3(256), 0, c->stream, rows, n, idx, cnt, (uint32_t)row_base, c0, c1, part, NJ);
   }
   HIP_TRY(c, hipGetLastError());
-  hipLaunchKernelGGL(k_eval_reduce_sum<LOGQ>, dim3((NJ + 255) / 256, S::KW, nacc), dim3(256), 0, c->stream, part, nchunks, (uint32_t)nacc, NJ, lazy);
-  hipLaunchKernelGGL(k_eval_reduce_carry<LOGQ>, dim3((n + 1 + 255) / 256, nacc), dim3(256), 0, c->stream, lazy, NJ, n, rop0, rop1, accumulate);
+  hipLaunchKernelGGL(k_eval_reduce_sum<LOGQ>, dim3((NJ + 255) / 256, S::KW * nacc, NG), dim3(256), 0, c->stream, part, nchunks, (uint32_t)nacc, NJ, lazy);
+  hipLaunchKernelGGL(k_eval_reduce_carry<LOGQ>, dim3((n + 1 + 255) / 256, nacc), dim3(256), 0, c->stream, lazy, NG, (uint32_t)nacc, NJ, n, rop0, rop1,
+                     accumulate);
   HIP_TRY(c, hipGetLastError());
   return MFH_OK;
 }
@@ -1110,31 +1109,32 @@ int mfh_ct_smudge(mfh_ctx *c, uint64_t *d_cts, size_t count, const uint8_t *h_ma
   const uint32_t KW = 2 * (c->P.logq / 64);
   if (maglen + 4 > (size_t)KW * 4) { c->err = "smudge magnitude too wide"; return MFH_EINVAL; }
   HIP_TRY(c, hipSetDevice(c->device));
-  // u*p on the host (count is 5 per proof): schoolbook by 32-bit words
-  std::vector<uint32_t> up((size_t)count * KW, 0);
+  // u*p on the host (count is 5 per proof): schoolbook by 32-bit words, staged through pinned memory
+  const size_t ub = (size_t)count * KW * 4;
+  uint8_t *stage = (uint8_t *)pin_acquire(c, c->pin_smudge, ub + count);
+  if (!stage) return MFH_ENOMEM;
+  uint32_t *up = (uint32_t *)stage;
   for (size_t i = 0; i < count; i++) {
-    std::vector<uint8_t> m(((maglen + 3) / 4) * 4, 0);
-    memcpy(m.data(), h_mag + i * maglen, maglen);
     uint64_t carry = 0;
     for (uint32_t l = 0; l < KW; l++) {
       uint32_t w = 0;
-      if ((size_t)l * 4 < m.size()) memcpy(&w, m.data() + (size_t)l * 4, 4);
+      const size_t o = (size_t)l * 4;
+      if (o < maglen) memcpy(&w, h_mag + i * maglen + o, std::min<size_t>(4, maglen - o));
       uint64_t t = (uint64_t)w * MFH_P + carry;
       up[i * KW + l] = (uint32_t)t;
       carry = t >> 32;
     }
   }
-  const size_t ub = up.size() * 4;
-  int rc = ws_reserve(c, ub + count);
+  memcpy(stage + ub, h_sign, count);
+  int rc = aux_reserve(c, ub + count);
   if (rc) return rc;
-  HIP_TRY(c, hipMemcpyAsync(c->ws, up.data(), ub, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipMemcpyAsync((uint8_t *)c->ws + ub, h_sign, count, hipMemcpyHostToDevice, c->stream));
-  DISPATCH_LOGQ(c, hipLaunchKernelGGL(k_smudge<736>, dim3(((uint32_t)count + 63) / 64), dim3(64), 0, c->stream, d_cts, c->P.n, (const uint32_t *)c->ws,
-                                      (const uint8_t *)c->ws + ub, (uint32_t)count),
-                hipLaunchKernelGGL(k_smudge<1472>, dim3(((uint32_t)count + 63) / 64), dim3(64), 0, c->stream, d_cts, c->P.n, (const uint32_t *)c->ws,
-                                   (const uint8_t *)c->ws + ub, (uint32_t)count));
+  HIP_TRY(c, hipMemcpyAsync(c->aux, stage, ub + count, hipMemcpyHostToDevice, c->stream));
+  pin_release(c, c->pin_smudge);
+  DISPATCH_LOGQ(c, hipLaunchKernelGGL(k_smudge<736>, dim3(((uint32_t)count + 63) / 64), dim3(64), 0, c->stream, d_cts, c->P.n, (const uint32_t *)c->aux,
+                                      (const uint8_t *)c->aux + ub, (uint32_t)count),
+                hipLaunchKernelGGL(k_smudge<1472>, dim3(((uint32_t)count + 63) / 64), dim3(64), 0, c->stream, d_cts, c->P.n, (const uint32_t *)c->aux,
+                                   (const uint8_t *)c->aux + ub, (uint32_t)count));
   HIP_TRY(c, hipGetLastError());
-  HIP_TRY(c, hipStreamSynchronize(c->stream));  // host vectors go out of scope
   return MFH_OK;
 }
 
@@ -1164,22 +1164,23 @@ int mfh_witness_poly(mfh_ctx *c, const uint32_t *d_ssp, const uint8_t *h_bits, u
   const uint32_t d = c->P.d, m = c->P.m;
   if (d % 4) { c->err = "d must be a multiple of 4"; return MFH_EINVAL; }
   HIP_TRY(c, hipSetDevice(c->device));
-  std::vector<uint32_t> rows;
+  uint32_t *rows = (uint32_t *)pin_acquire(c, c->pin_rows, (size_t)m * 4 + 4);
+  if (!rows) return MFH_ENOMEM;
+  uint32_t nsel = 0;
   for (uint32_t i = 1; i < m; i++)
-    if ((h_bits[(i - 1) >> 3] >> ((i - 1) & 7)) & 1) rows.push_back(i + 1);  // slot of v_i
-  const uint32_t nsel = (uint32_t)rows.size();
+    if ((h_bits[(i - 1) >> 3] >> ((i - 1) & 7)) & 1) rows[nsel++] = i + 1;  // slot of v_i
   const uint32_t G = std::max(1u, std::min(64u, nsel / 8 + 1));
   const size_t rows_b = ((size_t)nsel * 4 + 255) & ~(size_t)255;
   int rc = ws_reserve(c, rows_b + (size_t)G * d * 8);
   if (rc) return rc;
   uint32_t *d_rows = (uint32_t *)c->ws;
   uint64_t *partial = (uint64_t *)((uint8_t *)c->ws + rows_b);
-  if (nsel) HIP_TRY(c, hipMemcpyAsync(d_rows, rows.data(), (size_t)nsel * 4, hipMemcpyHostToDevice, c->stream));
+  if (nsel) HIP_TRY(c, hipMemcpyAsync(d_rows, rows, (size_t)nsel * 4, hipMemcpyHostToDevice, c->stream));
+  pin_release(c, c->pin_rows);
   hipLaunchKernelGGL(k_witness_partial, dim3((d / 4 + 255) / 256, G), dim3(256), 0, c->stream, d_ssp, d_rows, nsel, d, partial);
   HIP_TRY(c, hipGetLastError());
   hipLaunchKernelGGL(k_witness_finish, dim3((d + 255) / 256), dim3(256), 0, c->stream, d_ssp, partial, G, d, delta, d_w);
   HIP_TRY(c, hipGetLastError());
-  HIP_TRY(c, hipStreamSynchronize(c->stream));  // `rows` goes out of scope
   return MFH_OK;
 }
 

@@ -92,6 +92,112 @@ __global__ void k_ntt_dit(uint32_t *__restrict__ a, uint32_t N, uint32_t len, co
   x[0] = add_mod(u, v, q.p);
   x[half] = sub_mod(u, v, q.p);
 }
+// ---- fused stages ---------------------------------------------------------------------------------------------
+// K consecutive DIF stages (block lengths len, len/2, ..., len>>(K-1)) in registers: a thread owns the 2^K elements
+// {s + j + m*q}, q = len >> K.  grid = (N >> K) threads x 3 primes.
+template <int K>
+__global__ __launch_bounds__(256) void k_ntt_dif_multi(uint32_t *__restrict__ a, uint32_t N, uint32_t len, const uint32_t *__restrict__ tw,
+                                                       uint32_t half_max, Primes3 P) {
+  constexpr int R = 1 << K;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (N >> K)) return;
+  const NttPrime q = P.q[blockIdx.y];
+  const uint32_t qd = len >> K;              // distance between a thread's elements
+  const uint32_t j = i & (qd - 1);
+  const uint32_t s = (i - j) << K;
+  uint32_t *x = a + (size_t)blockIdx.y * N + s + j;
+  const uint32_t *t = tw + (size_t)blockIdx.y * half_max;
+  uint32_t v[R];
+#pragma unroll
+  for (int m = 0; m < R; m++) v[m] = x[(size_t)m * qd];
+#pragma unroll
+  for (int st = 0; st < K; st++) {
+    const int h = R >> (st + 1);             // pair distance in register index
+    const uint32_t L = len >> st;            // block length of this stage
+    const uint32_t tstep = (half_max * 2) / L;
+#pragma unroll
+    for (int m = 0; m < R; m++) {
+      if ((m & h) == 0) {
+        const uint32_t pos = j + (uint32_t)(m & (h - 1)) * qd;  // position inside the half block
+        const uint32_t w = t[(size_t)pos * tstep];
+        const uint32_t u = v[m], z = v[m + h];
+        v[m] = add_mod(u, z, q.p);
+        v[m + h] = mont_mul(sub_mod(u, z, q.p), w, q.p, q.ninv);
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < R; m++) x[(size_t)m * qd] = v[m];
+}
+// K consecutive DIT stages with block lengths len, 2len, ..., len<<(K-1) (inverse twiddles)
+template <int K>
+__global__ __launch_bounds__(256) void k_ntt_dit_multi(uint32_t *__restrict__ a, uint32_t N, uint32_t len, const uint32_t *__restrict__ tw,
+                                                       uint32_t half_max, Primes3 P) {
+  constexpr int R = 1 << K;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (N >> K)) return;
+  const NttPrime q = P.q[blockIdx.y];
+  const uint32_t qd = len >> 1;              // distance between a thread's elements = half of the first stage
+  const uint32_t j = i & (qd - 1);
+  const uint32_t s = (i - j) << K;
+  uint32_t *x = a + (size_t)blockIdx.y * N + s + j;
+  const uint32_t *t = tw + (size_t)blockIdx.y * half_max;
+  uint32_t v[R];
+#pragma unroll
+  for (int m = 0; m < R; m++) v[m] = x[(size_t)m * qd];
+#pragma unroll
+  for (int st = 0; st < K; st++) {
+    const int h = 1 << st;
+    const uint32_t L = len << st;
+    const uint32_t tstep = (half_max * 2) / L;
+#pragma unroll
+    for (int m = 0; m < R; m++) {
+      if ((m & h) == 0) {
+        const uint32_t pos = j + (uint32_t)(m & (h - 1)) * qd;
+        const uint32_t w = t[(size_t)pos * tstep];
+        const uint32_t u = v[m], z = mont_mul(v[m + h], w, q.p, q.ninv);
+        v[m] = add_mod(u, z, q.p);
+        v[m + h] = sub_mod(u, z, q.p);
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < R; m++) x[(size_t)m * qd] = v[m];
+}
+// the lowest B stages (block lengths 2^B .. 2, or 2 .. 2^B for DIT) of every contiguous 2^B block, in LDS.  B <= 11.
+template <bool DIT>
+__global__ __launch_bounds__(256) void k_ntt_lds(uint32_t *__restrict__ a, uint32_t N, uint32_t B, const uint32_t *__restrict__ tw,
+                                                 uint32_t half_max, Primes3 P) {
+  __shared__ uint32_t sm[2048];
+  const NttPrime q = P.q[blockIdx.y];
+  const uint32_t BL = 1u << B;
+  uint32_t *x = a + (size_t)blockIdx.y * N + (size_t)blockIdx.x * BL;
+  const uint32_t *t = tw + (size_t)blockIdx.y * half_max;
+  for (uint32_t i = threadIdx.x; i < BL; i += 256) sm[i] = x[i];
+  __syncthreads();
+  for (uint32_t st = 0; st < B; st++) {
+    const uint32_t len = DIT ? (2u << st) : (BL >> st);
+    const uint32_t half = len >> 1, tstep = (half_max * 2) / len;
+    for (uint32_t i = threadIdx.x; i < BL / 2; i += 256) {
+      const uint32_t j = i & (half - 1);
+      const uint32_t p0 = ((i - j) << 1) + j;
+      const uint32_t w = t[(size_t)j * tstep];
+      const uint32_t u = sm[p0];
+      if (DIT) {
+        const uint32_t z = mont_mul(sm[p0 + half], w, q.p, q.ninv);
+        sm[p0] = add_mod(u, z, q.p);
+        sm[p0 + half] = sub_mod(u, z, q.p);
+      } else {
+        const uint32_t z = sm[p0 + half];
+        sm[p0] = add_mod(u, z, q.p);
+        sm[p0 + half] = mont_mul(sub_mod(u, z, q.p), w, q.p, q.ninv);
+      }
+    }
+    __syncthreads();
+  }
+  for (uint32_t i = threadIdx.x; i < BL; i += 256) x[i] = sm[i];
+}
+
 __global__ void k_pointwise(uint32_t *__restrict__ a, const uint32_t *__restrict__ b, uint32_t N, Primes3 P) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
@@ -244,14 +350,36 @@ uint32_t ceil_log2(size_t x) {
 void forward(mfh_ctx *c, uint32_t *buf, uint32_t logN) {
   PolyState *S = c->poly;
   const uint32_t N = 1u << logN, half_max = 1u << (S->logmax - 1);
-  for (uint32_t len = N; len >= 2; len >>= 1)
-    hipLaunchKernelGGL(k_ntt_dif, dim3((N / 2 + 255) / 256, 3), dim3(256), 0, c->stream, buf, N, len, S->d_tw, half_max, S->P);
+  const uint32_t B = std::min(logN, 11u);
+  uint32_t top = logN - B;  // stages with block length > 2^B, done in registers 3 (or fewer) at a time
+  uint32_t len = N;
+  while (top) {
+    const uint32_t k = std::min(top, 3u);
+    dim3 g(((N >> k) + 255) / 256, 3);
+    if (k == 3) hipLaunchKernelGGL(k_ntt_dif_multi<3>, g, dim3(256), 0, c->stream, buf, N, len, S->d_tw, half_max, S->P);
+    else if (k == 2) hipLaunchKernelGGL(k_ntt_dif_multi<2>, g, dim3(256), 0, c->stream, buf, N, len, S->d_tw, half_max, S->P);
+    else hipLaunchKernelGGL(k_ntt_dif_multi<1>, g, dim3(256), 0, c->stream, buf, N, len, S->d_tw, half_max, S->P);
+    len >>= k;
+    top -= k;
+  }
+  hipLaunchKernelGGL(k_ntt_lds<false>, dim3(N >> B, 3), dim3(256), 0, c->stream, buf, N, B, S->d_tw, half_max, S->P);
 }
 void inverse(mfh_ctx *c, uint32_t *buf, uint32_t logN) {
   PolyState *S = c->poly;
   const uint32_t N = 1u << logN, half_max = 1u << (S->logmax - 1);
-  for (uint32_t len = 2; len <= N; len <<= 1)
-    hipLaunchKernelGGL(k_ntt_dit, dim3((N / 2 + 255) / 256, 3), dim3(256), 0, c->stream, buf, N, len, S->d_twi, half_max, S->P);
+  const uint32_t B = std::min(logN, 11u);
+  hipLaunchKernelGGL(k_ntt_lds<true>, dim3(N >> B, 3), dim3(256), 0, c->stream, buf, N, B, S->d_twi, half_max, S->P);
+  uint32_t top = logN - B;
+  uint32_t len = 2u << B;  // block length of the first remaining stage
+  while (top) {
+    const uint32_t k = std::min(top, 3u);
+    dim3 g(((N >> k) + 255) / 256, 3);
+    if (k == 3) hipLaunchKernelGGL(k_ntt_dit_multi<3>, g, dim3(256), 0, c->stream, buf, N, len, S->d_twi, half_max, S->P);
+    else if (k == 2) hipLaunchKernelGGL(k_ntt_dit_multi<2>, g, dim3(256), 0, c->stream, buf, N, len, S->d_twi, half_max, S->P);
+    else hipLaunchKernelGGL(k_ntt_dit_multi<1>, g, dim3(256), 0, c->stream, buf, N, len, S->d_twi, half_max, S->P);
+    len <<= k;
+    top -= k;
+  }
 }
 Crt make_crt(const PolyState *S, uint32_t logN) {
   Crt C{};

@@ -195,10 +195,12 @@ int mfh_prove_partial(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp
   int rc = mfh_witness_poly(c, d_ssp, h_witness_bits, delta, w);
   if (rc) return rc;
   // b_w = delta * ct_t + sum_{bit} ct_{v_i}: rows BT, BV.. are m consecutive stream rows (src/snark.c:143-155)
-  c->h_cw.resize(m);
-  c->h_cw[0] = delta;
-  for (uint32_t i = 1; i < m; i++) c->h_cw[i] = (h_witness_bits[(i - 1) >> 3] >> ((i - 1) & 7)) & 1;
-  HIP_TRY(c, hipMemcpyAsync(cw, c->h_cw.data(), (size_t)m * 4, hipMemcpyHostToDevice, c->stream));
+  uint32_t *h_cw = (uint32_t *)pin_acquire(c, c->pin_cw, (size_t)m * 4);
+  if (!h_cw) return MFH_ENOMEM;
+  h_cw[0] = delta;
+  for (uint32_t i = 1; i < m; i++) h_cw[i] = (h_witness_bits[(i - 1) >> 3] >> ((i - 1) & 7)) & 1;
+  HIP_TRY(c, hipMemcpyAsync(cw, h_cw, (size_t)m * 4, hipMemcpyHostToDevice, c->stream));
+  pin_release(c, c->pin_cw);
   const uint64_t ctr_ct = (uint64_t)ctb * n;
   uint32_t lo, cnt;
   share(m, lo, cnt);
