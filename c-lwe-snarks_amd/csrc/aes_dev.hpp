@@ -134,6 +134,52 @@ __device__ __forceinline__ uint32_t aes_last(const uint8_t *tab, const AesLane &
   return MF_XOR3(lo, hi, rk);
 }
 
+// ---- counter-mode shortcut for rounds 1-2 (Bernstein-Schwabe style counter caching) ---------------------------
+// Input block = nonce || ctr: inside a span of 256 consecutive counters only byte 0 of column 2 changes.  Round 1 then
+// changes only through T0[b0(s2)] in column 2, and round 2 through the four bytes of that column:
+//   t2 = T0[b0(s2)] ^ C2 ;  u0 = D0 ^ T2[b2(t2)], u1 = D1 ^ T1[b1(t2)], u2 = D2 ^ T0[b0(t2)], u3 = D3 ^ T3[b3(t2)]
+// {C2, D0..D3} depend on ctr >> 8 only: 27 lookups once per span instead of 28 extra lookups per block.
+#define MF_T0AT(s, k) MF_LD(MF_A(s, L.lo0, k))
+#define MF_T2AT(s, k) MF_LD(MF_A(s, L.lo2, k))
+__device__ __forceinline__ uint32_t rotl8_(uint32_t x) { return __builtin_amdgcn_alignbit(x, x, 24); }
+
+__device__ __forceinline__ void aes_span_consts(const uint8_t *tab, const AesLane &L, const AesKey &k, uint64_t span /* ctr >> 8 */, uint32_t sc[5]) {
+  const uint64_t ctr = span << 8;
+  const uint32_t s0 = k.nonce_lo ^ k.rk[0], s1 = k.nonce_hi ^ k.rk[1];
+  const uint32_t s2 = (uint32_t)ctr ^ k.rk[2], s3 = (uint32_t)(ctr >> 32) ^ k.rk[3];  // byte 0 of s2 is not used below
+  const uint32_t t0 = aes_col(tab, L, s0, s1, s2, s3, k.rk[4]);
+  const uint32_t t1 = aes_col(tab, L, s1, s2, s3, s0, k.rk[5]);
+  const uint32_t t3 = aes_col(tab, L, s3, s0, s1, s2, k.rk[7]);
+  sc[0] = rotl8_(MF_T0AT(s3, 1) ^ MF_T2AT(s1, 3)) ^ MF_T2AT(s0, 2) ^ k.rk[6];                     // C2
+  sc[1] = MF_T0AT(t0, 0) ^ rotl8_(MF_T0AT(t1, 1) ^ MF_T2AT(t3, 3)) ^ k.rk[8];                     // D0
+  sc[2] = MF_T0AT(t1, 0) ^ MF_T2AT(t3, 2) ^ rotl8_(MF_T2AT(t0, 3)) ^ k.rk[9];                     // D1
+  sc[3] = rotl8_(MF_T0AT(t3, 1) ^ MF_T2AT(t1, 3)) ^ MF_T2AT(t0, 2) ^ k.rk[10];                    // D2
+  sc[4] = MF_T0AT(t3, 0) ^ rotl8_(MF_T0AT(t0, 1)) ^ MF_T2AT(t1, 2) ^ k.rk[11];                    // D3
+}
+
+// the same block as aes256_ctr_block, entering at round 3 with the span constants of ctr >> 8
+__device__ __forceinline__ void aes256_ctr_block_sc(const uint8_t *tab, const AesLane &L, const AesKey &k, uint64_t ctr, const uint32_t sc[5],
+                                                    uint32_t out[4]) {
+  const uint32_t s2 = (uint32_t)ctr ^ k.rk[2];
+  const uint32_t t2 = MF_T0AT(s2, 0) ^ sc[0];
+  uint32_t s0 = sc[1] ^ MF_T2AT(t2, 2);
+  uint32_t s1 = sc[2] ^ rotl8_(MF_T0AT(t2, 1));
+  uint32_t sB = sc[3] ^ MF_T0AT(t2, 0);
+  uint32_t s3 = sc[4] ^ rotl8_(MF_T2AT(t2, 3));
+#pragma unroll
+  for (int r = 3; r < 14; r++) {
+    uint32_t u0 = aes_col(tab, L, s0, s1, sB, s3, k.rk[4 * r]);
+    uint32_t u1 = aes_col(tab, L, s1, sB, s3, s0, k.rk[4 * r + 1]);
+    uint32_t u2 = aes_col(tab, L, sB, s3, s0, s1, k.rk[4 * r + 2]);
+    uint32_t u3 = aes_col(tab, L, s3, s0, s1, sB, k.rk[4 * r + 3]);
+    s0 = u0; s1 = u1; sB = u2; s3 = u3;
+  }
+  out[0] = aes_last(tab, L, s0, s1, sB, s3, k.rk[56]);
+  out[1] = aes_last(tab, L, s1, sB, s3, s0, k.rk[57]);
+  out[2] = aes_last(tab, L, sB, s3, s0, s1, k.rk[58]);
+  out[3] = aes_last(tab, L, s3, s0, s1, sB, k.rk[59]);
+}
+
 // One stream block: AES256_K(nonce_le64 || le64(ctr)) as 4 little-endian words.
 __device__ __forceinline__ void aes256_ctr_block(const uint8_t *tab, const AesLane &L, const AesKey &k, uint64_t ctr, uint32_t out[4]) {
   uint32_t s0 = k.nonce_lo ^ k.rk[0], s1 = k.nonce_hi ^ k.rk[1];

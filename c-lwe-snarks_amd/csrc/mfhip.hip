@@ -109,20 +109,48 @@ __global__ __launch_bounds__(256) void k_compact_rows(const uint32_t *__restrict
 // (block b -> thread b % TILE of round b / TILE), so a round in which a wave has no block is skipped by
 // that wave entirely: no half-empty issue slots.
 // ------------------------------------------------------------------------------------------------------
+constexpr int kSpanSlots = 16;  // a row tile covers <= 2945 blocks = at most 13 spans of 256 counters
+
+struct TileGeom {
+  uint64_t cb0;   // first AES block of the tile
+  uint32_t head;  // byte offset of the tile's first element inside that block
+  uint32_t nblk;
+};
 template <int LOGQ>
-__device__ __forceinline__ uint32_t expand_tile_to_lds(const uint8_t *tab, const mf::AesLane &L, const AesKey &key, uint8_t *ks,
-                                                       uint64_t rowoff, uint32_t j0, uint32_t nelem, uint32_t t) {
+__device__ __forceinline__ TileGeom tile_geom(uint64_t rowoff, uint32_t j0, uint32_t nelem) {
   using S = PS<LOGQ>;
   const uint64_t B0 = rowoff + (uint64_t)j0 * S::CTB;
-  const uint64_t cb0 = B0 >> 4;
-  const uint32_t head = (uint32_t)(B0 & 15);
-  const uint32_t nblk = (head + nelem * S::CTB + 15) >> 4;
-  for (uint32_t b = t; b < nblk; b += S::TILE) {
+  TileGeom g;
+  g.cb0 = B0 >> 4;
+  g.head = (uint32_t)(B0 & 15);
+  g.nblk = (g.head + nelem * S::CTB + 15) >> 4;
+  return g;
+}
+// threads t < (number of spans) fill spanc[t][0..5) for the tile (rounds 1-2 constants, aes_dev.hpp)
+__device__ __forceinline__ void fill_span_table(const uint8_t *tab, const mf::AesLane &L, const AesKey &key, const TileGeom &g, uint32_t t,
+                                                uint32_t (*spanc)[8]) {
+  const uint64_t sp0 = g.cb0 >> 8;
+  const uint32_t nsp = g.nblk ? (uint32_t)(((g.cb0 + g.nblk - 1) >> 8) - sp0 + 1) : 0;
+  if (t < nsp) {
+    uint32_t sc[5];
+    mf::aes_span_consts(tab, L, key, sp0 + t, sc);
+#pragma unroll
+    for (int i = 0; i < 5; i++) spanc[t][i] = sc[i];
+  }
+}
+template <int LOGQ>
+__device__ __forceinline__ void expand_tile_to_lds(const uint8_t *tab, const mf::AesLane &L, const AesKey &key, uint8_t *ks, const TileGeom &g,
+                                                   uint32_t t, const uint32_t (*spanc)[8]) {
+  using S = PS<LOGQ>;
+  const uint64_t sp0 = g.cb0 >> 8;
+  for (uint32_t b = t; b < g.nblk; b += S::TILE) {
+    const uint64_t ctr = g.cb0 + b;
+    const uint32_t *scp = spanc[(uint32_t)((ctr >> 8) - sp0)];
+    uint32_t sc[5] = {scp[0], scp[1], scp[2], scp[3], scp[4]};
     uint32_t w[4];
-    mf::aes256_ctr_block(tab, L, key, cb0 + b, w);
+    mf::aes256_ctr_block_sc(tab, L, key, ctr, sc, w);
     *reinterpret_cast<uint4 *>(ks + 16 * b) = make_uint4(w[0], w[1], w[2], w[3]);
   }
-  return head;
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -139,6 +167,7 @@ __global__ __launch_bounds__(PS<LOGQ>::THREADS) void k_eval(AesKey key, const ui
   using S = PS<LOGQ>;
   __shared__ __attribute__((aligned(16))) uint32_t lt[mf::kTabBytes / 4];
   __shared__ __attribute__((aligned(16))) uint8_t ksbuf[S::ROWS][S::KS_BYTES];
+  __shared__ uint32_t spanc[S::ROWS][kSpanSlots][8];
   mf::lds_fill_tab(lt, g_t0);
   const uint8_t *tab = reinterpret_cast<const uint8_t *>(lt);
   const mf::AesLane L = mf::aes_lane();
@@ -161,27 +190,44 @@ __global__ __launch_bounds__(PS<LOGQ>::THREADS) void k_eval(AesKey key, const ui
 #pragma unroll
     for (int l = 0; l < S::KW; l++) acc[a][l] = 0;
 
+  // span constants of the first row, then one barrier; afterwards they are refreshed during the previous row's MAC phase
+  TileGeom g{};
+  bool have = k0 + rs < k1;
+  uint32_t row = 0;
+  if (have) {
+    row = idx[k0 + rs];
+    g = tile_geom<LOGQ>(off + (uint64_t)row * n * S::CTB, j0, nelem);
+  }
+  __syncthreads();
+  if (have) fill_span_table(tab, L, key, g, t, spanc[rs]);
   __syncthreads();
   for (uint32_t kk = k0; kk < k1; kk += S::ROWS) {  // uniform trip count for the whole workgroup (barriers inside)
-    const uint32_t k = kk + rs;
-    const bool have = k < k1;  // uniform per row-half (a half is whole waves)
-    uint32_t row = 0, head = 0;
     uint32_t c[NACC];
     if (have) {
-      row = idx[k];
       c[0] = coeff0[row];
       if constexpr (NACC > 1) c[1] = coeff1[row];
-      head = expand_tile_to_lds<LOGQ>(tab, L, key, ks, off + (uint64_t)row * n * S::CTB, j0, nelem, t);
+      expand_tile_to_lds<LOGQ>(tab, L, key, ks, g, t, spanc[rs]);
     }
+    const uint32_t head = g.head;
+    const uint32_t cur_row = row;
+    const bool cur_have = have;
     __syncthreads();
-    if (have && j <= n) {
+    // next row of this half: geometry + span constants (nobody reads spanc until after the next barrier)
+    const uint32_t kn = kk + S::ROWS + rs;
+    have = kn < k1;
+    if (have) {
+      row = idx[kn];
+      g = tile_geom<LOGQ>(off + (uint64_t)row * n * S::CTB, j0, nelem);
+      fill_span_table(tab, L, key, g, t, spanc[rs]);
+    }
+    if (cur_have && j <= n) {
       uint32_t a[S::KW];
       if (j < n) {
         const uint32_t *kw = reinterpret_cast<const uint32_t *>(ks + head) + t * S::EW;
 #pragma unroll
         for (int l = 0; l < S::KW; l++) a[l] = kw[l];
       } else {
-        const uint32_t *bw = reinterpret_cast<const uint32_t *>(c8 + (uint64_t)row * S::CTB);
+        const uint32_t *bw = reinterpret_cast<const uint32_t *>(c8 + (uint64_t)cur_row * S::CTB);
 #pragma unroll
         for (int l = 0; l < S::KW; l++) a[l] = bw[l];
       }
@@ -229,6 +275,7 @@ __global__ __launch_bounds__(PS<LOGQ>::THREADS) void k_expand(AesKey key, const 
   using R = RL<LOGQ>;
   __shared__ __attribute__((aligned(16))) uint32_t lt[mf::kTabBytes / 4];
   __shared__ __attribute__((aligned(16))) uint8_t ksbuf[S::ROWS][S::KS_BYTES];
+  __shared__ uint32_t spanc[S::ROWS][kSpanSlots][8];
   mf::lds_fill_tab(lt, g_t0);
   const uint8_t *tab = reinterpret_cast<const uint8_t *>(lt);
   const mf::AesLane L = mf::aes_lane();
@@ -238,28 +285,39 @@ __global__ __launch_bounds__(PS<LOGQ>::THREADS) void k_expand(AesKey key, const 
   const uint32_t nelem = j0 >= n ? 0u : min((uint32_t)S::TILE, n - j0);
   const uint32_t r0 = blockIdx.y * rows_per_chunk, r1 = min(nrows, r0 + rows_per_chunk);
   const uint32_t RS = R::rs(n);
+  TileGeom g{};
+  uint32_t row = r0 + rs;
+  bool have = row < r1;
+  if (have) g = tile_geom<LOGQ>(off + (uint64_t)row * n * S::CTB, j0, nelem);
+  __syncthreads();
+  if (have) fill_span_table(tab, L, key, g, t, spanc[rs]);
   __syncthreads();
   for (uint32_t rr = r0; rr < r1; rr += S::ROWS) {
-    const uint32_t row = rr + rs;
-    const bool have = row < r1;
-    uint32_t head = 0;
-    if (have) head = expand_tile_to_lds<LOGQ>(tab, L, key, ks, off + (uint64_t)row * n * S::CTB, j0, nelem, t);
+    if (have) expand_tile_to_lds<LOGQ>(tab, L, key, ks, g, t, spanc[rs]);
+    const uint32_t head = g.head, cur_row = row;
+    const bool cur_have = have;
     __syncthreads();
-    if (have && j < RS) {
+    row = rr + S::ROWS + rs;
+    have = row < r1;
+    if (have) {
+      g = tile_geom<LOGQ>(off + (uint64_t)row * n * S::CTB, j0, nelem);
+      fill_span_table(tab, L, key, g, t, spanc[rs]);
+    }
+    if (cur_have && j < RS) {
       uint32_t a[S::KW];
       if (j < n) {
         const uint32_t *kw = reinterpret_cast<const uint32_t *>(ks + head) + t * S::EW;
 #pragma unroll
         for (int l = 0; l < S::KW; l++) a[l] = kw[l];
       } else if (j == n) {
-        const uint32_t *bw = reinterpret_cast<const uint32_t *>(c8 + (uint64_t)row * S::CTB);
+        const uint32_t *bw = reinterpret_cast<const uint32_t *>(c8 + (uint64_t)cur_row * S::CTB);
 #pragma unroll
         for (int l = 0; l < S::KW; l++) a[l] = bw[l];
       } else {
 #pragma unroll
         for (int l = 0; l < S::KW; l++) a[l] = 0;
       }
-      uint8_t *rowp = out + (uint64_t)row * R::row_bytes(n);
+      uint8_t *rowp = out + (uint64_t)cur_row * R::row_bytes(n);
 #pragma unroll
       for (int k = 0; k < R::NP16; k++)
         reinterpret_cast<uint4 *>(rowp + (uint64_t)k * RS * 16)[j] = make_uint4(a[4 * k], a[4 * k + 1], a[4 * k + 2], a[4 * k + 3]);
@@ -387,6 +445,7 @@ __global__ __launch_bounds__(PS<LOGQ>::THREADS) void k_encrypt(AesKey key, const
   __shared__ __attribute__((aligned(16))) uint32_t lt[mf::kTabBytes / 4];
   __shared__ __attribute__((aligned(16))) uint8_t ksbuf[S::ROWS][S::KS_BYTES];
   __shared__ uint64_t sums[S::ROWS][S::KW];
+  __shared__ uint32_t spanc[S::ROWS][kSpanSlots][8];
   mf::lds_fill_tab(lt, g_t0);
   const uint8_t *tab = reinterpret_cast<const uint8_t *>(lt);
   const mf::AesLane L = mf::aes_lane();
@@ -407,13 +466,25 @@ __global__ __launch_bounds__(PS<LOGQ>::THREADS) void k_encrypt(AesKey key, const
   }
   uint32_t *red = reinterpret_cast<uint32_t *>(ks);  // [KW][TILE] words, reuses this half's keystream tile
 
+  TileGeom g{};
+  uint32_t nrow = r0 + rs;
+  bool nhave = nrow < r1;
+  if (nhave) g = tile_geom<LOGQ>(off + (uint64_t)nrow * n * S::CTB, j0, nelem);
+  __syncthreads();
+  if (nhave) fill_span_table(tab, L, key, g, t, spanc[rs]);
   __syncthreads();
   for (uint32_t rr = r0; rr < r1; rr += S::ROWS) {
-    const uint32_t row = rr + rs;
-    const bool have = row < r1;
-    uint32_t head = 0;
-    if (have) head = expand_tile_to_lds<LOGQ>(tab, L, key, ks, off + (uint64_t)row * n * S::CTB, j0, nelem, t);
+    const uint32_t row = nrow;
+    const bool have = nhave;
+    if (have) expand_tile_to_lds<LOGQ>(tab, L, key, ks, g, t, spanc[rs]);
+    const uint32_t head = g.head;
     __syncthreads();
+    nrow = rr + S::ROWS + rs;
+    nhave = nrow < r1;
+    if (nhave) {  // next row's span constants (nobody reads spanc again before three more barriers)
+      g = tile_geom<LOGQ>(off + (uint64_t)nrow * n * S::CTB, j0, nelem);
+      fill_span_table(tab, L, key, g, t, spanc[rs]);
+    }
     uint32_t prod[S::KW];
 #pragma unroll
     for (int l = 0; l < S::KW; l++) prod[l] = 0;
