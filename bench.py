@@ -108,8 +108,15 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # MFUOCO_DIST_BACKEND=gloo + MFUOCO_SHARE_GPU=1 rehearse the multi-rank path on a one-GPU box (all ranks on cuda:0)
+        backend = os.environ.get("MFUOCO_DIST_BACKEND", "nccl")
+        if os.environ.get("MFUOCO_SHARE_GPU") == "1":
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         dist = None
         torch.cuda.set_device(0)

@@ -1,0 +1,114 @@
+"""GPU, BASELINE.json's full sizes (NDEBUG default instance: D = 2^15, M = 21845, 87 381 CRS rows, 11.8 GB of stream):
+size-independent properties instead of a full oracle run (the oracle needs ~2 minutes per full-size proof).
+
+  * acceptance: setup -> prover -> the four verifier equations on GPU-decrypted values (src/snark.c:192-250);
+    a flipped witness bit is rejected;
+  * linearity: eval(c0) + eval(c1) == eval(c0 + c1) over a whole region (exact, mod 2^704);
+  * the sharded prover (3 shares) and the resident-CRS regime give the byte-identical proof;
+  * sampled windows of the 11.8 GB stream against the oracle; sampled CRS rows decrypt to s^i / alpha*s^i;
+  * sampled rows of the full-size batched encryption against the oracle.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+SEED = bytes((91 * i + 7) & 0xFF for i in range(40))
+
+
+@pytest.fixture(scope="module")
+def world(gpu_ctx_factory):
+    import torch
+
+    import bench
+    import c_lwe_snarks_amd as mf
+
+    p = mf.DEFAULT
+    ctx = gpu_ctx_factory(p)
+    ctx.set_seed(SEED)
+    inst = bench.build_instance(mf, ctx, torch, p, 424242)
+    ctx.ssp_prepare(inst["d_ssp"])
+    d_crs = ctx.setup(inst["d_ssp"], inst["alpha"], inst["beta"], inst["s"], inst["sk"], inst["err"])
+    return dict(mf=mf, bench=bench, torch=torch, ctx=ctx, p=p, inst=inst, d_crs=d_crs)
+
+
+def _entropy(seed):
+    rng = np.random.default_rng(seed)
+    return int(rng.integers(0, ol.P, dtype=np.uint64)), rng.integers(0, 256, size=400, dtype=np.uint8).tobytes(), bytes(rng.integers(0, 2, size=5, dtype=np.uint8).tolist())
+
+
+def test_stream_windows_and_crs_rows(world, oracle):
+    W = world
+    ctx, p, inst = W["ctx"], W["p"], W["inst"]
+    end = (2 * p.d + p.m) * p.ctr_ct
+    for off in (0, p.ctr_as - 100, p.ctr_bt, p.ctr_bv + 12345 * p.ctr_ct + 4, end - 4096):
+        assert ctx.to_host(ctx.keystream(off, 4096)).tobytes() == oracle.keystream(SEED, off, 4096)
+    unit = ctx.to_device(np.ones(1, dtype=np.uint32))
+    for region_off, row0, i, expect in [(p.ctr_s, 0, 0, 1), (p.ctr_s, 0, 31000, pow(inst["s"], 31000, ol.P)),
+                                        (p.ctr_as, p.d, p.d - 1, inst["alpha"] * pow(inst["s"], p.d - 1, ol.P) % ol.P)]:
+        ct, _ = ctx.eval_rows(region_off + i * p.ctr_ct, 1, W["d_crs"][(row0 + i) * p.ctb:], unit)
+        assert int(ctx.to_host(ctx.decrypt(inst["sk"], ct, 1), np.uint32)[0]) == expect
+    # sampled rows of the 87 381-row batched encryption against the oracle's regev_encrypt2
+    sk = ctx.to_host(inst["sk"], np.uint64).reshape(p.n, p.L)
+    err = ctx.to_host(inst["err"], np.uint64).reshape(-1, p.L)
+    msg = ctx.to_host(ctx.setup_messages(inst["d_ssp"], inst["alpha"], inst["beta"], inst["s"]), np.uint32)
+    crs = ctx.to_host(W["d_crs"])
+    for i in (0, 1, 40001, 2 * p.d, 2 * p.d + p.m - 1):
+        r = oracle.rng(SEED, i * p.ctr_ct)
+        exp = oracle.ct_export(p, oracle.encrypt(p, r, sk, int(msg[i]), err[i]))
+        assert crs[i * p.ctb:(i + 1) * p.ctb].tobytes() == exp
+
+
+def test_full_size_proof_is_accepted_and_sound(world):
+    W = world
+    ctx, inst = W["ctx"], W["inst"]
+    delta, mags, signs = _entropy(1)
+    proof = ctx.prove(W["d_crs"], inst["d_ssp"], inst["bits"], delta, mags, signs)
+    assert W["bench"].verify_on_gpu(W["mf"], ctx, inst, proof)
+    bad = bytearray(inst["bits"])
+    bad[100] ^= 0x10
+    proof_bad = ctx.prove(W["d_crs"], inst["d_ssp"], bytes(bad), delta, mags, signs)
+    assert not W["bench"].verify_on_gpu(W["mf"], ctx, inst, proof_bad)
+    W["proof"] = proof.clone()
+    W["entropy"] = (delta, mags, signs)
+
+
+def test_sharded_and_resident_give_identical_proof(world):
+    W = world
+    ctx, p, inst, torch = W["ctx"], W["p"], W["inst"], W["torch"]
+    delta, mags, signs = W["entropy"]
+    lanes = None
+    for r in range(3):
+        part = ctx.prove_partial(W["d_crs"], inst["d_ssp"], inst["bits"], delta, r, 3)
+        ln = ctx.ct_to_lanes(part, 5).clone()
+        lanes = ln if lanes is None else lanes + ln
+    proof = ctx.ct_from_lanes(lanes, 5)
+    ctx.prove_finish(proof, mags, signs)
+    assert torch.equal(proof, W["proof"])
+    image = ctx.crs_expand(0, 2 * p.d + p.m, W["d_crs"])
+    ctx.set_resident(image)
+    try:
+        proof_r = ctx.prove(W["d_crs"], inst["d_ssp"], inst["bits"], delta, mags, signs)
+    finally:
+        ctx.set_resident(None)
+    assert torch.equal(proof_r, W["proof"])
+
+
+def test_linearity_over_a_whole_region(world):
+    W = world
+    ctx, p = W["ctx"], W["p"]
+    rng = np.random.default_rng(3)
+    c0 = rng.integers(0, 1 << 31, size=p.d, dtype=np.uint64)
+    c1 = rng.integers(0, 1 << 31, size=p.d, dtype=np.uint64)
+    d0, d1, d01 = (ctx.to_device(c.astype(np.uint32)) for c in (c0, c1, c0 + c1))
+    c8 = W["d_crs"][p.d * p.ctb:]
+    e0, e1 = ctx.eval_rows(p.ctr_as, p.d, c8, d0, d1)
+    e01, _ = ctx.eval_rows(p.ctr_as, p.d, c8, d01)
+    assert W["torch"].equal(ctx.ct_add(e0, e1), e01)
