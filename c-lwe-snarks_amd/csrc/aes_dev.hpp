@@ -115,7 +115,9 @@ __device__ __forceinline__ AesLane aes_lane() {
 
 #define MF_XOR3(a, b, c) __builtin_amdgcn_bitop3_b32((a), (b), (c), 0x96)
 #define MF_ANDOR(a, m, c) __builtin_amdgcn_bitop3_b32((a), (m), (c), 0xEA) /* (a & m) | c */
+#ifndef MF_LD  /* tools/aes3_ubench.hip overrides this to time the VALU stream alone */
 #define MF_LD(addr) (*reinterpret_cast<const uint32_t *>(tab + (addr)))
+#endif
 // address of entry byte_k(s) in the T0 (lo0) or T2 (lo2) half
 #define MF_A(s, lo, k) ((k) == 1 ? MF_ANDOR((s), L.m1, (lo)) : __builtin_amdgcn_perm((s), (lo), 0x0c0c0400u + ((k) << 8)))
 

@@ -391,7 +391,8 @@ __global__ __launch_bounds__(256) void k_mac_resident(const uint8_t *__restrict_
 template <int LOGQ>
 __global__ __launch_bounds__(256) void k_eval_reduce_sum(const uint32_t *__restrict__ part, uint32_t nslabs, uint32_t nacc, uint32_t NJ,
                                                          uint64_t *__restrict__ lazy) {
-  // grid = (NJ/256, KW * nacc, NG): slab group g sums slabs g, g+NG, ... ; lazy[g][(a*KW + l)*NJ + j]
+  // grid = (NJ/256, KW * nacc, NG): slab group g sums slabs g, g+NG, ... and adds into lazy[(a*KW + l)*NJ + j] (zeroed beforehand;
+  // integer atomics: the result does not depend on the order)
   using S = PS<LOGQ>;
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t l = blockIdx.y % S::KW, a = blockIdx.y / S::KW;
@@ -408,7 +409,7 @@ __global__ __launch_bounds__(256) void k_eval_reduce_sum(const uint32_t *__restr
     s3 += p[(uint64_t)(ch + 3 * NG) * stride];
   }
   for (; ch < nslabs; ch += NG) s0 += p[(uint64_t)ch * stride];
-  lazy[((uint64_t)g * nacc * S::KW + (uint64_t)a * S::KW + l) * NJ + j] = s0 + s1 + s2 + s3;
+  atomicAdd(reinterpret_cast<unsigned long long *>(&lazy[((uint64_t)a * S::KW + l) * NJ + j]), (unsigned long long)(s0 + s1 + s2 + s3));
 }
 // stage 2: propagate carries over the KW words of each coordinate, write natural-layout values (optionally += previous)
 template <int LOGQ>
@@ -422,8 +423,7 @@ __global__ void k_eval_reduce_carry(const uint64_t *__restrict__ lazy, uint32_t 
   uint32_t *out = reinterpret_cast<uint32_t *>(rop + (uint64_t)j * S::L);
   uint64_t carry = 0;
   for (int l = 0; l < S::KW; l++) {
-    uint64_t s = carry;  // < 2^32 * slabs + carry: no overflow
-    for (uint32_t g = 0; g < NG; g++) s += lazy[((uint64_t)g * nacc * S::KW + (uint64_t)a * S::KW + l) * NJ + j];
+    uint64_t s = lazy[((uint64_t)a * S::KW + l) * NJ + j] + carry;  // < 2^32 * slabs + carry: no overflow
     if (accumulate) s += out[l];
     out[l] = (uint32_t)s;
     carry = s >> 32;
@@ -976,7 +976,7 @@ static int eval_rows(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *c8, 
   const uint32_t NJ = ntiles * S::TILE;
   const size_t part_bytes = (size_t)nslabs * nacc * S::KW * NJ * 4;
   const uint32_t NG = 8;  // slab groups of the first reduction stage
-  const size_t lazy_bytes = (size_t)NG * nacc * S::KW * NJ * 8;
+  const size_t lazy_bytes = (size_t)nacc * S::KW * NJ * 8;
   const size_t idx_bytes = (((size_t)nrows + 1) * 4 + 255) & ~(size_t)255;
   int rc = ws_reserve(c, part_bytes + lazy_bytes + idx_bytes);
   if (rc) return rc;
@@ -997,6 +997,7 @@ static int eval_rows(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *c8, 
                          part);
   }
   HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemsetAsync(lazy, 0, lazy_bytes, c->stream));
   hipLaunchKernelGGL(k_eval_reduce_sum<LOGQ>, dim3((NJ + 255) / 256, S::KW * nacc, NG), dim3(256), 0, c->stream, part, nslabs, (uint32_t)nacc, NJ, lazy);
   hipLaunchKernelGGL(k_eval_reduce_carry<LOGQ>, dim3((n + 1 + 255) / 256, nacc), dim3(256), 0, c->stream, lazy, NG, (uint32_t)nacc, NJ, n, rop0, rop1,
                      accumulate);
@@ -1034,7 +1035,7 @@ static int eval_rows_resident(mfh_ctx *c, const uint8_t *rows, size_t row_base, 
   const uint32_t nchunks = std::max(1u, std::min((uint32_t)nrows, (256u * 8u) / gx));  // ~8 workgroups of 4 waves per CU
   const size_t part_bytes = (size_t)nchunks * nacc * S::KW * NJ * 4;
   const uint32_t NG = 8;  // slab groups of the first reduction stage
-  const size_t lazy_bytes = (size_t)NG * nacc * S::KW * NJ * 8;
+  const size_t lazy_bytes = (size_t)nacc * S::KW * NJ * 8;
   const size_t idx_bytes = (((size_t)nrows + 1) * 4 + 255) & ~(size_t)255;
   int rc = ws_reserve(c, part_bytes + lazy_bytes + idx_bytes);
   if (rc) return rc;
@@ -1053,6 +1054,7 @@ static int eval_rows_resident(mfh_ctx *c, const uint8_t *rows, size_t row_base, 
       hipLaunchKernelGGL((k_mac_resident<LOGQ, 1>), dim3(gx, nchunks), dim3(256), 0, c->stream, rows, n, idx, cnt, (uint32_t)row_base, c0, c1, part, NJ);
   }
   HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemsetAsync(lazy, 0, lazy_bytes, c->stream));
   hipLaunchKernelGGL(k_eval_reduce_sum<LOGQ>, dim3((NJ + 255) / 256, S::KW * nacc, NG), dim3(256), 0, c->stream, part, nchunks, (uint32_t)nacc, NJ, lazy);
   hipLaunchKernelGGL(k_eval_reduce_carry<LOGQ>, dim3((n + 1 + 255) / 256, nacc), dim3(256), 0, c->stream, lazy, NG, (uint32_t)nacc, NJ, n, rop0, rop1,
                      accumulate);

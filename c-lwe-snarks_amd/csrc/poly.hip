@@ -198,6 +198,54 @@ __global__ __launch_bounds__(256) void k_ntt_lds(uint32_t *__restrict__ a, uint3
   for (uint32_t i = threadIdx.x; i < BL; i += 256) x[i] = sm[i];
 }
 
+// forward low stages + pointwise product + inverse low stages of one 2^B block, all in LDS: a <- INTT_low( NTT_low(a) .* rhs ),
+// rhs = NTT_low-transformed b (b == nullptr: a itself, i.e. squaring; b_is_hat: b is already fully transformed, e.g. the cached G^).
+__global__ __launch_bounds__(256) void k_ntt_lds_mul(uint32_t *__restrict__ a, const uint32_t *__restrict__ b, int b_is_hat, uint32_t N, uint32_t B,
+                                                     const uint32_t *__restrict__ tw, const uint32_t *__restrict__ twi, uint32_t half_max, Primes3 P) {
+  __shared__ uint32_t sa[2048];
+  __shared__ uint32_t sb[2048];
+  const NttPrime q = P.q[blockIdx.y];
+  const uint32_t BL = 1u << B;
+  const size_t base = (size_t)blockIdx.y * N + (size_t)blockIdx.x * BL;
+  const uint32_t *t = tw + (size_t)blockIdx.y * half_max, *ti = twi + (size_t)blockIdx.y * half_max;
+  for (uint32_t i = threadIdx.x; i < BL; i += 256) {
+    sa[i] = a[base + i];
+    if (b) sb[i] = b[base + i];
+  }
+  __syncthreads();
+  const bool fwd_b = b && !b_is_hat;
+  for (uint32_t st = 0; st < B; st++) {
+    const uint32_t len = BL >> st, half = len >> 1, tstep = (half_max * 2) / len;
+    for (uint32_t i = threadIdx.x; i < BL / 2; i += 256) {
+      const uint32_t j = i & (half - 1), p0 = ((i - j) << 1) + j;
+      const uint32_t w = t[(size_t)j * tstep];
+      uint32_t u = sa[p0], z = sa[p0 + half];
+      sa[p0] = add_mod(u, z, q.p);
+      sa[p0 + half] = mont_mul(sub_mod(u, z, q.p), w, q.p, q.ninv);
+      if (fwd_b) {
+        u = sb[p0]; z = sb[p0 + half];
+        sb[p0] = add_mod(u, z, q.p);
+        sb[p0 + half] = mont_mul(sub_mod(u, z, q.p), w, q.p, q.ninv);
+      }
+    }
+    __syncthreads();
+  }
+  for (uint32_t i = threadIdx.x; i < BL; i += 256) sa[i] = mont_mul(sa[i], b ? sb[i] : sa[i], q.p, q.ninv);
+  __syncthreads();
+  for (uint32_t st = 0; st < B; st++) {
+    const uint32_t len = 2u << st, half = len >> 1, tstep = (half_max * 2) / len;
+    for (uint32_t i = threadIdx.x; i < BL / 2; i += 256) {
+      const uint32_t j = i & (half - 1), p0 = ((i - j) << 1) + j;
+      const uint32_t w = ti[(size_t)j * tstep];
+      const uint32_t u = sa[p0], z = mont_mul(sa[p0 + half], w, q.p, q.ninv);
+      sa[p0] = add_mod(u, z, q.p);
+      sa[p0 + half] = sub_mod(u, z, q.p);
+    }
+    __syncthreads();
+  }
+  for (uint32_t i = threadIdx.x; i < BL; i += 256) a[base + i] = sa[i];
+}
+
 __global__ void k_pointwise(uint32_t *__restrict__ a, const uint32_t *__restrict__ b, uint32_t N, Primes3 P) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
@@ -347,12 +395,11 @@ uint32_t ceil_log2(size_t x) {
   return l;
 }
 
-void forward(mfh_ctx *c, uint32_t *buf, uint32_t logN) {
+// the top (register) stages of a forward / inverse transform; the low B = min(logN, 11) stages run in LDS
+void forward_top(mfh_ctx *c, uint32_t *buf, uint32_t logN) {
   PolyState *S = c->poly;
   const uint32_t N = 1u << logN, half_max = 1u << (S->logmax - 1);
-  const uint32_t B = std::min(logN, 11u);
-  uint32_t top = logN - B;  // stages with block length > 2^B, done in registers 3 (or fewer) at a time
-  uint32_t len = N;
+  uint32_t top = logN - std::min(logN, 11u), len = N;
   while (top) {
     const uint32_t k = std::min(top, 3u);
     dim3 g(((N >> k) + 255) / 256, 3);
@@ -362,15 +409,12 @@ void forward(mfh_ctx *c, uint32_t *buf, uint32_t logN) {
     len >>= k;
     top -= k;
   }
-  hipLaunchKernelGGL(k_ntt_lds<false>, dim3(N >> B, 3), dim3(256), 0, c->stream, buf, N, B, S->d_tw, half_max, S->P);
 }
-void inverse(mfh_ctx *c, uint32_t *buf, uint32_t logN) {
+void inverse_top(mfh_ctx *c, uint32_t *buf, uint32_t logN) {
   PolyState *S = c->poly;
   const uint32_t N = 1u << logN, half_max = 1u << (S->logmax - 1);
   const uint32_t B = std::min(logN, 11u);
-  hipLaunchKernelGGL(k_ntt_lds<true>, dim3(N >> B, 3), dim3(256), 0, c->stream, buf, N, B, S->d_twi, half_max, S->P);
-  uint32_t top = logN - B;
-  uint32_t len = 2u << B;  // block length of the first remaining stage
+  uint32_t top = logN - B, len = 2u << B;
   while (top) {
     const uint32_t k = std::min(top, 3u);
     dim3 g(((N >> k) + 255) / 256, 3);
@@ -380,6 +424,12 @@ void inverse(mfh_ctx *c, uint32_t *buf, uint32_t logN) {
     len <<= k;
     top -= k;
   }
+}
+void forward(mfh_ctx *c, uint32_t *buf, uint32_t logN) {  // complete forward transform (used for the cached G^)
+  PolyState *S = c->poly;
+  const uint32_t N = 1u << logN, half_max = 1u << (S->logmax - 1), B = std::min(logN, 11u);
+  forward_top(c, buf, logN);
+  hipLaunchKernelGGL(k_ntt_lds<false>, dim3(N >> B, 3), dim3(256), 0, c->stream, buf, N, B, S->d_tw, half_max, S->P);
 }
 Crt make_crt(const PolyState *S, uint32_t logN) {
   Crt C{};
@@ -403,21 +453,24 @@ int poly_mul(mfh_ctx *c, const uint32_t *a, uint32_t la, const uint32_t *b, uint
     c->err = "poly_mul: size exceeds the prepared NTT length";
     return MFH_EINVAL;
   }
-  const uint32_t N = 1u << logN;
+  const uint32_t N = 1u << logN, half_max = 1u << (S->logmax - 1), B = std::min(logN, 11u);
   hipLaunchKernelGGL(k_ntt_load, dim3((N + 255) / 256, 3), dim3(256), 0, c->stream, a, la, N, S->P, S->d_bufA);
-  forward(c, S->d_bufA, logN);
-  const uint32_t *rhs = bhat;
+  forward_top(c, S->d_bufA, logN);
+  const uint32_t *rhs = bhat;  // already fully transformed
+  int is_hat = 1;
   if (!bhat) {
+    is_hat = 0;
     if (b == a && lb == la) {
-      rhs = S->d_bufA;
+      rhs = nullptr;  // square
     } else {
       hipLaunchKernelGGL(k_ntt_load, dim3((N + 255) / 256, 3), dim3(256), 0, c->stream, b, lb, N, S->P, S->d_bufB);
-      forward(c, S->d_bufB, logN);
+      forward_top(c, S->d_bufB, logN);
       rhs = S->d_bufB;
     }
   }
-  hipLaunchKernelGGL(k_pointwise, dim3((N + 255) / 256, 3), dim3(256), 0, c->stream, S->d_bufA, rhs, N, S->P);
-  inverse(c, S->d_bufA, logN);
+  // low forward stages of both operands, pointwise product, low inverse stages: one kernel, the block never leaves LDS
+  hipLaunchKernelGGL(k_ntt_lds_mul, dim3(N >> B, 3), dim3(256), 0, c->stream, S->d_bufA, rhs, is_hat, N, B, S->d_tw, S->d_twi, half_max, S->P);
+  inverse_top(c, S->d_bufA, logN);
   hipLaunchKernelGGL(k_crt, g1(keep), dim3(256), 0, c->stream, S->d_bufA, N, keep, S->P, make_crt(S, logN), out);
   HIP_TRY(c, hipGetLastError());
   return MFH_OK;
