@@ -88,6 +88,7 @@ EXPORTS = [
     "mfh_ssp_prepare", "mfh_poly_h", "mfh_setup_messages", "mfh_setup", "mfh_prove",
     "mfh_prove_partial", "mfh_prove_finish", "mfh_ct_to_lanes", "mfh_ct_from_lanes", "mfh_timing_drain", "mfh_add_dotp",
     "mfh_resident_row_bytes", "mfh_crs_expand", "mfh_eval_rows_resident", "mfh_crs_set_resident",
+    "mfh_witness_lanes", "mfh_witness_from_lanes", "mfh_prove_partial_w",
 ]
 
 
@@ -136,6 +137,9 @@ def load_library():
         "mfh_ct_to_lanes": (i32, [vp, vp, sz, vp]),
         "mfh_ct_from_lanes": (i32, [vp, vp, sz, vp]),
         "mfh_add_dotp": (i32, [vp, vp, vp, vp, sz]),
+        "mfh_witness_lanes": (i32, [vp, vp, ctypes.c_char_p, u32, u32, vp]),
+        "mfh_witness_from_lanes": (i32, [vp, vp, vp, u32, vp]),
+        "mfh_prove_partial_w": (i32, [vp, vp, vp, ctypes.c_char_p, u32, u32, u32, vp, vp]),
         "mfh_resident_row_bytes": (sz, [vp]),
         "mfh_crs_expand": (i32, [vp, u64, sz, vp, vp]),
         "mfh_eval_rows_resident": (i32, [vp, vp, sz, sz, vp, vp, vp, vp, i32]),
@@ -385,3 +389,14 @@ class Context:
     def set_resident(self, rows):
         self._resident = rows  # keep the tensor alive
         self._chk(self.lib.mfh_crs_set_resident(self._h, _ptr(rows)))
+
+    def witness_lanes(self, d_ssp, witness_bits: bytes, rank, world, out=None):
+        out = self.torch.empty(self.params.d, dtype=self.torch.int64, device=self.device) if out is None else out
+        self._chk(self.lib.mfh_witness_lanes(self._h, _ptr(d_ssp), bytes(witness_bits), rank, world, _ptr(out)))
+        return out
+
+    def prove_partial_w(self, d_crs, d_ssp, witness_bits: bytes, delta, rank, world, wlanes, out=None):
+        p = self.params
+        out = self.empty(5 * p.ct_limbs * 8) if out is None else out
+        self._chk(self.lib.mfh_prove_partial_w(self._h, _ptr(d_crs), _ptr(d_ssp), bytes(witness_bits), delta, rank, world, _ptr(wlanes), _ptr(out)))
+        return out

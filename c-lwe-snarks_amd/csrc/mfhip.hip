@@ -751,6 +751,14 @@ __global__ void k_witness_finish(const uint32_t *__restrict__ ssp, const uint64_
   w[k] = (uint32_t)s;
 }
 
+__global__ void k_witness_lanes(const uint64_t *__restrict__ partial, uint32_t G, uint32_t d, uint64_t *__restrict__ lanes) {
+  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= d) return;
+  uint64_t s = 0;
+  for (uint32_t g = 0; g < G; g++) s = (s + partial[(uint64_t)g * d + k] % MFH_P) % MFH_P;
+  lanes[k] = s;
+}
+
 // ------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------
@@ -1231,28 +1239,66 @@ int mfh_ssp_upload(mfh_ctx *c, const void *h_ssp_u64, uint32_t *d_ssp, size_t fi
   return rc;
 }
 
-int mfh_witness_poly(mfh_ctx *c, const uint32_t *d_ssp, const uint8_t *h_bits, uint32_t delta, uint32_t *d_w) {
-  if (!c || !d_ssp || !h_bits || !d_w) return MFH_EINVAL;
-  if (delta >= MFH_P) { c->err = "delta must be < p"; return MFH_EINVAL; }
+// shared body: partial[g][k] sums over this rank's share of the selected SSP rows
+static int witness_partials(mfh_ctx *c, const uint32_t *d_ssp, const uint8_t *h_bits, uint32_t rank, uint32_t world, uint32_t *G_out,
+                            uint64_t **partial_out) {
   const uint32_t d = c->P.d, m = c->P.m;
   if (d % 4) { c->err = "d must be a multiple of 4"; return MFH_EINVAL; }
-  HIP_TRY(c, hipSetDevice(c->device));
   uint32_t *rows = (uint32_t *)pin_acquire(c, c->pin_rows, (size_t)m * 4 + 4);
   if (!rows) return MFH_ENOMEM;
-  uint32_t nsel = 0;
+  uint32_t nall = 0;
   for (uint32_t i = 1; i < m; i++)
-    if ((h_bits[(i - 1) >> 3] >> ((i - 1) & 7)) & 1) rows[nsel++] = i + 1;  // slot of v_i
+    if ((h_bits[(i - 1) >> 3] >> ((i - 1) & 7)) & 1) rows[nall++] = i + 1;  // slot of v_i
+  // contiguous share of the selected rows
+  const uint32_t lo = (uint32_t)((uint64_t)nall * rank / world), hi = (uint32_t)((uint64_t)nall * (rank + 1) / world);
+  const uint32_t nsel = hi - lo;
   const uint32_t G = std::max(1u, std::min(64u, nsel / 8 + 1));
-  const size_t rows_b = ((size_t)nsel * 4 + 255) & ~(size_t)255;
+  const size_t rows_b = ((size_t)m * 4 + 255) & ~(size_t)255;
   int rc = ws_reserve(c, rows_b + (size_t)G * d * 8);
   if (rc) return rc;
   uint32_t *d_rows = (uint32_t *)c->ws;
   uint64_t *partial = (uint64_t *)((uint8_t *)c->ws + rows_b);
-  if (nsel) HIP_TRY(c, hipMemcpyAsync(d_rows, rows, (size_t)nsel * 4, hipMemcpyHostToDevice, c->stream));
+  if (nsel) HIP_TRY(c, hipMemcpyAsync(d_rows, rows + lo, (size_t)nsel * 4, hipMemcpyHostToDevice, c->stream));
   pin_release(c, c->pin_rows);
   hipLaunchKernelGGL(k_witness_partial, dim3((d / 4 + 255) / 256, G), dim3(256), 0, c->stream, d_ssp, d_rows, nsel, d, partial);
   HIP_TRY(c, hipGetLastError());
-  hipLaunchKernelGGL(k_witness_finish, dim3((d + 255) / 256), dim3(256), 0, c->stream, d_ssp, partial, G, d, delta, d_w);
+  *G_out = G;
+  *partial_out = partial;
+  return MFH_OK;
+}
+
+int mfh_witness_poly(mfh_ctx *c, const uint32_t *d_ssp, const uint8_t *h_bits, uint32_t delta, uint32_t *d_w) {
+  if (!c || !d_ssp || !h_bits || !d_w) return MFH_EINVAL;
+  if (delta >= MFH_P) { c->err = "delta must be < p"; return MFH_EINVAL; }
+  HIP_TRY(c, hipSetDevice(c->device));
+  uint32_t G;
+  uint64_t *partial;
+  int rc = witness_partials(c, d_ssp, h_bits, 0, 1, &G, &partial);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_witness_finish, dim3((c->P.d + 255) / 256), dim3(256), 0, c->stream, d_ssp, partial, G, c->P.d, delta, d_w);
+  HIP_TRY(c, hipGetLastError());
+  return MFH_OK;
+}
+
+// rank's share of sum_{bit} v_i as d uint64 lanes, each already reduced mod p (so `world` of them sum without overflow)
+int mfh_witness_lanes(mfh_ctx *c, const uint32_t *d_ssp, const uint8_t *h_bits, uint32_t rank, uint32_t world, uint64_t *d_lanes) {
+  if (!c || !d_ssp || !h_bits || !d_lanes || world == 0 || rank >= world) return MFH_EINVAL;
+  HIP_TRY(c, hipSetDevice(c->device));
+  uint32_t G;
+  uint64_t *partial;
+  int rc = witness_partials(c, d_ssp, h_bits, rank, world, &G, &partial);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_witness_lanes, dim3((c->P.d + 255) / 256), dim3(256), 0, c->stream, partial, G, c->P.d, d_lanes);
+  HIP_TRY(c, hipGetLastError());
+  return MFH_OK;
+}
+
+// w = delta*t + (summed lanes) mod p
+int mfh_witness_from_lanes(mfh_ctx *c, const uint32_t *d_ssp, const uint64_t *d_lanes, uint32_t delta, uint32_t *d_w) {
+  if (!c || !d_ssp || !d_lanes || !d_w) return MFH_EINVAL;
+  if (delta >= MFH_P) { c->err = "delta must be < p"; return MFH_EINVAL; }
+  HIP_TRY(c, hipSetDevice(c->device));
+  hipLaunchKernelGGL(k_witness_finish, dim3((c->P.d + 255) / 256), dim3(256), 0, c->stream, d_ssp, d_lanes, 1u, c->P.d, delta, d_w);
   HIP_TRY(c, hipGetLastError());
   return MFH_OK;
 }

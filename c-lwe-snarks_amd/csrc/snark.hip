@@ -168,8 +168,8 @@ int mfh_ct_from_lanes(mfh_ctx *c, const uint64_t *d_lanes, size_t count, uint64_
   return MFH_OK;
 }
 
-int mfh_prove_partial(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, const uint8_t *h_witness_bits, uint32_t delta,
-                      uint32_t rank, uint32_t world, uint64_t *d_partial) {
+static int prove_partial_impl(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, const uint8_t *h_witness_bits, uint32_t delta,
+                              uint32_t rank, uint32_t world, const uint64_t *d_wlanes, uint64_t *d_partial) {
   if (!c || !d_crs_c8 || !d_ssp || !h_witness_bits || !d_partial || world == 0 || rank >= world) return MFH_EINVAL;
   if (delta >= P32) { c->err = "delta must be < p"; return MFH_EINVAL; }
   const uint32_t d = c->P.d, m = c->P.m, n = c->P.n;
@@ -192,7 +192,7 @@ int mfh_prove_partial(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp
   };
 
   // w(x) = delta t + sum_{bit} v_i   (src/snark.c:141,147-155); every rank needs all of w for the polynomial step
-  int rc = mfh_witness_poly(c, d_ssp, h_witness_bits, delta, w);
+  int rc = d_wlanes ? mfh_witness_from_lanes(c, d_ssp, d_wlanes, delta, w) : mfh_witness_poly(c, d_ssp, h_witness_bits, delta, w);
   if (rc) return rc;
   // b_w = delta * ct_t + sum_{bit} ct_{v_i}: rows BT, BV.. are m consecutive stream rows (src/snark.c:143-155)
   uint32_t *h_cw = (uint32_t *)pin_acquire(c, c->pin_cw, (size_t)m * 4);
@@ -223,6 +223,17 @@ int mfh_prove_partial(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp
   rc = mfh_eval_rows(c, ctr_ct * lo, cnt, d_crs_c8 + (size_t)lo * ctb, w + lo, h + lo, pi_v_w, pi_h, 0);
   if (rc) return rc;
   return mfh_eval_rows(c, ctr_ct * ((uint64_t)d + lo), cnt, d_crs_c8 + ((size_t)d + lo) * ctb, v + lo, h + lo, pi_hat_v, pi_hat_h, 0);
+}
+
+int mfh_prove_partial(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, const uint8_t *h_witness_bits, uint32_t delta,
+                      uint32_t rank, uint32_t world, uint64_t *d_partial) {
+  return prove_partial_impl(c, d_crs_c8, d_ssp, h_witness_bits, delta, rank, world, nullptr, d_partial);
+}
+
+int mfh_prove_partial_w(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, const uint8_t *h_witness_bits, uint32_t delta,
+                        uint32_t rank, uint32_t world, const uint64_t *d_wlanes, uint64_t *d_partial) {
+  if (!d_wlanes) return MFH_EINVAL;
+  return prove_partial_impl(c, d_crs_c8, d_ssp, h_witness_bits, delta, rank, world, d_wlanes, d_partial);
 }
 
 int mfh_prove_finish(mfh_ctx *c, uint64_t *d_proof, const uint8_t *h_smudge_mag, size_t maglen, const uint8_t *h_smudge_sign) {

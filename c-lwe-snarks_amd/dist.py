@@ -1,8 +1,9 @@
 """Row-sharded prover across GPUs: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI).
 
 SURVEY 8(e): every proof element is sum_i coeff_i * row_i over CRS rows and the AES-CTR stream is seekable, so
-each rank takes a contiguous share of the rows of every region and produces five partial ciphertexts.  The only
-exchange step is ONE all-reduce per proof of 5 x 1471 x 22 uint64 lanes (1.3 MB): each 32-bit limb travels in its own
+each rank takes a contiguous share of the rows of every region and produces five partial ciphertexts.  The
+exchange steps are one all-reduce per proof of 5 x 1471 x 22 uint64 lanes (1.3 MB) and, so that the SSP pass shards
+as well, one of D uint64 lanes for the witness polynomial (256 KB): each 32-bit limb travels in its own
 64-bit lane so RCCL's integer sum cannot overflow (2^32 ranks of headroom), carries are propagated once afterwards,
 and because sums mod 2^704 are order-independent the result is bit-identical to the single-GPU proof.
 """
@@ -22,7 +23,14 @@ def prove_sharded(ctx, d_crs, d_ssp, witness_bits, delta, smudge_mag, smudge_sig
     """prover() (reference src/snark.c:117-190) with the CRS rows sharded over `world` ranks.  Every rank returns the
     complete proof.  `bufs` may hold reusable device buffers {"partial", "lanes", "proof"}."""
     bufs = {} if bufs is None else bufs
-    partial = ctx.prove_partial(d_crs, d_ssp, witness_bits, delta, rank, world, out=bufs.get("partial"))
+    if world > 1:
+        # first exchange: the SSP pass is sharded too (each rank sums its share of the selected v_i), d uint64 lanes
+        wl = ctx.witness_lanes(d_ssp, witness_bits, rank, world, out=bufs.get("wlanes"))
+        allreduce_lanes(wl, group)
+        bufs["wlanes"] = wl
+        partial = ctx.prove_partial_w(d_crs, d_ssp, witness_bits, delta, rank, world, wl, out=bufs.get("partial"))
+    else:
+        partial = ctx.prove_partial(d_crs, d_ssp, witness_bits, delta, rank, world, out=bufs.get("partial"))
     lanes = ctx.ct_to_lanes(partial, 5, out=bufs.get("lanes"))
     allreduce_lanes(lanes, group)
     proof = ctx.ct_from_lanes(lanes, 5, out=bufs.get("proof"))

@@ -161,6 +161,13 @@ int mfh_prove(mfh_ctx *ctx, const uint8_t *d_crs_c8, const uint32_t *d_ssp, cons
 int mfh_prove_partial(mfh_ctx *ctx, const uint8_t *d_crs_c8, const uint32_t *d_ssp, const uint8_t *h_witness_bits, uint32_t delta,
                       uint32_t rank, uint32_t world, uint64_t *d_partial);
 int mfh_prove_finish(mfh_ctx *ctx, uint64_t *d_proof, const uint8_t *h_smudge_mag, size_t maglen, const uint8_t *h_smudge_sign);
+/* Optional second exchange that also shards the witness polynomial (the SSP pass, 1.4 GB per proof at the default size):
+ * mfh_witness_lanes = this rank's share of sum_{bit} v_i as d uint64 lanes (each < p) -> all-reduce (sum) ->
+ * mfh_prove_partial_w takes the summed lanes instead of recomputing w on every rank.  mfh_witness_from_lanes: w = delta t + lanes mod p. */
+int mfh_witness_lanes(mfh_ctx *ctx, const uint32_t *d_ssp, const uint8_t *h_witness_bits, uint32_t rank, uint32_t world, uint64_t *d_lanes);
+int mfh_witness_from_lanes(mfh_ctx *ctx, const uint32_t *d_ssp, const uint64_t *d_lanes, uint32_t delta, uint32_t *d_w);
+int mfh_prove_partial_w(mfh_ctx *ctx, const uint8_t *d_crs_c8, const uint32_t *d_ssp, const uint8_t *h_witness_bits, uint32_t delta,
+                        uint32_t rank, uint32_t world, const uint64_t *d_wlanes, uint64_t *d_partial);
 /* count ciphertexts <-> count*(n+1)*2K uint64 lanes (one per surviving 32-bit word) */
 int mfh_ct_to_lanes(mfh_ctx *ctx, const uint64_t *d_cts, size_t count, uint64_t *d_lanes);
 int mfh_ct_from_lanes(mfh_ctx *ctx, const uint64_t *d_lanes, size_t count, uint64_t *d_cts);

@@ -224,3 +224,24 @@ def test_witness_poly(ctx, oracle, mf):
         if (bits[(i - 1) >> 3] >> ((i - 1) & 7)) & 1:
             w = (w + red[i + 1].astype(object)) % ol.P
     assert np.array_equal(got.astype(np.uint64), np.array(w, dtype=np.uint64))
+
+
+# ---------------------------------------------------------------- BASELINE configs 4/5: stream offsets of a 2^20-constraint CRS
+@pytest.mark.parametrize("logq", [736, 1472])
+def test_rows_at_2pow20_scale_offsets(gpu_ctx_factory, oracle, mf, logq):
+    """D = 2^20, M = 699 050 (378 GB of stream at logq 736, 757 GB at 1472): rows addressed deep inside the AS / BV
+    regions (byte offsets > 2^38) must equal the oracle's.  The reference cannot run these sizes at all."""
+    p = mf.Params(logq=logq, d=1 << 20, m=699050)
+    c = gpu_ctx_factory(p)
+    c.set_seed(SEED2)
+    rng = np.random.default_rng(logq)
+    for off in (p.ctr_as + 7 * p.ctr_ct, p.ctr_bv + 699000 * p.ctr_ct):
+        assert off > (1 << 37)
+        nrows = 6
+        c8 = rng.integers(0, 256, size=nrows * p.ctb, dtype=np.uint8)
+        co = rng.integers(0, ol.P, size=nrows, dtype=np.uint64)
+        r0, _ = c.eval_rows(off, nrows, c.to_device(c8), c.to_device(co.astype(np.uint32)))
+        exp = oracle.eval_poly(p, SEED2, off, c8.tobytes(), co)
+        assert np.array_equal(c.to_host(r0, np.uint64).reshape(exp.shape), exp)
+        got = c.to_host(c.sample_rows(off, 1), np.uint64).reshape(1, p.n, p.L)
+        assert np.array_equal(got, oracle.sample_rows(p, SEED2, off, 1))

@@ -231,3 +231,24 @@ def test_resident_crs_matches_regenerated(ctx, oracle, instance, mf):
     finally:
         ctx.set_resident(None)
     assert np.array_equal(regen, res)
+
+
+def test_sharded_witness_lanes(ctx, instance):
+    """the second exchange of the sharded prover: per-rank witness lanes sum to the replicated witness polynomial"""
+    I = instance
+    p = I["p"]
+    delta = 4242
+    world = 3
+    lanes = None
+    for r in range(world):
+        ln = ctx.witness_lanes(I["d_ssp"], I["bits"], r, world).clone()
+        lanes = ln if lanes is None else lanes + ln
+    d_crs = ctx.to_device(_crs_stream_order(p, I["crs"]))
+    total = None
+    for r in range(world):
+        part = ctx.prove_partial_w(d_crs, I["d_ssp"], I["bits"], delta, r, world, lanes)
+        ln = ctx.ct_to_lanes(part, 5).clone()
+        total = ln if total is None else total + ln
+    proof = ctx.ct_from_lanes(total, 5)
+    ref = ctx.prove_partial(d_crs, I["d_ssp"], I["bits"], delta, 0, 1)
+    assert np.array_equal(ctx.to_host(proof), ctx.to_host(ref))
