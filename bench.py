@@ -204,6 +204,13 @@ def main():
         same = bool(torch.equal(proof_r, proof))
         ctx.set_resident(None)
         rb = ctx.resident_row_bytes()
+        traffic_r = None
+        tf2 = os.path.join(ROOT, "profiles", "traffic_mac2.json")
+        if os.path.exists(tf2):
+            try:
+                traffic_r = json.load(open(tf2)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic_r = None
         avg = m2ms / max(m2n, 1)
         lr = m2rows / max(m2n, 1)
         resident = {"value": args.steps / el_r, "unit": "proofs/s", "ms_per_step": el_r / args.steps * 1e3, "proof_identical_to_regenerated": same,
@@ -211,7 +218,7 @@ def main():
                     "roofline": {"bound": "hbm", "kernel": "k_mac_resident<736,2> (streaming 2x MAC over the expanded S / AS rows)",
                                  "achieved": lr * ROW_BYTES / (avg * 1e-3) / 1e9 if m2n else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": (lr * ROW_BYTES / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS) if m2n else None,
-                                 "bytes_read_per_row": rb, "read_gbs": lr * rb / (avg * 1e-3) / 1e9 if m2n else None,
+                                 "traffic": traffic_r, "bytes_read_per_row": rb, "read_gbs": lr * rb / (avg * 1e-3) / 1e9 if m2n else None,
                                  "launches": m2n, "avg_launch_ms": avg, "rows_per_launch": lr},
                     "mac1": {"launches": m1n, "avg_launch_ms": m1ms / max(m1n, 1), "rows_per_launch": m1rows / max(m1n, 1)}}
         del image
@@ -246,6 +253,22 @@ def main():
                "sample": f"{args.cpu_rows} prover row-touches (ct_import + ct_addmul_ui, one AES block per call) of the oracle in {cpu_s:.1f} s "
                          f"= {rows_per_s:.0f} rows/s, scaled to the reference prover's {ref_rows} row-touches; h=(v^2-1)/t excluded",
                "rows_per_s": rows_per_s}
+        # calibration against the REAL reference where its build travelled (oracle/_ref = reference src/aes.c + src/entropy.c):
+        # its keystream generator is ~97 % of a reference prover row, so this bounds the reference's rows/s.
+        ref_so = os.path.join(ROOT, "oracle", "_ref", "libmfref.so")
+        if os.path.exists(ref_so):
+            import ctypes
+
+            rl = ctypes.CDLL(ref_so)
+            rl.ref_bench_keystream.restype = ctypes.c_uint64
+            nbytes = 135240 * 4000
+            r0 = time.perf_counter()
+            rl.ref_bench_keystream(ctypes.c_char_p(seed), ctypes.c_size_t(nbytes), ctypes.c_size_t(92))
+            rs = time.perf_counter() - r0
+            cpu["reference_keystream_MBps"] = nbytes / rs / 1e6
+            cpu["reference_rows_per_s_upper_bound"] = 4000 / rs
+            cpu["note"] = ("the oracle's table AES is faster than the reference's OpenSSL AES_encrypt path; reference_* fields time the real "
+                           "reference aes.c/entropy.c (92-byte reads, as ct_import does) on this host")
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3

@@ -493,16 +493,21 @@ __global__ __launch_bounds__(PS<LOGQ>::THREADS) void k_encrypt(AesKey key, const
       const uint32_t *kw = reinterpret_cast<const uint32_t *>(ks + head) + t * S::EW;
 #pragma unroll
       for (int l = 0; l < S::KW; l++) a[l] = kw[l];
-      // prod = low KW words of a * s (operand scanning, carries dropped beyond KW)
+      // prod = low KW words of a * s: product scanning, one 96-bit column accumulator (v_mad_u64_u32 + carry count),
+      // no per-term carry chain; columns >= KW are never formed (mod 2^(32 KW))
+      uint64_t lo = 0;
+      uint32_t hi = 0;
 #pragma unroll
-      for (int u = 0; u < S::KW; u++) {
-        uint32_t carry = 0;
+      for (int k = 0; k < S::KW; k++) {
 #pragma unroll
-        for (int v = 0; u + v < S::KW; v++) {
-          uint64_t tt = (uint64_t)a[u] * s[v] + prod[u + v] + carry;
-          prod[u + v] = (uint32_t)tt;
-          carry = (uint32_t)(tt >> 32);
+        for (int u = 0; u <= k; u++) {
+          const uint64_t pr = (uint64_t)a[u] * s[k - u];
+          lo += pr;
+          hi += lo < pr;
         }
+        prod[k] = (uint32_t)lo;
+        lo = (lo >> 32) | ((uint64_t)hi << 32);
+        hi = 0;
       }
     }
     __syncthreads();  // everyone has read its keystream words

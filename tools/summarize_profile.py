@@ -54,6 +54,14 @@ if ev2 and "FETCH_SIZE" in ev2 and "WRITE_SIZE" in ev2:
     json.dump({"kernel": "k_eval<736,2>", "fetch_bytes_x2_corrected": fetch, "write_bytes": write, "hbm_bytes_per_launch": fetch + write,
                "note": "separate --pmc passes; FETCH_SIZE doubled per the gfx950 correction"}, open(os.path.join(out_dir, "traffic_eval2.json"), "w"), indent=1)
     print("traffic", fetch + write)
+mr = next((v for k, v in res.items() if k.startswith("void k_mac_resident<736, 2>")), None)
+if mr and "FETCH_SIZE" in mr and "WRITE_SIZE" in mr:
+    fetch = mr["FETCH_SIZE"]["mean"] * 1024 * 2
+    write = mr["WRITE_SIZE"]["mean"] * 1024
+    json.dump({"kernel": "k_mac_resident<736,2>", "fetch_bytes_x2_corrected": fetch, "write_bytes": write, "hbm_bytes_per_launch": fetch + write,
+               "note": "separate --pmc passes; FETCH_SIZE doubled per the gfx950 correction for wide coalesced streaming reads"},
+              open(os.path.join(out_dir, "traffic_mac2.json"), "w"), indent=1)
+    print("traffic mac2", fetch + write)
 for k, v in res.items():
-    if "k_eval<736, 2>" in k or "k_encrypt<736>" in k or "k_keystream" in k:
+    if "k_mac_resident" in k or "k_eval<736, 2>" in k or "k_encrypt<736>" in k or "k_keystream" in k:
         print(k, {c: round(x["mean"]) for c, x in v.items()})
