@@ -88,7 +88,7 @@ EXPORTS = [
     "mfh_ssp_prepare", "mfh_poly_h", "mfh_setup_messages", "mfh_setup", "mfh_prove",
     "mfh_prove_partial", "mfh_prove_finish", "mfh_ct_to_lanes", "mfh_ct_from_lanes", "mfh_timing_drain", "mfh_add_dotp",
     "mfh_resident_row_bytes", "mfh_crs_expand", "mfh_eval_rows_resident", "mfh_crs_set_resident",
-    "mfh_witness_lanes", "mfh_witness_from_lanes", "mfh_prove_partial_w",
+    "mfh_witness_lanes", "mfh_witness_from_lanes", "mfh_prove_partial_w", "mfh_verify",
 ]
 
 
@@ -137,6 +137,7 @@ def load_library():
         "mfh_ct_to_lanes": (i32, [vp, vp, sz, vp]),
         "mfh_ct_from_lanes": (i32, [vp, vp, sz, vp]),
         "mfh_add_dotp": (i32, [vp, vp, vp, vp, sz]),
+        "mfh_verify": (i32, [vp, vp, u32, u32, u32, vp, vp, sz, vp]),
         "mfh_witness_lanes": (i32, [vp, vp, ctypes.c_char_p, u32, u32, vp]),
         "mfh_witness_from_lanes": (i32, [vp, vp, vp, u32, vp]),
         "mfh_prove_partial_w": (i32, [vp, vp, vp, ctypes.c_char_p, u32, u32, u32, vp, vp]),
@@ -400,3 +401,9 @@ class Context:
         out = self.empty(5 * p.ct_limbs * 8) if out is None else out
         self._chk(self.lib.mfh_prove_partial_w(self._h, _ptr(d_crs), _ptr(d_ssp), bytes(witness_bits), delta, rank, world, _ptr(wlanes), _ptr(out)))
         return out
+
+    def verify(self, d_ssp, alpha, beta, s, d_sk, d_proofs, count=1):
+        """verifier() (src/snark.c:192-250) for `count` proofs on the device; returns a uint8 tensor of accept bits"""
+        ok = self.empty(count)
+        self._chk(self.lib.mfh_verify(self._h, _ptr(d_ssp), alpha, beta, s, _ptr(d_sk), _ptr(d_proofs), count, _ptr(ok)))
+        return ok

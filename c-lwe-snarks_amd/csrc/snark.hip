@@ -89,6 +89,36 @@ __global__ void k_ct_from_lanes(const uint64_t *__restrict__ lanes, uint64_t nva
   for (uint32_t w = KW; w < 2 * L; w++) o[w] = 0;  // modq
 }
 
+// scal[r] = <slot r, pw> mod p for r = 0 (t) and 1 (v_0): nmod_poly_evaluate_nmod of src/snark.c:201,213
+__global__ __launch_bounds__(256) void k_eval_slots01(const uint32_t *__restrict__ ssp, const uint32_t *__restrict__ pw, uint32_t d, uint32_t *__restrict__ scal) {
+  __shared__ uint64_t red[4];
+  const uint32_t *row = ssp + (uint64_t)blockIdx.x * d;
+  uint64_t acc = 0;
+  for (uint32_t k = threadIdx.x; k < d; k += 256) {
+    uint64_t pr = (uint64_t)row[k] * pw[k];
+    acc += (pr >> 32) * 5 + (uint32_t)pr;
+  }
+  acc = red_p32(acc);
+  for (int o = 32; o; o >>= 1) acc += __shfl_xor(acc, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) scal[blockIdx.x] = red_p32(red[0] + red[1] + red[2] + red[3]);
+}
+// the four checks of verifier() (src/snark.c:219-235) on decrypted values dec[5*i .. 5*i+5) = h, hat_h, hat_v, v_w, b_w
+__global__ void k_verify(const uint32_t *__restrict__ dec, const uint32_t *__restrict__ scal, uint32_t alpha, uint32_t beta, uint32_t count,
+                         uint8_t *__restrict__ ok) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const uint32_t h_s = dec[5 * i], hath_s = dec[5 * i + 1], hatv_s = dec[5 * i + 2], w_s = dec[5 * i + 3], b_s = dec[5 * i + 4];
+  const uint32_t t_s = scal[0];
+  const uint32_t v_s = red_p32((uint64_t)scal[1] + w_s);
+  bool good = mulmod(h_s, alpha) == hath_s;                                         // eq-pke
+  good = good && mulmod(v_s, alpha) == hatv_s;
+  good = good && red_p32((uint64_t)mulmod(v_s, v_s) + P32 - 1) == mulmod(h_s, t_s);  // eq-div
+  good = good && mulmod(w_s, beta) == b_s;                                          // eq-lin
+  ok[i] = good ? 1 : 0;  // the reference's "test-error" bound (src/snark.c:238-241) can never reject
+}
+
 inline dim3 g1(uint32_t n) { return dim3((n + 255) / 256); }
 
 }  // namespace
@@ -146,6 +176,26 @@ int mfh_setup(mfh_ctx *c, const uint32_t *d_ssp, uint32_t alpha, uint32_t beta, 
   if (rc) return rc;
   // all 2d+m encryptions are consecutive rows of the stream starting at CTR_S = 0 (src/snark.c:75-110)
   return mfh_encrypt_rows(c, 0, rows, d_sk, c->d_msg, d_err, d_crs_c8);
+}
+
+int mfh_verify(mfh_ctx *c, const uint32_t *d_ssp, uint32_t alpha, uint32_t beta, uint32_t s, const uint64_t *d_sk, const uint64_t *d_proofs,
+               size_t count, uint8_t *d_ok) {
+  if (!c || !d_ssp || !d_sk || (count && (!d_proofs || !d_ok))) return MFH_EINVAL;
+  if (alpha >= P32 || beta >= P32 || s >= P32) { c->err = "alpha, beta, s must be < p"; return MFH_EINVAL; }
+  if (!count) return MFH_OK;
+  const uint32_t d = c->P.d;
+  HIP_TRY(c, hipSetDevice(c->device));
+  int rc = aux_reserve(c, (size_t)d * 4 + 16 + count * 5 * 4);
+  if (rc) return rc;
+  uint32_t *pw = (uint32_t *)c->aux, *scal = pw + d, *dec = scal + 4;
+  hipLaunchKernelGGL(k_powers, g1(d), dim3(256), 0, c->stream, s, d, pw);
+  hipLaunchKernelGGL(k_eval_slots01, dim3(2), dim3(256), 0, c->stream, d_ssp, pw, d, scal);
+  HIP_TRY(c, hipGetLastError());
+  rc = mfh_decrypt(c, d_sk, d_proofs, 5 * count, dec);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_verify, g1((uint32_t)count), dim3(256), 0, c->stream, dec, scal, alpha, beta, (uint32_t)count, d_ok);
+  HIP_TRY(c, hipGetLastError());
+  return MFH_OK;
 }
 
 int mfh_ct_to_lanes(mfh_ctx *c, const uint64_t *d_cts, size_t count, uint64_t *d_lanes) {

@@ -153,6 +153,12 @@ int mfh_setup(mfh_ctx *ctx, const uint32_t *d_ssp, uint32_t alpha, uint32_t beta
 int mfh_prove(mfh_ctx *ctx, const uint8_t *d_crs_c8, const uint32_t *d_ssp, const uint8_t *h_witness_bits, uint32_t delta,
               const uint8_t *h_smudge_mag, size_t maglen, const uint8_t *h_smudge_sign, uint64_t *d_proof);
 
+/* verifier() (src/snark.c:192-250) for `count` proofs (5 ciphertexts each) entirely on the device: t(s), v_0(s), the 5*count
+ * decryptions and the eq-pke / eq-div / eq-lin checks.  d_ok[i] = 1 iff proof i is accepted.  (The reference's final
+ * "test-error" bound never rejects: SIZ of a non-positive value is <= 0, src/snark.c:238-241.) */
+int mfh_verify(mfh_ctx *ctx, const uint32_t *d_ssp, uint32_t alpha, uint32_t beta, uint32_t s, const uint64_t *d_sk,
+               const uint64_t *d_proofs, size_t count, uint8_t *d_ok);
+
 /* ---- multi-GPU: row-sharded prover -------------------------------------------------------------
  * Every proof element is sum_i coeff_i * row_i and the public stream is seekable, so the CRS rows of each region are
  * split into `world` contiguous shares.  mfh_prove_partial computes rank `rank`'s share of the five (un-smudged)

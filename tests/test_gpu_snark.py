@@ -252,3 +252,25 @@ def test_sharded_witness_lanes(ctx, instance):
     proof = ctx.ct_from_lanes(total, 5)
     ref = ctx.prove_partial(d_crs, I["d_ssp"], I["bits"], delta, 0, 1)
     assert np.array_equal(ctx.to_host(proof), ctx.to_host(ref))
+
+
+def test_device_verifier_agrees_with_oracle(ctx, oracle, instance):
+    I = instance
+    p = I["p"]
+    rng = np.random.default_rng(31)
+    d_crs = ctx.to_device(_crs_stream_order(p, I["crs"]))
+    proofs = []
+    expect = []
+    for k in range(4):
+        bits = bytearray(I["bits"])
+        if k % 2:
+            bits[k] ^= 4  # invalid witness
+        delta = int(rng.integers(0, ol.P, dtype=np.uint64))
+        pr = ctx.to_host(ctx.prove(d_crs, I["d_ssp"], bytes(bits), delta, rng.integers(0, 256, size=400, dtype=np.uint8).tobytes(), bytes(5)),
+                         np.uint64).reshape(5, p.n + 1, p.L).copy()
+        if k == 2:
+            pr[4, p.n, 0] ^= np.uint64(2)  # tamper with b_w
+        proofs.append(pr)
+        expect.append(oracle.verifier(p, I["ssp"], I["alpha"], I["beta"], I["s"], I["sk"], pr))
+    ok = ctx.to_host(ctx.verify(I["d_ssp"], I["alpha"], I["beta"], I["s"], ctx.to_device(I["sk"]), ctx.to_device(np.stack(proofs)), 4))
+    assert [bool(x) for x in ok] == expect == [True, False, False, False]
