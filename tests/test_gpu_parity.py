@@ -245,3 +245,44 @@ def test_rows_at_2pow20_scale_offsets(gpu_ctx_factory, oracle, mf, logq):
         assert np.array_equal(c.to_host(r0, np.uint64).reshape(exp.shape), exp)
         got = c.to_host(c.sample_rows(off, 1), np.uint64).reshape(1, p.n, p.L)
         assert np.array_equal(got, oracle.sample_rows(p, SEED2, off, 1))
+
+
+def test_eval_over_a_2pow20_row_region_sparse(gpu_ctx_factory, oracle, mf):
+    """A whole S region of the 2^20-constraint CRS (1 048 576 rows) in one call: all but a handful of coefficients are zero, so
+    the active-row compaction must pick exactly those rows at their (far apart) stream offsets."""
+    p = mf.Params(d=1 << 20, m=699050)
+    c = gpu_ctx_factory(p)
+    c.set_seed(SEED2)
+    rng = np.random.default_rng(9)
+    nrows = p.d
+    rows = sorted(int(x) for x in rng.choice(nrows, size=5, replace=False)) + [nrows - 1]
+    co = np.zeros(nrows, dtype=np.uint32)
+    vals = rng.integers(1, ol.P, size=len(rows), dtype=np.uint64)
+    co[rows] = vals.astype(np.uint32)
+    c8 = c.to_device(rng.integers(0, 256, size=nrows * p.ctb, dtype=np.uint8))
+    r0, _ = c.eval_rows(p.ctr_s, nrows, c8, c.to_device(co))
+    exp = np.zeros((p.n + 1, p.L), dtype=np.uint64)
+    c8h = c.to_host(c8)
+    for r, v in zip(rows, vals):
+        exp = oracle.eval_poly(p, SEED2, r * p.ctr_ct, c8h[r * p.ctb:(r + 1) * p.ctb].tobytes(), np.array([v], dtype=np.uint64), rop=exp)
+    assert np.array_equal(c.to_host(r0, np.uint64).reshape(exp.shape), exp)
+
+
+# ---------------------------------------------------------------- error behaviour of the C ABI
+def test_error_paths(gpu_ctx_factory, mf):
+    import ctypes
+
+    lib = mf.load_library()
+    h = ctypes.c_void_p()
+    bad = mf._CParams(1470, 700, 256, 64)  # the reference has `#error "Not implemented"` for any other GAMMA_LOGQ
+    assert lib.mfh_ctx_create(ctypes.byref(h), 0, ctypes.byref(bad)) == -4
+    assert lib.mfh_ctx_create(ctypes.byref(h), 99, ctypes.byref(mf._CParams(1470, 736, 256, 64))) == -2
+    c = gpu_ctx_factory(mf.DEBUG)  # no seed set yet
+    with pytest.raises(mf.MfhError, match="mfh_set_seed"):
+        c.keystream(0, 16)
+    c.set_seed(SEED)
+    with pytest.raises(mf.MfhError):
+        c.witness_poly(c.zeros((mf.DEBUG.m + 3) * mf.DEBUG.d * 4), bytes(8), 0xFFFFFFFB)  # delta must be < p
+    with pytest.raises(mf.MfhError):
+        c.poly_h(c.zeros(mf.DEBUG.d * 4))  # no SSP prepared
+    assert lib.mfh_eval_rows(c._h, 0, 4, None, None, None, None, None, 0) == -1

@@ -4,6 +4,9 @@ f = glob.glob(sys.argv[1])[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 # last k_smudge marks the end of a proof; take the window between the 3rd-last and last pair of smudges
 idx = [i for i, r in enumerate(rows) if "k_smudge" in r["Kernel_Name"]]
+if len(sys.argv) > 2 and sys.argv[2] == "regen":  # last proof before the CRS expansion (regenerate regime)
+    ex = [i for i, r in enumerate(rows) if "k_expand" in r["Kernel_Name"]][0]
+    idx = [i for i in idx if i < ex]
 end = idx[-1]; start = idx[-3] + 1
 t0 = int(rows[start]["Start_Timestamp"]); prev_end = t0
 tot_k = 0
