@@ -286,3 +286,25 @@ def test_error_paths(gpu_ctx_factory, mf):
     with pytest.raises(mf.MfhError):
         c.poly_h(c.zeros(mf.DEBUG.d * 4))  # no SSP prepared
     assert lib.mfh_eval_rows(c._h, 0, 4, None, None, None, None, None, 0) == -1
+
+
+def test_degenerate_inputs(ctx, mf):
+    """all-zero coefficient vectors (every row skipped) and an all-zero witness (empty row selection)"""
+    p = mf.DEBUG
+    nrows = 33
+    c8 = ctx.zeros(nrows * p.ctb)
+    z = ctx.zeros(nrows * 4)
+    r0, r1 = ctx.eval_rows(0, nrows, c8, z, z)
+    assert not ctx.to_host(r0).any() and not ctx.to_host(r1).any()
+    keep = ctx.to_device(np.arange(p.ct_limbs, dtype=np.uint64) & np.uint64(0xFFFF))
+    before = ctx.to_host(keep).copy()
+    ctx.eval_rows(0, nrows, c8, z, rop0=keep, accumulate=True)
+    got = ctx.to_host(keep, np.uint64).reshape(p.n + 1, p.L)
+    exp = before.view(np.uint64).reshape(p.n + 1, p.L).copy()
+    exp[:, p.K:] = 0  # accumulate re-applies modq
+    assert np.array_equal(got, exp)
+    rng = np.random.default_rng(12)
+    ssp = rng.integers(0, ol.P, size=(p.m + 3) * p.d, dtype=np.uint64)
+    d_ssp = ctx.ssp_upload(ssp)
+    w = ctx.to_host(ctx.witness_poly(d_ssp, bytes((p.m + 7) // 8), 3), np.uint32)
+    assert np.array_equal(w.astype(np.uint64), ssp[: p.d] * np.uint64(3) % np.uint64(ol.P))
