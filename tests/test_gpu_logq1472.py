@@ -58,3 +58,41 @@ def test_encrypt_decrypt(setup, oracle):
         unit[i] = 1
         ct, _ = ctx.eval_rows(0, nrows, c8, ctx.to_device(unit))
         assert int(ctx.to_host(ctx.decrypt(d_sk, ct, 1), np.uint32)[0]) == int(msg[i])
+
+
+def test_full_snark_at_logq1472(setup, oracle):
+    """setup -> prover -> verifier at log q = 1472 (D = 64, M = 16): every proof element equals the oracle's, the oracle's
+    verifier and the device verifier accept, and the resident-CRS layout (11 full planes + 1 half plane) gives the same proof."""
+    ctx, p = setup
+    rng = np.random.default_rng(77)
+    bits = rng.bytes((p.m + 7) // 8)
+    tape = rng.integers(0, 256, size=p.m * 8 * p.d, dtype=np.uint8)
+    ssp = oracle.ssp_from_tape(p, tape, bits)
+    alpha, beta, s = (int(x) for x in rng.integers(1, ol.P, size=3, dtype=np.uint64))
+    sk = ol.rand_values(rng, p.n, p.L, p.logq)
+    etape = ol.rand_values(rng, 2 * p.d + p.m, p.L, 559)
+    crs = oracle.setup(p, SEED, ssp, alpha, beta, s, sk, etape)
+    stream_order = np.concatenate([crs["s"], crs["as_"], crs["t"], crs["v"][: (p.m - 1) * p.ctb]])
+    d_ssp = ctx.ssp_upload(ssp)
+    ctx.ssp_prepare(d_ssp)
+    d_sk = ctx.to_device(sk)
+    d_crs = ctx.setup(d_ssp, alpha, beta, s, d_sk, ctx.to_device(etape))
+    assert np.array_equal(ctx.to_host(d_crs), stream_order)
+    delta = int(rng.integers(0, ol.P, dtype=np.uint64))
+    mags = rng.integers(0, 256, size=400, dtype=np.uint8).tobytes()
+    signs = bytes([0, 1, 0, 1, 1])
+    t5 = b"".join(mags[80 * k: 80 * k + 80] + signs[k: k + 1] for k in range(5))
+    ref = oracle.prover(p, crs, ssp, bits, delta, t5, 80)
+    proof = ctx.prove(d_crs, d_ssp, bits, delta, mags, signs)
+    got = ctx.to_host(proof, np.uint64).reshape(5, p.n + 1, p.L)
+    assert np.array_equal(got, ref["proof"])
+    assert oracle.verifier(p, ssp, alpha, beta, s, sk, got)
+    assert int(ctx.to_host(ctx.verify(d_ssp, alpha, beta, s, d_sk, proof, 1))[0]) == 1
+    image = ctx.crs_expand(0, 2 * p.d + p.m, d_crs)
+    assert image.numel() == (2 * p.d + p.m) * ctx.resident_row_bytes() and ctx.resident_row_bytes() == 1472 * 46 * 4
+    ctx.set_resident(image)
+    try:
+        again = ctx.to_host(ctx.prove(d_crs, d_ssp, bits, delta, mags, signs)).copy()
+    finally:
+        ctx.set_resident(None)
+    assert np.array_equal(again, ctx.to_host(proof))
