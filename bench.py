@@ -58,7 +58,9 @@ def build_instance(mf, ctx, torch, p, seed_int):
     alpha, beta, s = (int(x) for x in rng.integers(1, P, size=3, dtype=np.uint64))
     # secret key: n uniform 736-bit values; errors: 559-bit (src/lwe.c:30-34,60-63)
     sk = torch.randint(-(2 ** 63), 2 ** 63 - 1, (p.n, p.L), dtype=torch.int64, device=dev, generator=g)
-    sk[:, p.L - 1] &= (1 << (p.logq - 64 * (p.L - 1))) - 1
+    top_bits = p.logq - 64 * (p.L - 1)
+    if top_bits < 64:
+        sk[:, p.L - 1] &= (1 << top_bits) - 1
     rows = 2 * p.d + p.m
     err = torch.randint(-(2 ** 63), 2 ** 63 - 1, (rows, p.L), dtype=torch.int64, device=dev, generator=g)
     err[:, 8] &= (1 << (559 - 512)) - 1

@@ -112,3 +112,40 @@ def test_linearity_over_a_whole_region(world):
     e0, e1 = ctx.eval_rows(p.ctr_as, p.d, c8, d0, d1)
     e01, _ = ctx.eval_rows(p.ctr_as, p.d, c8, d01)
     assert W["torch"].equal(ctx.ct_add(e0, e1), e01)
+
+
+@pytest.mark.parametrize("logq", [736, 1472])
+def test_2pow20_constraints_instance(gpu_ctx_factory, logq):
+    """BASELINE configs 4/5 in the constraint dimension: D = 2^20 (2 097 216 CRS rows = 284 GB / 567 GB of public stream,
+    polynomial products of length 2^21), with M = 64 wires so that the dense SSP still fits (the reference's 2^20 instance
+    would need a 5.9 TB SSP and cannot be run at all).  Properties: the device verifier accepts the proof, rejects a proof for a
+    flipped witness bit and a tampered ciphertext, and the 3-way sharded proof is byte-identical."""
+    import torch
+
+    import bench
+    import c_lwe_snarks_amd as mf
+
+    p = mf.Params(logq=logq, d=1 << 20, m=64)
+    ctx = gpu_ctx_factory(p)
+    ctx.set_seed(SEED)
+    inst = bench.build_instance(mf, ctx, torch, p, 99 + logq)
+    ctx.ssp_prepare(inst["d_ssp"])
+    d_crs = ctx.setup(inst["d_ssp"], inst["alpha"], inst["beta"], inst["s"], inst["sk"], inst["err"])
+    delta, mags, signs = _entropy(logq)
+    proof = ctx.prove(d_crs, inst["d_ssp"], inst["bits"], delta, mags, signs)
+    ver = lambda pr: int(ctx.to_host(ctx.verify(inst["d_ssp"], inst["alpha"], inst["beta"], inst["s"], inst["sk"], pr, 1))[0])
+    assert ver(proof) == 1
+    bad_bits = bytearray(inst["bits"])
+    bad_bits[3] ^= 2
+    assert ver(ctx.prove(d_crs, inst["d_ssp"], bytes(bad_bits), delta, mags, signs)) == 0
+    tampered = proof.clone()
+    tampered[(3 * p.ct_limbs + p.n * p.L) * 8] ^= 1  # low byte of b in v_w
+    assert ver(tampered) == 0
+    lanes = None
+    for r in range(3):
+        ln = ctx.ct_to_lanes(ctx.prove_partial(d_crs, inst["d_ssp"], inst["bits"], delta, r, 3), 5).clone()
+        lanes = ln if lanes is None else lanes + ln
+    shard = ctx.ct_from_lanes(lanes, 5)
+    ctx.prove_finish(shard, mags, signs)
+    assert torch.equal(shard, proof)
+    ctx.close()
