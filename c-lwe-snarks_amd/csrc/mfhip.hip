@@ -431,6 +431,12 @@ __global__ void k_eval_reduce_carry(const uint64_t *__restrict__ lazy, uint32_t 
   for (int l = S::KW; l < 2 * S::L; l++) out[l] = 0;  // modq: limbs >= K dropped (src/lwe.h:107-118)
 }
 
+// (hi:lo) += a * b  as a 96-bit accumulator: v_mad_u64_u32 (carry out in vcc) + v_addc_co_u32.  Two instructions per product;
+// the compiler's own lowering of `lo += p; hi += lo < p` takes four (64-bit add, 64-bit compare, select, add).
+__device__ __forceinline__ void mac96(uint64_t &lo, uint32_t &hi, uint32_t a, uint32_t b) {
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(hi) : "v"(a), "v"(b) : "vcc");
+}
+
 // ------------------------------------------------------------------------------------------------------
 // encrypt kernel: per row, <sk, a> over a coordinate tile (truncated KW-word products), reduced in LDS.
 // grid = (ntiles, nchunks); thread (rs, t): rows r0 + rs, r0 + rs + ROWS, ...
@@ -500,11 +506,7 @@ __global__ __launch_bounds__(PS<LOGQ>::THREADS) void k_encrypt(AesKey key, const
 #pragma unroll
       for (int k = 0; k < S::KW; k++) {
 #pragma unroll
-        for (int u = 0; u <= k; u++) {
-          const uint64_t pr = (uint64_t)a[u] * s[k - u];
-          lo += pr;
-          hi += lo < pr;
-        }
+        for (int u = 0; u <= k; u++) mac96(lo, hi, a[u], s[k - u]);
         prod[k] = (uint32_t)lo;
         lo = (lo >> 32) | ((uint64_t)hi << 32);
         hi = 0;
