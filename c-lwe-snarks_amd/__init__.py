@@ -89,6 +89,7 @@ EXPORTS = [
     "mfh_prove_partial", "mfh_prove_finish", "mfh_ct_to_lanes", "mfh_ct_from_lanes", "mfh_timing_drain", "mfh_add_dotp",
     "mfh_resident_row_bytes", "mfh_crs_expand", "mfh_eval_rows_resident", "mfh_crs_set_resident",
     "mfh_witness_lanes", "mfh_witness_from_lanes", "mfh_prove_partial_w", "mfh_verify",
+    "mfh_ssp_set_prg", "mfh_ssp_prg_make_t", "mfh_ssp_prg_fill",
 ]
 
 
@@ -137,6 +138,9 @@ def load_library():
         "mfh_ct_to_lanes": (i32, [vp, vp, sz, vp]),
         "mfh_ct_from_lanes": (i32, [vp, vp, sz, vp]),
         "mfh_add_dotp": (i32, [vp, vp, vp, vp, sz]),
+        "mfh_ssp_set_prg": (i32, [vp, u64, vp]),
+        "mfh_ssp_prg_make_t": (i32, [vp, u64, ctypes.c_char_p, vp]),
+        "mfh_ssp_prg_fill": (i32, [vp, u64, sz, sz, vp]),
         "mfh_verify": (i32, [vp, vp, u32, u32, u32, vp, vp, sz, vp]),
         "mfh_witness_lanes": (i32, [vp, vp, ctypes.c_char_p, u32, u32, vp]),
         "mfh_witness_from_lanes": (i32, [vp, vp, vp, u32, vp]),
@@ -407,3 +411,18 @@ class Context:
         ok = self.empty(count)
         self._chk(self.lib.mfh_verify(self._h, _ptr(d_ssp), alpha, beta, s, _ptr(d_sk), _ptr(d_proofs), count, _ptr(ok)))
         return ok
+
+    # -- generator-defined SSP (BASELINE configs 4/5): pass d_ssp=None to the SSP-consuming calls afterwards ---------
+    def ssp_prg_make_t(self, seed64, witness_bits: bytes):
+        t = self.empty(self.params.d * 4)
+        self._chk(self.lib.mfh_ssp_prg_make_t(self._h, seed64, bytes(witness_bits), _ptr(t)))
+        return t
+
+    def ssp_set_prg(self, seed64, d_t):
+        self._prg_t = d_t  # keep alive
+        self._chk(self.lib.mfh_ssp_set_prg(self._h, seed64, _ptr(d_t)))
+
+    def ssp_prg_fill(self, seed64, first_slot, nslots):
+        out = self.empty(nslots * self.params.d * 4)
+        self._chk(self.lib.mfh_ssp_prg_fill(self._h, seed64, first_slot, nslots, _ptr(out)))
+        return out

@@ -9,6 +9,7 @@
 
 #include "aes_dev.hpp"
 #include "mfhip.h"
+#include "ssp_prg.hpp"
 
 #define HIP_TRY(ctx, expr)                                                        \
   do {                                                                            \
@@ -58,6 +59,10 @@ struct mfh_ctx {
   size_t prover_words = 0;
   std::vector<uint32_t> h_cw;
   PinBuf pin_rows, pin_cw, pin_smudge;
+  // generator-defined SSP (ssp_prg.hpp): used by every entry point that is handed d_ssp == NULL
+  bool prg_on = false;
+  uint64_t prg_seed = 0;
+  const uint32_t *prg_t = nullptr;
   const uint8_t *resident_rows = nullptr;  // expanded CRS (mfh_crs_expand layout) or null: regenerate the keystream
 };
 
@@ -102,6 +107,14 @@ inline void pin_free(PinBuf &b) {
   if (b.p) hipHostFree(b.p);
   if (b.ev) hipEventDestroy(b.ev);
   b = PinBuf();
+}
+
+// resolves the d_ssp argument of an entry point: a dense image, or (NULL) the registered generator-defined SSP
+inline int ssp_src(mfh_ctx *c, const uint32_t *d_ssp, mf::SspSrc &src) {
+  if (d_ssp) { src = mf::SspSrc{d_ssp, d_ssp, 0}; return MFH_OK; }
+  if (!c->prg_on || !c->prg_t) { c->err = "d_ssp is NULL and no generator-defined SSP is registered (mfh_ssp_set_prg)"; return MFH_EINVAL; }
+  src = mf::SspSrc{nullptr, c->prg_t, c->prg_seed};
+  return MFH_OK;
 }
 
 void mfh_poly_destroy(mfh_ctx *c);

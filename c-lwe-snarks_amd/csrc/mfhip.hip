@@ -749,6 +749,41 @@ __global__ __launch_bounds__(256) void k_witness_partial(const uint32_t *__restr
   o[0] = s0; o[1] = s1; o[2] = s2; o[3] = s3;
 }
 
+// the same partial sums with generator-defined rows: every thread makes 4 consecutive coefficients of each selected row
+__global__ __launch_bounds__(256) void k_witness_partial_prg(uint64_t seed, const uint32_t *__restrict__ rows, uint32_t nsel, uint32_t d,
+                                                             uint64_t *__restrict__ partial) {
+  const uint32_t k4 = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k4 * 4 >= d) return;
+  const uint32_t G = gridDim.y, g = blockIdx.y;
+  const uint32_t k = k4 * 4;
+  uint64_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  for (uint32_t i = g; i < nsel; i += G) {
+    const uint32_t rk = mf::ssp_prg_rowkey(seed, rows[i]);
+    s0 += mf::ssp_prg_coeff(rk, k);
+    s1 += mf::ssp_prg_coeff(rk, k + 1);
+    s2 += mf::ssp_prg_coeff(rk, k + 2);
+    s3 += mf::ssp_prg_coeff(rk, k + 3);
+  }
+  uint64_t *o = partial + (uint64_t)g * d + k;
+  o[0] = s0; o[1] = s1; o[2] = s2; o[3] = s3;
+}
+// materialise generator-defined slots [first, first+nslots) as a dense uint32 image (tests; small instances)
+__global__ void k_ssp_prg_fill(uint64_t seed, uint32_t first_slot, uint32_t d, uint64_t total, uint32_t *__restrict__ out) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t slot = first_slot + (uint32_t)(i / d), k = (uint32_t)(i % d);
+    out[i] = mf::ssp_prg_coeff(mf::ssp_prg_rowkey(seed, slot), k);
+  }
+}
+// t = v_0 + (summed selected rows) - 1: random_ssp's definition (src/ssp.c:59-71), for a generator-defined SSP
+__global__ void k_ssp_prg_make_t(uint64_t seed, const uint64_t *__restrict__ partial, uint32_t G, uint32_t d, uint32_t *__restrict__ t) {
+  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= d) return;
+  uint64_t s = mf::ssp_prg_coeff(mf::ssp_prg_rowkey(seed, 1), k);  // v_0 = slot 1
+  for (uint32_t g = 0; g < G; g++) s = (s + partial[(uint64_t)g * d + k] % MFH_P) % MFH_P;
+  if (k == 0) s = (s + MFH_P - 1) % MFH_P;
+  t[k] = (uint32_t)s;
+}
+
 __global__ void k_witness_finish(const uint32_t *__restrict__ ssp, const uint64_t *__restrict__ partial, uint32_t G, uint32_t d, uint32_t delta,
                                  uint32_t *__restrict__ w) {
   uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1247,7 +1282,7 @@ int mfh_ssp_upload(mfh_ctx *c, const void *h_ssp_u64, uint32_t *d_ssp, size_t fi
 }
 
 // shared body: partial[g][k] sums over this rank's share of the selected SSP rows
-static int witness_partials(mfh_ctx *c, const uint32_t *d_ssp, const uint8_t *h_bits, uint32_t rank, uint32_t world, uint32_t *G_out,
+static int witness_partials(mfh_ctx *c, const mf::SspSrc &src, const uint8_t *h_bits, uint32_t rank, uint32_t world, uint32_t *G_out,
                             uint64_t **partial_out) {
   const uint32_t d = c->P.d, m = c->P.m;
   if (d % 4) { c->err = "d must be a multiple of 4"; return MFH_EINVAL; }
@@ -1267,33 +1302,74 @@ static int witness_partials(mfh_ctx *c, const uint32_t *d_ssp, const uint8_t *h_
   uint64_t *partial = (uint64_t *)((uint8_t *)c->ws + rows_b);
   if (nsel) HIP_TRY(c, hipMemcpyAsync(d_rows, rows + lo, (size_t)nsel * 4, hipMemcpyHostToDevice, c->stream));
   pin_release(c, c->pin_rows);
-  hipLaunchKernelGGL(k_witness_partial, dim3((d / 4 + 255) / 256, G), dim3(256), 0, c->stream, d_ssp, d_rows, nsel, d, partial);
+  if (src.dense)
+    hipLaunchKernelGGL(k_witness_partial, dim3((d / 4 + 255) / 256, G), dim3(256), 0, c->stream, src.dense, d_rows, nsel, d, partial);
+  else
+    hipLaunchKernelGGL(k_witness_partial_prg, dim3((d / 4 + 255) / 256, G), dim3(256), 0, c->stream, src.seed, d_rows, nsel, d, partial);
   HIP_TRY(c, hipGetLastError());
   *G_out = G;
   *partial_out = partial;
   return MFH_OK;
 }
 
-int mfh_witness_poly(mfh_ctx *c, const uint32_t *d_ssp, const uint8_t *h_bits, uint32_t delta, uint32_t *d_w) {
-  if (!c || !d_ssp || !h_bits || !d_w) return MFH_EINVAL;
-  if (delta >= MFH_P) { c->err = "delta must be < p"; return MFH_EINVAL; }
+int mfh_ssp_set_prg(mfh_ctx *c, uint64_t seed, const uint32_t *d_t) {
+  if (!c) return MFH_EINVAL;
+  c->prg_on = d_t != nullptr;
+  c->prg_seed = seed;
+  c->prg_t = d_t;
+  return MFH_OK;
+}
+
+int mfh_ssp_prg_fill(mfh_ctx *c, uint64_t seed, size_t first_slot, size_t nslots, uint32_t *d_out) {
+  if (!c || !d_out) return MFH_EINVAL;
   HIP_TRY(c, hipSetDevice(c->device));
+  const uint64_t total = (uint64_t)nslots * c->P.d;
+  if (!total) return MFH_OK;
+  hipLaunchKernelGGL(k_ssp_prg_fill, dim3((uint32_t)std::min<uint64_t>((total + 255) / 256, 4096)), dim3(256), 0, c->stream, seed, (uint32_t)first_slot,
+                     c->P.d, total, d_out);
+  HIP_TRY(c, hipGetLastError());
+  return MFH_OK;
+}
+
+int mfh_ssp_prg_make_t(mfh_ctx *c, uint64_t seed, const uint8_t *h_bits, uint32_t *d_t) {
+  if (!c || !h_bits || !d_t) return MFH_EINVAL;
+  HIP_TRY(c, hipSetDevice(c->device));
+  mf::SspSrc src{nullptr, d_t, seed};
   uint32_t G;
   uint64_t *partial;
-  int rc = witness_partials(c, d_ssp, h_bits, 0, 1, &G, &partial);
+  int rc = witness_partials(c, src, h_bits, 0, 1, &G, &partial);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_witness_finish, dim3((c->P.d + 255) / 256), dim3(256), 0, c->stream, d_ssp, partial, G, c->P.d, delta, d_w);
+  hipLaunchKernelGGL(k_ssp_prg_make_t, dim3((c->P.d + 255) / 256), dim3(256), 0, c->stream, seed, partial, G, c->P.d, d_t);
+  HIP_TRY(c, hipGetLastError());
+  return MFH_OK;
+}
+
+int mfh_witness_poly(mfh_ctx *c, const uint32_t *d_ssp, const uint8_t *h_bits, uint32_t delta, uint32_t *d_w) {
+  if (!c || !h_bits || !d_w) return MFH_EINVAL;
+  if (delta >= MFH_P) { c->err = "delta must be < p"; return MFH_EINVAL; }
+  HIP_TRY(c, hipSetDevice(c->device));
+  mf::SspSrc src;
+  int rc = ssp_src(c, d_ssp, src);
+  if (rc) return rc;
+  uint32_t G;
+  uint64_t *partial;
+  rc = witness_partials(c, src, h_bits, 0, 1, &G, &partial);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_witness_finish, dim3((c->P.d + 255) / 256), dim3(256), 0, c->stream, src.t, partial, G, c->P.d, delta, d_w);
   HIP_TRY(c, hipGetLastError());
   return MFH_OK;
 }
 
 // rank's share of sum_{bit} v_i as d uint64 lanes, each already reduced mod p (so `world` of them sum without overflow)
 int mfh_witness_lanes(mfh_ctx *c, const uint32_t *d_ssp, const uint8_t *h_bits, uint32_t rank, uint32_t world, uint64_t *d_lanes) {
-  if (!c || !d_ssp || !h_bits || !d_lanes || world == 0 || rank >= world) return MFH_EINVAL;
+  if (!c || !h_bits || !d_lanes || world == 0 || rank >= world) return MFH_EINVAL;
   HIP_TRY(c, hipSetDevice(c->device));
+  mf::SspSrc src;
+  int rc = ssp_src(c, d_ssp, src);
+  if (rc) return rc;
   uint32_t G;
   uint64_t *partial;
-  int rc = witness_partials(c, d_ssp, h_bits, rank, world, &G, &partial);
+  rc = witness_partials(c, src, h_bits, rank, world, &G, &partial);
   if (rc) return rc;
   hipLaunchKernelGGL(k_witness_lanes, dim3((c->P.d + 255) / 256), dim3(256), 0, c->stream, partial, G, c->P.d, d_lanes);
   HIP_TRY(c, hipGetLastError());
@@ -1302,10 +1378,13 @@ int mfh_witness_lanes(mfh_ctx *c, const uint32_t *d_ssp, const uint8_t *h_bits, 
 
 // w = delta*t + (summed lanes) mod p
 int mfh_witness_from_lanes(mfh_ctx *c, const uint32_t *d_ssp, const uint64_t *d_lanes, uint32_t delta, uint32_t *d_w) {
-  if (!c || !d_ssp || !d_lanes || !d_w) return MFH_EINVAL;
+  if (!c || !d_lanes || !d_w) return MFH_EINVAL;
   if (delta >= MFH_P) { c->err = "delta must be < p"; return MFH_EINVAL; }
   HIP_TRY(c, hipSetDevice(c->device));
-  hipLaunchKernelGGL(k_witness_finish, dim3((c->P.d + 255) / 256), dim3(256), 0, c->stream, d_ssp, d_lanes, 1u, c->P.d, delta, d_w);
+  mf::SspSrc src;
+  int rc0 = ssp_src(c, d_ssp, src);
+  if (rc0) return rc0;
+  hipLaunchKernelGGL(k_witness_finish, dim3((c->P.d + 255) / 256), dim3(256), 0, c->stream, src.t, d_lanes, 1u, c->P.d, delta, d_w);
   HIP_TRY(c, hipGetLastError());
   return MFH_OK;
 }

@@ -21,6 +21,12 @@ __device__ __forceinline__ uint32_t red_p32(uint64_t x) {
 }
 __device__ __forceinline__ uint32_t mulmod(uint32_t a, uint32_t b) { return red_p32((uint64_t)a * b); }
 
+// coefficient k of SSP slot `slot` from either source (ssp_prg.hpp)
+__device__ __forceinline__ uint32_t ssp_coef(const mf::SspSrc &src, uint32_t slot, uint32_t rowkey, uint32_t d, uint32_t k) {
+  if (src.dense) return src.dense[(uint64_t)slot * d + k];
+  return slot == 0 ? src.t[k] : mf::ssp_prg_coeff(rowkey, k);
+}
+
 // pw[k] = s^k mod p
 __global__ void k_powers(uint32_t s, uint32_t d, uint32_t *__restrict__ pw) {
   uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -42,27 +48,42 @@ __global__ void k_msg_powers(const uint32_t *__restrict__ pw, uint32_t d, uint32
 }
 // msg[2d + r] = beta * <slot(r), pw>, slot(0) = t (slot 0), slot(r) = v_r (slot r+1) for r = 1..m-1: Horner's value
 // nmod_poly_evaluate_nmod(v_i, s) * beta (src/snark.c:97-98,105-106), computed as a dot product with the powers of s.
-__global__ __launch_bounds__(256) void k_msg_evals(const uint32_t *__restrict__ ssp, const uint32_t *__restrict__ pw, uint32_t d, uint32_t beta,
+__global__ __launch_bounds__(256) void k_msg_evals(mf::SspSrc src, const uint32_t *__restrict__ pw, uint32_t d, uint32_t beta,
                                                    uint32_t *__restrict__ msg) {
   __shared__ uint64_t red[4];
   const uint32_t r = blockIdx.x;
   const uint32_t slot = r == 0 ? 0 : r + 1;
-  const uint32_t *row = ssp + (uint64_t)slot * d;
   uint64_t acc = 0;
-  for (uint32_t k = threadIdx.x * 4; k < d; k += 256 * 4) {
-    const uint4 v = *reinterpret_cast<const uint4 *>(row + k);
-    const uint4 w = *reinterpret_cast<const uint4 *>(pw + k);
-    uint64_t p0 = (uint64_t)v.x * w.x, p1 = (uint64_t)v.y * w.y, p2 = (uint64_t)v.z * w.z, p3 = (uint64_t)v.w * w.w;
-    acc += (p0 >> 32) * 5 + (uint32_t)p0;  // each < 2^35: > 2^28 terms before overflow
-    acc += (p1 >> 32) * 5 + (uint32_t)p1;
-    acc += (p2 >> 32) * 5 + (uint32_t)p2;
-    acc += (p3 >> 32) * 5 + (uint32_t)p3;
+  if (src.dense || slot == 0) {
+    const uint32_t *row = src.dense ? src.dense + (uint64_t)slot * d : src.t;
+    for (uint32_t k = threadIdx.x * 4; k < d; k += 256 * 4) {
+      const uint4 v = *reinterpret_cast<const uint4 *>(row + k);
+      const uint4 w = *reinterpret_cast<const uint4 *>(pw + k);
+      uint64_t p0 = (uint64_t)v.x * w.x, p1 = (uint64_t)v.y * w.y, p2 = (uint64_t)v.z * w.z, p3 = (uint64_t)v.w * w.w;
+      acc += (p0 >> 32) * 5 + (uint32_t)p0;  // each < 2^35: > 2^28 terms before overflow
+      acc += (p1 >> 32) * 5 + (uint32_t)p1;
+      acc += (p2 >> 32) * 5 + (uint32_t)p2;
+      acc += (p3 >> 32) * 5 + (uint32_t)p3;
+    }
+  } else {
+    const uint32_t rk = mf::ssp_prg_rowkey(src.seed, slot);
+    for (uint32_t k = threadIdx.x; k < d; k += 256) {
+      const uint64_t pr = (uint64_t)mf::ssp_prg_coeff(rk, k) * pw[k];
+      acc += (pr >> 32) * 5 + (uint32_t)pr;
+    }
   }
   acc = red_p32(acc);
   for (int o = 32; o; o >>= 1) acc += __shfl_xor(acc, o);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) msg[2 * d + r] = mulmod(red_p32(red[0] + red[1] + red[2] + red[3]), beta);
+}
+
+// out = a + (slot `slot` of the SSP) mod p
+__global__ void k_add_slot(const uint32_t *__restrict__ a, mf::SspSrc src, uint32_t slot, uint32_t d, uint32_t *__restrict__ out) {
+  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= d) return;
+  out[k] = red_p32((uint64_t)a[k] + ssp_coef(src, slot, mf::ssp_prg_rowkey(src.seed, slot), d, k));
 }
 
 // ciphertext values (KW significant 32-bit words each) <-> one uint64 "lane" per 32-bit word.  Lanes of several
@@ -90,12 +111,13 @@ __global__ void k_ct_from_lanes(const uint64_t *__restrict__ lanes, uint64_t nva
 }
 
 // scal[r] = <slot r, pw> mod p for r = 0 (t) and 1 (v_0): nmod_poly_evaluate_nmod of src/snark.c:201,213
-__global__ __launch_bounds__(256) void k_eval_slots01(const uint32_t *__restrict__ ssp, const uint32_t *__restrict__ pw, uint32_t d, uint32_t *__restrict__ scal) {
+__global__ __launch_bounds__(256) void k_eval_slots01(mf::SspSrc src, const uint32_t *__restrict__ pw, uint32_t d, uint32_t *__restrict__ scal) {
   __shared__ uint64_t red[4];
-  const uint32_t *row = ssp + (uint64_t)blockIdx.x * d;
+  const uint32_t slot = blockIdx.x;
+  const uint32_t rk = mf::ssp_prg_rowkey(src.seed, slot);
   uint64_t acc = 0;
   for (uint32_t k = threadIdx.x; k < d; k += 256) {
-    uint64_t pr = (uint64_t)row[k] * pw[k];
+    uint64_t pr = (uint64_t)ssp_coef(src, slot, rk, d, k) * pw[k];
     acc += (pr >> 32) * 5 + (uint32_t)pr;
   }
   acc = red_p32(acc);
@@ -142,29 +164,35 @@ int aux_reserve(mfh_ctx *c, size_t bytes) {
 extern "C" {
 
 int mfh_ssp_prepare(mfh_ctx *c, const uint32_t *d_ssp) {
-  if (!c || !d_ssp) return MFH_EINVAL;
-  return mfh_poly_prepare_t(c, d_ssp);  // slot 0 = t
+  if (!c) return MFH_EINVAL;
+  mf::SspSrc src;
+  int rc = ssp_src(c, d_ssp, src);
+  if (rc) return rc;
+  return mfh_poly_prepare_t(c, src.t);  // slot 0 = t
 }
 
 int mfh_setup_messages(mfh_ctx *c, const uint32_t *d_ssp, uint32_t alpha, uint32_t beta, uint32_t s, uint32_t *d_msg) {
-  if (!c || !d_ssp || !d_msg) return MFH_EINVAL;
+  if (!c || !d_msg) return MFH_EINVAL;
   if (alpha >= P32 || beta >= P32 || s >= P32) { c->err = "alpha, beta, s must be < p"; return MFH_EINVAL; }
   const uint32_t d = c->P.d, m = c->P.m;
   if (d % 4) { c->err = "d must be a multiple of 4"; return MFH_EINVAL; }
   HIP_TRY(c, hipSetDevice(c->device));
-  int rc = aux_reserve(c, (size_t)d * 4);
+  mf::SspSrc src;
+  int rc = ssp_src(c, d_ssp, src);
+  if (rc) return rc;
+  rc = aux_reserve(c, (size_t)d * 4);
   if (rc) return rc;
   uint32_t *pw = (uint32_t *)c->aux;
   hipLaunchKernelGGL(k_powers, g1(d), dim3(256), 0, c->stream, s, d, pw);
   hipLaunchKernelGGL(k_msg_powers, g1(d), dim3(256), 0, c->stream, pw, d, alpha, d_msg);
-  hipLaunchKernelGGL(k_msg_evals, dim3(m), dim3(256), 0, c->stream, d_ssp, pw, d, beta, d_msg);
+  hipLaunchKernelGGL(k_msg_evals, dim3(m), dim3(256), 0, c->stream, src, pw, d, beta, d_msg);
   HIP_TRY(c, hipGetLastError());
   return MFH_OK;
 }
 
 int mfh_setup(mfh_ctx *c, const uint32_t *d_ssp, uint32_t alpha, uint32_t beta, uint32_t s, const uint64_t *d_sk, const uint64_t *d_err,
               uint8_t *d_crs_c8) {
-  if (!c || !d_ssp || !d_sk || !d_err || !d_crs_c8) return MFH_EINVAL;
+  if (!c || !d_sk || !d_err || !d_crs_c8) return MFH_EINVAL;
   const size_t rows = (size_t)2 * c->P.d + c->P.m;
   HIP_TRY(c, hipSetDevice(c->device));
   if (!c->d_msg || c->msg_rows < rows) {
@@ -180,16 +208,19 @@ int mfh_setup(mfh_ctx *c, const uint32_t *d_ssp, uint32_t alpha, uint32_t beta, 
 
 int mfh_verify(mfh_ctx *c, const uint32_t *d_ssp, uint32_t alpha, uint32_t beta, uint32_t s, const uint64_t *d_sk, const uint64_t *d_proofs,
                size_t count, uint8_t *d_ok) {
-  if (!c || !d_ssp || !d_sk || (count && (!d_proofs || !d_ok))) return MFH_EINVAL;
+  if (!c || !d_sk || (count && (!d_proofs || !d_ok))) return MFH_EINVAL;
   if (alpha >= P32 || beta >= P32 || s >= P32) { c->err = "alpha, beta, s must be < p"; return MFH_EINVAL; }
   if (!count) return MFH_OK;
   const uint32_t d = c->P.d;
   HIP_TRY(c, hipSetDevice(c->device));
-  int rc = aux_reserve(c, (size_t)d * 4 + 16 + count * 5 * 4);
+  mf::SspSrc src;
+  int rc = ssp_src(c, d_ssp, src);
+  if (rc) return rc;
+  rc = aux_reserve(c, (size_t)d * 4 + 16 + count * 5 * 4);
   if (rc) return rc;
   uint32_t *pw = (uint32_t *)c->aux, *scal = pw + d, *dec = scal + 4;
   hipLaunchKernelGGL(k_powers, g1(d), dim3(256), 0, c->stream, s, d, pw);
-  hipLaunchKernelGGL(k_eval_slots01, dim3(2), dim3(256), 0, c->stream, d_ssp, pw, d, scal);
+  hipLaunchKernelGGL(k_eval_slots01, dim3(2), dim3(256), 0, c->stream, src, pw, d, scal);
   HIP_TRY(c, hipGetLastError());
   rc = mfh_decrypt(c, d_sk, d_proofs, 5 * count, dec);
   if (rc) return rc;
@@ -220,8 +251,13 @@ int mfh_ct_from_lanes(mfh_ctx *c, const uint64_t *d_lanes, size_t count, uint64_
 
 static int prove_partial_impl(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, const uint8_t *h_witness_bits, uint32_t delta,
                               uint32_t rank, uint32_t world, const uint64_t *d_wlanes, uint64_t *d_partial) {
-  if (!c || !d_crs_c8 || !d_ssp || !h_witness_bits || !d_partial || world == 0 || rank >= world) return MFH_EINVAL;
+  if (!c || !d_crs_c8 || !h_witness_bits || !d_partial || world == 0 || rank >= world) return MFH_EINVAL;
   if (delta >= P32) { c->err = "delta must be < p"; return MFH_EINVAL; }
+  mf::SspSrc src;
+  {
+    int rc0 = ssp_src(c, d_ssp, src);
+    if (rc0) return rc0;
+  }
   const uint32_t d = c->P.d, m = c->P.m, n = c->P.n;
   const uint32_t L = (c->P.logq + 63) / 64, ctb = c->P.logq / 8;
   const size_t ctl = (size_t)(n + 1) * L;
@@ -259,8 +295,8 @@ static int prove_partial_impl(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_
            : mfh_eval_rows(c, 2 * ctr_ct * d + ctr_ct * lo, cnt, d_crs_c8 + ((size_t)2 * d + lo) * ctb, cw + lo, nullptr, pi_b_w, nullptr, 0);
   if (rc) return rc;
   // v = w + v_0 ; h = (v^2 - 1) / t   (src/snark.c:161-169)
-  rc = mfh_poly_add(c, w, d_ssp + (size_t)d, d, v);
-  if (rc) return rc;
+  hipLaunchKernelGGL(k_add_slot, g1(d), dim3(256), 0, c->stream, w, src, 1u, d, v);
+  HIP_TRY(c, hipGetLastError());
   rc = mfh_poly_h(c, v, h);
   if (rc) return rc;
   // S rows: (w, h) -> (v_w, h);  AS rows: (v, h) -> (hat_v, hat_h)   (src/snark.c:157-158,163-164,171-174, each row expanded once)

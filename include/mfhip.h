@@ -125,6 +125,17 @@ int mfh_ssp_upload(mfh_ctx *ctx, const void *h_ssp_u64, uint32_t *d_ssp, size_t 
  * h_witness_bits: little-endian bit string, bit i-1 <-> v_i (mpz_tstbit).  d_w: d uint32. */
 int mfh_witness_poly(mfh_ctx *ctx, const uint32_t *d_ssp, const uint8_t *h_witness_bits, uint32_t delta, uint32_t *d_w);
 
+/* Generator-defined SSP (BASELINE configs 4/5; SURVEY 8(d): "SSP coefficients defined by a counter-based PRG (not stored)").
+ * The dense buffer of src/ssp.h:6-9 is 5.9 TB at 2^20 constraints; here v_i[k] = f(seed, slot i+1, k) (a 32-bit integer hash
+ * reduced into [0,p), csrc/ssp_prg.hpp) and only slot 0 (t, d uint32) is stored.  mfh_ssp_prg_make_t builds
+ * t = v_0 + sum_{witness bit} v_i - 1 as random_ssp does (src/ssp.c:59-71); mfh_ssp_set_prg(ctx, seed, d_t) registers the SSP,
+ * after which EVERY entry point that takes `d_ssp` accepts NULL to mean "the registered generator-defined SSP"
+ * (mfh_witness_poly, mfh_witness_lanes, mfh_ssp_prepare, mfh_setup_messages, mfh_setup, mfh_prove*, mfh_verify).
+ * mfh_ssp_prg_fill materialises slots [first_slot, first_slot+nslots) (slots >= 1) as a dense uint32 image (tests). */
+int mfh_ssp_set_prg(mfh_ctx *ctx, uint64_t seed, const uint32_t *d_t);
+int mfh_ssp_prg_make_t(mfh_ctx *ctx, uint64_t seed, const uint8_t *h_witness_bits, uint32_t *d_t);
+int mfh_ssp_prg_fill(mfh_ctx *ctx, uint64_t seed, size_t first_slot, size_t nslots, uint32_t *d_out);
+
 /* ---- L3/L4: polynomial step, setup, prover ------------------------------------------------------------ */
 /* c = a*b over F_p[x] (la+lb-1 canonical coefficients).  What nmod_poly_mul/pow compute (src/snark.c:167). */
 int mfh_poly_mul(mfh_ctx *ctx, const uint32_t *d_a, size_t la, const uint32_t *d_b, size_t lb, uint32_t *d_c);

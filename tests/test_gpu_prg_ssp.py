@@ -1,0 +1,107 @@
+"""GPU: the generator-defined SSP (BASELINE configs 4/5).  Small sizes: generator mode == dense mode on the
+materialised image == the oracle.  Full config shapes (D = 2^20 constraints, M = 699 050 wires; log q = 736 and 1472), which the
+reference cannot run at all: setup -> prover -> device verifier, acceptance / rejection properties."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+SEED = bytes((17 * i + 9) & 0xFF for i in range(40))
+PRG_SEED = 0x0123456789ABCDEF
+
+
+@pytest.fixture(scope="module")
+def mf():
+    import c_lwe_snarks_amd as m
+
+    return m
+
+
+def test_generator_mode_equals_dense_mode_and_oracle(gpu_ctx_factory, oracle, mf):
+    p = mf.DEBUG
+    ctx = gpu_ctx_factory(p)
+    ctx.set_seed(SEED)
+    rng = np.random.default_rng(5)
+    bits = rng.bytes((p.m + 7) // 8)
+    d_t = ctx.ssp_prg_make_t(PRG_SEED, bits)
+    ctx.ssp_set_prg(PRG_SEED, d_t)
+    import torch
+
+    dense = torch.cat([d_t, ctx.ssp_prg_fill(PRG_SEED, 1, p.m + 2)])  # slot 0 = t, slots 1.. = generator
+    host = ctx.to_host(dense, np.uint32).astype(np.uint64)  # the oracle's (and the reference's) uint64 layout
+    assert (host < ol.P).all()
+    ssp2 = host.reshape(p.m + 3, p.d)
+    v = ssp2[1].copy()
+    for i in range(1, p.m):
+        if (bits[(i - 1) >> 3] >> ((i - 1) & 7)) & 1:
+            v = (v + ssp2[i + 1]) % np.uint64(ol.P)
+    assert oracle.poly_divides(v, ssp2[0])  # make_t built a valid instance
+    delta = 31337
+    assert torch.equal(ctx.witness_poly(None, bits, delta), ctx.witness_poly(dense, bits, delta))
+    alpha, beta, s = (int(x) for x in rng.integers(1, ol.P, size=3, dtype=np.uint64))
+    assert torch.equal(ctx.setup_messages(None, alpha, beta, s), ctx.setup_messages(dense, alpha, beta, s))
+    sk = ol.rand_values(rng, p.n, p.L, p.logq)
+    etape = ol.rand_values(rng, 2 * p.d + p.m, p.L, 559)
+    d_sk, d_err = ctx.to_device(sk), ctx.to_device(etape)
+    ctx.ssp_prepare(None)
+    d_crs = ctx.setup(None, alpha, beta, s, d_sk, d_err)
+    crs = oracle.setup(p, SEED, host, alpha, beta, s, sk, etape)
+    assert np.array_equal(ctx.to_host(d_crs), np.concatenate([crs["s"], crs["as_"], crs["t"], crs["v"][: (p.m - 1) * p.ctb]]))
+    mags = rng.integers(0, 256, size=400, dtype=np.uint8).tobytes()
+    signs = bytes([1, 0, 0, 1, 0])
+    proof = ctx.prove(d_crs, None, bits, delta, mags, signs)
+    t5 = b"".join(mags[80 * k: 80 * k + 80] + signs[k: k + 1] for k in range(5))
+    ref = oracle.prover(p, crs, host, bits, delta, t5, 80)
+    assert np.array_equal(ctx.to_host(proof, np.uint64).reshape(5, p.n + 1, p.L), ref["proof"])
+    assert int(ctx.to_host(ctx.verify(None, alpha, beta, s, d_sk, proof, 1))[0]) == 1
+    assert int(ctx.to_host(ctx.verify(dense, alpha, beta, s, d_sk, proof, 1))[0]) == 1
+    # sharded witness lanes in generator mode
+    lanes = sum(ctx.witness_lanes(None, bits, r, 3).clone() for r in range(3))
+    part = ctx.prove_partial_w(d_crs, None, bits, delta, 0, 1, lanes)
+    ctx.prove_finish(part, mags, signs)
+    assert torch.equal(part, proof)
+
+
+@pytest.mark.parametrize("logq", [736, 1472])
+def test_full_2pow20_config_shape(gpu_ctx_factory, mf, logq):
+    """BASELINE config 4 (logq 736) / 5 (logq 1472): D = 1 048 576, M = 699 050: 2 796 202 CRS rows, 378 / 757 GB of public
+    stream regenerated per proof, 3.7e11 generator-defined SSP coefficients per witness polynomial."""
+    import torch
+
+    p = mf.Params(logq=logq, d=1 << 20, m=699050)
+    ctx = gpu_ctx_factory(p)
+    ctx.set_seed(SEED)
+    rng = np.random.default_rng(logq)
+    bits = rng.bytes((p.m + 7) // 8)
+    d_t = ctx.ssp_prg_make_t(PRG_SEED, bits)
+    ctx.ssp_set_prg(PRG_SEED, d_t)
+    ctx.ssp_prepare(None)
+    alpha, beta, s = (int(x) for x in rng.integers(1, ol.P, size=3, dtype=np.uint64))
+    g = torch.Generator(device=ctx.device)
+    g.manual_seed(logq)
+    sk = torch.randint(-(2 ** 63), 2 ** 63 - 1, (p.n, p.L), dtype=torch.int64, device=ctx.device, generator=g)
+    if p.logq - 64 * (p.L - 1) < 64:
+        sk[:, p.L - 1] &= (1 << (p.logq - 64 * (p.L - 1))) - 1
+    rows = 2 * p.d + p.m
+    err = torch.randint(-(2 ** 63), 2 ** 63 - 1, (rows, p.L), dtype=torch.int64, device=ctx.device, generator=g)
+    err[:, 8] &= (1 << 47) - 1
+    err[:, 9:] = 0
+    d_sk, d_err = sk.view(torch.uint8).reshape(-1), err.view(torch.uint8).reshape(-1)
+    d_crs = ctx.setup(None, alpha, beta, s, d_sk, d_err)
+    del err, d_err
+    delta = int(rng.integers(0, ol.P, dtype=np.uint64))
+    mags = rng.integers(0, 256, size=400, dtype=np.uint8).tobytes()
+    signs = bytes([0, 1, 1, 0, 1])
+    torch.cuda.synchronize()
+    import time
+
+    t0 = time.perf_counter()
+    proof = ctx.prove(d_crs, None, bits, delta, mags, signs)
+    torch.cuda.synchronize()
+    print(f"\n[config D=2^20 M=699050 logq={logq}] one proof on one MI355X: {time.perf_counter() - t0:.3f} s")
+    assert int(ctx.to_host(ctx.verify(None, alpha, beta, s, d_sk, proof, 1))[0]) == 1
+    bad = bytearray(bits)
+    bad[1000] ^= 8
+    assert int(ctx.to_host(ctx.verify(None, alpha, beta, s, d_sk, ctx.prove(d_crs, None, bytes(bad), delta, mags, signs), 1))[0]) == 0
+    ctx.close()
