@@ -27,7 +27,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import numpy as np  # noqa: E402
 
-ROW_BYTES = 1471 * 92  # algorithmic bytes of one expanded ciphertext row (keystream + b)
+ROW_BYTES = 1471 * 92  # algorithmic bytes of one expanded ciphertext row (keystream + b); x2 at logq 1472
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 
@@ -69,6 +69,27 @@ def build_instance(mf, ctx, torch, p, seed_int):
                 err=err.view(torch.uint8).reshape(-1), t_host=t.cpu().numpy(), v0_host=v0.cpu().numpy())
 
 
+def build_prg_instance(mf, ctx, torch, p, seed_int):
+    """BASELINE configs 4/5: generator-defined SSP (csrc/ssp_prg.hpp), only t is stored; d_ssp = None selects it."""
+    rng = np.random.default_rng(seed_int)
+    bits = rng.bytes((p.m + 7) // 8)
+    prg_seed = 0x5EED5EED00000000 | seed_int
+    d_t = ctx.ssp_prg_make_t(prg_seed, bits)
+    ctx.ssp_set_prg(prg_seed, d_t)
+    alpha, beta, s = (int(x) for x in rng.integers(1, mf.P, size=3, dtype=np.uint64))
+    g = torch.Generator(device=ctx.device)
+    g.manual_seed(seed_int)
+    sk = torch.randint(-(2 ** 63), 2 ** 63 - 1, (p.n, p.L), dtype=torch.int64, device=ctx.device, generator=g)
+    top_bits = p.logq - 64 * (p.L - 1)
+    if top_bits < 64:
+        sk[:, p.L - 1] &= (1 << top_bits) - 1
+    rows = 2 * p.d + p.m
+    err = torch.randint(-(2 ** 63), 2 ** 63 - 1, (rows, p.L), dtype=torch.int64, device=ctx.device, generator=g)
+    err[:, 8] &= (1 << (559 - 512)) - 1
+    err[:, 9:] = 0
+    return dict(d_ssp=None, bits=bits, alpha=alpha, beta=beta, s=s, sk=sk.view(torch.uint8).reshape(-1), err=err.view(torch.uint8).reshape(-1))
+
+
 def horner(coeffs, x, P):
     r = 0
     for c in reversed(coeffs.tolist()):
@@ -95,6 +116,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-resident", action="store_true", help="skip the resident-CRS regime")
+    ap.add_argument("--workload", choices=["default", "config4", "config5"], default="default",
+                    help="default = benchmark_snark NDEBUG instance (the driver's workload); config4/config5 = BASELINE's 2^20-constraint "
+                         "instance (M = 699050, generator-defined SSP) at logq 736 / 1472")
     ap.add_argument("--cpu-rows", type=int, default=20000, help="rows of the CPU baseline sample (~0.65 ms each on one core)")
     args = ap.parse_args()
 
@@ -125,11 +149,16 @@ def main():
     if world != args.gpus and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
-    p = mf.DEFAULT
+    big = args.workload != "default"
+    p = mf.DEFAULT if not big else mf.Params(logq=736 if args.workload == "config4" else 1472, d=1 << 20, m=699050)
     ctx = mf.Context(p, local_rank)
     seed = bytes((37 * i + 11) & 0xFF for i in range(40))
     ctx.set_seed(seed)
-    inst = build_instance(mf, ctx, torch, p, 20260101)
+    if not big:
+        inst = build_instance(mf, ctx, torch, p, 20260101)
+    else:
+        inst = build_prg_instance(mf, ctx, torch, p, 20260101)
+        args.no_resident = True  # the expanded CRS of these configs (362 / 724 GB) does not fit one GPU
     ctx.ssp_prepare(inst["d_ssp"])  # per-circuit constant: rev(t)^-1 (depends on the SSP only)
 
     def barrier():
@@ -174,7 +203,13 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    accepted = verify_on_gpu(mf, ctx, inst, proof) if rank == 0 else True
+    if rank != 0:
+        accepted = True
+    elif big:
+        accepted = bool(int(ctx.to_host(ctx.verify(None, inst["alpha"], inst["beta"], inst["s"], inst["sk"], proof, 1))[0]))
+    else:
+        accepted = verify_on_gpu(mf, ctx, inst, proof) and bool(
+            int(ctx.to_host(ctx.verify(inst["d_ssp"], inst["alpha"], inst["beta"], inst["s"], inst["sk"], proof, 1))[0]))
 
     # ---- second regime: the expanded CRS resident in HBM (11.3 GB), streamed at HBM speed
     resident = None
@@ -229,7 +264,7 @@ def main():
     # ---- LWE batch (BASELINE config 1/2: one batch of 65 536 encryptions, rows at stream offset k*135240)
     enc_per_s = None
     if rank == 0:
-        B = 65536
+        B = 65536 if not big else 16384
         msg = ctx.to_device(np.random.default_rng(5).integers(0, mf.P, size=B, dtype=np.uint64).astype(np.uint32))
         errB = inst["err"][: B * p.L * 8]
         outB = ctx.empty(B * p.ctb)
@@ -242,7 +277,7 @@ def main():
 
     # ---- CPU baseline: the oracle's reference-faithful row touch (ct_import + ct_addmul_ui), one thread
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not big:
         import oracle_lib as ol
 
         o = ol.Oracle()
@@ -277,7 +312,8 @@ def main():
         ms_step = elapsed / args.steps * 1e3
         launch_rows = rows2 / max(n2, 1)
         avg_ms = ms2 / max(n2, 1)
-        achieved = launch_rows * ROW_BYTES / (avg_ms * 1e-3) / 1e9 if n2 else None
+        row_bytes = (p.n + 1) * p.ctb
+        achieved = launch_rows * row_bytes / (avg_ms * 1e-3) / 1e9 if n2 else None
         traffic = None
         tf = os.path.join(ROOT, "profiles", "traffic_eval2.json")
         if os.path.exists(tf):
@@ -298,20 +334,22 @@ def main():
             "vs_baseline": None,
             "dtype": "u32 limbs (704-bit integers mod 2^704) + AES-256 bytes",
             "data": "synthetic (valid random SSP, random witness, seeded secrets)",
-            "config": {"workload": "benchmark_snark default SSP instance (NDEBUG): D=32768, M=21845, N=1470, logq=736; full prover() "
-                                   "from the compressed CRS, keystream regenerated in the timed region",
+            "config": {"workload": ("benchmark_snark default SSP instance (NDEBUG): D=32768, M=21845, N=1470, logq=736; full prover() "
+                                    "from the compressed CRS, keystream regenerated in the timed region") if not big else
+                                   (f"BASELINE {args.workload}: D=2^20, M=699050, N=1470, logq={p.logq}, generator-defined SSP; full prover() from the "
+                                    "compressed CRS, keystream regenerated in the timed region"),
                        "rows_per_proof": rows_crs, "sharding": f"CRS rows over {world} rank(s), 1 all-reduce/proof" if world > 1 else "single GPU"},
             "proof_accepted": bool(accepted),
             "lwe_enc_per_s": enc_per_s,
             "setup_s": setup_s,
             "setup_enc_per_s": rows_crs / setup_s,
-            "roofline": {"bound": "hbm", "kernel": "k_eval<736,2> (fused AES-256-CTR expansion + 2x MAC, S and AS regions)",
+            "roofline": {"bound": "hbm", "kernel": f"k_eval<{p.logq},2> (fused AES-256-CTR expansion + 2x MAC, S and AS regions)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                          "traffic": traffic, "launches": n2, "avg_launch_ms": avg_ms, "rows_per_launch": launch_rows,
-                         "bytes_per_row": ROW_BYTES,
+                         "bytes_per_row": row_bytes,
                          "note": "algorithmic bytes = expanded row bytes; the kernel regenerates them with AES on the CU (LDS T-tables), "
                                  "it is LDS-lookup/VALU bound and moves ~0 HBM bytes: see DESIGN.md",
-                         "aes_gblocks_per_s": (launch_rows * 8452.5 / (avg_ms * 1e-3) / 1e9) if n2 else None},
+                         "aes_gblocks_per_s": (launch_rows * (p.ctr_ct / 16.0) / (avg_ms * 1e-3) / 1e9) if n2 else None},
             "eval1": {"launches": n1, "avg_launch_ms": ms1 / max(n1, 1), "rows_per_launch": rows1 / max(n1, 1)},
             "resident_crs": resident,
             "cpu_baseline": cpu,
