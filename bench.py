@@ -158,7 +158,10 @@ def main():
         inst = build_instance(mf, ctx, torch, p, 20260101)
     else:
         inst = build_prg_instance(mf, ctx, torch, p, 20260101)
-        args.no_resident = True  # the expanded CRS of these configs (362 / 724 GB) does not fit one GPU
+        # the expanded CRS of these configs is 362 / 724 GB: resident only when this rank's share fits (45 GB/GPU on 8)
+        share_bytes = int(ctx.lib.mfh_resident_share_rows(ctx._h, rank, world)) * ctx.resident_row_bytes()
+        if share_bytes > 200e9:
+            args.no_resident = True
     ctx.ssp_prepare(inst["d_ssp"])  # per-circuit constant: rev(t)^-1 (depends on the SSP only)
 
     def barrier():
@@ -214,13 +217,14 @@ def main():
     # ---- second regime: the expanded CRS resident in HBM (11.3 GB), streamed at HBM speed
     resident = None
     if not args.no_resident:
-        image = ctx.empty(rows_crs * ctx.resident_row_bytes())
+        share_rows = int(ctx.lib.mfh_resident_share_rows(ctx._h, rank, world))
+        image = ctx.empty(share_rows * ctx.resident_row_bytes())  # this rank's shares only (= the whole CRS when world == 1)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        ctx.crs_expand(0, rows_crs, d_crs, out=image)
+        ctx.crs_expand_share(d_crs, rank, world, out=image)
         torch.cuda.synchronize()
         expand_s = time.perf_counter() - t1
-        ctx.set_resident(image)
+        ctx.set_resident_share(image, rank, world)
         for _ in range(args.warmup):
             proof_r = step()
         ctx.set_timing(True)
@@ -240,7 +244,7 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el_r = float(tt.item())
         same = bool(torch.equal(proof_r, proof))
-        ctx.set_resident(None)
+        ctx.set_resident_share(None, 0, 1)
         rb = ctx.resident_row_bytes()
         traffic_r = None
         tf2 = os.path.join(ROOT, "profiles", "traffic_mac2.json")
@@ -252,10 +256,10 @@ def main():
         avg = m2ms / max(m2n, 1)
         lr = m2rows / max(m2n, 1)
         resident = {"value": args.steps / el_r, "unit": "proofs/s", "ms_per_step": el_r / args.steps * 1e3, "proof_identical_to_regenerated": same,
-                    "crs_expand_s": expand_s, "image_bytes": rows_crs * rb,
-                    "roofline": {"bound": "hbm", "kernel": "k_mac_resident<736,2> (streaming 2x MAC over the expanded S / AS rows)",
-                                 "achieved": lr * ROW_BYTES / (avg * 1e-3) / 1e9 if m2n else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": (lr * ROW_BYTES / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS) if m2n else None,
+                    "crs_expand_s": expand_s, "image_bytes_per_rank": share_rows * rb,
+                    "roofline": {"bound": "hbm", "kernel": f"k_mac_resident<{p.logq},2> (streaming 2x MAC over the expanded S / AS rows)",
+                                 "achieved": lr * (p.n + 1) * p.ctb / (avg * 1e-3) / 1e9 if m2n else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": (lr * (p.n + 1) * p.ctb / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS) if m2n else None,
                                  "traffic": traffic_r, "bytes_read_per_row": rb, "read_gbs": lr * rb / (avg * 1e-3) / 1e9 if m2n else None,
                                  "launches": m2n, "avg_launch_ms": avg, "rows_per_launch": lr},
                     "mac1": {"launches": m1n, "avg_launch_ms": m1ms / max(m1n, 1), "rows_per_launch": m1rows / max(m1n, 1)}}

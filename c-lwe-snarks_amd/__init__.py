@@ -90,6 +90,7 @@ EXPORTS = [
     "mfh_resident_row_bytes", "mfh_crs_expand", "mfh_eval_rows_resident", "mfh_crs_set_resident",
     "mfh_witness_lanes", "mfh_witness_from_lanes", "mfh_prove_partial_w", "mfh_verify",
     "mfh_ssp_set_prg", "mfh_ssp_prg_make_t", "mfh_ssp_prg_fill",
+    "mfh_resident_share_rows", "mfh_crs_expand_share", "mfh_crs_set_resident_share",
 ]
 
 
@@ -138,6 +139,9 @@ def load_library():
         "mfh_ct_to_lanes": (i32, [vp, vp, sz, vp]),
         "mfh_ct_from_lanes": (i32, [vp, vp, sz, vp]),
         "mfh_add_dotp": (i32, [vp, vp, vp, vp, sz]),
+        "mfh_resident_share_rows": (sz, [vp, u32, u32]),
+        "mfh_crs_expand_share": (i32, [vp, vp, u32, u32, vp]),
+        "mfh_crs_set_resident_share": (i32, [vp, vp, u32, u32]),
         "mfh_ssp_set_prg": (i32, [vp, u64, vp]),
         "mfh_ssp_prg_make_t": (i32, [vp, u64, ctypes.c_char_p, vp]),
         "mfh_ssp_prg_fill": (i32, [vp, u64, sz, sz, vp]),
@@ -426,3 +430,14 @@ class Context:
         out = self.empty(nslots * self.params.d * 4)
         self._chk(self.lib.mfh_ssp_prg_fill(self._h, seed64, first_slot, nslots, _ptr(out)))
         return out
+
+    # -- sharded resident CRS (one share per rank) -------------------------------------------------------------------
+    def crs_expand_share(self, d_crs, rank, world, out=None):
+        rows = int(self.lib.mfh_resident_share_rows(self._h, rank, world))
+        out = self.empty(rows * self.resident_row_bytes()) if out is None else out
+        self._chk(self.lib.mfh_crs_expand_share(self._h, _ptr(d_crs), rank, world, _ptr(out)))
+        return out
+
+    def set_resident_share(self, image, rank, world):
+        self._resident = image
+        self._chk(self.lib.mfh_crs_set_resident_share(self._h, _ptr(image), rank, world))

@@ -1166,6 +1166,45 @@ int mfh_eval_rows_resident(mfh_ctx *c, const void *d_rows, size_t first_row, siz
 int mfh_crs_set_resident(mfh_ctx *c, const void *d_rows) {
   if (!c) return MFH_EINVAL;
   c->resident_rows = (const uint8_t *)d_rows;
+  c->resident_sharded = false;
+  return MFH_OK;
+}
+
+static void row_share(uint32_t rows, uint32_t rank, uint32_t world, uint32_t &lo, uint32_t &cnt) {
+  lo = (uint32_t)((uint64_t)rows * rank / world);
+  cnt = (uint32_t)((uint64_t)rows * (rank + 1) / world) - lo;
+}
+
+size_t mfh_resident_share_rows(const mfh_ctx *c, uint32_t rank, uint32_t world) {
+  if (!c || !world || rank >= world) return 0;
+  uint32_t lo, cs, cb;
+  row_share(c->P.d, rank, world, lo, cs);
+  row_share(c->P.m, rank, world, lo, cb);
+  return (size_t)2 * cs + cb;
+}
+
+int mfh_crs_expand_share(mfh_ctx *c, const uint8_t *d_crs_c8, uint32_t rank, uint32_t world, void *d_image) {
+  if (!c || !d_crs_c8 || !d_image || !world || rank >= world) return MFH_EINVAL;
+  const uint32_t d = c->P.d, m = c->P.m, ctb = c->P.logq / 8;
+  const uint64_t ctr_ct = (uint64_t)ctb * c->P.n;
+  const size_t rb = mfh_resident_row_bytes(c);
+  uint32_t loS, cS, loB, cB;
+  row_share(d, rank, world, loS, cS);
+  row_share(m, rank, world, loB, cB);
+  uint8_t *img = (uint8_t *)d_image;
+  int rc = mfh_crs_expand(c, ctr_ct * loS, cS, d_crs_c8 + (size_t)loS * ctb, img);                                   // S share
+  if (rc) return rc;
+  rc = mfh_crs_expand(c, ctr_ct * ((uint64_t)d + loS), cS, d_crs_c8 + ((size_t)d + loS) * ctb, img + (size_t)cS * rb);  // AS share
+  if (rc) return rc;
+  return mfh_crs_expand(c, ctr_ct * ((uint64_t)2 * d + loB), cB, d_crs_c8 + ((size_t)2 * d + loB) * ctb, img + (size_t)2 * cS * rb);  // BT+BV share
+}
+
+int mfh_crs_set_resident_share(mfh_ctx *c, const void *d_image, uint32_t rank, uint32_t world) {
+  if (!c || !world || rank >= world) return MFH_EINVAL;
+  c->resident_rows = (const uint8_t *)d_image;
+  c->resident_sharded = d_image != nullptr;
+  c->res_rank = rank;
+  c->res_world = world;
   return MFH_OK;
 }
 

@@ -291,7 +291,16 @@ static int prove_partial_impl(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_
   uint32_t lo, cnt;
   share(m, lo, cnt);
   const void *res = c->resident_rows;
-  rc = res ? mfh_eval_rows_resident(c, res, (size_t)2 * d + lo, cnt, cw + lo, nullptr, pi_b_w, nullptr, 0)
+  if (res && c->resident_sharded && (c->res_rank != rank || c->res_world != world)) {
+    c->err = "the resident CRS image holds the shares of a different (rank, world)";
+    return MFH_EINVAL;
+  }
+  // image row of a region's first share row: absolute stream order for a full image; S | AS | BT+BV shares for a sharded one
+  uint32_t loS, cS;
+  share(d, loS, cS);
+  const size_t imgB = c->resident_sharded ? (size_t)2 * cS : (size_t)2 * d + lo;
+  const size_t imgS = c->resident_sharded ? 0 : loS, imgAS = c->resident_sharded ? cS : (size_t)d + loS;
+  rc = res ? mfh_eval_rows_resident(c, res, imgB, cnt, cw + lo, nullptr, pi_b_w, nullptr, 0)
            : mfh_eval_rows(c, 2 * ctr_ct * d + ctr_ct * lo, cnt, d_crs_c8 + ((size_t)2 * d + lo) * ctb, cw + lo, nullptr, pi_b_w, nullptr, 0);
   if (rc) return rc;
   // v = w + v_0 ; h = (v^2 - 1) / t   (src/snark.c:161-169)
@@ -302,9 +311,9 @@ static int prove_partial_impl(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_
   // S rows: (w, h) -> (v_w, h);  AS rows: (v, h) -> (hat_v, hat_h)   (src/snark.c:157-158,163-164,171-174, each row expanded once)
   share(d, lo, cnt);
   if (res) {
-    rc = mfh_eval_rows_resident(c, res, lo, cnt, w + lo, h + lo, pi_v_w, pi_h, 0);
+    rc = mfh_eval_rows_resident(c, res, imgS, cnt, w + lo, h + lo, pi_v_w, pi_h, 0);
     if (rc) return rc;
-    return mfh_eval_rows_resident(c, res, (size_t)d + lo, cnt, v + lo, h + lo, pi_hat_v, pi_hat_h, 0);
+    return mfh_eval_rows_resident(c, res, imgAS, cnt, v + lo, h + lo, pi_hat_v, pi_hat_h, 0);
   }
   rc = mfh_eval_rows(c, ctr_ct * lo, cnt, d_crs_c8 + (size_t)lo * ctb, w + lo, h + lo, pi_v_w, pi_h, 0);
   if (rc) return rc;

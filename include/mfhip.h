@@ -98,6 +98,12 @@ int mfh_crs_expand(mfh_ctx *ctx, uint64_t off, size_t nrows, const uint8_t *d_c8
 int mfh_eval_rows_resident(mfh_ctx *ctx, const void *d_rows, size_t first_row, size_t nrows, const uint32_t *d_coeff0,
                            const uint32_t *d_coeff1, uint64_t *d_rop0, uint64_t *d_rop1, int accumulate);
 int mfh_crs_set_resident(mfh_ctx *ctx, const void *d_rows);
+/* Multi-GPU form ("GPU g ... keeps its slice of the expanded CRS resident", 45 GB per GPU for the 2^20-constraint
+ * CRS on 8 GPUs): the image holds only rank `rank`'s contiguous shares, in the order S share | AS share | BT+BV share
+ * (mfh_resident_share_rows() rows of mfh_resident_row_bytes() each).  mfh_prove_partial* with the same (rank, world) then streams it. */
+size_t mfh_resident_share_rows(const mfh_ctx *ctx, uint32_t rank, uint32_t world);
+int mfh_crs_expand_share(mfh_ctx *ctx, const uint8_t *d_crs_c8, uint32_t rank, uint32_t world, void *d_image);
+int mfh_crs_set_resident_share(mfh_ctx *ctx, const void *d_image, uint32_t rank, uint32_t world);
 
 /* Batched regev_encrypt2 + ct_export (src/lwe.c:78-97,115-119): for i < nrows
  *   b_i = (e_i*p + <sk, a_i> + m_i) mod 2^(64K),  a_i = row at stream offset off + i*n*CT_BYTES

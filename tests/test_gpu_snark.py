@@ -274,3 +274,29 @@ def test_device_verifier_agrees_with_oracle(ctx, oracle, instance):
         expect.append(oracle.verifier(p, I["ssp"], I["alpha"], I["beta"], I["s"], I["sk"], pr))
     ok = ctx.to_host(ctx.verify(I["d_ssp"], I["alpha"], I["beta"], I["s"], ctx.to_device(I["sk"]), ctx.to_device(np.stack(proofs)), 4))
     assert [bool(x) for x in ok] == expect == [True, False, False, False]
+
+
+def test_sharded_resident_image(ctx, instance):
+    """each rank keeps only its share of the expanded CRS (S share | AS share | BT+BV share) and streams it"""
+    I = instance
+    p = I["p"]
+    d_crs = ctx.to_device(_crs_stream_order(p, I["crs"]))
+    delta = 99
+    ref = ctx.prove_partial(d_crs, I["d_ssp"], I["bits"], delta, 0, 1)
+    world = 3
+    total = None
+    rows = 0
+    for r in range(world):
+        image = ctx.crs_expand_share(d_crs, r, world)
+        rows += image.numel() // ctx.resident_row_bytes()
+        ctx.set_resident_share(image, r, world)
+        try:
+            part = ctx.prove_partial(d_crs, I["d_ssp"], I["bits"], delta, r, world)
+            with pytest.raises(Exception):
+                ctx.prove_partial(d_crs, I["d_ssp"], I["bits"], delta, (r + 1) % world, world)  # image of another rank
+        finally:
+            ctx.set_resident_share(None, 0, 1)
+        ln = ctx.ct_to_lanes(part, 5).clone()
+        total = ln if total is None else total + ln
+    assert rows == 2 * p.d + p.m
+    assert np.array_equal(ctx.to_host(ctx.ct_from_lanes(total, 5)), ctx.to_host(ref))
