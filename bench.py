@@ -353,7 +353,12 @@ def main():
                          "bytes_per_row": row_bytes,
                          "note": "algorithmic bytes = expanded row bytes; the kernel regenerates them with AES on the CU (LDS T-tables), "
                                  "it is LDS-lookup/VALU bound and moves ~0 HBM bytes: see DESIGN.md",
-                         "aes_gblocks_per_s": (launch_rows * (p.ctr_ct / 16.0) / (avg_ms * 1e-3) / 1e9) if n2 else None},
+                         "aes_gblocks_per_s": (launch_rows * (p.ctr_ct / 16.0) / (avg_ms * 1e-3) / 1e9) if n2 else None,
+                         # the kernel's real limiter: LDS table lookups (201 per AES block with the counter-mode shortcut, one ds_read_b32
+                         # wave-instruction per 2.15 CU-cycles measured, 256 CUs at 2.4 GHz => 256*2.4e9*64/(201*2.15) blocks/s)
+                         "lds_lookup_roofline": {"achieved_gblocks_per_s": (launch_rows * (p.ctr_ct / 16.0) / (avg_ms * 1e-3) / 1e9) if n2 else None,
+                                                 "peak_gblocks_per_s": 256 * 2.4e9 * 64 / (201 * 2.15) / 1e9,
+                                                 "frac": ((launch_rows * (p.ctr_ct / 16.0) / (avg_ms * 1e-3) / 1e9) / (256 * 2.4e9 * 64 / (201 * 2.15) / 1e9)) if n2 else None}},
             "eval1": {"launches": n1, "avg_launch_ms": ms1 / max(n1, 1), "rows_per_launch": rows1 / max(n1, 1)},
             "resident_crs": resident,
             "cpu_baseline": cpu,
