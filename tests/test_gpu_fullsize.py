@@ -149,3 +149,49 @@ def test_2pow20_constraints_instance(gpu_ctx_factory, logq):
     ctx.prove_finish(shard, mags, signs)
     assert torch.equal(shard, proof)
     ctx.close()
+
+
+def test_default_size_proof_matches_oracle_hashes(gpu_ctx_factory):
+    """Bit-exactness at the FULL NDEBUG default size against the oracle's complete prover run (tests/golden/default_size_proof.json,
+    generated once on the CPU by tests/golden/make_default_size_golden.py): t, the witness polynomial, h = (v^2-1)/t and all five
+    proof ciphertexts, before and after smudging."""
+    import hashlib
+    import importlib.util
+    import json
+
+    import c_lwe_snarks_amd as mf
+
+    gdir = os.path.join(ROOT, "tests", "golden")
+    gold_path = os.path.join(gdir, "default_size_proof.json")
+    if not os.path.exists(gold_path):
+        pytest.fail("tests/golden/default_size_proof.json is missing")
+    gold = json.load(open(gold_path))
+    spec = importlib.util.spec_from_file_location("mk_gold", os.path.join(gdir, "make_default_size_golden.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    p = mf.DEFAULT
+    I = mk.instance(p)
+    ctx = gpu_ctx_factory(p)
+    ctx.set_seed(I["seed"])
+    sha = lambda t: hashlib.sha256(ctx.to_host(t).tobytes()).hexdigest()
+    d_t = ctx.ssp_prg_make_t(gold["prg_seed"], I["bits"])
+    assert sha(d_t) == gold["t_sha256"]
+    ctx.ssp_set_prg(gold["prg_seed"], d_t)
+    ctx.ssp_prepare(None)
+    assert sha(ctx.witness_poly(None, I["bits"], I["delta"])) == gold["w_sha256"]
+    d_crs = ctx.to_device(I["c8"])
+    pre = ctx.prove_partial(d_crs, None, I["bits"], I["delta"], 0, 1)
+    names = ["h", "hat_h", "hat_v", "v_w", "b_w"]
+    nb = p.ct_limbs * 8
+    for k, nme in enumerate(names):
+        assert sha(pre[k * nb:(k + 1) * nb]) == gold["pre_smudge_sha256"][nme], nme
+    proof = ctx.prove(d_crs, None, I["bits"], I["delta"], I["mags"], I["signs"])
+    for k, nme in enumerate(names):
+        assert sha(proof[k * nb:(k + 1) * nb]) == gold["proof_sha256"][nme], nme
+    assert sha(proof) == gold["proof_all_sha256"]
+    # the same proof from the dense image of the same SSP (generator mode == dense mode at full size)
+    import torch
+
+    dense = torch.cat([d_t, ctx.ssp_prg_fill(gold["prg_seed"], 1, p.m + 2)])
+    assert sha(ctx.prove(d_crs, dense, I["bits"], I["delta"], I["mags"], I["signs"])) == gold["proof_all_sha256"]
+    ctx.close()
