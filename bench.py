@@ -116,6 +116,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-resident", action="store_true", help="skip the resident-CRS regime")
+    ap.add_argument("--resident-gb", type=float, default=200.0, help="HBM budget for the resident CRS image per GPU")
     ap.add_argument("--workload", choices=["default", "config4", "config5"], default="default",
                     help="default = benchmark_snark NDEBUG instance (the driver's workload); config4/config5 = BASELINE's 2^20-constraint "
                          "instance (M = 699050, generator-defined SSP) at logq 736 / 1472")
@@ -158,9 +159,10 @@ def main():
         inst = build_instance(mf, ctx, torch, p, 20260101)
     else:
         inst = build_prg_instance(mf, ctx, torch, p, 20260101)
-        # the expanded CRS of these configs is 362 / 724 GB: resident only when this rank's share fits (45 GB/GPU on 8)
+        # the expanded CRS of these configs is 362 / 724 GB: a rank's share fits from 2-4 GPUs on (45 GB/GPU on 8);
+        # on one GPU a prefix of --resident-gb stays resident and the rest of the rows is regenerated
         share_bytes = int(ctx.lib.mfh_resident_share_rows(ctx._h, rank, world)) * ctx.resident_row_bytes()
-        if share_bytes > 200e9:
+        if world > 1 and share_bytes > args.resident_gb * 1e9:
             args.no_resident = True
     ctx.ssp_prepare(inst["d_ssp"])  # per-circuit constant: rev(t)^-1 (depends on the SSP only)
 
@@ -218,13 +220,23 @@ def main():
     resident = None
     if not args.no_resident:
         share_rows = int(ctx.lib.mfh_resident_share_rows(ctx._h, rank, world))
+        budget_rows = int(args.resident_gb * 1e9) // ctx.resident_row_bytes()
+        partial_res = world == 1 and share_rows > budget_rows  # single GPU and the image does not fit: keep a prefix resident
+        if partial_res:
+            share_rows = budget_rows
         image = ctx.empty(share_rows * ctx.resident_row_bytes())  # this rank's shares only (= the whole CRS when world == 1)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        ctx.crs_expand_share(d_crs, rank, world, out=image)
+        if partial_res:
+            ctx.crs_expand(0, share_rows, d_crs, out=image)
+        else:
+            ctx.crs_expand_share(d_crs, rank, world, out=image)
         torch.cuda.synchronize()
         expand_s = time.perf_counter() - t1
-        ctx.set_resident_share(image, rank, world)
+        if partial_res:
+            ctx.set_resident_prefix(image, share_rows)
+        else:
+            ctx.set_resident_share(image, rank, world)
         for _ in range(args.warmup):
             proof_r = step()
         ctx.set_timing(True)
@@ -256,7 +268,7 @@ def main():
         avg = m2ms / max(m2n, 1)
         lr = m2rows / max(m2n, 1)
         resident = {"value": args.steps / el_r, "unit": "proofs/s", "ms_per_step": el_r / args.steps * 1e3, "proof_identical_to_regenerated": same,
-                    "crs_expand_s": expand_s, "image_bytes_per_rank": share_rows * rb,
+                    "crs_expand_s": expand_s, "image_bytes_per_rank": share_rows * rb, "resident_rows": share_rows, "partially_resident": partial_res,
                     "roofline": {"bound": "hbm", "kernel": f"k_mac_resident<{p.logq},2> (streaming 2x MAC over the expanded S / AS rows)",
                                  "achieved": lr * (p.n + 1) * p.ctb / (avg * 1e-3) / 1e9 if m2n else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": (lr * (p.n + 1) * p.ctb / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS) if m2n else None,

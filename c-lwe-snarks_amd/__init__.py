@@ -90,7 +90,7 @@ EXPORTS = [
     "mfh_resident_row_bytes", "mfh_crs_expand", "mfh_eval_rows_resident", "mfh_crs_set_resident",
     "mfh_witness_lanes", "mfh_witness_from_lanes", "mfh_prove_partial_w", "mfh_verify",
     "mfh_ssp_set_prg", "mfh_ssp_prg_make_t", "mfh_ssp_prg_fill",
-    "mfh_resident_share_rows", "mfh_crs_expand_share", "mfh_crs_set_resident_share",
+    "mfh_resident_share_rows", "mfh_crs_expand_share", "mfh_crs_set_resident_share", "mfh_crs_set_resident_prefix",
 ]
 
 
@@ -139,6 +139,7 @@ def load_library():
         "mfh_ct_to_lanes": (i32, [vp, vp, sz, vp]),
         "mfh_ct_from_lanes": (i32, [vp, vp, sz, vp]),
         "mfh_add_dotp": (i32, [vp, vp, vp, vp, sz]),
+        "mfh_crs_set_resident_prefix": (i32, [vp, vp, sz]),
         "mfh_resident_share_rows": (sz, [vp, u32, u32]),
         "mfh_crs_expand_share": (i32, [vp, vp, u32, u32, vp]),
         "mfh_crs_set_resident_share": (i32, [vp, vp, u32, u32]),
@@ -441,3 +442,8 @@ class Context:
     def set_resident_share(self, image, rank, world):
         self._resident = image
         self._chk(self.lib.mfh_crs_set_resident_share(self._h, _ptr(image), rank, world))
+
+    def set_resident_prefix(self, image, nrows_resident):
+        """only stream rows [0, nrows_resident) are resident; the rest is regenerated"""
+        self._resident = image
+        self._chk(self.lib.mfh_crs_set_resident_prefix(self._h, _ptr(image), nrows_resident))

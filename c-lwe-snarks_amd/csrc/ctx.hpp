@@ -64,6 +64,7 @@ struct mfh_ctx {
   uint64_t prg_seed = 0;
   const uint32_t *prg_t = nullptr;
   const uint8_t *resident_rows = nullptr;  // expanded CRS (mfh_crs_expand layout) or null: regenerate the keystream
+  uint64_t resident_nrows = ~0ull;         // full image: rows [0, resident_nrows) in stream order are resident, the rest is regenerated
   bool resident_sharded = false;           // image holds only rank res_rank's shares: S share | AS share | BT+BV share
   uint32_t res_rank = 0, res_world = 1;
 };

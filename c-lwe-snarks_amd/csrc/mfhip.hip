@@ -1167,6 +1167,15 @@ int mfh_crs_set_resident(mfh_ctx *c, const void *d_rows) {
   if (!c) return MFH_EINVAL;
   c->resident_rows = (const uint8_t *)d_rows;
   c->resident_sharded = false;
+  c->resident_nrows = ~0ull;
+  return MFH_OK;
+}
+
+int mfh_crs_set_resident_prefix(mfh_ctx *c, const void *d_rows, size_t nrows_resident) {
+  if (!c) return MFH_EINVAL;
+  c->resident_rows = (const uint8_t *)d_rows;
+  c->resident_sharded = false;
+  c->resident_nrows = nrows_resident;
   return MFH_OK;
 }
 

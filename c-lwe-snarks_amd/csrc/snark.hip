@@ -295,13 +295,21 @@ static int prove_partial_impl(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_
     c->err = "the resident CRS image holds the shares of a different (rank, world)";
     return MFH_EINVAL;
   }
-  // image row of a region's first share row: absolute stream order for a full image; S | AS | BT+BV shares for a sharded one
+  // One region = `cnt` consecutive CRS rows starting at absolute stream row `abs_row` (compressed bytes at d_crs_c8 + abs_row*ctb).
+  // Rows that are resident (whole image, a prefix of it, or this rank's share at image row `img_row`) are streamed from HBM, the
+  // rest is regenerated from the seed and accumulated on top.
+  auto eval_region = [&](size_t abs_row, size_t img_row, uint32_t cnt, const uint32_t *c0, const uint32_t *c1, uint64_t *r0, uint64_t *r1) -> int {
+    size_t nres = 0;
+    if (res) nres = c->resident_sharded ? cnt : (abs_row >= c->resident_nrows ? 0 : std::min<uint64_t>(cnt, c->resident_nrows - abs_row));
+    int rc2 = MFH_OK;
+    if (nres) rc2 = mfh_eval_rows_resident(c, res, c->resident_sharded ? img_row : abs_row, nres, c0, c1, r0, r1, 0);
+    if (rc2 || nres == cnt) return rc2;
+    return mfh_eval_rows(c, ctr_ct * (abs_row + nres), cnt - nres, d_crs_c8 + (abs_row + nres) * ctb, c0 + nres, c1 ? c1 + nres : nullptr, r0, r1,
+                         nres ? 1 : 0);
+  };
   uint32_t loS, cS;
   share(d, loS, cS);
-  const size_t imgB = c->resident_sharded ? (size_t)2 * cS : (size_t)2 * d + lo;
-  const size_t imgS = c->resident_sharded ? 0 : loS, imgAS = c->resident_sharded ? cS : (size_t)d + loS;
-  rc = res ? mfh_eval_rows_resident(c, res, imgB, cnt, cw + lo, nullptr, pi_b_w, nullptr, 0)
-           : mfh_eval_rows(c, 2 * ctr_ct * d + ctr_ct * lo, cnt, d_crs_c8 + ((size_t)2 * d + lo) * ctb, cw + lo, nullptr, pi_b_w, nullptr, 0);
+  rc = eval_region((size_t)2 * d + lo, (size_t)2 * cS, cnt, cw + lo, nullptr, pi_b_w, nullptr);
   if (rc) return rc;
   // v = w + v_0 ; h = (v^2 - 1) / t   (src/snark.c:161-169)
   hipLaunchKernelGGL(k_add_slot, g1(d), dim3(256), 0, c->stream, w, src, 1u, d, v);
@@ -309,15 +317,9 @@ static int prove_partial_impl(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_
   rc = mfh_poly_h(c, v, h);
   if (rc) return rc;
   // S rows: (w, h) -> (v_w, h);  AS rows: (v, h) -> (hat_v, hat_h)   (src/snark.c:157-158,163-164,171-174, each row expanded once)
-  share(d, lo, cnt);
-  if (res) {
-    rc = mfh_eval_rows_resident(c, res, imgS, cnt, w + lo, h + lo, pi_v_w, pi_h, 0);
-    if (rc) return rc;
-    return mfh_eval_rows_resident(c, res, imgAS, cnt, v + lo, h + lo, pi_hat_v, pi_hat_h, 0);
-  }
-  rc = mfh_eval_rows(c, ctr_ct * lo, cnt, d_crs_c8 + (size_t)lo * ctb, w + lo, h + lo, pi_v_w, pi_h, 0);
+  rc = eval_region(loS, 0, cS, w + loS, h + loS, pi_v_w, pi_h);
   if (rc) return rc;
-  return mfh_eval_rows(c, ctr_ct * ((uint64_t)d + lo), cnt, d_crs_c8 + ((size_t)d + lo) * ctb, v + lo, h + lo, pi_hat_v, pi_hat_h, 0);
+  return eval_region((size_t)d + loS, cS, cS, v + loS, h + loS, pi_hat_v, pi_hat_h);
 }
 
 int mfh_prove_partial(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, const uint8_t *h_witness_bits, uint32_t delta,

@@ -98,6 +98,9 @@ int mfh_crs_expand(mfh_ctx *ctx, uint64_t off, size_t nrows, const uint8_t *d_c8
 int mfh_eval_rows_resident(mfh_ctx *ctx, const void *d_rows, size_t first_row, size_t nrows, const uint32_t *d_coeff0,
                            const uint32_t *d_coeff1, uint64_t *d_rop0, uint64_t *d_rop1, int accumulate);
 int mfh_crs_set_resident(mfh_ctx *ctx, const void *d_rows);
+/* Partial residency for a CRS whose expansion exceeds HBM (362 GB for the 2^20-constraint CRS): only stream rows
+ * [0, nrows_resident) are in the image; mfh_prove* streams those and regenerates the remaining rows from the seed. */
+int mfh_crs_set_resident_prefix(mfh_ctx *ctx, const void *d_rows, size_t nrows_resident);
 /* Multi-GPU form ("GPU g ... keeps its slice of the expanded CRS resident", 45 GB per GPU for the 2^20-constraint
  * CRS on 8 GPUs): the image holds only rank `rank`'s contiguous shares, in the order S share | AS share | BT+BV share
  * (mfh_resident_share_rows() rows of mfh_resident_row_bytes() each).  mfh_prove_partial* with the same (rank, world) then streams it. */

@@ -300,3 +300,21 @@ def test_sharded_resident_image(ctx, instance):
         total = ln if total is None else total + ln
     assert rows == 2 * p.d + p.m
     assert np.array_equal(ctx.to_host(ctx.ct_from_lanes(total, 5)), ctx.to_host(ref))
+
+
+@pytest.mark.parametrize("nres", [0, 1, 255, 300, 512, 513, 540])
+def test_partially_resident_crs(ctx, instance, nres):
+    """rows [0, nres) streamed from the expanded image, the rest regenerated from the seed: same proof for every split point
+    (inside S, at the S/AS boundary, inside AS, at the AS/BT boundary, inside BV)"""
+    I = instance
+    p = I["p"]
+    d_crs = ctx.to_device(_crs_stream_order(p, I["crs"]))
+    delta = 5150
+    ref = ctx.to_host(ctx.prove_partial(d_crs, I["d_ssp"], I["bits"], delta, 0, 1)).copy()
+    image = ctx.crs_expand(0, max(nres, 1), d_crs)
+    ctx.set_resident_prefix(image, nres)
+    try:
+        got = ctx.to_host(ctx.prove_partial(d_crs, I["d_ssp"], I["bits"], delta, 0, 1)).copy()
+    finally:
+        ctx.set_resident(None)
+    assert np.array_equal(got, ref)
