@@ -759,10 +759,10 @@ __global__ __launch_bounds__(256) void k_witness_partial_prg(uint64_t seed, cons
   uint64_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
   for (uint32_t i = g; i < nsel; i += G) {
     const uint32_t rk = mf::ssp_prg_rowkey(seed, rows[i]);
-    s0 += mf::ssp_prg_coeff(rk, k);
-    s1 += mf::ssp_prg_coeff(rk, k + 1);
-    s2 += mf::ssp_prg_coeff(rk, k + 2);
-    s3 += mf::ssp_prg_coeff(rk, k + 3);
+    s0 += mf::ssp_prg_raw(rk, k);  // raw values: congruent to the coefficients mod p, the sums are reduced by the finish kernels
+    s1 += mf::ssp_prg_raw(rk, k + 1);
+    s2 += mf::ssp_prg_raw(rk, k + 2);
+    s3 += mf::ssp_prg_raw(rk, k + 3);
   }
   uint64_t *o = partial + (uint64_t)g * d + k;
   o[0] = s0; o[1] = s1; o[2] = s2; o[3] = s3;

@@ -25,13 +25,19 @@ MF_HD uint32_t ssp_prg_rowkey(uint64_t seed, uint32_t slot) {  // per-row part, 
   r ^= (uint32_t)(seed >> 32);
   return r | 1u;
 }
-MF_HD uint32_t ssp_prg_coeff(uint32_t rowkey, uint32_t k) {
+// the un-reduced 32-bit hash; coefficient = raw mod p.  Sums of coefficients may be formed from the raw values and reduced once:
+// raw and coefficient differ by a multiple of p (0 or p).
+MF_HD uint32_t ssp_prg_raw(uint32_t rowkey, uint32_t k) {
   uint32_t x = (k + 0x632BE5ABu) * rowkey;
   x ^= x >> 16;
   x *= 0x7FEB352Du;
   x ^= x >> 15;
   x *= 0x846CA68Bu;
   x ^= x >> 16;
+  return x;
+}
+MF_HD uint32_t ssp_prg_coeff(uint32_t rowkey, uint32_t k) {
+  const uint32_t x = ssp_prg_raw(rowkey, k);
   return x >= 0xfffffffbu ? x - 0xfffffffbu : x;
 }
 
