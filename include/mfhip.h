@@ -19,6 +19,9 @@
  *   Pointers named d_* are DEVICE pointers (HBM); h_* are host pointers.  All launches go to the
  *   context's HIP stream and are asynchronous unless stated; mfh_sync() waits.
  *
+ * Threading: like the reference (no function of which is re-entrant w.r.t. a shared rng_t), a context is NOT thread-safe; use
+ * one context per thread / per GPU.  Different contexts are independent.
+ *
  * Error behaviour: the reference API is void and asserts preconditions (debug builds only).  Here every
  * function returns 0 on success or a negative MFH_E* code; mfh_last_error() gives the text.  There is no
  * CPU fallback anywhere in the library: without a usable HIP device mfh_ctx_create fails.
