@@ -21,7 +21,8 @@ def allreduce_lanes(lanes, group=None):
 
 def prove_sharded(ctx, d_crs, d_ssp, witness_bits, delta, smudge_mag, smudge_sign, rank, world, maglen=80, bufs=None, group=None):
     """prover() (reference src/snark.c:117-190) with the CRS rows sharded over `world` ranks.  Every rank returns the
-    complete proof.  `bufs` may hold reusable device buffers {"partial", "lanes", "proof"}."""
+    complete proof.  `bufs` may hold reusable device buffers {"partial", "lanes", "proof"}.  world == 1 proves alone: no
+    collective is issued even inside a process group (independent provers per rank)."""
     bufs = {} if bufs is None else bufs
     if world > 1:
         # first exchange: the SSP pass is sharded too (each rank sums its share of the selected v_i), d uint64 lanes
@@ -32,7 +33,8 @@ def prove_sharded(ctx, d_crs, d_ssp, witness_bits, delta, smudge_mag, smudge_sig
     else:
         partial = ctx.prove_partial(d_crs, d_ssp, witness_bits, delta, rank, world, out=bufs.get("partial"))
     lanes = ctx.ct_to_lanes(partial, 5, out=bufs.get("lanes"))
-    allreduce_lanes(lanes, group)
+    if world > 1:
+        allreduce_lanes(lanes, group)
     proof = ctx.ct_from_lanes(lanes, 5, out=bufs.get("proof"))
     ctx.prove_finish(proof, smudge_mag, smudge_sign, maglen)
     bufs.update(partial=partial, lanes=lanes, proof=proof)

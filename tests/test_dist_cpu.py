@@ -77,3 +77,31 @@ def test_lane_roundtrip_and_carries():
     total = lanes.sum(axis=0, keepdims=True)
     got = mfdist.limbs_from_lanes_cpu(total, L, K)
     assert int.from_bytes(got.tobytes(), "little") == sum(vals) % (1 << 704)
+
+
+class _FakeCtx:
+    """Records the order of C-ABI calls prove_sharded makes (no GPU needed): the host sequencing is what is under test."""
+
+    def __init__(self):
+        self.calls = []
+
+    def __getattr__(self, name):
+        def f(*a, **k):
+            self.calls.append(name)
+            return name
+        return f
+
+
+@pytest.mark.parametrize("world,expect", [
+    (1, ["prove_partial", "ct_to_lanes", "ct_from_lanes", "prove_finish"]),
+    (4, ["witness_lanes", "ALLREDUCE", "prove_partial_w", "ct_to_lanes", "ALLREDUCE", "ct_from_lanes", "prove_finish"]),
+])
+def test_prove_sharded_call_sequence(monkeypatch, world, expect):
+    """world == 1 issues no collective (independent provers inside a process group); world > 1 issues exactly the two
+    lane all-reduces of SURVEY 8(e), witness lanes first."""
+    from c_lwe_snarks_amd import dist as mfdist
+
+    ctx = _FakeCtx()
+    monkeypatch.setattr(mfdist, "allreduce_lanes", lambda lanes, group=None: ctx.calls.append("ALLREDUCE"))
+    mfdist.prove_sharded(ctx, None, None, None, None, None, None, 0, world)
+    assert ctx.calls == expect
