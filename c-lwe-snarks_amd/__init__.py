@@ -214,6 +214,12 @@ class Context:
 
     def to_device(self, arr):
         a = np.ascontiguousarray(arr)
+        if not a.flags.writeable:  # read-only file mappings (files.crs_map): the host tensor is only a copy source
+            import warnings
+
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore", UserWarning)
+                return self.torch.from_numpy(a.view(np.uint8).reshape(-1)).to(self.device)
         return self.torch.from_numpy(a.view(np.uint8).reshape(-1)).to(self.device)
 
     def to_host(self, t, dtype=np.uint8):

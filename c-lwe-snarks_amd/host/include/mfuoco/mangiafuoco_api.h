@@ -111,6 +111,30 @@ void mfuoco_gpu_invalidate(void);
 /* select the GPU (default 0, or $MFUOCO_GPU); must precede the first call */
 void mfuoco_gpu_set_device(int device);
 
+
+/* ---- flat on-disk images (host only; host/mfuoco_files.c).  Sizes are the reference's: CRS_SIZE (src/snark.h:6),
+ * SSP_SIZE (src/ssp.h:6), d * CT_BYTES for ciphertext-row files (src/benchmark_eval.c:44-66).  Return 0 / a valid
+ * pointer on success, -1 / NULL with errno set otherwise (EINVAL: the file does not have the expected size). ---- */
+#define CRS_SIZE (CT_BYTES * (2 * GAMMA_D + GAMMA_M + 1 + 2))
+/* rows in keystream order: s[0..D) | as[0..D) | t | v[0..M) | 2 trailer rows = 40-byte seed + zeros */
+int mfuoco_crs_save(const char *path, const struct crs *crs);
+/* point crs->s/as/t/v into a mapping of the image and copy the seed out; release with mfuoco_crs_unmap, NOT crs_clear */
+int mfuoco_crs_map(struct crs *crs, const char *path, int writable);
+/* create the image (seed taken from crs->seed) and map it writable, so that setup() fills the file directly;
+ * call mfuoco_crs_sync_seed before unmapping if crs->seed changed afterwards */
+int mfuoco_crs_create(struct crs *crs, const char *path);
+void mfuoco_crs_sync_seed(struct crs *crs);
+void mfuoco_crs_unmap(struct crs *crs);
+int mfuoco_ssp_save(const char *path, const uint8_t *ssp);
+uint8_t *mfuoco_ssp_map(const char *path, int writable);
+void mfuoco_ssp_unmap(uint8_t *ssp);
+int mfuoco_rows_save(const char *path, uint8_t (*c8)[CT_BYTES], size_t rows);
+uint8_t (*mfuoco_rows_map(const char *path, size_t *rows))[CT_BYTES];
+void mfuoco_rows_unmap(uint8_t (*c8)[CT_BYTES], size_t rows);
+/* 5 ciphertexts in struct order, each GAMMA_N + 1 values of CT_BYTES little-endian bytes (the reference has no proof format) */
+int mfuoco_proof_save(const char *path, proof_t pi);
+int mfuoco_proof_load(proof_t pi, const char *path);
+
 #ifdef __cplusplus
 }
 #endif

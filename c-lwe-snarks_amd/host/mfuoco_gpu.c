@@ -391,7 +391,7 @@ void random_ssp(mpz_t input, uint8_t *circuit)
 /* ---- L4: SNARK -------------------------------------------------------------------------------------------- */
 void proof_init(proof_t pi) { ct_init(pi->h); ct_init(pi->hat_h); ct_init(pi->hat_v); ct_init(pi->v_w); ct_init(pi->b_w); }
 void proof_clear(proof_t pi) { ct_clear(pi->h); ct_clear(pi->hat_h); ct_clear(pi->hat_v); ct_clear(pi->v_w); ct_clear(pi->b_w); }
-void crs_init(struct crs *crs)
+void crs_init(crs_t crs)
 {
   if (getrandom(crs->seed, sizeof(rseed_t), GRND_NONBLOCK) < 0) perror("getrandom");
   crs->s = malloc(CT_BYTES * GAMMA_D);
@@ -400,7 +400,7 @@ void crs_init(struct crs *crs)
   crs->t = malloc(CT_BYTES);
   if (!crs->s || !crs->as || !crs->v || !crs->t) perror("Error allocating memory");
 }
-void crs_clear(struct crs *crs) { free(crs->s); free(crs->as); free(crs->v); free(crs->t); }
+void crs_clear(crs_t crs) { free(crs->s); free(crs->as); free(crs->v); free(crs->t); }
 
 static uint64_t rand_modp_(void)
 {

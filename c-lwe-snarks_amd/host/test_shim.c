@@ -4,10 +4,13 @@
  * D = 256, M = 64 like the reference's tests).  Our own text.  Exit code 0 = all properties hold.  Needs a GPU.
  */
 #define _GNU_SOURCE
+#include <errno.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <sys/random.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include "mfuoco/mangiafuoco_api.h"
 
@@ -173,6 +176,109 @@ static void t_snark(void)
   rng_clear(rng);
 }
 
+/* on-disk images: setup() straight into a mapped crs.mfuoco, SSP and proof through files, prover from the
+ * re-mapped read-only images, verifier on the re-loaded proof; plus a "coeffs" row file driving eval_poly as
+ * src/benchmark_eval.c:44-70 does. */
+static void t_files(void)
+{
+  char dir[] = "/tmp/mfuoco_files_XXXXXX", path[4][64];
+  CHECK(mkdtemp(dir) != NULL);
+  const char *names[4] = { "crs.mfuoco", "ssp.mfuoco", "proof.mfuoco", "coeffs" };
+  for (int i = 0; i < 4; i++) snprintf(path[i], sizeof path[i], "%s/%s", dir, names[i]);
+
+  uint8_t *ssp = calloc(1, SSP_SIZE);
+  mpz_t witness;
+  mpz_init(witness);
+  random_ssp(witness, ssp);
+  CHECK(mfuoco_ssp_save(path[1], ssp) == 0);
+  free(ssp);
+
+  crs_t crs;
+  CHECK(getrandom(crs->seed, sizeof(rseed_t), GRND_NONBLOCK) == sizeof(rseed_t));
+  CHECK(mfuoco_crs_create(crs, path[0]) == 0);
+  ssp = mfuoco_ssp_map(path[1], 0);
+  CHECK(ssp != NULL);
+  vrs_t vrs;
+  setup(crs, vrs, ssp);
+  rseed_t seed;
+  memcpy(seed, crs->seed, sizeof seed);
+  mfuoco_crs_unmap(crs);
+  struct stat st;
+  CHECK(stat(path[0], &st) == 0 && (size_t)st.st_size == CRS_SIZE);
+  CHECK(stat(path[1], &st) == 0 && (size_t)st.st_size == SSP_SIZE);
+
+  crs_t crs2;
+  CHECK(mfuoco_crs_map(crs2, path[0], 0) == 0);
+  CHECK(!memcmp(crs2->seed, seed, sizeof seed));
+  CHECK((uint8_t *)crs2->as == (uint8_t *)crs2->s + CT_BYTES * GAMMA_D && crs2->t == (uint8_t *)crs2->s + 2 * CT_BYTES * GAMMA_D &&
+        (uint8_t *)crs2->v == crs2->t + CT_BYTES);
+  proof_t pi, pj;
+  proof_init(pi);
+  proof_init(pj);
+  prover(pi, crs2, ssp, witness);
+  CHECK(mfuoco_proof_save(path[2], pi) == 0);
+  CHECK(mfuoco_proof_load(pj, path[2]) == 0);
+  for (size_t j = 0; j <= GAMMA_N; j++) CHECK(!mpz_cmp(pi->h[j], pj->h[j]) && !mpz_cmp(pi->b_w[j], pj->b_w[j]));
+  CHECK(verifier(ssp, vrs, pj));
+  /* a saved copy of the heap-allocated form is the same image */
+  crs_t crs3;
+  crs_init(crs3);
+  memcpy(crs3->seed, seed, sizeof seed);
+  memcpy(crs3->s, crs2->s, CT_BYTES * GAMMA_D);
+  memcpy(crs3->as, crs2->as, CT_BYTES * GAMMA_D);
+  memcpy(crs3->t, crs2->t, CT_BYTES);
+  memcpy(crs3->v, crs2->v, CT_BYTES * GAMMA_M);
+  char copy[80];
+  snprintf(copy, sizeof copy, "%s/copy.mfuoco", dir);
+  CHECK(mfuoco_crs_save(copy, crs3) == 0);
+  crs_t crs4;
+  CHECK(mfuoco_crs_map(crs4, copy, 0) == 0);
+  CHECK(!memcmp(crs4->s, crs2->s, CRS_SIZE));
+  mfuoco_crs_unmap(crs4);
+  crs_clear(crs3);
+  /* wrong size is refused */
+  CHECK(mfuoco_crs_map(crs4, path[1], 0) == -1 && errno == EINVAL);
+
+  /* ciphertext-row file -> eval_poly over the mapping == eval_poly over the heap rows */
+  {
+    enum { ROWS = 19 };
+    uint8_t (*rows)[CT_BYTES] = malloc(ROWS * CT_BYTES);
+    CHECK(getrandom(rows, ROWS * CT_BYTES, GRND_NONBLOCK) == ROWS * CT_BYTES);
+    CHECK(mfuoco_rows_save(path[3], rows, ROWS) == 0);
+    size_t n = 0;
+    uint8_t (*mapped)[CT_BYTES] = mfuoco_rows_map(path[3], &n);
+    CHECK(mapped != NULL && n == ROWS);
+    nmod_poly_t co;
+    nmod_poly_init(co, GAMMA_P);
+    for (size_t i = 0; i < ROWS; i++) nmod_poly_set_coeff_ui(co, i, 1000003u * (i + 1));
+    rng_t rng;
+    rng_init(rng, seed);
+    ct_t a, b;
+    ct_init(a);
+    ct_init(b);
+    eval_poly(a, rng, rows, co, ROWS);
+    rng_seek(rng, 0);
+    eval_poly(b, rng, mapped, co, ROWS);
+    for (size_t j = 0; j <= GAMMA_N; j++) CHECK(!mpz_cmp(a[j], b[j]));
+    ct_clear(a);
+    ct_clear(b);
+    rng_clear(rng);
+    nmod_poly_clear(co);
+    mfuoco_rows_unmap(mapped, n);
+    free(rows);
+  }
+
+  mfuoco_crs_unmap(crs2);
+  mfuoco_ssp_unmap(ssp);
+  proof_clear(pi);
+  proof_clear(pj);
+  key_clear(vrs->sk);
+  mpz_clear(witness);
+  for (int i = 0; i < 4; i++) unlink(path[i]);
+  unlink(copy);
+  rmdir(dir);
+}
+
 int main(void)
 {
   t_entropy();
@@ -181,5 +287,7 @@ int main(void)
   puts("lwe ok");
   t_snark();
   puts("snark ok");
+  t_files();
+  puts("files ok");
   return 0;
 }
