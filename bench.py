@@ -119,6 +119,7 @@ def main():
     ap.add_argument("--sharding", choices=["rows", "proofs"], default="rows",
                     help="N > 1: 'rows' = every proof is computed cooperatively, CRS rows sharded over the ranks + all-reduce (strong scaling, "
                          "default); 'proofs' = every rank proves its own statements, no collective (weak scaling)")
+    ap.add_argument("--no-overlap", action="store_true", help="run the prover on one stream (A/B check of the side-stream overlap)")
     ap.add_argument("--resident-gb", type=float, default=200.0, help="HBM budget for the resident CRS image per GPU")
     ap.add_argument("--workload", choices=["default", "config4", "config5"], default="default",
                     help="default = benchmark_snark NDEBUG instance (the driver's workload); config4/config5 = BASELINE's 2^20-constraint "
@@ -156,6 +157,8 @@ def main():
     big = args.workload != "default"
     p = mf.DEFAULT if not big else mf.Params(logq=736 if args.workload == "config4" else 1472, d=1 << 20, m=699050)
     ctx = mf.Context(p, local_rank)
+    if args.no_overlap:
+        ctx.set_overlap(False)
     seed = bytes((37 * i + 11) & 0xFF for i in range(40))
     ctx.set_seed(seed)
     if not big:

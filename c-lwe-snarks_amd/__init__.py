@@ -84,7 +84,7 @@ EXPORTS = [
     "mfh_ctx_create", "mfh_ctx_destroy", "mfh_set_stream", "mfh_sync", "mfh_last_error", "mfh_set_seed",
     "mfh_keystream", "mfh_sample_rows", "mfh_ct_add", "mfh_ct_mul_ui", "mfh_ct_addmul_ui", "mfh_eval_rows",
     "mfh_encrypt_rows", "mfh_decrypt", "mfh_ct_smudge", "mfh_ssp_upload", "mfh_witness_poly", "mfh_version",
-    "mfh_workspace_bytes", "mfh_last_kernel_ms", "mfh_set_timing", "mfh_poly_mul", "mfh_poly_add", "mfh_poly_prepare_t",
+    "mfh_workspace_bytes", "mfh_last_kernel_ms", "mfh_set_timing", "mfh_set_overlap", "mfh_poly_mul", "mfh_poly_add", "mfh_poly_prepare_t",
     "mfh_ssp_prepare", "mfh_poly_h", "mfh_setup_messages", "mfh_setup", "mfh_prove",
     "mfh_prove_partial", "mfh_prove_finish", "mfh_ct_to_lanes", "mfh_ct_from_lanes", "mfh_timing_drain", "mfh_add_dotp",
     "mfh_resident_row_bytes", "mfh_crs_expand", "mfh_eval_rows_resident", "mfh_crs_set_resident",
@@ -126,6 +126,7 @@ def load_library():
         "mfh_workspace_bytes": (sz, [vp]),
         "mfh_last_kernel_ms": (ctypes.c_float, [vp, ctypes.c_char_p]),
         "mfh_set_timing": (i32, [vp, i32]),
+        "mfh_set_overlap": (i32, [vp, i32]),
         "mfh_poly_mul": (i32, [vp, vp, sz, vp, sz, vp]),
         "mfh_poly_add": (i32, [vp, vp, vp, sz, vp]),
         "mfh_poly_prepare_t": (i32, [vp, vp]),
@@ -230,6 +231,9 @@ class Context:
 
     def set_timing(self, on=True):
         self._chk(self.lib.mfh_set_timing(self._h, 1 if on else 0))
+
+    def set_overlap(self, on=True):
+        self._chk(self.lib.mfh_set_overlap(self._h, 1 if on else 0))
 
     def timing_drain(self, which):
         """(launch count, total ms, total rows) of the launches of kind `which` since the last drain"""

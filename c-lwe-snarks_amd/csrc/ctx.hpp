@@ -40,6 +40,12 @@ struct mfh_ctx {
   uint32_t *d_t0 = nullptr;  // 256 words
   void *ws = nullptr;        // scratch (partials etc.)
   size_t ws_bytes = 0;
+  void *wws = nullptr;       // scratch of the witness pass (its own buffer: the pass may run beside an eval launch that owns `ws`)
+  size_t wws_bytes = 0;
+  // prover overlap: witness pass + polynomial step on `side` while b_w's rows are evaluated on `stream` (snark.hip)
+  bool overlap = true;
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   std::string err;
   // kernel timing (bench.py's roofline leg): HIP events recorded on the launch stream, resolved lazily
   bool timing = false;
@@ -123,20 +129,22 @@ inline int ssp_src(mfh_ctx *c, const uint32_t *d_ssp, mf::SspSrc &src) {
 void mfh_poly_destroy(mfh_ctx *c);
 int aux_reserve(mfh_ctx *c, size_t bytes);
 
-inline int ws_reserve(mfh_ctx *c, size_t bytes) {
-  if (bytes <= c->ws_bytes) return MFH_OK;
-  if (c->ws) {
+inline int buf_reserve(mfh_ctx *c, void *&buf, size_t &have, size_t bytes) {
+  if (bytes <= have) return MFH_OK;
+  if (buf) {
     hipStreamSynchronize(c->stream);
-    hipFree(c->ws);
-    c->ws = nullptr;
-    c->ws_bytes = 0;
+    hipFree(buf);
+    buf = nullptr;
+    have = 0;
   }
   bytes = (bytes + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
-  if (hipMalloc(&c->ws, bytes) != hipSuccess) {
+  if (hipMalloc(&buf, bytes) != hipSuccess) {
     c->err = "hipMalloc(workspace) failed";
     return MFH_ENOMEM;
   }
-  c->ws_bytes = bytes;
+  have = bytes;
   return MFH_OK;
 }
+inline int ws_reserve(mfh_ctx *c, size_t bytes) { return buf_reserve(c, c->ws, c->ws_bytes, bytes); }
+inline int wws_reserve(mfh_ctx *c, size_t bytes) { return buf_reserve(c, c->wws, c->wws_bytes, bytes); }
 

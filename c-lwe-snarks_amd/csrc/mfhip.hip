@@ -842,8 +842,13 @@ void mfh_ctx_destroy(mfh_ctx *c) {
   pin_free(c->pin_rows);
   pin_free(c->pin_cw);
   pin_free(c->pin_smudge);
+  if (c->side) hipStreamSynchronize(c->side);
   if (c->ws) hipFree(c->ws);
+  if (c->wws) hipFree(c->wws);
   if (c->aux) hipFree(c->aux);
+  if (c->ev_fork) hipEventDestroy(c->ev_fork);
+  if (c->ev_join) hipEventDestroy(c->ev_join);
+  if (c->side) hipStreamDestroy(c->side);
   if (c->d_msg) hipFree(c->d_msg);
   if (c->d_prover) hipFree(c->d_prover);
   if (c->d_t0) hipFree(c->d_t0);
@@ -867,6 +872,12 @@ int mfh_sync(mfh_ctx *c) {
 
 const char *mfh_last_error(const mfh_ctx *c) { return c ? c->err.c_str() : "null context"; }
 size_t mfh_workspace_bytes(const mfh_ctx *c) { return c ? c->ws_bytes : 0; }
+int mfh_set_overlap(mfh_ctx *c, int en) {
+  if (!c) return MFH_EINVAL;
+  c->overlap = en != 0;
+  return MFH_OK;
+}
+
 int mfh_set_timing(mfh_ctx *c, int en) {
   if (!c) return MFH_EINVAL;
   c->timing = en != 0;
@@ -1344,10 +1355,10 @@ static int witness_partials(mfh_ctx *c, const mf::SspSrc &src, const uint8_t *h_
   const uint32_t nsel = hi - lo;
   const uint32_t G = std::max(1u, std::min(64u, nsel / 8 + 1));
   const size_t rows_b = ((size_t)m * 4 + 255) & ~(size_t)255;
-  int rc = ws_reserve(c, rows_b + (size_t)G * d * 8);
+  int rc = wws_reserve(c, rows_b + (size_t)G * d * 8);
   if (rc) return rc;
-  uint32_t *d_rows = (uint32_t *)c->ws;
-  uint64_t *partial = (uint64_t *)((uint8_t *)c->ws + rows_b);
+  uint32_t *d_rows = (uint32_t *)c->wws;
+  uint64_t *partial = (uint64_t *)((uint8_t *)c->wws + rows_b);
   if (nsel) HIP_TRY(c, hipMemcpyAsync(d_rows, rows + lo, (size_t)nsel * 4, hipMemcpyHostToDevice, c->stream));
   pin_release(c, c->pin_rows);
   if (src.dense)

@@ -277,9 +277,40 @@ static int prove_partial_impl(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_
     cnt = (uint32_t)((uint64_t)rows * (rank + 1) / world) - lo;
   };
 
-  // w(x) = delta t + sum_{bit} v_i   (src/snark.c:141,147-155); every rank needs all of w for the polynomial step
-  int rc = d_wlanes ? mfh_witness_from_lanes(c, d_ssp, d_wlanes, delta, w) : mfh_witness_poly(c, d_ssp, h_witness_bits, delta, w);
-  if (rc) return rc;
+  // The witness pass (HBM-bound over the SSP) and the polynomial step (a chain of short launches) do not depend on b_w, and b_w's
+  // rows need neither: the two run side by side, chain on the side stream, b_w's rows on the caller's stream, joined before the
+  // S / AS regions (which need w, v and h).  The side stream waits for everything already queued on the caller's stream first, so
+  // the previous proof's reads of w, v, h are over before they are rewritten.
+  const bool fork = c->overlap;
+  hipStream_t main_stream = c->stream;
+  if (fork) {
+    if (!c->side) {
+      HIP_TRY(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+      HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+      HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    }
+    HIP_TRY(c, hipEventRecord(c->ev_fork, main_stream));
+    HIP_TRY(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
+  }
+  struct StreamSwap {  // every helper launches on c->stream
+    mfh_ctx *c;
+    hipStream_t keep;
+    StreamSwap(mfh_ctx *c_, hipStream_t s) : c(c_), keep(c_->stream) { c->stream = s; }
+    ~StreamSwap() { c->stream = keep; }
+  };
+  int rc;
+  {
+    StreamSwap on_side(c, fork ? c->side : main_stream);
+    // w(x) = delta t + sum_{bit} v_i   (src/snark.c:141,147-155); every rank needs all of w for the polynomial step
+    rc = d_wlanes ? mfh_witness_from_lanes(c, d_ssp, d_wlanes, delta, w) : mfh_witness_poly(c, d_ssp, h_witness_bits, delta, w);
+    if (rc) return rc;
+    // v = w + v_0 ; h = (v^2 - 1) / t   (src/snark.c:161-169)
+    hipLaunchKernelGGL(k_add_slot, g1(d), dim3(256), 0, c->stream, w, src, 1u, d, v);
+    HIP_TRY(c, hipGetLastError());
+    rc = mfh_poly_h(c, v, h);
+    if (rc) return rc;
+    if (fork) HIP_TRY(c, hipEventRecord(c->ev_join, c->side));
+  }
   // b_w = delta * ct_t + sum_{bit} ct_{v_i}: rows BT, BV.. are m consecutive stream rows (src/snark.c:143-155)
   uint32_t *h_cw = (uint32_t *)pin_acquire(c, c->pin_cw, (size_t)m * 4);
   if (!h_cw) return MFH_ENOMEM;
@@ -311,11 +342,7 @@ static int prove_partial_impl(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_
   share(d, loS, cS);
   rc = eval_region((size_t)2 * d + lo, (size_t)2 * cS, cnt, cw + lo, nullptr, pi_b_w, nullptr);
   if (rc) return rc;
-  // v = w + v_0 ; h = (v^2 - 1) / t   (src/snark.c:161-169)
-  hipLaunchKernelGGL(k_add_slot, g1(d), dim3(256), 0, c->stream, w, src, 1u, d, v);
-  HIP_TRY(c, hipGetLastError());
-  rc = mfh_poly_h(c, v, h);
-  if (rc) return rc;
+  if (fork) HIP_TRY(c, hipStreamWaitEvent(main_stream, c->ev_join, 0));
   // S rows: (w, h) -> (v_w, h);  AS rows: (v, h) -> (hat_v, hat_h)   (src/snark.c:157-158,163-164,171-174, each row expanded once)
   rc = eval_region(loS, 0, cS, w + loS, h + loS, pi_v_w, pi_h);
   if (rc) return rc;
