@@ -165,11 +165,19 @@ __global__ __launch_bounds__(PS<LOGQ>::THREADS) void k_eval(AesKey key, const ui
                                                             const uint8_t *__restrict__ c8, const uint32_t *__restrict__ coeff0,
                                                             const uint32_t *__restrict__ coeff1, uint32_t *__restrict__ part) {
   using S = PS<LOGQ>;
-  __shared__ __attribute__((aligned(16))) uint32_t lt[mf::kTabBytes / 4];
-  __shared__ __attribute__((aligned(16))) uint8_t ksbuf[S::ROWS][S::KS_BYTES];
-  __shared__ uint32_t spanc[S::ROWS][kSpanSlots][8];
-  mf::lds_fill_tab(lt, g_t0);
-  const uint8_t *tab = reinterpret_cast<const uint8_t *>(lt);
+  // One LDS object with the AES table FIRST: it then sits at LDS address 0 and a lookup's address is exactly (entry << 8) | replica
+  // offset.  As separate __shared__ arrays the compiler put the table behind the tiles (0x17020), beyond ds_read's 16-bit immediate,
+  // and paid one v_add_u32 per lookup (203 per block, a quarter of the VALU work).
+  struct __attribute__((aligned(16))) Lds {
+    uint32_t lt[mf::kTabBytes / 4];
+    uint8_t ksbuf[S::ROWS][S::KS_BYTES];
+    uint32_t spanc[S::ROWS][kSpanSlots][8];
+  };
+  __shared__ Lds lds;
+  auto &ksbuf = lds.ksbuf;
+  auto &spanc = lds.spanc;
+  mf::lds_fill_tab(lds.lt, g_t0);
+  const uint8_t *tab = reinterpret_cast<const uint8_t *>(lds.lt);
   const mf::AesLane L = mf::aes_lane();
   const uint32_t rs = threadIdx.x / S::TILE, t = threadIdx.x % S::TILE;
   uint8_t *ks = ksbuf[rs];
@@ -273,11 +281,19 @@ __global__ __launch_bounds__(PS<LOGQ>::THREADS) void k_expand(AesKey key, const 
                                                               uint8_t *__restrict__ out) {
   using S = PS<LOGQ>;
   using R = RL<LOGQ>;
-  __shared__ __attribute__((aligned(16))) uint32_t lt[mf::kTabBytes / 4];
-  __shared__ __attribute__((aligned(16))) uint8_t ksbuf[S::ROWS][S::KS_BYTES];
-  __shared__ uint32_t spanc[S::ROWS][kSpanSlots][8];
-  mf::lds_fill_tab(lt, g_t0);
-  const uint8_t *tab = reinterpret_cast<const uint8_t *>(lt);
+  // One LDS object with the AES table FIRST: it then sits at LDS address 0 and a lookup's address is exactly (entry << 8) | replica
+  // offset.  As separate __shared__ arrays the compiler put the table behind the tiles (0x17020), beyond ds_read's 16-bit immediate,
+  // and paid one v_add_u32 per lookup (203 per block, a quarter of the VALU work).
+  struct __attribute__((aligned(16))) Lds {
+    uint32_t lt[mf::kTabBytes / 4];
+    uint8_t ksbuf[S::ROWS][S::KS_BYTES];
+    uint32_t spanc[S::ROWS][kSpanSlots][8];
+  };
+  __shared__ Lds lds;
+  auto &ksbuf = lds.ksbuf;
+  auto &spanc = lds.spanc;
+  mf::lds_fill_tab(lds.lt, g_t0);
+  const uint8_t *tab = reinterpret_cast<const uint8_t *>(lds.lt);
   const mf::AesLane L = mf::aes_lane();
   const uint32_t rs = threadIdx.x / S::TILE, t = threadIdx.x % S::TILE;
   uint8_t *ks = ksbuf[rs];
@@ -448,12 +464,18 @@ __global__ __launch_bounds__(PS<LOGQ>::THREADS) void k_encrypt(AesKey key, const
                                                                const uint64_t *__restrict__ sk, uint32_t *__restrict__ pb) {
   using S = PS<LOGQ>;
   constexpr int NW = S::TILE / 64;
-  __shared__ __attribute__((aligned(16))) uint32_t lt[mf::kTabBytes / 4];
-  __shared__ __attribute__((aligned(16))) uint8_t ksbuf[S::ROWS][S::KS_BYTES];
-  __shared__ uint64_t sums[S::ROWS][S::KW];
-  __shared__ uint32_t spanc[S::ROWS][kSpanSlots][8];
-  mf::lds_fill_tab(lt, g_t0);
-  const uint8_t *tab = reinterpret_cast<const uint8_t *>(lt);
+  struct __attribute__((aligned(16))) Lds {  // AES table first => LDS address 0 (see k_eval)
+    uint32_t lt[mf::kTabBytes / 4];
+    uint8_t ksbuf[S::ROWS][S::KS_BYTES];
+    uint64_t sums[S::ROWS][S::KW];
+    uint32_t spanc[S::ROWS][kSpanSlots][8];
+  };
+  __shared__ Lds lds;
+  auto &ksbuf = lds.ksbuf;
+  auto &sums = lds.sums;
+  auto &spanc = lds.spanc;
+  mf::lds_fill_tab(lds.lt, g_t0);
+  const uint8_t *tab = reinterpret_cast<const uint8_t *>(lds.lt);
   const mf::AesLane L = mf::aes_lane();
   const uint32_t rs = threadIdx.x / S::TILE, t = threadIdx.x % S::TILE;
   uint8_t *ks = ksbuf[rs];
