@@ -119,7 +119,9 @@ __device__ __forceinline__ AesLane aes_lane() {
 #define MF_LD(addr) (*reinterpret_cast<const uint32_t *>(tab + (addr)))
 #endif
 // address of entry byte_k(s) in the T0 (lo0) or T2 (lo2) half
+#ifndef MF_A  /* tools/aes3_ubench.hip overrides this too (cheap-address build: how much does the address VALU cost?) */
 #define MF_A(s, lo, k) ((k) == 1 ? MF_ANDOR((s), L.m1, (lo)) : __builtin_amdgcn_perm((s), (lo), 0x0c0c0400u + ((k) << 8)))
+#endif
 
 __device__ __forceinline__ uint32_t aes_col(const uint8_t *tab, const AesLane &L, uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t rk) {
   uint32_t x0 = MF_LD(MF_A(a, L.lo0, 0)), x1 = MF_LD(MF_A(b, L.lo0, 1));

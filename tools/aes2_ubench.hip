@@ -58,7 +58,8 @@ __device__ __forceinline__ void aes2_pipelined(const uint8_t *tab, const AesLane
 
 template <int V>
 __global__ __launch_bounds__(1024) void k_bench(AesKey key, const uint32_t *g_t0, uint32_t nb, uint32_t *out) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  __shared__ __attribute__((aligned(16))) uint8_t smem[65536 + 94240];  // static, table at LDS address 0 (see aes3_ubench.hip); 1 WG/CU
+  if (nb == 0xffffffffu) smem[65536 + threadIdx.x] = 1;
   mf::lds_fill_tab(reinterpret_cast<uint32_t *>(smem), g_t0);
   __syncthreads();
   const AesLane L = mf::aes_lane();
@@ -76,7 +77,8 @@ __global__ __launch_bounds__(1024) void k_bench(AesKey key, const uint32_t *g_t0
   out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
 __global__ __launch_bounds__(1024) void k_ref(AesKey key, const uint32_t *g_t0, uint32_t nb, uint32_t *out) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  __shared__ __attribute__((aligned(16))) uint8_t smem[65536 + 94240];  // static, table at LDS address 0 (see aes3_ubench.hip); 1 WG/CU
+  if (nb == 0xffffffffu) smem[65536 + threadIdx.x] = 1;
   mf::lds_fill_tab(reinterpret_cast<uint32_t *>(smem), g_t0);
   __syncthreads();
   const AesLane L = mf::aes_lane();
@@ -92,12 +94,12 @@ __global__ __launch_bounds__(1024) void k_ref(AesKey key, const uint32_t *g_t0, 
 }
 template <typename F>
 static void run(const char *name, F kern, const AesKey &key, const uint32_t *d_t0, uint32_t *d_out, int threads, size_t lds) {
-  hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const uint32_t nb = 256; float best = 1e30f;
   for (int it = 0; it < 4; it++) {
     hipEventRecord(e0, 0);
-    hipLaunchKernelGGL(kern, dim3(256), dim3(threads), lds, 0, key, d_t0, nb, d_out);
+    hipLaunchKernelGGL(kern, dim3(256), dim3(threads), 0, 0, key, d_t0, nb, d_out);
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); if (it && ms < best) best = ms;
   }
@@ -110,10 +112,8 @@ int main() {
   uint32_t t0[256]; mf::make_t0_le(t0);
   uint32_t *d_t0, *d_out; hipMalloc(&d_t0, sizeof t0); hipMemcpy(d_t0, t0, sizeof t0, hipMemcpyHostToDevice); hipMalloc(&d_out, 256 * 1024 * 4);
   std::vector<uint32_t> a(1024), b(1024);
-  hipFuncSetAttribute((const void *)k_ref, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-  hipFuncSetAttribute((const void *)k_bench<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-  hipLaunchKernelGGL(k_ref, dim3(1), dim3(1024), 65536, 0, key, d_t0, 4u, d_out); hipMemcpy(a.data(), d_out, 4096, hipMemcpyDeviceToHost);
-  hipLaunchKernelGGL(k_bench<1>, dim3(1), dim3(1024), 65536, 0, key, d_t0, 4u, d_out); hipMemcpy(b.data(), d_out, 4096, hipMemcpyDeviceToHost);
+  hipLaunchKernelGGL(k_ref, dim3(1), dim3(1024), 0, 0, key, d_t0, 4u, d_out); hipMemcpy(a.data(), d_out, 4096, hipMemcpyDeviceToHost);
+  hipLaunchKernelGGL(k_bench<1>, dim3(1), dim3(1024), 0, 0, key, d_t0, 4u, d_out); hipMemcpy(b.data(), d_out, 4096, hipMemcpyDeviceToHost);
   printf("pipelined == reference: %s\n", memcmp(a.data(), b.data(), 4096) ? "NO" : "yes");
   run("single block (product)", k_bench<0>, key, d_t0, d_out, 1024, 65536 + 94240);
   run("2 blocks sequential", k_ref, key, d_t0, d_out, 1024, 65536 + 94240);

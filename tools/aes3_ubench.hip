@@ -2,14 +2,25 @@
 //   -DFAKE_LD : table lookups replaced by a 1-op VALU stand-in (VALU stream alone)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+//   -DCHEAP_ADDR : every lookup address formed with one full-rate v_bitop3 (wrong bytes, same dependences): LDS stream + light VALU
 #ifdef FAKE_LD
 #define MF_LD(addr) ((addr) ^ 0x9e3779b9u)
 #endif
+#ifdef CHEAP_ADDR
+#define MF_A(s, lo, k) MF_ANDOR((s), L.m1, (lo))
+#endif
+//   -DSHIFT_ADDR : correct addresses from full-rate ops only: shift the byte to bits 8..15, then one v_bitop3 and-or (no v_perm)
+#ifdef SHIFT_ADDR
+#define MF_A(s, lo, k) MF_ANDOR(((k) == 0 ? (s) << 8 : (k) == 1 ? (s) : (s) >> (8 * ((k) - 1))), L.m1, (lo))
+#endif
 #include "aes_dev.hpp"
 using mf::AesKey;
-template <int MINW>
+// Static LDS, table first: the table is then at LDS address 0 and the compiler folds the base away (with `extern __shared__` it
+// cannot, and every lookup pays a v_add_u32 -- the condition the product kernels were in before their LDS was made one object).
+template <int MINW, int PAD>
 __global__ __launch_bounds__(1024, MINW) void k_bench(AesKey key, const uint32_t *g_t0, uint32_t nb, uint32_t *out) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  __shared__ __attribute__((aligned(16))) uint8_t smem[65536 + PAD];
+  if (PAD && nb == 0xffffffffu) smem[65536 + threadIdx.x % PAD] = 1;  // keep the pad allocated
   mf::lds_fill_tab(reinterpret_cast<uint32_t *>(smem), g_t0);
   __syncthreads();
   const mf::AesLane L = mf::aes_lane();
@@ -18,14 +29,13 @@ __global__ __launch_bounds__(1024, MINW) void k_bench(AesKey key, const uint32_t
   for (uint32_t i = 0; i < nb; i++) { uint32_t w[4]; mf::aes256_ctr_block(smem, L, key, base + i, w); acc ^= w[0] ^ w[1] ^ w[2] ^ w[3]; }
   out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
-template <int MINW>
-static void run(const char *name, const AesKey &key, const uint32_t *d_t0, uint32_t *d_out, int threads, int wgcu, size_t lds) {
-  hipFuncSetAttribute((const void *)k_bench<MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+template <int MINW, int PAD>
+static void run(const char *name, const AesKey &key, const uint32_t *d_t0, uint32_t *d_out, int threads, int wgcu) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const uint32_t nb = 256; float best = 1e30f;
   for (int it = 0; it < 4; it++) {
     hipEventRecord(e0, 0);
-    hipLaunchKernelGGL(k_bench<MINW>, dim3(256 * wgcu), dim3(threads), lds, 0, key, d_t0, nb, d_out);
+    hipLaunchKernelGGL((k_bench<MINW, PAD>), dim3(256 * wgcu), dim3(threads), 0, 0, key, d_t0, nb, d_out);
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); if (it && ms < best) best = ms;
   }
@@ -40,13 +50,17 @@ int main() {
   uint32_t *d_t0, *d_out; hipMalloc(&d_t0, sizeof t0); hipMemcpy(d_t0, t0, sizeof t0, hipMemcpyHostToDevice); hipMalloc(&d_out, 256 * 2 * 1024 * 4);
 #ifdef FAKE_LD
   const char *n = "VALU-only";
+#elif defined(CHEAP_ADDR)
+  const char *n = "cheap-addr";
+#elif defined(SHIFT_ADDR)
+  const char *n = "shift-addr";
 #else
   const char *n = "real";
 #endif
-  run<1>(n, key, d_t0, d_out, 256, 1, 65536);
-  run<2>(n, key, d_t0, d_out, 512, 1, 65536);
-  run<4>(n, key, d_t0, d_out, 1024, 1, 65536 + 94240);
-  run<4>(n, key, d_t0, d_out, 512, 2, 65536);
-  run<8>(n, key, d_t0, d_out, 1024, 2, 65536);
+  run<1, 94240>(n, key, d_t0, d_out, 256, 1);
+  run<2, 94240>(n, key, d_t0, d_out, 512, 1);
+  run<4, 94240>(n, key, d_t0, d_out, 1024, 1);
+  run<4, 0>(n, key, d_t0, d_out, 512, 2);
+  run<8, 0>(n, key, d_t0, d_out, 1024, 2);
   return 0;
 }
