@@ -42,6 +42,12 @@ struct mfh_ctx {
   size_t ws_bytes = 0;
   void *wws = nullptr;       // scratch of the witness pass (its own buffer: the pass may run beside an eval launch that owns `ws`)
   size_t wws_bytes = 0;
+  // lazy-carry image (one u64 per accumulator word and coordinate) + active-row counter of the eval launches.  Invariant: all
+  // zero between launches (k_eval_reduce_carry clears what it reads), so no memset is queued per evaluation.
+  uint64_t *lazy = nullptr;
+  uint32_t *lazy_cnt = nullptr;
+  size_t lazy_bytes = 0;
+  bool eval_dense = false;  // caller's hint: the coefficient vectors have (practically) no zero entry, skip the row compaction
   // prover overlap: witness pass + polynomial step on `side` while b_w's rows are evaluated on `stream` (snark.hip)
   bool overlap = true;
   hipStream_t side = nullptr;
@@ -143,6 +149,24 @@ inline int buf_reserve(mfh_ctx *c, void *&buf, size_t &have, size_t bytes) {
     return MFH_ENOMEM;
   }
   have = bytes;
+  return MFH_OK;
+}
+inline int lazy_reserve(mfh_ctx *c, size_t bytes) {
+  if (bytes <= c->lazy_bytes) return MFH_OK;
+  if (c->lazy) {
+    hipStreamSynchronize(c->stream);
+    hipFree(c->lazy);
+    c->lazy = nullptr;
+    c->lazy_bytes = 0;
+  }
+  bytes = (bytes + 255) & ~(size_t)255;
+  if (hipMalloc((void **)&c->lazy, bytes + 256) != hipSuccess) {
+    c->err = "hipMalloc(lazy image) failed";
+    return MFH_ENOMEM;
+  }
+  if (hipMemsetAsync(c->lazy, 0, bytes + 256, c->stream) != hipSuccess) return MFH_EDEVICE;
+  c->lazy_cnt = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(c->lazy) + bytes);
+  c->lazy_bytes = bytes;
   return MFH_OK;
 }
 inline int ws_reserve(mfh_ctx *c, size_t bytes) { return buf_reserve(c, c->ws, c->ws_bytes, bytes); }

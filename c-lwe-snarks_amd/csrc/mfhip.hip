@@ -162,8 +162,9 @@ __device__ __forceinline__ void expand_tile_to_lds(const uint8_t *tab, const mf:
 template <int LOGQ, int NACC>
 __global__ __launch_bounds__(PS<LOGQ>::THREADS) void k_eval(AesKey key, const uint32_t *__restrict__ g_t0, uint64_t off, uint32_t n,
                                                             const uint32_t *__restrict__ idx, const uint32_t *__restrict__ cnt,
-                                                            const uint8_t *__restrict__ c8, const uint32_t *__restrict__ coeff0,
-                                                            const uint32_t *__restrict__ coeff1, uint32_t *__restrict__ part) {
+                                                            uint32_t nrows_dense, const uint8_t *__restrict__ c8,
+                                                            const uint32_t *__restrict__ coeff0, const uint32_t *__restrict__ coeff1,
+                                                            uint32_t *__restrict__ part) {
   using S = PS<LOGQ>;
   // One LDS object with the AES table FIRST: it then sits at LDS address 0 and a lookup's address is exactly (entry << 8) | replica
   // offset.  As separate __shared__ arrays the compiler put the table behind the tiles (0x17020), beyond ds_read's 16-bit immediate,
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(PS<LOGQ>::THREADS) void k_eval(AesKey key, const ui
   const uint32_t j0 = blockIdx.x * S::TILE;
   const uint32_t j = j0 + t;
   const uint32_t nelem = j0 >= n ? 0u : min((uint32_t)S::TILE, n - j0);  // keystream-backed coordinates in this tile
-  const uint32_t nact = cnt[0];
+  const uint32_t nact = idx ? cnt[0] : nrows_dense;  // idx == nullptr: every row is active (row k is row k)
   // chunks of a multiple of ROWS active rows
   uint32_t per = (nact + gridDim.y - 1) / gridDim.y;
   per = (per + S::ROWS - 1) / S::ROWS * S::ROWS;
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(PS<LOGQ>::THREADS) void k_eval(AesKey key, const ui
   bool have = k0 + rs < k1;
   uint32_t row = 0;
   if (have) {
-    row = idx[k0 + rs];
+    row = idx ? idx[k0 + rs] : k0 + rs;
     g = tile_geom<LOGQ>(off + (uint64_t)row * n * S::CTB, j0, nelem);
   }
   __syncthreads();
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(PS<LOGQ>::THREADS) void k_eval(AesKey key, const ui
     const uint32_t kn = kk + S::ROWS + rs;
     have = kn < k1;
     if (have) {
-      row = idx[kn];
+      row = idx ? idx[kn] : kn;
       g = tile_geom<LOGQ>(off + (uint64_t)row * n * S::CTB, j0, nelem);
       fill_span_table(tab, L, key, g, t, spanc[rs]);
     }
@@ -252,11 +253,29 @@ __global__ __launch_bounds__(PS<LOGQ>::THREADS) void k_eval(AesKey key, const ui
     }
     __syncthreads();
   }
+  // Fold the second row half into the first through the (now free) keystream tiles, so that one partial sum per workgroup and
+  // coordinate goes to HBM instead of two.  Sums are mod 2^(32 KW): the carry out of the top word is dropped, as in the MAC.
+  static_assert(S::ROWS == 2 && (size_t)S::ROWS * S::KS_BYTES >= (size_t)2 * S::KW * S::TILE * 4, "fold buffer");
+  uint32_t *xch = reinterpret_cast<uint32_t *>(&ksbuf[0][0]);
+  if (rs == 1) {
 #pragma unroll
-  for (int a = 0; a < NACC; a++)
+    for (int a = 0; a < NACC; a++)
 #pragma unroll
-    for (int l = 0; l < S::KW; l++)
-      part[((((uint64_t)blockIdx.y * S::ROWS + rs) * NACC + a) * S::KW + l) * NJ + j] = acc[a][l];
+      for (int l = 0; l < S::KW; l++) xch[(a * S::KW + l) * S::TILE + t] = acc[a][l];
+  }
+  __syncthreads();
+  if (rs == 0) {
+#pragma unroll
+    for (int a = 0; a < NACC; a++) {
+      uint32_t carry = 0;
+#pragma unroll
+      for (int l = 0; l < S::KW; l++) {
+        const uint64_t tt = (uint64_t)acc[a][l] + xch[(a * S::KW + l) * S::TILE + t] + carry;
+        part[(((uint64_t)blockIdx.y * NACC + a) * S::KW + l) * NJ + j] = (uint32_t)tt;
+        carry = (uint32_t)(tt >> 32);
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -349,13 +368,14 @@ __global__ __launch_bounds__(PS<LOGQ>::THREADS) void k_expand(AesKey key, const 
 // part layout as k_eval's: part[((slab*NACC + a)*KW + l)*NJ + j], slab = chunk*4 + wave-in-block ... here one slab per block row-share.
 template <int LOGQ, int NACC>
 __global__ __launch_bounds__(256) void k_mac_resident(const uint8_t *__restrict__ rows, uint32_t n, const uint32_t *__restrict__ idx,
-                                                      const uint32_t *__restrict__ cnt, uint32_t row_base, const uint32_t *__restrict__ coeff0,
-                                                      const uint32_t *__restrict__ coeff1, uint32_t *__restrict__ part, uint32_t NJ) {
+                                                      const uint32_t *__restrict__ cnt, uint32_t nrows_dense, uint32_t row_base,
+                                                      const uint32_t *__restrict__ coeff0, const uint32_t *__restrict__ coeff1,
+                                                      uint32_t *__restrict__ part, uint32_t NJ) {
   using S = PS<LOGQ>;
   using R = RL<LOGQ>;
   const uint32_t RS = R::rs(n);
   const uint32_t j = blockIdx.x * 256 + threadIdx.x;
-  const uint32_t nact = cnt[0];
+  const uint32_t nact = idx ? cnt[0] : nrows_dense;
   const uint32_t per = (nact + gridDim.y - 1) / gridDim.y;
   const uint32_t k0 = blockIdx.y * per, k1 = min(nact, k0 + per);
   uint32_t acc[NACC][S::KW];
@@ -365,7 +385,7 @@ __global__ __launch_bounds__(256) void k_mac_resident(const uint8_t *__restrict_
     for (int l = 0; l < S::KW; l++) acc[a][l] = 0;
   if (j < RS) {
     for (uint32_t k = k0; k < k1; k++) {
-      const uint32_t row = idx[k];
+      const uint32_t row = idx ? idx[k] : k;
       uint32_t c[NACC];
       c[0] = coeff0[row];
       if constexpr (NACC > 1) c[1] = coeff1[row];
@@ -428,18 +448,26 @@ __global__ __launch_bounds__(256) void k_eval_reduce_sum(const uint32_t *__restr
   atomicAdd(reinterpret_cast<unsigned long long *>(&lazy[((uint64_t)a * S::KW + l) * NJ + j]), (unsigned long long)(s0 + s1 + s2 + s3));
 }
 // stage 2: propagate carries over the KW words of each coordinate, write natural-layout values (optionally += previous)
+// The lazy image and the active-row counter are zero between launches: this kernel, their last reader, clears what it read
+// (that replaces two memset launches per evaluation).
 template <int LOGQ>
-__global__ void k_eval_reduce_carry(const uint64_t *__restrict__ lazy, uint32_t NG, uint32_t nacc, uint32_t NJ, uint32_t n,
+__global__ void k_eval_reduce_carry(uint64_t *__restrict__ lazy, uint32_t *__restrict__ cnt, uint32_t nacc, uint32_t NJ, uint32_t n,
                                     uint64_t *__restrict__ rop0, uint64_t *__restrict__ rop1, int accumulate) {
   using S = PS<LOGQ>;
   uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t a = blockIdx.y;
-  if (j > n) return;
+  if (j == 0 && a == 0) cnt[0] = 0;
+  if (j >= NJ) return;
+  if (j > n) {  // padding coordinates: their sums are zero by construction; keep the invariant explicit all the same
+    for (int l = 0; l < S::KW; l++) lazy[((uint64_t)a * S::KW + l) * NJ + j] = 0;
+    return;
+  }
   uint64_t *rop = a == 0 ? rop0 : rop1;
   uint32_t *out = reinterpret_cast<uint32_t *>(rop + (uint64_t)j * S::L);
   uint64_t carry = 0;
   for (int l = 0; l < S::KW; l++) {
     uint64_t s = lazy[((uint64_t)a * S::KW + l) * NJ + j] + carry;  // < 2^32 * slabs + carry: no overflow
+    lazy[((uint64_t)a * S::KW + l) * NJ + j] = 0;
     if (accumulate) s += out[l];
     out[l] = (uint32_t)s;
     carry = s >> 32;
@@ -867,6 +895,7 @@ void mfh_ctx_destroy(mfh_ctx *c) {
   if (c->side) hipStreamSynchronize(c->side);
   if (c->ws) hipFree(c->ws);
   if (c->wws) hipFree(c->wws);
+  if (c->lazy) hipFree(c->lazy);
   if (c->aux) hipFree(c->aux);
   if (c->ev_fork) hipEventDestroy(c->ev_fork);
   if (c->ev_join) hipEventDestroy(c->ev_join);
@@ -1042,7 +1071,7 @@ int mfh_ct_addmul_ui(mfh_ctx *c, uint64_t *rop, const uint64_t *a, uint32_t x, s
 
 // number of row chunks: one workgroup per CU per tile row is the sweet spot (64 KiB table + 2 keystream tiles fill the LDS)
 static uint32_t pick_chunks(uint32_t nrows, uint32_t ntiles, uint32_t rows_per_iter) {
-  uint32_t target = std::max(1u, (256u * 2u) / ntiles);  // ~2 workgroups per CU in flight over the launch
+  uint32_t target = std::max(1u, 255u / ntiles);  // one workgroup per CU for the whole launch (LDS allows only one at a time anyway)
   uint32_t maxc = std::max(1u, (nrows + rows_per_iter * 4 - 1) / (rows_per_iter * 4));  // >= 4 iterations per chunk to amortise the table fill
   return std::min(target, maxc);
 }
@@ -1055,34 +1084,36 @@ static int eval_rows(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *c8, 
   const uint32_t ntiles = (n + 1 + S::TILE - 1) / S::TILE;
   const int nacc = c1 ? 2 : 1;
   const uint32_t nchunks = pick_chunks((uint32_t)nrows, ntiles, S::ROWS);
-  const uint32_t nslabs = nchunks * S::ROWS;
+  const uint32_t nslabs = nchunks;  // the two row halves of a workgroup are folded before they leave the kernel
   const uint32_t NJ = ntiles * S::TILE;
   const size_t part_bytes = (size_t)nslabs * nacc * S::KW * NJ * 4;
   const uint32_t NG = 8;  // slab groups of the first reduction stage
-  const size_t lazy_bytes = (size_t)nacc * S::KW * NJ * 8;
   const size_t idx_bytes = (((size_t)nrows + 1) * 4 + 255) & ~(size_t)255;
-  int rc = ws_reserve(c, part_bytes + lazy_bytes + idx_bytes);
+  int rc = ws_reserve(c, part_bytes + idx_bytes);
+  if (rc) return rc;
+  rc = lazy_reserve(c, (size_t)nacc * S::KW * NJ * 8);
   if (rc) return rc;
   uint32_t *part = (uint32_t *)c->ws;
-  uint64_t *lazy = (uint64_t *)((uint8_t *)c->ws + part_bytes);
-  uint32_t *idx = (uint32_t *)((uint8_t *)c->ws + part_bytes + lazy_bytes);
-  uint32_t *cnt = idx + nrows;
-  HIP_TRY(c, hipMemsetAsync(cnt, 0, 4, c->stream));
-  hipLaunchKernelGGL(k_compact_rows, dim3(((uint32_t)nrows + 255) / 256), dim3(256), 0, c->stream, c0, c1, (uint32_t)nrows, idx, cnt);
-  HIP_TRY(c, hipGetLastError());
+  uint64_t *lazy = c->lazy;
+  uint32_t *cnt = c->lazy_cnt;
+  uint32_t *idx = nullptr;
+  if (!c->eval_dense) {  // drop the rows whose coefficients are all zero (the reference expands them only to advance its stream)
+    idx = (uint32_t *)((uint8_t *)c->ws + part_bytes);
+    hipLaunchKernelGGL(k_compact_rows, dim3(((uint32_t)nrows + 255) / 256), dim3(256), 0, c->stream, c0, c1, (uint32_t)nrows, idx, cnt);
+    HIP_TRY(c, hipGetLastError());
+  }
   {
     Timer t(c, nacc, nrows);
     if (nacc == 2)
-      hipLaunchKernelGGL((k_eval<LOGQ, 2>), dim3(ntiles, nchunks), dim3(S::THREADS), 0, c->stream, c->key, c->d_t0, off, n, idx, cnt, c8, c0, c1,
-                         part);
+      hipLaunchKernelGGL((k_eval<LOGQ, 2>), dim3(ntiles, nchunks), dim3(S::THREADS), 0, c->stream, c->key, c->d_t0, off, n, idx, cnt,
+                         (uint32_t)nrows, c8, c0, c1, part);
     else
-      hipLaunchKernelGGL((k_eval<LOGQ, 1>), dim3(ntiles, nchunks), dim3(S::THREADS), 0, c->stream, c->key, c->d_t0, off, n, idx, cnt, c8, c0, c1,
-                         part);
+      hipLaunchKernelGGL((k_eval<LOGQ, 1>), dim3(ntiles, nchunks), dim3(S::THREADS), 0, c->stream, c->key, c->d_t0, off, n, idx, cnt,
+                         (uint32_t)nrows, c8, c0, c1, part);
   }
   HIP_TRY(c, hipGetLastError());
-  HIP_TRY(c, hipMemsetAsync(lazy, 0, lazy_bytes, c->stream));
   hipLaunchKernelGGL(k_eval_reduce_sum<LOGQ>, dim3((NJ + 255) / 256, S::KW * nacc, NG), dim3(256), 0, c->stream, part, nslabs, (uint32_t)nacc, NJ, lazy);
-  hipLaunchKernelGGL(k_eval_reduce_carry<LOGQ>, dim3((n + 1 + 255) / 256, nacc), dim3(256), 0, c->stream, lazy, NG, (uint32_t)nacc, NJ, n, rop0, rop1,
+  hipLaunchKernelGGL(k_eval_reduce_carry<LOGQ>, dim3((NJ + 255) / 256, nacc), dim3(256), 0, c->stream, lazy, cnt, (uint32_t)nacc, NJ, n, rop0, rop1,
                      accumulate);
   HIP_TRY(c, hipGetLastError());
   return MFH_OK;
@@ -1118,28 +1149,32 @@ static int eval_rows_resident(mfh_ctx *c, const uint8_t *rows, size_t row_base, 
   const uint32_t nchunks = std::max(1u, std::min((uint32_t)nrows, (256u * 8u) / gx));  // ~8 workgroups of 4 waves per CU
   const size_t part_bytes = (size_t)nchunks * nacc * S::KW * NJ * 4;
   const uint32_t NG = 8;  // slab groups of the first reduction stage
-  const size_t lazy_bytes = (size_t)nacc * S::KW * NJ * 8;
   const size_t idx_bytes = (((size_t)nrows + 1) * 4 + 255) & ~(size_t)255;
-  int rc = ws_reserve(c, part_bytes + lazy_bytes + idx_bytes);
+  int rc = ws_reserve(c, part_bytes + idx_bytes);
+  if (rc) return rc;
+  rc = lazy_reserve(c, (size_t)nacc * S::KW * NJ * 8);
   if (rc) return rc;
   uint32_t *part = (uint32_t *)c->ws;
-  uint64_t *lazy = (uint64_t *)((uint8_t *)c->ws + part_bytes);
-  uint32_t *idx = (uint32_t *)((uint8_t *)c->ws + part_bytes + lazy_bytes);
-  uint32_t *cnt = idx + nrows;
-  HIP_TRY(c, hipMemsetAsync(cnt, 0, 4, c->stream));
-  hipLaunchKernelGGL(k_compact_rows, dim3(((uint32_t)nrows + 255) / 256), dim3(256), 0, c->stream, c0, c1, (uint32_t)nrows, idx, cnt);
-  HIP_TRY(c, hipGetLastError());
+  uint64_t *lazy = c->lazy;
+  uint32_t *cnt = c->lazy_cnt;
+  uint32_t *idx = nullptr;
+  if (!c->eval_dense) {
+    idx = (uint32_t *)((uint8_t *)c->ws + part_bytes);
+    hipLaunchKernelGGL(k_compact_rows, dim3(((uint32_t)nrows + 255) / 256), dim3(256), 0, c->stream, c0, c1, (uint32_t)nrows, idx, cnt);
+    HIP_TRY(c, hipGetLastError());
+  }
   {
     Timer t(c, 4 + nacc, nrows);
     if (nacc == 2)
-      hipLaunchKernelGGL((k_mac_resident<LOGQ, 2>), dim3(gx, nchunks), dim3(256), 0, c->stream, rows, n, idx, cnt, (uint32_t)row_base, c0, c1, part, NJ);
+      hipLaunchKernelGGL((k_mac_resident<LOGQ, 2>), dim3(gx, nchunks), dim3(256), 0, c->stream, rows, n, idx, cnt, (uint32_t)nrows, (uint32_t)row_base,
+                         c0, c1, part, NJ);
     else
-      hipLaunchKernelGGL((k_mac_resident<LOGQ, 1>), dim3(gx, nchunks), dim3(256), 0, c->stream, rows, n, idx, cnt, (uint32_t)row_base, c0, c1, part, NJ);
+      hipLaunchKernelGGL((k_mac_resident<LOGQ, 1>), dim3(gx, nchunks), dim3(256), 0, c->stream, rows, n, idx, cnt, (uint32_t)nrows, (uint32_t)row_base,
+                         c0, c1, part, NJ);
   }
   HIP_TRY(c, hipGetLastError());
-  HIP_TRY(c, hipMemsetAsync(lazy, 0, lazy_bytes, c->stream));
   hipLaunchKernelGGL(k_eval_reduce_sum<LOGQ>, dim3((NJ + 255) / 256, S::KW * nacc, NG), dim3(256), 0, c->stream, part, nchunks, (uint32_t)nacc, NJ, lazy);
-  hipLaunchKernelGGL(k_eval_reduce_carry<LOGQ>, dim3((n + 1 + 255) / 256, nacc), dim3(256), 0, c->stream, lazy, NG, (uint32_t)nacc, NJ, n, rop0, rop1,
+  hipLaunchKernelGGL(k_eval_reduce_carry<LOGQ>, dim3((NJ + 255) / 256, nacc), dim3(256), 0, c->stream, lazy, cnt, (uint32_t)nacc, NJ, n, rop0, rop1,
                      accumulate);
   HIP_TRY(c, hipGetLastError());
   return MFH_OK;

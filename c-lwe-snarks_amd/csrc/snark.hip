@@ -344,9 +344,13 @@ static int prove_partial_impl(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_
   if (rc) return rc;
   if (fork) HIP_TRY(c, hipStreamWaitEvent(main_stream, c->ev_join, 0));
   // S rows: (w, h) -> (v_w, h);  AS rows: (v, h) -> (hat_v, hat_h)   (src/snark.c:157-158,163-164,171-174, each row expanded once)
+  // the coefficients of w, v, h are residues mod p of polynomial arithmetic: a zero is a 2^-32 event, so the row compaction would
+  // only copy the identity; rows with a zero pair are still correct without it (they add zero)
+  c->eval_dense = true;
   rc = eval_region(loS, 0, cS, w + loS, h + loS, pi_v_w, pi_h);
-  if (rc) return rc;
-  return eval_region((size_t)d + loS, cS, cS, v + loS, h + loS, pi_hat_v, pi_hat_h);
+  if (!rc) rc = eval_region((size_t)d + loS, cS, cS, v + loS, h + loS, pi_hat_v, pi_hat_h);
+  c->eval_dense = false;
+  return rc;
 }
 
 int mfh_prove_partial(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, const uint8_t *h_witness_bits, uint32_t delta,
