@@ -50,6 +50,7 @@ struct mfh_ctx {
   bool eval_dense = false;  // caller's hint: the coefficient vectors have (practically) no zero entry, skip the row compaction
   // prover overlap: witness pass + polynomial step on `side` while b_w's rows are evaluated on `stream` (snark.hip)
   bool overlap = true;
+  int overlap_mode = 1;  // 1 = pick the queueing order by the size of b_w's share, 2 = b_w first, 3 = chain first (mfh_set_overlap)
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   std::string err;

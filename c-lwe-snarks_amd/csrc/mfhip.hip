@@ -926,6 +926,7 @@ size_t mfh_workspace_bytes(const mfh_ctx *c) { return c ? c->ws_bytes : 0; }
 int mfh_set_overlap(mfh_ctx *c, int en) {
   if (!c) return MFH_EINVAL;
   c->overlap = en != 0;
+  c->overlap_mode = en > 1 ? en : 1;
   return MFH_OK;
 }
 

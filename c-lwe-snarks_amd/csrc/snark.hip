@@ -299,18 +299,6 @@ static int prove_partial_impl(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_
     ~StreamSwap() { c->stream = keep; }
   };
   int rc;
-  {
-    StreamSwap on_side(c, fork ? c->side : main_stream);
-    // w(x) = delta t + sum_{bit} v_i   (src/snark.c:141,147-155); every rank needs all of w for the polynomial step
-    rc = d_wlanes ? mfh_witness_from_lanes(c, d_ssp, d_wlanes, delta, w) : mfh_witness_poly(c, d_ssp, h_witness_bits, delta, w);
-    if (rc) return rc;
-    // v = w + v_0 ; h = (v^2 - 1) / t   (src/snark.c:161-169)
-    hipLaunchKernelGGL(k_add_slot, g1(d), dim3(256), 0, c->stream, w, src, 1u, d, v);
-    HIP_TRY(c, hipGetLastError());
-    rc = mfh_poly_h(c, v, h);
-    if (rc) return rc;
-    if (fork) HIP_TRY(c, hipEventRecord(c->ev_join, c->side));
-  }
   // b_w = delta * ct_t + sum_{bit} ct_{v_i}: rows BT, BV.. are m consecutive stream rows (src/snark.c:143-155)
   uint32_t *h_cw = (uint32_t *)pin_acquire(c, c->pin_cw, (size_t)m * 4);
   if (!h_cw) return MFH_ENOMEM;
@@ -340,7 +328,31 @@ static int prove_partial_impl(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_
   };
   uint32_t loS, cS;
   share(d, loS, cS);
-  rc = eval_region((size_t)2 * d + lo, (size_t)2 * cS, cnt, cw + lo, nullptr, pi_b_w, nullptr);
+  auto run_bw = [&]() -> int { return eval_region((size_t)2 * d + lo, (size_t)2 * cS, cnt, cw + lo, nullptr, pi_b_w, nullptr); };
+  auto run_chain = [&]() -> int {
+    StreamSwap on_side(c, fork ? c->side : main_stream);
+    // w(x) = delta t + sum_{bit} v_i   (src/snark.c:141,147-155); every rank needs all of w for the polynomial step
+    int r = d_wlanes ? mfh_witness_from_lanes(c, d_ssp, d_wlanes, delta, w) : mfh_witness_poly(c, d_ssp, h_witness_bits, delta, w);
+    if (r) return r;
+    // v = w + v_0 ; h = (v^2 - 1) / t   (src/snark.c:161-169)
+    hipLaunchKernelGGL(k_add_slot, g1(d), dim3(256), 0, c->stream, w, src, 1u, d, v);
+    HIP_TRY(c, hipGetLastError());
+    r = mfh_poly_h(c, v, h);
+    if (r) return r;
+    if (fork) HIP_TRY(c, hipEventRecord(c->ev_join, c->side));
+    return MFH_OK;
+  };
+  // Host queueing order.  b_w first: the GPU already runs that long kernel while the host enqueues the chain's ~25 short launches --
+  // pays when the b_w launch is long (it holds every CU's LDS, so the chain's LDS kernels mostly run after it anyway).  Chain first:
+  // the chain runs at full speed alone and b_w's rows follow -- better when b_w's share is short (many ranks, resident CRS).
+  const bool bw_first = c->overlap_mode == 2 || (c->overlap_mode == 1 && !res && (uint64_t)cnt * 2 >= m);
+  if (bw_first) {
+    rc = run_bw();
+    if (!rc) rc = run_chain();
+  } else {
+    rc = run_chain();
+    if (!rc) rc = run_bw();
+  }
   if (rc) return rc;
   if (fork) HIP_TRY(c, hipStreamWaitEvent(main_stream, c->ev_join, 0));
   // S rows: (w, h) -> (v_w, h);  AS rows: (v, h) -> (hat_v, hat_h)   (src/snark.c:157-158,163-164,171-174, each row expanded once)

@@ -210,9 +210,10 @@ size_t mfh_workspace_bytes(const mfh_ctx *ctx);
  * reports and forgets the launches of kind `which`: "eval2" / "eval1" (k_eval with 2 / 1 coefficient vectors),
  * "eval" (both), "encrypt", "keystream", "expand", "mac2" / "mac1" (resident MAC).  total_rows = rows handed to those launches (AES blocks for "keystream"). */
 int mfh_set_timing(mfh_ctx *ctx, int enabled);
-/* prover scheduling (default on): mfh_prove* run the witness pass + polynomial step on an internal stream beside the
- * evaluation of b_w's rows and join before the S / AS regions; results are identical either way.  Off = one stream. */
-int mfh_set_overlap(mfh_ctx *ctx, int enabled);
+/* prover scheduling: mfh_prove* run the witness pass + polynomial step on an internal stream beside the evaluation of
+ * b_w's rows and join before the S / AS regions; results are identical in every mode.  0 = one stream, 1 (default) = two
+ * streams, queueing order picked from the size of b_w's share, 2 = b_w's rows queued first, 3 = the chain queued first. */
+int mfh_set_overlap(mfh_ctx *ctx, int mode);
 int mfh_timing_drain(mfh_ctx *ctx, const char *which, uint64_t *count, double *total_ms, uint64_t *total_rows, float *last_ms);
 float mfh_last_kernel_ms(mfh_ctx *ctx, const char *which); /* = last_ms of mfh_timing_drain; < 0 if none */
 

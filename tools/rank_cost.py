@@ -18,6 +18,8 @@ from c_lwe_snarks_amd import dist as mfdist  # noqa: E402
 worlds = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]
 p = mf.DEFAULT
 ctx = mf.Context(p, 0)
+if os.environ.get("MFUOCO_OVERLAP"):  # 0 off, 1 auto, 2 b_w first, 3 chain first
+    ctx.lib.mfh_set_overlap(ctx._h, int(os.environ["MFUOCO_OVERLAP"]))
 ctx.set_seed(bytes((37 * i + 11) & 0xFF for i in range(40)))
 inst = bench.build_instance(mf, ctx, torch, p, 20260101)
 ctx.ssp_prepare(inst["d_ssp"])
