@@ -232,8 +232,9 @@ class Context:
     def set_timing(self, on=True):
         self._chk(self.lib.mfh_set_timing(self._h, 1 if on else 0))
 
-    def set_overlap(self, on=True):
-        self._chk(self.lib.mfh_set_overlap(self._h, 1 if on else 0))
+    def set_overlap(self, mode=1):
+        """0 = one stream, 1 = two streams with the queueing order picked automatically, 2 = b_w first, 3 = chain first"""
+        self._chk(self.lib.mfh_set_overlap(self._h, int(mode)))
 
     def timing_drain(self, which):
         """(launch count, total ms, total rows) of the launches of kind `which` since the last drain"""

@@ -318,3 +318,26 @@ def test_partially_resident_crs(ctx, instance, nres):
     finally:
         ctx.set_resident(None)
     assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+def test_prover_scheduling_modes_and_zero_coefficients(ctx, oracle, instance, mode):
+    """Every queueing mode of mfh_set_overlap gives the oracle's proof, also when whole coefficient vectors are zero: with
+    delta = 0 and an all-zero witness w = 0, so the S region is evaluated with an all-zero first vector on the path that
+    skips the row compaction (dense hint), and b_w's coefficient vector is all zero on the path that compacts."""
+    I = instance
+    p = I["p"]
+    zero_bits = bytes(len(I["bits"]))
+    mags = bytes(range(80)) * 5
+    signs = bytes([0, 1, 0, 1, 0])
+    tape = b"".join(mags[80 * k: 80 * k + 80] + signs[k: k + 1] for k in range(5))
+    d_crs = ctx.to_device(_crs_stream_order(p, I["crs"]))
+    ctx.set_overlap(mode)
+    try:
+        for bits, delta in ((zero_bits, 0), (I["bits"], 12345)):
+            ref = oracle.prover(p, I["crs"], I["ssp"], bits, delta, tape, 80)
+            got = ctx.to_host(ctx.prove(d_crs, I["d_ssp"], bits, delta, mags, signs), np.uint64).reshape(5, p.n + 1, p.L)
+            for k in range(5):
+                assert np.array_equal(got[k], ref["proof"][k]), (mode, delta, k)
+    finally:
+        ctx.set_overlap(1)
