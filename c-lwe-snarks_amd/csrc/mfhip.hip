@@ -157,7 +157,7 @@ __device__ __forceinline__ void expand_tile_to_lds(const uint8_t *tab, const mf:
 // eval kernel: fused ct_import + ct_addmul_ui over the active rows, 1 or 2 coefficient vectors.
 // grid = (ntiles, nchunks); block = ROWS x TILE threads; thread (rs, t) owns coordinate j0 + t for the rows
 // idx[k], k = k0 + rs, k0 + rs + ROWS, ... of its chunk.
-// partials: part[(((chunk*ROWS + rs)*NACC + a)*KW + l)*NJ + j]  (uint32), NJ = ntiles*TILE
+// partials (the two row halves folded first): part[((chunk*NACC + a)*KW + l)*NJ + j]  (uint32), NJ = ntiles*TILE
 // ------------------------------------------------------------------------------------------------------
 template <int LOGQ, int NACC>
 __global__ __launch_bounds__(PS<LOGQ>::THREADS) void k_eval(AesKey key, const uint32_t *__restrict__ g_t0, uint64_t off, uint32_t n,
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(PS<LOGQ>::THREADS) void k_expand(AesKey key, const 
 
 // streaming MAC over resident rows: grid = (RS/64 column groups x nchunks), 256 threads = 4 waves; each wave owns 64
 // coordinates and walks its share of the active rows, two rows in flight.
-// part layout as k_eval's: part[((slab*NACC + a)*KW + l)*NJ + j], slab = chunk*4 + wave-in-block ... here one slab per block row-share.
+// part layout as k_eval's: part[((chunk*NACC + a)*KW + l)*NJ + j], one slab per row chunk (blockIdx.y).
 template <int LOGQ, int NACC>
 __global__ __launch_bounds__(256) void k_mac_resident(const uint8_t *__restrict__ rows, uint32_t n, const uint32_t *__restrict__ idx,
                                                       const uint32_t *__restrict__ cnt, uint32_t nrows_dense, uint32_t row_base,
