@@ -24,20 +24,20 @@ def prove_sharded(ctx, d_crs, d_ssp, witness_bits, delta, smudge_mag, smudge_sig
     complete proof.  `bufs` may hold reusable device buffers {"partial", "lanes", "proof"}.  world == 1 proves alone: no
     collective is issued even inside a process group (independent provers per rank)."""
     bufs = {} if bufs is None else bufs
-    if world > 1:
-        # first exchange: the SSP pass is sharded too (each rank sums its share of the selected v_i), d uint64 lanes
-        wl = ctx.witness_lanes(d_ssp, witness_bits, rank, world, out=bufs.get("wlanes"))
-        allreduce_lanes(wl, group)
-        bufs["wlanes"] = wl
-        partial = ctx.prove_partial_w(d_crs, d_ssp, witness_bits, delta, rank, world, wl, out=bufs.get("partial"))
-    else:
-        partial = ctx.prove_partial(d_crs, d_ssp, witness_bits, delta, rank, world, out=bufs.get("partial"))
+    if world == 1:  # nothing to exchange: the partial proof is the proof (mfh_prove = mfh_prove_partial + mfh_prove_finish)
+        proof = ctx.prove(d_crs, d_ssp, witness_bits, delta, smudge_mag, smudge_sign, maglen, out=bufs.get("proof"))
+        bufs["proof"] = proof
+        return proof
+    # first exchange: the SSP pass is sharded too (each rank sums its share of the selected v_i), d uint64 lanes
+    wl = ctx.witness_lanes(d_ssp, witness_bits, rank, world, out=bufs.get("wlanes"))
+    allreduce_lanes(wl, group)
+    partial = ctx.prove_partial_w(d_crs, d_ssp, witness_bits, delta, rank, world, wl, out=bufs.get("partial"))
+    # second exchange: the five partial ciphertexts, one 32-bit word per uint64 lane
     lanes = ctx.ct_to_lanes(partial, 5, out=bufs.get("lanes"))
-    if world > 1:
-        allreduce_lanes(lanes, group)
+    allreduce_lanes(lanes, group)
     proof = ctx.ct_from_lanes(lanes, 5, out=bufs.get("proof"))
     ctx.prove_finish(proof, smudge_mag, smudge_sign, maglen)
-    bufs.update(partial=partial, lanes=lanes, proof=proof)
+    bufs.update(wlanes=wl, partial=partial, lanes=lanes, proof=proof)
     return proof
 
 

@@ -93,7 +93,7 @@ class _FakeCtx:
 
 
 @pytest.mark.parametrize("world,expect", [
-    (1, ["prove_partial", "ct_to_lanes", "ct_from_lanes", "prove_finish"]),
+    (1, ["prove"]),
     (4, ["witness_lanes", "ALLREDUCE", "prove_partial_w", "ct_to_lanes", "ALLREDUCE", "ct_from_lanes", "prove_finish"]),
 ])
 def test_prove_sharded_call_sequence(monkeypatch, world, expect):
