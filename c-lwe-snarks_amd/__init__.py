@@ -84,7 +84,7 @@ EXPORTS = [
     "mfh_ctx_create", "mfh_ctx_destroy", "mfh_set_stream", "mfh_sync", "mfh_last_error", "mfh_set_seed",
     "mfh_keystream", "mfh_sample_rows", "mfh_ct_add", "mfh_ct_mul_ui", "mfh_ct_addmul_ui", "mfh_eval_rows",
     "mfh_encrypt_rows", "mfh_decrypt", "mfh_ct_smudge", "mfh_ssp_upload", "mfh_witness_poly", "mfh_version",
-    "mfh_workspace_bytes", "mfh_last_kernel_ms", "mfh_set_timing", "mfh_set_overlap", "mfh_poly_mul", "mfh_poly_add", "mfh_poly_prepare_t",
+    "mfh_workspace_bytes", "mfh_last_kernel_ms", "mfh_set_timing", "mfh_set_overlap", "mfh_eval_rows_multi", "mfh_poly_mul", "mfh_poly_add", "mfh_poly_prepare_t",
     "mfh_ssp_prepare", "mfh_poly_h", "mfh_setup_messages", "mfh_setup", "mfh_prove",
     "mfh_prove_partial", "mfh_prove_finish", "mfh_ct_to_lanes", "mfh_ct_from_lanes", "mfh_timing_drain", "mfh_add_dotp",
     "mfh_resident_row_bytes", "mfh_crs_expand", "mfh_eval_rows_resident", "mfh_crs_set_resident",
@@ -127,6 +127,7 @@ def load_library():
         "mfh_last_kernel_ms": (ctypes.c_float, [vp, ctypes.c_char_p]),
         "mfh_set_timing": (i32, [vp, i32]),
         "mfh_set_overlap": (i32, [vp, i32]),
+        "mfh_eval_rows_multi": (i32, [vp, u64, sz, vp, vp, ctypes.c_uint32, vp, i32]),
         "mfh_poly_mul": (i32, [vp, vp, sz, vp, sz, vp]),
         "mfh_poly_add": (i32, [vp, vp, vp, sz, vp]),
         "mfh_poly_prepare_t": (i32, [vp, vp]),
@@ -288,6 +289,12 @@ class Context:
         self._chk(self.lib.mfh_eval_rows(self._h, off, nrows, _ptr(c8), _ptr(coeff0), _ptr(coeff1), _ptr(rop0), _ptr(rop1),
                                          1 if accumulate else 0))
         return rop0, rop1
+
+    def eval_rows_multi(self, off, nrows, c8, coeffs, nvec, out=None, accumulate=False):
+        """coeffs: nvec x nrows uint32 on the device (vector-major) -> nvec ciphertexts (vector-major); matrix-core path"""
+        out = self.empty(nvec * self.params.ct_limbs * 8) if out is None else out
+        self._chk(self.lib.mfh_eval_rows_multi(self._h, off, nrows, _ptr(c8), _ptr(coeffs), nvec, _ptr(out), 1 if accumulate else 0))
+        return out
 
     def encrypt_rows(self, off, nrows, sk, msg, err, out=None):
         """regev_encrypt2 + ct_export batch (src/lwe.c:78-97,115-119)."""

@@ -1,0 +1,297 @@
+// evalmm.hip -- eval_poly (reference src/lwe.c:160-178) for MANY coefficient vectors over the same CRS rows: one expansion of the
+// rows, the multiply-accumulate on the matrix cores.
+//
+// With one or two coefficient vectors (one proof) the MAC is GEMV-shaped and k_eval (mfhip.hip) does it on the VALU.  With V
+// vectors -- the S / AS / BV regions of a batch of proofs under one CRS -- it is a GEMM over the rows:
+//
+//     out_v[j] = sum_i c_v[i] * a_ij   (mod 2^704)
+//   a_ij = sum_u A[i][(j,u)] 256^u   (88 significant bytes of the 92-byte stream value)
+//   c_v[i] = sum_w C[i][(v,w)] 128^w (five 7-bit digits: non-negative as int8, so only A needs an offset)
+//   G[(j,u)][(v,w)] = sum_i A[i][(j,u)] * C[i][(v,w)]           M = 1471*88, N = 5V, K = rows
+//   out_v[j] = sum_{u,w} G[(j,u)][(v,w)] 2^(8u + 7w)
+//
+// v_mfma_i32_32x32x32_i8 is signed: the keystream bytes are produced as A' = A - 128 (0x80808080 folded into the last AES round key,
+// so the offset costs nothing) and the finish kernel adds 128 * sum_i C[i][n] back.  |A'| <= 128, C <= 127: an int32 accumulator
+// holds 132 104 rows; launches split the rows accordingly.
+//
+// Workgroup = 1024 threads, one column tile of CT = 4 coordinates (352 byte positions = 11 MFMA row tiles) x one row chunk.
+// Per unit of RT = 128 rows: (1) all 16 waves expand the 128 x 368-byte row segments into a row-major LDS tile (23-24 AES blocks
+// per row, the product AES of aes_dev.hpp); (2) waves 0..10 gather their A fragments from the tile (byte position m of 16
+// consecutive rows: the row<->byte transposition every MFMA formulation of this product needs, done on the read side), load the
+// B fragments (coefficient digits, 16 consecutive rows per lane, contiguous in the digit matrix) and issue NT MFMAs per 32 rows,
+// while waves 11..15 compute the next unit's counter-mode span constants.  LDS: 64 KiB table (first, at address 0) + 48 KiB tile
+// + 8 KiB span constants.
+#include <algorithm>
+
+#include "ctx.hpp"
+
+namespace {
+
+using mf::AesKey;
+
+constexpr int CT = 4;             // coordinates per column tile
+constexpr int SB = 88;            // significant bytes per value at logq = 736 (K = 11 limbs)
+constexpr int VB = 92;            // stream bytes per value (CT_BYTES)
+constexpr int MB = CT * SB;       // 352 byte positions per column tile
+constexpr int MT = MB / 32;       // 11 MFMA row tiles
+constexpr int RT = 128;           // rows per unit
+constexpr int TSTRIDE = 384;      // tile row stride: 24 AES blocks
+constexpr int BLK_PER_ROW = 24;
+constexpr int ND = 5;             // 7-bit digits per coefficient
+static_assert(MB % 32 == 0 && CT * VB + 15 <= TSTRIDE, "tile geometry");
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+// digit matrix: Cd[n][i] = digit w of c_v[i] for n = ND v + w (zero for n >= ND V and i >= nrows); rows padded to rpad
+__global__ void k_mm_digits(const uint32_t *__restrict__ coeff, uint32_t nvec, uint32_t nrows, uint32_t rpad, uint32_t ncols,
+                            int8_t *__restrict__ cd) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
+  if (i >= rpad || n >= ncols) return;
+  const uint32_t v = n / ND, w = n % ND;
+  uint32_t d = 0;
+  if (v < nvec && i < nrows) d = (coeff[(uint64_t)v * nrows + i] >> (7 * w)) & 127u;
+  cd[(uint64_t)n * rpad + i] = (int8_t)d;
+}
+// sc[n] = sum_i Cd[n][i]
+__global__ void k_mm_colsum(const int8_t *__restrict__ cd, uint32_t rpad, uint32_t *__restrict__ sc) {
+  __shared__ uint32_t red[256];
+  const uint32_t n = blockIdx.x;
+  uint32_t s = 0;
+  for (uint32_t i = threadIdx.x; i < rpad; i += blockDim.x) s += (uint32_t)cd[(uint64_t)n * rpad + i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) sc[n] = red[0];
+}
+
+struct RowGeom {
+  uint64_t cb0;   // first AES block of the row's segment
+  uint32_t head;  // byte offset of the segment inside that block
+  uint32_t nblk;
+};
+__device__ __forceinline__ RowGeom row_geom(uint64_t off, uint64_t row, uint32_t n, uint32_t j0, uint32_t nks /* keystream-backed coords */) {
+  const uint64_t B0 = off + row * ((uint64_t)n * VB) + (uint64_t)j0 * VB;
+  RowGeom g;
+  g.cb0 = B0 >> 4;
+  g.head = (uint32_t)(B0 & 15);
+  g.nblk = nks ? (g.head + nks * VB + 15) >> 4 : 0;
+  return g;
+}
+
+// grid = (column tiles, row chunks); NT = 32-column tiles of the digit matrix (N = 32 NT)
+template <int NT>
+__global__ __launch_bounds__(1024) void k_evalmm(AesKey key /* rk[56..59] ^ 0x80808080 */, const uint32_t *__restrict__ g_t0, uint64_t off,
+                                                 uint32_t n, uint32_t nrows, uint32_t rows_per_chunk, const uint8_t *__restrict__ c8,
+                                                 const int8_t *__restrict__ cd, uint32_t rpad, int *__restrict__ part) {
+  struct __attribute__((aligned(16))) Lds {
+    uint32_t lt[mf::kTabBytes / 4];      // first: LDS address 0 (aes_dev.hpp)
+    uint8_t tile[RT * TSTRIDE];
+    uint32_t spanc[RT][2][8];            // per row: the rounds-1-2 constants of the (at most two) 256-counter spans its segment touches
+  };
+  __shared__ Lds lds;
+  mf::lds_fill_tab(lds.lt, g_t0);
+  const uint8_t *tab = reinterpret_cast<const uint8_t *>(lds.lt);
+  const mf::AesLane L = mf::aes_lane();
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t j0 = blockIdx.x * CT;
+  const uint32_t nks = j0 >= n ? 0u : min((uint32_t)CT, n - j0);  // keystream-backed coordinates of this tile (the last tile also holds b)
+  const bool has_b = j0 + CT > n && j0 <= n;                      // coordinate n = the row's b, read from the compressed CRS
+  const uint32_t r0 = blockIdx.y * rows_per_chunk;
+  const uint32_t r1 = min(nrows, r0 + rows_per_chunk);
+
+  v16i acc[NT];
+#pragma unroll
+  for (int q = 0; q < NT; q++)
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[q][e] = 0;
+
+  // per-lane column of this wave's MFMA row tile inside a row segment (without the row's head offset)
+  const uint32_t r32 = lane & 31, h = lane >> 5;
+  const uint32_t m = wave * 32 + r32;            // byte position, < MB for waves < MT
+  const uint32_t mcol = (m / SB) * VB + (m % SB);
+
+  auto span_task = [&](uint32_t u0, uint32_t task) {  // task = 2 * local row + which span
+    const uint32_t lr = task >> 1, which = task & 1;
+    const uint64_t row = (uint64_t)u0 + lr;
+    if (row >= r1 || !nks) return;
+    const RowGeom g = row_geom(off, row, n, j0, nks);
+    const uint64_t sp0 = g.cb0 >> 8, sp1 = (g.cb0 + g.nblk - 1) >> 8;
+    if (which && sp1 == sp0) return;
+    uint32_t sc[5];
+    mf::aes_span_consts(tab, L, key, sp0 + which, sc);
+#pragma unroll
+    for (int i = 0; i < 5; i++) lds.spanc[lr][which][i] = sc[i];
+  };
+
+  __syncthreads();
+  if (tid < 2 * RT) span_task(r0, tid);
+  __syncthreads();
+  for (uint32_t u0 = r0; u0 < r1; u0 += RT) {
+    // ---- (1) expansion: block slot s -> (local row s / 24, block s % 24)
+    for (uint32_t s = tid; s < RT * BLK_PER_ROW; s += 1024) {
+      const uint32_t lr = s / BLK_PER_ROW, k = s % BLK_PER_ROW;
+      const uint64_t row = (uint64_t)u0 + lr;
+      if (row >= r1) continue;
+      const RowGeom g = row_geom(off, row, n, j0, nks);
+      if (k >= g.nblk) continue;
+      const uint64_t ctr = g.cb0 + k;
+      const uint32_t *scp = lds.spanc[lr][(uint32_t)((ctr >> 8) - (g.cb0 >> 8))];
+      uint32_t sc[5] = {scp[0], scp[1], scp[2], scp[3], scp[4]};
+      uint32_t w[4];
+      mf::aes256_ctr_block_sc(tab, L, key, ctr, sc, w);
+      *reinterpret_cast<uint4 *>(&lds.tile[lr * TSTRIDE + 16 * k]) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    __syncthreads();
+    if (has_b) {  // b of each row: CT_BYTES from the compressed CRS, offset by 128 like the keystream, behind the keystream coordinates
+      for (uint32_t s = tid; s < RT * VB; s += 1024) {
+        const uint32_t lr = s / VB, k = s % VB;
+        const uint64_t row = (uint64_t)u0 + lr;
+        if (row >= r1) continue;
+        const RowGeom g = row_geom(off, row, n, j0, nks);
+        lds.tile[lr * TSTRIDE + g.head + nks * VB + k] = (uint8_t)(c8[row * VB + k] ^ 0x80);
+      }
+      __syncthreads();
+    }
+    // ---- (2) waves 0..MT-1: MFMA over the unit's rows; waves MT..15: span constants of the next unit
+    if (wave < MT) {
+      const uint32_t head0 = row_geom(off, u0, n, j0, 1).head, hstep = (n * VB) & 15;  // head of local row lr = (head0 + hstep lr) & 15
+#pragma unroll
+      for (int ks = 0; ks < RT / 32; ks++) {
+        const uint32_t lrb = ks * 32 + 16 * h;
+        if ((uint64_t)u0 + ks * 32 >= r1) break;  // whole k-step beyond the chunk (wave-uniform)
+        union { v4i v; uint8_t b[16]; } a;
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+          const uint32_t lr = lrb + e;
+          const uint8_t x = lds.tile[lr * TSTRIDE + ((head0 + hstep * lr) & 15) + mcol];
+          a.b[e] = ((uint64_t)u0 + lr < r1) ? x : (uint8_t)0;  // rows beyond the chunk hold stale bytes: their digits are zero, keep A finite anyway
+        }
+        const int8_t *bp = cd + (uint64_t)r32 * rpad + u0 + lrb;
+#pragma unroll
+        for (int q = 0; q < NT; q++) {
+          const v4i b = *reinterpret_cast<const v4i *>(bp + (uint64_t)(32 * q) * rpad);
+          acc[q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a.v, b, acc[q], 0, 0, 0);
+        }
+      }
+    } else {
+      const uint32_t t2 = tid - MT * 64;  // 0..319 >= 2 RT
+      if (t2 < 2 * RT) span_task(u0 + RT, t2);
+    }
+    __syncthreads();
+  }
+  // ---- partial G of this workgroup: part[((chunk * ntiles + tile) * MB + m) * N + n]
+  if (wave < MT) {
+    const uint32_t N = 32 * NT;
+    int *p = part + ((uint64_t)blockIdx.y * gridDim.x + blockIdx.x) * MB * N;
+#pragma unroll
+    for (int q = 0; q < NT; q++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        const uint32_t mm = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        p[(uint64_t)mm * N + 32 * q + r32] = acc[q][e];
+      }
+  }
+}
+
+// out_v[j] = sum_{u,w} (sum_chunks G'[(j,u)][(v,w)] + 128 sc[(v,w)]) 2^(8u + 7w)  mod 2^704; thread = (vector v fastest, coordinate j)
+__global__ void k_evalmm_finish(const int *__restrict__ part, const uint32_t *__restrict__ sc, uint32_t nchunks, uint32_t ntiles, uint32_t N,
+                                uint32_t nvec, uint32_t n, uint64_t *__restrict__ rops /* [nvec][(n+1) * 12] */, int accumulate) {
+  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t v = gid % nvec, j = gid / nvec;
+  if (j > n) return;
+  const uint32_t tile = j / CT, jj = j % CT;
+  uint32_t *out = reinterpret_cast<uint32_t *>(rops + ((uint64_t)v * (n + 1) + j) * 12);
+  uint64_t corr[ND];
+#pragma unroll
+  for (int w = 0; w < ND; w++) corr[w] = 128ull * sc[ND * v + w];
+  // running sum in 32-bit words: lo64 holds bits [32 l, 32 l + 64) of the partial result, hi its overflow
+  unsigned __int128 run = 0;
+  for (int l = 0; l < 22; l++) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t u = 4 * l + k;
+      const uint32_t mm = jj * SB + u;
+      uint64_t t = 0;
+#pragma unroll
+      for (int w = 0; w < ND; w++) {
+        int64_t g = 0;
+        for (uint32_t ch = 0; ch < nchunks; ch++) g += part[(((uint64_t)ch * ntiles + tile) * MB + mm) * N + ND * v + w];
+        t += (uint64_t)(g + (int64_t)corr[w]) << (7 * w);  // g + corr >= 0: it is the true (unsigned) digit product sum
+      }
+      run += (unsigned __int128)t << (8 * k);
+    }
+    uint64_t word = (uint64_t)run & 0xffffffffu;
+    if (accumulate) {
+      word += out[l];
+      run += (unsigned __int128)(word >> 32) << 32;  // carry of the accumulate into the next word
+      word &= 0xffffffffu;
+    }
+    out[l] = (uint32_t)word;
+    run >>= 32;
+  }
+  out[22] = 0;  // modq: limbs >= K dropped (src/lwe.h:107-118)
+  out[23] = 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mfh_eval_rows_multi(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d_c8, const uint32_t *d_coeffs, uint32_t nvec, uint64_t *d_rops,
+                        int accumulate) {
+  if (!c || !d_rops || !nvec || (nrows && (!d_c8 || !d_coeffs))) return MFH_EINVAL;
+  if (!c->have_seed) { c->err = "mfh_set_seed has not been called"; return MFH_EINVAL; }
+  if (c->P.logq != 736) { c->err = "mfh_eval_rows_multi: only logq = 736 has a matrix-core path"; return MFH_EUNSUPPORTED; }
+  if (nvec > 25) { c->err = "mfh_eval_rows_multi: at most 25 coefficient vectors per call (128 digit columns)"; return MFH_EINVAL; }
+  if (nrows > 0xffffffffu - 256) return MFH_EINVAL;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint32_t n = c->P.n;
+  const size_t ctl = (size_t)(n + 1) * 12;
+  if (nrows == 0) {
+    if (!accumulate) HIP_TRY(c, hipMemsetAsync(d_rops, 0, (size_t)nvec * ctl * 8, c->stream));
+    return MFH_OK;
+  }
+  const uint32_t NT = nvec * ND <= 64 ? 2 : 4, N = 32 * NT;
+  const uint32_t ntiles = (n + 1 + CT - 1) / CT;
+  // row chunks: fill the CUs about three times over; an int32 accumulator holds 132 104 rows
+  // row chunks: 368 column tiles x 2 chunks = 736 workgroups = 2.9 rounds of the 256 CUs (one workgroup per CU at a time); an int32
+  // accumulator holds 132 104 rows
+  uint32_t nchunks = nrows >= 8 * RT ? 2 : 1;
+  nchunks = std::max<uint32_t>(nchunks, ((uint32_t)nrows + 131071) / 131072);
+  uint32_t rpc = ((uint32_t)nrows + nchunks - 1) / nchunks;
+  rpc = (rpc + RT - 1) / RT * RT;
+  nchunks = ((uint32_t)nrows + rpc - 1) / rpc;
+  const uint32_t rpad = nchunks * rpc + RT;  // digit rows past nrows are zero; + RT: the last k-step's 16-byte loads stay inside
+  const size_t cd_bytes = ((size_t)N * rpad + 255) & ~(size_t)255;
+  const size_t sc_bytes = 256 * 4;
+  const size_t part_bytes = (size_t)nchunks * ntiles * MB * N * 4;
+  int rc = ws_reserve(c, cd_bytes + sc_bytes + part_bytes);
+  if (rc) return rc;
+  int8_t *cd = (int8_t *)c->ws;
+  uint32_t *sc = (uint32_t *)((uint8_t *)c->ws + cd_bytes);
+  int *part = (int *)((uint8_t *)c->ws + cd_bytes + sc_bytes);
+  hipLaunchKernelGGL(k_mm_digits, dim3((rpad + 255) / 256, N), dim3(256), 0, c->stream, d_coeffs, nvec, (uint32_t)nrows, rpad, N, cd);
+  hipLaunchKernelGGL(k_mm_colsum, dim3(N), dim3(256), 0, c->stream, cd, rpad, sc);
+  AesKey keyx = c->key;
+  for (int i = 56; i < 60; i++) keyx.rk[i] ^= 0x80808080u;  // the kernel's keystream bytes come out as A - 128
+  {
+    Timer t(c, 7, nrows);
+    if (NT == 2)
+      hipLaunchKernelGGL(k_evalmm<2>, dim3(ntiles, nchunks), dim3(1024), 0, c->stream, keyx, c->d_t0, off, n, (uint32_t)nrows, rpc, d_c8, cd, rpad,
+                         part);
+    else
+      hipLaunchKernelGGL(k_evalmm<4>, dim3(ntiles, nchunks), dim3(1024), 0, c->stream, keyx, c->d_t0, off, n, (uint32_t)nrows, rpc, d_c8, cd, rpad,
+                         part);
+  }
+  HIP_TRY(c, hipGetLastError());
+  const uint32_t total = (n + 1) * nvec;
+  hipLaunchKernelGGL(k_evalmm_finish, dim3((total + 127) / 128), dim3(128), 0, c->stream, part, sc, nchunks, ntiles, N, nvec, n, d_rops, accumulate);
+  HIP_TRY(c, hipGetLastError());
+  return MFH_OK;
+}
+
+}  // extern "C"

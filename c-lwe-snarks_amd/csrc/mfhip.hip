@@ -944,6 +944,7 @@ static int timing_kind(const char *which) {
   if (!strcmp(which, "expand")) return 4;
   if (!strcmp(which, "mac1")) return 5;
   if (!strcmp(which, "mac2")) return 6;
+  if (!strcmp(which, "evalmm")) return 7;
   return -1;
 }
 

@@ -205,10 +205,18 @@ int mfh_ct_from_lanes(mfh_ctx *ctx, const uint64_t *d_lanes, size_t count, uint6
 const char *mfh_version(void);
 /* size in bytes the context's scratch currently occupies on the device */
 size_t mfh_workspace_bytes(const mfh_ctx *ctx);
+/* eval_poly (src/lwe.c:160-178) for MANY coefficient vectors over the same nrows CRS rows -- the S / AS / BV regions of a batch of
+ * proofs under one CRS: the rows are expanded once and the multiply-accumulate runs on the matrix cores (i8 MFMA over 8-bit
+ * keystream digits x 7-bit coefficient digits; exact integer arithmetic, same result as nvec calls of mfh_eval_rows).
+ * d_coeffs = nvec vectors of nrows uint32 (< 2^32), vector-major; d_rops = nvec ciphertexts, vector-major; nvec <= 25.
+ * logq = 736 only (MFH_EUNSUPPORTED otherwise). */
+int mfh_eval_rows_multi(mfh_ctx *ctx, uint64_t off, size_t nrows, const uint8_t *d_c8, const uint32_t *d_coeffs, uint32_t nvec,
+                        uint64_t *d_rops, int accumulate);
+
 /* Kernel timing for the roofline leg of bench.py.  With timing enabled every launch of a hot kernel is bracketed by
  * HIP events on the context's stream (no synchronisation is added).  mfh_timing_drain waits for the stream, then
  * reports and forgets the launches of kind `which`: "eval2" / "eval1" (k_eval with 2 / 1 coefficient vectors),
- * "eval" (both), "encrypt", "keystream", "expand", "mac2" / "mac1" (resident MAC).  total_rows = rows handed to those launches (AES blocks for "keystream"). */
+ * "eval" (both), "encrypt", "keystream", "expand", "mac2" / "mac1" (resident MAC), "evalmm" (mfh_eval_rows_multi).  total_rows = rows handed to those launches (AES blocks for "keystream"). */
 int mfh_set_timing(mfh_ctx *ctx, int enabled);
 /* prover scheduling: mfh_prove* run the witness pass + polynomial step on an internal stream beside the evaluation of
  * b_w's rows and join before the S / AS regions; results are identical in every mode.  0 = one stream, 1 (default) = two
