@@ -71,6 +71,8 @@ struct mfh_ctx {
   uint32_t *d_prover = nullptr;  // prover polynomials w, v, h and the b_w coefficient vector
   size_t prover_words = 0;
   std::vector<uint32_t> h_cw;
+  void *d_batch = nullptr;  // mfh_prove_batch group scratch: W | H | V | CW | OUT
+  size_t batch_bytes = 0;
   PinBuf pin_rows, pin_cw, pin_smudge;
   // generator-defined SSP (ssp_prg.hpp): used by every entry point that is handed d_ssp == NULL
   bool prg_on = false;

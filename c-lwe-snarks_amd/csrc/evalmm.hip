@@ -43,22 +43,26 @@ static_assert(MB % 32 == 0 && CT * VB + 15 <= TSTRIDE, "tile geometry");
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
-// digit matrix: Cd[n][i] = digit w of c_v[i] for n = ND v + w (zero for n >= ND V and i >= nrows); rows padded to rpad
-__global__ void k_mm_digits(const uint32_t *__restrict__ coeff, uint32_t nvec, uint32_t nrows, uint32_t rpad, uint32_t ncols,
+// Digit matrix in MFMA B-fragment order: for k-step K = i / 32 (32 rows), column tile q and lane (r = n & 31, h): 16 bytes = digit
+// n = 32 q + r of rows 32 K + 16 h + e, e = 0..15, at cd[((K * NT + q) * 64 + 32 h + r) * 16 + e].  A unit's (RT rows) fragments are one
+// contiguous RT * N bytes.  Digit w of c_v[i] sits in column n = ND v + w; columns >= ND nvec and rows >= nrows are zero.
+__global__ void k_mm_digits(const uint32_t *__restrict__ coeff, uint32_t nvec, uint32_t nrows, uint32_t rpad, uint32_t NT,
                             int8_t *__restrict__ cd) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
-  if (i >= rpad || n >= ncols) return;
+  if (i >= rpad) return;
   const uint32_t v = n / ND, w = n % ND;
   uint32_t d = 0;
   if (v < nvec && i < nrows) d = (coeff[(uint64_t)v * nrows + i] >> (7 * w)) & 127u;
-  cd[(uint64_t)n * rpad + i] = (int8_t)d;
+  const uint32_t K = i >> 5, h = (i >> 4) & 1, e = i & 15, q = n >> 5, r = n & 31;
+  cd[((((uint64_t)K * NT + q) * 64 + 32 * h + r) << 4) + e] = (int8_t)d;
 }
-// sc[n] = sum_i Cd[n][i]
-__global__ void k_mm_colsum(const int8_t *__restrict__ cd, uint32_t rpad, uint32_t *__restrict__ sc) {
+// sc[n] = sum_i (digit n of row i), from the coefficient vectors
+__global__ void k_mm_colsum(const uint32_t *__restrict__ coeff, uint32_t nvec, uint32_t nrows, uint32_t *__restrict__ sc) {
   __shared__ uint32_t red[256];
-  const uint32_t n = blockIdx.x;
+  const uint32_t n = blockIdx.x, v = n / ND, w = n % ND;
   uint32_t s = 0;
-  for (uint32_t i = threadIdx.x; i < rpad; i += blockDim.x) s += (uint32_t)cd[(uint64_t)n * rpad + i];
+  if (v < nvec)
+    for (uint32_t i = threadIdx.x; i < nrows; i += blockDim.x) s += (coeff[(uint64_t)v * nrows + i] >> (7 * w)) & 127u;
   red[threadIdx.x] = s;
   __syncthreads();
   for (int o = 128; o; o >>= 1) {
@@ -91,6 +95,7 @@ __global__ __launch_bounds__(1024) void k_evalmm(AesKey key /* rk[56..59] ^ 0x80
     uint32_t lt[mf::kTabBytes / 4];      // first: LDS address 0 (aes_dev.hpp)
     uint8_t tile[RT * TSTRIDE];
     uint32_t spanc[RT][2][8];            // per row: the rounds-1-2 constants of the (at most two) 256-counter spans its segment touches
+    v4i bfrag[RT / 32][NT][64];          // the unit's coefficient-digit fragments, in the order the MFMA lanes read them
   };
   __shared__ Lds lds;
   mf::lds_fill_tab(lds.lt, g_t0);
@@ -131,6 +136,10 @@ __global__ __launch_bounds__(1024) void k_evalmm(AesKey key /* rk[56..59] ^ 0x80
   if (tid < 2 * RT) span_task(r0, tid);
   __syncthreads();
   for (uint32_t u0 = r0; u0 < r1; u0 += RT) {
+    // the unit's digit fragments: RT * N contiguous bytes, one 16-byte load per thread, in flight under the expansion
+    v4i bstage = {0, 0, 0, 0};
+    const bool bload = tid < (RT / 32) * NT * 64;
+    if (bload) bstage = *reinterpret_cast<const v4i *>(cd + ((uint64_t)(u0 >> 5) * NT * 64 + tid) * 16);
     // ---- (1) expansion: block slot s -> (local row s / 24, block s % 24)
     for (uint32_t s = tid; s < RT * BLK_PER_ROW; s += 1024) {
       const uint32_t lr = s / BLK_PER_ROW, k = s % BLK_PER_ROW;
@@ -145,6 +154,7 @@ __global__ __launch_bounds__(1024) void k_evalmm(AesKey key /* rk[56..59] ^ 0x80
       mf::aes256_ctr_block_sc(tab, L, key, ctr, sc, w);
       *reinterpret_cast<uint4 *>(&lds.tile[lr * TSTRIDE + 16 * k]) = make_uint4(w[0], w[1], w[2], w[3]);
     }
+    if (bload) (&lds.bfrag[0][0][0])[tid] = bstage;
     __syncthreads();
     if (has_b) {  // b of each row: CT_BYTES from the compressed CRS, offset by 128 like the keystream, behind the keystream coordinates
       for (uint32_t s = tid; s < RT * VB; s += 1024) {
@@ -157,27 +167,32 @@ __global__ __launch_bounds__(1024) void k_evalmm(AesKey key /* rk[56..59] ^ 0x80
       __syncthreads();
     }
     // ---- (2) waves 0..MT-1: MFMA over the unit's rows; waves MT..15: span constants of the next unit
+#ifndef MM_SKIP_MFMA
     if (wave < MT) {
       const uint32_t head0 = row_geom(off, u0, n, j0, 1).head, hstep = (n * VB) & 15;  // head of local row lr = (head0 + hstep lr) & 15
-#pragma unroll
+#pragma unroll 1
       for (int ks = 0; ks < RT / 32; ks++) {
-        const uint32_t lrb = ks * 32 + 16 * h;
         if ((uint64_t)u0 + ks * 32 >= r1) break;  // whole k-step beyond the chunk (wave-uniform)
-        union { v4i v; uint8_t b[16]; } a;
+        const uint32_t lrb = ks * 32 + 16 * h;
+        // A fragment: byte position m of 16 consecutive rows.  Rows at or beyond nrows hold stale bytes; their digits are zero.
+        uint32_t aw[4];
 #pragma unroll
-        for (int e = 0; e < 16; e++) {
-          const uint32_t lr = lrb + e;
-          const uint8_t x = lds.tile[lr * TSTRIDE + ((head0 + hstep * lr) & 15) + mcol];
-          a.b[e] = ((uint64_t)u0 + lr < r1) ? x : (uint8_t)0;  // rows beyond the chunk hold stale bytes: their digits are zero, keep A finite anyway
-        }
-        const int8_t *bp = cd + (uint64_t)r32 * rpad + u0 + lrb;
+        for (int e4 = 0; e4 < 4; e4++) {
+          uint32_t x = 0;
 #pragma unroll
-        for (int q = 0; q < NT; q++) {
-          const v4i b = *reinterpret_cast<const v4i *>(bp + (uint64_t)(32 * q) * rpad);
-          acc[q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a.v, b, acc[q], 0, 0, 0);
+          for (int e = 0; e < 4; e++) {
+            const uint32_t lr = lrb + 4 * e4 + e;
+            x |= (uint32_t)lds.tile[lr * TSTRIDE + ((head0 + hstep * lr) & 15) + mcol] << (8 * e);
+          }
+          aw[e4] = x;
         }
+        const v4i a = {(int)aw[0], (int)aw[1], (int)aw[2], (int)aw[3]};
+#pragma unroll
+        for (int q = 0; q < NT; q++) acc[q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, lds.bfrag[ks][q][lane], acc[q], 0, 0, 0);
       }
-    } else {
+    } else
+#endif
+    if (wave >= MT) {
       const uint32_t t2 = tid - MT * 64;  // 0..319 >= 2 RT
       if (t2 < 2 * RT) span_task(u0 + RT, t2);
     }
@@ -265,7 +280,7 @@ int mfh_eval_rows_multi(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d
   uint32_t rpc = ((uint32_t)nrows + nchunks - 1) / nchunks;
   rpc = (rpc + RT - 1) / RT * RT;
   nchunks = ((uint32_t)nrows + rpc - 1) / rpc;
-  const uint32_t rpad = nchunks * rpc + RT;  // digit rows past nrows are zero; + RT: the last k-step's 16-byte loads stay inside
+  const uint32_t rpad = nchunks * rpc;  // a multiple of RT: digit rows past nrows are zero
   const size_t cd_bytes = ((size_t)N * rpad + 255) & ~(size_t)255;
   const size_t sc_bytes = 256 * 4;
   const size_t part_bytes = (size_t)nchunks * ntiles * MB * N * 4;
@@ -274,8 +289,8 @@ int mfh_eval_rows_multi(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d
   int8_t *cd = (int8_t *)c->ws;
   uint32_t *sc = (uint32_t *)((uint8_t *)c->ws + cd_bytes);
   int *part = (int *)((uint8_t *)c->ws + cd_bytes + sc_bytes);
-  hipLaunchKernelGGL(k_mm_digits, dim3((rpad + 255) / 256, N), dim3(256), 0, c->stream, d_coeffs, nvec, (uint32_t)nrows, rpad, N, cd);
-  hipLaunchKernelGGL(k_mm_colsum, dim3(N), dim3(256), 0, c->stream, cd, rpad, sc);
+  hipLaunchKernelGGL(k_mm_digits, dim3((rpad + 255) / 256, N), dim3(256), 0, c->stream, d_coeffs, nvec, (uint32_t)nrows, rpad, NT, cd);
+  hipLaunchKernelGGL(k_mm_colsum, dim3(N), dim3(256), 0, c->stream, d_coeffs, nvec, (uint32_t)nrows, sc);
   AesKey keyx = c->key;
   for (int i = 56; i < 60; i++) keyx.rk[i] ^= 0x80808080u;  // the kernel's keystream bytes come out as A - 128
   {

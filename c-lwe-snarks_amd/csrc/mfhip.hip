@@ -902,6 +902,7 @@ void mfh_ctx_destroy(mfh_ctx *c) {
   if (c->side) hipStreamDestroy(c->side);
   if (c->d_msg) hipFree(c->d_msg);
   if (c->d_prover) hipFree(c->d_prover);
+  if (c->d_batch) hipFree(c->d_batch);
   if (c->d_t0) hipFree(c->d_t0);
   for (auto &t : c->timed) { hipEventDestroy(t.e0); hipEventDestroy(t.e1); }
   for (auto e : c->ev_pool) hipEventDestroy(e);

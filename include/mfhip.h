@@ -182,6 +182,14 @@ int mfh_prove(mfh_ctx *ctx, const uint8_t *d_crs_c8, const uint32_t *d_ssp, cons
 int mfh_verify(mfh_ctx *ctx, const uint32_t *d_ssp, uint32_t alpha, uint32_t beta, uint32_t s, const uint64_t *d_sk,
                const uint64_t *d_proofs, size_t count, uint8_t *d_ok);
 
+/* prover() for nproofs statements under ONE CRS and SSP.  Each CRS region is expanded once per group of up to 12 proofs and the
+ * multiply-accumulate of the group's coefficient vectors runs on the matrix cores (mfh_eval_rows_multi); proof b is bit-identical to
+ * mfh_prove(witness b, delta b, smudging b).  h_witness_bits: nproofs bit strings, bits_stride bytes apart; h_delta: nproofs values
+ * < p; h_smudge_mag: nproofs x 5 x maglen bytes; h_smudge_sign: nproofs x 5 bytes; d_proofs: nproofs x 5 ciphertexts.
+ * Regenerates the keystream (no resident CRS image may be set); logq = 736 only. */
+int mfh_prove_batch(mfh_ctx *ctx, const uint8_t *d_crs_c8, const uint32_t *d_ssp, uint32_t nproofs, const uint8_t *h_witness_bits,
+                    size_t bits_stride, const uint32_t *h_delta, const uint8_t *h_smudge_mag, size_t maglen, const uint8_t *h_smudge_sign,
+                    uint64_t *d_proofs);
 /* ---- multi-GPU: row-sharded prover -------------------------------------------------------------
  * Every proof element is sum_i coeff_i * row_i and the public stream is seekable, so the CRS rows of each region are
  * split into `world` contiguous shares.  mfh_prove_partial computes rank `rank`'s share of the five (un-smudged)

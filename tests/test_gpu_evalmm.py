@@ -73,3 +73,44 @@ def test_multi_argument_checks(ctx):
         ctx.eval_rows_multi(0, 4, ctx.zeros(4 * p.ctb), ctx.zeros(26 * 4 * 4), 26)
     out = ctx.eval_rows_multi(0, 0, ctx.zeros(16), ctx.zeros(16), 2)  # no rows: zero ciphertexts
     assert not ctx.to_host(out).any()
+
+
+@pytest.mark.parametrize("nproofs", [1, 5, 13])
+def test_prove_batch_equals_single_proofs(gpu_ctx_factory, oracle, nproofs):
+    """mfh_prove_batch: proof b of the batch == mfh_prove(statement b), bit for bit (groups of 12: 13 = one full + one partial
+    group); the first proof is also checked against the oracle's prover and every proof is accepted by the device verifier."""
+    import c_lwe_snarks_amd as mf
+
+    p = mf.DEBUG
+    c = gpu_ctx_factory(p)
+    c.set_seed(SEED)
+    rng = np.random.default_rng(4242)
+    nbytes = (p.m + 7) // 8
+    wits = [rng.integers(0, 256, size=nbytes, dtype=np.uint8).tobytes() for _ in range(nproofs)]
+    tape = rng.integers(0, 256, size=p.m * 8 * p.d, dtype=np.uint8)
+    # one SSP must be satisfied by every witness of the batch: random_ssp builds it around ONE witness, so use the same satisfying
+    # witness with different deltas / smudging for the accepted proofs, and flipped witnesses for the rest (those must be rejected)
+    ssp = oracle.ssp_from_tape(p, tape, wits[0])
+    alpha, beta, s = (int(x) for x in rng.integers(1, ol.P, size=3, dtype=np.uint64))
+    sk = ol.rand_values(rng, p.n, p.L, p.logq)
+    etape = ol.rand_values(rng, 2 * p.d + p.m, p.L, 559)
+    crs = oracle.setup(p, SEED, ssp, alpha, beta, s, sk, etape)
+    d_ssp = c.ssp_upload(ssp)
+    c.ssp_prepare(d_ssp)
+    d_crs = c.to_device(np.concatenate([crs["s"], crs["as_"], crs["t"], crs["v"][: (p.m - 1) * p.ctb]]))
+    valid = [b % 3 != 2 for b in range(nproofs)]
+    stmts = [wits[0] if valid[b] else wits[b] for b in range(nproofs)]
+    if nproofs > 2:
+        assert stmts[2] != wits[0]
+    deltas = [int(x) for x in rng.integers(0, ol.P, size=nproofs, dtype=np.uint64)]
+    mags = [rng.integers(0, 256, size=400, dtype=np.uint8).tobytes() for _ in range(nproofs)]
+    signs = [bytes(rng.integers(0, 2, size=5, dtype=np.uint8).tolist()) for _ in range(nproofs)]
+    got = c.to_host(c.prove_batch(d_crs, d_ssp, stmts, deltas, mags, signs), np.uint64).reshape(nproofs, 5, p.n + 1, p.L).copy()
+    for b in range(nproofs):
+        one = c.to_host(c.prove(d_crs, d_ssp, stmts[b], deltas[b], mags[b], signs[b]), np.uint64).reshape(5, p.n + 1, p.L)
+        assert np.array_equal(got[b], one), f"proof {b} of the batch differs from the single-proof path"
+    stape = b"".join(mags[0][80 * k: 80 * k + 80] + signs[0][k: k + 1] for k in range(5))
+    ref = oracle.prover(p, crs, ssp, stmts[0], deltas[0], stape, 80)
+    assert np.array_equal(got[0], np.stack(ref["proof"]))
+    ok = c.to_host(c.verify(d_ssp, alpha, beta, s, c.to_device(sk), c.to_device(got), nproofs))
+    assert [bool(x) for x in ok] == valid
