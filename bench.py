@@ -119,6 +119,11 @@ def main():
     ap.add_argument("--sharding", choices=["rows", "proofs"], default="rows",
                     help="N > 1: 'rows' = every proof is computed cooperatively, CRS rows sharded over the ranks + all-reduce (strong scaling, "
                          "default); 'proofs' = every rank proves its own statements, no collective (weak scaling)")
+    ap.add_argument("--mode", choices=["batch", "single"], default=None,
+                    help="batch (default at the default workload): a step = --batch statements per GPU proved by mfh_prove_batch (CRS regions "
+                         "expanded once per group of 12, MAC on the matrix cores), ranks take disjoint statements, no collective; "
+                         "single: a step = one prover() call, CRS rows sharded over the ranks + lane all-reduces")
+    ap.add_argument("--batch", type=int, default=48, help="statements per GPU per step in batch mode")
     ap.add_argument("--no-overlap", action="store_true", help="run the prover on one stream (A/B check of the side-stream overlap)")
     ap.add_argument("--resident-gb", type=float, default=200.0, help="HBM budget for the resident CRS image per GPU")
     ap.add_argument("--workload", choices=["default", "config4", "config5"], default="default",
@@ -156,6 +161,11 @@ def main():
 
     big = args.workload != "default"
     p = mf.DEFAULT if not big else mf.Params(logq=736 if args.workload == "config4" else 1472, d=1 << 20, m=699050)
+    mode = args.mode or ("batch" if not big else "single")
+    if mode == "batch" and p.logq != 736:
+        raise SystemExit("--mode batch needs logq = 736 (the matrix-core path)")
+    run_single = mode == "single" or world == 1  # the single-proof path is always reported on one GPU
+    single_steps = args.steps if mode == "single" else min(args.steps, 10)
     ctx = mf.Context(p, local_rank)
     if args.no_overlap:
         ctx.set_overlap(False)
@@ -199,35 +209,41 @@ def main():
     def step():
         return mfdist.prove_sharded(ctx, d_crs, inst["d_ssp"], inst["bits"], delta, mags, signs, eff_rank, eff_world, bufs=bufs)
 
-    for _ in range(args.warmup):
-        proof = step()
-    ctx.set_timing(True)
-    ctx.timing_drain("eval")
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        proof = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    ctx.set_timing(False)
-    n2, ms2, rows2 = ctx.timing_drain("eval2")
-    n1, ms1, rows1 = ctx.timing_drain("eval1")
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=ctx.device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    proof = None
+    elapsed = float("nan")
+    n2 = n1 = rows2 = rows1 = 0
+    ms2 = ms1 = 0.0
+    accepted = True
+    if run_single:
+        for _ in range(args.warmup):
+            proof = step()
+        ctx.set_timing(True)
+        ctx.timing_drain("eval")
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(single_steps):
+            proof = step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        ctx.set_timing(False)
+        n2, ms2, rows2 = ctx.timing_drain("eval2")
+        n1, ms1, rows1 = ctx.timing_drain("eval1")
+        if dist is not None:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=ctx.device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
 
-    if rank != 0:
-        accepted = True
-    elif big:
-        accepted = bool(int(ctx.to_host(ctx.verify(None, inst["alpha"], inst["beta"], inst["s"], inst["sk"], proof, 1))[0]))
-    else:
-        accepted = verify_on_gpu(mf, ctx, inst, proof) and bool(
-            int(ctx.to_host(ctx.verify(inst["d_ssp"], inst["alpha"], inst["beta"], inst["s"], inst["sk"], proof, 1))[0]))
+        if rank != 0:
+            accepted = True
+        elif big:
+            accepted = bool(int(ctx.to_host(ctx.verify(None, inst["alpha"], inst["beta"], inst["s"], inst["sk"], proof, 1))[0]))
+        else:
+            accepted = verify_on_gpu(mf, ctx, inst, proof) and bool(
+                int(ctx.to_host(ctx.verify(inst["d_ssp"], inst["alpha"], inst["beta"], inst["s"], inst["sk"], proof, 1))[0]))
 
     # ---- second regime: the expanded CRS resident in HBM (11.3 GB), streamed at HBM speed
     resident = None
-    if not args.no_resident:
+    if not args.no_resident and run_single:
         share_rows = int(ctx.lib.mfh_resident_share_rows(ctx._h, eff_rank, eff_world))
         budget_rows = int(args.resident_gb * 1e9) // ctx.resident_row_bytes()
         partial_res = eff_world == 1 and share_rows > budget_rows  # single GPU and the image does not fit: keep a prefix resident
@@ -253,7 +269,7 @@ def main():
         ctx.timing_drain("mac1")
         barrier()
         t1 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(single_steps):
             proof_r = step()
         barrier()
         el_r = time.perf_counter() - t1
@@ -276,7 +292,7 @@ def main():
                 traffic_r = None
         avg = m2ms / max(m2n, 1)
         lr = m2rows / max(m2n, 1)
-        resident = {"value": args.steps / el_r * (1 if by_rows else world), "unit": "proofs/s", "ms_per_step": el_r / args.steps * 1e3, "proof_identical_to_regenerated": same,
+        resident = {"value": single_steps / el_r * (1 if by_rows else world), "unit": "proofs/s", "ms_per_step": el_r / single_steps * 1e3, "proof_identical_to_regenerated": same,
                     "crs_expand_s": expand_s, "image_bytes_per_rank": share_rows * rb, "resident_rows": share_rows, "partially_resident": partial_res,
                     "roofline": {"bound": "hbm", "kernel": f"k_mac_resident<{p.logq},2> (streaming 2x MAC over the expanded S / AS rows)",
                                  "achieved": lr * (p.n + 1) * p.ctb / (avg * 1e-3) / 1e9 if m2n else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -285,6 +301,67 @@ def main():
                                  "launches": m2n, "avg_launch_ms": avg, "rows_per_launch": lr},
                     "mac1": {"launches": m1n, "avg_launch_ms": m1ms / max(m1n, 1), "rows_per_launch": m1rows / max(m1n, 1)}}
         del image
+
+    # ---- batch mode: --batch statements per GPU per step through mfh_prove_batch (disjoint statements per rank, no collective)
+    batched = None
+    if mode == "batch":
+        nb = args.batch
+        brng = np.random.default_rng(1000 + rank)  # every rank proves its own statements: same witness, its own deltas and smudging
+        b_delta = [int(x) for x in brng.integers(0, mf.P, size=nb, dtype=np.uint64)]
+        b_mags = [brng.integers(0, 256, size=5 * 80, dtype=np.uint8).tobytes() for _ in range(nb)]
+        b_signs = [bytes(brng.integers(0, 2, size=5, dtype=np.uint8).tolist()) for _ in range(nb)]
+        b_bits = [inst["bits"]] * nb
+        d_ssp_b = inst["d_ssp"]
+        out_b = ctx.prove_batch(d_crs, d_ssp_b, b_bits, b_delta, b_mags, b_signs)
+        for _ in range(max(args.warmup - 1, 0)):
+            ctx.prove_batch(d_crs, d_ssp_b, b_bits, b_delta, b_mags, b_signs, out=out_b)
+        ctx.set_timing(True)
+        ctx.timing_drain("evalmm")
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            ctx.prove_batch(d_crs, d_ssp_b, b_bits, b_delta, b_mags, b_signs, out=out_b)
+        barrier()
+        el_b = time.perf_counter() - t1
+        ctx.set_timing(False)
+        mmn, mmms, mmrows = ctx.timing_drain("evalmm")
+        if dist is not None:
+            tt = torch.tensor([el_b], dtype=torch.float64, device=ctx.device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el_b = float(tt.item())
+        ok_b = ctx.to_host(ctx.verify(d_ssp_b, inst["alpha"], inst["beta"], inst["s"], inst["sk"], out_b, nb))
+        one = ctx.prove(d_crs, d_ssp_b, inst["bits"], b_delta[nb - 1], b_mags[nb - 1], b_signs[nb - 1])
+        same_b = bool(torch.equal(out_b.view(nb, -1)[nb - 1], one))
+        all_ok = bool(int(ok_b.sum()) == nb) and same_b
+        if dist is not None:
+            ta = torch.tensor([1 if all_ok else 0], dtype=torch.int64, device=ctx.device)
+            dist.all_reduce(ta, op=dist.ReduceOp.MIN)
+            all_ok = bool(int(ta.item()))
+        row_bytes_b = (p.n + 1) * p.ctb
+        avg_mm = mmms / max(mmn, 1)
+        rows_mm = mmrows / max(mmn, 1)
+        blocks_mm = rows_mm * (p.ctr_ct / 16.0)
+        traffic_mm = None
+        tfm = os.path.join(ROOT, "profiles", "traffic_evalmm.json")
+        if os.path.exists(tfm):
+            try:
+                traffic_mm = json.load(open(tfm)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic_mm = None
+        gbs = rows_mm * row_bytes_b / (avg_mm * 1e-3) / 1e9 if mmn else None
+        batched = {"value": world * nb * args.steps / el_b, "unit": "proofs/s", "ms_per_step": el_b / args.steps * 1e3, "statements_per_gpu_per_step": nb,
+                   "all_accepted_and_last_identical_to_single_proof_path": all_ok,
+                   "roofline": {"bound": "hbm", "kernel": "k_evalmm<4> (AES-256-CTR expansion of the rows, once per group of 12 proofs, + i8 MFMA "
+                                                            "multiply-accumulate of the group's 24 (S, AS) / 12 (BT+BV) coefficient vectors)",
+                                "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (gbs / HBM_PEAK_GBS) if gbs else None, "traffic": traffic_mm,
+                                "launches": mmn, "avg_launch_ms": avg_mm, "rows_per_launch": rows_mm, "bytes_per_row": row_bytes_b,
+                                "note": "algorithmic bytes = expanded row bytes, regenerated with AES on the CU (LDS T-tables): LDS-lookup / VALU "
+                                        "bound, ~0 HBM bytes; the MFMA work (2 x 129448 x 128 x rows int8 ops) is ~5 % of the kernel",
+                                "aes_gblocks_per_s": blocks_mm / (avg_mm * 1e-3) / 1e9 if mmn else None,
+                                "lds_lookup_roofline": {"achieved_gblocks_per_s": blocks_mm / (avg_mm * 1e-3) / 1e9 if mmn else None,
+                                                        "peak_gblocks_per_s": 256 * 2.4e9 * 64 / (201 * 2.15) / 1e9,
+                                                        "frac": (blocks_mm / (avg_mm * 1e-3) / 1e9) / (256 * 2.4e9 * 64 / (201 * 2.15) / 1e9) if mmn else None},
+                                "mfma_int8_tops": 2.0 * 129448 * 128 * rows_mm / (avg_mm * 1e-3) / 1e12 if mmn else None}}
 
     # ---- LWE batch (BASELINE config 1/2: one batch of 65 536 encryptions, rows at stream offset k*135240)
     enc_per_s = None
@@ -334,7 +411,6 @@ def main():
                            "reference aes.c/entropy.c (92-byte reads, as ct_import does) on this host")
 
     if rank == 0:
-        ms_step = elapsed / args.steps * 1e3
         launch_rows = rows2 / max(n2, 1)
         avg_ms = ms2 / max(n2, 1)
         row_bytes = (p.n + 1) * p.ctb
@@ -346,46 +422,72 @@ def main():
                 traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        lds_peak = 256 * 2.4e9 * 64 / (201 * 2.15) / 1e9
+        gblk = (launch_rows * (p.ctr_ct / 16.0) / (avg_ms * 1e-3) / 1e9) if n2 else None
+        single = None
+        if run_single:
+            single = {
+                "value": single_steps / elapsed * (1 if by_rows else world), "unit": "proofs/s", "steps": single_steps,
+                "ms_per_step": elapsed / single_steps * 1e3, "proof_accepted": bool(accepted),
+                "sharding": ((f"CRS rows over {world} rank(s), 2 lane all-reduces per proof" if by_rows else f"{world} independent provers, no collective")
+                             if world > 1 else "single GPU"),
+                "roofline": {"bound": "hbm", "kernel": f"k_eval<{p.logq},2> (fused AES-256-CTR expansion + 2x MAC, S and AS regions)",
+                             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+                             "traffic": traffic, "launches": n2, "avg_launch_ms": avg_ms, "rows_per_launch": launch_rows, "bytes_per_row": row_bytes,
+                             "note": "algorithmic bytes = expanded row bytes; the kernel regenerates them with AES on the CU (LDS T-tables), "
+                                     "it is LDS-lookup/VALU bound and moves ~0 HBM bytes: see DESIGN.md",
+                             "aes_gblocks_per_s": gblk,
+                             # the kernel's real limiter: LDS table lookups (201 per AES block with the counter-mode shortcut, one ds_read_b32
+                             # wave-instruction per 2.15 CU-cycles measured, 256 CUs at 2.4 GHz => 256*2.4e9*64/(201*2.15) blocks/s)
+                             "lds_lookup_roofline": {"achieved_gblocks_per_s": gblk, "peak_gblocks_per_s": lds_peak, "frac": (gblk / lds_peak) if gblk else None}},
+                "eval1": {"launches": n1, "avg_launch_ms": ms1 / max(n1, 1), "rows_per_launch": rows1 / max(n1, 1)},
+                "resident_crs": resident,
+            }
+        base_workload = ("benchmark_snark default SSP instance (NDEBUG): D=32768, M=21845, N=1470, logq=736; full prover() from the compressed "
+                         "CRS, keystream regenerated in the timed region") if not big else (
+                             f"BASELINE {args.workload}: D=2^20, M=699050, N=1470, logq={p.logq}, generator-defined SSP; full prover() from the "
+                             "compressed CRS, keystream regenerated in the timed region")
+        if mode == "batch":
+            head = {"value": batched["value"], "ms_per_step": batched["ms_per_step"], "scaling": "weak", "roofline": batched["roofline"],
+                    "proof_accepted": batched["all_accepted_and_last_identical_to_single_proof_path"],
+                    "config": {"workload": base_workload + f"; a step = {args.batch} statements per GPU (same circuit and CRS, own randomness) through "
+                                           "mfh_prove_batch: each CRS region is expanded once per group of 12 proofs and the group's multiply-accumulate "
+                                           "runs on the matrix cores; every proof is bit-identical to the single-proof prover()'s",
+                               "rows_per_proof": rows_crs, "statements_per_gpu_per_step": args.batch,
+                               "sharding": f"{world} ranks, disjoint statements, no collective" if world > 1 else "single GPU"}}
+            ok_all = head["proof_accepted"] and bool(accepted)
+        else:
+            head = {"value": single["value"], "ms_per_step": single["ms_per_step"], "scaling": "strong" if by_rows else "weak",
+                    "roofline": single["roofline"], "proof_accepted": bool(accepted),
+                    "config": {"workload": base_workload, "rows_per_proof": rows_crs, "sharding": single["sharding"]}}
+            ok_all = bool(accepted)
         out = {
             "metric": "snark_proofs_per_sec",
-            "value": args.steps / elapsed * (1 if by_rows else world),
+            "value": head["value"],
             "unit": "proofs/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": ms_step,
+            "ms_per_step": head["ms_per_step"],
             "higher_is_better": True,
-            "scaling": "strong" if by_rows else "weak",
+            "scaling": head["scaling"],
             "vs_baseline": None,
-            "dtype": "u32 limbs (704-bit integers mod 2^704) + AES-256 bytes",
+            "dtype": "u32 limbs (704-bit integers mod 2^704) + AES-256 bytes" + ("; int8 digits on the matrix cores, int32 accumulation (exact)" if mode == "batch" else ""),
             "data": "synthetic (valid random SSP, random witness, seeded secrets)",
-            "config": {"workload": ("benchmark_snark default SSP instance (NDEBUG): D=32768, M=21845, N=1470, logq=736; full prover() "
-                                    "from the compressed CRS, keystream regenerated in the timed region") if not big else
-                                   (f"BASELINE {args.workload}: D=2^20, M=699050, N=1470, logq={p.logq}, generator-defined SSP; full prover() from the "
-                                    "compressed CRS, keystream regenerated in the timed region"),
-                       "rows_per_proof": rows_crs, "sharding": (f"CRS rows over {world} rank(s), 2 lane all-reduces per proof" if by_rows else f"{world} independent provers, no collective")
-                       if world > 1 else "single GPU"},
-            "proof_accepted": bool(accepted),
+            "mode": mode,
+            "config": head["config"],
+            "proof_accepted": head["proof_accepted"],
             "lwe_enc_per_s": enc_per_s,
             "setup_s": setup_s,
             "setup_enc_per_s": rows_crs / setup_s,
-            "roofline": {"bound": "hbm", "kernel": f"k_eval<{p.logq},2> (fused AES-256-CTR expansion + 2x MAC, S and AS regions)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                         "traffic": traffic, "launches": n2, "avg_launch_ms": avg_ms, "rows_per_launch": launch_rows,
-                         "bytes_per_row": row_bytes,
-                         "note": "algorithmic bytes = expanded row bytes; the kernel regenerates them with AES on the CU (LDS T-tables), "
-                                 "it is LDS-lookup/VALU bound and moves ~0 HBM bytes: see DESIGN.md",
-                         "aes_gblocks_per_s": (launch_rows * (p.ctr_ct / 16.0) / (avg_ms * 1e-3) / 1e9) if n2 else None,
-                         # the kernel's real limiter: LDS table lookups (201 per AES block with the counter-mode shortcut, one ds_read_b32
-                         # wave-instruction per 2.15 CU-cycles measured, 256 CUs at 2.4 GHz => 256*2.4e9*64/(201*2.15) blocks/s)
-                         "lds_lookup_roofline": {"achieved_gblocks_per_s": (launch_rows * (p.ctr_ct / 16.0) / (avg_ms * 1e-3) / 1e9) if n2 else None,
-                                                 "peak_gblocks_per_s": 256 * 2.4e9 * 64 / (201 * 2.15) / 1e9,
-                                                 "frac": ((launch_rows * (p.ctr_ct / 16.0) / (avg_ms * 1e-3) / 1e9) / (256 * 2.4e9 * 64 / (201 * 2.15) / 1e9)) if n2 else None}},
-            "eval1": {"launches": n1, "avg_launch_ms": ms1 / max(n1, 1), "rows_per_launch": rows1 / max(n1, 1)},
-            "resident_crs": resident,
+            "roofline": head["roofline"],
+            "single_proof": single if mode == "batch" else None,
+            "eval1": single["eval1"] if mode == "single" else None,
+            "resident_crs": resident if mode == "single" else None,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
+        accepted = ok_all
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -281,7 +281,10 @@ static int prove_partial_impl(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_
   // rows need neither: the two run side by side, chain on the side stream, b_w's rows on the caller's stream, joined before the
   // S / AS regions (which need w, v and h).  The side stream waits for everything already queued on the caller's stream first, so
   // the previous proof's reads of w, v, h are over before they are rewritten.
-  const bool fork = c->overlap;
+  // Only for the single-GPU prover: with the witness lanes coming out of a collective the chain is short and the gain is within noise
+  // (tools/rank_cost.py), and two processes sharing one GPU (the one-GPU rehearsal of the multi-rank path) serialise badly on
+  // cross-queue event waits.
+  const bool fork = c->overlap && world == 1;
   hipStream_t main_stream = c->stream;
   if (fork) {
     if (!c->side) {
