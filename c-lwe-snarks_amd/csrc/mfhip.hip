@@ -817,6 +817,41 @@ __global__ __launch_bounds__(256) void k_witness_partial_prg(uint64_t seed, cons
   uint64_t *o = partial + (uint64_t)g * d + k;
   o[0] = s0; o[1] = s1; o[2] = s2; o[3] = s3;
 }
+// The witness pass for NB statements at once: every selected SSP row is read ONCE and added into the accumulators of the statements
+// whose bit selects it.  list[i] = {slot, mask}: bit b of mask = statement b selects the row (uniform per row: scalar branches).
+// partial[(b * G + g) * d + k]: the per-statement layout k_witness_finish reads.
+template <int NB>
+__global__ __launch_bounds__(256) void k_witness_partial_multi(const uint32_t *__restrict__ ssp, const uint2 *__restrict__ list, uint32_t nsel,
+                                                               uint32_t d, uint64_t *__restrict__ partial) {
+  const uint32_t k4 = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k4 * 4 >= d) return;
+  const uint32_t G = gridDim.y, g = blockIdx.y;
+  uint64_t acc[NB][4];
+#pragma unroll
+  for (int b = 0; b < NB; b++) acc[b][0] = acc[b][1] = acc[b][2] = acc[b][3] = 0;
+  auto add = [&](const uint4 &v, uint32_t mask) {
+#pragma unroll
+    for (int b = 0; b < NB; b++)
+      if ((mask >> b) & 1) { acc[b][0] += v.x; acc[b][1] += v.y; acc[b][2] += v.z; acc[b][3] += v.w; }
+  };
+  const uint32_t *col = ssp + (uint64_t)k4 * 4;
+  uint32_t i = g;
+  for (; i + 3 * G < nsel; i += 4 * G) {  // four rows in flight
+    const uint2 e0 = list[i], e1 = list[i + G], e2 = list[i + 2 * G], e3 = list[i + 3 * G];
+    const uint4 v0 = *reinterpret_cast<const uint4 *>(col + (uint64_t)e0.x * d), v1 = *reinterpret_cast<const uint4 *>(col + (uint64_t)e1.x * d);
+    const uint4 v2 = *reinterpret_cast<const uint4 *>(col + (uint64_t)e2.x * d), v3 = *reinterpret_cast<const uint4 *>(col + (uint64_t)e3.x * d);
+    add(v0, e0.y); add(v1, e1.y); add(v2, e2.y); add(v3, e3.y);
+  }
+  for (; i < nsel; i += G) {
+    const uint2 e = list[i];
+    add(*reinterpret_cast<const uint4 *>(col + (uint64_t)e.x * d), e.y);
+  }
+#pragma unroll
+  for (int b = 0; b < NB; b++) {
+    uint64_t *o = partial + ((uint64_t)b * G + g) * d + (uint64_t)k4 * 4;
+    o[0] = acc[b][0]; o[1] = acc[b][1]; o[2] = acc[b][2]; o[3] = acc[b][3];
+  }
+}
 // materialise generator-defined slots [first, first+nslots) as a dense uint32 image (tests; small instances)
 __global__ void k_ssp_prg_fill(uint64_t seed, uint32_t first_slot, uint32_t d, uint64_t total, uint32_t *__restrict__ out) {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -1475,6 +1510,41 @@ int mfh_witness_poly(mfh_ctx *c, const uint32_t *d_ssp, const uint8_t *h_bits, u
   rc = witness_partials(c, src, h_bits, 0, 1, &G, &partial);
   if (rc) return rc;
   hipLaunchKernelGGL(k_witness_finish, dim3((c->P.d + 255) / 256), dim3(256), 0, c->stream, src.t, partial, G, c->P.d, delta, d_w);
+  HIP_TRY(c, hipGetLastError());
+  return MFH_OK;
+}
+
+// mfh_witness_poly for up to 12 statements in one pass over the SSP (dense SSP only): d_w = nstmt polynomials of d coefficients
+int mfh_witness_poly_multi(mfh_ctx *c, const uint32_t *d_ssp, uint32_t nstmt, const uint8_t *h_bits, size_t bits_stride, const uint32_t *h_delta,
+                           uint32_t *d_w) {
+  constexpr int NB = 12;
+  if (!c || !d_ssp || !h_bits || !h_delta || !d_w || nstmt == 0 || nstmt > NB) return MFH_EINVAL;
+  const uint32_t d = c->P.d, m = c->P.m;
+  if (d % 4) { c->err = "d must be a multiple of 4"; return MFH_EINVAL; }
+  for (uint32_t b = 0; b < nstmt; b++)
+    if (h_delta[b] >= MFH_P) { c->err = "delta must be < p"; return MFH_EINVAL; }
+  HIP_TRY(c, hipSetDevice(c->device));
+  uint2 *list = (uint2 *)pin_acquire(c, c->pin_rows, (size_t)m * 8 + 8);
+  if (!list) return MFH_ENOMEM;
+  uint32_t nsel = 0;
+  for (uint32_t i = 1; i < m; i++) {
+    uint32_t mask = 0;
+    for (uint32_t b = 0; b < nstmt; b++) mask |= (uint32_t)((h_bits[b * bits_stride + ((i - 1) >> 3)] >> ((i - 1) & 7)) & 1) << b;
+    if (mask) list[nsel++] = make_uint2(i + 1, mask);  // slot of v_i
+  }
+  const uint32_t G = std::max(1u, std::min(16u, nsel / 8 + 1));
+  const size_t list_b = ((size_t)m * 8 + 255) & ~(size_t)255;
+  int rc = wws_reserve(c, list_b + (size_t)NB * G * d * 8);
+  if (rc) return rc;
+  uint2 *d_list = (uint2 *)c->wws;
+  uint64_t *partial = (uint64_t *)((uint8_t *)c->wws + list_b);
+  if (nsel) HIP_TRY(c, hipMemcpyAsync(d_list, list, (size_t)nsel * 8, hipMemcpyHostToDevice, c->stream));
+  pin_release(c, c->pin_rows);
+  hipLaunchKernelGGL(k_witness_partial_multi<NB>, dim3((d / 4 + 255) / 256, G), dim3(256), 0, c->stream, d_ssp, d_list, nsel, d, partial);
+  HIP_TRY(c, hipGetLastError());
+  for (uint32_t b = 0; b < nstmt; b++)
+    hipLaunchKernelGGL(k_witness_finish, dim3((d + 255) / 256), dim3(256), 0, c->stream, d_ssp, partial + (size_t)b * G * d, G, d, h_delta[b],
+                       d_w + (size_t)b * d);
   HIP_TRY(c, hipGetLastError());
   return MFH_OK;
 }

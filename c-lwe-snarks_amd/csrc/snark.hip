@@ -444,9 +444,13 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
     HIP_TRY(c, hipMemcpyAsync(CW, h_cw, (size_t)g * m * 4, hipMemcpyHostToDevice, c->stream));
     pin_release(c, c->pin_cw);
     // per proof: w = delta t + sum_bits v_i, v = w + v_0, h = (v^2 - 1) / t   (src/snark.c:141-169)
+    if (src.dense) {  // one pass over the SSP for the whole group
+      int rcw = mfh_witness_poly_multi(c, d_ssp, g, h_witness_bits + (size_t)g0 * bits_stride, bits_stride, h_delta + g0, W);
+      if (rcw) return rcw;
+    }
     for (uint32_t b = 0; b < g; b++) {
       uint32_t *w = W + (size_t)b * d, *v = V + (size_t)b * d, *h = H + (size_t)b * d;
-      int rc = mfh_witness_poly(c, d_ssp, h_witness_bits + (size_t)(g0 + b) * bits_stride, h_delta[g0 + b], w);
+      int rc = src.dense ? MFH_OK : mfh_witness_poly(c, d_ssp, h_witness_bits + (size_t)(g0 + b) * bits_stride, h_delta[g0 + b], w);
       if (rc) return rc;
       hipLaunchKernelGGL(k_add_slot, g1(d), dim3(256), 0, c->stream, w, src, 1u, d, v);
       HIP_TRY(c, hipGetLastError());

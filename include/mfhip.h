@@ -198,6 +198,10 @@ int mfh_prove_batch(mfh_ctx *ctx, const uint8_t *d_crs_c8, const uint32_t *d_ssp
 int mfh_prove_partial(mfh_ctx *ctx, const uint8_t *d_crs_c8, const uint32_t *d_ssp, const uint8_t *h_witness_bits, uint32_t delta,
                       uint32_t rank, uint32_t world, uint64_t *d_partial);
 int mfh_prove_finish(mfh_ctx *ctx, uint64_t *d_proof, const uint8_t *h_smudge_mag, size_t maglen, const uint8_t *h_smudge_sign);
+/* mfh_witness_poly for nstmt <= 12 statements in ONE pass over the (dense) SSP: every selected v_i is read once and added into the
+ * polynomials of the statements whose bit selects it.  h_bits: nstmt bit strings bits_stride bytes apart; d_w: nstmt x d coefficients. */
+int mfh_witness_poly_multi(mfh_ctx *ctx, const uint32_t *d_ssp, uint32_t nstmt, const uint8_t *h_bits, size_t bits_stride, const uint32_t *h_delta,
+                           uint32_t *d_w);
 /* Optional second exchange that also shards the witness polynomial (the SSP pass, 1.4 GB per proof at the default size):
  * mfh_witness_lanes = this rank's share of sum_{bit} v_i as d uint64 lanes (each < p) -> all-reduce (sum) ->
  * mfh_prove_partial_w takes the summed lanes instead of recomputing w on every rank.  mfh_witness_from_lanes: w = delta t + lanes mod p. */
