@@ -6,13 +6,15 @@
 //
 //     out_v[j] = sum_i c_v[i] * a_ij   (mod 2^704)
 //   a_ij = sum_u A[i][(j,u)] 256^u   (88 significant bytes of the 92-byte stream value)
-//   c_v[i] = sum_w C[i][(v,w)] 128^w (five 7-bit digits: non-negative as int8, so only A needs an offset)
-//   G[(j,u)][(v,w)] = sum_i A[i][(j,u)] * C[i][(v,w)]           M = 1471*88, N = 5V, K = rows
-//   out_v[j] = sum_{u,w} G[(j,u)][(v,w)] 2^(8u + 7w)
+//   c_v[i] = sum_w C[i][(v,w)] 256^w (four bytes)
+//   G[(j,u)][(v,w)] = sum_i A[i][(j,u)] * C[i][(v,w)]           M = 1471*88, N = 4V + 1, K = rows
+//   out_v[j] = sum_{u,w} G[(j,u)][(v,w)] 256^(u + w)
 //
-// v_mfma_i32_32x32x32_i8 is signed: the keystream bytes are produced as A' = A - 128 (0x80808080 folded into the last AES round key,
-// so the offset costs nothing) and the finish kernel adds 128 * sum_i C[i][n] back.  |A'| <= 128, C <= 127: an int32 accumulator
-// holds 132 104 rows; launches split the rows accordingly.
+// v_mfma_i32_32x32x32_i8 is signed: both operands go in offset by 128.  The keystream bytes are produced as A' = A - 128 (0x80808080
+// folded into the last AES round key, so the offset costs nothing), the digit matrix holds C' = C - 128, and
+//     sum_i A C = sum_i A'C' + 128 sum_i A' + 128 sum_i C' + 16384 rows:
+// sum_i A'[m] comes out of the same MFMA through one extra digit column of ones, sum_i C'[n] from a small kernel.  |A'C'| <= 16384: an
+// int32 accumulator holds 131 071 rows; launches split the rows accordingly.  128 digit columns = 31 vectors + the ones column.
 //
 // Workgroup = 1024 threads, one column tile of CT = 4 coordinates (352 byte positions = 11 MFMA row tiles) x one row chunk.
 // Per unit of RT = 128 rows: (1) all 16 waves expand the 128 x 368-byte row segments into a row-major LDS tile (23-24 AES blocks
@@ -37,7 +39,8 @@ constexpr int MT = MB / 32;       // 11 MFMA row tiles
 constexpr int RT = 128;           // rows per unit
 constexpr int TSTRIDE = 384;      // tile row stride: 24 AES blocks
 constexpr int BLK_PER_ROW = 24;
-constexpr int ND = 5;             // 7-bit digits per coefficient
+constexpr int ND = 4;             // bytes per coefficient
+constexpr int MAXV = 31;          // vectors per call: 4 * 31 + the ones column = 125 of 128 digit columns
 static_assert(MB % 32 == 0 && CT * VB + 15 <= TSTRIDE, "tile geometry");
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -45,31 +48,35 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 
 // Digit matrix in MFMA B-fragment order: for k-step K = i / 32 (32 rows), column tile q and lane (r = n & 31, h): 16 bytes = digit
 // n = 32 q + r of rows 32 K + 16 h + e, e = 0..15, at cd[((K * NT + q) * 64 + 32 h + r) * 16 + e].  A unit's (RT rows) fragments are one
-// contiguous RT * N bytes.  Digit w of c_v[i] sits in column n = ND v + w; columns >= ND nvec and rows >= nrows are zero.
+// contiguous RT * N bytes.  Column n = ND v + w holds byte w of c_v[i] minus 128; column ND nvec is the ones column; every other
+// column, and every row >= nrows, is zero (such rows and columns then add nothing to G').
 __global__ void k_mm_digits(const uint32_t *__restrict__ coeff, uint32_t nvec, uint32_t nrows, uint32_t rpad, uint32_t NT,
                             int8_t *__restrict__ cd) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
   if (i >= rpad) return;
   const uint32_t v = n / ND, w = n % ND;
-  uint32_t d = 0;
-  if (v < nvec && i < nrows) d = (coeff[(uint64_t)v * nrows + i] >> (7 * w)) & 127u;
+  int dgt = 0;
+  if (i < nrows) {
+    if (v < nvec) dgt = (int)((coeff[(uint64_t)v * nrows + i] >> (8 * w)) & 255u) - 128;
+    else if (n == ND * nvec) dgt = 1;
+  }
   const uint32_t K = i >> 5, h = (i >> 4) & 1, e = i & 15, q = n >> 5, r = n & 31;
-  cd[((((uint64_t)K * NT + q) * 64 + 32 * h + r) << 4) + e] = (int8_t)d;
+  cd[((((uint64_t)K * NT + q) * 64 + 32 * h + r) << 4) + e] = (int8_t)dgt;
 }
-// sc[n] = sum_i (digit n of row i), from the coefficient vectors
-__global__ void k_mm_colsum(const uint32_t *__restrict__ coeff, uint32_t nvec, uint32_t nrows, uint32_t *__restrict__ sc) {
+// sc[n] = sum_i C'[i][n] = sum_i (byte w of c_v[i]) - 128 nrows, from the coefficient vectors (signed)
+__global__ void k_mm_colsum(const uint32_t *__restrict__ coeff, uint32_t nvec, uint32_t nrows, int64_t *__restrict__ sc) {
   __shared__ uint32_t red[256];
   const uint32_t n = blockIdx.x, v = n / ND, w = n % ND;
   uint32_t s = 0;
   if (v < nvec)
-    for (uint32_t i = threadIdx.x; i < nrows; i += blockDim.x) s += (coeff[(uint64_t)v * nrows + i] >> (7 * w)) & 127u;
+    for (uint32_t i = threadIdx.x; i < nrows; i += blockDim.x) s += (coeff[(uint64_t)v * nrows + i] >> (8 * w)) & 255u;
   red[threadIdx.x] = s;
   __syncthreads();
   for (int o = 128; o; o >>= 1) {
     if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) sc[n] = red[0];
+  if (threadIdx.x == 0) sc[n] = (int64_t)red[0] - 128ll * nrows;
 }
 
 struct RowGeom {
@@ -212,31 +219,33 @@ __global__ __launch_bounds__(1024) void k_evalmm(AesKey key /* rk[56..59] ^ 0x80
   }
 }
 
-// out_v[j] = sum_{u,w} (sum_chunks G'[(j,u)][(v,w)] + 128 sc[(v,w)]) 2^(8u + 7w)  mod 2^704; thread = (vector v fastest, coordinate j)
-__global__ void k_evalmm_finish(const int *__restrict__ part, const uint32_t *__restrict__ sc, uint32_t nchunks, uint32_t ntiles, uint32_t N,
-                                uint32_t nvec, uint32_t n, uint64_t *__restrict__ rops /* [nvec][(n+1) * 12] */, int accumulate) {
+// out_v[j] = sum_{u,w} G[(j,u)][(v,w)] 256^(u + w) mod 2^704 with G = G' + 128 SA[(j,u)] + 128 sc[(v,w)] + 16384 nrows, G' and
+// SA = G'[.][ones column] summed over the row chunks; thread = (vector v fastest, coordinate j)
+__global__ void k_evalmm_finish(const int *__restrict__ part, const int64_t *__restrict__ sc, uint32_t nchunks, uint32_t ntiles, uint32_t N,
+                                uint32_t nvec, uint32_t n, uint32_t nrows, uint64_t *__restrict__ rops /* [nvec][(n+1) * 12] */, int accumulate) {
   const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t v = gid % nvec, j = gid / nvec;
   if (j > n) return;
   const uint32_t tile = j / CT, jj = j % CT;
   uint32_t *out = reinterpret_cast<uint32_t *>(rops + ((uint64_t)v * (n + 1) + j) * 12);
-  uint64_t corr[ND];
+  int64_t corr[ND];
 #pragma unroll
-  for (int w = 0; w < ND; w++) corr[w] = 128ull * sc[ND * v + w];
-  // running sum in 32-bit words: lo64 holds bits [32 l, 32 l + 64) of the partial result, hi its overflow
-  unsigned __int128 run = 0;
+  for (int w = 0; w < ND; w++) corr[w] = 128 * sc[ND * v + w] + 16384ll * nrows;
+  unsigned __int128 run = 0;  // bits [32 l, ...) of the partial result
   for (int l = 0; l < 22; l++) {
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      const uint32_t u = 4 * l + k;
-      const uint32_t mm = jj * SB + u;
+      const uint32_t mm = jj * SB + 4 * l + k;
+      int64_t g[ND] = {0, 0, 0, 0}, sa = 0;
+      for (uint32_t ch = 0; ch < nchunks; ch++) {
+        const int *row = part + (((uint64_t)ch * ntiles + tile) * MB + mm) * N;
+#pragma unroll
+        for (int w = 0; w < ND; w++) g[w] += row[ND * v + w];
+        sa += row[ND * nvec];
+      }
       uint64_t t = 0;
 #pragma unroll
-      for (int w = 0; w < ND; w++) {
-        int64_t g = 0;
-        for (uint32_t ch = 0; ch < nchunks; ch++) g += part[(((uint64_t)ch * ntiles + tile) * MB + mm) * N + ND * v + w];
-        t += (uint64_t)(g + (int64_t)corr[w]) << (7 * w);  // g + corr >= 0: it is the true (unsigned) digit product sum
-      }
+      for (int w = 0; w < ND; w++) t += (uint64_t)(g[w] + 128 * sa + corr[w]) << (8 * w);  // each term is a true byte-product sum: >= 0, < 2^31
       run += (unsigned __int128)t << (8 * k);
     }
     uint64_t word = (uint64_t)run & 0xffffffffu;
@@ -261,7 +270,7 @@ int mfh_eval_rows_multi(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d
   if (!c || !d_rops || !nvec || (nrows && (!d_c8 || !d_coeffs))) return MFH_EINVAL;
   if (!c->have_seed) { c->err = "mfh_set_seed has not been called"; return MFH_EINVAL; }
   if (c->P.logq != 736) { c->err = "mfh_eval_rows_multi: only logq = 736 has a matrix-core path"; return MFH_EUNSUPPORTED; }
-  if (nvec > 25) { c->err = "mfh_eval_rows_multi: at most 25 coefficient vectors per call (128 digit columns)"; return MFH_EINVAL; }
+  if (nvec > MAXV) { c->err = "mfh_eval_rows_multi: at most 31 coefficient vectors per call (128 digit columns)"; return MFH_EINVAL; }
   if (nrows > 0xffffffffu - 256) return MFH_EINVAL;
   HIP_TRY(c, hipSetDevice(c->device));
   const uint32_t n = c->P.n;
@@ -270,24 +279,24 @@ int mfh_eval_rows_multi(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d
     if (!accumulate) HIP_TRY(c, hipMemsetAsync(d_rops, 0, (size_t)nvec * ctl * 8, c->stream));
     return MFH_OK;
   }
-  const uint32_t NT = nvec * ND <= 64 ? 2 : 4, N = 32 * NT;
+  const uint32_t NT = nvec * ND + 1 <= 64 ? 2 : 4, N = 32 * NT;
   const uint32_t ntiles = (n + 1 + CT - 1) / CT;
   // row chunks: fill the CUs about three times over; an int32 accumulator holds 132 104 rows
   // row chunks: 368 column tiles x 2 chunks = 736 workgroups = 2.9 rounds of the 256 CUs (one workgroup per CU at a time); an int32
-  // accumulator holds 132 104 rows
+  // accumulator holds 131 071 rows
   uint32_t nchunks = nrows >= 8 * RT ? 2 : 1;
-  nchunks = std::max<uint32_t>(nchunks, ((uint32_t)nrows + 131071) / 131072);
+  nchunks = std::max<uint32_t>(nchunks, ((uint32_t)nrows + 131070) / 131071);
   uint32_t rpc = ((uint32_t)nrows + nchunks - 1) / nchunks;
   rpc = (rpc + RT - 1) / RT * RT;
   nchunks = ((uint32_t)nrows + rpc - 1) / rpc;
   const uint32_t rpad = nchunks * rpc;  // a multiple of RT: digit rows past nrows are zero
   const size_t cd_bytes = ((size_t)N * rpad + 255) & ~(size_t)255;
-  const size_t sc_bytes = 256 * 4;
+  const size_t sc_bytes = 256 * 8;
   const size_t part_bytes = (size_t)nchunks * ntiles * MB * N * 4;
   int rc = ws_reserve(c, cd_bytes + sc_bytes + part_bytes);
   if (rc) return rc;
   int8_t *cd = (int8_t *)c->ws;
-  uint32_t *sc = (uint32_t *)((uint8_t *)c->ws + cd_bytes);
+  int64_t *sc = (int64_t *)((uint8_t *)c->ws + cd_bytes);
   int *part = (int *)((uint8_t *)c->ws + cd_bytes + sc_bytes);
   hipLaunchKernelGGL(k_mm_digits, dim3((rpad + 255) / 256, N), dim3(256), 0, c->stream, d_coeffs, nvec, (uint32_t)nrows, rpad, NT, cd);
   hipLaunchKernelGGL(k_mm_colsum, dim3(N), dim3(256), 0, c->stream, d_coeffs, nvec, (uint32_t)nrows, sc);
@@ -304,7 +313,7 @@ int mfh_eval_rows_multi(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d
   }
   HIP_TRY(c, hipGetLastError());
   const uint32_t total = (n + 1) * nvec;
-  hipLaunchKernelGGL(k_evalmm_finish, dim3((total + 127) / 128), dim3(128), 0, c->stream, part, sc, nchunks, ntiles, N, nvec, n, d_rops, accumulate);
+  hipLaunchKernelGGL(k_evalmm_finish, dim3((total + 127) / 128), dim3(128), 0, c->stream, part, sc, nchunks, ntiles, N, nvec, n, (uint32_t)nrows, d_rops, accumulate);
   HIP_TRY(c, hipGetLastError());
   return MFH_OK;
 }

@@ -396,7 +396,7 @@ int mfh_prove(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, const 
   return mfh_prove_finish(c, d_proof, h_smudge_mag, maglen, h_smudge_sign);
 }
 
-// prover() for a batch of statements under one CRS and SSP: the three CRS regions are expanded ONCE per group of up to 12 proofs and
+// prover() for a batch of statements under one CRS and SSP: the three CRS regions are expanded ONCE per group of up to 15 proofs and
 // the multiply-accumulate of all their coefficient vectors runs on the matrix cores (mfh_eval_rows_multi, evalmm.hip); the witness
 // pass, the polynomial step and the smudging stay per proof.  Proof b is bit-identical to mfh_prove with the same inputs.
 int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, uint32_t nproofs, const uint8_t *h_witness_bits,
@@ -417,7 +417,7 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
   const uint32_t ctb = c->P.logq / 8;
   const size_t ctl = (size_t)(n + 1) * ((c->P.logq + 63) / 64);
   const uint64_t ctr_ct = (uint64_t)ctb * n;
-  constexpr uint32_t G = 12;  // proofs per expansion: 24 coefficient vectors = 120 of the 128 digit columns
+  constexpr uint32_t G = 15;  // proofs per expansion: 30 coefficient vectors x 4 bytes + the ones column = 121 of the 128 digit columns
   HIP_TRY(c, hipSetDevice(c->device));
   // group scratch: W | H | V (g x d each, in this order: the S region takes (W, H), the AS region (H, V)), CW (G x m), OUT (2G ciphertexts)
   const size_t words = (size_t)3 * G * d + (size_t)G * m, need = words * 4 + (size_t)2 * G * ctl * 8;
@@ -444,9 +444,12 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
     HIP_TRY(c, hipMemcpyAsync(CW, h_cw, (size_t)g * m * 4, hipMemcpyHostToDevice, c->stream));
     pin_release(c, c->pin_cw);
     // per proof: w = delta t + sum_bits v_i, v = w + v_0, h = (v^2 - 1) / t   (src/snark.c:141-169)
-    if (src.dense) {  // one pass over the SSP for the whole group
-      int rcw = mfh_witness_poly_multi(c, d_ssp, g, h_witness_bits + (size_t)g0 * bits_stride, bits_stride, h_delta + g0, W);
-      if (rcw) return rcw;
+    if (src.dense) {  // the SSP is read once per (at most 12) statements
+      for (uint32_t b0 = 0; b0 < g; b0 += 12) {
+        int rcw = mfh_witness_poly_multi(c, d_ssp, std::min(12u, g - b0), h_witness_bits + (size_t)(g0 + b0) * bits_stride, bits_stride,
+                                         h_delta + g0 + b0, W + (size_t)b0 * d);
+        if (rcw) return rcw;
+      }
     }
     for (uint32_t b = 0; b < g; b++) {
       uint32_t *w = W + (size_t)b * d, *v = V + (size_t)b * d, *h = H + (size_t)b * d;

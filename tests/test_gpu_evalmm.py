@@ -23,14 +23,16 @@ def _vectors(rng, nvec, nrows, kind):
     co = rng.integers(0, ol.P, size=(nvec, nrows), dtype=np.uint64).astype(np.uint32)
     if kind == "edges":
         co[0, :] = 0                      # an all-zero vector
-        co[1 % nvec, :] = 0xFFFFFFFA      # p - 1 everywhere: every 7-bit digit at its maximum pattern
+        co[1 % nvec, :] = 0xFFFFFFFA      # p - 1 everywhere
+        co[3 % nvec, :] = 0xFFFFFFFF      # every byte 255 (the ABI takes any uint32)
+        co[4 % nvec, :] = 0x80808080      # every offset digit exactly 0
         co[2 % nvec, ::2] = 1             # 0/1 vectors like b_w's witness bits
         co[2 % nvec, 1::2] = 0
     return co
 
 
 @pytest.mark.parametrize("nrows,nvec,kind,off_rows", [
-    (1, 1, "rand", 0), (5, 2, "rand", 3), (128, 3, "edges", 0), (129, 12, "rand", 7), (300, 13, "edges", 1), (1100, 25, "rand", 2),
+    (1, 1, "rand", 0), (5, 2, "rand", 3), (128, 3, "edges", 0), (129, 12, "rand", 7), (300, 13, "edges", 1), (1100, 31, "rand", 2), (64, 16, "edges", 0),
 ])
 def test_multi_equals_single_vector_path(ctx, nrows, nvec, kind, off_rows):
     p = ctx.params
@@ -70,14 +72,14 @@ def test_multi_argument_checks(ctx):
 
     p = ctx.params
     with pytest.raises(mf.MfhError):
-        ctx.eval_rows_multi(0, 4, ctx.zeros(4 * p.ctb), ctx.zeros(26 * 4 * 4), 26)
+        ctx.eval_rows_multi(0, 4, ctx.zeros(4 * p.ctb), ctx.zeros(32 * 4 * 4), 32)
     out = ctx.eval_rows_multi(0, 0, ctx.zeros(16), ctx.zeros(16), 2)  # no rows: zero ciphertexts
     assert not ctx.to_host(out).any()
 
 
-@pytest.mark.parametrize("nproofs", [1, 5, 13])
+@pytest.mark.parametrize("nproofs", [1, 5, 16])
 def test_prove_batch_equals_single_proofs(gpu_ctx_factory, oracle, nproofs):
-    """mfh_prove_batch: proof b of the batch == mfh_prove(statement b), bit for bit (groups of 12: 13 = one full + one partial
+    """mfh_prove_batch: proof b of the batch == mfh_prove(statement b), bit for bit (groups of 15: 16 = one full + one partial
     group); the first proof is also checked against the oracle's prover and every proof is accepted by the device verifier."""
     import c_lwe_snarks_amd as mf
 
