@@ -127,7 +127,7 @@ def load_library():
         "mfh_last_kernel_ms": (ctypes.c_float, [vp, ctypes.c_char_p]),
         "mfh_set_timing": (i32, [vp, i32]),
         "mfh_set_overlap": (i32, [vp, i32]),
-        "mfh_eval_rows_multi": (i32, [vp, u64, sz, vp, vp, ctypes.c_uint32, vp, i32]),
+        "mfh_eval_rows_multi": (i32, [vp, u64, sz, vp, vp, u32, u32, vp, i32]),
         "mfh_witness_poly_multi": (i32, [vp, vp, u32, ctypes.c_char_p, sz, vp, vp]),
         "mfh_prove_batch": (i32, [vp, vp, vp, u32, ctypes.c_char_p, sz, vp, ctypes.c_char_p, sz, ctypes.c_char_p, vp]),
         "mfh_poly_mul": (i32, [vp, vp, sz, vp, sz, vp]),
@@ -292,10 +292,11 @@ class Context:
                                          1 if accumulate else 0))
         return rop0, rop1
 
-    def eval_rows_multi(self, off, nrows, c8, coeffs, nvec, out=None, accumulate=False):
-        """coeffs: nvec x nrows uint32 on the device (vector-major) -> nvec ciphertexts (vector-major); matrix-core path"""
+    def eval_rows_multi(self, off, nrows, c8, coeffs, nvec, out=None, accumulate=False, coeff_bytes=4):
+        """coeffs: nvec x nrows uint32 on the device (vector-major) -> nvec ciphertexts (vector-major); matrix-core path.
+        coeff_bytes = 1: every coefficient < 256 (up to 127 vectors); 4: any uint32 (up to 31 vectors)"""
         out = self.empty(nvec * self.params.ct_limbs * 8) if out is None else out
-        self._chk(self.lib.mfh_eval_rows_multi(self._h, off, nrows, _ptr(c8), _ptr(coeffs), nvec, _ptr(out), 1 if accumulate else 0))
+        self._chk(self.lib.mfh_eval_rows_multi(self._h, off, nrows, _ptr(c8), _ptr(coeffs), nvec, coeff_bytes, _ptr(out), 1 if accumulate else 0))
         return out
 
     def encrypt_rows(self, off, nrows, sk, msg, err, out=None):

@@ -39,8 +39,7 @@ constexpr int MT = MB / 32;       // 11 MFMA row tiles
 constexpr int RT = 128;           // rows per unit
 constexpr int TSTRIDE = 384;      // tile row stride: 24 AES blocks
 constexpr int BLK_PER_ROW = 24;
-constexpr int ND = 4;             // bytes per coefficient
-constexpr int MAXV = 31;          // vectors per call: 4 * 31 + the ones column = 125 of 128 digit columns
+constexpr int NDMAX = 4;          // bytes per coefficient: 4 (any uint32) or 1 (coefficients < 256, e.g. b_w's witness bits)
 static_assert(MB % 32 == 0 && CT * VB + 15 <= TSTRIDE, "tile geometry");
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -50,7 +49,7 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 // n = 32 q + r of rows 32 K + 16 h + e, e = 0..15, at cd[((K * NT + q) * 64 + 32 h + r) * 16 + e].  A unit's (RT rows) fragments are one
 // contiguous RT * N bytes.  Column n = ND v + w holds byte w of c_v[i] minus 128; column ND nvec is the ones column; every other
 // column, and every row >= nrows, is zero (such rows and columns then add nothing to G').
-__global__ void k_mm_digits(const uint32_t *__restrict__ coeff, uint32_t nvec, uint32_t nrows, uint32_t rpad, uint32_t NT,
+__global__ void k_mm_digits(const uint32_t *__restrict__ coeff, uint32_t nvec, uint32_t ND, uint32_t nrows, uint32_t rpad, uint32_t NT,
                             int8_t *__restrict__ cd) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
   if (i >= rpad) return;
@@ -64,7 +63,7 @@ __global__ void k_mm_digits(const uint32_t *__restrict__ coeff, uint32_t nvec, u
   cd[((((uint64_t)K * NT + q) * 64 + 32 * h + r) << 4) + e] = (int8_t)dgt;
 }
 // sc[n] = sum_i C'[i][n] = sum_i (byte w of c_v[i]) - 128 nrows, from the coefficient vectors (signed)
-__global__ void k_mm_colsum(const uint32_t *__restrict__ coeff, uint32_t nvec, uint32_t nrows, int64_t *__restrict__ sc) {
+__global__ void k_mm_colsum(const uint32_t *__restrict__ coeff, uint32_t nvec, uint32_t ND, uint32_t nrows, int64_t *__restrict__ sc) {
   __shared__ uint32_t red[256];
   const uint32_t n = blockIdx.x, v = n / ND, w = n % ND;
   uint32_t s = 0;
@@ -221,6 +220,7 @@ __global__ __launch_bounds__(1024) void k_evalmm(AesKey key /* rk[56..59] ^ 0x80
 
 // out_v[j] = sum_{u,w} G[(j,u)][(v,w)] 256^(u + w) mod 2^704 with G = G' + 128 SA[(j,u)] + 128 sc[(v,w)] + 16384 nrows, G' and
 // SA = G'[.][ones column] summed over the row chunks; thread = (vector v fastest, coordinate j)
+template <int ND>
 __global__ void k_evalmm_finish(const int *__restrict__ part, const int64_t *__restrict__ sc, uint32_t nchunks, uint32_t ntiles, uint32_t N,
                                 uint32_t nvec, uint32_t n, uint32_t nrows, uint64_t *__restrict__ rops /* [nvec][(n+1) * 12] */, int accumulate) {
   const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -236,7 +236,7 @@ __global__ void k_evalmm_finish(const int *__restrict__ part, const int64_t *__r
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const uint32_t mm = jj * SB + 4 * l + k;
-      int64_t g[ND] = {0, 0, 0, 0}, sa = 0;
+      int64_t g[ND] = {}, sa = 0;
       for (uint32_t ch = 0; ch < nchunks; ch++) {
         const int *row = part + (((uint64_t)ch * ntiles + tile) * MB + mm) * N;
 #pragma unroll
@@ -265,12 +265,13 @@ __global__ void k_evalmm_finish(const int *__restrict__ part, const int64_t *__r
 
 extern "C" {
 
-int mfh_eval_rows_multi(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d_c8, const uint32_t *d_coeffs, uint32_t nvec, uint64_t *d_rops,
-                        int accumulate) {
-  if (!c || !d_rops || !nvec || (nrows && (!d_c8 || !d_coeffs))) return MFH_EINVAL;
+int mfh_eval_rows_multi(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d_c8, const uint32_t *d_coeffs, uint32_t nvec, uint32_t coeff_bytes,
+                        uint64_t *d_rops, int accumulate) {
+  if (!c || !d_rops || !nvec || (nrows && (!d_c8 || !d_coeffs)) || (coeff_bytes != 1 && coeff_bytes != 4)) return MFH_EINVAL;
+  const uint32_t ND = coeff_bytes, MAXV = 127 / ND;
   if (!c->have_seed) { c->err = "mfh_set_seed has not been called"; return MFH_EINVAL; }
   if (c->P.logq != 736) { c->err = "mfh_eval_rows_multi: only logq = 736 has a matrix-core path"; return MFH_EUNSUPPORTED; }
-  if (nvec > MAXV) { c->err = "mfh_eval_rows_multi: at most 31 coefficient vectors per call (128 digit columns)"; return MFH_EINVAL; }
+  if (nvec > MAXV) { c->err = "mfh_eval_rows_multi: at most 31 four-byte (127 one-byte) coefficient vectors per call (128 digit columns)"; return MFH_EINVAL; }
   if (nrows > 0xffffffffu - 256) return MFH_EINVAL;
   HIP_TRY(c, hipSetDevice(c->device));
   const uint32_t n = c->P.n;
@@ -298,8 +299,8 @@ int mfh_eval_rows_multi(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d
   int8_t *cd = (int8_t *)c->ws;
   int64_t *sc = (int64_t *)((uint8_t *)c->ws + cd_bytes);
   int *part = (int *)((uint8_t *)c->ws + cd_bytes + sc_bytes);
-  hipLaunchKernelGGL(k_mm_digits, dim3((rpad + 255) / 256, N), dim3(256), 0, c->stream, d_coeffs, nvec, (uint32_t)nrows, rpad, NT, cd);
-  hipLaunchKernelGGL(k_mm_colsum, dim3(N), dim3(256), 0, c->stream, d_coeffs, nvec, (uint32_t)nrows, sc);
+  hipLaunchKernelGGL(k_mm_digits, dim3((rpad + 255) / 256, N), dim3(256), 0, c->stream, d_coeffs, nvec, ND, (uint32_t)nrows, rpad, NT, cd);
+  hipLaunchKernelGGL(k_mm_colsum, dim3(N), dim3(256), 0, c->stream, d_coeffs, nvec, ND, (uint32_t)nrows, sc);
   AesKey keyx = c->key;
   for (int i = 56; i < 60; i++) keyx.rk[i] ^= 0x80808080u;  // the kernel's keystream bytes come out as A - 128
   {
@@ -313,7 +314,12 @@ int mfh_eval_rows_multi(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d
   }
   HIP_TRY(c, hipGetLastError());
   const uint32_t total = (n + 1) * nvec;
-  hipLaunchKernelGGL(k_evalmm_finish, dim3((total + 127) / 128), dim3(128), 0, c->stream, part, sc, nchunks, ntiles, N, nvec, n, (uint32_t)nrows, d_rops, accumulate);
+  if (ND == 4)
+    hipLaunchKernelGGL(k_evalmm_finish<4>, dim3((total + 127) / 128), dim3(128), 0, c->stream, part, sc, nchunks, ntiles, N, nvec, n, (uint32_t)nrows, d_rops,
+                       accumulate);
+  else
+    hipLaunchKernelGGL(k_evalmm_finish<1>, dim3((total + 127) / 128), dim3(128), 0, c->stream, part, sc, nchunks, ntiles, N, nvec, n, (uint32_t)nrows, d_rops,
+                       accumulate);
   HIP_TRY(c, hipGetLastError());
   return MFH_OK;
 }

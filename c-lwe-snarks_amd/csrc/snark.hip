@@ -396,9 +396,10 @@ int mfh_prove(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, const 
   return mfh_prove_finish(c, d_proof, h_smudge_mag, maglen, h_smudge_sign);
 }
 
-// prover() for a batch of statements under one CRS and SSP: the three CRS regions are expanded ONCE per group of up to 15 proofs and
-// the multiply-accumulate of all their coefficient vectors runs on the matrix cores (mfh_eval_rows_multi, evalmm.hip); the witness
-// pass, the polynomial step and the smudging stay per proof.  Proof b is bit-identical to mfh_prove with the same inputs.
+// prover() for a batch of statements under one CRS and SSP.  The S and AS regions are expanded ONCE per group of up to 15 proofs and
+// the BT+BV region once per up to 60 (b_w's coefficients are witness bits: one byte-digit column per proof), the multiply-accumulate of
+// all their coefficient vectors runs on the matrix cores (mfh_eval_rows_multi, evalmm.hip); the witness pass reads the SSP once per 12
+// statements; the polynomial step and the smudging stay per proof.  Proof b is bit-identical to mfh_prove with the same inputs.
 int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, uint32_t nproofs, const uint8_t *h_witness_bits,
                     size_t bits_stride, const uint32_t *h_delta, const uint8_t *h_smudge_mag, size_t maglen, const uint8_t *h_smudge_sign,
                     uint64_t *d_proofs) {
@@ -417,68 +418,82 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
   const uint32_t ctb = c->P.logq / 8;
   const size_t ctl = (size_t)(n + 1) * ((c->P.logq + 63) / 64);
   const uint64_t ctr_ct = (uint64_t)ctb * n;
-  constexpr uint32_t G = 15;  // proofs per expansion: 30 coefficient vectors x 4 bytes + the ones column = 121 of the 128 digit columns
+  constexpr uint32_t G = 15;   // proofs per S / AS expansion: 30 coefficient vectors x 4 bytes + the ones column = 121 of 128 digit columns
+  constexpr uint32_t SG = 60;  // proofs per BT+BV expansion: one byte column each + the ones column = 61 of 64 digit columns
   HIP_TRY(c, hipSetDevice(c->device));
-  // group scratch: W | H | V (g x d each, in this order: the S region takes (W, H), the AS region (H, V)), CW (G x m), OUT (2G ciphertexts)
-  const size_t words = (size_t)3 * G * d + (size_t)G * m, need = words * 4 + (size_t)2 * G * ctl * 8;
+  // scratch: W | H | V (g x d each, in this order: the S region takes (W, H), the AS region (H, V)), CW (SG x m), ONE (1 word), OUT
+  // (SG ciphertexts, >= 2G), CT_T (1 ciphertext)
+  const size_t words = (size_t)3 * G * d + (size_t)SG * m + 64, need = words * 4 + (size_t)(SG + 1) * ctl * 8;
   if (c->batch_bytes < need) {
     if (c->d_batch) { hipStreamSynchronize(c->stream); hipFree(c->d_batch); c->d_batch = nullptr; c->batch_bytes = 0; }
     HIP_TRY(c, hipMalloc(&c->d_batch, need));
     c->batch_bytes = need;
   }
-  uint32_t *const base = (uint32_t *)c->d_batch, *const CW = base + (size_t)3 * G * d;
-  for (uint32_t g0 = 0; g0 < nproofs; g0 += G) {
-    const uint32_t g = std::min(G, nproofs - g0);
-    uint64_t *proofs = d_proofs + (size_t)g0 * 5 * ctl;
-    uint64_t *OUT = (uint64_t *)((uint8_t *)c->d_batch + words * 4);
-    uint32_t *W = base, *H = W + (size_t)g * d, *V = H + (size_t)g * d;  // g-strided blocks: (W, H) and (H, V) are contiguous 2g-vector matrices
-    // b_w coefficient vectors of the group: (delta, witness bits) -- src/snark.c:143-155
-    uint32_t *h_cw = (uint32_t *)pin_acquire(c, c->pin_cw, (size_t)g * m * 4);
-    if (!h_cw) return MFH_ENOMEM;
-    for (uint32_t b = 0; b < g; b++) {
-      const uint8_t *bits = h_witness_bits + (size_t)(g0 + b) * bits_stride;
-      uint32_t *cw = h_cw + (size_t)b * m;
-      cw[0] = h_delta[g0 + b];
-      for (uint32_t i = 1; i < m; i++) cw[i] = (bits[(i - 1) >> 3] >> ((i - 1) & 7)) & 1;
-    }
-    HIP_TRY(c, hipMemcpyAsync(CW, h_cw, (size_t)g * m * 4, hipMemcpyHostToDevice, c->stream));
-    pin_release(c, c->pin_cw);
-    // per proof: w = delta t + sum_bits v_i, v = w + v_0, h = (v^2 - 1) / t   (src/snark.c:141-169)
-    if (src.dense) {  // the SSP is read once per (at most 12) statements
-      for (uint32_t b0 = 0; b0 < g; b0 += 12) {
-        int rcw = mfh_witness_poly_multi(c, d_ssp, std::min(12u, g - b0), h_witness_bits + (size_t)(g0 + b0) * bits_stride, bits_stride,
-                                         h_delta + g0 + b0, W + (size_t)b0 * d);
-        if (rcw) return rcw;
-      }
-    }
-    for (uint32_t b = 0; b < g; b++) {
-      uint32_t *w = W + (size_t)b * d, *v = V + (size_t)b * d, *h = H + (size_t)b * d;
-      int rc = src.dense ? MFH_OK : mfh_witness_poly(c, d_ssp, h_witness_bits + (size_t)(g0 + b) * bits_stride, h_delta[g0 + b], w);
-      if (rc) return rc;
-      hipLaunchKernelGGL(k_add_slot, g1(d), dim3(256), 0, c->stream, w, src, 1u, d, v);
-      HIP_TRY(c, hipGetLastError());
-      rc = mfh_poly_h(c, v, h);
-      if (rc) return rc;
-    }
-    // one ciphertext of OUT per coefficient vector -> component `slot` of the group's proofs (struct order h | hat_h | hat_v | v_w | b_w)
-    auto scatter = [&](const uint64_t *from, uint32_t slot) -> int {
-      HIP_TRY(c, hipMemcpy2DAsync(proofs + (size_t)slot * ctl, 5 * ctl * 8, from, ctl * 8, ctl * 8, g, hipMemcpyDeviceToDevice, c->stream));
+  uint32_t *const base = (uint32_t *)c->d_batch, *const CW = base + (size_t)3 * G * d, *const ONE = CW + (size_t)SG * m;
+  uint64_t *const OUT = (uint64_t *)((uint8_t *)c->d_batch + words * 4), *const CT_T = OUT + (size_t)SG * ctl;
+  // ct_t = the BT row as a ciphertext (eval_poly of one row with coefficient 1): b_w's delta * ct_t term is added per proof below
+  {
+    const uint32_t one = 1;
+    HIP_TRY(c, hipMemcpyAsync(ONE, &one, 4, hipMemcpyHostToDevice, c->stream));
+    int rc = mfh_eval_rows(c, ctr_ct * 2 * d, 1, d_crs_c8 + (size_t)2 * d * ctb, ONE, nullptr, CT_T, nullptr, 0);
+    if (rc) return rc;
+  }
+  for (uint32_t s0 = 0; s0 < nproofs; s0 += SG) {
+    const uint32_t sg = std::min(SG, nproofs - s0);
+    uint64_t *sproofs = d_proofs + (size_t)s0 * 5 * ctl;
+    // one ciphertext of `from` per coefficient vector -> component `slot` of `count` consecutive proofs (struct order h | hat_h | hat_v | v_w | b_w)
+    auto scatter = [&](const uint64_t *from, uint64_t *proofs, uint32_t count, uint32_t slot) -> int {
+      HIP_TRY(c, hipMemcpy2DAsync(proofs + (size_t)slot * ctl, 5 * ctl * 8, from, ctl * 8, ctl * 8, count, hipMemcpyDeviceToDevice, c->stream));
       return MFH_OK;
     };
-    // BT + BV rows with (delta, bits) -> b_w
-    int rc = mfh_eval_rows_multi(c, ctr_ct * 2 * d, m, d_crs_c8 + (size_t)2 * d * ctb, CW, g, OUT, 0);
-    if (!rc) rc = scatter(OUT, 4);
-    // S rows with (w, h) -> (v_w, h); AS rows with (h, v) -> (hat_h, hat_v): every row expanded once for the whole group
-    if (!rc) rc = mfh_eval_rows_multi(c, 0, d, d_crs_c8, W, 2 * g, OUT, 0);
-    if (!rc) rc = scatter(OUT, 3);
-    if (!rc) rc = scatter(OUT + (size_t)g * ctl, 0);
-    if (!rc) rc = mfh_eval_rows_multi(c, ctr_ct * d, d, d_crs_c8 + (size_t)d * ctb, H, 2 * g, OUT, 0);
-    if (!rc) rc = scatter(OUT, 1);
-    if (!rc) rc = scatter(OUT + (size_t)g * ctl, 2);
+    // ---- b_w = delta ct_t + sum_{bit} ct_{v_i} (src/snark.c:143-155): the bits of all sg statements as byte coefficients over the BT+BV rows
+    uint32_t *h_cw = (uint32_t *)pin_acquire(c, c->pin_cw, (size_t)sg * m * 4);
+    if (!h_cw) return MFH_ENOMEM;
+    for (uint32_t b = 0; b < sg; b++) {
+      const uint8_t *bits = h_witness_bits + (size_t)(s0 + b) * bits_stride;
+      uint32_t *cw = h_cw + (size_t)b * m;
+      cw[0] = 0;  // the BT row: delta can be any residue, its term is added below
+      for (uint32_t i = 1; i < m; i++) cw[i] = (bits[(i - 1) >> 3] >> ((i - 1) & 7)) & 1;
+    }
+    HIP_TRY(c, hipMemcpyAsync(CW, h_cw, (size_t)sg * m * 4, hipMemcpyHostToDevice, c->stream));
+    pin_release(c, c->pin_cw);
+    int rc = mfh_eval_rows_multi(c, ctr_ct * 2 * d, m, d_crs_c8 + (size_t)2 * d * ctb, CW, sg, 1, OUT, 0);
+    if (!rc) rc = scatter(OUT, sproofs, sg, 4);
+    for (uint32_t b = 0; b < sg && !rc; b++) rc = mfh_ct_addmul_ui(c, sproofs + ((size_t)b * 5 + 4) * ctl, CT_T, h_delta[s0 + b], 1);
     if (rc) return rc;
-    for (uint32_t b = 0; b < g; b++) {
-      rc = mfh_prove_finish(c, proofs + (size_t)b * 5 * ctl, h_smudge_mag + (size_t)(g0 + b) * 5 * maglen, maglen, h_smudge_sign + (size_t)(g0 + b) * 5);
+    for (uint32_t g0 = s0; g0 < s0 + sg; g0 += G) {
+      const uint32_t g = std::min(G, s0 + sg - g0);
+      uint64_t *proofs = d_proofs + (size_t)g0 * 5 * ctl;
+      uint32_t *W = base, *H = W + (size_t)g * d, *V = H + (size_t)g * d;  // g-strided blocks: (W, H) and (H, V) are contiguous 2g-vector matrices
+      // per proof: w = delta t + sum_bits v_i, v = w + v_0, h = (v^2 - 1) / t   (src/snark.c:141-169)
+      if (src.dense) {  // the SSP is read once per (at most 12) statements
+        for (uint32_t b0 = 0; b0 < g; b0 += 12) {
+          int rcw = mfh_witness_poly_multi(c, d_ssp, std::min(12u, g - b0), h_witness_bits + (size_t)(g0 + b0) * bits_stride, bits_stride,
+                                           h_delta + g0 + b0, W + (size_t)b0 * d);
+          if (rcw) return rcw;
+        }
+      }
+      for (uint32_t b = 0; b < g; b++) {
+        uint32_t *w = W + (size_t)b * d, *v = V + (size_t)b * d, *h = H + (size_t)b * d;
+        rc = src.dense ? MFH_OK : mfh_witness_poly(c, d_ssp, h_witness_bits + (size_t)(g0 + b) * bits_stride, h_delta[g0 + b], w);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_add_slot, g1(d), dim3(256), 0, c->stream, w, src, 1u, d, v);
+        HIP_TRY(c, hipGetLastError());
+        rc = mfh_poly_h(c, v, h);
+        if (rc) return rc;
+      }
+      // S rows with (w, h) -> (v_w, h); AS rows with (h, v) -> (hat_h, hat_v): every row expanded once for the whole group
+      rc = mfh_eval_rows_multi(c, 0, d, d_crs_c8, W, 2 * g, 4, OUT, 0);
+      if (!rc) rc = scatter(OUT, proofs, g, 3);
+      if (!rc) rc = scatter(OUT + (size_t)g * ctl, proofs, g, 0);
+      if (!rc) rc = mfh_eval_rows_multi(c, ctr_ct * d, d, d_crs_c8 + (size_t)d * ctb, H, 2 * g, 4, OUT, 0);
+      if (!rc) rc = scatter(OUT, proofs, g, 1);
+      if (!rc) rc = scatter(OUT + (size_t)g * ctl, proofs, g, 2);
       if (rc) return rc;
+      for (uint32_t b = 0; b < g; b++) {
+        rc = mfh_prove_finish(c, proofs + (size_t)b * 5 * ctl, h_smudge_mag + (size_t)(g0 + b) * 5 * maglen, maglen, h_smudge_sign + (size_t)(g0 + b) * 5);
+        if (rc) return rc;
+      }
     }
   }
   return MFH_OK;

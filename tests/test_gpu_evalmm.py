@@ -67,6 +67,24 @@ def test_multi_matches_oracle_and_accumulates(ctx, oracle):
         assert np.array_equal(twice[v], ctx.to_host(ctx.ct_add(a, a), np.uint64).reshape(p.n + 1, p.L))
 
 
+def test_multi_one_byte_coefficients(ctx):
+    """coeff_bytes = 1: up to 127 vectors with coefficients < 256 (b_w's witness bits), one digit column each"""
+    p = ctx.params
+    rng = np.random.default_rng(11)
+    nrows, nvec = 200, 70
+    c8 = rng.integers(0, 256, size=nrows * p.ctb, dtype=np.uint8)
+    co = rng.integers(0, 2, size=(nvec, nrows), dtype=np.uint32)
+    co[0, :] = 255
+    co[1, :] = 0
+    co[2, :] = rng.integers(0, 256, size=nrows, dtype=np.uint32)
+    d_c8 = ctx.to_device(c8)
+    off = p.ctr_bt
+    got = ctx.to_host(ctx.eval_rows_multi(off, nrows, d_c8, ctx.to_device(co), nvec, coeff_bytes=1), np.uint64).reshape(nvec, p.n + 1, p.L)
+    for v in (0, 1, 2, 3, 33, 69):
+        ref, _ = ctx.eval_rows(off, nrows, d_c8, ctx.to_device(co[v]))
+        assert np.array_equal(got[v], ctx.to_host(ref, np.uint64).reshape(p.n + 1, p.L)), f"vector {v}"
+
+
 def test_multi_argument_checks(ctx):
     import c_lwe_snarks_amd as mf
 
@@ -77,10 +95,9 @@ def test_multi_argument_checks(ctx):
     assert not ctx.to_host(out).any()
 
 
-@pytest.mark.parametrize("nproofs", [1, 5, 16])
+@pytest.mark.parametrize("nproofs", [1, 5, 16, 62])
 def test_prove_batch_equals_single_proofs(gpu_ctx_factory, oracle, nproofs):
-    """mfh_prove_batch: proof b of the batch == mfh_prove(statement b), bit for bit (groups of 15: 16 = one full + one partial
-    group); the first proof is also checked against the oracle's prover and every proof is accepted by the device verifier."""
+    """mfh_prove_batch: proof b of the batch == mfh_prove(statement b), bit for bit (S / AS groups of 15, BT+BV groups of 60: 16 = one full + one partial group, 62 = two BT+BV groups); the first proof is also checked against the oracle's prover and every proof is accepted by the device verifier."""
     import c_lwe_snarks_amd as mf
 
     p = mf.DEBUG
