@@ -136,6 +136,7 @@ inline int ssp_src(mfh_ctx *c, const uint32_t *d_ssp, mf::SspSrc &src) {
 }
 
 void mfh_poly_destroy(mfh_ctx *c);
+extern "C" int mfh_poly_h_multi(mfh_ctx *c, const uint32_t *d_v, uint32_t *d_h, uint32_t nb);
 int aux_reserve(mfh_ctx *c, size_t bytes);
 
 inline int buf_reserve(mfh_ctx *c, void *&buf, size_t &have, size_t bytes) {

@@ -56,11 +56,13 @@ uint64_t h_powmod(uint64_t a, uint64_t e, uint64_t p) {
 
 // ---- kernels -------------------------------------------------------------------------------------------
 // load `len` coefficients (mod p32) into [3][N] Montgomery residues, zero padded
-__global__ void k_ntt_load(const uint32_t *__restrict__ in, uint32_t len, uint32_t N, Primes3 P, uint32_t *__restrict__ out) {
+// grid.y = 3 * batch everywhere below: blockIdx.y % 3 is the prime, blockIdx.y / 3 the polynomial of the batch; transform buffers are
+// [batch][3][N], so blockIdx.y * N addresses them as before
+__global__ void k_ntt_load(const uint32_t *__restrict__ in, uint32_t len, uint32_t N, Primes3 P, uint32_t *__restrict__ out, size_t in_stride) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
-  const NttPrime q = P.q[blockIdx.y];
-  uint32_t x = i < len ? in[i] : 0u;
+  const NttPrime q = P.q[blockIdx.y % 3];
+  uint32_t x = i < len ? in[(size_t)(blockIdx.y / 3) * in_stride + i] : 0u;
   out[(size_t)blockIdx.y * N + i] = mont_mul(x, q.r2, q.p, q.ninv);  // x * R mod p (x < 2^32, r2 < p: product < p * 2^32)
 }
 
@@ -68,12 +70,12 @@ __global__ void k_ntt_load(const uint32_t *__restrict__ in, uint32_t len, uint32
 __global__ void k_ntt_dif(uint32_t *__restrict__ a, uint32_t N, uint32_t len, const uint32_t *__restrict__ tw, uint32_t tw_stride_n, Primes3 P) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N / 2) return;
-  const NttPrime q = P.q[blockIdx.y];
+  const NttPrime q = P.q[blockIdx.y % 3];
   const uint32_t half = len >> 1;
   const uint32_t j = i & (half - 1);
   const uint32_t s = (i - j) * 2;
   uint32_t *x = a + (size_t)blockIdx.y * N + s + j;
-  const uint32_t w = tw[(size_t)blockIdx.y * tw_stride_n + (size_t)j * (tw_stride_n * 2 / len)];
+  const uint32_t w = tw[(size_t)(blockIdx.y % 3) * tw_stride_n + (size_t)j * (tw_stride_n * 2 / len)];
   uint32_t u = x[0], v = x[half];
   x[0] = add_mod(u, v, q.p);
   x[half] = mont_mul(sub_mod(u, v, q.p), w, q.p, q.ninv);
@@ -82,12 +84,12 @@ __global__ void k_ntt_dif(uint32_t *__restrict__ a, uint32_t N, uint32_t len, co
 __global__ void k_ntt_dit(uint32_t *__restrict__ a, uint32_t N, uint32_t len, const uint32_t *__restrict__ tw, uint32_t tw_stride_n, Primes3 P) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N / 2) return;
-  const NttPrime q = P.q[blockIdx.y];
+  const NttPrime q = P.q[blockIdx.y % 3];
   const uint32_t half = len >> 1;
   const uint32_t j = i & (half - 1);
   const uint32_t s = (i - j) * 2;
   uint32_t *x = a + (size_t)blockIdx.y * N + s + j;
-  const uint32_t w = tw[(size_t)blockIdx.y * tw_stride_n + (size_t)j * (tw_stride_n * 2 / len)];
+  const uint32_t w = tw[(size_t)(blockIdx.y % 3) * tw_stride_n + (size_t)j * (tw_stride_n * 2 / len)];
   uint32_t u = x[0], v = mont_mul(x[half], w, q.p, q.ninv);
   x[0] = add_mod(u, v, q.p);
   x[half] = sub_mod(u, v, q.p);
@@ -101,12 +103,12 @@ __global__ __launch_bounds__(256) void k_ntt_dif_multi(uint32_t *__restrict__ a,
   constexpr int R = 1 << K;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (N >> K)) return;
-  const NttPrime q = P.q[blockIdx.y];
+  const NttPrime q = P.q[blockIdx.y % 3];
   const uint32_t qd = len >> K;              // distance between a thread's elements
   const uint32_t j = i & (qd - 1);
   const uint32_t s = (i - j) << K;
   uint32_t *x = a + (size_t)blockIdx.y * N + s + j;
-  const uint32_t *t = tw + (size_t)blockIdx.y * half_max;
+  const uint32_t *t = tw + (size_t)(blockIdx.y % 3) * half_max;
   uint32_t v[R];
 #pragma unroll
   for (int m = 0; m < R; m++) v[m] = x[(size_t)m * qd];
@@ -136,12 +138,12 @@ __global__ __launch_bounds__(256) void k_ntt_dit_multi(uint32_t *__restrict__ a,
   constexpr int R = 1 << K;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (N >> K)) return;
-  const NttPrime q = P.q[blockIdx.y];
+  const NttPrime q = P.q[blockIdx.y % 3];
   const uint32_t qd = len >> 1;              // distance between a thread's elements = half of the first stage
   const uint32_t j = i & (qd - 1);
   const uint32_t s = (i - j) << K;
   uint32_t *x = a + (size_t)blockIdx.y * N + s + j;
-  const uint32_t *t = tw + (size_t)blockIdx.y * half_max;
+  const uint32_t *t = tw + (size_t)(blockIdx.y % 3) * half_max;
   uint32_t v[R];
 #pragma unroll
   for (int m = 0; m < R; m++) v[m] = x[(size_t)m * qd];
@@ -169,10 +171,10 @@ template <bool DIT>
 __global__ __launch_bounds__(256) void k_ntt_lds(uint32_t *__restrict__ a, uint32_t N, uint32_t B, const uint32_t *__restrict__ tw,
                                                  uint32_t half_max, Primes3 P) {
   __shared__ uint32_t sm[2048];
-  const NttPrime q = P.q[blockIdx.y];
+  const NttPrime q = P.q[blockIdx.y % 3];
   const uint32_t BL = 1u << B;
   uint32_t *x = a + (size_t)blockIdx.y * N + (size_t)blockIdx.x * BL;
-  const uint32_t *t = tw + (size_t)blockIdx.y * half_max;
+  const uint32_t *t = tw + (size_t)(blockIdx.y % 3) * half_max;
   for (uint32_t i = threadIdx.x; i < BL; i += 256) sm[i] = x[i];
   __syncthreads();
   for (uint32_t st = 0; st < B; st++) {
@@ -204,13 +206,13 @@ __global__ __launch_bounds__(256) void k_ntt_lds_mul(uint32_t *__restrict__ a, c
                                                      const uint32_t *__restrict__ tw, const uint32_t *__restrict__ twi, uint32_t half_max, Primes3 P) {
   __shared__ uint32_t sa[2048];
   __shared__ uint32_t sb[2048];
-  const NttPrime q = P.q[blockIdx.y];
+  const NttPrime q = P.q[blockIdx.y % 3];
   const uint32_t BL = 1u << B;
   const size_t base = (size_t)blockIdx.y * N + (size_t)blockIdx.x * BL;
-  const uint32_t *t = tw + (size_t)blockIdx.y * half_max, *ti = twi + (size_t)blockIdx.y * half_max;
+  const uint32_t *t = tw + (size_t)(blockIdx.y % 3) * half_max, *ti = twi + (size_t)(blockIdx.y % 3) * half_max;
   for (uint32_t i = threadIdx.x; i < BL; i += 256) {
     sa[i] = a[base + i];
-    if (b) sb[i] = b[base + i];
+    if (b) sb[i] = b_is_hat ? b[(size_t)(blockIdx.y % 3) * N + (size_t)blockIdx.x * BL + i] : b[base + i];  // a cached transform is shared by the batch
   }
   __syncthreads();
   const bool fwd_b = b && !b_is_hat;
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(256) void k_ntt_lds_mul(uint32_t *__restrict__ a, c
 __global__ void k_pointwise(uint32_t *__restrict__ a, const uint32_t *__restrict__ b, uint32_t N, Primes3 P) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
-  const NttPrime q = P.q[blockIdx.y];
+  const NttPrime q = P.q[blockIdx.y % 3];
   size_t o = (size_t)blockIdx.y * N + i;
   a[o] = mont_mul(a[o], b[o], q.p, q.ninv);
 }
@@ -259,9 +261,11 @@ struct Crt {
   uint32_t p1_mod, p1p2_mod;                 // p1 mod p32, p1*p2 mod p32
 };
 // residues (Montgomery, unscaled inverse transform) -> coefficient mod p32, first `count` coefficients
-__global__ void k_crt(const uint32_t *__restrict__ r, uint32_t N, uint32_t count, Primes3 P, Crt C, uint32_t *__restrict__ out) {
+__global__ void k_crt(const uint32_t *__restrict__ r, uint32_t N, uint32_t count, Primes3 P, Crt C, uint32_t *__restrict__ out, size_t out_stride) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
+  r += (size_t)blockIdx.y * 3 * N;  // grid.y = batch
+  out += (size_t)blockIdx.y * out_stride;
   const NttPrime q1 = P.q[0], q2 = P.q[1], q3 = P.q[2];
   uint32_t x1 = mont_mul(r[i], C.ninv_std[0], q1.p, q1.ninv);
   uint32_t r2 = mont_mul(r[(size_t)N + i], C.ninv_std[1], q2.p, q2.ninv);
@@ -277,9 +281,12 @@ __global__ void k_crt(const uint32_t *__restrict__ r, uint32_t N, uint32_t count
   out[i] = red_p32(acc);
 }
 
-__global__ void k_reverse(const uint32_t *__restrict__ in, int64_t top, uint32_t count, uint32_t *__restrict__ out) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;  // out[i] = in[top - i] (0 if top - i < 0)
+__global__ void k_reverse(const uint32_t *__restrict__ in, int64_t top, uint32_t count, uint32_t *__restrict__ out, size_t in_stride = 0,
+                          size_t out_stride = 0) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;  // out[i] = in[top - i] (0 if top - i < 0); grid.y = batch
   if (i >= count) return;
+  in += (size_t)blockIdx.y * in_stride;
+  out += (size_t)blockIdx.y * out_stride;
   int64_t s = top - (int64_t)i;
   out[i] = s >= 0 ? in[s] : 0u;
 }
@@ -290,17 +297,20 @@ __global__ void k_two_minus(uint32_t *__restrict__ e, uint32_t count) {  // e <-
   uint32_t neg = v ? P32 - v : 0u;
   e[i] = i == 0 ? red_p32((uint64_t)neg + 2) : neg;
 }
-__global__ void k_sub_const0(uint32_t *__restrict__ a, uint32_t c) {  // a[0] -= c
-  if (threadIdx.x == 0 && blockIdx.x == 0) a[0] = red_p32((uint64_t)a[0] + P32 - c);
+__global__ void k_sub_const0(uint32_t *__restrict__ a, uint32_t c, size_t stride = 0) {  // a[0] -= c; grid.x = batch
+  if (threadIdx.x == 0) a[(size_t)blockIdx.x * stride] = red_p32((uint64_t)a[(size_t)blockIdx.x * stride] + P32 - c);
 }
 __global__ void k_add_vec(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, uint32_t count, uint32_t *__restrict__ out) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < count) out[i] = red_p32((uint64_t)a[i] + b[i]);
 }
 // out[i] = q[n-1-i] for i < min(n, d), zero above (quotient reversed back, first d coefficients)
-__global__ void k_unreverse_pad(const uint32_t *__restrict__ qrev, uint32_t n, uint32_t d, uint32_t *__restrict__ out) {
+__global__ void k_unreverse_pad(const uint32_t *__restrict__ qrev, uint32_t n, uint32_t d, uint32_t *__restrict__ out, size_t in_stride = 0,
+                                size_t out_stride = 0) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= d) return;
+  qrev += (size_t)blockIdx.y * in_stride;
+  out += (size_t)blockIdx.y * out_stride;
   out[i] = i < n ? qrev[n - 1 - i] : 0u;
 }
 
@@ -317,6 +327,7 @@ struct PolyState {
   uint32_t *d_bufA = nullptr, *d_bufB = nullptr;  // [3][Nmax] transform buffers
   uint32_t *d_tmp = nullptr;  // Nmax coefficients
   uint32_t *d_tmp2 = nullptr;
+  uint32_t nb_cap = 1;  // polynomials the buffers above hold side by side (poly_batch_reserve)
   // per-SSP quotient precomputation
   bool have_t = false;
   uint32_t d = 0, dt = 0, n = 0, logN2 = 0;
@@ -389,6 +400,27 @@ int poly_init(mfh_ctx *c, uint32_t logmax) {
   return MFH_OK;
 }
 
+// grow the transform / scratch buffers to hold nb polynomials side by side ([nb][3][Nmax] and [nb][Nmax])
+int poly_batch_reserve(mfh_ctx *c, uint32_t nb) {
+  PolyState *S = c->poly;
+  if (nb <= S->nb_cap) return MFH_OK;
+  const size_t Nmax = (size_t)1 << S->logmax;
+  hipStreamSynchronize(c->stream);
+  for (uint32_t **p : {&S->d_bufA, &S->d_bufB, &S->d_tmp, &S->d_tmp2}) {
+    if (*p) hipFree(*p);
+    *p = nullptr;
+  }
+  S->nb_cap = 1;
+  bool ok = hipMalloc(&S->d_bufA, (size_t)nb * 3 * Nmax * 4) == hipSuccess && hipMalloc(&S->d_bufB, (size_t)nb * 3 * Nmax * 4) == hipSuccess &&
+            hipMalloc(&S->d_tmp, (size_t)nb * Nmax * 4) == hipSuccess && hipMalloc(&S->d_tmp2, (size_t)nb * Nmax * 4) == hipSuccess;
+  if (!ok) {
+    c->err = "poly_batch_reserve: device allocation failed";
+    return MFH_ENOMEM;
+  }
+  S->nb_cap = nb;
+  return MFH_OK;
+}
+
 uint32_t ceil_log2(size_t x) {
   uint32_t l = 0;
   while (((size_t)1 << l) < x) l++;
@@ -396,13 +428,13 @@ uint32_t ceil_log2(size_t x) {
 }
 
 // the top (register) stages of a forward / inverse transform; the low B = min(logN, 11) stages run in LDS
-void forward_top(mfh_ctx *c, uint32_t *buf, uint32_t logN) {
+void forward_top(mfh_ctx *c, uint32_t *buf, uint32_t logN, uint32_t nb = 1) {
   PolyState *S = c->poly;
   const uint32_t N = 1u << logN, half_max = 1u << (S->logmax - 1);
   uint32_t top = logN - std::min(logN, 11u), len = N;
   while (top) {
     const uint32_t k = std::min(top, 3u);
-    dim3 g(((N >> k) + 255) / 256, 3);
+    dim3 g(((N >> k) + 255) / 256, 3 * nb);
     if (k == 3) hipLaunchKernelGGL(k_ntt_dif_multi<3>, g, dim3(256), 0, c->stream, buf, N, len, S->d_tw, half_max, S->P);
     else if (k == 2) hipLaunchKernelGGL(k_ntt_dif_multi<2>, g, dim3(256), 0, c->stream, buf, N, len, S->d_tw, half_max, S->P);
     else hipLaunchKernelGGL(k_ntt_dif_multi<1>, g, dim3(256), 0, c->stream, buf, N, len, S->d_tw, half_max, S->P);
@@ -410,14 +442,14 @@ void forward_top(mfh_ctx *c, uint32_t *buf, uint32_t logN) {
     top -= k;
   }
 }
-void inverse_top(mfh_ctx *c, uint32_t *buf, uint32_t logN) {
+void inverse_top(mfh_ctx *c, uint32_t *buf, uint32_t logN, uint32_t nb = 1) {
   PolyState *S = c->poly;
   const uint32_t N = 1u << logN, half_max = 1u << (S->logmax - 1);
   const uint32_t B = std::min(logN, 11u);
   uint32_t top = logN - B, len = 2u << B;
   while (top) {
     const uint32_t k = std::min(top, 3u);
-    dim3 g(((N >> k) + 255) / 256, 3);
+    dim3 g(((N >> k) + 255) / 256, 3 * nb);
     if (k == 3) hipLaunchKernelGGL(k_ntt_dit_multi<3>, g, dim3(256), 0, c->stream, buf, N, len, S->d_twi, half_max, S->P);
     else if (k == 2) hipLaunchKernelGGL(k_ntt_dit_multi<2>, g, dim3(256), 0, c->stream, buf, N, len, S->d_twi, half_max, S->P);
     else hipLaunchKernelGGL(k_ntt_dit_multi<1>, g, dim3(256), 0, c->stream, buf, N, len, S->d_twi, half_max, S->P);
@@ -444,8 +476,9 @@ Crt make_crt(const PolyState *S, uint32_t logN) {
 }
 
 // c[0..keep) = (a * b)[0..keep) mod p32.  bhat != null: use that precomputed forward transform (size 2^logN) instead of b.
+// nb > 1: nb products side by side, polynomial k at a + k a_stride (and b + k a_stride), result at out + k out_stride.
 int poly_mul(mfh_ctx *c, const uint32_t *a, uint32_t la, const uint32_t *b, uint32_t lb, const uint32_t *bhat, uint32_t logN_hat,
-             uint32_t *out, uint32_t keep) {
+             uint32_t *out, uint32_t keep, uint32_t nb = 1, size_t a_stride = 0, size_t out_stride = 0) {
   PolyState *S = c->poly;
   uint32_t logN = bhat ? logN_hat : ceil_log2((size_t)la + lb - 1);
   if (logN < 1) logN = 1;
@@ -454,8 +487,8 @@ int poly_mul(mfh_ctx *c, const uint32_t *a, uint32_t la, const uint32_t *b, uint
     return MFH_EINVAL;
   }
   const uint32_t N = 1u << logN, half_max = 1u << (S->logmax - 1), B = std::min(logN, 11u);
-  hipLaunchKernelGGL(k_ntt_load, dim3((N + 255) / 256, 3), dim3(256), 0, c->stream, a, la, N, S->P, S->d_bufA);
-  forward_top(c, S->d_bufA, logN);
+  hipLaunchKernelGGL(k_ntt_load, dim3((N + 255) / 256, 3 * nb), dim3(256), 0, c->stream, a, la, N, S->P, S->d_bufA, a_stride);
+  forward_top(c, S->d_bufA, logN, nb);
   const uint32_t *rhs = bhat;  // already fully transformed
   int is_hat = 1;
   if (!bhat) {
@@ -463,15 +496,15 @@ int poly_mul(mfh_ctx *c, const uint32_t *a, uint32_t la, const uint32_t *b, uint
     if (b == a && lb == la) {
       rhs = nullptr;  // square
     } else {
-      hipLaunchKernelGGL(k_ntt_load, dim3((N + 255) / 256, 3), dim3(256), 0, c->stream, b, lb, N, S->P, S->d_bufB);
-      forward_top(c, S->d_bufB, logN);
+      hipLaunchKernelGGL(k_ntt_load, dim3((N + 255) / 256, 3 * nb), dim3(256), 0, c->stream, b, lb, N, S->P, S->d_bufB, a_stride);
+      forward_top(c, S->d_bufB, logN, nb);
       rhs = S->d_bufB;
     }
   }
   // low forward stages of both operands, pointwise product, low inverse stages: one kernel, the block never leaves LDS
-  hipLaunchKernelGGL(k_ntt_lds_mul, dim3(N >> B, 3), dim3(256), 0, c->stream, S->d_bufA, rhs, is_hat, N, B, S->d_tw, S->d_twi, half_max, S->P);
-  inverse_top(c, S->d_bufA, logN);
-  hipLaunchKernelGGL(k_crt, g1(keep), dim3(256), 0, c->stream, S->d_bufA, N, keep, S->P, make_crt(S, logN), out);
+  hipLaunchKernelGGL(k_ntt_lds_mul, dim3(N >> B, 3 * nb), dim3(256), 0, c->stream, S->d_bufA, rhs, is_hat, N, B, S->d_tw, S->d_twi, half_max, S->P);
+  inverse_top(c, S->d_bufA, logN, nb);
+  hipLaunchKernelGGL(k_crt, dim3((keep + 255) / 256, nb), dim3(256), 0, c->stream, S->d_bufA, N, keep, S->P, make_crt(S, logN), out, out_stride);
   HIP_TRY(c, hipGetLastError());
   return MFH_OK;
 }
@@ -541,7 +574,7 @@ int mfh_poly_prepare_t(mfh_ctx *c, const uint32_t *d_t) {
     k = k2;
   }
   // forward transform of G at the size used per proof
-  hipLaunchKernelGGL(k_ntt_load, dim3((N2 + 255) / 256, 3), dim3(256), 0, c->stream, S->d_G, n, N2, S->P, S->d_Ghat);
+  hipLaunchKernelGGL(k_ntt_load, dim3((N2 + 255) / 256, 3), dim3(256), 0, c->stream, S->d_G, n, N2, S->P, S->d_Ghat, (size_t)0);
   forward(c, S->d_Ghat, S->logN2);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -549,28 +582,34 @@ int mfh_poly_prepare_t(mfh_ctx *c, const uint32_t *d_t) {
   return MFH_OK;
 }
 
-int mfh_poly_h(mfh_ctx *c, const uint32_t *d_v, uint32_t *d_h) {
-  if (!c || !d_v || !d_h) return MFH_EINVAL;
+// h_k = floor((v_k^2 - 1) / t) for nb polynomials side by side (v_k = d_v + k d, h_k = d_h + k d): the same launches as for one, nb times
+// the work each
+int mfh_poly_h_multi(mfh_ctx *c, const uint32_t *d_v, uint32_t *d_h, uint32_t nb) {
+  if (!c || !d_v || !d_h || !nb) return MFH_EINVAL;
   PolyState *S = c->poly;
   if (!S || !S->have_t) {
     c->err = "mfh_poly_prepare_t has not been called for this SSP";
     return MFH_EINVAL;
   }
   HIP_TRY(c, hipSetDevice(c->device));
+  int rc = poly_batch_reserve(c, nb);
+  if (rc) return rc;
   const uint32_t d = S->d, n = S->n;
+  const size_t Nmax = (size_t)1 << S->logmax;
   // A = v^2 - 1 : 2d-1 coefficients (nominal degree 2d-2)
-  int rc = poly_mul(c, d_v, d, d_v, d, nullptr, 0, S->d_tmp, 2 * d - 1);
+  rc = poly_mul(c, d_v, d, d_v, d, nullptr, 0, S->d_tmp, 2 * d - 1, nb, d, Nmax);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_sub_const0, dim3(1), dim3(64), 0, c->stream, S->d_tmp, 1u);
+  hipLaunchKernelGGL(k_sub_const0, dim3(nb), dim3(64), 0, c->stream, S->d_tmp, 1u, Nmax);
   // rev(A)[:n]
-  hipLaunchKernelGGL(k_reverse, g1(n), dim3(256), 0, c->stream, S->d_tmp, (int64_t)(2 * d - 2), n, S->d_tmp2);
+  hipLaunchKernelGGL(k_reverse, dim3((n + 255) / 256, nb), dim3(256), 0, c->stream, S->d_tmp, (int64_t)(2 * d - 2), n, S->d_tmp2, Nmax, Nmax);
   // qrev = rev(A)[:n] * G mod x^n
-  rc = poly_mul(c, S->d_tmp2, n, nullptr, n, S->d_Ghat, S->logN2, S->d_tmp, n);
+  rc = poly_mul(c, S->d_tmp2, n, nullptr, n, S->d_Ghat, S->logN2, S->d_tmp, n, nb, Nmax, Nmax);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_unreverse_pad, g1(d), dim3(256), 0, c->stream, S->d_tmp, n, d, d_h);
+  hipLaunchKernelGGL(k_unreverse_pad, dim3((d + 255) / 256, nb), dim3(256), 0, c->stream, S->d_tmp, n, d, d_h, Nmax, (size_t)d);
   HIP_TRY(c, hipGetLastError());
   return MFH_OK;
 }
+int mfh_poly_h(mfh_ctx *c, const uint32_t *d_v, uint32_t *d_h) { return mfh_poly_h_multi(c, d_v, d_h, 1); }
 
 int mfh_poly_add(mfh_ctx *c, const uint32_t *d_a, const uint32_t *d_b, size_t count, uint32_t *d_out) {
   if (!c || !d_a || !d_b || !d_out) return MFH_EINVAL;

@@ -479,9 +479,10 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
         if (rc) return rc;
         hipLaunchKernelGGL(k_add_slot, g1(d), dim3(256), 0, c->stream, w, src, 1u, d, v);
         HIP_TRY(c, hipGetLastError());
-        rc = mfh_poly_h(c, v, h);
-        if (rc) return rc;
+        (void)h;
       }
+      rc = mfh_poly_h_multi(c, V, H, g);  // the group's polynomial steps side by side: the launches of one, g times the work each
+      if (rc) return rc;
       // S rows with (w, h) -> (v_w, h); AS rows with (h, v) -> (hat_h, hat_v): every row expanded once for the whole group
       rc = mfh_eval_rows_multi(c, 0, d, d_crs_c8, W, 2 * g, 4, OUT, 0);
       if (!rc) rc = scatter(OUT, proofs, g, 3);

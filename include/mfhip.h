@@ -158,6 +158,8 @@ int mfh_poly_prepare_t(mfh_ctx *ctx, const uint32_t *d_t);
 int mfh_ssp_prepare(mfh_ctx *ctx, const uint32_t *d_ssp); /* = mfh_poly_prepare_t(slot 0) */
 /* h = floor((v^2 - 1) / t), first d coefficients (nmod_poly_pow/sub/div, src/snark.c:166-169).  v: d coefficients. */
 int mfh_poly_h(mfh_ctx *ctx, const uint32_t *d_v, uint32_t *d_h);
+/* the same for nb polynomials side by side (v_k at d_v + k d, h_k at d_h + k d): one set of launches for the whole batch */
+int mfh_poly_h_multi(mfh_ctx *ctx, const uint32_t *d_v, uint32_t *d_h, uint32_t nb);
 
 /* The 2d+m plaintexts setup() encrypts, in stream order: s^i | alpha s^i | beta t(s) | beta v_i(s), i=1..m-1
  * (src/snark.c:73-110; the Horner values nmod_poly_evaluate_nmod are computed as dot products with the powers of s). */
