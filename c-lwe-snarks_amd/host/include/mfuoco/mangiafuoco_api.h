@@ -108,6 +108,9 @@ bool verifier(ssp_t ssp, vrs_t vrs, proof_t pi);
 /* The shim keeps the last SSP it uploaded (keyed by host pointer) resident in HBM; call this after changing the
  * bytes of an SSP buffer in place. */
 void mfuoco_gpu_invalidate(void);
+/* prover() for `count` statements under one CRS and SSP: rows expanded once per group of proofs, multiply-accumulate on the matrix
+ * cores; every proof is what prover() would produce with the same randomness.  pis[k] initialised by proof_init. */
+void mfuoco_prover_batch(proof_t *pis, crs_t crs, ssp_t ssp, mpz_t *witnesses, size_t count);
 /* select the GPU (default 0, or $MFUOCO_GPU); must precede the first call */
 void mfuoco_gpu_set_device(int device);
 

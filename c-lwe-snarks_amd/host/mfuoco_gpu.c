@@ -472,6 +472,40 @@ void prover(proof_t pi, crs_t crs, ssp_t ssp, mpz_t witness)
   ct_from_dev(pi->b_w, G.d_proof + 4 * CTL, GAMMA_N + 1);
 }
 
+/* prover() for `count` statements under one CRS and SSP (not in the reference): the CRS rows are expanded once per group of proofs
+ * and the multiply-accumulate runs on the matrix cores (mfh_prove_batch).  Entropy per proof as in prover(): delta, then 5 x
+ * [80-byte magnitude, sign byte].  pis[k] must be initialised (proof_init). */
+void mfuoco_prover_batch(proof_t *pis, crs_t crs, ssp_t ssp, mpz_t *witnesses, size_t count)
+{
+  if (!count) return;
+  gpu();
+  use_seed(crs->seed);
+  ssp_resident(ssp);
+  HK(hipMemcpy(G.d_crs, crs->s, CT_BYTES * GAMMA_D, hipMemcpyHostToDevice));
+  HK(hipMemcpy(G.d_crs + CT_BYTES * GAMMA_D, crs->as, CT_BYTES * GAMMA_D, hipMemcpyHostToDevice));
+  HK(hipMemcpy(G.d_crs + 2 * CT_BYTES * GAMMA_D, crs->t, CT_BYTES, hipMemcpyHostToDevice));
+  HK(hipMemcpy(G.d_crs + (2 * GAMMA_D + 1) * CT_BYTES, crs->v, CT_BYTES * (GAMMA_M - 1), hipMemcpyHostToDevice));
+  const size_t stride = (GAMMA_M + 7) / 8 + 8, maglen = GAMMA_LOG_SMUDGING / 8;
+  uint8_t *bits = calloc(count, stride), *mag = malloc(count * 5 * maglen), *sign = malloc(count * 5);
+  uint32_t *delta = malloc(count * 4);
+  uint64_t *d_out = NULL;
+  HK(hipMalloc((void **)&d_out, count * 5 * CTL * 8));
+  for (size_t k = 0; k < count; k++) {
+    if (mpz_sizeinbase(witnesses[k], 2) > GAMMA_M + 8) die("prover: witness wider than M bits");
+    mpz_export(bits + k * stride, NULL, -1, 1, -1, 0, witnesses[k]);
+    delta[k] = (uint32_t)rand_modp_();
+    for (int q = 0; q < 5; q++)
+      if (getrandom(mag + (k * 5 + q) * maglen, maglen, GRND_NONBLOCK) < 0 || getrandom(sign + k * 5 + q, 1, GRND_NONBLOCK) < 0) perror("getrandom");
+  }
+  CK(mfh_prove_batch(G.ctx, G.d_crs, G.d_ssp, (uint32_t)count, bits, stride, delta, mag, maglen, sign, d_out));
+  for (size_t k = 0; k < count; k++) {
+    mpz_t *cts[5] = { pis[k]->h, pis[k]->hat_h, pis[k]->hat_v, pis[k]->v_w, pis[k]->b_w };
+    for (int q = 0; q < 5; q++) ct_from_dev(cts[q], d_out + (k * 5 + q) * CTL, GAMMA_N + 1);
+  }
+  HK(hipFree(d_out));
+  free(bits); free(mag); free(sign); free(delta);
+}
+
 static uint64_t horner_modp(const uint8_t *slot, uint64_t x)
 {
   unsigned __int128 r = 0;

@@ -167,6 +167,15 @@ static void t_snark(void)
   CHECK(verifier(ssp, vrs, pi));                   /* :105-107 */
   mpz_add_ui(pi->v_w[GAMMA_N], pi->v_w[GAMMA_N], 1);
   CHECK(!verifier(ssp, vrs, pi));
+  { /* three statements in one batch: the witness twice (accepted) and a corrupted witness (rejected) */
+    proof_t pb[3];
+    mpz_t wit[3];
+    for (int k = 0; k < 3; k++) { proof_init(pb[k]); mpz_init_set(wit[k], witness); }
+    mpz_combit(wit[1], 3);
+    mfuoco_prover_batch(pb, crs, ssp, wit, 3);
+    CHECK(verifier(ssp, vrs, pb[0]) && !verifier(ssp, vrs, pb[1]) && verifier(ssp, vrs, pb[2]));
+    for (int k = 0; k < 3; k++) { proof_clear(pb[k]); mpz_clear(wit[k]); }
+  }
   proof_clear(pi);
   crs_clear(crs);
   free(ssp);
