@@ -49,7 +49,7 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 // n = 32 q + r of rows 32 K + 16 h + e, e = 0..15, at cd[((K * NT + q) * 64 + 32 h + r) * 16 + e].  A unit's (RT rows) fragments are one
 // contiguous RT * N bytes.  Column n = ND v + w holds byte w of c_v[i] minus 128; column ND nvec is the ones column; every other
 // column, and every row >= nrows, is zero (such rows and columns then add nothing to G').
-__global__ void k_mm_digits(const uint32_t *__restrict__ coeff, uint32_t nvec, uint32_t ND, uint32_t nrows, uint32_t rpad, uint32_t NT,
+__global__ void k_mm_digits(const uint32_t *__restrict__ coeff, uint32_t nvec, uint32_t ND, uint32_t nrows, uint32_t rpad, uint32_t NT, int wide,
                             int8_t *__restrict__ cd) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
   if (i >= rpad) return;
@@ -59,8 +59,14 @@ __global__ void k_mm_digits(const uint32_t *__restrict__ coeff, uint32_t nvec, u
     if (v < nvec) dgt = (int)((coeff[(uint64_t)v * nrows + i] >> (8 * w)) & 255u) - 128;
     else if (n == ND * nvec) dgt = 1;
   }
-  const uint32_t K = i >> 5, h = (i >> 4) & 1, e = i & 15, q = n >> 5, r = n & 31;
-  cd[((((uint64_t)K * NT + q) * 64 + 32 * h + r) << 4) + e] = (int8_t)dgt;
+  const uint32_t e = i & 15;
+  if (!wide) {  // v_mfma_i32_32x32x32_i8: k-step = 32 rows, lane = 32 h + r
+    const uint32_t K = i >> 5, h = (i >> 4) & 1, q = n >> 5, r = n & 31;
+    cd[((((uint64_t)K * NT + q) * 64 + 32 * h + r) << 4) + e] = (int8_t)dgt;
+  } else {      // v_mfma_i32_16x16x64_i8: k-step = 64 rows, lane = 16 g + c, NT column tiles of 16
+    const uint32_t K = i >> 6, g = (i >> 4) & 3, q = n >> 4, c = n & 15;
+    cd[((((uint64_t)K * NT + q) * 64 + 16 * g + c) << 4) + e] = (int8_t)dgt;
+  }
 }
 // sc[n] = sum_i C'[i][n] = sum_i (byte w of c_v[i]) - 128 nrows, from the coefficient vectors (signed)
 __global__ void k_mm_colsum(const uint32_t *__restrict__ coeff, uint32_t nvec, uint32_t ND, uint32_t nrows, int64_t *__restrict__ sc) {
@@ -218,15 +224,145 @@ __global__ __launch_bounds__(1024) void k_evalmm(AesKey key /* rk[56..59] ^ 0x80
   }
 }
 
+// ---- the wide variant: 256 digit columns (63 four-byte vectors = 31 proofs' pairs per expansion) ---------------------------------
+// Same scheme with v_mfma_i32_16x16x64_i8: the column tile shrinks to 2 coordinates (176 byte positions = 11 row tiles of 16, one per
+// wave, 16 column tiles x 4 accumulator registers each = the same 64 accumulator VGPRs), a row segment is 184 bytes = exactly 12 AES
+// blocks when the stream offset is a multiple of 8 (it is for every CRS region), a unit is 256 rows (3072 blocks = 3 full rounds of
+// the 16 waves).  The unit's digit fragments (64 KiB) do not fit LDS beside the table and the tile: they are staged per 64-row
+// k-step (16 KiB), double buffered, by the waves that have no row tile (11..15), one barrier per k-step.
+constexpr int CT2 = 2, MB2 = CT2 * SB, MT2 = MB2 / 16, RT2 = 256, TS2 = 192, BPR2 = 12, NQ2 = 16, N2 = 16 * NQ2;
+static_assert(MB2 % 16 == 0 && MT2 <= 16 && RT2 * BPR2 == 3 * 1024, "wide tile geometry");
+
+__global__ __launch_bounds__(1024) void k_evalmm16(AesKey key /* rk[56..59] ^ 0x80808080 */, const uint32_t *__restrict__ g_t0, uint64_t off,
+                                                   uint32_t n, uint32_t nrows, uint32_t rows_per_chunk, const uint8_t *__restrict__ c8,
+                                                   const int8_t *__restrict__ cd, int *__restrict__ part) {
+  struct __attribute__((aligned(16))) Lds {
+    uint32_t lt[mf::kTabBytes / 4];  // first: LDS address 0 (aes_dev.hpp)
+    uint8_t tile[RT2 * TS2];
+    v4i bfrag[2][NQ2][64];           // the current and the next k-step's coefficient-digit fragments
+    uint32_t spanc[RT2][2][5];
+  };
+  __shared__ Lds lds;
+  mf::lds_fill_tab(lds.lt, g_t0);
+  const uint8_t *tab = reinterpret_cast<const uint8_t *>(lds.lt);
+  const mf::AesLane L = mf::aes_lane();
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t j0 = blockIdx.x * CT2;
+  const uint32_t nks = j0 >= n ? 0u : min((uint32_t)CT2, n - j0);
+  const bool has_b = j0 + CT2 > n && j0 <= n;
+  const uint32_t r0 = blockIdx.y * rows_per_chunk;
+  const uint32_t r1 = min(nrows, r0 + rows_per_chunk);
+
+  v4i acc[NQ2];
+#pragma unroll
+  for (int q = 0; q < NQ2; q++) acc[q] = v4i{0, 0, 0, 0};
+
+  const uint32_t c16 = lane & 15, g4 = lane >> 4;
+  const uint32_t m = wave * 16 + c16;  // byte position, < MB2 for waves < MT2
+  const uint32_t mcol = (m / SB) * VB + (m % SB);
+  const uint32_t hstep = (n * VB) & 15;
+
+  auto span_task = [&](uint32_t u0, uint32_t task) {  // task = 2 * local row + which span
+    const uint32_t lr = task >> 1, which = task & 1;
+    const uint64_t row = (uint64_t)u0 + lr;
+    if (row >= r1 || !nks) return;
+    const RowGeom g = row_geom(off, row, n, j0, nks);
+    const uint64_t sp0 = g.cb0 >> 8, sp1 = (g.cb0 + g.nblk - 1) >> 8;
+    if (which && sp1 == sp0) return;
+    uint32_t sc[5];
+    mf::aes_span_consts(tab, L, key, sp0 + which, sc);
+#pragma unroll
+    for (int i = 0; i < 5; i++) lds.spanc[lr][which][i] = sc[i];
+  };
+  const v4i *cdv = reinterpret_cast<const v4i *>(cd);
+
+  __syncthreads();
+  if (tid < 2 * RT2) span_task(r0, tid);
+  __syncthreads();
+  for (uint32_t u0 = r0; u0 < r1; u0 += RT2) {
+    // first k-step's digit fragments: 16 KiB contiguous, one 16-byte load per thread, in flight under the expansion
+    const v4i bstage = cdv[(uint64_t)(u0 >> 6) * NQ2 * 64 + tid];
+    // ---- (1) expansion: block slot s -> (local row s / 12, block s % 12): exactly three slots per thread
+    for (uint32_t s2 = tid; s2 < RT2 * BPR2; s2 += 1024) {
+      const uint32_t lr = s2 / BPR2, k = s2 % BPR2;
+      const uint64_t row = (uint64_t)u0 + lr;
+      if (row >= r1) continue;
+      const RowGeom g = row_geom(off, row, n, j0, nks);
+      if (k >= g.nblk) continue;
+      const uint64_t ctr = g.cb0 + k;
+      const uint32_t *scp = lds.spanc[lr][(uint32_t)((ctr >> 8) - (g.cb0 >> 8))];
+      uint32_t sc[5] = {scp[0], scp[1], scp[2], scp[3], scp[4]};
+      uint32_t w[4];
+      mf::aes256_ctr_block_sc(tab, L, key, ctr, sc, w);
+      *reinterpret_cast<uint4 *>(&lds.tile[lr * TS2 + 16 * k]) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    (&lds.bfrag[0][0][0])[tid] = bstage;
+    __syncthreads();
+    if (has_b) {
+      for (uint32_t s2 = tid; s2 < RT2 * VB; s2 += 1024) {
+        const uint32_t lr = s2 / VB, k = s2 % VB;
+        const uint64_t row = (uint64_t)u0 + lr;
+        if (row >= r1) continue;
+        const RowGeom g = row_geom(off, row, n, j0, nks);
+        lds.tile[lr * TS2 + g.head + nks * VB + k] = (uint8_t)(c8[row * VB + k] ^ 0x80);
+      }
+      __syncthreads();
+    }
+    // ---- (2) per 64-row k-step: waves 0..10 MFMA from bfrag[ks & 1]; waves 11..15 stage the next k-step's fragments (and, once,
+    //          the next unit's span constants)
+    const uint32_t head0 = row_geom(off, u0, n, j0, 1).head;
+#pragma unroll 1
+    for (int ks = 0; ks < RT2 / 64; ks++) {
+      if (wave < MT2) {
+        if ((uint64_t)u0 + ks * 64 < r1) {  // else: whole k-step beyond the chunk (its digits are zero anyway)
+          const uint32_t lrb = ks * 64 + 16 * g4;
+          uint32_t aw[4];
+#pragma unroll
+          for (int e4 = 0; e4 < 4; e4++) {
+            uint32_t x = 0;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+              const uint32_t lr = lrb + 4 * e4 + e;
+              x |= (uint32_t)lds.tile[lr * TS2 + ((head0 + hstep * lr) & 15) + mcol] << (8 * e);
+            }
+            aw[e4] = x;
+          }
+          const v4i a = {(int)aw[0], (int)aw[1], (int)aw[2], (int)aw[3]};
+#pragma unroll
+          for (int q = 0; q < NQ2; q++) acc[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, lds.bfrag[ks & 1][q][lane], acc[q], 0, 0, 0);
+        }
+      } else {
+        const uint32_t t2 = tid - MT2 * 64;  // 0..319
+        if (ks + 1 < RT2 / 64) {
+          const v4i *src = cdv + ((uint64_t)(u0 >> 6) + ks + 1) * NQ2 * 64;
+          v4i *dst = &lds.bfrag[(ks + 1) & 1][0][0];
+          for (uint32_t i = t2; i < NQ2 * 64; i += 320) dst[i] = src[i];
+        }
+        if (ks == 0)
+          for (uint32_t task = t2; task < 2 * RT2; task += 320) span_task(u0 + RT2, task);
+      }
+      __syncthreads();
+    }
+  }
+  if (wave < MT2) {
+    int *p = part + ((uint64_t)blockIdx.y * gridDim.x + blockIdx.x) * MB2 * N2;
+#pragma unroll
+    for (int q = 0; q < NQ2; q++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) p[(uint64_t)(wave * 16 + 4 * g4 + e) * N2 + 16 * q + c16] = acc[q][e];
+  }
+}
+
 // out_v[j] = sum_{u,w} G[(j,u)][(v,w)] 256^(u + w) mod 2^704 with G = G' + 128 SA[(j,u)] + 128 sc[(v,w)] + 16384 nrows, G' and
 // SA = G'[.][ones column] summed over the row chunks; thread = (vector v fastest, coordinate j)
 template <int ND>
 __global__ void k_evalmm_finish(const int *__restrict__ part, const int64_t *__restrict__ sc, uint32_t nchunks, uint32_t ntiles, uint32_t N,
-                                uint32_t nvec, uint32_t n, uint32_t nrows, uint64_t *__restrict__ rops /* [nvec][(n+1) * 12] */, int accumulate) {
+                                uint32_t nvec, uint32_t n, uint32_t nrows, uint32_t ct, uint64_t *__restrict__ rops /* [nvec][(n+1) * 12] */,
+                                int accumulate) {
   const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t v = gid % nvec, j = gid / nvec;
   if (j > n) return;
-  const uint32_t tile = j / CT, jj = j % CT;
+  const uint32_t tile = j / ct, jj = j % ct, MBv = ct * SB;  // ct coordinates per column tile (4: k_evalmm, 2: k_evalmm16)
   uint32_t *out = reinterpret_cast<uint32_t *>(rops + ((uint64_t)v * (n + 1) + j) * 12);
   int64_t corr[ND];
 #pragma unroll
@@ -238,7 +374,7 @@ __global__ void k_evalmm_finish(const int *__restrict__ part, const int64_t *__r
       const uint32_t mm = jj * SB + 4 * l + k;
       int64_t g[ND] = {}, sa = 0;
       for (uint32_t ch = 0; ch < nchunks; ch++) {
-        const int *row = part + (((uint64_t)ch * ntiles + tile) * MB + mm) * N;
+        const int *row = part + (((uint64_t)ch * ntiles + tile) * MBv + mm) * N;
 #pragma unroll
         for (int w = 0; w < ND; w++) g[w] += row[ND * v + w];
         sa += row[ND * nvec];
@@ -268,44 +404,50 @@ extern "C" {
 int mfh_eval_rows_multi(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d_c8, const uint32_t *d_coeffs, uint32_t nvec, uint32_t coeff_bytes,
                         uint64_t *d_rops, int accumulate) {
   if (!c || !d_rops || !nvec || (nrows && (!d_c8 || !d_coeffs)) || (coeff_bytes != 1 && coeff_bytes != 4)) return MFH_EINVAL;
-  const uint32_t ND = coeff_bytes, MAXV = 127 / ND;
+  const uint32_t ND = coeff_bytes;
+  const uint32_t n = c->P.n;
+  // 128 digit columns: k_evalmm (32x32x32 MFMA, 4-coordinate tiles); up to 256: k_evalmm16 (16x16x64, 2-coordinate tiles), which
+  // needs every row segment to start at byte 0 or 8 of an AES block: stream offset and row length multiples of 8
+  const bool wide = nvec * ND + 1 > 128;
+  if (nvec * ND + 1 > 256) { c->err = "mfh_eval_rows_multi: at most 63 four-byte (255 one-byte) coefficient vectors per call (256 digit columns)"; return MFH_EINVAL; }
+  if (wide && ((off & 7) || (((uint64_t)n * VB) & 7))) { c->err = "mfh_eval_rows_multi: more than 128 digit columns need off and the row length to be multiples of 8"; return MFH_EINVAL; }
   if (!c->have_seed) { c->err = "mfh_set_seed has not been called"; return MFH_EINVAL; }
   if (c->P.logq != 736) { c->err = "mfh_eval_rows_multi: only logq = 736 has a matrix-core path"; return MFH_EUNSUPPORTED; }
-  if (nvec > MAXV) { c->err = "mfh_eval_rows_multi: at most 31 four-byte (127 one-byte) coefficient vectors per call (128 digit columns)"; return MFH_EINVAL; }
   if (nrows > 0xffffffffu - 256) return MFH_EINVAL;
   HIP_TRY(c, hipSetDevice(c->device));
-  const uint32_t n = c->P.n;
   const size_t ctl = (size_t)(n + 1) * 12;
   if (nrows == 0) {
     if (!accumulate) HIP_TRY(c, hipMemsetAsync(d_rops, 0, (size_t)nvec * ctl * 8, c->stream));
     return MFH_OK;
   }
-  const uint32_t NT = nvec * ND + 1 <= 64 ? 2 : 4, N = 32 * NT;
-  const uint32_t ntiles = (n + 1 + CT - 1) / CT;
-  // row chunks: fill the CUs about three times over; an int32 accumulator holds 132 104 rows
-  // row chunks: 368 column tiles x 2 chunks = 736 workgroups = 2.9 rounds of the 256 CUs (one workgroup per CU at a time); an int32
-  // accumulator holds 131 071 rows
-  uint32_t nchunks = nrows >= 8 * RT ? 2 : 1;
+  const uint32_t ct = wide ? CT2 : CT, mb = ct * SB, rt = wide ? RT2 : RT;
+  const uint32_t NT = wide ? NQ2 : (nvec * ND + 1 <= 64 ? 2 : 4), N = wide ? N2 : 32 * NT;
+  const uint32_t ntiles = (n + 1 + ct - 1) / ct;
+  // row chunks: column tiles x 2 chunks = 736 (1472) workgroups = 2.9 (5.75) rounds of the 256 CUs (one workgroup per CU at a time); an
+  // int32 accumulator holds 131 071 rows
+  uint32_t nchunks = nrows >= 8 * rt ? 2 : 1;
   nchunks = std::max<uint32_t>(nchunks, ((uint32_t)nrows + 131070) / 131071);
   uint32_t rpc = ((uint32_t)nrows + nchunks - 1) / nchunks;
-  rpc = (rpc + RT - 1) / RT * RT;
+  rpc = (rpc + rt - 1) / rt * rt;
   nchunks = ((uint32_t)nrows + rpc - 1) / rpc;
-  const uint32_t rpad = nchunks * rpc;  // a multiple of RT: digit rows past nrows are zero
+  const uint32_t rpad = nchunks * rpc;  // a multiple of the unit: digit rows past nrows are zero
   const size_t cd_bytes = ((size_t)N * rpad + 255) & ~(size_t)255;
   const size_t sc_bytes = 256 * 8;
-  const size_t part_bytes = (size_t)nchunks * ntiles * MB * N * 4;
+  const size_t part_bytes = (size_t)nchunks * ntiles * mb * N * 4;
   int rc = ws_reserve(c, cd_bytes + sc_bytes + part_bytes);
   if (rc) return rc;
   int8_t *cd = (int8_t *)c->ws;
   int64_t *sc = (int64_t *)((uint8_t *)c->ws + cd_bytes);
   int *part = (int *)((uint8_t *)c->ws + cd_bytes + sc_bytes);
-  hipLaunchKernelGGL(k_mm_digits, dim3((rpad + 255) / 256, N), dim3(256), 0, c->stream, d_coeffs, nvec, ND, (uint32_t)nrows, rpad, NT, cd);
+  hipLaunchKernelGGL(k_mm_digits, dim3((rpad + 255) / 256, N), dim3(256), 0, c->stream, d_coeffs, nvec, ND, (uint32_t)nrows, rpad, NT, wide ? 1 : 0, cd);
   hipLaunchKernelGGL(k_mm_colsum, dim3(N), dim3(256), 0, c->stream, d_coeffs, nvec, ND, (uint32_t)nrows, sc);
   AesKey keyx = c->key;
   for (int i = 56; i < 60; i++) keyx.rk[i] ^= 0x80808080u;  // the kernel's keystream bytes come out as A - 128
   {
     Timer t(c, 7, nrows);
-    if (NT == 2)
+    if (wide)
+      hipLaunchKernelGGL(k_evalmm16, dim3(ntiles, nchunks), dim3(1024), 0, c->stream, keyx, c->d_t0, off, n, (uint32_t)nrows, rpc, d_c8, cd, part);
+    else if (NT == 2)
       hipLaunchKernelGGL(k_evalmm<2>, dim3(ntiles, nchunks), dim3(1024), 0, c->stream, keyx, c->d_t0, off, n, (uint32_t)nrows, rpc, d_c8, cd, rpad,
                          part);
     else
@@ -315,11 +457,11 @@ int mfh_eval_rows_multi(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d
   HIP_TRY(c, hipGetLastError());
   const uint32_t total = (n + 1) * nvec;
   if (ND == 4)
-    hipLaunchKernelGGL(k_evalmm_finish<4>, dim3((total + 127) / 128), dim3(128), 0, c->stream, part, sc, nchunks, ntiles, N, nvec, n, (uint32_t)nrows, d_rops,
-                       accumulate);
+    hipLaunchKernelGGL(k_evalmm_finish<4>, dim3((total + 127) / 128), dim3(128), 0, c->stream, part, sc, nchunks, ntiles, N, nvec, n, (uint32_t)nrows, ct,
+                       d_rops, accumulate);
   else
-    hipLaunchKernelGGL(k_evalmm_finish<1>, dim3((total + 127) / 128), dim3(128), 0, c->stream, part, sc, nchunks, ntiles, N, nvec, n, (uint32_t)nrows, d_rops,
-                       accumulate);
+    hipLaunchKernelGGL(k_evalmm_finish<1>, dim3((total + 127) / 128), dim3(128), 0, c->stream, part, sc, nchunks, ntiles, N, nvec, n, (uint32_t)nrows, ct,
+                       d_rops, accumulate);
   HIP_TRY(c, hipGetLastError());
   return MFH_OK;
 }

@@ -33,6 +33,7 @@ def _vectors(rng, nvec, nrows, kind):
 
 @pytest.mark.parametrize("nrows,nvec,kind,off_rows", [
     (1, 1, "rand", 0), (5, 2, "rand", 3), (128, 3, "edges", 0), (129, 12, "rand", 7), (300, 13, "edges", 1), (1100, 31, "rand", 2), (64, 16, "edges", 0),
+    (3, 32, "rand", 0), (257, 40, "edges", 1), (700, 63, "rand", 3),  # > 31 vectors: the 256-column kernel (k_evalmm16)
 ])
 def test_multi_equals_single_vector_path(ctx, nrows, nvec, kind, off_rows):
     p = ctx.params
@@ -71,7 +72,7 @@ def test_multi_one_byte_coefficients(ctx):
     """coeff_bytes = 1: up to 127 vectors with coefficients < 256 (b_w's witness bits), one digit column each"""
     p = ctx.params
     rng = np.random.default_rng(11)
-    nrows, nvec = 200, 70
+    nrows, nvec = 300, 200
     c8 = rng.integers(0, 256, size=nrows * p.ctb, dtype=np.uint8)
     co = rng.integers(0, 2, size=(nvec, nrows), dtype=np.uint32)
     co[0, :] = 255
@@ -80,7 +81,7 @@ def test_multi_one_byte_coefficients(ctx):
     d_c8 = ctx.to_device(c8)
     off = p.ctr_bt
     got = ctx.to_host(ctx.eval_rows_multi(off, nrows, d_c8, ctx.to_device(co), nvec, coeff_bytes=1), np.uint64).reshape(nvec, p.n + 1, p.L)
-    for v in (0, 1, 2, 3, 33, 69):
+    for v in (0, 1, 2, 3, 33, 69, 127, 128, 199):
         ref, _ = ctx.eval_rows(off, nrows, d_c8, ctx.to_device(co[v]))
         assert np.array_equal(got[v], ctx.to_host(ref, np.uint64).reshape(p.n + 1, p.L)), f"vector {v}"
 
@@ -90,7 +91,9 @@ def test_multi_argument_checks(ctx):
 
     p = ctx.params
     with pytest.raises(mf.MfhError):
-        ctx.eval_rows_multi(0, 4, ctx.zeros(4 * p.ctb), ctx.zeros(32 * 4 * 4), 32)
+        ctx.eval_rows_multi(0, 4, ctx.zeros(4 * p.ctb), ctx.zeros(64 * 4 * 4), 64)
+    with pytest.raises(mf.MfhError):  # the 256-column kernel needs row segments at byte 0 or 8 of an AES block
+        ctx.eval_rows_multi(4, 4, ctx.zeros(4 * p.ctb), ctx.zeros(40 * 4 * 4), 40)
     out = ctx.eval_rows_multi(0, 0, ctx.zeros(16), ctx.zeros(16), 2)  # no rows: zero ciphertexts
     assert not ctx.to_host(out).any()
 

@@ -10,7 +10,7 @@ ctx.set_seed(bytes(range(40)))
 nrows = int(sys.argv[1]) if len(sys.argv) > 1 else p.d
 g = torch.Generator(device="cuda").manual_seed(1)
 c8 = torch.randint(0, 256, (nrows * p.ctb,), dtype=torch.uint8, device="cuda", generator=g)
-for nvec in (2, 12, 24):
+for nvec in (2, 30, 62):
     co = torch.randint(0, 2**32 - 6, (nvec, nrows), dtype=torch.int64, device="cuda", generator=g).to(torch.int32).view(torch.uint8)
     out = ctx.eval_rows_multi(p.ctr_s, nrows, c8, co, nvec)
     ctx.set_timing(True); ctx.timing_drain("evalmm")
