@@ -121,9 +121,9 @@ def main():
                          "default); 'proofs' = every rank proves its own statements, no collective (weak scaling)")
     ap.add_argument("--mode", choices=["batch", "single"], default=None,
                     help="batch (default at the default workload): a step = --batch statements per GPU proved by mfh_prove_batch (CRS regions "
-                         "expanded once per group of 15, MAC on the matrix cores), ranks take disjoint statements, no collective; "
+                         "expanded once per group of 31, MAC on the matrix cores), ranks take disjoint statements, no collective; "
                          "single: a step = one prover() call, CRS rows sharded over the ranks + lane all-reduces")
-    ap.add_argument("--batch", type=int, default=60, help="statements per GPU per step in batch mode")
+    ap.add_argument("--batch", type=int, default=124, help="statements per GPU per step in batch mode")
     ap.add_argument("--no-overlap", action="store_true", help="run the prover on one stream (A/B check of the side-stream overlap)")
     ap.add_argument("--resident-gb", type=float, default=200.0, help="HBM budget for the resident CRS image per GPU")
     ap.add_argument("--workload", choices=["default", "config4", "config5"], default="default",
@@ -356,17 +356,17 @@ def main():
         gbs = rows_mm * row_bytes_b / (avg_mm * 1e-3) / 1e9 if mmn else None
         batched = {"value": world * nb * args.steps / el_b, "unit": "proofs/s", "ms_per_step": el_b / args.steps * 1e3, "statements_per_gpu_per_step": nb,
                    "valid_accepted_invalid_rejected_and_identical_to_single_proof_path": all_ok,
-                   "roofline": {"bound": "hbm", "kernel": "k_evalmm<4> (AES-256-CTR expansion of the rows, once per group of 15 proofs, + i8 MFMA "
-                                                            "multiply-accumulate of the group's 30 (S, AS) / 15 (BT+BV) coefficient vectors)",
+                   "roofline": {"bound": "hbm", "kernel": "k_evalmm16 (AES-256-CTR expansion of the rows, once per group of 31 proofs, + i8 MFMA "
+                                                            "multiply-accumulate of the group's 62 coefficient vectors; the BT+BV region runs once per 124 proofs on k_evalmm<4>)",
                                 "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (gbs / HBM_PEAK_GBS) if gbs else None, "traffic": traffic_mm,
                                 "launches": mmn, "avg_launch_ms": avg_mm, "rows_per_launch": rows_mm, "bytes_per_row": row_bytes_b,
                                 "note": "algorithmic bytes = expanded row bytes, regenerated with AES on the CU (LDS T-tables): LDS-lookup / VALU "
-                                        "bound, ~0 HBM bytes; the MFMA work (2 x 129448 x 128 x rows int8 ops) is ~5 % of the kernel",
+                                        "bound, ~0 HBM bytes; the MFMA work (2 x 129448 x 256 x rows int8 ops) is a few % of the kernel",
                                 "aes_gblocks_per_s": blocks_mm / (avg_mm * 1e-3) / 1e9 if mmn else None,
                                 "lds_lookup_roofline": {"achieved_gblocks_per_s": blocks_mm / (avg_mm * 1e-3) / 1e9 if mmn else None,
                                                         "peak_gblocks_per_s": 256 * 2.4e9 * 64 / (201 * 2.15) / 1e9,
                                                         "frac": (blocks_mm / (avg_mm * 1e-3) / 1e9) / (256 * 2.4e9 * 64 / (201 * 2.15) / 1e9) if mmn else None},
-                                "mfma_int8_tops": 2.0 * 129448 * 128 * rows_mm / (avg_mm * 1e-3) / 1e12 if mmn else None}}
+                                "mfma_int8_tops": 2.0 * 129448 * 256 * rows_mm / (avg_mm * 1e-3) / 1e12 if mmn else None}}
 
     # ---- LWE batch (BASELINE config 1/2: one batch of 65 536 encryptions, rows at stream offset k*135240)
     enc_per_s = None
@@ -456,7 +456,7 @@ def main():
             head = {"value": batched["value"], "ms_per_step": batched["ms_per_step"], "scaling": "weak", "roofline": batched["roofline"],
                     "proof_accepted": batched["valid_accepted_invalid_rejected_and_identical_to_single_proof_path"],
                     "config": {"workload": base_workload + f"; a step = {args.batch} statements per GPU (same circuit and CRS; half with the satisfying witness, half with random ones; own randomness) through "
-                                           "mfh_prove_batch: each CRS region is expanded once per group of 15 proofs and the group's multiply-accumulate "
+                                           "mfh_prove_batch: the S / AS regions are expanded once per group of 31 proofs (BT+BV once per 124) and the group's multiply-accumulate "
                                            "runs on the matrix cores; every proof is bit-identical to the single-proof prover()'s",
                                "rows_per_proof": rows_crs, "statements_per_gpu_per_step": args.batch,
                                "sharding": f"{world} ranks, disjoint statements, no collective" if world > 1 else "single GPU"}}

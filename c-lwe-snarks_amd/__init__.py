@@ -371,7 +371,7 @@ class Context:
         return out
 
     def prove_batch(self, d_crs, d_ssp, witness_bits_list, deltas, smudge_mags, smudge_signs, maglen=80, out=None):
-        """prover() for len(witness_bits_list) statements under one CRS: regions expanded once per group of 15, MAC on the matrix cores"""
+        """prover() for len(witness_bits_list) statements under one CRS: regions expanded once per group of 31, MAC on the matrix cores"""
         p = self.params
         nb = len(witness_bits_list)
         stride = (p.m + 6) // 8

@@ -184,8 +184,8 @@ int mfh_prove(mfh_ctx *ctx, const uint8_t *d_crs_c8, const uint32_t *d_ssp, cons
 int mfh_verify(mfh_ctx *ctx, const uint32_t *d_ssp, uint32_t alpha, uint32_t beta, uint32_t s, const uint64_t *d_sk,
                const uint64_t *d_proofs, size_t count, uint8_t *d_ok);
 
-/* prover() for nproofs statements under ONE CRS and SSP.  The S and AS regions are expanded once per group of up to 15 proofs, the
- * BT+BV region once per up to 60, and the multiply-accumulate of the coefficient vectors runs on the matrix cores (mfh_eval_rows_multi); proof b is bit-identical to
+/* prover() for nproofs statements under ONE CRS and SSP.  The S and AS regions are expanded once per group of up to 31 proofs, the
+ * BT+BV region once per up to 124, and the multiply-accumulate of the coefficient vectors runs on the matrix cores (mfh_eval_rows_multi); proof b is bit-identical to
  * mfh_prove(witness b, delta b, smudging b).  h_witness_bits: nproofs bit strings, bits_stride bytes apart; h_delta: nproofs values
  * < p; h_smudge_mag: nproofs x 5 x maglen bytes; h_smudge_sign: nproofs x 5 bytes; d_proofs: nproofs x 5 ciphertexts.
  * Regenerates the keystream (no resident CRS image may be set); logq = 736 only. */
@@ -222,8 +222,9 @@ size_t mfh_workspace_bytes(const mfh_ctx *ctx);
 /* eval_poly (src/lwe.c:160-178) for MANY coefficient vectors over the same nrows CRS rows -- the S / AS / BV regions of a batch of
  * proofs under one CRS: the rows are expanded once and the multiply-accumulate runs on the matrix cores (i8 MFMA over 8-bit
  * keystream bytes x coefficient bytes; exact integer arithmetic, same result as nvec calls of mfh_eval_rows).
- * d_coeffs = nvec vectors of nrows uint32, vector-major; coeff_bytes = 4: any uint32 value, nvec <= 31; coeff_bytes = 1: the caller
- * guarantees every coefficient < 256 (only the low byte is used), nvec <= 127.  d_rops = nvec ciphertexts, vector-major.
+ * d_coeffs = nvec vectors of nrows uint32, vector-major; coeff_bytes = 4: any uint32 value, nvec <= 63; coeff_bytes = 1: the caller
+ * guarantees every coefficient < 256 (only the low byte is used), nvec <= 255.  More than 128 digit columns (nvec * coeff_bytes + 1)
+ * select the 256-column kernel, which needs off and the row length n * CT_BYTES to be multiples of 8 (true for every CRS region).  d_rops = nvec ciphertexts, vector-major.
  * logq = 736 only (MFH_EUNSUPPORTED otherwise). */
 int mfh_eval_rows_multi(mfh_ctx *ctx, uint64_t off, size_t nrows, const uint8_t *d_c8, const uint32_t *d_coeffs, uint32_t nvec,
                         uint32_t coeff_bytes, uint64_t *d_rops, int accumulate);
