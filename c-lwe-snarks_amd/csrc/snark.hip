@@ -5,6 +5,8 @@
 // of the stream offsets CTR_S / CTR_AS / CTR_BT / CTR_BV (src/snark.h:8-12).  The reference keeps four mallocs
 // (struct crs, src/snark.h:27-33); the host shim copies between the two.
 #include <algorithm>
+#include <cstring>
+#include <vector>
 
 #include "ctx.hpp"
 
@@ -491,8 +493,23 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
       if (!rc) rc = scatter(OUT, proofs, g, 1);
       if (!rc) rc = scatter(OUT + (size_t)g * ctl, proofs, g, 2);
       if (rc) return rc;
-      for (uint32_t b = 0; b < g; b++) {
-        rc = mfh_prove_finish(c, proofs + (size_t)b * 5 * ctl, h_smudge_mag + (size_t)(g0 + b) * 5 * maglen, maglen, h_smudge_sign + (size_t)(g0 + b) * 5);
+      // smudging of the whole group in two launches: h, hat_h, hat_v, v_w with draws 0..3, then v_w AGAIN with draw 4; b_w never
+      // (src/snark.c:185-189).  A zero magnitude leaves a ciphertext unchanged.
+      std::vector<uint8_t> mags((size_t)g * 5 * maglen), signs((size_t)g * 5);
+      for (int pass = 0; pass < 2; pass++) {
+        std::fill(mags.begin(), mags.end(), 0);
+        std::fill(signs.begin(), signs.end(), 0);
+        for (uint32_t b = 0; b < g; b++) {
+          const uint8_t *pm = h_smudge_mag + (size_t)(g0 + b) * 5 * maglen, *ps = h_smudge_sign + (size_t)(g0 + b) * 5;
+          if (pass == 0) {
+            memcpy(&mags[(size_t)b * 5 * maglen], pm, 4 * maglen);
+            memcpy(&signs[(size_t)b * 5], ps, 4);
+          } else {
+            memcpy(&mags[((size_t)b * 5 + 3) * maglen], pm + 4 * maglen, maglen);
+            signs[(size_t)b * 5 + 3] = ps[4];
+          }
+        }
+        rc = mfh_ct_smudge(c, proofs, (size_t)g * 5, mags.data(), maglen, signs.data());
         if (rc) return rc;
       }
     }
