@@ -229,7 +229,8 @@ __global__ __launch_bounds__(1024) void k_evalmm(AesKey key /* rk[56..59] ^ 0x80
 // wave, 16 column tiles x 4 accumulator registers each = the same 64 accumulator VGPRs), a row segment is 184 bytes = exactly 12 AES
 // blocks when the stream offset is a multiple of 8 (it is for every CRS region), a unit is 256 rows (3072 blocks = 3 full rounds of
 // the 16 waves).  The unit's digit fragments (64 KiB) do not fit LDS beside the table and the tile: they are staged per 64-row
-// k-step (16 KiB), double buffered, by the waves that have no row tile (11..15), one barrier per k-step.
+// k-step (16 KiB), double buffered, by the waves that have no row tile (11..15; they prefetch the fragments into their idle accumulator
+// registers under the expansion), one barrier per k-step.
 constexpr int CT2 = 2, MB2 = CT2 * SB, MT2 = MB2 / 16, RT2 = 256, TS2 = 192, BPR2 = 12, NQ2 = 16, N2 = 16 * NQ2;
 static_assert(MB2 % 16 == 0 && MT2 <= 16 && RT2 * BPR2 == 3 * 1024, "wide tile geometry");
 
@@ -282,6 +283,18 @@ __global__ __launch_bounds__(1024) void k_evalmm16(AesKey key /* rk[56..59] ^ 0x
   for (uint32_t u0 = r0; u0 < r1; u0 += RT2) {
     // first k-step's digit fragments: 16 KiB contiguous, one 16-byte load per thread, in flight under the expansion
     const v4i bstage = cdv[(uint64_t)(u0 >> 6) * NQ2 * 64 + tid];
+    // the other k-steps' fragments: the waves without a row tile fetch them NOW, into the (for them unused) accumulator registers, so
+    // that the loads land under the expansion and staging them later costs no global latency
+    if (wave >= MT2) {
+      const uint32_t t2 = tid - MT2 * 64;
+#pragma unroll
+      for (int k2 = 1; k2 < RT2 / 64; k2++)
+#pragma unroll
+        for (int i2 = 0; i2 < 4; i2++) {
+          const uint32_t idx = t2 + 320 * i2;
+          if (idx < NQ2 * 64) acc[(k2 - 1) * 4 + i2] = cdv[((uint64_t)(u0 >> 6) + k2) * NQ2 * 64 + idx];
+        }
+    }
     // ---- (1) expansion: block slot s -> (local row s / 12, block s % 12): exactly three slots per thread
     for (uint32_t s2 = tid; s2 < RT2 * BPR2; s2 += 1024) {
       const uint32_t lr = s2 / BPR2, k = s2 % BPR2;
@@ -311,7 +324,7 @@ __global__ __launch_bounds__(1024) void k_evalmm16(AesKey key /* rk[56..59] ^ 0x
     // ---- (2) per 64-row k-step: waves 0..10 MFMA from bfrag[ks & 1]; waves 11..15 stage the next k-step's fragments (and, once,
     //          the next unit's span constants)
     const uint32_t head0 = row_geom(off, u0, n, j0, 1).head;
-#pragma unroll 1
+#pragma unroll
     for (int ks = 0; ks < RT2 / 64; ks++) {
       if (wave < MT2) {
         if ((uint64_t)u0 + ks * 64 < r1) {  // else: whole k-step beyond the chunk (its digits are zero anyway)
@@ -328,15 +341,22 @@ __global__ __launch_bounds__(1024) void k_evalmm16(AesKey key /* rk[56..59] ^ 0x
             aw[e4] = x;
           }
           const v4i a = {(int)aw[0], (int)aw[1], (int)aw[2], (int)aw[3]};
+#ifndef MM_SKIP_MFMA
 #pragma unroll
           for (int q = 0; q < NQ2; q++) acc[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, lds.bfrag[ks & 1][q][lane], acc[q], 0, 0, 0);
+#else
+          acc[0][0] += a[0] + a[1] + a[2] + a[3];
+#endif
         }
       } else {
         const uint32_t t2 = tid - MT2 * 64;  // 0..319
         if (ks + 1 < RT2 / 64) {
-          const v4i *src = cdv + ((uint64_t)(u0 >> 6) + ks + 1) * NQ2 * 64;
           v4i *dst = &lds.bfrag[(ks + 1) & 1][0][0];
-          for (uint32_t i = t2; i < NQ2 * 64; i += 320) dst[i] = src[i];
+#pragma unroll
+          for (int i2 = 0; i2 < 4; i2++) {
+            const uint32_t idx = t2 + 320 * i2;
+            if (idx < NQ2 * 64) dst[idx] = acc[ks * 4 + i2];
+          }
         }
         if (ks == 0)
           for (uint32_t task = t2; task < 2 * RT2; task += 320) span_task(u0 + RT2, task);
