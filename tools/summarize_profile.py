@@ -40,7 +40,7 @@ for name in ("fetch", "write", "sq"):
         continue
     agg = defaultdict(lambda: defaultdict(list))
     for r in csv.DictReader(open(f)):
-        agg[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        agg[r["Kernel_Name"][:80]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, cs in agg.items():
         for c, v in cs.items():
             res.setdefault(k, {})[c] = {"launches": len(v), "mean": sum(v) / len(v), "max": max(v)}
@@ -54,6 +54,15 @@ if ev2 and "FETCH_SIZE" in ev2 and "WRITE_SIZE" in ev2:
     json.dump({"kernel": "k_eval<736,2>", "fetch_bytes_x2_corrected": fetch, "write_bytes": write, "hbm_bytes_per_launch": fetch + write,
                "note": "separate --pmc passes; FETCH_SIZE doubled per the gfx950 correction"}, open(os.path.join(out_dir, "traffic_eval2.json"), "w"), indent=1)
     print("traffic", fetch + write)
+mm = next((v for k, v in res.items() if "k_evalmm16" in k), None)
+if mm and "FETCH_SIZE" in mm and "WRITE_SIZE" in mm:
+    fetch = mm["FETCH_SIZE"]["mean"] * 1024 * 2
+    write = mm["WRITE_SIZE"]["mean"] * 1024
+    json.dump({"kernel": "k_evalmm16", "fetch_bytes_x2_corrected": fetch, "write_bytes": write, "hbm_bytes_per_launch": fetch + write,
+               "note": "separate --pmc passes; FETCH_SIZE doubled per the gfx950 correction (upper bound: the kernel reads the 3 MB compressed CRS "
+                       "region and the 8 MB digit matrix, and writes 132 MB of int32 partial products)"},
+              open(os.path.join(out_dir, "traffic_evalmm.json"), "w"), indent=1)
+    print("traffic evalmm", fetch + write)
 mr = next((v for k, v in res.items() if k.startswith("void k_mac_resident<736, 2>")), None)
 if mr and "FETCH_SIZE" in mr and "WRITE_SIZE" in mr:
     fetch = mr["FETCH_SIZE"]["mean"] * 1024 * 2
