@@ -84,7 +84,7 @@ EXPORTS = [
     "mfh_ctx_create", "mfh_ctx_destroy", "mfh_set_stream", "mfh_sync", "mfh_last_error", "mfh_set_seed",
     "mfh_keystream", "mfh_sample_rows", "mfh_ct_add", "mfh_ct_mul_ui", "mfh_ct_addmul_ui", "mfh_eval_rows",
     "mfh_encrypt_rows", "mfh_decrypt", "mfh_ct_smudge", "mfh_ssp_upload", "mfh_witness_poly", "mfh_version",
-    "mfh_workspace_bytes", "mfh_last_kernel_ms", "mfh_set_timing", "mfh_set_overlap", "mfh_eval_rows_multi", "mfh_prove_batch", "mfh_witness_poly_multi", "mfh_poly_h_multi", "mfh_poly_mul", "mfh_poly_add", "mfh_poly_prepare_t",
+    "mfh_workspace_bytes", "mfh_last_kernel_ms", "mfh_set_timing", "mfh_set_overlap", "mfh_eval_rows_multi", "mfh_prove_batch", "mfh_crs_mm_image_bytes", "mfh_crs_expand_mm", "mfh_crs_set_resident_mm", "mfh_witness_poly_multi", "mfh_poly_h_multi", "mfh_poly_mul", "mfh_poly_add", "mfh_poly_prepare_t",
     "mfh_ssp_prepare", "mfh_poly_h", "mfh_setup_messages", "mfh_setup", "mfh_prove",
     "mfh_prove_partial", "mfh_prove_finish", "mfh_ct_to_lanes", "mfh_ct_from_lanes", "mfh_timing_drain", "mfh_add_dotp",
     "mfh_resident_row_bytes", "mfh_crs_expand", "mfh_eval_rows_resident", "mfh_crs_set_resident",
@@ -130,6 +130,9 @@ def load_library():
         "mfh_eval_rows_multi": (i32, [vp, u64, sz, vp, vp, u32, u32, vp, i32]),
         "mfh_poly_h_multi": (i32, [vp, vp, vp, u32]),
         "mfh_witness_poly_multi": (i32, [vp, vp, u32, ctypes.c_char_p, sz, vp, vp]),
+        "mfh_crs_mm_image_bytes": (sz, [vp]),
+        "mfh_crs_expand_mm": (i32, [vp, vp, vp]),
+        "mfh_crs_set_resident_mm": (i32, [vp, vp]),
         "mfh_prove_batch": (i32, [vp, vp, vp, u32, ctypes.c_char_p, sz, vp, ctypes.c_char_p, sz, ctypes.c_char_p, vp]),
         "mfh_poly_mul": (i32, [vp, vp, sz, vp, sz, vp]),
         "mfh_poly_add": (i32, [vp, vp, vp, sz, vp]),
@@ -369,6 +372,16 @@ class Context:
         self._chk(self.lib.mfh_prove(self._h, _ptr(d_crs), _ptr(d_ssp), bytes(witness_bits), delta, bytes(smudge_mag), maglen,
                                      bytes(smudge_sign), _ptr(out)))
         return out
+
+    def crs_expand_mm(self, d_crs, out=None):
+        """the CRS expanded once for the matrix-core batch prover (12.4 GB at the default instance)"""
+        out = self.empty(int(self.lib.mfh_crs_mm_image_bytes(self._h))) if out is None else out
+        self._chk(self.lib.mfh_crs_expand_mm(self._h, _ptr(d_crs), _ptr(out)))
+        return out
+
+    def set_resident_mm(self, image):
+        self._resident_mm = image
+        self._chk(self.lib.mfh_crs_set_resident_mm(self._h, _ptr(image)))
 
     def prove_batch(self, d_crs, d_ssp, witness_bits_list, deltas, smudge_mags, smudge_signs, maglen=80, out=None):
         """prover() for len(witness_bits_list) statements under one CRS: regions expanded once per group of 31, MAC on the matrix cores"""

@@ -71,6 +71,9 @@ struct mfh_ctx {
   uint32_t *d_prover = nullptr;  // prover polynomials w, v, h and the b_w coefficient vector
   size_t prover_words = 0;
   std::vector<uint32_t> h_cw;
+  const uint8_t *mm_image = nullptr;  // CRS expanded for the matrix-core path (mfh_crs_expand_mm): S | AS | BT+BV regions
+  uint64_t mm_off[3] = {0, 0, 0}, mm_rows[3] = {0, 0, 0};
+  size_t mm_base[3] = {0, 0, 0};
   void *d_batch = nullptr;  // mfh_prove_batch group scratch: W | H | V | CW | OUT
   size_t batch_bytes = 0;
   PinBuf pin_rows, pin_cw, pin_smudge;

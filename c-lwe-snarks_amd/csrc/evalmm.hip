@@ -234,9 +234,14 @@ __global__ __launch_bounds__(1024) void k_evalmm(AesKey key /* rk[56..59] ^ 0x80
 constexpr int CT2 = 2, MB2 = CT2 * SB, MT2 = MB2 / 16, RT2 = 256, TS2 = 192, BPR2 = 12, NQ2 = 16, N2 = 16 * NQ2;
 static_assert(MB2 % 16 == 0 && MT2 <= 16 && RT2 * BPR2 == 3 * 1024, "wide tile geometry");
 
+// MODE 0: regenerate the keystream (AES) and multiply-accumulate.  MODE 1: regenerate and WRITE each unit's LDS tile (48 KiB, the
+// kernel's own row-major, offset-by-128 form, b coordinate included) to `image` -- the CRS expanded once for the matrix-core path.
+// MODE 2: READ the tiles from that image instead of running AES: the resident-CRS regime of the batch prover, HBM-bound.
+// image tile of (column tile t, unit u = row / 256) at image + (t * units + u) * RT2 * TS2.
+template <int MODE>
 __global__ __launch_bounds__(1024) void k_evalmm16(AesKey key /* rk[56..59] ^ 0x80808080 */, const uint32_t *__restrict__ g_t0, uint64_t off,
                                                    uint32_t n, uint32_t nrows, uint32_t rows_per_chunk, const uint8_t *__restrict__ c8,
-                                                   const int8_t *__restrict__ cd, int *__restrict__ part) {
+                                                   const int8_t *__restrict__ cd, int *__restrict__ part, uint8_t *__restrict__ image) {
   struct __attribute__((aligned(16))) Lds {
     uint32_t lt[mf::kTabBytes / 4];  // first: LDS address 0 (aes_dev.hpp)
     uint8_t tile[RT2 * TS2];
@@ -244,7 +249,7 @@ __global__ __launch_bounds__(1024) void k_evalmm16(AesKey key /* rk[56..59] ^ 0x
     uint32_t spanc[RT2][2][5];
   };
   __shared__ Lds lds;
-  mf::lds_fill_tab(lds.lt, g_t0);
+  if (MODE != 2) mf::lds_fill_tab(lds.lt, g_t0);
   const uint8_t *tab = reinterpret_cast<const uint8_t *>(lds.lt);
   const mf::AesLane L = mf::aes_lane();
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -276,11 +281,52 @@ __global__ __launch_bounds__(1024) void k_evalmm16(AesKey key /* rk[56..59] ^ 0x
     for (int i = 0; i < 5; i++) lds.spanc[lr][which][i] = sc[i];
   };
   const v4i *cdv = reinterpret_cast<const v4i *>(cd);
+  const uint32_t units = (nrows + RT2 - 1) / RT2;
+  uint4 *img = reinterpret_cast<uint4 *>(image) + (uint64_t)blockIdx.x * units * (RT2 * TS2 / 16);  // this column tile's units
+  uint4 pre[3];  // MODE 2: the next unit's tile, in flight under the MFMA phase
 
   __syncthreads();
-  if (tid < 2 * RT2) span_task(r0, tid);
+  if (MODE != 2 && tid < 2 * RT2) span_task(r0, tid);
+  if (MODE == 2 && r0 < r1) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) pre[i] = img[(uint64_t)(r0 / RT2) * (RT2 * TS2 / 16) + tid + 1024 * i];
+  }
   __syncthreads();
   for (uint32_t u0 = r0; u0 < r1; u0 += RT2) {
+    if (MODE == 1) {  // expansion only: tile -> image
+      for (uint32_t s2 = tid; s2 < RT2 * BPR2; s2 += 1024) {
+        const uint32_t lr = s2 / BPR2, k = s2 % BPR2;
+        const uint64_t row = (uint64_t)u0 + lr;
+        uint32_t w[4] = {0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};  // rows past the region: A' = -128, i.e. A = 0
+        if (row < r1) {
+          const RowGeom g = row_geom(off, row, n, j0, nks);
+          if (k < g.nblk) {
+            const uint64_t ctr = g.cb0 + k;
+            const uint32_t *scp = lds.spanc[lr][(uint32_t)((ctr >> 8) - (g.cb0 >> 8))];
+            uint32_t sc[5] = {scp[0], scp[1], scp[2], scp[3], scp[4]};
+            mf::aes256_ctr_block_sc(tab, L, key, ctr, sc, w);
+          }
+        }
+        *reinterpret_cast<uint4 *>(&lds.tile[lr * TS2 + 16 * k]) = make_uint4(w[0], w[1], w[2], w[3]);
+      }
+      __syncthreads();
+      if (has_b) {
+        for (uint32_t s2 = tid; s2 < RT2 * VB; s2 += 1024) {
+          const uint32_t lr = s2 / VB, k = s2 % VB;
+          const uint64_t row = (uint64_t)u0 + lr;
+          if (row >= r1) continue;
+          const RowGeom g = row_geom(off, row, n, j0, nks);
+          lds.tile[lr * TS2 + g.head + nks * VB + k] = (uint8_t)(c8[row * VB + k] ^ 0x80);
+        }
+        __syncthreads();
+      }
+      uint4 *dst = img + (uint64_t)(u0 / RT2) * (RT2 * TS2 / 16);
+#pragma unroll
+      for (int i = 0; i < 3; i++) dst[tid + 1024 * i] = reinterpret_cast<const uint4 *>(lds.tile)[tid + 1024 * i];
+      if (tid < 2 * RT2) span_task(u0 + RT2, tid);
+      __syncthreads();
+      continue;
+    }
     // first k-step's digit fragments: 16 KiB contiguous, one 16-byte load per thread, in flight under the expansion
     const v4i bstage = cdv[(uint64_t)(u0 >> 6) * NQ2 * 64 + tid];
     // the other k-steps' fragments: the waves without a row tile fetch them NOW, into the (for them unused) accumulator registers, so
@@ -295,8 +341,16 @@ __global__ __launch_bounds__(1024) void k_evalmm16(AesKey key /* rk[56..59] ^ 0x
           if (idx < NQ2 * 64) acc[(k2 - 1) * 4 + i2] = cdv[((uint64_t)(u0 >> 6) + k2) * NQ2 * 64 + idx];
         }
     }
+    if (MODE == 2) {  // the unit's tile from the image (loaded one unit ahead), then the next unit's loads go out
+#pragma unroll
+      for (int i = 0; i < 3; i++) reinterpret_cast<uint4 *>(lds.tile)[tid + 1024 * i] = pre[i];
+      if (u0 + RT2 < r1) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) pre[i] = img[(uint64_t)(u0 / RT2 + 1) * (RT2 * TS2 / 16) + tid + 1024 * i];
+      }
+    }
     // ---- (1) expansion: block slot s -> (local row s / 12, block s % 12): exactly three slots per thread
-    for (uint32_t s2 = tid; s2 < RT2 * BPR2; s2 += 1024) {
+    for (uint32_t s2 = tid; MODE == 0 && s2 < RT2 * BPR2; s2 += 1024) {
       const uint32_t lr = s2 / BPR2, k = s2 % BPR2;
       const uint64_t row = (uint64_t)u0 + lr;
       if (row >= r1) continue;
@@ -311,7 +365,7 @@ __global__ __launch_bounds__(1024) void k_evalmm16(AesKey key /* rk[56..59] ^ 0x
     }
     (&lds.bfrag[0][0][0])[tid] = bstage;
     __syncthreads();
-    if (has_b) {
+    if (MODE == 0 && has_b) {
       for (uint32_t s2 = tid; s2 < RT2 * VB; s2 += 1024) {
         const uint32_t lr = s2 / VB, k = s2 % VB;
         const uint64_t row = (uint64_t)u0 + lr;
@@ -358,13 +412,13 @@ __global__ __launch_bounds__(1024) void k_evalmm16(AesKey key /* rk[56..59] ^ 0x
             if (idx < NQ2 * 64) dst[idx] = acc[ks * 4 + i2];
           }
         }
-        if (ks == 0)
+        if (MODE == 0 && ks == 0)
           for (uint32_t task = t2; task < 2 * RT2; task += 320) span_task(u0 + RT2, task);
       }
       __syncthreads();
     }
   }
-  if (wave < MT2) {
+  if (MODE != 1 && wave < MT2) {
     int *p = part + ((uint64_t)blockIdx.y * gridDim.x + blockIdx.x) * MB2 * N2;
 #pragma unroll
     for (int q = 0; q < NQ2; q++)
@@ -428,7 +482,11 @@ int mfh_eval_rows_multi(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d
   const uint32_t n = c->P.n;
   // 128 digit columns: k_evalmm (32x32x32 MFMA, 4-coordinate tiles); up to 256: k_evalmm16 (16x16x64, 2-coordinate tiles), which
   // needs every row segment to start at byte 0 or 8 of an AES block: stream offset and row length multiples of 8
-  const bool wide = nvec * ND + 1 > 128;
+  // a registered matrix-core CRS image (mfh_crs_set_resident_mm) serves the region it was expanded from: always the 256-column kernel
+  const uint8_t *img_region = nullptr;
+  for (int r = 0; r < 3 && c->mm_image; r++)
+    if (c->mm_off[r] == off && c->mm_rows[r] == nrows && nrows) img_region = c->mm_image + c->mm_base[r];
+  const bool wide = img_region || nvec * ND + 1 > 128;
   if (nvec * ND + 1 > 256) { c->err = "mfh_eval_rows_multi: at most 63 four-byte (255 one-byte) coefficient vectors per call (256 digit columns)"; return MFH_EINVAL; }
   if (wide && ((off & 7) || (((uint64_t)n * VB) & 7))) { c->err = "mfh_eval_rows_multi: more than 128 digit columns need off and the row length to be multiples of 8"; return MFH_EINVAL; }
   if (!c->have_seed) { c->err = "mfh_set_seed has not been called"; return MFH_EINVAL; }
@@ -464,9 +522,13 @@ int mfh_eval_rows_multi(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d
   AesKey keyx = c->key;
   for (int i = 56; i < 60; i++) keyx.rk[i] ^= 0x80808080u;  // the kernel's keystream bytes come out as A - 128
   {
-    Timer t(c, 7, nrows);
-    if (wide)
-      hipLaunchKernelGGL(k_evalmm16, dim3(ntiles, nchunks), dim3(1024), 0, c->stream, keyx, c->d_t0, off, n, (uint32_t)nrows, rpc, d_c8, cd, part);
+    Timer t(c, img_region ? 8 : 7, nrows);
+    if (img_region)
+      hipLaunchKernelGGL(k_evalmm16<2>, dim3(ntiles, nchunks), dim3(1024), 0, c->stream, keyx, c->d_t0, off, n, (uint32_t)nrows, rpc, d_c8, cd, part,
+                         const_cast<uint8_t *>(img_region));
+    else if (wide)
+      hipLaunchKernelGGL(k_evalmm16<0>, dim3(ntiles, nchunks), dim3(1024), 0, c->stream, keyx, c->d_t0, off, n, (uint32_t)nrows, rpc, d_c8, cd, part,
+                         (uint8_t *)nullptr);
     else if (NT == 2)
       hipLaunchKernelGGL(k_evalmm<2>, dim3(ntiles, nchunks), dim3(1024), 0, c->stream, keyx, c->d_t0, off, n, (uint32_t)nrows, rpc, d_c8, cd, rpad,
                          part);
@@ -483,6 +545,55 @@ int mfh_eval_rows_multi(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d
     hipLaunchKernelGGL(k_evalmm_finish<1>, dim3((total + 127) / 128), dim3(128), 0, c->stream, part, sc, nchunks, ntiles, N, nvec, n, (uint32_t)nrows, ct,
                        d_rops, accumulate);
   HIP_TRY(c, hipGetLastError());
+  return MFH_OK;
+}
+
+// ---- the CRS expanded once for the matrix-core path (second regime of SURVEY 8(d) for the batch prover) -------------------------
+static size_t mm_region_bytes(uint32_t n, uint64_t rows) {
+  const uint64_t ntiles = (n + 1 + CT2 - 1) / CT2, units = (rows + RT2 - 1) / RT2;
+  return (size_t)(ntiles * units * RT2 * TS2);
+}
+size_t mfh_crs_mm_image_bytes(const mfh_ctx *c) {
+  if (!c || c->P.logq != 736) return 0;
+  return 2 * mm_region_bytes(c->P.n, c->P.d) + mm_region_bytes(c->P.n, c->P.m);
+}
+// expands the S, AS and BT+BV regions of the compressed CRS into d_image (mfh_crs_mm_image_bytes bytes): k_evalmm16's own LDS tiles
+int mfh_crs_expand_mm(mfh_ctx *c, const uint8_t *d_crs_c8, uint8_t *d_image) {
+  if (!c || !d_crs_c8 || !d_image) return MFH_EINVAL;
+  if (!c->have_seed) { c->err = "mfh_set_seed has not been called"; return MFH_EINVAL; }
+  if (c->P.logq != 736) { c->err = "mfh_crs_expand_mm: only logq = 736 has a matrix-core path"; return MFH_EUNSUPPORTED; }
+  const uint32_t n = c->P.n, d = c->P.d, m = c->P.m;
+  if (((uint64_t)n * VB) & 7) { c->err = "mfh_crs_expand_mm: the row length must be a multiple of 8"; return MFH_EUNSUPPORTED; }
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint64_t ctr_ct = (uint64_t)VB * n;
+  const uint64_t offs[3] = {0, ctr_ct * d, ctr_ct * 2 * d};
+  const uint64_t rows[3] = {d, d, m};
+  const size_t c8off[3] = {0, (size_t)d * VB, (size_t)2 * d * VB};
+  AesKey keyx = c->key;
+  for (int i = 56; i < 60; i++) keyx.rk[i] ^= 0x80808080u;
+  const uint32_t ntiles = (n + 1 + CT2 - 1) / CT2;
+  size_t base = 0;
+  for (int r = 0; r < 3; r++) {
+    const uint32_t units = (uint32_t)((rows[r] + RT2 - 1) / RT2);
+    const uint32_t nchunks = std::max(1u, std::min(units, 4u));
+    const uint32_t rpc = (units + nchunks - 1) / nchunks * RT2;
+    Timer t(c, 4, rows[r]);
+    hipLaunchKernelGGL(k_evalmm16<1>, dim3(ntiles, (uint32_t)((rows[r] + rpc - 1) / rpc)), dim3(1024), 0, c->stream, keyx, c->d_t0, offs[r], n,
+                       (uint32_t)rows[r], rpc, d_crs_c8 + c8off[r], (const int8_t *)nullptr, (int *)nullptr, d_image + base);
+    base += mm_region_bytes(n, rows[r]);
+  }
+  HIP_TRY(c, hipGetLastError());
+  return MFH_OK;
+}
+// registers (or, with NULL, clears) the image: mfh_eval_rows_multi / mfh_prove_batch then stream the three CRS regions from it
+int mfh_crs_set_resident_mm(mfh_ctx *c, const uint8_t *d_image) {
+  if (!c) return MFH_EINVAL;
+  c->mm_image = d_image;
+  const uint32_t n = c->P.n, d = c->P.d, m = c->P.m;
+  const uint64_t ctr_ct = (uint64_t)VB * n;
+  c->mm_off[0] = 0; c->mm_off[1] = ctr_ct * d; c->mm_off[2] = ctr_ct * 2 * d;
+  c->mm_rows[0] = d; c->mm_rows[1] = d; c->mm_rows[2] = m;
+  c->mm_base[0] = 0; c->mm_base[1] = mm_region_bytes(n, d); c->mm_base[2] = 2 * mm_region_bytes(n, d);
   return MFH_OK;
 }
 

@@ -981,6 +981,7 @@ static int timing_kind(const char *which) {
   if (!strcmp(which, "mac1")) return 5;
   if (!strcmp(which, "mac2")) return 6;
   if (!strcmp(which, "evalmm")) return 7;
+  if (!strcmp(which, "evalmm_resident")) return 8;
   return -1;
 }
 

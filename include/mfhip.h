@@ -184,6 +184,13 @@ int mfh_prove(mfh_ctx *ctx, const uint8_t *d_crs_c8, const uint32_t *d_ssp, cons
 int mfh_verify(mfh_ctx *ctx, const uint32_t *d_ssp, uint32_t alpha, uint32_t beta, uint32_t s, const uint64_t *d_sk,
                const uint64_t *d_proofs, size_t count, uint8_t *d_ok);
 
+/* The CRS expanded ONCE for the matrix-core path (the resident regime of the batch prover): mfh_crs_expand_mm writes the S, AS and
+ * BT+BV regions as k_evalmm16's own tiles (mfh_crs_mm_image_bytes bytes: 12.4 GB at the default instance); while an image is
+ * registered with mfh_crs_set_resident_mm (NULL clears it), mfh_eval_rows_multi over exactly one of those regions -- hence
+ * mfh_prove_batch -- streams it from HBM instead of regenerating the keystream.  Results are identical.  logq = 736 only. */
+size_t mfh_crs_mm_image_bytes(const mfh_ctx *ctx);
+int mfh_crs_expand_mm(mfh_ctx *ctx, const uint8_t *d_crs_c8, uint8_t *d_image);
+int mfh_crs_set_resident_mm(mfh_ctx *ctx, const uint8_t *d_image);
 /* prover() for nproofs statements under ONE CRS and SSP.  The S and AS regions are expanded once per group of up to 31 proofs, the
  * BT+BV region once per up to 124, and the multiply-accumulate of the coefficient vectors runs on the matrix cores (mfh_eval_rows_multi); proof b is bit-identical to
  * mfh_prove(witness b, delta b, smudging b).  h_witness_bits: nproofs bit strings, bits_stride bytes apart; h_delta: nproofs values
@@ -232,7 +239,7 @@ int mfh_eval_rows_multi(mfh_ctx *ctx, uint64_t off, size_t nrows, const uint8_t 
 /* Kernel timing for the roofline leg of bench.py.  With timing enabled every launch of a hot kernel is bracketed by
  * HIP events on the context's stream (no synchronisation is added).  mfh_timing_drain waits for the stream, then
  * reports and forgets the launches of kind `which`: "eval2" / "eval1" (k_eval with 2 / 1 coefficient vectors),
- * "eval" (both), "encrypt", "keystream", "expand", "mac2" / "mac1" (resident MAC), "evalmm" (mfh_eval_rows_multi).  total_rows = rows handed to those launches (AES blocks for "keystream"). */
+ * "eval" (both), "encrypt", "keystream", "expand", "mac2" / "mac1" (resident MAC), "evalmm" / "evalmm_resident" (mfh_eval_rows_multi from the seed / from the image).  total_rows = rows handed to those launches (AES blocks for "keystream"). */
 int mfh_set_timing(mfh_ctx *ctx, int enabled);
 /* prover scheduling: mfh_prove* run the witness pass + polynomial step on an internal stream beside the evaluation of
  * b_w's rows and join before the S / AS regions; results are identical in every mode.  0 = one stream, 1 (default) = two

@@ -137,3 +137,50 @@ def test_prove_batch_equals_single_proofs(gpu_ctx_factory, oracle, nproofs):
     assert np.array_equal(got[0], np.stack(ref["proof"]))
     ok = c.to_host(c.verify(d_ssp, alpha, beta, s, c.to_device(sk), c.to_device(got), nproofs))
     assert [bool(x) for x in ok] == valid
+
+
+def test_batch_prover_from_the_matrix_core_crs_image(gpu_ctx_factory, oracle):
+    """Second regime of the batch prover: the CRS expanded once into k_evalmm16's tile image (mfh_crs_expand_mm); with the image
+    registered mfh_eval_rows_multi / mfh_prove_batch stream it from HBM and give the bytes of the regenerate path."""
+    import c_lwe_snarks_amd as mf
+
+    p = mf.DEBUG
+    c = gpu_ctx_factory(p)
+    c.set_seed(SEED)
+    rng = np.random.default_rng(515)
+    nbytes = (p.m + 7) // 8
+    wit = rng.integers(0, 256, size=nbytes, dtype=np.uint8).tobytes()
+    ssp = oracle.ssp_from_tape(p, rng.integers(0, 256, size=p.m * 8 * p.d, dtype=np.uint8), wit)
+    alpha, beta, s = (int(x) for x in rng.integers(1, ol.P, size=3, dtype=np.uint64))
+    sk = ol.rand_values(rng, p.n, p.L, p.logq)
+    etape = ol.rand_values(rng, 2 * p.d + p.m, p.L, 559)
+    d_ssp = c.ssp_upload(ssp)
+    c.ssp_prepare(d_ssp)
+    d_crs = c.setup(d_ssp, alpha, beta, s, c.to_device(sk), c.to_device(etape))
+    nb = 35
+    stmts = [wit if b % 2 == 0 else rng.integers(0, 256, size=nbytes, dtype=np.uint8).tobytes() for b in range(nb)]
+    deltas = [int(x) for x in rng.integers(0, ol.P, size=nb, dtype=np.uint64)]
+    mags = [rng.integers(0, 256, size=400, dtype=np.uint8).tobytes() for _ in range(nb)]
+    signs = [bytes(rng.integers(0, 2, size=5, dtype=np.uint8).tolist()) for _ in range(nb)]
+    regen = c.to_host(c.prove_batch(d_crs, d_ssp, stmts, deltas, mags, signs)).copy()
+    image = c.crs_expand_mm(d_crs)
+    assert image.numel() == int(c.lib.mfh_crs_mm_image_bytes(c._h)) == 3 * 736 * 256 * 192
+    c.set_resident_mm(image)
+    try:
+        res = c.to_host(c.prove_batch(d_crs, d_ssp, stmts, deltas, mags, signs))
+        assert np.array_equal(res, regen)
+        # a region that is not one of the image's three (other row count) still regenerates, and agrees with the VALU path
+        co = rng.integers(0, ol.P, size=(2, 10), dtype=np.uint64).astype(np.uint32)
+        got = c.to_host(c.eval_rows_multi(p.ctr_as, 10, d_crs[p.d * p.ctb:], c.to_device(co), 2), np.uint64).reshape(2, p.n + 1, p.L)
+        r0, r1 = c.eval_rows(p.ctr_as, 10, d_crs[p.d * p.ctb:], c.to_device(co[0]), c.to_device(co[1]))
+        assert np.array_equal(got[0], c.to_host(r0, np.uint64).reshape(p.n + 1, p.L))
+        assert np.array_equal(got[1], c.to_host(r1, np.uint64).reshape(p.n + 1, p.L))
+        # the whole AS region with 3 vectors: from the image == from the seed
+        co3 = rng.integers(0, ol.P, size=(3, p.d), dtype=np.uint64).astype(np.uint32)
+        a = c.to_host(c.eval_rows_multi(p.ctr_as, p.d, d_crs[p.d * p.ctb:], c.to_device(co3), 3)).copy()
+    finally:
+        c.set_resident_mm(None)
+    b = c.to_host(c.eval_rows_multi(p.ctr_as, p.d, d_crs[p.d * p.ctb:], c.to_device(co3), 3))
+    assert np.array_equal(a, b)
+    ok = c.to_host(c.verify(d_ssp, alpha, beta, s, c.to_device(sk), c.to_device(res), nb))
+    assert [bool(x) for x in ok] == [b % 2 == 0 for b in range(nb)]
