@@ -12,7 +12,14 @@ inst = bench.build_instance(mf, ctx, torch, p, 20260101)
 ctx.ssp_prepare(inst["d_ssp"])
 d_crs = ctx.setup(inst["d_ssp"], inst["alpha"], inst["beta"], inst["s"], inst["sk"], inst["err"])
 rng = np.random.default_rng(5)
-for nb in [int(a) for a in sys.argv[1:]] or [12, 24]:
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+if "--resident" in sys.argv:
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    image = ctx.crs_expand_mm(d_crs)
+    torch.cuda.synchronize()
+    print(f"matrix-core CRS image: {image.numel()/1e9:.2f} GB expanded in {(time.perf_counter()-t0)*1e3:.1f} ms", flush=True)
+    ctx.set_resident_mm(image)
+for nb in [int(a) for a in args] or [12, 24]:
     deltas = [int(x) for x in rng.integers(0, mf.P, size=nb, dtype=np.uint64)]
     mags = [rng.integers(0, 256, size=400, dtype=np.uint8).tobytes() for _ in range(nb)]
     signs = [bytes(5)] * nb
