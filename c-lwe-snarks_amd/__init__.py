@@ -84,7 +84,7 @@ EXPORTS = [
     "mfh_ctx_create", "mfh_ctx_destroy", "mfh_set_stream", "mfh_sync", "mfh_last_error", "mfh_set_seed",
     "mfh_keystream", "mfh_sample_rows", "mfh_ct_add", "mfh_ct_mul_ui", "mfh_ct_addmul_ui", "mfh_eval_rows",
     "mfh_encrypt_rows", "mfh_decrypt", "mfh_ct_smudge", "mfh_ssp_upload", "mfh_witness_poly", "mfh_version",
-    "mfh_workspace_bytes", "mfh_last_kernel_ms", "mfh_set_timing", "mfh_set_overlap", "mfh_eval_rows_multi", "mfh_prove_batch", "mfh_crs_mm_image_bytes", "mfh_crs_expand_mm", "mfh_crs_set_resident_mm", "mfh_witness_poly_multi", "mfh_poly_h_multi", "mfh_poly_mul", "mfh_poly_add", "mfh_poly_prepare_t",
+    "mfh_workspace_bytes", "mfh_last_kernel_ms", "mfh_set_timing", "mfh_set_overlap", "mfh_eval_rows_multi", "mfh_prove_batch", "mfh_crs_mm_image_bytes", "mfh_crs_expand_mm", "mfh_crs_set_resident_mm", "mfh_witness_poly_multi", "mfh_witness_poly_mm", "mfh_poly_h_multi", "mfh_poly_mul", "mfh_poly_add", "mfh_poly_prepare_t",
     "mfh_ssp_prepare", "mfh_poly_h", "mfh_setup_messages", "mfh_setup", "mfh_prove",
     "mfh_prove_partial", "mfh_prove_finish", "mfh_ct_to_lanes", "mfh_ct_from_lanes", "mfh_timing_drain", "mfh_add_dotp",
     "mfh_resident_row_bytes", "mfh_crs_expand", "mfh_eval_rows_resident", "mfh_crs_set_resident",
@@ -129,6 +129,7 @@ def load_library():
         "mfh_set_overlap": (i32, [vp, i32]),
         "mfh_eval_rows_multi": (i32, [vp, u64, sz, vp, vp, u32, u32, vp, i32]),
         "mfh_poly_h_multi": (i32, [vp, vp, vp, u32]),
+        "mfh_witness_poly_mm": (i32, [vp, vp, u32, ctypes.c_char_p, sz, vp, vp]),
         "mfh_witness_poly_multi": (i32, [vp, vp, u32, ctypes.c_char_p, sz, vp, vp]),
         "mfh_crs_mm_image_bytes": (sz, [vp]),
         "mfh_crs_expand_mm": (i32, [vp, vp, vp]),
@@ -382,6 +383,18 @@ class Context:
     def set_resident_mm(self, image):
         self._resident_mm = image
         self._chk(self.lib.mfh_crs_set_resident_mm(self._h, _ptr(image)))
+
+    def witness_poly_many(self, d_ssp, witness_bits_list, deltas, mm=True):
+        """w polynomials of up to 32 (mm) / 12 statements in one read of the SSP -> len x d uint32 on the device"""
+        p = self.params
+        nb = len(witness_bits_list)
+        stride = (p.m + 6) // 8
+        bits = b"".join(bytes(w[:stride]).ljust(stride, b"\0") for w in witness_bits_list)
+        dl = (ctypes.c_uint32 * nb)(*[int(x) for x in deltas])
+        out = self.empty(nb * p.d * 4)
+        fn = self.lib.mfh_witness_poly_mm if mm else self.lib.mfh_witness_poly_multi
+        self._chk(fn(self._h, _ptr(d_ssp), nb, bits, stride, ctypes.cast(dl, ctypes.c_void_p), _ptr(out)))
+        return out
 
     def prove_batch(self, d_crs, d_ssp, witness_bits_list, deltas, smudge_mags, smudge_signs, maglen=80, out=None):
         """prover() for len(witness_bits_list) statements under one CRS: regions expanded once per group of 31, MAC on the matrix cores"""

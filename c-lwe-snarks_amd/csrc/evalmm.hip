@@ -24,6 +24,7 @@
 // while waves 11..15 compute the next unit's counter-mode span constants.  LDS: 64 KiB table (first, at address 0) + 48 KiB tile
 // + 8 KiB span constants.
 #include <algorithm>
+#include <cstring>
 
 #include "ctx.hpp"
 
@@ -471,6 +472,82 @@ __global__ void k_evalmm_finish(const int *__restrict__ part, const int64_t *__r
   out[23] = 0;
 }
 
+// ---- the witness pass of up to 32 statements as a GEMM over the SSP rows (one read of the SSP) ---------------------------------------
+//   sum_b[k] = sum_i bit_b[i] * v_i[k]:   A = the statements' witness bits (0/1), B = the bytes of v_i[k] (offset by 128), K = rows.
+// The SSP is row-major (v_i[k], k fastest), the MFMA wants 16 consecutive ROWS per lane: lane (k = tile + (l & 31), h = l >> 5) loads the
+// dword v_i[k] of its 16 rows (a wave reads 32 consecutive dwords of each of 32 rows: coalesced, every SSP byte read once), transposes
+// the 16 x 4 bytes in registers into the four byte-column fragments and issues four 32x32x32 MFMAs (M = 32 statements).
+// grid = (d / 128, row chunks); block = 4 waves, one 32-coefficient tile each.  part[((chunk * 4 + w) * 32 + stmt) * d + k].
+__global__ __launch_bounds__(256) void k_witness_mm(const uint32_t *__restrict__ ssp, const v4i *__restrict__ bitfrag, uint32_t nrowsel /* m - 1 */,
+                                                    uint32_t ksteps_per_chunk, uint32_t d, int *__restrict__ part) {
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t r32 = lane & 31, h = lane >> 5;
+  const uint32_t k = (blockIdx.x * 4 + wave) * 32 + r32;
+  const uint32_t K0 = blockIdx.y * ksteps_per_chunk, K1 = min((nrowsel + 31) / 32, K0 + ksteps_per_chunk);
+  v16i acc[4];
+#pragma unroll
+  for (int w = 0; w < 4; w++)
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[w][e] = 0;
+  for (uint32_t K = K0; K < K1; K++) {
+    const uint32_t rb = K * 32 + 16 * h;
+    uint32_t x[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+      const uint32_t r = min(rb + e, nrowsel - 1);  // rows past the end: any valid row, their bits are zero
+      x[e] = ssp[(uint64_t)(r + 2) * d + k] ^ 0x80808080u;  // row r = v_{r+1} = slot r + 2; bytes offset by 128
+    }
+    const v4i a = bitfrag[(uint64_t)K * 64 + lane];
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      uint32_t f[4];
+#pragma unroll
+      for (int g = 0; g < 4; g++) {  // byte w of x[4g .. 4g+3]
+        const uint32_t lo = __builtin_amdgcn_perm(x[4 * g + 1], x[4 * g], 0x0c0c0400u + 0x00000101u * w);      // {x0.bw, x1.bw, 0, 0}
+        const uint32_t hi = __builtin_amdgcn_perm(x[4 * g + 3], x[4 * g + 2], 0x04000c0cu + 0x01010000u * w);  // {0, 0, x2.bw, x3.bw}
+        f[g] = lo | hi;
+      }
+      const v4i b = {(int)f[0], (int)f[1], (int)f[2], (int)f[3]};
+      acc[w] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc[w], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int w = 0; w < 4; w++)
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+      const uint32_t stmt = (e & 3) + 8 * (e >> 2) + 4 * h;
+      part[(((uint64_t)blockIdx.y * 4 + w) * 32 + stmt) * d + k] = acc[w][e];
+    }
+}
+// bits of nstmt statements (packed, bits_stride bytes apart) -> A fragments: bitfrag[K][lane (stmt = l & 31, h)][e] = bit (32 K + 16 h + e)
+__global__ void k_witness_bits(const uint8_t *__restrict__ bits, size_t bits_stride, uint32_t nstmt, uint32_t nrowsel, uint32_t ksteps,
+                               int8_t *__restrict__ bitfrag) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;  // one output byte
+  if (i >= ksteps * 1024) return;
+  const uint32_t e = i & 15, lane = (i >> 4) & 63, K = i >> 10, stmt = lane & 31, h = lane >> 5;
+  const uint32_t r = K * 32 + 16 * h + e;
+  int8_t v = 0;
+  if (stmt < nstmt && r < nrowsel) v = (int8_t)((bits[stmt * bits_stride + (r >> 3)] >> (r & 7)) & 1);
+  bitfrag[i] = v;
+}
+// w_b[k] = delta_b t[k] + sum_i bit_b[i] v_i[k] mod p from the chunk partials: sum_w 256^w (G'_w + 128 cnt_b)
+__global__ void k_witness_mm_finish(const int *__restrict__ part, uint32_t nchunks, const uint32_t *__restrict__ t, const uint32_t *__restrict__ cnt_delta,
+                                    uint32_t nstmt, uint32_t d, uint32_t *__restrict__ w_out) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (k >= d || b >= nstmt) return;
+  const uint64_t corr = 128ull * cnt_delta[2 * b];
+  const uint32_t delta = cnt_delta[2 * b + 1];
+  uint64_t val = 0;
+#pragma unroll
+  for (int w = 0; w < 4; w++) {
+    int64_t g = 0;
+    for (uint32_t ch = 0; ch < nchunks; ch++) g += part[(((uint64_t)ch * 4 + w) * 32 + b) * d + k];
+    val += (uint64_t)(g + (int64_t)corr) << (8 * w);  // the true byte sum: >= 0
+  }
+  const uint64_t P = MFH_P;
+  w_out[(uint64_t)b * d + k] = (uint32_t)((val % P + (uint64_t)t[k] * delta % P) % P);
+}
+
 }  // namespace
 
 extern "C" {
@@ -594,6 +671,46 @@ int mfh_crs_set_resident_mm(mfh_ctx *c, const uint8_t *d_image) {
   c->mm_off[0] = 0; c->mm_off[1] = ctr_ct * d; c->mm_off[2] = ctr_ct * 2 * d;
   c->mm_rows[0] = d; c->mm_rows[1] = d; c->mm_rows[2] = m;
   c->mm_base[0] = 0; c->mm_base[1] = mm_region_bytes(n, d); c->mm_base[2] = 2 * mm_region_bytes(n, d);
+  return MFH_OK;
+}
+
+// mfh_witness_poly for up to 32 statements in ONE read of the (dense) SSP, on the matrix cores: d_w = nstmt polynomials of d coefficients
+int mfh_witness_poly_mm(mfh_ctx *c, const uint32_t *d_ssp, uint32_t nstmt, const uint8_t *h_bits, size_t bits_stride, const uint32_t *h_delta,
+                        uint32_t *d_w) {
+  if (!c || !d_ssp || !h_bits || !h_delta || !d_w || nstmt == 0 || nstmt > 32) return MFH_EINVAL;
+  const uint32_t d = c->P.d, m = c->P.m;
+  if (d % 128 || m < 2) { c->err = "mfh_witness_poly_mm: d must be a multiple of 128"; return MFH_EUNSUPPORTED; }
+  for (uint32_t b = 0; b < nstmt; b++)
+    if (h_delta[b] >= MFH_P) { c->err = "delta must be < p"; return MFH_EINVAL; }
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint32_t nrowsel = m - 1, ksteps = (nrowsel + 31) / 32;
+  const uint32_t nchunks = std::min(ksteps, 4u), kpc = (ksteps + nchunks - 1) / nchunks;
+  const size_t packed = (size_t)nstmt * bits_stride, head_b = ((packed + 32 * 8 + 255) & ~(size_t)255);
+  const size_t frag_b = (size_t)ksteps * 1024, part_b = (size_t)nchunks * 4 * 32 * d * 4;
+  int rc = wws_reserve(c, head_b + frag_b + part_b);
+  if (rc) return rc;
+  // staged: packed bits, then (count of selected rows, delta) per statement
+  uint8_t *stage = (uint8_t *)pin_acquire(c, c->pin_rows, head_b);
+  if (!stage) return MFH_ENOMEM;
+  memcpy(stage, h_bits, packed);
+  uint32_t *cd = (uint32_t *)(stage + packed + ((8 - packed % 8) % 8));
+  for (uint32_t b = 0; b < nstmt; b++) {
+    uint32_t cnt = 0;
+    for (uint32_t r = 0; r < nrowsel; r++) cnt += (h_bits[b * bits_stride + (r >> 3)] >> (r & 7)) & 1;
+    cd[2 * b] = cnt;
+    cd[2 * b + 1] = h_delta[b];
+  }
+  uint8_t *dev = (uint8_t *)c->wws;
+  HIP_TRY(c, hipMemcpyAsync(dev, stage, head_b, hipMemcpyHostToDevice, c->stream));
+  pin_release(c, c->pin_rows);
+  const uint32_t *d_cd = (const uint32_t *)(dev + packed + ((8 - packed % 8) % 8));
+  int8_t *d_frag = (int8_t *)(dev + head_b);
+  int *d_part = (int *)(dev + head_b + frag_b);
+  hipLaunchKernelGGL(k_witness_bits, dim3((uint32_t)((frag_b + 255) / 256)), dim3(256), 0, c->stream, dev, bits_stride, nstmt, nrowsel, ksteps, d_frag);
+  hipLaunchKernelGGL(k_witness_mm, dim3(d / 128, (ksteps + kpc - 1) / kpc), dim3(256), 0, c->stream, d_ssp, (const v4i *)d_frag, nrowsel, kpc, d, d_part);
+  hipLaunchKernelGGL(k_witness_mm_finish, dim3((d + 255) / 256, nstmt), dim3(256), 0, c->stream, d_part, (ksteps + kpc - 1) / kpc, d_ssp, d_cd, nstmt, d,
+                     d_w);
+  HIP_TRY(c, hipGetLastError());
   return MFH_OK;
 }
 

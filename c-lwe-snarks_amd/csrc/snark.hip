@@ -400,8 +400,8 @@ int mfh_prove(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, const 
 
 // prover() for a batch of statements under one CRS and SSP.  The S and AS regions are expanded ONCE per group of up to 31 proofs and
 // the BT+BV region once per up to 124 (b_w's coefficients are witness bits: one byte-digit column per proof), the multiply-accumulate of
-// all their coefficient vectors runs on the matrix cores (mfh_eval_rows_multi, evalmm.hip); the witness pass reads the SSP once per 12
-// statements; the polynomial step and the smudging stay per proof.  Proof b is bit-identical to mfh_prove with the same inputs.
+// all their coefficient vectors runs on the matrix cores (mfh_eval_rows_multi, evalmm.hip); the witness pass reads the SSP once per group (as
+// a GEMM of the witness bits with the SSP bytes on the matrix cores); the polynomial step and the smudging stay per proof.  Proof b is bit-identical to mfh_prove with the same inputs.
 int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, uint32_t nproofs, const uint8_t *h_witness_bits,
                     size_t bits_stride, const uint32_t *h_delta, const uint8_t *h_smudge_mag, size_t maglen, const uint8_t *h_smudge_sign,
                     uint64_t *d_proofs) {
@@ -468,7 +468,10 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
       uint64_t *proofs = d_proofs + (size_t)g0 * 5 * ctl;
       uint32_t *W = base, *H = W + (size_t)g * d, *V = H + (size_t)g * d;  // g-strided blocks: (W, H) and (H, V) are contiguous 2g-vector matrices
       // per proof: w = delta t + sum_bits v_i, v = w + v_0, h = (v^2 - 1) / t   (src/snark.c:141-169)
-      if (src.dense) {  // the SSP is read once per (at most 12) statements
+      if (src.dense && d % 128 == 0) {  // the whole group in ONE read of the SSP, on the matrix cores
+        int rcw = mfh_witness_poly_mm(c, d_ssp, g, h_witness_bits + (size_t)g0 * bits_stride, bits_stride, h_delta + g0, W);
+        if (rcw) return rcw;
+      } else if (src.dense) {  // VALU form: the SSP is read once per (at most 12) statements
         for (uint32_t b0 = 0; b0 < g; b0 += 12) {
           int rcw = mfh_witness_poly_multi(c, d_ssp, std::min(12u, g - b0), h_witness_bits + (size_t)(g0 + b0) * bits_stride, bits_stride,
                                            h_delta + g0 + b0, W + (size_t)b0 * d);

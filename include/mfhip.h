@@ -211,6 +211,10 @@ int mfh_prove_finish(mfh_ctx *ctx, uint64_t *d_proof, const uint8_t *h_smudge_ma
  * polynomials of the statements whose bit selects it.  h_bits: nstmt bit strings bits_stride bytes apart; d_w: nstmt x d coefficients. */
 int mfh_witness_poly_multi(mfh_ctx *ctx, const uint32_t *d_ssp, uint32_t nstmt, const uint8_t *h_bits, size_t bits_stride, const uint32_t *h_delta,
                            uint32_t *d_w);
+/* The same for nstmt <= 32 statements in ONE read of the SSP, as a GEMM on the matrix cores (bits x SSP bytes, exact); d a multiple
+ * of 128.  Used by mfh_prove_batch. */
+int mfh_witness_poly_mm(mfh_ctx *ctx, const uint32_t *d_ssp, uint32_t nstmt, const uint8_t *h_bits, size_t bits_stride, const uint32_t *h_delta,
+                        uint32_t *d_w);
 /* Optional second exchange that also shards the witness polynomial (the SSP pass, 1.4 GB per proof at the default size):
  * mfh_witness_lanes = this rank's share of sum_{bit} v_i as d uint64 lanes (each < p) -> all-reduce (sum) ->
  * mfh_prove_partial_w takes the summed lanes instead of recomputing w on every rank.  mfh_witness_from_lanes: w = delta t + lanes mod p. */

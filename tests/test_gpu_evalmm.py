@@ -184,3 +184,33 @@ def test_batch_prover_from_the_matrix_core_crs_image(gpu_ctx_factory, oracle):
     assert np.array_equal(a, b)
     ok = c.to_host(c.verify(d_ssp, alpha, beta, s, c.to_device(sk), c.to_device(res), nb))
     assert [bool(x) for x in ok] == [b % 2 == 0 for b in range(nb)]
+
+
+@pytest.mark.parametrize("nstmt", [1, 7, 32])
+def test_witness_pass_on_the_matrix_cores(gpu_ctx_factory, nstmt):
+    """mfh_witness_poly_mm (bits x SSP bytes as a GEMM, one read of the SSP) and mfh_witness_poly_multi (VALU, 12 at a time) give
+    mfh_witness_poly's polynomials, also for all-zero / all-one witnesses and edge SSP values (0, p - 1)."""
+    import c_lwe_snarks_amd as mf
+
+    p = mf.DEBUG
+    c = gpu_ctx_factory(p)
+    rng = np.random.default_rng(900 + nstmt)
+    ssp = rng.integers(0, ol.P, size=(p.m + 3) * p.d, dtype=np.uint64)
+    ssp[: 3 * p.d: 2] = ol.P - 1
+    ssp[1: 3 * p.d: 2] = 0
+    ssp[5 * p.d: 6 * p.d] = ol.P - 1
+    d_ssp = c.ssp_upload(ssp)
+    nbytes = (p.m + 7) // 8
+    wits = [rng.integers(0, 256, size=nbytes, dtype=np.uint8).tobytes() for _ in range(nstmt)]
+    wits[0] = bytes(nbytes)
+    if nstmt > 1:
+        wits[1] = b"\\xff" * nbytes
+    deltas = [int(x) for x in rng.integers(0, ol.P, size=nstmt, dtype=np.uint64)]
+    deltas[0] = 0
+    got_mm = c.to_host(c.witness_poly_many(d_ssp, wits, deltas, mm=True), np.uint32).reshape(nstmt, p.d)
+    for b in range(nstmt):
+        ref = c.to_host(c.witness_poly(d_ssp, wits[b], deltas[b]), np.uint32)
+        assert np.array_equal(got_mm[b], ref), f"statement {b}"
+    if nstmt <= 12:
+        got_v = c.to_host(c.witness_poly_many(d_ssp, wits, deltas, mm=False), np.uint32).reshape(nstmt, p.d)
+        assert np.array_equal(got_v, got_mm)
