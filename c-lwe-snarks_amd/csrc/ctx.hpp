@@ -74,6 +74,9 @@ struct mfh_ctx {
   const uint8_t *mm_image = nullptr;  // CRS expanded for the matrix-core path (mfh_crs_expand_mm): S | AS | BT+BV regions
   uint64_t mm_off[3] = {0, 0, 0}, mm_rows[3] = {0, 0, 0};
   size_t mm_base[3] = {0, 0, 0};
+  void *ssp_frag = nullptr;  // the dense SSP in MFMA B-fragment order (evalmm.hip: witness pass of the batch prover); built lazily
+  size_t ssp_frag_bytes = 0;
+  const uint32_t *ssp_frag_src = nullptr;  // the d_ssp it was built from; mfh_ssp_prepare / mfh_ssp_upload reset it
   void *d_batch = nullptr;  // mfh_prove_batch group scratch: W | H | V | CW | OUT
   size_t batch_bytes = 0;
   PinBuf pin_rows, pin_cw, pin_smudge;

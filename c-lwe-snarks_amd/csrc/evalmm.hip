@@ -474,15 +474,37 @@ __global__ void k_evalmm_finish(const int *__restrict__ part, const int64_t *__r
 
 // ---- the witness pass of up to 32 statements as a GEMM over the SSP rows (one read of the SSP) ---------------------------------------
 //   sum_b[k] = sum_i bit_b[i] * v_i[k]:   A = the statements' witness bits (0/1), B = the bytes of v_i[k] (offset by 128), K = rows.
-// The SSP is row-major (v_i[k], k fastest), the MFMA wants 16 consecutive ROWS per lane: lane (k = tile + (l & 31), h = l >> 5) loads the
-// dword v_i[k] of its 16 rows (a wave reads 32 consecutive dwords of each of 32 rows: coalesced, every SSP byte read once), transposes
-// the 16 x 4 bytes in registers into the four byte-column fragments and issues four 32x32x32 MFMAs (M = 32 statements).
+// The SSP is row-major (v_i[k], k fastest) but the MFMA wants 16 consecutive ROWS per lane, so a second image of the SSP in B-fragment
+// order is built once per SSP (k_ssp_frag, same size as the uint32 SSP): for row step K (32 rows), coefficient tile kt (32
+// coefficients), byte w and lane (k = 32 kt + (l & 31), h = l >> 5): the 16 bytes [byte w of v_{32K+16h+e+1}[k]] ^ 0x80, e = 0..15, at
+// frag[(((K * KT + kt) * 4 + w) * 64 + l) * 16 + e].  The pass is then a pure stream: four 16-byte loads and four 32x32x32 MFMAs
+// (M = 32 statements) per wave and row step.
+__global__ void k_ssp_frag(const uint32_t *__restrict__ ssp, uint32_t nrowsel, uint32_t d, uint32_t *__restrict__ frag) {
+  // one thread = 4 rows x 1 coefficient -> one dword of each of the four byte columns
+  const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t KT = d / 32;
+  const uint32_t lane = gid & 63, eg = (gid >> 6) & 3;
+  const uint64_t tile = gid >> 8;  // K * KT + kt
+  const uint32_t kt = (uint32_t)(tile % KT), K = (uint32_t)(tile / KT);
+  if ((uint64_t)K * 32 >= ((uint64_t)nrowsel + 31) / 32 * 32) return;
+  const uint32_t k = kt * 32 + (lane & 31), rb = K * 32 + 16 * (lane >> 5) + 4 * eg;
+  uint32_t x[4];
+#pragma unroll
+  for (int e = 0; e < 4; e++) x[e] = rb + e < nrowsel ? ssp[(uint64_t)(rb + e + 2) * d + k] ^ 0x80808080u : 0u;  // row r = v_{r+1} = slot r + 2
+#pragma unroll
+  for (int w = 0; w < 4; w++) {
+    const uint32_t lo = __builtin_amdgcn_perm(x[1], x[0], 0x0c0c0400u + 0x00000101u * w);  // {x0.bw, x1.bw, 0, 0}
+    const uint32_t hi = __builtin_amdgcn_perm(x[3], x[2], 0x04000c0cu + 0x01010000u * w);  // {0, 0, x2.bw, x3.bw}
+    frag[(((tile * 4 + w) * 64 + lane) << 2) + eg] = lo | hi;
+  }
+}
 // grid = (d / 128, row chunks); block = 4 waves, one 32-coefficient tile each.  part[((chunk * 4 + w) * 32 + stmt) * d + k].
-__global__ __launch_bounds__(256) void k_witness_mm(const uint32_t *__restrict__ ssp, const v4i *__restrict__ bitfrag, uint32_t nrowsel /* m - 1 */,
+__global__ __launch_bounds__(256) void k_witness_mm(const v4i *__restrict__ sspfrag, const v4i *__restrict__ bitfrag, uint32_t nrowsel /* m - 1 */,
                                                     uint32_t ksteps_per_chunk, uint32_t d, int *__restrict__ part) {
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t r32 = lane & 31, h = lane >> 5;
-  const uint32_t k = (blockIdx.x * 4 + wave) * 32 + r32;
+  const uint32_t kt = blockIdx.x * 4 + wave, KT = d / 32;
+  const uint32_t k = kt * 32 + r32;
   const uint32_t K0 = blockIdx.y * ksteps_per_chunk, K1 = min((nrowsel + 31) / 32, K0 + ksteps_per_chunk);
   v16i acc[4];
 #pragma unroll
@@ -490,26 +512,13 @@ __global__ __launch_bounds__(256) void k_witness_mm(const uint32_t *__restrict__
 #pragma unroll
     for (int e = 0; e < 16; e++) acc[w][e] = 0;
   for (uint32_t K = K0; K < K1; K++) {
-    const uint32_t rb = K * 32 + 16 * h;
-    uint32_t x[16];
-#pragma unroll
-    for (int e = 0; e < 16; e++) {
-      const uint32_t r = min(rb + e, nrowsel - 1);  // rows past the end: any valid row, their bits are zero
-      x[e] = ssp[(uint64_t)(r + 2) * d + k] ^ 0x80808080u;  // row r = v_{r+1} = slot r + 2; bytes offset by 128
-    }
+    const v4i *src = sspfrag + (((uint64_t)K * KT + kt) * 4) * 64 + lane;
+    const v4i b0 = src[0], b1 = src[64], b2 = src[128], b3 = src[192];
     const v4i a = bitfrag[(uint64_t)K * 64 + lane];
-#pragma unroll
-    for (int w = 0; w < 4; w++) {
-      uint32_t f[4];
-#pragma unroll
-      for (int g = 0; g < 4; g++) {  // byte w of x[4g .. 4g+3]
-        const uint32_t lo = __builtin_amdgcn_perm(x[4 * g + 1], x[4 * g], 0x0c0c0400u + 0x00000101u * w);      // {x0.bw, x1.bw, 0, 0}
-        const uint32_t hi = __builtin_amdgcn_perm(x[4 * g + 3], x[4 * g + 2], 0x04000c0cu + 0x01010000u * w);  // {0, 0, x2.bw, x3.bw}
-        f[g] = lo | hi;
-      }
-      const v4i b = {(int)f[0], (int)f[1], (int)f[2], (int)f[3]};
-      acc[w] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc[w], 0, 0, 0);
-    }
+    acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b0, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b1, acc[1], 0, 0, 0);
+    acc[2] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b2, acc[2], 0, 0, 0);
+    acc[3] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b3, acc[3], 0, 0, 0);
   }
 #pragma unroll
   for (int w = 0; w < 4; w++)
@@ -685,6 +694,19 @@ int mfh_witness_poly_mm(mfh_ctx *c, const uint32_t *d_ssp, uint32_t nstmt, const
   HIP_TRY(c, hipSetDevice(c->device));
   const uint32_t nrowsel = m - 1, ksteps = (nrowsel + 31) / 32;
   const uint32_t nchunks = std::min(ksteps, 4u), kpc = (ksteps + nchunks - 1) / nchunks;
+  // the SSP in B-fragment order: built on first use per SSP (mfh_ssp_prepare invalidates it), kept beside the uint32 image
+  const size_t sfrag_b = (size_t)ksteps * 32 * d * 4;
+  if (c->ssp_frag_src != d_ssp || c->ssp_frag_bytes < sfrag_b) {
+    if (c->ssp_frag_bytes < sfrag_b) {
+      if (c->ssp_frag) { hipStreamSynchronize(c->stream); hipFree(c->ssp_frag); c->ssp_frag = nullptr; c->ssp_frag_bytes = 0; }
+      HIP_TRY(c, hipMalloc(&c->ssp_frag, sfrag_b));
+      c->ssp_frag_bytes = sfrag_b;
+    }
+    const uint64_t nthreads = (uint64_t)ksteps * (d / 32) * 256;
+    hipLaunchKernelGGL(k_ssp_frag, dim3((uint32_t)((nthreads + 255) / 256)), dim3(256), 0, c->stream, d_ssp, nrowsel, d, (uint32_t *)c->ssp_frag);
+    HIP_TRY(c, hipGetLastError());
+    c->ssp_frag_src = d_ssp;
+  }
   const size_t packed = (size_t)nstmt * bits_stride, head_b = ((packed + 32 * 8 + 255) & ~(size_t)255);
   const size_t frag_b = (size_t)ksteps * 1024, part_b = (size_t)nchunks * 4 * 32 * d * 4;
   int rc = wws_reserve(c, head_b + frag_b + part_b);
@@ -707,7 +729,8 @@ int mfh_witness_poly_mm(mfh_ctx *c, const uint32_t *d_ssp, uint32_t nstmt, const
   int8_t *d_frag = (int8_t *)(dev + head_b);
   int *d_part = (int *)(dev + head_b + frag_b);
   hipLaunchKernelGGL(k_witness_bits, dim3((uint32_t)((frag_b + 255) / 256)), dim3(256), 0, c->stream, dev, bits_stride, nstmt, nrowsel, ksteps, d_frag);
-  hipLaunchKernelGGL(k_witness_mm, dim3(d / 128, (ksteps + kpc - 1) / kpc), dim3(256), 0, c->stream, d_ssp, (const v4i *)d_frag, nrowsel, kpc, d, d_part);
+  hipLaunchKernelGGL(k_witness_mm, dim3(d / 128, (ksteps + kpc - 1) / kpc), dim3(256), 0, c->stream, (const v4i *)c->ssp_frag, (const v4i *)d_frag, nrowsel, kpc, d,
+                     d_part);
   hipLaunchKernelGGL(k_witness_mm_finish, dim3((d + 255) / 256, nstmt), dim3(256), 0, c->stream, d_part, (ksteps + kpc - 1) / kpc, d_ssp, d_cd, nstmt, d,
                      d_w);
   HIP_TRY(c, hipGetLastError());

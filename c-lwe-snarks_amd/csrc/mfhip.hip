@@ -938,6 +938,7 @@ void mfh_ctx_destroy(mfh_ctx *c) {
   if (c->d_msg) hipFree(c->d_msg);
   if (c->d_prover) hipFree(c->d_prover);
   if (c->d_batch) hipFree(c->d_batch);
+  if (c->ssp_frag) hipFree(c->ssp_frag);
   if (c->d_t0) hipFree(c->d_t0);
   for (auto &t : c->timed) { hipEventDestroy(t.e0); hipEventDestroy(t.e1); }
   for (auto e : c->ev_pool) hipEventDestroy(e);
@@ -1418,6 +1419,7 @@ int mfh_ct_smudge(mfh_ctx *c, uint64_t *d_cts, size_t count, const uint8_t *h_ma
 
 int mfh_ssp_upload(mfh_ctx *c, const void *h_ssp_u64, uint32_t *d_ssp, size_t first_slot, size_t nslots) {
   if (!c || !h_ssp_u64 || !d_ssp) return MFH_EINVAL;
+  c->ssp_frag_src = nullptr;  // derived images of the SSP are stale
   HIP_TRY(c, hipSetDevice(c->device));
   const size_t d = c->P.d;
   const size_t chunk_slots = std::max<size_t>(1, (64u << 20) / (8 * d));

@@ -527,6 +527,7 @@ int mfh_poly_mul(mfh_ctx *c, const uint32_t *d_a, size_t la, const uint32_t *d_b
 }
 
 int mfh_poly_prepare_t(mfh_ctx *c, const uint32_t *d_t) {
+  if (c) c->ssp_frag_src = nullptr;  // a (new) SSP is being prepared: derived images are stale
   if (!c || !d_t) return MFH_EINVAL;
   HIP_TRY(c, hipSetDevice(c->device));
   const uint32_t d = c->P.d;
