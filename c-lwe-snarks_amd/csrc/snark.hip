@@ -88,6 +88,29 @@ __global__ void k_add_slot(const uint32_t *__restrict__ a, mf::SspSrc src, uint3
   out[k] = red_p32((uint64_t)a[k] + ssp_coef(src, slot, mf::ssp_prg_rowkey(src.seed, slot), d, k));
 }
 
+// the same for `gridDim.y` polynomials side by side (a, out strided by d)
+__global__ void k_add_slot_multi(const uint32_t *__restrict__ a, mf::SspSrc src, uint32_t slot, uint32_t d, uint32_t *__restrict__ out) {
+  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= d) return;
+  const size_t o = (size_t)blockIdx.y * d + k;
+  out[o] = red_p32((uint64_t)a[o] + ssp_coef(src, slot, mf::ssp_prg_rowkey(src.seed, slot), d, k));
+}
+// b_w of proof blockIdx.y += delta[blockIdx.y] * ct_t (ct_addmul_ui, src/lwe.c:141-149, for a batch: proofs are 5 ciphertexts apart)
+__global__ void k_bw_add_delta_ct(uint64_t *__restrict__ proofs, const uint64_t *__restrict__ ct_t, const uint32_t *__restrict__ delta, uint32_t nvalues,
+                                  uint32_t L, uint32_t KW) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nvalues) return;
+  const uint32_t x = delta[blockIdx.y];
+  const uint32_t *aw = reinterpret_cast<const uint32_t *>(ct_t + (size_t)i * L);
+  uint32_t *rw = reinterpret_cast<uint32_t *>(proofs + ((size_t)blockIdx.y * 5 + 4) * nvalues * L + (size_t)i * L);
+  uint64_t carry = 0;
+  for (uint32_t l = 0; l < KW; l++) {
+    const uint64_t t = (uint64_t)aw[l] * x + carry + rw[l];
+    rw[l] = (uint32_t)t;
+    carry = t >> 32;
+  }
+}
+
 // ciphertext values (KW significant 32-bit words each) <-> one uint64 "lane" per 32-bit word.  Lanes of several
 // partial ciphertexts can be added word-wise (RCCL sum on uint64, 2^32 ranks of headroom) and the carries propagated
 // once afterwards: sums mod 2^(32 KW) do not depend on the order.
@@ -461,8 +484,13 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
     pin_release(c, c->pin_cw);
     int rc = mfh_eval_rows_multi(c, ctr_ct * 2 * d, m, d_crs_c8 + (size_t)2 * d * ctb, CW, sg, 1, OUT, 0);
     if (!rc) rc = scatter(OUT, sproofs, sg, 4);
-    for (uint32_t b = 0; b < sg && !rc; b++) rc = mfh_ct_addmul_ui(c, sproofs + ((size_t)b * 5 + 4) * ctl, CT_T, h_delta[s0 + b], 1);
     if (rc) return rc;
+    {  // + delta_b ct_t for the sg proofs in one launch; the deltas travel in the (now consumed) first words of the CW staging area
+      HIP_TRY(c, hipMemcpyAsync(CW, h_delta + s0, (size_t)sg * 4, hipMemcpyHostToDevice, c->stream));
+      hipLaunchKernelGGL(k_bw_add_delta_ct, dim3((n + 1 + 255) / 256, sg), dim3(256), 0, c->stream, sproofs, CT_T, CW, n + 1,
+                         (c->P.logq + 63) / 64, 2 * (c->P.logq / 64));
+      HIP_TRY(c, hipGetLastError());
+    }
     for (uint32_t g0 = s0; g0 < s0 + sg; g0 += G) {
       const uint32_t g = std::min(G, s0 + sg - g0);
       uint64_t *proofs = d_proofs + (size_t)g0 * 5 * ctl;
@@ -478,14 +506,12 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
           if (rcw) return rcw;
         }
       }
-      for (uint32_t b = 0; b < g; b++) {
-        uint32_t *w = W + (size_t)b * d, *v = V + (size_t)b * d, *h = H + (size_t)b * d;
-        rc = src.dense ? MFH_OK : mfh_witness_poly(c, d_ssp, h_witness_bits + (size_t)(g0 + b) * bits_stride, h_delta[g0 + b], w);
+      for (uint32_t b = 0; b < g && !src.dense; b++) {
+        rc = mfh_witness_poly(c, d_ssp, h_witness_bits + (size_t)(g0 + b) * bits_stride, h_delta[g0 + b], W + (size_t)b * d);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_add_slot, g1(d), dim3(256), 0, c->stream, w, src, 1u, d, v);
-        HIP_TRY(c, hipGetLastError());
-        (void)h;
       }
+      hipLaunchKernelGGL(k_add_slot_multi, dim3((d + 255) / 256, g), dim3(256), 0, c->stream, W, src, 1u, d, V);  // v = w + v_0 for the group
+      HIP_TRY(c, hipGetLastError());
       rc = mfh_poly_h_multi(c, V, H, g);  // the group's polynomial steps side by side: the launches of one, g times the work each
       if (rc) return rc;
       // S rows with (w, h) -> (v_w, h); AS rows with (h, v) -> (hat_h, hat_v): every row expanded once for the whole group
