@@ -123,7 +123,7 @@ def main():
                     help="batch (default at the default workload): a step = --batch statements per GPU proved by mfh_prove_batch (CRS regions "
                          "expanded once per group of 31, MAC on the matrix cores), ranks take disjoint statements, no collective; "
                          "single: a step = one prover() call, CRS rows sharded over the ranks + lane all-reduces")
-    ap.add_argument("--batch", type=int, default=124, help="statements per GPU per step in batch mode")
+    ap.add_argument("--batch", type=int, default=248, help="statements per GPU per step in batch mode")
     ap.add_argument("--no-overlap", action="store_true", help="run the prover on one stream (A/B check of the side-stream overlap)")
     ap.add_argument("--resident-gb", type=float, default=200.0, help="HBM budget for the resident CRS image per GPU")
     ap.add_argument("--workload", choices=["default", "config4", "config5"], default="default",
@@ -397,7 +397,7 @@ def main():
         batched = {"value": world * nb * args.steps / el_b, "unit": "proofs/s", "ms_per_step": el_b / args.steps * 1e3, "statements_per_gpu_per_step": nb,
                    "valid_accepted_invalid_rejected_and_identical_to_single_proof_path": all_ok, "resident_crs": resident_b,
                    "roofline": {"bound": "hbm", "kernel": "k_evalmm16 (AES-256-CTR expansion of the rows, once per group of 31 proofs, + i8 MFMA "
-                                                            "multiply-accumulate of the group's 62 coefficient vectors; the BT+BV region runs once per 124 proofs on k_evalmm<4>)",
+                                                            "multiply-accumulate of the group's 62 coefficient vectors; the BT+BV region runs once per 248 proofs, one byte column per proof)",
                                 "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (gbs / HBM_PEAK_GBS) if gbs else None, "traffic": traffic_mm,
                                 "launches": mmn, "avg_launch_ms": avg_mm, "rows_per_launch": rows_mm, "bytes_per_row": row_bytes_b,
                                 "note": "algorithmic bytes = expanded row bytes, regenerated with AES on the CU (LDS T-tables): LDS-lookup / VALU "
@@ -496,7 +496,7 @@ def main():
             head = {"value": batched["value"], "ms_per_step": batched["ms_per_step"], "scaling": "weak", "roofline": batched["roofline"],
                     "proof_accepted": batched["valid_accepted_invalid_rejected_and_identical_to_single_proof_path"],
                     "config": {"workload": base_workload + f"; a step = {args.batch} statements per GPU (same circuit and CRS; half with the satisfying witness, half with random ones; own randomness) through "
-                                           "mfh_prove_batch: the S / AS regions are expanded once per group of 31 proofs (BT+BV once per 124) and the group's multiply-accumulate "
+                                           "mfh_prove_batch: the S / AS regions are expanded once per group of 31 proofs (BT+BV once per 248) and the group's multiply-accumulate "
                                            "runs on the matrix cores; every proof is bit-identical to the single-proof prover()'s",
                                "rows_per_proof": rows_crs, "statements_per_gpu_per_step": args.batch,
                                "sharding": f"{world} ranks, disjoint statements, no collective" if world > 1 else "single GPU"}}

@@ -422,7 +422,7 @@ int mfh_prove(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, const 
 }
 
 // prover() for a batch of statements under one CRS and SSP.  The S and AS regions are expanded ONCE per group of up to 31 proofs and
-// the BT+BV region once per up to 124 (b_w's coefficients are witness bits: one byte-digit column per proof), the multiply-accumulate of
+// the BT+BV region once per up to 248 (b_w's coefficients are witness bits: one byte-digit column per proof), the multiply-accumulate of
 // all their coefficient vectors runs on the matrix cores (mfh_eval_rows_multi, evalmm.hip); the witness pass reads the SSP once per group (as
 // a GEMM of the witness bits with the SSP bytes on the matrix cores); the polynomial step and the smudging stay per proof.  Proof b is bit-identical to mfh_prove with the same inputs.
 int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, uint32_t nproofs, const uint8_t *h_witness_bits,
@@ -444,7 +444,7 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
   const size_t ctl = (size_t)(n + 1) * ((c->P.logq + 63) / 64);
   const uint64_t ctr_ct = (uint64_t)ctb * n;
   constexpr uint32_t G = 31;    // proofs per S / AS expansion: 62 coefficient vectors x 4 bytes + the ones column = 249 of 256 digit columns
-  constexpr uint32_t SG = 124;  // proofs per BT+BV expansion: one byte column each + the ones column = 125 of 128 digit columns
+  constexpr uint32_t SG = 248;  // proofs per BT+BV expansion: one byte column each + the ones column = 249 of 256 digit columns
   HIP_TRY(c, hipSetDevice(c->device));
   // scratch: W | H | V (g x d each, in this order: the S region takes (W, H), the AS region (H, V)), CW (SG x m), ONE (1 word), OUT
   // (SG ciphertexts, >= 2G), CT_T (1 ciphertext)

@@ -192,7 +192,7 @@ size_t mfh_crs_mm_image_bytes(const mfh_ctx *ctx);
 int mfh_crs_expand_mm(mfh_ctx *ctx, const uint8_t *d_crs_c8, uint8_t *d_image);
 int mfh_crs_set_resident_mm(mfh_ctx *ctx, const uint8_t *d_image);
 /* prover() for nproofs statements under ONE CRS and SSP.  The S and AS regions are expanded once per group of up to 31 proofs, the
- * BT+BV region once per up to 124, and the multiply-accumulate of the coefficient vectors runs on the matrix cores (mfh_eval_rows_multi); proof b is bit-identical to
+ * BT+BV region once per up to 248, and the multiply-accumulate of the coefficient vectors runs on the matrix cores (mfh_eval_rows_multi); proof b is bit-identical to
  * mfh_prove(witness b, delta b, smudging b).  h_witness_bits: nproofs bit strings, bits_stride bytes apart; h_delta: nproofs values
  * < p; h_smudge_mag: nproofs x 5 x maglen bytes; h_smudge_sign: nproofs x 5 bytes; d_proofs: nproofs x 5 ciphertexts.
  * Regenerates the keystream (no resident CRS image may be set); logq = 736 only. */

@@ -98,10 +98,10 @@ def test_multi_argument_checks(ctx):
     assert not ctx.to_host(out).any()
 
 
-@pytest.mark.parametrize("nproofs", [1, 5, 16, 33, 126])
+@pytest.mark.parametrize("nproofs", [1, 5, 16, 33, 126, 250])
 def test_prove_batch_equals_single_proofs(gpu_ctx_factory, oracle, nproofs):
-    """mfh_prove_batch: proof b of the batch == mfh_prove(statement b), bit for bit (S / AS groups of 31 on the 256-column kernel, smaller groups on the 128-column one, BT+BV groups of 124: 33 = one
-    full + one partial S / AS group, 126 = two BT+BV groups); the first proof is also checked against the oracle's prover and every proof is accepted by the device verifier."""
+    """mfh_prove_batch: proof b of the batch == mfh_prove(statement b), bit for bit (S / AS groups of 31 on the 256-column kernel, smaller groups on the 128-column one, BT+BV groups of 248 (128-column kernel up to 127 proofs, 256-column kernel above): 33 = one
+    full + one partial S / AS group, 250 = two BT+BV groups); the first proof is also checked against the oracle's prover and every proof is accepted by the device verifier."""
     import c_lwe_snarks_amd as mf
 
     p = mf.DEBUG
