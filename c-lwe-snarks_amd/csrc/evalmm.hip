@@ -235,10 +235,10 @@ __global__ __launch_bounds__(1024) void k_evalmm(AesKey key /* rk[56..59] ^ 0x80
 constexpr int CT2 = 2, MB2 = CT2 * SB, MT2 = MB2 / 16, RT2 = 256, TS2 = 192, BPR2 = 12, NQ2 = 16, N2 = 16 * NQ2;
 static_assert(MB2 % 16 == 0 && MT2 <= 16 && RT2 * BPR2 == 3 * 1024, "wide tile geometry");
 
-// MODE 0: regenerate the keystream (AES) and multiply-accumulate.  MODE 1: regenerate and WRITE each unit's LDS tile (48 KiB, the
-// kernel's own row-major, offset-by-128 form, b coordinate included) to `image` -- the CRS expanded once for the matrix-core path.
-// MODE 2: READ the tiles from that image instead of running AES: the resident-CRS regime of the batch prover, HBM-bound.
-// image tile of (column tile t, unit u = row / 256) at image + (t * units + u) * RT2 * TS2.
+// MODE 0: regenerate the keystream (AES) and multiply-accumulate.  MODE 1: regenerate and WRITE the rows to `image` in A-FRAGMENT order
+// (offset-by-128 bytes, b coordinate included) -- the CRS expanded once for the matrix-core path, streamed by k_mmstream below.
+// Fragment of (row tile mt = 11 * column tile + wave, 64-row k-step s): 64 lanes x 16 bytes at image + ((mt * KS + s) * 64 + lane) * 16,
+// KS = 4 * ceil(rows / 256) k-steps per region.
 template <int MODE>
 __global__ __launch_bounds__(1024) void k_evalmm16(AesKey key /* rk[56..59] ^ 0x80808080 */, const uint32_t *__restrict__ g_t0, uint64_t off,
                                                    uint32_t n, uint32_t nrows, uint32_t rows_per_chunk, const uint8_t *__restrict__ c8,
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(1024) void k_evalmm16(AesKey key /* rk[56..59] ^ 0x
     uint32_t spanc[RT2][2][5];
   };
   __shared__ Lds lds;
-  if (MODE != 2) mf::lds_fill_tab(lds.lt, g_t0);
+  mf::lds_fill_tab(lds.lt, g_t0);
   const uint8_t *tab = reinterpret_cast<const uint8_t *>(lds.lt);
   const mf::AesLane L = mf::aes_lane();
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -282,16 +282,10 @@ __global__ __launch_bounds__(1024) void k_evalmm16(AesKey key /* rk[56..59] ^ 0x
     for (int i = 0; i < 5; i++) lds.spanc[lr][which][i] = sc[i];
   };
   const v4i *cdv = reinterpret_cast<const v4i *>(cd);
-  const uint32_t units = (nrows + RT2 - 1) / RT2;
-  uint4 *img = reinterpret_cast<uint4 *>(image) + (uint64_t)blockIdx.x * units * (RT2 * TS2 / 16);  // this column tile's units
-  uint4 pre[3];  // MODE 2: the next unit's tile, in flight under the MFMA phase
+  const uint32_t KS = (nrows + RT2 - 1) / RT2 * (RT2 / 64);  // 64-row k-steps of the region (MODE 1)
 
   __syncthreads();
-  if (MODE != 2 && tid < 2 * RT2) span_task(r0, tid);
-  if (MODE == 2 && r0 < r1) {
-#pragma unroll
-    for (int i = 0; i < 3; i++) pre[i] = img[(uint64_t)(r0 / RT2) * (RT2 * TS2 / 16) + tid + 1024 * i];
-  }
+  if (tid < 2 * RT2) span_task(r0, tid);
   __syncthreads();
   for (uint32_t u0 = r0; u0 < r1; u0 += RT2) {
     if (MODE == 1) {  // expansion only: tile -> image
@@ -321,10 +315,29 @@ __global__ __launch_bounds__(1024) void k_evalmm16(AesKey key /* rk[56..59] ^ 0x
         }
         __syncthreads();
       }
-      uint4 *dst = img + (uint64_t)(u0 / RT2) * (RT2 * TS2 / 16);
+      if (wave < MT2) {  // this wave's row tile, four k-steps: the byte gather of the MFMA phase, stored instead of multiplied
+        const uint32_t head0 = row_geom(off, u0, n, j0, 1).head;
+        v4i *dst = reinterpret_cast<v4i *>(image) + ((uint64_t)(MT2 * blockIdx.x + wave) * KS + (u0 >> 6)) * 64 + lane;
 #pragma unroll
-      for (int i = 0; i < 3; i++) dst[tid + 1024 * i] = reinterpret_cast<const uint4 *>(lds.tile)[tid + 1024 * i];
-      if (tid < 2 * RT2) span_task(u0 + RT2, tid);
+        for (int ks = 0; ks < RT2 / 64; ks++) {
+          const uint32_t lrb = ks * 64 + 16 * g4;
+          uint32_t aw[4];
+#pragma unroll
+          for (int e4 = 0; e4 < 4; e4++) {
+            uint32_t x = 0;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+              const uint32_t lr = lrb + 4 * e4 + e;
+              x |= (uint32_t)lds.tile[lr * TS2 + ((head0 + hstep * lr) & 15) + mcol] << (8 * e);
+            }
+            aw[e4] = x;
+          }
+          dst[(uint64_t)ks * 64] = v4i{(int)aw[0], (int)aw[1], (int)aw[2], (int)aw[3]};
+        }
+      } else {
+        const uint32_t t2 = tid - MT2 * 64;
+        for (uint32_t task = t2; task < 2 * RT2; task += 320) span_task(u0 + RT2, task);
+      }
       __syncthreads();
       continue;
     }
@@ -342,16 +355,8 @@ __global__ __launch_bounds__(1024) void k_evalmm16(AesKey key /* rk[56..59] ^ 0x
           if (idx < NQ2 * 64) acc[(k2 - 1) * 4 + i2] = cdv[((uint64_t)(u0 >> 6) + k2) * NQ2 * 64 + idx];
         }
     }
-    if (MODE == 2) {  // the unit's tile from the image (loaded one unit ahead), then the next unit's loads go out
-#pragma unroll
-      for (int i = 0; i < 3; i++) reinterpret_cast<uint4 *>(lds.tile)[tid + 1024 * i] = pre[i];
-      if (u0 + RT2 < r1) {
-#pragma unroll
-        for (int i = 0; i < 3; i++) pre[i] = img[(uint64_t)(u0 / RT2 + 1) * (RT2 * TS2 / 16) + tid + 1024 * i];
-      }
-    }
     // ---- (1) expansion: block slot s -> (local row s / 12, block s % 12): exactly three slots per thread
-    for (uint32_t s2 = tid; MODE == 0 && s2 < RT2 * BPR2; s2 += 1024) {
+    for (uint32_t s2 = tid; s2 < RT2 * BPR2; s2 += 1024) {
       const uint32_t lr = s2 / BPR2, k = s2 % BPR2;
       const uint64_t row = (uint64_t)u0 + lr;
       if (row >= r1) continue;
@@ -366,7 +371,7 @@ __global__ __launch_bounds__(1024) void k_evalmm16(AesKey key /* rk[56..59] ^ 0x
     }
     (&lds.bfrag[0][0][0])[tid] = bstage;
     __syncthreads();
-    if (MODE == 0 && has_b) {
+    if (has_b) {
       for (uint32_t s2 = tid; s2 < RT2 * VB; s2 += 1024) {
         const uint32_t lr = s2 / VB, k = s2 % VB;
         const uint64_t row = (uint64_t)u0 + lr;
@@ -413,18 +418,93 @@ __global__ __launch_bounds__(1024) void k_evalmm16(AesKey key /* rk[56..59] ^ 0x
             if (idx < NQ2 * 64) dst[idx] = acc[ks * 4 + i2];
           }
         }
-        if (MODE == 0 && ks == 0)
+        if (ks == 0)
           for (uint32_t task = t2; task < 2 * RT2; task += 320) span_task(u0 + RT2, task);
       }
       __syncthreads();
     }
   }
-  if (MODE != 1 && wave < MT2) {
+  if (MODE == 0 && wave < MT2) {  // (MODE 1 has no partial products: part is null)
     int *p = part + ((uint64_t)blockIdx.y * gridDim.x + blockIdx.x) * MB2 * N2;
 #pragma unroll
     for (int q = 0; q < NQ2; q++)
 #pragma unroll
       for (int e = 0; e < 4; e++) p[(uint64_t)(wave * 16 + 4 * g4 + e) * N2 + 16 * q + c16] = acc[q][e];
+  }
+}
+
+
+// ---- k_mmstream: the resident regime of the batch prover -- the same GEMM streamed from the A-fragment image ---------------------
+// No AES, no tile, no gather: a wave owns two row tiles (2 x 16 byte positions x 256 digit columns = 128 accumulator VGPRs) and reads
+// their fragments straight from HBM (1 KiB per wave, row tile and 64-row k-step, coalesced, one 256-row stage ahead in registers);
+// the stage's digit fragments (64 KiB) are shared by the 8 waves of the workgroup through LDS, double buffered, one barrier per 256
+// rows.  HBM-bound by construction: per stage and CU 64 KiB of A against 128 x 8 MFMAs (1.7 us of matrix core) and 512 KiB of LDS
+// fragment reads.  grid = (row-tile pairs / 8, row chunks); part[((chunk * Mtot) + m) * 256 + n] as k_evalmm16 writes it.
+constexpr int SW = 8;  // waves per workgroup
+__global__ __launch_bounds__(SW * 64) void k_mmstream(const v4i *__restrict__ image, uint32_t mtiles, uint32_t KS, uint32_t nrows,
+                                                      uint32_t rows_per_chunk, const v4i *__restrict__ cdv, int *__restrict__ part) {
+  __shared__ v4i bfrag[2][RT2 / 64][NQ2][64];  // 2 x 64 KiB
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t c16 = lane & 15, g4 = lane >> 4;
+  const uint32_t mt0 = (blockIdx.x * SW + wave) * 2;  // this wave's two row tiles
+  const bool live0 = mt0 < mtiles, live1 = mt0 + 1 < mtiles;
+  const uint32_t r0 = blockIdx.y * rows_per_chunk, r1 = min(nrows, r0 + rows_per_chunk);
+  v4i acc[2][NQ2];
+#pragma unroll
+  for (int t = 0; t < 2; t++)
+#pragma unroll
+    for (int q = 0; q < NQ2; q++) acc[t][q] = v4i{0, 0, 0, 0};
+  constexpr int BPT = (RT2 / 64) * NQ2 * 64 / (SW * 64);  // digit fragments per thread and stage: 8
+  const v4i zero = {0, 0, 0, 0};
+  v4i an[2][RT2 / 64], bn[BPT];
+  auto fetch = [&](uint32_t u0) {  // the stage's A fragments of this wave and this thread's share of its digit fragments
+#pragma unroll
+    for (int ks = 0; ks < RT2 / 64; ks++) {
+      an[0][ks] = live0 ? image[((uint64_t)mt0 * KS + (u0 >> 6) + ks) * 64 + lane] : zero;
+      an[1][ks] = live1 ? image[((uint64_t)(mt0 + 1) * KS + (u0 >> 6) + ks) * 64 + lane] : zero;
+    }
+#pragma unroll
+    for (int i = 0; i < BPT; i++) bn[i] = cdv[(uint64_t)(u0 >> 6) * NQ2 * 64 + tid + SW * 64 * i];
+  };
+  if (r0 < r1) {
+    fetch(r0);
+#pragma unroll
+    for (int i = 0; i < BPT; i++) (&bfrag[0][0][0][0])[tid + SW * 64 * i] = bn[i];
+  }
+  __syncthreads();
+  uint32_t buf = 0;
+  for (uint32_t u0 = r0; u0 < r1; u0 += RT2) {
+    v4i a[2][RT2 / 64];
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+      for (int ks = 0; ks < RT2 / 64; ks++) a[t][ks] = an[t][ks];
+    const bool more = u0 + RT2 < r1;
+    if (more) fetch(u0 + RT2);  // in flight under this stage's MFMAs
+#pragma unroll
+    for (int ks = 0; ks < RT2 / 64; ks++)
+#pragma unroll
+      for (int q = 0; q < NQ2; q++) {
+        const v4i b = bfrag[buf][ks][q][lane];
+        acc[0][q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[0][ks], b, acc[0][q], 0, 0, 0);
+        acc[1][q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[1][ks], b, acc[1][q], 0, 0, 0);
+      }
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < BPT; i++) (&bfrag[buf ^ 1][0][0][0])[tid + SW * 64 * i] = bn[i];
+    }
+    __syncthreads();  // the other buffer is complete; everyone is done with this one
+    buf ^= 1;
+  }
+  const uint64_t Mtot = (uint64_t)mtiles * 16;
+#pragma unroll
+  for (int t = 0; t < 2; t++) {
+    if (!(t ? live1 : live0)) continue;
+    int *p = part + ((uint64_t)blockIdx.y * Mtot + (uint64_t)(mt0 + t) * 16) * N2;
+#pragma unroll
+    for (int q = 0; q < NQ2; q++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) p[(uint64_t)(4 * g4 + e) * N2 + 16 * q + c16] = acc[t][q][e];
   }
 }
 
@@ -609,10 +689,11 @@ int mfh_eval_rows_multi(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d
   for (int i = 56; i < 60; i++) keyx.rk[i] ^= 0x80808080u;  // the kernel's keystream bytes come out as A - 128
   {
     Timer t(c, img_region ? 8 : 7, nrows);
-    if (img_region)
-      hipLaunchKernelGGL(k_evalmm16<2>, dim3(ntiles, nchunks), dim3(1024), 0, c->stream, keyx, c->d_t0, off, n, (uint32_t)nrows, rpc, d_c8, cd, part,
-                         const_cast<uint8_t *>(img_region));
-    else if (wide)
+    if (img_region) {
+      const uint32_t mtiles = ntiles * MT2, KS = ((uint32_t)nrows + RT2 - 1) / RT2 * (RT2 / 64);
+      hipLaunchKernelGGL(k_mmstream, dim3((mtiles + 2 * SW - 1) / (2 * SW), nchunks), dim3(SW * 64), 0, c->stream, (const v4i *)img_region, mtiles, KS,
+                         (uint32_t)nrows, rpc, (const v4i *)cd, part);
+    } else if (wide)
       hipLaunchKernelGGL(k_evalmm16<0>, dim3(ntiles, nchunks), dim3(1024), 0, c->stream, keyx, c->d_t0, off, n, (uint32_t)nrows, rpc, d_c8, cd, part,
                          (uint8_t *)nullptr);
     else if (NT == 2)
@@ -635,15 +716,15 @@ int mfh_eval_rows_multi(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d
 }
 
 // ---- the CRS expanded once for the matrix-core path (second regime of SURVEY 8(d) for the batch prover) -------------------------
-static size_t mm_region_bytes(uint32_t n, uint64_t rows) {
-  const uint64_t ntiles = (n + 1 + CT2 - 1) / CT2, units = (rows + RT2 - 1) / RT2;
-  return (size_t)(ntiles * units * RT2 * TS2);
+static size_t mm_region_bytes(uint32_t n, uint64_t rows) {  // row tiles x 64-row k-steps x 1 KiB fragments
+  const uint64_t mtiles = (uint64_t)((n + 1 + CT2 - 1) / CT2) * MT2, ksteps = (rows + RT2 - 1) / RT2 * (RT2 / 64);
+  return (size_t)(mtiles * ksteps * 1024);
 }
 size_t mfh_crs_mm_image_bytes(const mfh_ctx *c) {
   if (!c || c->P.logq != 736) return 0;
   return 2 * mm_region_bytes(c->P.n, c->P.d) + mm_region_bytes(c->P.n, c->P.m);
 }
-// expands the S, AS and BT+BV regions of the compressed CRS into d_image (mfh_crs_mm_image_bytes bytes): k_evalmm16's own LDS tiles
+// expands the S, AS and BT+BV regions of the compressed CRS into d_image (mfh_crs_mm_image_bytes bytes), in MFMA A-fragment order
 int mfh_crs_expand_mm(mfh_ctx *c, const uint8_t *d_crs_c8, uint8_t *d_image) {
   if (!c || !d_crs_c8 || !d_image) return MFH_EINVAL;
   if (!c->have_seed) { c->err = "mfh_set_seed has not been called"; return MFH_EINVAL; }

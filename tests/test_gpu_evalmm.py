@@ -140,8 +140,8 @@ def test_prove_batch_equals_single_proofs(gpu_ctx_factory, oracle, nproofs):
 
 
 def test_batch_prover_from_the_matrix_core_crs_image(gpu_ctx_factory, oracle):
-    """Second regime of the batch prover: the CRS expanded once into k_evalmm16's tile image (mfh_crs_expand_mm); with the image
-    registered mfh_eval_rows_multi / mfh_prove_batch stream it from HBM and give the bytes of the regenerate path."""
+    """Second regime of the batch prover: the CRS expanded once into an MFMA A-fragment image (mfh_crs_expand_mm); with the image
+    registered mfh_eval_rows_multi / mfh_prove_batch stream it from HBM (k_mmstream) and give the bytes of the regenerate path."""
     import c_lwe_snarks_amd as mf
 
     p = mf.DEBUG
@@ -164,7 +164,7 @@ def test_batch_prover_from_the_matrix_core_crs_image(gpu_ctx_factory, oracle):
     signs = [bytes(rng.integers(0, 2, size=5, dtype=np.uint8).tolist()) for _ in range(nb)]
     regen = c.to_host(c.prove_batch(d_crs, d_ssp, stmts, deltas, mags, signs)).copy()
     image = c.crs_expand_mm(d_crs)
-    assert image.numel() == int(c.lib.mfh_crs_mm_image_bytes(c._h)) == 3 * 736 * 256 * 192
+    assert image.numel() == int(c.lib.mfh_crs_mm_image_bytes(c._h)) == 3 * (736 * 11) * 4 * 1024  # row tiles x k-steps x 1 KiB
     c.set_resident_mm(image)
     try:
         res = c.to_host(c.prove_batch(d_crs, d_ssp, stmts, deltas, mags, signs))
