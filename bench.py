@@ -370,18 +370,17 @@ def main():
             ctx.set_resident_mm(None)
             img_bytes = image_mm.numel()
             del image_mm
-            tile_bytes_per_row = 736 * 192  # 736 column tiles x 192-byte row segments
+            tile_bytes_per_row = 736 * 11 * 16  # 8096 row tiles x 16 byte positions: the image holds 88 of each value's 92 bytes
             avg_r = rms / max(rn, 1)
             rows_r = rrows / max(rn, 1)
             read_gbs = rows_r * tile_bytes_per_row / (avg_r * 1e-3) / 1e9 if rn else None
             resident_b = {"value": world * nb * args.steps / el_rb, "unit": "proofs/s", "ms_per_step": el_rb / args.steps * 1e3,
                           "proofs_identical_to_regenerated": same_rb, "crs_expand_s": expand_mm_s, "image_bytes_per_rank": img_bytes,
-                          "roofline": {"bound": "hbm", "kernel": "k_evalmm16<2> (row tiles streamed from the image + i8 MFMA multiply-accumulate)",
+                          "roofline": {"bound": "hbm", "kernel": "k_mmstream (A fragments streamed from the image, digit fragments through LDS, i8 MFMA 16x16x64)",
                                        "achieved": read_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (read_gbs / HBM_PEAK_GBS) if read_gbs else None,
                                        "traffic": None, "bytes_read_per_row": tile_bytes_per_row, "launches": rn, "avg_launch_ms": avg_r,
                                        "rows_per_launch": rows_r,
-                                       "note": "not yet HBM-bound: per 256-row unit the kernel keeps the regenerate kernel's phase structure (tile "
-                                               "through LDS, byte gathers, 5 barriers)"}}
+                                       "mfma_int8_tops": 2.0 * 129536 * 256 * rows_r / (avg_r * 1e-3) / 1e12 if rn else None}}
         row_bytes_b = (p.n + 1) * p.ctb
         avg_mm = mmms / max(mmn, 1)
         rows_mm = mmrows / max(mmn, 1)

@@ -185,7 +185,7 @@ int mfh_verify(mfh_ctx *ctx, const uint32_t *d_ssp, uint32_t alpha, uint32_t bet
                const uint64_t *d_proofs, size_t count, uint8_t *d_ok);
 
 /* The CRS expanded ONCE for the matrix-core path (the resident regime of the batch prover): mfh_crs_expand_mm writes the S, AS and
- * BT+BV regions as k_evalmm16's own tiles (mfh_crs_mm_image_bytes bytes: 12.4 GB at the default instance); while an image is
+ * BT+BV regions in MFMA A-fragment order (mfh_crs_mm_image_bytes bytes: 11.3 GB at the default instance); while an image is
  * registered with mfh_crs_set_resident_mm (NULL clears it), mfh_eval_rows_multi over exactly one of those regions -- hence
  * mfh_prove_batch -- streams it from HBM instead of regenerating the keystream.  Results are identical.  logq = 736 only. */
 size_t mfh_crs_mm_image_bytes(const mfh_ctx *ctx);
