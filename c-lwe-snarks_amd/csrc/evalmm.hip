@@ -454,44 +454,58 @@ __global__ __launch_bounds__(SW * 64) void k_mmstream(const v4i *__restrict__ im
   for (int t = 0; t < 2; t++)
 #pragma unroll
     for (int q = 0; q < NQ2; q++) acc[t][q] = v4i{0, 0, 0, 0};
-  constexpr int BPT = (RT2 / 64) * NQ2 * 64 / (SW * 64);  // digit fragments per thread and stage: 8
+  constexpr int KSN = RT2 / 64;                          // k-steps per stage: 4
+  constexpr int BPK = NQ2 * 64 / (SW * 64);              // digit fragments per thread and k-step: 2
+  constexpr int DEPTH = 8;                               // digit fragments in flight from LDS ahead of the MFMAs
   const v4i zero = {0, 0, 0, 0};
-  v4i an[2][RT2 / 64], bn[BPT];
-  auto fetch = [&](uint32_t u0) {  // the stage's A fragments of this wave and this thread's share of its digit fragments
+  auto a_load = [&](int t, uint32_t u0, int ks) -> v4i {
+    const bool live = t ? live1 : live0;
+    return live ? image[((uint64_t)(mt0 + t) * KS + (u0 >> 6) + ks) * 64 + lane] : zero;
+  };
+  v4i a[2][KSN];
+  if (r0 < r1) {
 #pragma unroll
-    for (int ks = 0; ks < RT2 / 64; ks++) {
-      an[0][ks] = live0 ? image[((uint64_t)mt0 * KS + (u0 >> 6) + ks) * 64 + lane] : zero;
-      an[1][ks] = live1 ? image[((uint64_t)(mt0 + 1) * KS + (u0 >> 6) + ks) * 64 + lane] : zero;
+    for (int ks = 0; ks < KSN; ks++) {
+      a[0][ks] = a_load(0, r0, ks);
+      a[1][ks] = a_load(1, r0, ks);
     }
 #pragma unroll
-    for (int i = 0; i < BPT; i++) bn[i] = cdv[(uint64_t)(u0 >> 6) * NQ2 * 64 + tid + SW * 64 * i];
-  };
-  if (r0 < r1) {
-    fetch(r0);
-#pragma unroll
-    for (int i = 0; i < BPT; i++) (&bfrag[0][0][0][0])[tid + SW * 64 * i] = bn[i];
+    for (int i = 0; i < KSN * BPK; i++) (&bfrag[0][0][0][0])[tid + SW * 64 * i] = cdv[(uint64_t)(r0 >> 6) * NQ2 * 64 + tid + SW * 64 * i];
   }
   __syncthreads();
   uint32_t buf = 0;
   for (uint32_t u0 = r0; u0 < r1; u0 += RT2) {
-    v4i a[2][RT2 / 64];
-#pragma unroll
-    for (int t = 0; t < 2; t++)
-#pragma unroll
-      for (int ks = 0; ks < RT2 / 64; ks++) a[t][ks] = an[t][ks];
     const bool more = u0 + RT2 < r1;
-    if (more) fetch(u0 + RT2);  // in flight under this stage's MFMAs
+    const v4i *bcur = &bfrag[buf][0][0][lane];  // fragment (ks, q) at bcur[(ks * NQ2 + q) * 64]
+    v4i *bnext = &bfrag[buf ^ 1][0][0][0];
+    // a ring of DEPTH digit fragments keeps the LDS reads ahead of the MFMAs that use them
+    v4i ring[DEPTH];
 #pragma unroll
-    for (int ks = 0; ks < RT2 / 64; ks++)
+    for (int i = 0; i < DEPTH; i++) ring[i] = bcur[i * 64];
+#pragma unroll
+    for (int ks = 0; ks < KSN; ks++) {
+      // this k-step's share of the next stage's digit fragments: global -> registers now, -> the other LDS buffer after the MFMAs
+      v4i bn[BPK];
+      if (more) {
+#pragma unroll
+        for (int i = 0; i < BPK; i++) bn[i] = cdv[(uint64_t)((u0 + RT2) >> 6) * NQ2 * 64 + (uint64_t)ks * NQ2 * 64 + tid + SW * 64 * i];
+      }
 #pragma unroll
       for (int q = 0; q < NQ2; q++) {
-        const v4i b = bfrag[buf][ks][q][lane];
+        const int it = ks * NQ2 + q;
+        const v4i b = ring[it % DEPTH];
+        if (it + DEPTH < KSN * NQ2) ring[it % DEPTH] = bcur[(it + DEPTH) * 64];
         acc[0][q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[0][ks], b, acc[0][q], 0, 0, 0);
         acc[1][q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[1][ks], b, acc[1][q], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);  // keep [refill one ring slot, two MFMAs] as written: the reads stay DEPTH fragments ahead
       }
-    if (more) {
+      if (more) {
+        // the A fragments of this k-step are spent: their registers take the next stage's (a whole stage to land)
+        a[0][ks] = a_load(0, u0 + RT2, ks);
+        a[1][ks] = a_load(1, u0 + RT2, ks);
 #pragma unroll
-      for (int i = 0; i < BPT; i++) (&bfrag[buf ^ 1][0][0][0])[tid + SW * 64 * i] = bn[i];
+        for (int i = 0; i < BPK; i++) bnext[ks * NQ2 * 64 + tid + SW * 64 * i] = bn[i];
+      }
     }
     __syncthreads();  // the other buffer is complete; everyone is done with this one
     buf ^= 1;
