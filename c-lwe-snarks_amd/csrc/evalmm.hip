@@ -681,9 +681,10 @@ int mfh_eval_rows_multi(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d
   const uint32_t ct = wide ? CT2 : CT, mb = ct * SB, rt = wide ? RT2 : RT;
   const uint32_t NT = wide ? NQ2 : (nvec * ND + 1 <= 64 ? 2 : 4), N = wide ? N2 : 32 * NT;
   const uint32_t ntiles = (n + 1 + ct - 1) / ct;
-  // row chunks: column tiles x 2 chunks = 736 (1472) workgroups = 2.9 (5.75) rounds of the 256 CUs (one workgroup per CU at a time); an
-  // int32 accumulator holds 131 071 rows
-  uint32_t nchunks = nrows >= 8 * rt ? 2 : 1;
+  // row chunks: 368 column tiles x 2 chunks = 736 workgroups = 2.9 rounds of the 256 CUs (one workgroup per CU at a time); an int32
+  // accumulator holds 131 071 rows
+  // (the 256-column kernels have 736 column tiles / 506 workgroups of row-tile pairs: one chunk already fills the CUs as evenly)
+  uint32_t nchunks = (!wide && nrows >= 8 * rt) ? 2 : 1;
   nchunks = std::max<uint32_t>(nchunks, ((uint32_t)nrows + 131070) / 131071);
   uint32_t rpc = ((uint32_t)nrows + nchunks - 1) / nchunks;
   rpc = (rpc + rt - 1) / rt * rt;
