@@ -592,7 +592,9 @@ __global__ void k_ssp_frag(const uint32_t *__restrict__ ssp, uint32_t nrowsel, u
     frag[(((tile * 4 + w) * 64 + lane) << 2) + eg] = lo | hi;
   }
 }
-// grid = (d / 128, row chunks); block = 4 waves, one 32-coefficient tile each.  part[((chunk * 4 + w) * 32 + stmt) * d + k].
+// grid = (d / 128, row chunks); block = 4 waves, one 32-coefficient tile each; MT = 1 or 2 tiles of 32 statements (the SSP is read
+// once per 32 MT statements).  part[((chunk * 4 + w) * 32 MT + stmt) * d + k].
+template <int MT>
 __global__ __launch_bounds__(256) void k_witness_mm(const v4i *__restrict__ sspfrag, const v4i *__restrict__ bitfrag, uint32_t nrowsel /* m - 1 */,
                                                     uint32_t ksteps_per_chunk, uint32_t d, int *__restrict__ part) {
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -600,34 +602,42 @@ __global__ __launch_bounds__(256) void k_witness_mm(const v4i *__restrict__ sspf
   const uint32_t kt = blockIdx.x * 4 + wave, KT = d / 32;
   const uint32_t k = kt * 32 + r32;
   const uint32_t K0 = blockIdx.y * ksteps_per_chunk, K1 = min((nrowsel + 31) / 32, K0 + ksteps_per_chunk);
-  v16i acc[4];
+  v16i acc[MT][4];
 #pragma unroll
-  for (int w = 0; w < 4; w++)
+  for (int t = 0; t < MT; t++)
 #pragma unroll
-    for (int e = 0; e < 16; e++) acc[w][e] = 0;
+    for (int w = 0; w < 4; w++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[t][w][e] = 0;
   for (uint32_t K = K0; K < K1; K++) {
     const v4i *src = sspfrag + (((uint64_t)K * KT + kt) * 4) * 64 + lane;
     const v4i b0 = src[0], b1 = src[64], b2 = src[128], b3 = src[192];
-    const v4i a = bitfrag[(uint64_t)K * 64 + lane];
-    acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b0, acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b1, acc[1], 0, 0, 0);
-    acc[2] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b2, acc[2], 0, 0, 0);
-    acc[3] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b3, acc[3], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < MT; t++) {
+      const v4i a = bitfrag[((uint64_t)K * MT + t) * 64 + lane];
+      acc[t][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b0, acc[t][0], 0, 0, 0);
+      acc[t][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b1, acc[t][1], 0, 0, 0);
+      acc[t][2] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b2, acc[t][2], 0, 0, 0);
+      acc[t][3] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b3, acc[t][3], 0, 0, 0);
+    }
   }
 #pragma unroll
-  for (int w = 0; w < 4; w++)
+  for (int t = 0; t < MT; t++)
 #pragma unroll
-    for (int e = 0; e < 16; e++) {
-      const uint32_t stmt = (e & 3) + 8 * (e >> 2) + 4 * h;
-      part[(((uint64_t)blockIdx.y * 4 + w) * 32 + stmt) * d + k] = acc[w][e];
-    }
+    for (int w = 0; w < 4; w++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        const uint32_t stmt = 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h;
+        part[(((uint64_t)blockIdx.y * 4 + w) * (32 * MT) + stmt) * d + k] = acc[t][w][e];
+      }
 }
-// bits of nstmt statements (packed, bits_stride bytes apart) -> A fragments: bitfrag[K][lane (stmt = l & 31, h)][e] = bit (32 K + 16 h + e)
-__global__ void k_witness_bits(const uint8_t *__restrict__ bits, size_t bits_stride, uint32_t nstmt, uint32_t nrowsel, uint32_t ksteps,
+// bits of nstmt statements (packed, bits_stride bytes apart) -> A fragments: bitfrag[K][t][lane (stmt = 32 t + (l & 31), h)][e] = bit
+// (32 K + 16 h + e) of that statement
+__global__ void k_witness_bits(const uint8_t *__restrict__ bits, size_t bits_stride, uint32_t nstmt, uint32_t nrowsel, uint32_t ksteps, uint32_t MT,
                                int8_t *__restrict__ bitfrag) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;  // one output byte
-  if (i >= ksteps * 1024) return;
-  const uint32_t e = i & 15, lane = (i >> 4) & 63, K = i >> 10, stmt = lane & 31, h = lane >> 5;
+  if (i >= ksteps * MT * 1024) return;
+  const uint32_t e = i & 15, lane = (i >> 4) & 63, t = (i >> 10) % MT, K = (i >> 10) / MT, stmt = 32 * t + (lane & 31), h = lane >> 5;
   const uint32_t r = K * 32 + 16 * h + e;
   int8_t v = 0;
   if (stmt < nstmt && r < nrowsel) v = (int8_t)((bits[stmt * bits_stride + (r >> 3)] >> (r & 7)) & 1);
@@ -635,7 +645,7 @@ __global__ void k_witness_bits(const uint8_t *__restrict__ bits, size_t bits_str
 }
 // w_b[k] = delta_b t[k] + sum_i bit_b[i] v_i[k] mod p from the chunk partials: sum_w 256^w (G'_w + 128 cnt_b)
 __global__ void k_witness_mm_finish(const int *__restrict__ part, uint32_t nchunks, const uint32_t *__restrict__ t, const uint32_t *__restrict__ cnt_delta,
-                                    uint32_t nstmt, uint32_t d, uint32_t *__restrict__ w_out) {
+                                    uint32_t nstmt, uint32_t mrows /* 32 MT */, uint32_t d, uint32_t *__restrict__ w_out) {
   const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
   if (k >= d || b >= nstmt) return;
   const uint64_t corr = 128ull * cnt_delta[2 * b];
@@ -644,7 +654,7 @@ __global__ void k_witness_mm_finish(const int *__restrict__ part, uint32_t nchun
 #pragma unroll
   for (int w = 0; w < 4; w++) {
     int64_t g = 0;
-    for (uint32_t ch = 0; ch < nchunks; ch++) g += part[(((uint64_t)ch * 4 + w) * 32 + b) * d + k];
+    for (uint32_t ch = 0; ch < nchunks; ch++) g += part[(((uint64_t)ch * 4 + w) * mrows + b) * d + k];
     val += (uint64_t)(g + (int64_t)corr) << (8 * w);  // the true byte sum: >= 0
   }
   const uint64_t P = MFH_P;
@@ -779,10 +789,11 @@ int mfh_crs_set_resident_mm(mfh_ctx *c, const uint8_t *d_image) {
   return MFH_OK;
 }
 
-// mfh_witness_poly for up to 32 statements in ONE read of the (dense) SSP, on the matrix cores: d_w = nstmt polynomials of d coefficients
+// mfh_witness_poly for up to 64 statements in ONE read of the (dense) SSP, on the matrix cores: d_w = nstmt polynomials of d coefficients
 int mfh_witness_poly_mm(mfh_ctx *c, const uint32_t *d_ssp, uint32_t nstmt, const uint8_t *h_bits, size_t bits_stride, const uint32_t *h_delta,
                         uint32_t *d_w) {
-  if (!c || !d_ssp || !h_bits || !h_delta || !d_w || nstmt == 0 || nstmt > 32) return MFH_EINVAL;
+  if (!c || !d_ssp || !h_bits || !h_delta || !d_w || nstmt == 0 || nstmt > 64) return MFH_EINVAL;
+  const uint32_t MT = nstmt > 32 ? 2 : 1;
   const uint32_t d = c->P.d, m = c->P.m;
   if (d % 128 || m < 2) { c->err = "mfh_witness_poly_mm: d must be a multiple of 128"; return MFH_EUNSUPPORTED; }
   for (uint32_t b = 0; b < nstmt; b++)
@@ -803,8 +814,8 @@ int mfh_witness_poly_mm(mfh_ctx *c, const uint32_t *d_ssp, uint32_t nstmt, const
     HIP_TRY(c, hipGetLastError());
     c->ssp_frag_src = d_ssp;
   }
-  const size_t packed = (size_t)nstmt * bits_stride, head_b = ((packed + 32 * 8 + 255) & ~(size_t)255);
-  const size_t frag_b = (size_t)ksteps * 1024, part_b = (size_t)nchunks * 4 * 32 * d * 4;
+  const size_t packed = (size_t)nstmt * bits_stride, head_b = ((packed + 64 * 8 + 255) & ~(size_t)255);
+  const size_t frag_b = (size_t)ksteps * MT * 1024, part_b = (size_t)nchunks * 4 * 32 * MT * d * 4;
   int rc = wws_reserve(c, head_b + frag_b + part_b);
   if (rc) return rc;
   // staged: packed bits, then (count of selected rows, delta) per statement
@@ -824,11 +835,15 @@ int mfh_witness_poly_mm(mfh_ctx *c, const uint32_t *d_ssp, uint32_t nstmt, const
   const uint32_t *d_cd = (const uint32_t *)(dev + packed + ((8 - packed % 8) % 8));
   int8_t *d_frag = (int8_t *)(dev + head_b);
   int *d_part = (int *)(dev + head_b + frag_b);
-  hipLaunchKernelGGL(k_witness_bits, dim3((uint32_t)((frag_b + 255) / 256)), dim3(256), 0, c->stream, dev, bits_stride, nstmt, nrowsel, ksteps, d_frag);
-  hipLaunchKernelGGL(k_witness_mm, dim3(d / 128, (ksteps + kpc - 1) / kpc), dim3(256), 0, c->stream, (const v4i *)c->ssp_frag, (const v4i *)d_frag, nrowsel, kpc, d,
-                     d_part);
-  hipLaunchKernelGGL(k_witness_mm_finish, dim3((d + 255) / 256, nstmt), dim3(256), 0, c->stream, d_part, (ksteps + kpc - 1) / kpc, d_ssp, d_cd, nstmt, d,
-                     d_w);
+  hipLaunchKernelGGL(k_witness_bits, dim3((uint32_t)((frag_b + 255) / 256)), dim3(256), 0, c->stream, dev, bits_stride, nstmt, nrowsel, ksteps, MT, d_frag);
+  if (MT == 1)
+    hipLaunchKernelGGL(k_witness_mm<1>, dim3(d / 128, (ksteps + kpc - 1) / kpc), dim3(256), 0, c->stream, (const v4i *)c->ssp_frag, (const v4i *)d_frag,
+                       nrowsel, kpc, d, d_part);
+  else
+    hipLaunchKernelGGL(k_witness_mm<2>, dim3(d / 128, (ksteps + kpc - 1) / kpc), dim3(256), 0, c->stream, (const v4i *)c->ssp_frag, (const v4i *)d_frag,
+                       nrowsel, kpc, d, d_part);
+  hipLaunchKernelGGL(k_witness_mm_finish, dim3((d + 255) / 256, nstmt), dim3(256), 0, c->stream, d_part, (ksteps + kpc - 1) / kpc, d_ssp, d_cd, nstmt, 32 * MT,
+                     d, d_w);
   HIP_TRY(c, hipGetLastError());
   return MFH_OK;
 }

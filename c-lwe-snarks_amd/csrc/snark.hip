@@ -423,8 +423,8 @@ int mfh_prove(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, const 
 
 // prover() for a batch of statements under one CRS and SSP.  The S and AS regions are expanded ONCE per group of up to 31 proofs and
 // the BT+BV region once per up to 248 (b_w's coefficients are witness bits: one byte-digit column per proof), the multiply-accumulate of
-// all their coefficient vectors runs on the matrix cores (mfh_eval_rows_multi, evalmm.hip); the witness pass reads the SSP once per group (as
-// a GEMM of the witness bits with the SSP bytes on the matrix cores); the polynomial step and the smudging stay per proof.  Proof b is bit-identical to mfh_prove with the same inputs.
+// all their coefficient vectors runs on the matrix cores (mfh_eval_rows_multi, evalmm.hip); the witness pass reads the SSP once per 62
+// statements (as a GEMM of the witness bits with the SSP bytes on the matrix cores); the polynomial step and the smudging stay per proof.  Proof b is bit-identical to mfh_prove with the same inputs.
 int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, uint32_t nproofs, const uint8_t *h_witness_bits,
                     size_t bits_stride, const uint32_t *h_delta, const uint8_t *h_smudge_mag, size_t maglen, const uint8_t *h_smudge_sign,
                     uint64_t *d_proofs) {
@@ -446,15 +446,15 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
   constexpr uint32_t G = 31;    // proofs per S / AS expansion: 62 coefficient vectors x 4 bytes + the ones column = 249 of 256 digit columns
   constexpr uint32_t SG = 248;  // proofs per BT+BV expansion: one byte column each + the ones column = 249 of 256 digit columns
   HIP_TRY(c, hipSetDevice(c->device));
-  // scratch: W | H | V (g x d each, in this order: the S region takes (W, H), the AS region (H, V)), CW (SG x m), ONE (1 word), OUT
-  // (SG ciphertexts, >= 2G), CT_T (1 ciphertext)
-  const size_t words = (size_t)3 * G * d + (size_t)SG * m + 64, need = words * 4 + (size_t)(SG + 1) * ctl * 8;
+  // scratch: W | H | V (g x d each, in this order: the S region takes (W, H), the AS region (H, V)), CW (SG x m), ONE (1 word), WALL (the
+  // witness polynomials of the whole super-group, SG x d), OUT (SG ciphertexts, >= 2G), CT_T (1 ciphertext)
+  const size_t words = (size_t)3 * G * d + (size_t)SG * m + 64 + (size_t)SG * d, need = words * 4 + (size_t)(SG + 1) * ctl * 8;
   if (c->batch_bytes < need) {
     if (c->d_batch) { hipStreamSynchronize(c->stream); hipFree(c->d_batch); c->d_batch = nullptr; c->batch_bytes = 0; }
     HIP_TRY(c, hipMalloc(&c->d_batch, need));
     c->batch_bytes = need;
   }
-  uint32_t *const base = (uint32_t *)c->d_batch, *const CW = base + (size_t)3 * G * d, *const ONE = CW + (size_t)SG * m;
+  uint32_t *const base = (uint32_t *)c->d_batch, *const CW = base + (size_t)3 * G * d, *const ONE = CW + (size_t)SG * m, *const WALL = ONE + 64;
   uint64_t *const OUT = (uint64_t *)((uint8_t *)c->d_batch + words * 4), *const CT_T = OUT + (size_t)SG * ctl;
   // ct_t = the BT row as a ciphertext (eval_poly of one row with coefficient 1): b_w's delta * ct_t term is added per proof below
   {
@@ -491,14 +491,23 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
                          (c->P.logq + 63) / 64, 2 * (c->P.logq / 64));
       HIP_TRY(c, hipGetLastError());
     }
+    // w = delta t + sum_bits v_i for the whole super-group (src/snark.c:141,147-155): dense SSP with d % 128 == 0: a GEMM on the matrix
+    // cores, one read of the SSP per 62 statements; otherwise the VALU forms
+    const bool wit_mm = src.dense && d % 128 == 0;
+    if (wit_mm) {
+      for (uint32_t b0 = 0; b0 < sg; b0 += 62) {
+        int rcw = mfh_witness_poly_mm(c, d_ssp, std::min(62u, sg - b0), h_witness_bits + (size_t)(s0 + b0) * bits_stride, bits_stride,
+                                      h_delta + s0 + b0, WALL + (size_t)b0 * d);
+        if (rcw) return rcw;
+      }
+    }
     for (uint32_t g0 = s0; g0 < s0 + sg; g0 += G) {
       const uint32_t g = std::min(G, s0 + sg - g0);
       uint64_t *proofs = d_proofs + (size_t)g0 * 5 * ctl;
       uint32_t *W = base, *H = W + (size_t)g * d, *V = H + (size_t)g * d;  // g-strided blocks: (W, H) and (H, V) are contiguous 2g-vector matrices
       // per proof: w = delta t + sum_bits v_i, v = w + v_0, h = (v^2 - 1) / t   (src/snark.c:141-169)
-      if (src.dense && d % 128 == 0) {  // the whole group in ONE read of the SSP, on the matrix cores
-        int rcw = mfh_witness_poly_mm(c, d_ssp, g, h_witness_bits + (size_t)g0 * bits_stride, bits_stride, h_delta + g0, W);
-        if (rcw) return rcw;
+      if (wit_mm) {
+        HIP_TRY(c, hipMemcpyAsync(W, WALL + (size_t)(g0 - s0) * d, (size_t)g * d * 4, hipMemcpyDeviceToDevice, c->stream));
       } else if (src.dense) {  // VALU form: the SSP is read once per (at most 12) statements
         for (uint32_t b0 = 0; b0 < g; b0 += 12) {
           int rcw = mfh_witness_poly_multi(c, d_ssp, std::min(12u, g - b0), h_witness_bits + (size_t)(g0 + b0) * bits_stride, bits_stride,
