@@ -374,11 +374,18 @@ def main():
             avg_r = rms / max(rn, 1)
             rows_r = rrows / max(rn, 1)
             read_gbs = rows_r * tile_bytes_per_row / (avg_r * 1e-3) / 1e9 if rn else None
+            traffic_ms = None
+            tfs = os.path.join(ROOT, "profiles", "traffic_mmstream.json")
+            if os.path.exists(tfs):
+                try:
+                    traffic_ms = json.load(open(tfs)).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic_ms = None
             resident_b = {"value": world * nb * args.steps / el_rb, "unit": "proofs/s", "ms_per_step": el_rb / args.steps * 1e3,
                           "proofs_identical_to_regenerated": same_rb, "crs_expand_s": expand_mm_s, "image_bytes_per_rank": img_bytes,
                           "roofline": {"bound": "hbm", "kernel": "k_mmstream (A fragments streamed from the image, digit fragments through LDS, i8 MFMA 16x16x64)",
                                        "achieved": read_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (read_gbs / HBM_PEAK_GBS) if read_gbs else None,
-                                       "traffic": None, "bytes_read_per_row": tile_bytes_per_row, "launches": rn, "avg_launch_ms": avg_r,
+                                       "traffic": traffic_ms, "bytes_read_per_row": tile_bytes_per_row, "launches": rn, "avg_launch_ms": avg_r,
                                        "rows_per_launch": rows_r,
                                        "mfma_int8_tops": 2.0 * 129536 * 256 * rows_r / (avg_r * 1e-3) / 1e12 if rn else None}}
         row_bytes_b = (p.n + 1) * p.ctb

@@ -63,6 +63,15 @@ if mm and "FETCH_SIZE" in mm and "WRITE_SIZE" in mm:
                        "region and the 8 MB digit matrix, and writes 132 MB of int32 partial products)"},
               open(os.path.join(out_dir, "traffic_evalmm.json"), "w"), indent=1)
     print("traffic evalmm", fetch + write)
+ms = next((v for k, v in res.items() if "k_mmstream" in k), None)
+if ms and "FETCH_SIZE" in ms and "WRITE_SIZE" in ms:
+    fetch = ms["FETCH_SIZE"]["mean"] * 1024 * 2
+    write = ms["WRITE_SIZE"]["mean"] * 1024
+    json.dump({"kernel": "k_mmstream", "fetch_bytes_x2_corrected": fetch, "write_bytes": write, "hbm_bytes_per_launch": fetch + write,
+               "note": "separate --pmc passes; FETCH_SIZE doubled per the gfx950 correction for wide coalesced streaming reads; algorithmic: "
+                       "4.24 GB of A fragments (S / AS region) + 8 MB of digits read, 133 MB of int32 partial products written"},
+              open(os.path.join(out_dir, "traffic_mmstream.json"), "w"), indent=1)
+    print("traffic mmstream", fetch + write)
 mr = next((v for k, v in res.items() if k.startswith("void k_mac_resident<736, 2>")), None)
 if mr and "FETCH_SIZE" in mr and "WRITE_SIZE" in mr:
     fetch = mr["FETCH_SIZE"]["mean"] * 1024 * 2
