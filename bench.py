@@ -342,7 +342,7 @@ def main():
             ta = torch.tensor([1 if all_ok else 0], dtype=torch.int64, device=ctx.device)
             dist.all_reduce(ta, op=dist.ReduceOp.MIN)
             all_ok = bool(int(ta.item()))
-        # second regime of the batch prover: the CRS expanded once into the matrix-core kernel's tile image, streamed from HBM
+        # second regime of the batch prover: the CRS expanded once in MFMA A-fragment order, streamed from HBM by k_mmstream
         resident_b = None
         if not args.no_resident and int(ctx.lib.mfh_crs_mm_image_bytes(ctx._h)) <= args.resident_gb * 1e9:
             torch.cuda.synchronize()

@@ -16,7 +16,15 @@
 // sum_i A'[m] comes out of the same MFMA through one extra digit column of ones, sum_i C'[n] from a small kernel.  |A'C'| <= 16384: an
 // int32 accumulator holds 131 071 rows; launches split the rows accordingly.  128 digit columns = 31 vectors + the ones column.
 //
-// Workgroup = 1024 threads, one column tile of CT = 4 coordinates (352 byte positions = 11 MFMA row tiles) x one row chunk.
+// Kernels in this file:
+//   k_evalmm<NT>     128 digit columns (v_mfma_i32_32x32x32_i8, 4-coordinate column tiles): described next
+//   k_evalmm16<0>    256 digit columns (v_mfma_i32_16x16x64_i8, 2-coordinate column tiles): 31 proofs' vector pairs per expansion
+//   k_evalmm16<1>    expansion only: the rows written to HBM in MFMA A-fragment order (the resident image of the batch prover)
+//   k_mmstream       the same GEMM streamed from that image: no AES, HBM / matrix-core bound
+//   k_witness_mm     the witness pass of up to 64 statements as a GEMM of witness bits x SSP bytes (one read of the SSP)
+//   k_mm_digits / k_mm_colsum / k_evalmm_finish, k_ssp_frag / k_witness_bits / k_witness_mm_finish: operand preparation and epilogues
+//
+// k_evalmm: workgroup = 1024 threads, one column tile of CT = 4 coordinates (352 byte positions = 11 MFMA row tiles) x one row chunk.
 // Per unit of RT = 128 rows: (1) all 16 waves expand the 128 x 368-byte row segments into a row-major LDS tile (23-24 AES blocks
 // per row, the product AES of aes_dev.hpp); (2) waves 0..10 gather their A fragments from the tile (byte position m of 16
 // consecutive rows: the row<->byte transposition every MFMA formulation of this product needs, done on the read side), load the
