@@ -852,6 +852,30 @@ __global__ __launch_bounds__(256) void k_witness_partial_multi(const uint32_t *_
     o[0] = acc[b][0]; o[1] = acc[b][1]; o[2] = acc[b][2]; o[3] = acc[b][3];
   }
 }
+// the same with generator-defined rows (csrc/ssp_prg.hpp): every selected row is GENERATED once per NB statements
+template <int NB>
+__global__ __launch_bounds__(256) void k_witness_partial_multi_prg(uint64_t seed, const uint2 *__restrict__ list, uint32_t nsel, uint32_t d,
+                                                                   uint64_t *__restrict__ partial) {
+  const uint32_t k4 = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k4 * 4 >= d) return;
+  const uint32_t G = gridDim.y, g = blockIdx.y, k = k4 * 4;
+  uint64_t acc[NB][4];
+#pragma unroll
+  for (int b = 0; b < NB; b++) acc[b][0] = acc[b][1] = acc[b][2] = acc[b][3] = 0;
+  for (uint32_t i = g; i < nsel; i += G) {
+    const uint2 e = list[i];
+    const uint32_t rk = mf::ssp_prg_rowkey(seed, e.x);
+    const uint32_t v0 = mf::ssp_prg_raw(rk, k), v1 = mf::ssp_prg_raw(rk, k + 1), v2 = mf::ssp_prg_raw(rk, k + 2), v3 = mf::ssp_prg_raw(rk, k + 3);
+#pragma unroll
+    for (int b = 0; b < NB; b++)
+      if ((e.y >> b) & 1) { acc[b][0] += v0; acc[b][1] += v1; acc[b][2] += v2; acc[b][3] += v3; }
+  }
+#pragma unroll
+  for (int b = 0; b < NB; b++) {
+    uint64_t *o = partial + ((uint64_t)b * G + g) * d + k;
+    o[0] = acc[b][0]; o[1] = acc[b][1]; o[2] = acc[b][2]; o[3] = acc[b][3];
+  }
+}
 // materialise generator-defined slots [first, first+nslots) as a dense uint32 image (tests; small instances)
 __global__ void k_ssp_prg_fill(uint64_t seed, uint32_t first_slot, uint32_t d, uint64_t total, uint32_t *__restrict__ out) {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -1517,11 +1541,17 @@ int mfh_witness_poly(mfh_ctx *c, const uint32_t *d_ssp, const uint8_t *h_bits, u
   return MFH_OK;
 }
 
-// mfh_witness_poly for up to 12 statements in one pass over the SSP (dense SSP only): d_w = nstmt polynomials of d coefficients
+// mfh_witness_poly for up to 12 statements in one pass over the SSP (d_ssp == NULL: the rows are generated once per pass): d_w = nstmt
+// polynomials of d coefficients
 int mfh_witness_poly_multi(mfh_ctx *c, const uint32_t *d_ssp, uint32_t nstmt, const uint8_t *h_bits, size_t bits_stride, const uint32_t *h_delta,
                            uint32_t *d_w) {
   constexpr int NB = 12;
-  if (!c || !d_ssp || !h_bits || !h_delta || !d_w || nstmt == 0 || nstmt > NB) return MFH_EINVAL;
+  if (!c || !h_bits || !h_delta || !d_w || nstmt == 0 || nstmt > NB) return MFH_EINVAL;
+  mf::SspSrc src;  // d_ssp == NULL: the registered generator-defined SSP
+  {
+    int rc0 = ssp_src(c, d_ssp, src);
+    if (rc0) return rc0;
+  }
   const uint32_t d = c->P.d, m = c->P.m;
   if (d % 4) { c->err = "d must be a multiple of 4"; return MFH_EINVAL; }
   for (uint32_t b = 0; b < nstmt; b++)
@@ -1543,10 +1573,13 @@ int mfh_witness_poly_multi(mfh_ctx *c, const uint32_t *d_ssp, uint32_t nstmt, co
   uint64_t *partial = (uint64_t *)((uint8_t *)c->wws + list_b);
   if (nsel) HIP_TRY(c, hipMemcpyAsync(d_list, list, (size_t)nsel * 8, hipMemcpyHostToDevice, c->stream));
   pin_release(c, c->pin_rows);
-  hipLaunchKernelGGL(k_witness_partial_multi<NB>, dim3((d / 4 + 255) / 256, G), dim3(256), 0, c->stream, d_ssp, d_list, nsel, d, partial);
+  if (src.dense)
+    hipLaunchKernelGGL(k_witness_partial_multi<NB>, dim3((d / 4 + 255) / 256, G), dim3(256), 0, c->stream, src.dense, d_list, nsel, d, partial);
+  else
+    hipLaunchKernelGGL(k_witness_partial_multi_prg<NB>, dim3((d / 4 + 255) / 256, G), dim3(256), 0, c->stream, src.seed, d_list, nsel, d, partial);
   HIP_TRY(c, hipGetLastError());
   for (uint32_t b = 0; b < nstmt; b++)
-    hipLaunchKernelGGL(k_witness_finish, dim3((d + 255) / 256), dim3(256), 0, c->stream, d_ssp, partial + (size_t)b * G * d, G, d, h_delta[b],
+    hipLaunchKernelGGL(k_witness_finish, dim3((d + 255) / 256), dim3(256), 0, c->stream, src.t, partial + (size_t)b * G * d, G, d, h_delta[b],
                        d_w + (size_t)b * d);
   HIP_TRY(c, hipGetLastError());
   return MFH_OK;

@@ -508,16 +508,12 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
       // per proof: w = delta t + sum_bits v_i, v = w + v_0, h = (v^2 - 1) / t   (src/snark.c:141-169)
       if (wit_mm) {
         HIP_TRY(c, hipMemcpyAsync(W, WALL + (size_t)(g0 - s0) * d, (size_t)g * d * 4, hipMemcpyDeviceToDevice, c->stream));
-      } else if (src.dense) {  // VALU form: the SSP is read once per (at most 12) statements
+      } else {  // VALU form: the SSP is read (or, generator-defined, generated) once per (at most 12) statements
         for (uint32_t b0 = 0; b0 < g; b0 += 12) {
           int rcw = mfh_witness_poly_multi(c, d_ssp, std::min(12u, g - b0), h_witness_bits + (size_t)(g0 + b0) * bits_stride, bits_stride,
                                            h_delta + g0 + b0, W + (size_t)b0 * d);
           if (rcw) return rcw;
         }
-      }
-      for (uint32_t b = 0; b < g && !src.dense; b++) {
-        rc = mfh_witness_poly(c, d_ssp, h_witness_bits + (size_t)(g0 + b) * bits_stride, h_delta[g0 + b], W + (size_t)b * d);
-        if (rc) return rc;
       }
       hipLaunchKernelGGL(k_add_slot_multi, dim3((d + 255) / 256, g), dim3(256), 0, c->stream, W, src, 1u, d, V);  // v = w + v_0 for the group
       HIP_TRY(c, hipGetLastError());

@@ -207,8 +207,8 @@ int mfh_prove_batch(mfh_ctx *ctx, const uint8_t *d_crs_c8, const uint32_t *d_ssp
 int mfh_prove_partial(mfh_ctx *ctx, const uint8_t *d_crs_c8, const uint32_t *d_ssp, const uint8_t *h_witness_bits, uint32_t delta,
                       uint32_t rank, uint32_t world, uint64_t *d_partial);
 int mfh_prove_finish(mfh_ctx *ctx, uint64_t *d_proof, const uint8_t *h_smudge_mag, size_t maglen, const uint8_t *h_smudge_sign);
-/* mfh_witness_poly for nstmt <= 12 statements in ONE pass over the (dense) SSP: every selected v_i is read once and added into the
- * polynomials of the statements whose bit selects it.  h_bits: nstmt bit strings bits_stride bytes apart; d_w: nstmt x d coefficients. */
+/* mfh_witness_poly for nstmt <= 12 statements in ONE pass over the SSP: every selected v_i is read (d_ssp == NULL: generated) once and
+ * added into the polynomials of the statements whose bit selects it.  h_bits: nstmt bit strings bits_stride bytes apart; d_w: nstmt x d coefficients. */
 int mfh_witness_poly_multi(mfh_ctx *ctx, const uint32_t *d_ssp, uint32_t nstmt, const uint8_t *h_bits, size_t bits_stride, const uint32_t *h_delta,
                            uint32_t *d_w);
 /* The same for nstmt <= 64 statements in ONE read of the SSP, as a GEMM on the matrix cores (bits x SSP bytes, exact); d a multiple

@@ -61,6 +61,18 @@ def test_generator_mode_equals_dense_mode_and_oracle(gpu_ctx_factory, oracle, mf
     part = ctx.prove_partial_w(d_crs, None, bits, delta, 0, 1, lanes)
     ctx.prove_finish(part, mags, signs)
     assert torch.equal(part, proof)
+    # the batch prover in generator mode: 14 statements (the witness pass generates every selected row once per 12) == the dense SSP
+    nb = 14
+    stmts = [bits if b % 3 else rng.bytes((p.m + 7) // 8) for b in range(nb)]
+    deltas = [int(x) for x in rng.integers(0, ol.P, size=nb, dtype=np.uint64)]
+    bm = [rng.integers(0, 256, size=400, dtype=np.uint8).tobytes() for _ in range(nb)]
+    bs = [bytes(rng.integers(0, 2, size=5, dtype=np.uint8).tolist()) for _ in range(nb)]
+    ctx.ssp_prepare(None)
+    gen = ctx.prove_batch(d_crs, None, stmts, deltas, bm, bs).clone()
+    ctx.ssp_prepare(dense)
+    assert torch.equal(ctx.prove_batch(d_crs, dense, stmts, deltas, bm, bs), gen)
+    ctx.ssp_prepare(None)
+    assert torch.equal(gen.view(nb, -1)[1], ctx.prove(d_crs, None, stmts[1], deltas[1], bm[1], bs[1]))
 
 
 @pytest.mark.parametrize("logq", [736, 1472])
