@@ -98,12 +98,13 @@ struct RowGeom {
   uint32_t head;  // byte offset of the segment inside that block
   uint32_t nblk;
 };
-__device__ __forceinline__ RowGeom row_geom(uint64_t off, uint64_t row, uint32_t n, uint32_t j0, uint32_t nks /* keystream-backed coords */) {
-  const uint64_t B0 = off + row * ((uint64_t)n * VB) + (uint64_t)j0 * VB;
+__device__ __forceinline__ RowGeom row_geom(uint64_t off, uint64_t row, uint32_t n, uint32_t j0, uint32_t nks /* keystream-backed coords */,
+                                            uint32_t vb = VB) {
+  const uint64_t B0 = off + row * ((uint64_t)n * vb) + (uint64_t)j0 * vb;
   RowGeom g;
   g.cb0 = B0 >> 4;
   g.head = (uint32_t)(B0 & 15);
-  g.nblk = nks ? (g.head + nks * VB + 15) >> 4 : 0;
+  g.nblk = nks ? (g.head + nks * vb + 15) >> 4 : 0;
   return g;
 }
 
@@ -240,17 +241,25 @@ __global__ __launch_bounds__(1024) void k_evalmm(AesKey key /* rk[56..59] ^ 0x80
 // the 16 waves).  The unit's digit fragments (64 KiB) do not fit LDS beside the table and the tile: they are staged per 64-row
 // k-step (16 KiB), double buffered, by the waves that have no row tile (11..15; they prefetch the fragments into their idle accumulator
 // registers under the expansion), one barrier per k-step.
-constexpr int CT2 = 2, MB2 = CT2 * SB, MT2 = MB2 / 16, RT2 = 256, TS2 = 192, BPR2 = 12, NQ2 = 16, N2 = 16 * NQ2;
-static_assert(MB2 % 16 == 0 && MT2 <= 16 && RT2 * BPR2 == 3 * 1024, "wide tile geometry");
+// logq = 1472 (values of 184 bytes, all significant) has the same 184-byte row segment with ONE coordinate per column tile: 184 byte
+// positions = 11.5 row tiles, padded to 12 (the last 8 positions are never read back).
+constexpr int RT2 = 256, TS2 = 192, BPR2 = 12, NQ2 = 16, N2 = 16 * NQ2;
+template <int LOGQ> struct W16;
+template <> struct W16<736> { static constexpr int CT = 2, SBY = 88, VBY = 92, MT = 11, MBP = 176, KW = 22, LL = 12; };
+template <> struct W16<1472> { static constexpr int CT = 1, SBY = 184, VBY = 184, MT = 12, MBP = 192, KW = 46, LL = 23; };
+static_assert(RT2 * BPR2 == 3 * 1024 && W16<736>::CT * W16<736>::VBY + 8 <= TS2 && W16<1472>::CT * W16<1472>::VBY + 8 <= TS2, "wide tile geometry");
 
 // MODE 0: regenerate the keystream (AES) and multiply-accumulate.  MODE 1: regenerate and WRITE the rows to `image` in A-FRAGMENT order
 // (offset-by-128 bytes, b coordinate included) -- the CRS expanded once for the matrix-core path, streamed by k_mmstream below.
 // Fragment of (row tile mt = 11 * column tile + wave, 64-row k-step s): 64 lanes x 16 bytes at image + ((mt * KS + s) * 64 + lane) * 16,
 // KS = 4 * ceil(rows / 256) k-steps per region.
-template <int MODE>
+template <int MODE, int LOGQ>
 __global__ __launch_bounds__(1024) void k_evalmm16(AesKey key /* rk[56..59] ^ 0x80808080 */, const uint32_t *__restrict__ g_t0, uint64_t off,
                                                    uint32_t n, uint32_t nrows, uint32_t rows_per_chunk, const uint8_t *__restrict__ c8,
                                                    const int8_t *__restrict__ cd, int *__restrict__ part, uint8_t *__restrict__ image) {
+  using G = W16<LOGQ>;
+  constexpr int CT2 = G::CT, MT2 = G::MT, MB2 = G::MBP, NSW = (16 - G::MT) * 64;  // NSW threads stage fragments / span constants
+  constexpr uint32_t SBq = G::SBY, VBq = G::VBY;
   struct __attribute__((aligned(16))) Lds {
     uint32_t lt[mf::kTabBytes / 4];  // first: LDS address 0 (aes_dev.hpp)
     uint8_t tile[RT2 * TS2];
@@ -274,14 +283,14 @@ __global__ __launch_bounds__(1024) void k_evalmm16(AesKey key /* rk[56..59] ^ 0x
 
   const uint32_t c16 = lane & 15, g4 = lane >> 4;
   const uint32_t m = wave * 16 + c16;  // byte position, < MB2 for waves < MT2
-  const uint32_t mcol = (m / SB) * VB + (m % SB);
-  const uint32_t hstep = (n * VB) & 15;
+  const uint32_t mcol = (m / SBq) * VBq + (m % SBq);
+  const uint32_t hstep = (n * VBq) & 15;
 
   auto span_task = [&](uint32_t u0, uint32_t task) {  // task = 2 * local row + which span
     const uint32_t lr = task >> 1, which = task & 1;
     const uint64_t row = (uint64_t)u0 + lr;
     if (row >= r1 || !nks) return;
-    const RowGeom g = row_geom(off, row, n, j0, nks);
+    const RowGeom g = row_geom(off, row, n, j0, nks, VBq);
     const uint64_t sp0 = g.cb0 >> 8, sp1 = (g.cb0 + g.nblk - 1) >> 8;
     if (which && sp1 == sp0) return;
     uint32_t sc[5];
@@ -302,7 +311,7 @@ __global__ __launch_bounds__(1024) void k_evalmm16(AesKey key /* rk[56..59] ^ 0x
         const uint64_t row = (uint64_t)u0 + lr;
         uint32_t w[4] = {0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};  // rows past the region: A' = -128, i.e. A = 0
         if (row < r1) {
-          const RowGeom g = row_geom(off, row, n, j0, nks);
+          const RowGeom g = row_geom(off, row, n, j0, nks, VBq);
           if (k < g.nblk) {
             const uint64_t ctr = g.cb0 + k;
             const uint32_t *scp = lds.spanc[lr][(uint32_t)((ctr >> 8) - (g.cb0 >> 8))];
@@ -314,17 +323,17 @@ __global__ __launch_bounds__(1024) void k_evalmm16(AesKey key /* rk[56..59] ^ 0x
       }
       __syncthreads();
       if (has_b) {
-        for (uint32_t s2 = tid; s2 < RT2 * VB; s2 += 1024) {
-          const uint32_t lr = s2 / VB, k = s2 % VB;
+        for (uint32_t s2 = tid; s2 < RT2 * VBq; s2 += 1024) {
+          const uint32_t lr = s2 / VBq, k = s2 % VBq;
           const uint64_t row = (uint64_t)u0 + lr;
           if (row >= r1) continue;
-          const RowGeom g = row_geom(off, row, n, j0, nks);
-          lds.tile[lr * TS2 + g.head + nks * VB + k] = (uint8_t)(c8[row * VB + k] ^ 0x80);
+          const RowGeom g = row_geom(off, row, n, j0, nks, VBq);
+          lds.tile[lr * TS2 + g.head + nks * VBq + k] = (uint8_t)(c8[row * VBq + k] ^ 0x80);
         }
         __syncthreads();
       }
       if (wave < MT2) {  // this wave's row tile, four k-steps: the byte gather of the MFMA phase, stored instead of multiplied
-        const uint32_t head0 = row_geom(off, u0, n, j0, 1).head;
+        const uint32_t head0 = row_geom(off, u0, n, j0, 1, VBq).head;
         v4i *dst = reinterpret_cast<v4i *>(image) + ((uint64_t)(MT2 * blockIdx.x + wave) * KS + (u0 >> 6)) * 64 + lane;
 #pragma unroll
         for (int ks = 0; ks < RT2 / 64; ks++) {
@@ -344,7 +353,7 @@ __global__ __launch_bounds__(1024) void k_evalmm16(AesKey key /* rk[56..59] ^ 0x
         }
       } else {
         const uint32_t t2 = tid - MT2 * 64;
-        for (uint32_t task = t2; task < 2 * RT2; task += 320) span_task(u0 + RT2, task);
+        for (uint32_t task = t2; task < 2 * RT2; task += NSW) span_task(u0 + RT2, task);
       }
       __syncthreads();
       continue;
@@ -359,7 +368,7 @@ __global__ __launch_bounds__(1024) void k_evalmm16(AesKey key /* rk[56..59] ^ 0x
       for (int k2 = 1; k2 < RT2 / 64; k2++)
 #pragma unroll
         for (int i2 = 0; i2 < 4; i2++) {
-          const uint32_t idx = t2 + 320 * i2;
+          const uint32_t idx = t2 + NSW * i2;
           if (idx < NQ2 * 64) acc[(k2 - 1) * 4 + i2] = cdv[((uint64_t)(u0 >> 6) + k2) * NQ2 * 64 + idx];
         }
     }
@@ -368,7 +377,7 @@ __global__ __launch_bounds__(1024) void k_evalmm16(AesKey key /* rk[56..59] ^ 0x
       const uint32_t lr = s2 / BPR2, k = s2 % BPR2;
       const uint64_t row = (uint64_t)u0 + lr;
       if (row >= r1) continue;
-      const RowGeom g = row_geom(off, row, n, j0, nks);
+      const RowGeom g = row_geom(off, row, n, j0, nks, VBq);
       if (k >= g.nblk) continue;
       const uint64_t ctr = g.cb0 + k;
       const uint32_t *scp = lds.spanc[lr][(uint32_t)((ctr >> 8) - (g.cb0 >> 8))];
@@ -380,18 +389,18 @@ __global__ __launch_bounds__(1024) void k_evalmm16(AesKey key /* rk[56..59] ^ 0x
     (&lds.bfrag[0][0][0])[tid] = bstage;
     __syncthreads();
     if (has_b) {
-      for (uint32_t s2 = tid; s2 < RT2 * VB; s2 += 1024) {
-        const uint32_t lr = s2 / VB, k = s2 % VB;
+      for (uint32_t s2 = tid; s2 < RT2 * VBq; s2 += 1024) {
+        const uint32_t lr = s2 / VBq, k = s2 % VBq;
         const uint64_t row = (uint64_t)u0 + lr;
         if (row >= r1) continue;
-        const RowGeom g = row_geom(off, row, n, j0, nks);
-        lds.tile[lr * TS2 + g.head + nks * VB + k] = (uint8_t)(c8[row * VB + k] ^ 0x80);
+        const RowGeom g = row_geom(off, row, n, j0, nks, VBq);
+        lds.tile[lr * TS2 + g.head + nks * VBq + k] = (uint8_t)(c8[row * VBq + k] ^ 0x80);
       }
       __syncthreads();
     }
     // ---- (2) per 64-row k-step: waves 0..10 MFMA from bfrag[ks & 1]; waves 11..15 stage the next k-step's fragments (and, once,
     //          the next unit's span constants)
-    const uint32_t head0 = row_geom(off, u0, n, j0, 1).head;
+    const uint32_t head0 = row_geom(off, u0, n, j0, 1, VBq).head;
 #pragma unroll
     for (int ks = 0; ks < RT2 / 64; ks++) {
       if (wave < MT2) {
@@ -422,12 +431,12 @@ __global__ __launch_bounds__(1024) void k_evalmm16(AesKey key /* rk[56..59] ^ 0x
           v4i *dst = &lds.bfrag[(ks + 1) & 1][0][0];
 #pragma unroll
           for (int i2 = 0; i2 < 4; i2++) {
-            const uint32_t idx = t2 + 320 * i2;
+            const uint32_t idx = t2 + NSW * i2;
             if (idx < NQ2 * 64) dst[idx] = acc[ks * 4 + i2];
           }
         }
         if (ks == 0)
-          for (uint32_t task = t2; task < 2 * RT2; task += 320) span_task(u0 + RT2, task);
+          for (uint32_t task = t2; task < 2 * RT2; task += NSW) span_task(u0 + RT2, task);
       }
       __syncthreads();
     }
@@ -534,21 +543,23 @@ __global__ __launch_bounds__(SW * 64) void k_mmstream(const v4i *__restrict__ im
 // SA = G'[.][ones column] summed over the row chunks; thread = (vector v fastest, coordinate j)
 template <int ND>
 __global__ void k_evalmm_finish(const int *__restrict__ part, const int64_t *__restrict__ sc, uint32_t nchunks, uint32_t ntiles, uint32_t N,
-                                uint32_t nvec, uint32_t n, uint32_t nrows, uint32_t ct, uint64_t *__restrict__ rops /* [nvec][(n+1) * 12] */,
-                                int accumulate) {
+                                uint32_t nvec, uint32_t n, uint32_t nrows, uint32_t ct, uint32_t MBv /* byte positions per column tile, padded */,
+                                uint32_t sby /* significant bytes per value */, uint32_t LL /* limbs per value */,
+                                uint64_t *__restrict__ rops /* [nvec][(n+1) * LL] */, int accumulate) {
   const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t v = gid % nvec, j = gid / nvec;
   if (j > n) return;
-  const uint32_t tile = j / ct, jj = j % ct, MBv = ct * SB;  // ct coordinates per column tile (4: k_evalmm, 2: k_evalmm16)
-  uint32_t *out = reinterpret_cast<uint32_t *>(rops + ((uint64_t)v * (n + 1) + j) * 12);
+  const uint32_t tile = j / ct, jj = j % ct;  // ct coordinates per column tile (4: k_evalmm, 2 | 1: k_evalmm16)
+  uint32_t *out = reinterpret_cast<uint32_t *>(rops + ((uint64_t)v * (n + 1) + j) * LL);
   int64_t corr[ND];
 #pragma unroll
   for (int w = 0; w < ND; w++) corr[w] = 128 * sc[ND * v + w] + 16384ll * nrows;
   unsigned __int128 run = 0;  // bits [32 l, ...) of the partial result
-  for (int l = 0; l < 22; l++) {
+  const uint32_t KWv = sby / 4;  // 22 | 46 words survive modq
+  for (uint32_t l = 0; l < KWv; l++) {
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      const uint32_t mm = jj * SB + 4 * l + k;
+      const uint32_t mm = jj * sby + 4 * l + k;
       int64_t g[ND] = {}, sa = 0;
       for (uint32_t ch = 0; ch < nchunks; ch++) {
         const int *row = part + (((uint64_t)ch * ntiles + tile) * MBv + mm) * N;
@@ -570,8 +581,7 @@ __global__ void k_evalmm_finish(const int *__restrict__ part, const int64_t *__r
     out[l] = (uint32_t)word;
     run >>= 32;
   }
-  out[22] = 0;  // modq: limbs >= K dropped (src/lwe.h:107-118)
-  out[23] = 0;
+  for (uint32_t l = KWv; l < 2 * LL; l++) out[l] = 0;  // modq: limbs >= K dropped (src/lwe.h:107-118)
 }
 
 // ---- the witness pass of up to 32 statements as a GEMM over the SSP rows (one read of the SSP) ---------------------------------------
@@ -673,35 +683,46 @@ __global__ void k_witness_mm_finish(const int *__restrict__ part, uint32_t nchun
 
 extern "C" {
 
+// geometry of the 256-column kernels for the context's modulus
+struct WideGeom { uint32_t ct, sby, vby, mt, mbp, LL; };
+static WideGeom wide_geom(const mfh_ctx *c) {
+  if (c->P.logq == 736) return {W16<736>::CT, W16<736>::SBY, W16<736>::VBY, W16<736>::MT, W16<736>::MBP, W16<736>::LL};
+  return {W16<1472>::CT, W16<1472>::SBY, W16<1472>::VBY, W16<1472>::MT, W16<1472>::MBP, W16<1472>::LL};
+}
+
 int mfh_eval_rows_multi(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d_c8, const uint32_t *d_coeffs, uint32_t nvec, uint32_t coeff_bytes,
                         uint64_t *d_rops, int accumulate) {
   if (!c || !d_rops || !nvec || (nrows && (!d_c8 || !d_coeffs)) || (coeff_bytes != 1 && coeff_bytes != 4)) return MFH_EINVAL;
   const uint32_t ND = coeff_bytes;
   const uint32_t n = c->P.n;
-  // 128 digit columns: k_evalmm (32x32x32 MFMA, 4-coordinate tiles); up to 256: k_evalmm16 (16x16x64, 2-coordinate tiles), which
-  // needs every row segment to start at byte 0 or 8 of an AES block: stream offset and row length multiples of 8
-  // a registered matrix-core CRS image (mfh_crs_set_resident_mm) serves the region it was expanded from: always the 256-column kernel
+  const bool q736 = c->P.logq == 736;
+  const WideGeom wg = wide_geom(c);
+  // 128 digit columns: k_evalmm (32x32x32 MFMA, 4-coordinate tiles, logq = 736 only); up to 256: k_evalmm16 (16x16x64, 2- or
+  // 1-coordinate tiles), which needs every row segment to start at byte 0 or 8 of an AES block: stream offset and row length multiples of 8.
+  // A registered matrix-core CRS image (mfh_crs_set_resident_mm) serves the region it was expanded from: always the 256-column layout.
   const uint8_t *img_region = nullptr;
   for (int r = 0; r < 3 && c->mm_image; r++)
     if (c->mm_off[r] == off && c->mm_rows[r] == nrows && nrows) img_region = c->mm_image + c->mm_base[r];
-  const bool wide = img_region || nvec * ND + 1 > 128;
+  const bool wide = img_region || !q736 || nvec * ND + 1 > 128;
   if (nvec * ND + 1 > 256) { c->err = "mfh_eval_rows_multi: at most 63 four-byte (255 one-byte) coefficient vectors per call (256 digit columns)"; return MFH_EINVAL; }
-  if (wide && ((off & 7) || (((uint64_t)n * VB) & 7))) { c->err = "mfh_eval_rows_multi: more than 128 digit columns need off and the row length to be multiples of 8"; return MFH_EINVAL; }
+  if (wide && ((off & 7) || (((uint64_t)n * wg.vby) & 7))) {
+    c->err = "mfh_eval_rows_multi: the 256-column kernel needs off and the row length to be multiples of 8";
+    return MFH_EINVAL;
+  }
   if (!c->have_seed) { c->err = "mfh_set_seed has not been called"; return MFH_EINVAL; }
-  if (c->P.logq != 736) { c->err = "mfh_eval_rows_multi: only logq = 736 has a matrix-core path"; return MFH_EUNSUPPORTED; }
   if (nrows > 0xffffffffu - 256) return MFH_EINVAL;
   HIP_TRY(c, hipSetDevice(c->device));
-  const size_t ctl = (size_t)(n + 1) * 12;
+  const size_t ctl = (size_t)(n + 1) * wg.LL;
   if (nrows == 0) {
     if (!accumulate) HIP_TRY(c, hipMemsetAsync(d_rops, 0, (size_t)nvec * ctl * 8, c->stream));
     return MFH_OK;
   }
-  const uint32_t ct = wide ? CT2 : CT, mb = ct * SB, rt = wide ? RT2 : RT;
+  const uint32_t ct = wide ? wg.ct : CT, mb = wide ? wg.mbp : CT * SB, rt = wide ? RT2 : RT;
   const uint32_t NT = wide ? NQ2 : (nvec * ND + 1 <= 64 ? 2 : 4), N = wide ? N2 : 32 * NT;
   const uint32_t ntiles = (n + 1 + ct - 1) / ct;
   // row chunks: 368 column tiles x 2 chunks = 736 workgroups = 2.9 rounds of the 256 CUs (one workgroup per CU at a time); an int32
   // accumulator holds 131 071 rows
-  // (the 256-column kernels have 736 column tiles / 506 workgroups of row-tile pairs: one chunk already fills the CUs as evenly)
+  // (the 256-column kernels have 736 (1471) column tiles / 506 workgroups of row-tile pairs: one chunk already fills the CUs as evenly)
   uint32_t nchunks = (!wide && nrows >= 8 * rt) ? 2 : 1;
   nchunks = std::max<uint32_t>(nchunks, ((uint32_t)nrows + 131070) / 131071);
   uint32_t rpc = ((uint32_t)nrows + nchunks - 1) / nchunks;
@@ -723,11 +744,14 @@ int mfh_eval_rows_multi(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d
   {
     Timer t(c, img_region ? 8 : 7, nrows);
     if (img_region) {
-      const uint32_t mtiles = ntiles * MT2, KS = ((uint32_t)nrows + RT2 - 1) / RT2 * (RT2 / 64);
+      const uint32_t mtiles = ntiles * wg.mt, KS = ((uint32_t)nrows + RT2 - 1) / RT2 * (RT2 / 64);
       hipLaunchKernelGGL(k_mmstream, dim3((mtiles + 2 * SW - 1) / (2 * SW), nchunks), dim3(SW * 64), 0, c->stream, (const v4i *)img_region, mtiles, KS,
                          (uint32_t)nrows, rpc, (const v4i *)cd, part);
-    } else if (wide)
-      hipLaunchKernelGGL(k_evalmm16<0>, dim3(ntiles, nchunks), dim3(1024), 0, c->stream, keyx, c->d_t0, off, n, (uint32_t)nrows, rpc, d_c8, cd, part,
+    } else if (wide && q736)
+      hipLaunchKernelGGL((k_evalmm16<0, 736>), dim3(ntiles, nchunks), dim3(1024), 0, c->stream, keyx, c->d_t0, off, n, (uint32_t)nrows, rpc, d_c8, cd, part,
+                         (uint8_t *)nullptr);
+    else if (wide)
+      hipLaunchKernelGGL((k_evalmm16<0, 1472>), dim3(ntiles, nchunks), dim3(1024), 0, c->stream, keyx, c->d_t0, off, n, (uint32_t)nrows, rpc, d_c8, cd, part,
                          (uint8_t *)nullptr);
     else if (NT == 2)
       hipLaunchKernelGGL(k_evalmm<2>, dim3(ntiles, nchunks), dim3(1024), 0, c->stream, keyx, c->d_t0, off, n, (uint32_t)nrows, rpc, d_c8, cd, rpad,
@@ -738,49 +762,56 @@ int mfh_eval_rows_multi(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d
   }
   HIP_TRY(c, hipGetLastError());
   const uint32_t total = (n + 1) * nvec;
+  const uint32_t sby = wide ? wg.sby : SB;
   if (ND == 4)
-    hipLaunchKernelGGL(k_evalmm_finish<4>, dim3((total + 127) / 128), dim3(128), 0, c->stream, part, sc, nchunks, ntiles, N, nvec, n, (uint32_t)nrows, ct,
-                       d_rops, accumulate);
+    hipLaunchKernelGGL(k_evalmm_finish<4>, dim3((total + 127) / 128), dim3(128), 0, c->stream, part, sc, nchunks, ntiles, N, nvec, n, (uint32_t)nrows, ct, mb,
+                       sby, wg.LL, d_rops, accumulate);
   else
-    hipLaunchKernelGGL(k_evalmm_finish<1>, dim3((total + 127) / 128), dim3(128), 0, c->stream, part, sc, nchunks, ntiles, N, nvec, n, (uint32_t)nrows, ct,
-                       d_rops, accumulate);
+    hipLaunchKernelGGL(k_evalmm_finish<1>, dim3((total + 127) / 128), dim3(128), 0, c->stream, part, sc, nchunks, ntiles, N, nvec, n, (uint32_t)nrows, ct, mb,
+                       sby, wg.LL, d_rops, accumulate);
   HIP_TRY(c, hipGetLastError());
   return MFH_OK;
 }
 
 // ---- the CRS expanded once for the matrix-core path (second regime of SURVEY 8(d) for the batch prover) -------------------------
-static size_t mm_region_bytes(uint32_t n, uint64_t rows) {  // row tiles x 64-row k-steps x 1 KiB fragments
-  const uint64_t mtiles = (uint64_t)((n + 1 + CT2 - 1) / CT2) * MT2, ksteps = (rows + RT2 - 1) / RT2 * (RT2 / 64);
+static size_t mm_region_bytes(const mfh_ctx *c, uint64_t rows) {  // row tiles x 64-row k-steps x 1 KiB fragments
+  const WideGeom wg = wide_geom(c);
+  const uint64_t mtiles = (uint64_t)((c->P.n + 1 + wg.ct - 1) / wg.ct) * wg.mt, ksteps = (rows + RT2 - 1) / RT2 * (RT2 / 64);
   return (size_t)(mtiles * ksteps * 1024);
 }
 size_t mfh_crs_mm_image_bytes(const mfh_ctx *c) {
-  if (!c || c->P.logq != 736) return 0;
-  return 2 * mm_region_bytes(c->P.n, c->P.d) + mm_region_bytes(c->P.n, c->P.m);
+  if (!c) return 0;
+  return 2 * mm_region_bytes(c, c->P.d) + mm_region_bytes(c, c->P.m);
 }
 // expands the S, AS and BT+BV regions of the compressed CRS into d_image (mfh_crs_mm_image_bytes bytes), in MFMA A-fragment order
 int mfh_crs_expand_mm(mfh_ctx *c, const uint8_t *d_crs_c8, uint8_t *d_image) {
   if (!c || !d_crs_c8 || !d_image) return MFH_EINVAL;
   if (!c->have_seed) { c->err = "mfh_set_seed has not been called"; return MFH_EINVAL; }
-  if (c->P.logq != 736) { c->err = "mfh_crs_expand_mm: only logq = 736 has a matrix-core path"; return MFH_EUNSUPPORTED; }
+  const WideGeom wg = wide_geom(c);
   const uint32_t n = c->P.n, d = c->P.d, m = c->P.m;
-  if (((uint64_t)n * VB) & 7) { c->err = "mfh_crs_expand_mm: the row length must be a multiple of 8"; return MFH_EUNSUPPORTED; }
+  if (((uint64_t)n * wg.vby) & 7) { c->err = "mfh_crs_expand_mm: the row length must be a multiple of 8"; return MFH_EUNSUPPORTED; }
   HIP_TRY(c, hipSetDevice(c->device));
-  const uint64_t ctr_ct = (uint64_t)VB * n;
+  const uint64_t ctr_ct = (uint64_t)wg.vby * n;
   const uint64_t offs[3] = {0, ctr_ct * d, ctr_ct * 2 * d};
   const uint64_t rows[3] = {d, d, m};
-  const size_t c8off[3] = {0, (size_t)d * VB, (size_t)2 * d * VB};
+  const size_t c8off[3] = {0, (size_t)d * wg.vby, (size_t)2 * d * wg.vby};
   AesKey keyx = c->key;
   for (int i = 56; i < 60; i++) keyx.rk[i] ^= 0x80808080u;
-  const uint32_t ntiles = (n + 1 + CT2 - 1) / CT2;
+  const uint32_t ntiles = (n + 1 + wg.ct - 1) / wg.ct;
   size_t base = 0;
   for (int r = 0; r < 3; r++) {
     const uint32_t units = (uint32_t)((rows[r] + RT2 - 1) / RT2);
     const uint32_t nchunks = std::max(1u, std::min(units, 4u));
     const uint32_t rpc = (units + nchunks - 1) / nchunks * RT2;
     Timer t(c, 4, rows[r]);
-    hipLaunchKernelGGL(k_evalmm16<1>, dim3(ntiles, (uint32_t)((rows[r] + rpc - 1) / rpc)), dim3(1024), 0, c->stream, keyx, c->d_t0, offs[r], n,
-                       (uint32_t)rows[r], rpc, d_crs_c8 + c8off[r], (const int8_t *)nullptr, (int *)nullptr, d_image + base);
-    base += mm_region_bytes(n, rows[r]);
+    const dim3 grid(ntiles, (uint32_t)((rows[r] + rpc - 1) / rpc));
+    if (c->P.logq == 736)
+      hipLaunchKernelGGL((k_evalmm16<1, 736>), grid, dim3(1024), 0, c->stream, keyx, c->d_t0, offs[r], n, (uint32_t)rows[r], rpc, d_crs_c8 + c8off[r],
+                         (const int8_t *)nullptr, (int *)nullptr, d_image + base);
+    else
+      hipLaunchKernelGGL((k_evalmm16<1, 1472>), grid, dim3(1024), 0, c->stream, keyx, c->d_t0, offs[r], n, (uint32_t)rows[r], rpc, d_crs_c8 + c8off[r],
+                         (const int8_t *)nullptr, (int *)nullptr, d_image + base);
+    base += mm_region_bytes(c, rows[r]);
   }
   HIP_TRY(c, hipGetLastError());
   return MFH_OK;
@@ -790,10 +821,10 @@ int mfh_crs_set_resident_mm(mfh_ctx *c, const uint8_t *d_image) {
   if (!c) return MFH_EINVAL;
   c->mm_image = d_image;
   const uint32_t n = c->P.n, d = c->P.d, m = c->P.m;
-  const uint64_t ctr_ct = (uint64_t)VB * n;
+  const uint64_t ctr_ct = (uint64_t)wide_geom(c).vby * n;
   c->mm_off[0] = 0; c->mm_off[1] = ctr_ct * d; c->mm_off[2] = ctr_ct * 2 * d;
   c->mm_rows[0] = d; c->mm_rows[1] = d; c->mm_rows[2] = m;
-  c->mm_base[0] = 0; c->mm_base[1] = mm_region_bytes(n, d); c->mm_base[2] = 2 * mm_region_bytes(n, d);
+  c->mm_base[0] = 0; c->mm_base[1] = mm_region_bytes(c, d); c->mm_base[2] = 2 * mm_region_bytes(c, d);
   return MFH_OK;
 }
 

@@ -429,7 +429,6 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
                     size_t bits_stride, const uint32_t *h_delta, const uint8_t *h_smudge_mag, size_t maglen, const uint8_t *h_smudge_sign,
                     uint64_t *d_proofs) {
   if (!c || !d_crs_c8 || !h_witness_bits || !h_delta || !h_smudge_mag || !h_smudge_sign || !d_proofs) return MFH_EINVAL;
-  if (c->P.logq != 736) { c->err = "mfh_prove_batch: only logq = 736 has a matrix-core path"; return MFH_EUNSUPPORTED; }
   if (c->resident_rows) { c->err = "mfh_prove_batch regenerates the keystream: clear the resident CRS image first"; return MFH_EUNSUPPORTED; }
   mf::SspSrc src;
   {

@@ -96,3 +96,58 @@ def test_full_snark_at_logq1472(setup, oracle):
     finally:
         ctx.set_resident(None)
     assert np.array_equal(again, ctx.to_host(proof))
+
+
+@pytest.mark.parametrize("nrows,nvec,cb", [(21, 3, 4), (300, 40, 4), (64, 63, 4), (70, 200, 1)])
+def test_matrix_core_eval_at_1472(setup, oracle, nrows, nvec, cb):
+    """mfh_eval_rows_multi at logq = 1472 (k_evalmm16<0,1472>: one coordinate = 184 bytes = 11.5 row tiles per column tile) against the
+    VALU path and the oracle."""
+    ctx, p = setup
+    rng = np.random.default_rng(nrows + nvec)
+    c8 = rng.integers(0, 256, size=nrows * p.ctb, dtype=np.uint8)
+    co = rng.integers(0, 256 if cb == 1 else ol.P, size=(nvec, nrows), dtype=np.uint64).astype(np.uint32)
+    co[0, :] = 0
+    co[1 % nvec, :] = 0xFF if cb == 1 else 0xFFFFFFFA
+    off = p.ctr_as + 3 * p.ctr_ct
+    d_c8 = ctx.to_device(c8)
+    got = ctx.to_host(ctx.eval_rows_multi(off, nrows, d_c8, ctx.to_device(co), nvec, coeff_bytes=cb), np.uint64).reshape(nvec, p.n + 1, p.L)
+    for v in sorted({0, 1 % nvec, nvec // 2, nvec - 1}):
+        ref, _ = ctx.eval_rows(off, nrows, d_c8, ctx.to_device(co[v]))
+        assert np.array_equal(got[v], ctx.to_host(ref, np.uint64).reshape(p.n + 1, p.L)), f"vector {v}"
+    exp = oracle.eval_poly(p, SEED, off, c8.tobytes(), co[nvec - 1].astype(np.uint64))
+    assert np.array_equal(got[nvec - 1], exp.reshape(p.n + 1, p.L))
+
+
+def test_batch_prover_at_1472(gpu_ctx_factory, mf, oracle):
+    """mfh_prove_batch at logq = 1472, regenerate and resident (A-fragment image) regimes, against mfh_prove proof by proof"""
+    p = mf.Params(logq=1472, d=128, m=24)
+    c = gpu_ctx_factory(p)
+    c.set_seed(SEED)
+    rng = np.random.default_rng(1472)
+    nbytes = (p.m + 7) // 8
+    wit = rng.integers(0, 256, size=nbytes, dtype=np.uint8).tobytes()
+    ssp = oracle.ssp_from_tape(p, rng.integers(0, 256, size=p.m * 8 * p.d, dtype=np.uint8), wit)
+    alpha, beta, s = (int(x) for x in rng.integers(1, ol.P, size=3, dtype=np.uint64))
+    sk = ol.rand_values(rng, p.n, p.L, p.logq)
+    etape = ol.rand_values(rng, 2 * p.d + p.m, p.L, 559)
+    d_ssp = c.ssp_upload(ssp)
+    c.ssp_prepare(d_ssp)
+    d_crs = c.setup(d_ssp, alpha, beta, s, c.to_device(sk), c.to_device(etape))
+    nb = 34
+    stmts = [wit if b % 2 == 0 else rng.integers(0, 256, size=nbytes, dtype=np.uint8).tobytes() for b in range(nb)]
+    deltas = [int(x) for x in rng.integers(0, ol.P, size=nb, dtype=np.uint64)]
+    mags = [rng.integers(0, 256, size=400, dtype=np.uint8).tobytes() for _ in range(nb)]
+    signs = [bytes(rng.integers(0, 2, size=5, dtype=np.uint8).tolist()) for _ in range(nb)]
+    got = c.to_host(c.prove_batch(d_crs, d_ssp, stmts, deltas, mags, signs), np.uint64).reshape(nb, -1).copy()
+    for b in (0, 1, 17, 33):
+        one = c.to_host(c.prove(d_crs, d_ssp, stmts[b], deltas[b], mags[b], signs[b]), np.uint64).reshape(-1)
+        assert np.array_equal(got[b], one), f"proof {b}"
+    image = c.crs_expand_mm(d_crs)
+    c.set_resident_mm(image)
+    try:
+        res = c.to_host(c.prove_batch(d_crs, d_ssp, stmts, deltas, mags, signs), np.uint64).reshape(nb, -1)
+    finally:
+        c.set_resident_mm(None)
+    assert np.array_equal(res, got)
+    ok = c.to_host(c.verify(d_ssp, alpha, beta, s, c.to_device(sk), c.to_device(got), nb))
+    assert [bool(x) for x in ok] == [b % 2 == 0 for b in range(nb)]
