@@ -162,8 +162,6 @@ def main():
     big = args.workload != "default"
     p = mf.DEFAULT if not big else mf.Params(logq=736 if args.workload == "config4" else 1472, d=1 << 20, m=699050)
     mode = args.mode or ("batch" if not big else "single")
-    if mode == "batch" and p.logq != 736:
-        raise SystemExit("--mode batch needs logq = 736 (the matrix-core path)")
     run_single = mode == "single" or world == 1  # the single-proof path is always reported on one GPU
     single_steps = args.steps if mode == "single" else min(args.steps, 10)
     ctx = mf.Context(p, local_rank)
@@ -370,7 +368,7 @@ def main():
             ctx.set_resident_mm(None)
             img_bytes = image_mm.numel()
             del image_mm
-            tile_bytes_per_row = 736 * 11 * 16  # 8096 row tiles x 16 byte positions: the image holds 88 of each value's 92 bytes
+            tile_bytes_per_row = (736 * 11 if p.logq == 736 else 1471 * 12) * 16  # row tiles x 16 byte positions (88 of each value's 92 bytes at 736)
             avg_r = rms / max(rn, 1)
             rows_r = rrows / max(rn, 1)
             read_gbs = rows_r * tile_bytes_per_row / (avg_r * 1e-3) / 1e9 if rn else None

@@ -187,7 +187,7 @@ int mfh_verify(mfh_ctx *ctx, const uint32_t *d_ssp, uint32_t alpha, uint32_t bet
 /* The CRS expanded ONCE for the matrix-core path (the resident regime of the batch prover): mfh_crs_expand_mm writes the S, AS and
  * BT+BV regions in MFMA A-fragment order (mfh_crs_mm_image_bytes bytes: 11.3 GB at the default instance); while an image is
  * registered with mfh_crs_set_resident_mm (NULL clears it), mfh_eval_rows_multi over exactly one of those regions -- hence
- * mfh_prove_batch -- streams it from HBM instead of regenerating the keystream.  Results are identical.  logq = 736 only. */
+ * mfh_prove_batch -- streams it from HBM instead of regenerating the keystream.  Results are identical. */
 size_t mfh_crs_mm_image_bytes(const mfh_ctx *ctx);
 int mfh_crs_expand_mm(mfh_ctx *ctx, const uint8_t *d_crs_c8, uint8_t *d_image);
 int mfh_crs_set_resident_mm(mfh_ctx *ctx, const uint8_t *d_image);
@@ -195,7 +195,7 @@ int mfh_crs_set_resident_mm(mfh_ctx *ctx, const uint8_t *d_image);
  * BT+BV region once per up to 248, and the multiply-accumulate of the coefficient vectors runs on the matrix cores (mfh_eval_rows_multi); proof b is bit-identical to
  * mfh_prove(witness b, delta b, smudging b).  h_witness_bits: nproofs bit strings, bits_stride bytes apart; h_delta: nproofs values
  * < p; h_smudge_mag: nproofs x 5 x maglen bytes; h_smudge_sign: nproofs x 5 bytes; d_proofs: nproofs x 5 ciphertexts.
- * Regenerates the keystream (no resident CRS image may be set); logq = 736 only. */
+ * The single-proof resident image (mfh_crs_set_resident) must not be set; the matrix-core image (mfh_crs_set_resident_mm) may. */
 int mfh_prove_batch(mfh_ctx *ctx, const uint8_t *d_crs_c8, const uint32_t *d_ssp, uint32_t nproofs, const uint8_t *h_witness_bits,
                     size_t bits_stride, const uint32_t *h_delta, const uint8_t *h_smudge_mag, size_t maglen, const uint8_t *h_smudge_sign,
                     uint64_t *d_proofs);
@@ -237,7 +237,7 @@ size_t mfh_workspace_bytes(const mfh_ctx *ctx);
  * d_coeffs = nvec vectors of nrows uint32, vector-major; coeff_bytes = 4: any uint32 value, nvec <= 63; coeff_bytes = 1: the caller
  * guarantees every coefficient < 256 (only the low byte is used), nvec <= 255.  More than 128 digit columns (nvec * coeff_bytes + 1)
  * select the 256-column kernel, which needs off and the row length n * CT_BYTES to be multiples of 8 (true for every CRS region).  d_rops = nvec ciphertexts, vector-major.
- * logq = 736 only (MFH_EUNSUPPORTED otherwise). */
+ * At logq = 1472 every call uses the 256-column kernel. */
 int mfh_eval_rows_multi(mfh_ctx *ctx, uint64_t off, size_t nrows, const uint8_t *d_c8, const uint32_t *d_coeffs, uint32_t nvec,
                         uint32_t coeff_bytes, uint64_t *d_rops, int accumulate);
 
