@@ -331,6 +331,12 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el_b = float(tt.item())
         ok_b = ctx.to_host(ctx.verify(d_ssp_b, inst["alpha"], inst["beta"], inst["s"], inst["sk"], out_b, nb))
+        torch.cuda.synchronize()
+        tv = time.perf_counter()
+        for _ in range(5):
+            ctx.verify(d_ssp_b, inst["alpha"], inst["beta"], inst["s"], inst["sk"], out_b, nb)
+        torch.cuda.synchronize()
+        verify_per_s = 5 * nb / (time.perf_counter() - tv)
         same_b = True
         for i in (0, nb - 1):  # a valid and (nb even) an invalid statement against the single-proof path, bit for bit
             one = ctx.prove(d_crs, d_ssp_b, b_bits[i], b_delta[i], b_mags[i], b_signs[i])
@@ -400,6 +406,7 @@ def main():
         gbs = rows_mm * row_bytes_b / (avg_mm * 1e-3) / 1e9 if mmn else None
         batched = {"value": world * nb * args.steps / el_b, "unit": "proofs/s", "ms_per_step": el_b / args.steps * 1e3, "statements_per_gpu_per_step": nb,
                    "valid_accepted_invalid_rejected_and_identical_to_single_proof_path": all_ok, "resident_crs": resident_b,
+                   "device_verifier_proofs_per_s": verify_per_s,
                    "roofline": {"bound": "hbm", "kernel": "k_evalmm16 (AES-256-CTR expansion of the rows, once per group of 31 proofs, + i8 MFMA "
                                                             "multiply-accumulate of the group's 62 coefficient vectors; the BT+BV region runs once per 248 proofs, one byte column per proof)",
                                 "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (gbs / HBM_PEAK_GBS) if gbs else None, "traffic": traffic_mm,
@@ -531,6 +538,7 @@ def main():
             "setup_enc_per_s": rows_crs / setup_s,
             "roofline": head["roofline"],
             "resident_crs_batch": batched["resident_crs"] if mode == "batch" else None,
+            "device_verifier_proofs_per_s": batched["device_verifier_proofs_per_s"] if mode == "batch" else None,
             "single_proof": single if mode == "batch" else None,
             "eval1": single["eval1"] if mode == "single" else None,
             "resident_crs": resident if mode == "single" else None,
