@@ -247,7 +247,7 @@ constexpr int RT2 = 256, TS2 = 192, BPR2 = 12, NQ2 = 16, N2 = 16 * NQ2;
 template <int LOGQ> struct W16;
 template <> struct W16<736> { static constexpr int CT = 2, SBY = 88, VBY = 92, MT = 11, MBP = 176, KW = 22, LL = 12; };
 template <> struct W16<1472> { static constexpr int CT = 1, SBY = 184, VBY = 184, MT = 12, MBP = 192, KW = 46, LL = 23; };
-static_assert(RT2 * BPR2 == 3 * 1024 && W16<736>::CT * W16<736>::VBY + 8 <= TS2 && W16<1472>::CT * W16<1472>::VBY + 8 <= TS2, "wide tile geometry");
+static_assert(RT2 * 4 == 1024 && BPR2 % 4 == 0 && RT2 * BPR2 == 3 * 1024 && W16<736>::CT * W16<736>::VBY + 8 <= TS2 && W16<1472>::CT * W16<1472>::VBY + 8 <= TS2, "wide tile geometry");
 
 // MODE 0: regenerate the keystream (AES) and multiply-accumulate.  MODE 1: regenerate and WRITE the rows to `image` in A-FRAGMENT order
 // (offset-by-128 bytes, b coordinate included) -- the CRS expanded once for the matrix-core path, streamed by k_mmstream below.
@@ -372,19 +372,25 @@ __global__ __launch_bounds__(1024) void k_evalmm16(AesKey key /* rk[56..59] ^ 0x
           if (idx < NQ2 * 64) acc[(k2 - 1) * 4 + i2] = cdv[((uint64_t)(u0 >> 6) + k2) * NQ2 * 64 + idx];
         }
     }
-    // ---- (1) expansion: block slot s -> (local row s / 12, block s % 12): exactly three slots per thread
-    for (uint32_t s2 = tid; s2 < RT2 * BPR2; s2 += 1024) {
-      const uint32_t lr = s2 / BPR2, k = s2 % BPR2;
+    // ---- (1) expansion: four lanes per row, each takes blocks (tid & 3) + 4 it, it = 0..2: exactly three blocks per thread, one row
+    //          geometry per thread and unit
+    {
+      const uint32_t lr = tid >> 2;
       const uint64_t row = (uint64_t)u0 + lr;
-      if (row >= r1) continue;
-      const RowGeom g = row_geom(off, row, n, j0, nks, VBq);
-      if (k >= g.nblk) continue;
-      const uint64_t ctr = g.cb0 + k;
-      const uint32_t *scp = lds.spanc[lr][(uint32_t)((ctr >> 8) - (g.cb0 >> 8))];
-      uint32_t sc[5] = {scp[0], scp[1], scp[2], scp[3], scp[4]};
-      uint32_t w[4];
-      mf::aes256_ctr_block_sc(tab, L, key, ctr, sc, w);
-      *reinterpret_cast<uint4 *>(&lds.tile[lr * TS2 + 16 * k]) = make_uint4(w[0], w[1], w[2], w[3]);
+      if (row < r1) {
+        const RowGeom g = row_geom(off, row, n, j0, nks, VBq);
+#pragma unroll 1
+        for (int it = 0; it < BPR2 / 4; it++) {
+          const uint32_t k = (tid & 3) + 4 * it;
+          if (k >= g.nblk) continue;
+          const uint64_t ctr = g.cb0 + k;
+          const uint32_t *scp = lds.spanc[lr][(uint32_t)((ctr >> 8) - (g.cb0 >> 8))];
+          uint32_t sc[5] = {scp[0], scp[1], scp[2], scp[3], scp[4]};
+          uint32_t w[4];
+          mf::aes256_ctr_block_sc(tab, L, key, ctr, sc, w);
+          *reinterpret_cast<uint4 *>(&lds.tile[lr * TS2 + 16 * k]) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+      }
     }
     (&lds.bfrag[0][0][0])[tid] = bstage;
     __syncthreads();
