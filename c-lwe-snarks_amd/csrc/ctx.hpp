@@ -40,6 +40,9 @@ struct mfh_ctx {
   uint32_t *d_t0 = nullptr;  // 256 words
   void *ws = nullptr;        // scratch (partials etc.)
   size_t ws_bytes = 0;
+  void *ws2 = nullptr;       // second scratch of mfh_eval_rows_multi: the launch in flight on the side stream (mfh_prove_batch)
+  size_t ws2_bytes = 0;
+  int mm_ws_sel = 0;         // 0: ws, 1: ws2
   void *wws = nullptr;       // scratch of the witness pass (its own buffer: the pass may run beside an eval launch that owns `ws`)
   size_t wws_bytes = 0;
   // lazy-carry image (one u64 per accumulator word and coordinate) + active-row counter of the eval launches.  Invariant: all
@@ -183,4 +186,5 @@ inline int lazy_reserve(mfh_ctx *c, size_t bytes) {
 }
 inline int ws_reserve(mfh_ctx *c, size_t bytes) { return buf_reserve(c, c->ws, c->ws_bytes, bytes); }
 inline int wws_reserve(mfh_ctx *c, size_t bytes) { return buf_reserve(c, c->wws, c->wws_bytes, bytes); }
+inline int ws2_reserve(mfh_ctx *c, size_t bytes) { return buf_reserve(c, c->ws2, c->ws2_bytes, bytes); }
 

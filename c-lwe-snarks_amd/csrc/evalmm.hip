@@ -738,11 +738,12 @@ int mfh_eval_rows_multi(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d
   const size_t cd_bytes = ((size_t)N * rpad + 255) & ~(size_t)255;
   const size_t sc_bytes = 256 * 8;
   const size_t part_bytes = (size_t)nchunks * ntiles * mb * N * 4;
-  int rc = ws_reserve(c, cd_bytes + sc_bytes + part_bytes);
+  int rc = c->mm_ws_sel ? ws2_reserve(c, cd_bytes + sc_bytes + part_bytes) : ws_reserve(c, cd_bytes + sc_bytes + part_bytes);
   if (rc) return rc;
-  int8_t *cd = (int8_t *)c->ws;
-  int64_t *sc = (int64_t *)((uint8_t *)c->ws + cd_bytes);
-  int *part = (int *)((uint8_t *)c->ws + cd_bytes + sc_bytes);
+  uint8_t *wsp = (uint8_t *)(c->mm_ws_sel ? c->ws2 : c->ws);  // the launch on the side stream of mfh_prove_batch has its own scratch
+  int8_t *cd = (int8_t *)wsp;
+  int64_t *sc = (int64_t *)(wsp + cd_bytes);
+  int *part = (int *)(wsp + cd_bytes + sc_bytes);
   hipLaunchKernelGGL(k_mm_digits, dim3((rpad + 255) / 256, N), dim3(256), 0, c->stream, d_coeffs, nvec, ND, (uint32_t)nrows, rpad, NT, wide ? 1 : 0, cd);
   hipLaunchKernelGGL(k_mm_colsum, dim3(N), dim3(256), 0, c->stream, d_coeffs, nvec, ND, (uint32_t)nrows, sc);
   AesKey keyx = c->key;

@@ -954,6 +954,7 @@ void mfh_ctx_destroy(mfh_ctx *c) {
   if (c->side) hipStreamSynchronize(c->side);
   if (c->ws) hipFree(c->ws);
   if (c->wws) hipFree(c->wws);
+  if (c->ws2) hipFree(c->ws2);
   if (c->lazy) hipFree(c->lazy);
   if (c->aux) hipFree(c->aux);
   if (c->ev_fork) hipEventDestroy(c->ev_fork);

@@ -445,16 +445,32 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
   constexpr uint32_t G = 31;    // proofs per S / AS expansion: 62 coefficient vectors x 4 bytes + the ones column = 249 of 256 digit columns
   constexpr uint32_t SG = 248;  // proofs per BT+BV expansion: one byte column each + the ones column = 249 of 256 digit columns
   HIP_TRY(c, hipSetDevice(c->device));
-  // scratch: W | H | V (g x d each, in this order: the S region takes (W, H), the AS region (H, V)), CW (SG x m), ONE (1 word), WALL (the
-  // witness polynomials of the whole super-group, SG x d), OUT (SG ciphertexts, >= 2G), CT_T (1 ciphertext)
-  const size_t words = (size_t)3 * G * d + (size_t)SG * m + 64 + (size_t)SG * d, need = words * 4 + (size_t)(SG + 1) * ctl * 8;
+  // scratch: WALL | HALL | VALL (the w, h, v polynomials of a super-group, SG x d each), COA | COB (the coefficient matrices of the two
+  // launches in flight, 2G x d each), CW (SG x m), ONE; then OUT (SG ciphertexts), OUTA | OUTB (2G each), CT_T (1 ciphertext)
+  const size_t words = (size_t)3 * SG * d + (size_t)4 * G * d + (size_t)SG * m + 64, need = words * 4 + (size_t)(SG + 4 * G + 1) * ctl * 8;
   if (c->batch_bytes < need) {
-    if (c->d_batch) { hipStreamSynchronize(c->stream); hipFree(c->d_batch); c->d_batch = nullptr; c->batch_bytes = 0; }
+    if (c->d_batch) { hipDeviceSynchronize(); hipFree(c->d_batch); c->d_batch = nullptr; c->batch_bytes = 0; }
     HIP_TRY(c, hipMalloc(&c->d_batch, need));
     c->batch_bytes = need;
   }
-  uint32_t *const base = (uint32_t *)c->d_batch, *const CW = base + (size_t)3 * G * d, *const ONE = CW + (size_t)SG * m, *const WALL = ONE + 64;
-  uint64_t *const OUT = (uint64_t *)((uint8_t *)c->d_batch + words * 4), *const CT_T = OUT + (size_t)SG * ctl;
+  uint32_t *const WALL = (uint32_t *)c->d_batch, *const HALL = WALL + (size_t)SG * d, *const VALL = HALL + (size_t)SG * d;
+  uint32_t *const COA = VALL + (size_t)SG * d, *const COB = COA + (size_t)2 * G * d, *const CW = COB + (size_t)2 * G * d, *const ONE = CW + (size_t)SG * m;
+  uint64_t *const OUT = (uint64_t *)((uint8_t *)c->d_batch + words * 4), *const OUTA = OUT + (size_t)SG * ctl, *const OUTB = OUTA + (size_t)2 * G * ctl,
+                  *const CT_T = OUTB + (size_t)2 * G * ctl;
+  // Two streams: the S-region launches of the groups run on the caller's stream, the AS-region launches on the side stream, so that the
+  // last, partly filled round of workgroups of one launch (736 workgroups on 256 CUs) is filled by the next launch's first ones.
+  if (!c->side) {
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+  }
+  hipStream_t const main_stream = c->stream, side_stream = c->side;
+  struct OnSide {  // mfh_eval_rows_multi launches on c->stream with the workspace c->mm_ws_sel selects
+    mfh_ctx *c;
+    hipStream_t keep;
+    OnSide(mfh_ctx *c_, hipStream_t s) : c(c_), keep(c_->stream) { c->stream = s; c->mm_ws_sel = 1; }
+    ~OnSide() { c->stream = keep; c->mm_ws_sel = 0; }
+  };
   // ct_t = the BT row as a ciphertext (eval_poly of one row with coefficient 1): b_w's delta * ct_t term is added per proof below
   {
     const uint32_t one = 1;
@@ -490,61 +506,70 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
                          (c->P.logq + 63) / 64, 2 * (c->P.logq / 64));
       HIP_TRY(c, hipGetLastError());
     }
-    // w = delta t + sum_bits v_i for the whole super-group (src/snark.c:141,147-155): dense SSP with d % 128 == 0: a GEMM on the matrix
-    // cores, one read of the SSP per 62 statements; otherwise the VALU forms
-    const bool wit_mm = src.dense && d % 128 == 0;
-    if (wit_mm) {
+    // ---- w = delta t + sum_bits v_i for the whole super-group (src/snark.c:141,147-155): dense SSP with d % 128 == 0: a GEMM on the
+    // matrix cores, one read of the SSP per 62 statements; otherwise the VALU form, read (or generated) once per 12 statements
+    if (src.dense && d % 128 == 0) {
       for (uint32_t b0 = 0; b0 < sg; b0 += 62) {
-        int rcw = mfh_witness_poly_mm(c, d_ssp, std::min(62u, sg - b0), h_witness_bits + (size_t)(s0 + b0) * bits_stride, bits_stride,
-                                      h_delta + s0 + b0, WALL + (size_t)b0 * d);
-        if (rcw) return rcw;
+        rc = mfh_witness_poly_mm(c, d_ssp, std::min(62u, sg - b0), h_witness_bits + (size_t)(s0 + b0) * bits_stride, bits_stride, h_delta + s0 + b0,
+                                 WALL + (size_t)b0 * d);
+        if (rc) return rc;
+      }
+    } else {
+      for (uint32_t b0 = 0; b0 < sg; b0 += 12) {
+        rc = mfh_witness_poly_multi(c, d_ssp, std::min(12u, sg - b0), h_witness_bits + (size_t)(s0 + b0) * bits_stride, bits_stride, h_delta + s0 + b0,
+                                    WALL + (size_t)b0 * d);
+        if (rc) return rc;
       }
     }
+    // ---- v = w + v_0, h = (v^2 - 1) / t for the whole super-group (src/snark.c:161-169): one set of launches, sg times the work each
+    hipLaunchKernelGGL(k_add_slot_multi, dim3((d + 255) / 256, sg), dim3(256), 0, c->stream, WALL, src, 1u, d, VALL);
+    HIP_TRY(c, hipGetLastError());
+    rc = mfh_poly_h_multi(c, VALL, HALL, sg);
+    if (rc) return rc;
+    HIP_TRY(c, hipEventRecord(c->ev_fork, main_stream));
+    HIP_TRY(c, hipStreamWaitEvent(side_stream, c->ev_fork, 0));
+    // ---- S rows with (w, h) -> (v_w, h) on the caller's stream; AS rows with (h, v) -> (hat_h, hat_v) on the side stream: every row
+    // expanded once per group of G proofs
     for (uint32_t g0 = s0; g0 < s0 + sg; g0 += G) {
       const uint32_t g = std::min(G, s0 + sg - g0);
       uint64_t *proofs = d_proofs + (size_t)g0 * 5 * ctl;
-      uint32_t *W = base, *H = W + (size_t)g * d, *V = H + (size_t)g * d;  // g-strided blocks: (W, H) and (H, V) are contiguous 2g-vector matrices
-      // per proof: w = delta t + sum_bits v_i, v = w + v_0, h = (v^2 - 1) / t   (src/snark.c:141-169)
-      if (wit_mm) {
-        HIP_TRY(c, hipMemcpyAsync(W, WALL + (size_t)(g0 - s0) * d, (size_t)g * d * 4, hipMemcpyDeviceToDevice, c->stream));
-      } else {  // VALU form: the SSP is read (or, generator-defined, generated) once per (at most 12) statements
-        for (uint32_t b0 = 0; b0 < g; b0 += 12) {
-          int rcw = mfh_witness_poly_multi(c, d_ssp, std::min(12u, g - b0), h_witness_bits + (size_t)(g0 + b0) * bits_stride, bits_stride,
-                                           h_delta + g0 + b0, W + (size_t)b0 * d);
-          if (rcw) return rcw;
-        }
-      }
-      hipLaunchKernelGGL(k_add_slot_multi, dim3((d + 255) / 256, g), dim3(256), 0, c->stream, W, src, 1u, d, V);  // v = w + v_0 for the group
-      HIP_TRY(c, hipGetLastError());
-      rc = mfh_poly_h_multi(c, V, H, g);  // the group's polynomial steps side by side: the launches of one, g times the work each
+      const size_t o = (size_t)(g0 - s0) * d, gb = (size_t)g * d * 4;
+      HIP_TRY(c, hipMemcpyAsync(COA, WALL + o, gb, hipMemcpyDeviceToDevice, main_stream));
+      HIP_TRY(c, hipMemcpyAsync(COA + (size_t)g * d, HALL + o, gb, hipMemcpyDeviceToDevice, main_stream));
+      rc = mfh_eval_rows_multi(c, 0, d, d_crs_c8, COA, 2 * g, 4, OUTA, 0);
+      if (!rc) rc = scatter(OUTA, proofs, g, 3);
+      if (!rc) rc = scatter(OUTA + (size_t)g * ctl, proofs, g, 0);
       if (rc) return rc;
-      // S rows with (w, h) -> (v_w, h); AS rows with (h, v) -> (hat_h, hat_v): every row expanded once for the whole group
-      rc = mfh_eval_rows_multi(c, 0, d, d_crs_c8, W, 2 * g, 4, OUT, 0);
-      if (!rc) rc = scatter(OUT, proofs, g, 3);
-      if (!rc) rc = scatter(OUT + (size_t)g * ctl, proofs, g, 0);
-      if (!rc) rc = mfh_eval_rows_multi(c, ctr_ct * d, d, d_crs_c8 + (size_t)d * ctb, H, 2 * g, 4, OUT, 0);
-      if (!rc) rc = scatter(OUT, proofs, g, 1);
-      if (!rc) rc = scatter(OUT + (size_t)g * ctl, proofs, g, 2);
-      if (rc) return rc;
-      // smudging of the whole group in two launches: h, hat_h, hat_v, v_w with draws 0..3, then v_w AGAIN with draw 4; b_w never
-      // (src/snark.c:185-189).  A zero magnitude leaves a ciphertext unchanged.
-      std::vector<uint8_t> mags((size_t)g * 5 * maglen), signs((size_t)g * 5);
-      for (int pass = 0; pass < 2; pass++) {
-        std::fill(mags.begin(), mags.end(), 0);
-        std::fill(signs.begin(), signs.end(), 0);
-        for (uint32_t b = 0; b < g; b++) {
-          const uint8_t *pm = h_smudge_mag + (size_t)(g0 + b) * 5 * maglen, *ps = h_smudge_sign + (size_t)(g0 + b) * 5;
-          if (pass == 0) {
-            memcpy(&mags[(size_t)b * 5 * maglen], pm, 4 * maglen);
-            memcpy(&signs[(size_t)b * 5], ps, 4);
-          } else {
-            memcpy(&mags[((size_t)b * 5 + 3) * maglen], pm + 4 * maglen, maglen);
-            signs[(size_t)b * 5 + 3] = ps[4];
-          }
-        }
-        rc = mfh_ct_smudge(c, proofs, (size_t)g * 5, mags.data(), maglen, signs.data());
+      {
+        OnSide side(c, side_stream);
+        HIP_TRY(c, hipMemcpyAsync(COB, HALL + o, gb, hipMemcpyDeviceToDevice, side_stream));
+        HIP_TRY(c, hipMemcpyAsync(COB + (size_t)g * d, VALL + o, gb, hipMemcpyDeviceToDevice, side_stream));
+        rc = mfh_eval_rows_multi(c, ctr_ct * d, d, d_crs_c8 + (size_t)d * ctb, COB, 2 * g, 4, OUTB, 0);
+        if (!rc) rc = scatter(OUTB, proofs, g, 1);
+        if (!rc) rc = scatter(OUTB + (size_t)g * ctl, proofs, g, 2);
         if (rc) return rc;
       }
+    }
+    HIP_TRY(c, hipEventRecord(c->ev_join, side_stream));
+    HIP_TRY(c, hipStreamWaitEvent(main_stream, c->ev_join, 0));
+    // ---- smudging of the super-group in two launches: h, hat_h, hat_v, v_w with draws 0..3, then v_w AGAIN with draw 4; b_w never
+    // (src/snark.c:185-189).  A zero magnitude leaves a ciphertext unchanged.
+    std::vector<uint8_t> mags((size_t)sg * 5 * maglen), signs((size_t)sg * 5);
+    for (int pass = 0; pass < 2; pass++) {
+      std::fill(mags.begin(), mags.end(), 0);
+      std::fill(signs.begin(), signs.end(), 0);
+      for (uint32_t b = 0; b < sg; b++) {
+        const uint8_t *pm = h_smudge_mag + (size_t)(s0 + b) * 5 * maglen, *ps = h_smudge_sign + (size_t)(s0 + b) * 5;
+        if (pass == 0) {
+          memcpy(&mags[(size_t)b * 5 * maglen], pm, 4 * maglen);
+          memcpy(&signs[(size_t)b * 5], ps, 4);
+        } else {
+          memcpy(&mags[((size_t)b * 5 + 3) * maglen], pm + 4 * maglen, maglen);
+          signs[(size_t)b * 5 + 3] = ps[4];
+        }
+      }
+      rc = mfh_ct_smudge(c, sproofs, (size_t)sg * 5, mags.data(), maglen, signs.data());
+      if (rc) return rc;
     }
   }
   return MFH_OK;
