@@ -29,6 +29,10 @@ import numpy as np  # noqa: E402
 
 ROW_BYTES = 1471 * 92  # algorithmic bytes of one expanded ciphertext row (keystream + b); x2 at logq 1472
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+CONC_NOTE = ("the batch prover queues a group's S launch on the caller's stream and its AS launch on a side stream, so two launches of this "
+             "kernel share the GPU: avg_launch_ms is the start-to-end time of one launch (what HIP events and rocprofv3 report), "
+             "busy_ms_per_launch the union of all launches' spans / launches (the time the GPU spends per launch); achieved = algorithmic "
+             "bytes per launch / busy_ms_per_launch")
 
 
 def build_instance(mf, ctx, torch, p, seed_int):
@@ -326,6 +330,7 @@ def main():
         el_b = time.perf_counter() - t1
         ctx.set_timing(False)
         mmn, mmms, mmrows = ctx.timing_drain("evalmm")
+        mm_busy = ctx.timing_busy_ms()  # the S and AS launches of a group run on two streams and overlap: union of their spans
         if dist is not None:
             tt = torch.tensor([el_b], dtype=torch.float64, device=ctx.device)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -366,6 +371,7 @@ def main():
             el_rb = time.perf_counter() - t2
             ctx.set_timing(False)
             rn, rms, rrows = ctx.timing_drain("evalmm_resident")
+            r_busy = ctx.timing_busy_ms()
             if dist is not None:
                 tt = torch.tensor([el_rb], dtype=torch.float64, device=ctx.device)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -376,8 +382,9 @@ def main():
             del image_mm
             tile_bytes_per_row = (736 * 11 if p.logq == 736 else 1471 * 12) * 16  # row tiles x 16 byte positions (88 of each value's 92 bytes at 736)
             avg_r = rms / max(rn, 1)
+            eff_r = r_busy / max(rn, 1)  # per launch, with the time two concurrent launches share counted once
             rows_r = rrows / max(rn, 1)
-            read_gbs = rows_r * tile_bytes_per_row / (avg_r * 1e-3) / 1e9 if rn else None
+            read_gbs = rows_r * tile_bytes_per_row / (eff_r * 1e-3) / 1e9 if rn else None
             traffic_ms = None
             tfs = os.path.join(ROOT, "profiles", "traffic_mmstream.json")
             if os.path.exists(tfs):
@@ -390,10 +397,12 @@ def main():
                           "roofline": {"bound": "hbm", "kernel": "k_mmstream (A fragments streamed from the image, digit fragments through LDS, i8 MFMA 16x16x64)",
                                        "achieved": read_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (read_gbs / HBM_PEAK_GBS) if read_gbs else None,
                                        "traffic": traffic_ms, "bytes_read_per_row": tile_bytes_per_row, "launches": rn, "avg_launch_ms": avg_r,
-                                       "rows_per_launch": rows_r,
-                                       "mfma_int8_tops": 2.0 * 129536 * 256 * rows_r / (avg_r * 1e-3) / 1e12 if rn else None}}
+                                       "busy_ms_per_launch": eff_r, "concurrency": avg_r / eff_r if rn else None, "rows_per_launch": rows_r,
+                                       "note": CONC_NOTE,
+                                       "mfma_int8_tops": 2.0 * 129536 * 256 * rows_r / (eff_r * 1e-3) / 1e12 if rn else None}}
         row_bytes_b = (p.n + 1) * p.ctb
         avg_mm = mmms / max(mmn, 1)
+        eff_mm = mm_busy / max(mmn, 1)
         rows_mm = mmrows / max(mmn, 1)
         blocks_mm = rows_mm * (p.ctr_ct / 16.0)
         traffic_mm = None
@@ -403,21 +412,22 @@ def main():
                 traffic_mm = json.load(open(tfm)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic_mm = None
-        gbs = rows_mm * row_bytes_b / (avg_mm * 1e-3) / 1e9 if mmn else None
+        gbs = rows_mm * row_bytes_b / (eff_mm * 1e-3) / 1e9 if mmn else None
         batched = {"value": world * nb * args.steps / el_b, "unit": "proofs/s", "ms_per_step": el_b / args.steps * 1e3, "statements_per_gpu_per_step": nb,
                    "valid_accepted_invalid_rejected_and_identical_to_single_proof_path": all_ok, "resident_crs": resident_b,
                    "device_verifier_proofs_per_s": verify_per_s,
                    "roofline": {"bound": "hbm", "kernel": "k_evalmm16 (AES-256-CTR expansion of the rows, once per group of 31 proofs, + i8 MFMA "
                                                             "multiply-accumulate of the group's 62 coefficient vectors; the BT+BV region runs once per 248 proofs, one byte column per proof)",
                                 "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (gbs / HBM_PEAK_GBS) if gbs else None, "traffic": traffic_mm,
-                                "launches": mmn, "avg_launch_ms": avg_mm, "rows_per_launch": rows_mm, "bytes_per_row": row_bytes_b,
-                                "note": "algorithmic bytes = expanded row bytes, regenerated with AES on the CU (LDS T-tables): LDS-lookup / VALU "
+                                "launches": mmn, "avg_launch_ms": avg_mm, "busy_ms_per_launch": eff_mm, "concurrency": avg_mm / eff_mm if mmn else None,
+                                "rows_per_launch": rows_mm, "bytes_per_row": row_bytes_b,
+                                "note": CONC_NOTE + "; algorithmic bytes = expanded row bytes, regenerated with AES on the CU (LDS T-tables): LDS-lookup / VALU "
                                         "bound, ~0 HBM bytes; the MFMA work (2 x 129448 x 256 x rows int8 ops) is a few % of the kernel",
-                                "aes_gblocks_per_s": blocks_mm / (avg_mm * 1e-3) / 1e9 if mmn else None,
-                                "lds_lookup_roofline": {"achieved_gblocks_per_s": blocks_mm / (avg_mm * 1e-3) / 1e9 if mmn else None,
+                                "aes_gblocks_per_s": blocks_mm / (eff_mm * 1e-3) / 1e9 if mmn else None,
+                                "lds_lookup_roofline": {"achieved_gblocks_per_s": blocks_mm / (eff_mm * 1e-3) / 1e9 if mmn else None,
                                                         "peak_gblocks_per_s": 256 * 2.4e9 * 64 / (201 * 2.15) / 1e9,
-                                                        "frac": (blocks_mm / (avg_mm * 1e-3) / 1e9) / (256 * 2.4e9 * 64 / (201 * 2.15) / 1e9) if mmn else None},
-                                "mfma_int8_tops": 2.0 * 129448 * 256 * rows_mm / (avg_mm * 1e-3) / 1e12 if mmn else None}}
+                                                        "frac": (blocks_mm / (eff_mm * 1e-3) / 1e9) / (256 * 2.4e9 * 64 / (201 * 2.15) / 1e9) if mmn else None},
+                                "mfma_int8_tops": 2.0 * 129448 * 256 * rows_mm / (eff_mm * 1e-3) / 1e12 if mmn else None}}
 
     # ---- LWE batch (BASELINE config 1/2: one batch of 65 536 encryptions, rows at stream offset k*135240)
     enc_per_s = None

@@ -65,6 +65,7 @@ struct mfh_ctx {
     uint64_t rows;   // rows handed to the launch
   };
   std::vector<Timed> timed;
+  double last_busy_ms = 0;  // union of the spans of the launches the last mfh_timing_drain matched
   std::vector<hipEvent_t> ev_pool;
   PolyState *poly = nullptr;  // NTT tables and per-SSP precomputation (poly.hip)
   void *aux = nullptr;        // small scratch that must survive an eval/encrypt launch (snark.hip)
@@ -149,6 +150,18 @@ extern "C" int mfh_witness_poly_mm(mfh_ctx *c, const uint32_t *d_ssp, uint32_t n
                                    uint32_t *d_w);
 extern "C" int mfh_poly_h_multi(mfh_ctx *c, const uint32_t *d_v, uint32_t *d_h, uint32_t nb);
 int aux_reserve(mfh_ctx *c, size_t bytes);
+
+// Operands of one multi-vector launch (evalmm.hip): coefficient vector v is coef[0] + v * nrows for v < csplit, else
+// coef[1] + (v - csplit) * nrows; its result goes to out[0] + v * ostride for v < osplit, else out[1] + (v - osplit) * ostride
+// (uint64 words).  mfh_prove_batch reads w | h | v where the polynomial step left them and writes the proof structs in place.
+struct MmIo {
+  const uint32_t *coef[2];
+  uint32_t csplit;
+  uint64_t *out[2];
+  uint32_t osplit;
+  uint64_t ostride;
+};
+int eval_rows_multi_io(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d_c8, const MmIo &io, uint32_t nvec, uint32_t coeff_bytes, int accumulate);
 
 inline int buf_reserve(mfh_ctx *c, void *&buf, size_t &have, size_t bytes) {
   if (bytes <= have) return MFH_OK;

@@ -58,14 +58,16 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 // n = 32 q + r of rows 32 K + 16 h + e, e = 0..15, at cd[((K * NT + q) * 64 + 32 h + r) * 16 + e].  A unit's (RT rows) fragments are one
 // contiguous RT * N bytes.  Column n = ND v + w holds byte w of c_v[i] minus 128; column ND nvec is the ones column; every other
 // column, and every row >= nrows, is zero (such rows and columns then add nothing to G').
-__global__ void k_mm_digits(const uint32_t *__restrict__ coeff, uint32_t nvec, uint32_t ND, uint32_t nrows, uint32_t rpad, uint32_t NT, int wide,
-                            int8_t *__restrict__ cd) {
+__device__ __forceinline__ const uint32_t *coef_of(const MmIo &io, uint32_t v, uint32_t nrows) {
+  return v < io.csplit ? io.coef[0] + (uint64_t)v * nrows : io.coef[1] + (uint64_t)(v - io.csplit) * nrows;
+}
+__global__ void k_mm_digits(MmIo io, uint32_t nvec, uint32_t ND, uint32_t nrows, uint32_t rpad, uint32_t NT, int wide, int8_t *__restrict__ cd) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
   if (i >= rpad) return;
   const uint32_t v = n / ND, w = n % ND;
   int dgt = 0;
   if (i < nrows) {
-    if (v < nvec) dgt = (int)((coeff[(uint64_t)v * nrows + i] >> (8 * w)) & 255u) - 128;
+    if (v < nvec) dgt = (int)((coef_of(io, v, nrows)[i] >> (8 * w)) & 255u) - 128;
     else if (n == ND * nvec) dgt = 1;
   }
   const uint32_t e = i & 15;
@@ -78,12 +80,14 @@ __global__ void k_mm_digits(const uint32_t *__restrict__ coeff, uint32_t nvec, u
   }
 }
 // sc[n] = sum_i C'[i][n] = sum_i (byte w of c_v[i]) - 128 nrows, from the coefficient vectors (signed)
-__global__ void k_mm_colsum(const uint32_t *__restrict__ coeff, uint32_t nvec, uint32_t ND, uint32_t nrows, int64_t *__restrict__ sc) {
+__global__ void k_mm_colsum(MmIo io, uint32_t nvec, uint32_t ND, uint32_t nrows, int64_t *__restrict__ sc) {
   __shared__ uint32_t red[256];
   const uint32_t n = blockIdx.x, v = n / ND, w = n % ND;
   uint32_t s = 0;
-  if (v < nvec)
-    for (uint32_t i = threadIdx.x; i < nrows; i += blockDim.x) s += (coeff[(uint64_t)v * nrows + i] >> (8 * w)) & 255u;
+  if (v < nvec) {
+    const uint32_t *coeff = coef_of(io, v, nrows);
+    for (uint32_t i = threadIdx.x; i < nrows; i += blockDim.x) s += (coeff[i] >> (8 * w)) & 255u;
+  }
   red[threadIdx.x] = s;
   __syncthreads();
   for (int o = 128; o; o >>= 1) {
@@ -551,12 +555,13 @@ template <int ND>
 __global__ void k_evalmm_finish(const int *__restrict__ part, const int64_t *__restrict__ sc, uint32_t nchunks, uint32_t ntiles, uint32_t N,
                                 uint32_t nvec, uint32_t n, uint32_t nrows, uint32_t ct, uint32_t MBv /* byte positions per column tile, padded */,
                                 uint32_t sby /* significant bytes per value */, uint32_t LL /* limbs per value */,
-                                uint64_t *__restrict__ rops /* [nvec][(n+1) * LL] */, int accumulate) {
+                                MmIo io /* out: (n+1) * LL words per vector */, int accumulate) {
   const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t v = gid % nvec, j = gid / nvec;
   if (j > n) return;
   const uint32_t tile = j / ct, jj = j % ct;  // ct coordinates per column tile (4: k_evalmm, 2 | 1: k_evalmm16)
-  uint32_t *out = reinterpret_cast<uint32_t *>(rops + ((uint64_t)v * (n + 1) + j) * LL);
+  uint32_t *out = reinterpret_cast<uint32_t *>((v < io.osplit ? io.out[0] + (uint64_t)v * io.ostride : io.out[1] + (uint64_t)(v - io.osplit) * io.ostride) +
+                                               (uint64_t)j * LL);
   int64_t corr[ND];
 #pragma unroll
   for (int w = 0; w < ND; w++) corr[w] = 128 * sc[ND * v + w] + 16384ll * nrows;
@@ -699,6 +704,15 @@ static WideGeom wide_geom(const mfh_ctx *c) {
 int mfh_eval_rows_multi(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d_c8, const uint32_t *d_coeffs, uint32_t nvec, uint32_t coeff_bytes,
                         uint64_t *d_rops, int accumulate) {
   if (!c || !d_rops || !nvec || (nrows && (!d_c8 || !d_coeffs)) || (coeff_bytes != 1 && coeff_bytes != 4)) return MFH_EINVAL;
+  const MmIo io = {{d_coeffs, nullptr}, nvec, {d_rops, nullptr}, nvec, (uint64_t)(c->P.n + 1) * wide_geom(c).LL};
+  return eval_rows_multi_io(c, off, nrows, d_c8, io, nvec, coeff_bytes, accumulate);
+}
+
+}  // extern "C"
+
+int eval_rows_multi_io(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d_c8, const MmIo &io, uint32_t nvec, uint32_t coeff_bytes, int accumulate) {
+  if (!c || !nvec || !io.out[0] || (io.osplit < nvec && !io.out[1]) || (coeff_bytes != 1 && coeff_bytes != 4)) return MFH_EINVAL;
+  if (nrows && (!d_c8 || !io.coef[0] || (io.csplit < nvec && !io.coef[1]))) return MFH_EINVAL;
   const uint32_t ND = coeff_bytes;
   const uint32_t n = c->P.n;
   const bool q736 = c->P.logq == 736;
@@ -719,8 +733,13 @@ int mfh_eval_rows_multi(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d
   if (nrows > 0xffffffffu - 256) return MFH_EINVAL;
   HIP_TRY(c, hipSetDevice(c->device));
   const size_t ctl = (size_t)(n + 1) * wg.LL;
+  if (io.ostride < ctl) return MFH_EINVAL;
   if (nrows == 0) {
-    if (!accumulate) HIP_TRY(c, hipMemsetAsync(d_rops, 0, (size_t)nvec * ctl * 8, c->stream));
+    const uint32_t n0 = std::min(nvec, io.osplit);
+    if (!accumulate) {
+      HIP_TRY(c, hipMemset2DAsync(io.out[0], io.ostride * 8, 0, ctl * 8, n0, c->stream));
+      if (n0 < nvec) HIP_TRY(c, hipMemset2DAsync(io.out[1], io.ostride * 8, 0, ctl * 8, nvec - n0, c->stream));
+    }
     return MFH_OK;
   }
   const uint32_t ct = wide ? wg.ct : CT, mb = wide ? wg.mbp : CT * SB, rt = wide ? RT2 : RT;
@@ -744,8 +763,8 @@ int mfh_eval_rows_multi(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d
   int8_t *cd = (int8_t *)wsp;
   int64_t *sc = (int64_t *)(wsp + cd_bytes);
   int *part = (int *)(wsp + cd_bytes + sc_bytes);
-  hipLaunchKernelGGL(k_mm_digits, dim3((rpad + 255) / 256, N), dim3(256), 0, c->stream, d_coeffs, nvec, ND, (uint32_t)nrows, rpad, NT, wide ? 1 : 0, cd);
-  hipLaunchKernelGGL(k_mm_colsum, dim3(N), dim3(256), 0, c->stream, d_coeffs, nvec, ND, (uint32_t)nrows, sc);
+  hipLaunchKernelGGL(k_mm_digits, dim3((rpad + 255) / 256, N), dim3(256), 0, c->stream, io, nvec, ND, (uint32_t)nrows, rpad, NT, wide ? 1 : 0, cd);
+  hipLaunchKernelGGL(k_mm_colsum, dim3(N), dim3(256), 0, c->stream, io, nvec, ND, (uint32_t)nrows, sc);
   AesKey keyx = c->key;
   for (int i = 56; i < 60; i++) keyx.rk[i] ^= 0x80808080u;  // the kernel's keystream bytes come out as A - 128
   {
@@ -772,13 +791,15 @@ int mfh_eval_rows_multi(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d
   const uint32_t sby = wide ? wg.sby : SB;
   if (ND == 4)
     hipLaunchKernelGGL(k_evalmm_finish<4>, dim3((total + 127) / 128), dim3(128), 0, c->stream, part, sc, nchunks, ntiles, N, nvec, n, (uint32_t)nrows, ct, mb,
-                       sby, wg.LL, d_rops, accumulate);
+                       sby, wg.LL, io, accumulate);
   else
     hipLaunchKernelGGL(k_evalmm_finish<1>, dim3((total + 127) / 128), dim3(128), 0, c->stream, part, sc, nchunks, ntiles, N, nvec, n, (uint32_t)nrows, ct, mb,
-                       sby, wg.LL, d_rops, accumulate);
+                       sby, wg.LL, io, accumulate);
   HIP_TRY(c, hipGetLastError());
   return MFH_OK;
 }
+
+extern "C" {
 
 // ---- the CRS expanded once for the matrix-core path (second regime of SURVEY 8(d) for the batch prover) -------------------------
 static size_t mm_region_bytes(const mfh_ctx *c, uint64_t rows) {  // row tiles x 64-row k-steps x 1 KiB fragments

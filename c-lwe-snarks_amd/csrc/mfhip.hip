@@ -1016,15 +1016,37 @@ int mfh_timing_drain(mfh_ctx *c, const char *which, uint64_t *count, double *tot
   const int kind = timing_kind(which);
   if (kind < 0) return MFH_EINVAL;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (c->side) HIP_TRY(c, hipStreamSynchronize(c->side));
   uint64_t n = 0, rows = 0;
   double tot = 0;
   float last = -1.f;
   std::vector<mfh_ctx::Timed> keep;
+  std::vector<std::pair<float, float>> spans;  // [start, end) of every matching launch, relative to the first one's start event
+  hipEvent_t base = nullptr;
   for (auto &t : c->timed) {
     const bool match = t.kind == kind || (kind == 12 && (t.kind == 1 || t.kind == 2));
     if (!match) { keep.push_back(t); continue; }
     float ms = 0;
-    if (hipEventElapsedTime(&ms, t.e0, t.e1) == hipSuccess) { n++; tot += ms; rows += t.rows; last = ms; }
+    if (hipEventElapsedTime(&ms, t.e0, t.e1) == hipSuccess) {
+      n++; tot += ms; rows += t.rows; last = ms;
+      if (!base) base = t.e0;
+      float s0 = 0;
+      if (hipEventElapsedTime(&s0, base, t.e0) == hipSuccess) spans.emplace_back(s0, s0 + ms);
+    }
+  }
+  // launches of one kind may overlap (mfh_prove_batch runs two streams): the busy time is the union of their spans
+  std::sort(spans.begin(), spans.end());
+  double busy = 0;
+  float hi = -1e30f;
+  for (auto &sp : spans) {
+    if (sp.second <= hi) continue;
+    busy += sp.second - std::max(sp.first, hi);
+    hi = sp.second;
+  }
+  c->last_busy_ms = busy;
+  for (auto &t : c->timed) {
+    const bool match = t.kind == kind || (kind == 12 && (t.kind == 1 || t.kind == 2));
+    if (!match) continue;
     c->ev_pool.push_back(t.e0);
     c->ev_pool.push_back(t.e1);
   }
@@ -1035,6 +1057,8 @@ int mfh_timing_drain(mfh_ctx *c, const char *which, uint64_t *count, double *tot
   if (last_ms) *last_ms = last;
   return MFH_OK;
 }
+
+double mfh_timing_busy_ms(const mfh_ctx *c) { return c ? c->last_busy_ms : -1.0; }
 
 float mfh_last_kernel_ms(mfh_ctx *c, const char *which) {
   float last = -1.f;

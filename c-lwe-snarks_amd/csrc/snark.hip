@@ -445,18 +445,17 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
   constexpr uint32_t G = 31;    // proofs per S / AS expansion: 62 coefficient vectors x 4 bytes + the ones column = 249 of 256 digit columns
   constexpr uint32_t SG = 248;  // proofs per BT+BV expansion: one byte column each + the ones column = 249 of 256 digit columns
   HIP_TRY(c, hipSetDevice(c->device));
-  // scratch: WALL | HALL | VALL (the w, h, v polynomials of a super-group, SG x d each), COA | COB (the coefficient matrices of the two
-  // launches in flight, 2G x d each), CW (SG x m), ONE; then OUT (SG ciphertexts), OUTA | OUTB (2G each), CT_T (1 ciphertext)
-  const size_t words = (size_t)3 * SG * d + (size_t)4 * G * d + (size_t)SG * m + 64, need = words * 4 + (size_t)(SG + 4 * G + 1) * ctl * 8;
+  // scratch: WALL | HALL | VALL (the w, h, v polynomials of a super-group, SG x d each), CW (SG x m), ONE, CT_T (1 ciphertext).  The
+  // multi-vector launches read their coefficient vectors where the polynomial step left them and write the proof structs in place (MmIo).
+  const size_t words = (size_t)3 * SG * d + (size_t)SG * m + 64, need = words * 4 + ctl * 8;
   if (c->batch_bytes < need) {
     if (c->d_batch) { hipDeviceSynchronize(); hipFree(c->d_batch); c->d_batch = nullptr; c->batch_bytes = 0; }
     HIP_TRY(c, hipMalloc(&c->d_batch, need));
     c->batch_bytes = need;
   }
   uint32_t *const WALL = (uint32_t *)c->d_batch, *const HALL = WALL + (size_t)SG * d, *const VALL = HALL + (size_t)SG * d;
-  uint32_t *const COA = VALL + (size_t)SG * d, *const COB = COA + (size_t)2 * G * d, *const CW = COB + (size_t)2 * G * d, *const ONE = CW + (size_t)SG * m;
-  uint64_t *const OUT = (uint64_t *)((uint8_t *)c->d_batch + words * 4), *const OUTA = OUT + (size_t)SG * ctl, *const OUTB = OUTA + (size_t)2 * G * ctl,
-                  *const CT_T = OUTB + (size_t)2 * G * ctl;
+  uint32_t *const CW = VALL + (size_t)SG * d, *const ONE = CW + (size_t)SG * m;
+  uint64_t *const CT_T = (uint64_t *)((uint8_t *)c->d_batch + words * 4);
   // Two streams: the S-region launches of the groups run on the caller's stream, the AS-region launches on the side stream, so that the
   // last, partly filled round of workgroups of one launch (736 workgroups on 256 CUs) is filled by the next launch's first ones.
   if (!c->side) {
@@ -481,11 +480,7 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
   for (uint32_t s0 = 0; s0 < nproofs; s0 += SG) {
     const uint32_t sg = std::min(SG, nproofs - s0);
     uint64_t *sproofs = d_proofs + (size_t)s0 * 5 * ctl;
-    // one ciphertext of `from` per coefficient vector -> component `slot` of `count` consecutive proofs (struct order h | hat_h | hat_v | v_w | b_w)
-    auto scatter = [&](const uint64_t *from, uint64_t *proofs, uint32_t count, uint32_t slot) -> int {
-      HIP_TRY(c, hipMemcpy2DAsync(proofs + (size_t)slot * ctl, 5 * ctl * 8, from, ctl * 8, ctl * 8, count, hipMemcpyDeviceToDevice, c->stream));
-      return MFH_OK;
-    };
+    const uint64_t pstride = 5 * ctl;  // component `slot` of consecutive proofs (struct order h | hat_h | hat_v | v_w | b_w)
     // ---- b_w = delta ct_t + sum_{bit} ct_{v_i} (src/snark.c:143-155): the bits of all sg statements as byte coefficients over the BT+BV rows
     uint32_t *h_cw = (uint32_t *)pin_acquire(c, c->pin_cw, (size_t)sg * m * 4);
     if (!h_cw) return MFH_ENOMEM;
@@ -497,8 +492,8 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
     }
     HIP_TRY(c, hipMemcpyAsync(CW, h_cw, (size_t)sg * m * 4, hipMemcpyHostToDevice, c->stream));
     pin_release(c, c->pin_cw);
-    int rc = mfh_eval_rows_multi(c, ctr_ct * 2 * d, m, d_crs_c8 + (size_t)2 * d * ctb, CW, sg, 1, OUT, 0);
-    if (!rc) rc = scatter(OUT, sproofs, sg, 4);
+    const MmIo io_bw = {{CW, nullptr}, sg, {sproofs + 4 * ctl, nullptr}, sg, pstride};
+    int rc = eval_rows_multi_io(c, ctr_ct * 2 * d, m, d_crs_c8 + (size_t)2 * d * ctb, io_bw, sg, 1, 0);
     if (rc) return rc;
     {  // + delta_b ct_t for the sg proofs in one launch; the deltas travel in the (now consumed) first words of the CW staging area
       HIP_TRY(c, hipMemcpyAsync(CW, h_delta + s0, (size_t)sg * 4, hipMemcpyHostToDevice, c->stream));
@@ -533,20 +528,14 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
     for (uint32_t g0 = s0; g0 < s0 + sg; g0 += G) {
       const uint32_t g = std::min(G, s0 + sg - g0);
       uint64_t *proofs = d_proofs + (size_t)g0 * 5 * ctl;
-      const size_t o = (size_t)(g0 - s0) * d, gb = (size_t)g * d * 4;
-      HIP_TRY(c, hipMemcpyAsync(COA, WALL + o, gb, hipMemcpyDeviceToDevice, main_stream));
-      HIP_TRY(c, hipMemcpyAsync(COA + (size_t)g * d, HALL + o, gb, hipMemcpyDeviceToDevice, main_stream));
-      rc = mfh_eval_rows_multi(c, 0, d, d_crs_c8, COA, 2 * g, 4, OUTA, 0);
-      if (!rc) rc = scatter(OUTA, proofs, g, 3);
-      if (!rc) rc = scatter(OUTA + (size_t)g * ctl, proofs, g, 0);
+      const size_t o = (size_t)(g0 - s0) * d;
+      const MmIo io_s = {{WALL + o, HALL + o}, g, {proofs + 3 * ctl, proofs}, g, pstride};             // (w, h) -> (v_w, h)
+      const MmIo io_as = {{HALL + o, VALL + o}, g, {proofs + ctl, proofs + 2 * ctl}, g, pstride};  // (h, v) -> (hat_h, hat_v)
+      rc = eval_rows_multi_io(c, 0, d, d_crs_c8, io_s, 2 * g, 4, 0);
       if (rc) return rc;
       {
         OnSide side(c, side_stream);
-        HIP_TRY(c, hipMemcpyAsync(COB, HALL + o, gb, hipMemcpyDeviceToDevice, side_stream));
-        HIP_TRY(c, hipMemcpyAsync(COB + (size_t)g * d, VALL + o, gb, hipMemcpyDeviceToDevice, side_stream));
-        rc = mfh_eval_rows_multi(c, ctr_ct * d, d, d_crs_c8 + (size_t)d * ctb, COB, 2 * g, 4, OUTB, 0);
-        if (!rc) rc = scatter(OUTB, proofs, g, 1);
-        if (!rc) rc = scatter(OUTB + (size_t)g * ctl, proofs, g, 2);
+        rc = eval_rows_multi_io(c, ctr_ct * d, d, d_crs_c8 + (size_t)d * ctb, io_as, 2 * g, 4, 0);
         if (rc) return rc;
       }
     }

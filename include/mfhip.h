@@ -252,6 +252,9 @@ int mfh_set_timing(mfh_ctx *ctx, int enabled);
 int mfh_set_overlap(mfh_ctx *ctx, int mode);
 int mfh_timing_drain(mfh_ctx *ctx, const char *which, uint64_t *count, double *total_ms, uint64_t *total_rows, float *last_ms);
 float mfh_last_kernel_ms(mfh_ctx *ctx, const char *which); /* = last_ms of mfh_timing_drain; < 0 if none */
+/* Union of the [start, end) spans of the launches the last mfh_timing_drain matched, in ms: equals total_ms when the launches
+ * ran one after the other, less when launches of two streams overlapped (mfh_prove_batch). */
+double mfh_timing_busy_ms(const mfh_ctx *ctx);
 
 #ifdef __cplusplus
 }

@@ -14,7 +14,7 @@ os.makedirs(out_dir, exist_ok=True)
 
 def one(pattern):
     g = glob.glob(os.path.join(ROOT, "gpurun_out", pattern))
-    return g[0] if g else None
+    return max(g, key=os.path.getmtime) if g else None   # gpurun merges outputs of earlier calls: take the newest
 
 
 # kernel stats
