@@ -56,6 +56,7 @@ struct mfh_ctx {
   int overlap_mode = 1;  // 1 = pick the queueing order by the size of b_w's share, 2 = b_w first, 3 = chain first (mfh_set_overlap)
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_chain = nullptr, ev_chain_done = nullptr;  // mfh_prove_batch: witness pass + polynomial step on `side`
   std::string err;
   // kernel timing (bench.py's roofline leg): HIP events recorded on the launch stream, resolved lazily
   bool timing = false;
@@ -81,8 +82,13 @@ struct mfh_ctx {
   void *ssp_frag = nullptr;  // the dense SSP in MFMA B-fragment order (evalmm.hip: witness pass of the batch prover); built lazily
   size_t ssp_frag_bytes = 0;
   const uint32_t *ssp_frag_src = nullptr;  // the d_ssp it was built from; mfh_ssp_prepare / mfh_ssp_upload reset it
-  void *d_batch = nullptr;  // mfh_prove_batch group scratch: W | H | V | CW | OUT
+  void *d_batch = nullptr;  // mfh_prove_batch group scratch: W | H | V | CW | ONE | CT_T
   size_t batch_bytes = 0;
+  // mfh_prove_batch, more than one group of proofs and no image registered: the CRS is expanded ONCE PER CALL into this scratch in
+  // MFMA A-fragment order and streamed for every group (k_mmstream) instead of running AES again per group (mfh_set_batch_image)
+  void *batch_img = nullptr;
+  size_t batch_img_bytes = 0;
+  int batch_image = 1;
   PinBuf pin_rows, pin_cw, pin_smudge;
   // generator-defined SSP (ssp_prg.hpp): used by every entry point that is handed d_ssp == NULL
   bool prg_on = false;

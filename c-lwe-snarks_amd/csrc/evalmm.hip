@@ -831,7 +831,7 @@ int mfh_crs_expand_mm(mfh_ctx *c, const uint8_t *d_crs_c8, uint8_t *d_image) {
     const uint32_t units = (uint32_t)((rows[r] + RT2 - 1) / RT2);
     const uint32_t nchunks = std::max(1u, std::min(units, 4u));
     const uint32_t rpc = (units + nchunks - 1) / nchunks * RT2;
-    Timer t(c, 4, rows[r]);
+    Timer t(c, 9, rows[r]);
     const dim3 grid(ntiles, (uint32_t)((rows[r] + rpc - 1) / rpc));
     if (c->P.logq == 736)
       hipLaunchKernelGGL((k_evalmm16<1, 736>), grid, dim3(1024), 0, c->stream, keyx, c->d_t0, offs[r], n, (uint32_t)rows[r], rpc, d_crs_c8 + c8off[r],

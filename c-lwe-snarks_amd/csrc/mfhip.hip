@@ -959,10 +959,13 @@ void mfh_ctx_destroy(mfh_ctx *c) {
   if (c->aux) hipFree(c->aux);
   if (c->ev_fork) hipEventDestroy(c->ev_fork);
   if (c->ev_join) hipEventDestroy(c->ev_join);
+  if (c->ev_chain) hipEventDestroy(c->ev_chain);
+  if (c->ev_chain_done) hipEventDestroy(c->ev_chain_done);
   if (c->side) hipStreamDestroy(c->side);
   if (c->d_msg) hipFree(c->d_msg);
   if (c->d_prover) hipFree(c->d_prover);
   if (c->d_batch) hipFree(c->d_batch);
+  if (c->batch_img) hipFree(c->batch_img);
   if (c->ssp_frag) hipFree(c->ssp_frag);
   if (c->d_t0) hipFree(c->d_t0);
   for (auto &t : c->timed) { hipEventDestroy(t.e0); hipEventDestroy(t.e1); }
@@ -992,6 +995,18 @@ int mfh_set_overlap(mfh_ctx *c, int en) {
   return MFH_OK;
 }
 
+int mfh_set_batch_image(mfh_ctx *c, int en) {
+  if (!c) return MFH_EINVAL;
+  c->batch_image = en != 0;
+  if (!en && c->batch_img) {
+    HIP_TRY(c, hipDeviceSynchronize());
+    hipFree(c->batch_img);
+    c->batch_img = nullptr;
+    c->batch_img_bytes = 0;
+  }
+  return MFH_OK;
+}
+
 int mfh_set_timing(mfh_ctx *c, int en) {
   if (!c) return MFH_EINVAL;
   c->timing = en != 0;
@@ -1008,6 +1023,7 @@ static int timing_kind(const char *which) {
   if (!strcmp(which, "mac2")) return 6;
   if (!strcmp(which, "evalmm")) return 7;
   if (!strcmp(which, "evalmm_resident")) return 8;
+  if (!strcmp(which, "expandmm")) return 9;
   return -1;
 }
 

@@ -463,13 +463,51 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   }
+  if (!c->ev_chain) {
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_chain, hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_chain_done, hipEventDisableTiming));
+  }
   hipStream_t const main_stream = c->stream, side_stream = c->side;
+  bool chain_forked = false;  // ev_chain already recorded for the coming super-group (before the CRS expansion)
+  struct OnStream {  // the witness pass and the polynomial step launch on c->stream and have their own scratch (wws, poly buffers)
+    mfh_ctx *c;
+    hipStream_t keep;
+    OnStream(mfh_ctx *c_, hipStream_t s) : c(c_), keep(c_->stream) { c->stream = s; }
+    ~OnStream() { c->stream = keep; }
+  };
   struct OnSide {  // mfh_eval_rows_multi launches on c->stream with the workspace c->mm_ws_sel selects
     mfh_ctx *c;
     hipStream_t keep;
     OnSide(mfh_ctx *c_, hipStream_t s) : c(c_), keep(c_->stream) { c->stream = s; c->mm_ws_sel = 1; }
     ~OnSide() { c->stream = keep; c->mm_ws_sel = 0; }
   };
+  // More than one group: expand the CRS once for the whole call into a transient image in MFMA A-fragment order
+  // (mfh_crs_mm_image_bytes of scratch, kept by the context) and stream it for every group, instead of running AES per group.
+  struct ImageGuard {
+    mfh_ctx *c;
+    bool on;
+    ~ImageGuard() { if (on) mfh_crs_set_resident_mm(c, nullptr); }
+  } transient{c, false};
+  if (!c->mm_image && c->batch_image && nproofs > G && (((uint64_t)n * ctb) & 7) == 0) {
+    const size_t ib = mfh_crs_mm_image_bytes(c);
+    if (c->batch_img_bytes < ib) {
+      if (c->batch_img) { hipDeviceSynchronize(); hipFree(c->batch_img); c->batch_img = nullptr; c->batch_img_bytes = 0; }
+      size_t mem_free = 0, mem_total = 0;
+      if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) mem_free = 0;
+      // no room (the rest of the call and the caller need memory too): the groups regenerate the keystream
+      if (ib <= mem_free / 4 * 3 && hipMalloc(&c->batch_img, ib) == hipSuccess) c->batch_img_bytes = ib;
+      else { c->batch_img = nullptr; (void)hipGetLastError(); }
+    }
+    if (c->batch_img) {
+      // the first super-group's witness pass and polynomial step (side stream, below) run beside this expansion
+      HIP_TRY(c, hipEventRecord(c->ev_chain, main_stream));
+      chain_forked = true;
+      int rc = mfh_crs_expand_mm(c, d_crs_c8, (uint8_t *)c->batch_img);
+      if (rc) return rc;
+      mfh_crs_set_resident_mm(c, (const uint8_t *)c->batch_img);
+      transient.on = true;
+    }
+  }
   // ct_t = the BT row as a ciphertext (eval_poly of one row with coefficient 1): b_w's delta * ct_t term is added per proof below
   {
     const uint32_t one = 1;
@@ -481,6 +519,36 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
     const uint32_t sg = std::min(SG, nproofs - s0);
     uint64_t *sproofs = d_proofs + (size_t)s0 * 5 * ctl;
     const uint64_t pstride = 5 * ctl;  // component `slot` of consecutive proofs (struct order h | hat_h | hat_v | v_w | b_w)
+    // ---- side stream: the witness pass and the polynomial step of the super-group, beside b_w's rows (and, for the first
+    // super-group, the CRS expansion) on the caller's stream
+    if (!chain_forked) HIP_TRY(c, hipEventRecord(c->ev_chain, main_stream));
+    chain_forked = false;
+    HIP_TRY(c, hipStreamWaitEvent(side_stream, c->ev_chain, 0));
+    int rc = MFH_OK;
+    {
+      OnStream chain(c, side_stream);
+      // ---- w = delta t + sum_bits v_i for the whole super-group (src/snark.c:141,147-155): dense SSP with d % 128 == 0: a GEMM on the
+      // matrix cores, one read of the SSP per 62 statements; otherwise the VALU form, read (or generated) once per 12 statements
+      if (src.dense && d % 128 == 0) {
+        for (uint32_t b0 = 0; b0 < sg; b0 += 62) {
+          rc = mfh_witness_poly_mm(c, d_ssp, std::min(62u, sg - b0), h_witness_bits + (size_t)(s0 + b0) * bits_stride, bits_stride, h_delta + s0 + b0,
+                                   WALL + (size_t)b0 * d);
+          if (rc) return rc;
+        }
+      } else {
+        for (uint32_t b0 = 0; b0 < sg; b0 += 12) {
+          rc = mfh_witness_poly_multi(c, d_ssp, std::min(12u, sg - b0), h_witness_bits + (size_t)(s0 + b0) * bits_stride, bits_stride, h_delta + s0 + b0,
+                                      WALL + (size_t)b0 * d);
+          if (rc) return rc;
+        }
+      }
+      // ---- v = w + v_0, h = (v^2 - 1) / t for the whole super-group (src/snark.c:161-169): one set of launches, sg times the work each
+      hipLaunchKernelGGL(k_add_slot_multi, dim3((d + 255) / 256, sg), dim3(256), 0, c->stream, WALL, src, 1u, d, VALL);
+      HIP_TRY(c, hipGetLastError());
+      rc = mfh_poly_h_multi(c, VALL, HALL, sg);
+      if (rc) return rc;
+      HIP_TRY(c, hipEventRecord(c->ev_chain_done, side_stream));
+    }
     // ---- b_w = delta ct_t + sum_{bit} ct_{v_i} (src/snark.c:143-155): the bits of all sg statements as byte coefficients over the BT+BV rows
     uint32_t *h_cw = (uint32_t *)pin_acquire(c, c->pin_cw, (size_t)sg * m * 4);
     if (!h_cw) return MFH_ENOMEM;
@@ -493,7 +561,7 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
     HIP_TRY(c, hipMemcpyAsync(CW, h_cw, (size_t)sg * m * 4, hipMemcpyHostToDevice, c->stream));
     pin_release(c, c->pin_cw);
     const MmIo io_bw = {{CW, nullptr}, sg, {sproofs + 4 * ctl, nullptr}, sg, pstride};
-    int rc = eval_rows_multi_io(c, ctr_ct * 2 * d, m, d_crs_c8 + (size_t)2 * d * ctb, io_bw, sg, 1, 0);
+    rc = eval_rows_multi_io(c, ctr_ct * 2 * d, m, d_crs_c8 + (size_t)2 * d * ctb, io_bw, sg, 1, 0);
     if (rc) return rc;
     {  // + delta_b ct_t for the sg proofs in one launch; the deltas travel in the (now consumed) first words of the CW staging area
       HIP_TRY(c, hipMemcpyAsync(CW, h_delta + s0, (size_t)sg * 4, hipMemcpyHostToDevice, c->stream));
@@ -501,26 +569,7 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
                          (c->P.logq + 63) / 64, 2 * (c->P.logq / 64));
       HIP_TRY(c, hipGetLastError());
     }
-    // ---- w = delta t + sum_bits v_i for the whole super-group (src/snark.c:141,147-155): dense SSP with d % 128 == 0: a GEMM on the
-    // matrix cores, one read of the SSP per 62 statements; otherwise the VALU form, read (or generated) once per 12 statements
-    if (src.dense && d % 128 == 0) {
-      for (uint32_t b0 = 0; b0 < sg; b0 += 62) {
-        rc = mfh_witness_poly_mm(c, d_ssp, std::min(62u, sg - b0), h_witness_bits + (size_t)(s0 + b0) * bits_stride, bits_stride, h_delta + s0 + b0,
-                                 WALL + (size_t)b0 * d);
-        if (rc) return rc;
-      }
-    } else {
-      for (uint32_t b0 = 0; b0 < sg; b0 += 12) {
-        rc = mfh_witness_poly_multi(c, d_ssp, std::min(12u, sg - b0), h_witness_bits + (size_t)(s0 + b0) * bits_stride, bits_stride, h_delta + s0 + b0,
-                                    WALL + (size_t)b0 * d);
-        if (rc) return rc;
-      }
-    }
-    // ---- v = w + v_0, h = (v^2 - 1) / t for the whole super-group (src/snark.c:161-169): one set of launches, sg times the work each
-    hipLaunchKernelGGL(k_add_slot_multi, dim3((d + 255) / 256, sg), dim3(256), 0, c->stream, WALL, src, 1u, d, VALL);
-    HIP_TRY(c, hipGetLastError());
-    rc = mfh_poly_h_multi(c, VALL, HALL, sg);
-    if (rc) return rc;
+    HIP_TRY(c, hipStreamWaitEvent(main_stream, c->ev_chain_done, 0));
     HIP_TRY(c, hipEventRecord(c->ev_fork, main_stream));
     HIP_TRY(c, hipStreamWaitEvent(side_stream, c->ev_fork, 0));
     // ---- S rows with (w, h) -> (v_w, h) on the caller's stream; AS rows with (h, v) -> (hat_h, hat_v) on the side stream: every row

@@ -195,7 +195,12 @@ int mfh_crs_set_resident_mm(mfh_ctx *ctx, const uint8_t *d_image);
  * BT+BV region once per up to 248, and the multiply-accumulate of the coefficient vectors runs on the matrix cores (mfh_eval_rows_multi); proof b is bit-identical to
  * mfh_prove(witness b, delta b, smudging b).  h_witness_bits: nproofs bit strings, bits_stride bytes apart; h_delta: nproofs values
  * < p; h_smudge_mag: nproofs x 5 x maglen bytes; h_smudge_sign: nproofs x 5 bytes; d_proofs: nproofs x 5 ciphertexts.
- * The single-proof resident image (mfh_crs_set_resident) must not be set; the matrix-core image (mfh_crs_set_resident_mm) may. */
+ * The single-proof resident image (mfh_crs_set_resident) must not be set; the matrix-core image (mfh_crs_set_resident_mm) may.
+ * With more than 31 proofs and no image registered, the call first expands the CRS into a transient image of
+ * mfh_crs_mm_image_bytes bytes (scratch kept by the context; expanded again by every call) and streams it for every group instead of
+ * running AES once per group; if that scratch cannot be allocated, or after mfh_set_batch_image(ctx, 0) (which also frees it), every
+ * group regenerates the keystream.  Same proofs either way. */
+int mfh_set_batch_image(mfh_ctx *ctx, int enabled);
 int mfh_prove_batch(mfh_ctx *ctx, const uint8_t *d_crs_c8, const uint32_t *d_ssp, uint32_t nproofs, const uint8_t *h_witness_bits,
                     size_t bits_stride, const uint32_t *h_delta, const uint8_t *h_smudge_mag, size_t maglen, const uint8_t *h_smudge_sign,
                     uint64_t *d_proofs);
@@ -244,7 +249,7 @@ int mfh_eval_rows_multi(mfh_ctx *ctx, uint64_t off, size_t nrows, const uint8_t 
 /* Kernel timing for the roofline leg of bench.py.  With timing enabled every launch of a hot kernel is bracketed by
  * HIP events on the context's stream (no synchronisation is added).  mfh_timing_drain waits for the stream, then
  * reports and forgets the launches of kind `which`: "eval2" / "eval1" (k_eval with 2 / 1 coefficient vectors),
- * "eval" (both), "encrypt", "keystream", "expand", "mac2" / "mac1" (resident MAC), "evalmm" / "evalmm_resident" (mfh_eval_rows_multi from the seed / from the image).  total_rows = rows handed to those launches (AES blocks for "keystream"). */
+ * "eval" (both), "encrypt", "keystream", "expand", "mac2" / "mac1" (resident MAC), "evalmm" / "evalmm_resident" (mfh_eval_rows_multi from the seed / from the image), "expandmm" (mfh_crs_expand_mm, one launch per region).  total_rows = rows handed to those launches (AES blocks for "keystream"). */
 int mfh_set_timing(mfh_ctx *ctx, int enabled);
 /* prover scheduling: mfh_prove* run the witness pass + polynomial step on an internal stream beside the evaluation of
  * b_w's rows and join before the S / AS regions; results are identical in every mode.  0 = one stream, 1 (default) = two

@@ -98,15 +98,18 @@ def test_multi_argument_checks(ctx):
     assert not ctx.to_host(out).any()
 
 
-@pytest.mark.parametrize("nproofs", [1, 5, 16, 33, 126, 250])
-def test_prove_batch_equals_single_proofs(gpu_ctx_factory, oracle, nproofs):
+@pytest.mark.parametrize("nproofs,transient_image", [(1, True), (5, True), (16, True), (33, True), (33, False), (126, False), (250, True), (250, False)])
+def test_prove_batch_equals_single_proofs(gpu_ctx_factory, oracle, nproofs, transient_image):
     """mfh_prove_batch: proof b of the batch == mfh_prove(statement b), bit for bit (S / AS groups of 31 on the 256-column kernel, smaller groups on the 128-column one, BT+BV groups of 248 (128-column kernel up to 127 proofs, 256-column kernel above): 33 = one
-    full + one partial S / AS group, 250 = two BT+BV groups); the first proof is also checked against the oracle's prover and every proof is accepted by the device verifier."""
+    full + one partial S / AS group, 250 = two BT+BV groups); the first proof is also checked against the oracle's prover and every proof is accepted by the device verifier.
+    transient_image: calls with more than 31 proofs expand the CRS once per call into a scratch image and stream it for every group
+    (the default), or (mfh_set_batch_image 0) regenerate the keystream per group."""
     import c_lwe_snarks_amd as mf
 
     p = mf.DEBUG
     c = gpu_ctx_factory(p)
     c.set_seed(SEED)
+    c.set_batch_image(transient_image)
     rng = np.random.default_rng(4242)
     nbytes = (p.m + 7) // 8
     wits = [rng.integers(0, 256, size=nbytes, dtype=np.uint8).tobytes() for _ in range(nproofs)]
@@ -162,7 +165,10 @@ def test_batch_prover_from_the_matrix_core_crs_image(gpu_ctx_factory, oracle):
     deltas = [int(x) for x in rng.integers(0, ol.P, size=nb, dtype=np.uint64)]
     mags = [rng.integers(0, 256, size=400, dtype=np.uint8).tobytes() for _ in range(nb)]
     signs = [bytes(rng.integers(0, 2, size=5, dtype=np.uint8).tolist()) for _ in range(nb)]
+    c.set_batch_image(False)  # every group regenerates the keystream
     regen = c.to_host(c.prove_batch(d_crs, d_ssp, stmts, deltas, mags, signs)).copy()
+    c.set_batch_image(True)   # the call expands the CRS into its own transient image
+    assert np.array_equal(c.to_host(c.prove_batch(d_crs, d_ssp, stmts, deltas, mags, signs)), regen)
     image = c.crs_expand_mm(d_crs)
     assert image.numel() == int(c.lib.mfh_crs_mm_image_bytes(c._h)) == 3 * (736 * 11) * 4 * 1024  # row tiles x k-steps x 1 KiB
     c.set_resident_mm(image)
