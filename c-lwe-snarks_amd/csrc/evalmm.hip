@@ -467,85 +467,104 @@ __global__ __launch_bounds__(1024) void k_evalmm16(AesKey key /* rk[56..59] ^ 0x
 // the stage's digit fragments (64 KiB) are shared by the 8 waves of the workgroup through LDS, double buffered, one barrier per 256
 // rows.  HBM-bound by construction: per stage and CU 64 KiB of A against 128 x 8 MFMAs (1.7 us of matrix core) and 512 KiB of LDS
 // fragment reads.  grid = (row-tile pairs / 8, row chunks); part[((chunk * Mtot) + m) * 256 + n] as k_evalmm16 writes it.
-constexpr int SW = 8;  // waves per workgroup
+constexpr int SW = 8;   // waves per workgroup: RG row groups x CG column groups
+#ifndef MMS_RQ
+#define MMS_RQ 2
+#endif
+constexpr int RQ = MMS_RQ;        // row tiles per wave
+constexpr int RG = 16 / RQ;       // row groups: the workgroup covers 16 row tiles
+constexpr int CG = SW / RG;       // column groups
+constexpr int CH = NQ2 / CG;      // column tiles per wave
 __global__ __launch_bounds__(SW * 64) void k_mmstream(const v4i *__restrict__ image, uint32_t mtiles, uint32_t KS, uint32_t nrows,
                                                       uint32_t rows_per_chunk, const v4i *__restrict__ cdv, int *__restrict__ part) {
   __shared__ v4i bfrag[2][RT2 / 64][NQ2][64];  // 2 x 64 KiB
-  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t tid = threadIdx.x, lane = tid & 63;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // uniform: the fragment addresses are a scalar base + the lane's 16 bytes
   const uint32_t c16 = lane & 15, g4 = lane >> 4;
-  const uint32_t mt0 = (blockIdx.x * SW + wave) * 2;  // this wave's two row tiles
-  const bool live0 = mt0 < mtiles, live1 = mt0 + 1 < mtiles;
+  const uint32_t rq = wave % RG, ch = wave / RG;
+  const uint32_t mt0 = (blockIdx.x * RG + rq) * RQ;  // this wave's row tiles (with CG > 1 the waves rq and rq + RG read the same A fragments)
   const uint32_t r0 = blockIdx.y * rows_per_chunk, r1 = min(nrows, r0 + rows_per_chunk);
-  v4i acc[2][NQ2];
+  v4i acc[RQ][CH];
 #pragma unroll
-  for (int t = 0; t < 2; t++)
+  for (int t = 0; t < RQ; t++)
 #pragma unroll
-    for (int q = 0; q < NQ2; q++) acc[t][q] = v4i{0, 0, 0, 0};
+    for (int q = 0; q < CH; q++) acc[t][q] = v4i{0, 0, 0, 0};
   constexpr int KSN = RT2 / 64;                          // k-steps per stage: 4
   constexpr int BPK = NQ2 * 64 / (SW * 64);              // digit fragments per thread and k-step: 2
-  constexpr int DEPTH = 8;                               // digit fragments in flight from LDS ahead of the MFMAs
+#ifndef MMS_DEPTH
+#define MMS_DEPTH 6
+#endif
+  constexpr int DEPTH = MMS_DEPTH;                       // digit fragments in flight from LDS ahead of the MFMAs
   const v4i zero = {0, 0, 0, 0};
   auto a_load = [&](int t, uint32_t u0, int ks) -> v4i {
-    const bool live = t ? live1 : live0;
-    return live ? image[((uint64_t)(mt0 + t) * KS + (u0 >> 6) + ks) * 64 + lane] : zero;
+#ifdef MMS_SKIP_A  // timing-only build: no HBM stream (wrong results)
+    return v4i{(int)u0, ks, t, (int)lane};
+#endif
+    const v4i *ap = image + ((uint64_t)(mt0 + t) * KS + (u0 >> 6) + ks) * 64;  // scalar
+    return mt0 + t < mtiles ? ap[lane] : zero;
   };
-  v4i a[2][KSN];
-  if (r0 < r1) {
+  v4i a[RQ][KSN];
+  // Vector-memory operations complete in issue order (s_waitcnt vmcnt), so every load of the loop is used exactly one stage after it was
+  // issued: the A fragments of stage s+1 and the digit fragments of stage s+2 (kept in registers for a stage, then written to the LDS
+  // buffer stage s has just finished with) are issued in k-step ks of stage s and waited for in k-step ks of stage s+1.
+  v4i bnr[KSN][BPK];
+  auto b_load = [&](uint32_t u0, int ks, int i) -> v4i {
+    const v4i *bp = cdv + (uint64_t)(u0 >> 6) * NQ2 * 64 + (uint64_t)ks * NQ2 * 64 + SW * 64 * i;  // scalar
+    return bp[tid];
+  };
+  if (r0 >= r1) return;  // (uniform; the host never launches an empty chunk)
+  const uint32_t ulast = r0 + (r1 - r0 - 1) / RT2 * RT2;  // first row of the chunk's last stage: prefetches past it re-read it (no branches in the loop)
 #pragma unroll
-    for (int ks = 0; ks < KSN; ks++) {
-      a[0][ks] = a_load(0, r0, ks);
-      a[1][ks] = a_load(1, r0, ks);
-    }
+  for (int i = 0; i < KSN * BPK; i++) (&bfrag[0][0][0][0])[tid + SW * 64 * i] = cdv[(uint64_t)(r0 >> 6) * NQ2 * 64 + tid + SW * 64 * i];
 #pragma unroll
-    for (int i = 0; i < KSN * BPK; i++) (&bfrag[0][0][0][0])[tid + SW * 64 * i] = cdv[(uint64_t)(r0 >> 6) * NQ2 * 64 + tid + SW * 64 * i];
+  for (int ks = 0; ks < KSN; ks++) {
+#pragma unroll
+    for (int t = 0; t < RQ; t++) a[t][ks] = a_load(t, r0, ks);
+#pragma unroll
+    for (int i = 0; i < BPK; i++) bnr[ks][i] = b_load(min(r0 + RT2, ulast), ks, i);
   }
   __syncthreads();
   uint32_t buf = 0;
   for (uint32_t u0 = r0; u0 < r1; u0 += RT2) {
-    const bool more = u0 + RT2 < r1;
-    const v4i *bcur = &bfrag[buf][0][0][lane];  // fragment (ks, q) at bcur[(ks * NQ2 + q) * 64]
+    const uint32_t un1 = min(u0 + RT2, ulast), un2 = min(u0 + 2 * RT2, ulast);
+    const v4i *bcur = &bfrag[buf][0][ch * CH][lane];  // this wave's fragment (ks, q) at bcur[(ks * NQ2 + q) * 64]
     v4i *bnext = &bfrag[buf ^ 1][0][0][0];
     // a ring of DEPTH digit fragments keeps the LDS reads ahead of the MFMAs that use them
     v4i ring[DEPTH];
 #pragma unroll
-    for (int i = 0; i < DEPTH; i++) ring[i] = bcur[i * 64];
+    for (int i = 0; i < DEPTH; i++) ring[i] = bcur[((i / CH) * NQ2 + i % CH) * 64];
 #pragma unroll
     for (int ks = 0; ks < KSN; ks++) {
-      // this k-step's share of the next stage's digit fragments: global -> registers now, -> the other LDS buffer after the MFMAs
-      v4i bn[BPK];
-      if (more) {
 #pragma unroll
-        for (int i = 0; i < BPK; i++) bn[i] = cdv[(uint64_t)((u0 + RT2) >> 6) * NQ2 * 64 + (uint64_t)ks * NQ2 * 64 + tid + SW * 64 * i];
-      }
-#pragma unroll
-      for (int q = 0; q < NQ2; q++) {
-        const int it = ks * NQ2 + q;
+      for (int q = 0; q < CH; q++) {
+        const int it = ks * CH + q;
         const v4i b = ring[it % DEPTH];
-        if (it + DEPTH < KSN * NQ2) ring[it % DEPTH] = bcur[(it + DEPTH) * 64];
-        acc[0][q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[0][ks], b, acc[0][q], 0, 0, 0);
-        acc[1][q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[1][ks], b, acc[1][q], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);  // keep [refill one ring slot, two MFMAs] as written: the reads stay DEPTH fragments ahead
-      }
-      if (more) {
-        // the A fragments of this k-step are spent: their registers take the next stage's (a whole stage to land)
-        a[0][ks] = a_load(0, u0 + RT2, ks);
-        a[1][ks] = a_load(1, u0 + RT2, ks);
+        if (it + DEPTH < KSN * CH) ring[it % DEPTH] = bcur[(((it + DEPTH) / CH) * NQ2 + (it + DEPTH) % CH) * 64];
 #pragma unroll
-        for (int i = 0; i < BPK; i++) bnext[ks * NQ2 * 64 + tid + SW * 64 * i] = bn[i];
+        for (int t = 0; t < RQ; t++) acc[t][q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[t][ks], b, acc[t][q], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);  // keep [refill one ring slot, RQ MFMAs] as written: the reads stay DEPTH fragments ahead
       }
+      // this k-step's share of the next stage's digit fragments (loaded a stage ago) -> the other LDS buffer; the A fragments of this
+      // k-step are spent: their registers take the next stage's
+#pragma unroll
+      for (int i = 0; i < BPK; i++) bnext[ks * NQ2 * 64 + tid + SW * 64 * i] = bnr[ks][i];
+#pragma unroll
+      for (int t = 0; t < RQ; t++) a[t][ks] = a_load(t, un1, ks);
+#pragma unroll
+      for (int i = 0; i < BPK; i++) bnr[ks][i] = b_load(un2, ks, i);
     }
     __syncthreads();  // the other buffer is complete; everyone is done with this one
     buf ^= 1;
   }
   const uint64_t Mtot = (uint64_t)mtiles * 16;
 #pragma unroll
-  for (int t = 0; t < 2; t++) {
-    if (!(t ? live1 : live0)) continue;
+  for (int t = 0; t < RQ; t++) {
+    if (mt0 + t >= mtiles) continue;
     int *p = part + ((uint64_t)blockIdx.y * Mtot + (uint64_t)(mt0 + t) * 16) * N2;
 #pragma unroll
-    for (int q = 0; q < NQ2; q++)
+    for (int q = 0; q < CH; q++)
 #pragma unroll
-      for (int e = 0; e < 4; e++) p[(uint64_t)(4 * g4 + e) * N2 + 16 * q + c16] = acc[t][q][e];
+      for (int e = 0; e < 4; e++) p[(uint64_t)(4 * g4 + e) * N2 + 16 * (ch * CH + q) + c16] = acc[t][q][e];
   }
 }
 
