@@ -127,7 +127,7 @@ def main():
                     help="batch (default at the default workload): a step = --batch statements per GPU proved by mfh_prove_batch (CRS regions "
                          "expanded once per group of 31, MAC on the matrix cores), ranks take disjoint statements, no collective; "
                          "single: a step = one prover() call, CRS rows sharded over the ranks + lane all-reduces")
-    ap.add_argument("--batch", type=int, default=248, help="statements per GPU per step in batch mode")
+    ap.add_argument("--batch", type=int, default=992, help="statements per GPU per step in batch mode (4 super-groups of 248)")
     ap.add_argument("--no-overlap", action="store_true", help="run the prover on one stream (A/B check of the side-stream overlap)")
     ap.add_argument("--resident-gb", type=float, default=200.0, help="HBM budget for the resident CRS image per GPU")
     ap.add_argument("--workload", choices=["default", "config4", "config5"], default="default",

@@ -54,7 +54,7 @@ struct mfh_ctx {
   // prover overlap: witness pass + polynomial step on `side` while b_w's rows are evaluated on `stream` (snark.hip)
   bool overlap = true;
   int overlap_mode = 1;  // 1 = pick the queueing order by the size of b_w's share, 2 = b_w first, 3 = chain first (mfh_set_overlap)
-  hipStream_t side = nullptr;
+  hipStream_t side = nullptr, side2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipEvent_t ev_chain = nullptr, ev_chain_done = nullptr;  // mfh_prove_batch: witness pass + polynomial step on `side`
   std::string err;

@@ -962,6 +962,7 @@ void mfh_ctx_destroy(mfh_ctx *c) {
   if (c->ev_chain) hipEventDestroy(c->ev_chain);
   if (c->ev_chain_done) hipEventDestroy(c->ev_chain_done);
   if (c->side) hipStreamDestroy(c->side);
+  if (c->side2) hipStreamDestroy(c->side2);
   if (c->d_msg) hipFree(c->d_msg);
   if (c->d_prover) hipFree(c->d_prover);
   if (c->d_batch) hipFree(c->d_batch);

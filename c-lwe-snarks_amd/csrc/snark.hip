@@ -445,16 +445,17 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
   constexpr uint32_t G = 31;    // proofs per S / AS expansion: 62 coefficient vectors x 4 bytes + the ones column = 249 of 256 digit columns
   constexpr uint32_t SG = 248;  // proofs per BT+BV expansion: one byte column each + the ones column = 249 of 256 digit columns
   HIP_TRY(c, hipSetDevice(c->device));
-  // scratch: WALL | HALL | VALL (the w, h, v polynomials of a super-group, SG x d each), CW (SG x m), ONE, CT_T (1 ciphertext).  The
+  // scratch: 2 x (WALL | HALL | VALL) (the w, h, v polynomials of a super-group, SG x d each), CW (SG x m), ONE, CT_T (1 ciphertext).  The
   // multi-vector launches read their coefficient vectors where the polynomial step left them and write the proof structs in place (MmIo).
-  const size_t words = (size_t)3 * SG * d + (size_t)SG * m + 64, need = words * 4 + ctl * 8;
+  const size_t words = (size_t)6 * SG * d + (size_t)SG * m + 64, need = words * 4 + ctl * 8;
   if (c->batch_bytes < need) {
     if (c->d_batch) { hipDeviceSynchronize(); hipFree(c->d_batch); c->d_batch = nullptr; c->batch_bytes = 0; }
     HIP_TRY(c, hipMalloc(&c->d_batch, need));
     c->batch_bytes = need;
   }
-  uint32_t *const WALL = (uint32_t *)c->d_batch, *const HALL = WALL + (size_t)SG * d, *const VALL = HALL + (size_t)SG * d;
-  uint32_t *const CW = VALL + (size_t)SG * d, *const ONE = CW + (size_t)SG * m;
+  // w | h | v twice: the chain (witness pass + polynomial step) of super-group k + 1 is queued while super-group k is still smudged
+  uint32_t *const WHV = (uint32_t *)c->d_batch;
+  uint32_t *const CW = WHV + (size_t)6 * SG * d, *const ONE = CW + (size_t)SG * m;
   uint64_t *const CT_T = (uint64_t *)((uint8_t *)c->d_batch + words * 4);
   // Two streams: the S-region launches of the groups run on the caller's stream, the AS-region launches on the side stream, so that the
   // last, partly filled round of workgroups of one launch (736 workgroups on 256 CUs) is filled by the next launch's first ones.
@@ -464,11 +465,11 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   }
   if (!c->ev_chain) {
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking));
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_chain, hipEventDisableTiming));
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_chain_done, hipEventDisableTiming));
   }
-  hipStream_t const main_stream = c->stream, side_stream = c->side;
-  bool chain_forked = false;  // ev_chain already recorded for the coming super-group (before the CRS expansion)
+  hipStream_t const main_stream = c->stream, side_stream = c->side, chain_stream = c->side2;
   struct OnStream {  // the witness pass and the polynomial step launch on c->stream and have their own scratch (wws, poly buffers)
     mfh_ctx *c;
     hipStream_t keep;
@@ -481,6 +482,42 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
     OnSide(mfh_ctx *c_, hipStream_t s) : c(c_), keep(c_->stream) { c->stream = s; c->mm_ws_sel = 1; }
     ~OnSide() { c->stream = keep; c->mm_ws_sel = 0; }
   };
+  // The chain of a super-group -- w = delta t + sum_bits v_i (src/snark.c:141,147-155), v = w + v_0, h = (v^2 - 1) / t
+  // (src/snark.c:161-169) -- on its own stream: the first one runs beside the CRS expansion, the chain of super-group k + 1 beside the
+  // smudging of super-group k and its own b_w rows.  The witness pass and the polynomial step have their own scratch (wws, the poly buffers).
+  auto launch_chain = [&](uint32_t sgi) -> int {
+    const uint32_t s0 = sgi * SG, sg = std::min(SG, nproofs - s0);
+    uint32_t *const WALL = WHV + (size_t)(sgi & 1) * 3 * SG * d, *const HALL = WALL + (size_t)SG * d, *const VALL = HALL + (size_t)SG * d;
+    HIP_TRY(c, hipEventRecord(c->ev_chain, main_stream));  // what the caller's stream has been given so far no longer reads these buffers
+    HIP_TRY(c, hipStreamWaitEvent(chain_stream, c->ev_chain, 0));
+    OnStream chain(c, chain_stream);
+    int rc = MFH_OK;
+    // dense SSP with d % 128 == 0: a GEMM on the matrix cores, one read of the SSP per 62 statements; otherwise the VALU form, read
+    // (or generated) once per 12 statements
+    if (src.dense && d % 128 == 0) {
+      for (uint32_t b0 = 0; b0 < sg; b0 += 62) {
+        rc = mfh_witness_poly_mm(c, d_ssp, std::min(62u, sg - b0), h_witness_bits + (size_t)(s0 + b0) * bits_stride, bits_stride, h_delta + s0 + b0,
+                                 WALL + (size_t)b0 * d);
+        if (rc) return rc;
+      }
+    } else {
+      for (uint32_t b0 = 0; b0 < sg; b0 += 12) {
+        rc = mfh_witness_poly_multi(c, d_ssp, std::min(12u, sg - b0), h_witness_bits + (size_t)(s0 + b0) * bits_stride, bits_stride, h_delta + s0 + b0,
+                                    WALL + (size_t)b0 * d);
+        if (rc) return rc;
+      }
+    }
+    hipLaunchKernelGGL(k_add_slot_multi, dim3((d + 255) / 256, sg), dim3(256), 0, c->stream, WALL, src, 1u, d, VALL);
+    HIP_TRY(c, hipGetLastError());
+    rc = mfh_poly_h_multi(c, VALL, HALL, sg);  // one set of launches, sg times the work each
+    if (rc) return rc;
+    HIP_TRY(c, hipEventRecord(c->ev_chain_done, chain_stream));
+    return MFH_OK;
+  };
+  {
+    int rc = launch_chain(0);
+    if (rc) return rc;
+  }
   // More than one group: expand the CRS once for the whole call into a transient image in MFMA A-fragment order
   // (mfh_crs_mm_image_bytes of scratch, kept by the context) and stream it for every group, instead of running AES per group.
   struct ImageGuard {
@@ -499,9 +536,6 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
       else { c->batch_img = nullptr; (void)hipGetLastError(); }
     }
     if (c->batch_img) {
-      // the first super-group's witness pass and polynomial step (side stream, below) run beside this expansion
-      HIP_TRY(c, hipEventRecord(c->ev_chain, main_stream));
-      chain_forked = true;
       int rc = mfh_crs_expand_mm(c, d_crs_c8, (uint8_t *)c->batch_img);
       if (rc) return rc;
       mfh_crs_set_resident_mm(c, (const uint8_t *)c->batch_img);
@@ -515,40 +549,12 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
     int rc = mfh_eval_rows(c, ctr_ct * 2 * d, 1, d_crs_c8 + (size_t)2 * d * ctb, ONE, nullptr, CT_T, nullptr, 0);
     if (rc) return rc;
   }
-  for (uint32_t s0 = 0; s0 < nproofs; s0 += SG) {
+  for (uint32_t s0 = 0, sgi = 0; s0 < nproofs; s0 += SG, sgi++) {
     const uint32_t sg = std::min(SG, nproofs - s0);
     uint64_t *sproofs = d_proofs + (size_t)s0 * 5 * ctl;
     const uint64_t pstride = 5 * ctl;  // component `slot` of consecutive proofs (struct order h | hat_h | hat_v | v_w | b_w)
-    // ---- side stream: the witness pass and the polynomial step of the super-group, beside b_w's rows (and, for the first
-    // super-group, the CRS expansion) on the caller's stream
-    if (!chain_forked) HIP_TRY(c, hipEventRecord(c->ev_chain, main_stream));
-    chain_forked = false;
-    HIP_TRY(c, hipStreamWaitEvent(side_stream, c->ev_chain, 0));
+    uint32_t *const WALL = WHV + (size_t)(sgi & 1) * 3 * SG * d, *const HALL = WALL + (size_t)SG * d, *const VALL = HALL + (size_t)SG * d;
     int rc = MFH_OK;
-    {
-      OnStream chain(c, side_stream);
-      // ---- w = delta t + sum_bits v_i for the whole super-group (src/snark.c:141,147-155): dense SSP with d % 128 == 0: a GEMM on the
-      // matrix cores, one read of the SSP per 62 statements; otherwise the VALU form, read (or generated) once per 12 statements
-      if (src.dense && d % 128 == 0) {
-        for (uint32_t b0 = 0; b0 < sg; b0 += 62) {
-          rc = mfh_witness_poly_mm(c, d_ssp, std::min(62u, sg - b0), h_witness_bits + (size_t)(s0 + b0) * bits_stride, bits_stride, h_delta + s0 + b0,
-                                   WALL + (size_t)b0 * d);
-          if (rc) return rc;
-        }
-      } else {
-        for (uint32_t b0 = 0; b0 < sg; b0 += 12) {
-          rc = mfh_witness_poly_multi(c, d_ssp, std::min(12u, sg - b0), h_witness_bits + (size_t)(s0 + b0) * bits_stride, bits_stride, h_delta + s0 + b0,
-                                      WALL + (size_t)b0 * d);
-          if (rc) return rc;
-        }
-      }
-      // ---- v = w + v_0, h = (v^2 - 1) / t for the whole super-group (src/snark.c:161-169): one set of launches, sg times the work each
-      hipLaunchKernelGGL(k_add_slot_multi, dim3((d + 255) / 256, sg), dim3(256), 0, c->stream, WALL, src, 1u, d, VALL);
-      HIP_TRY(c, hipGetLastError());
-      rc = mfh_poly_h_multi(c, VALL, HALL, sg);
-      if (rc) return rc;
-      HIP_TRY(c, hipEventRecord(c->ev_chain_done, side_stream));
-    }
     // ---- b_w = delta ct_t + sum_{bit} ct_{v_i} (src/snark.c:143-155): the bits of all sg statements as byte coefficients over the BT+BV rows
     uint32_t *h_cw = (uint32_t *)pin_acquire(c, c->pin_cw, (size_t)sg * m * 4);
     if (!h_cw) return MFH_ENOMEM;
@@ -590,6 +596,12 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
     }
     HIP_TRY(c, hipEventRecord(c->ev_join, side_stream));
     HIP_TRY(c, hipStreamWaitEvent(main_stream, c->ev_join, 0));
+    // the next super-group's chain (the other w | h | v buffers) runs beside this one's smudging and the next one's b_w rows; started
+    // any earlier it would share the GPU with the HBM-bound S / AS launches, which costs more than it hides (measured)
+    if (s0 + SG < nproofs) {
+      rc = launch_chain(sgi + 1);
+      if (rc) return rc;
+    }
     // ---- smudging of the super-group in two launches: h, hat_h, hat_v, v_w with draws 0..3, then v_w AGAIN with draw 4; b_w never
     // (src/snark.c:185-189).  A zero magnitude leaves a ciphertext unchanged.
     std::vector<uint8_t> mags((size_t)sg * 5 * maglen), signs((size_t)sg * 5);
