@@ -21,7 +21,7 @@
 //   k_evalmm16<0>    256 digit columns (v_mfma_i32_16x16x64_i8, 2-coordinate column tiles): 31 proofs' vector pairs per expansion
 //   k_evalmm16<1>    expansion only: the rows written to HBM in MFMA A-fragment order (the resident image of the batch prover)
 //   k_mmstream       the same GEMM streamed from that image: no AES, HBM / matrix-core bound
-//   k_witness_mm     the witness pass of up to 64 statements as a GEMM of witness bits x SSP bytes (one read of the SSP)
+//   k_witness_mm     the witness pass of up to 128 statements as a GEMM of witness bits x SSP bytes (one read of the SSP)
 //   k_mm_digits / k_mm_colsum / k_evalmm_finish, k_ssp_frag / k_witness_bits / k_witness_mm_finish: operand preparation and epilogues
 //
 // k_evalmm: workgroup = 1024 threads, one column tile of CT = 4 coordinates (352 byte positions = 11 MFMA row tiles) x one row chunk.
@@ -535,6 +535,10 @@ __global__ __launch_bounds__(SW * 64) void k_mmstream(const v4i *__restrict__ im
     for (int i = 0; i < DEPTH; i++) ring[i] = bcur[((i / CH) * NQ2 + i % CH) * 64];
 #pragma unroll
     for (int ks = 0; ks < KSN; ks++) {
+#ifdef MMS_LOADS_ONLY  // timing-only build (wrong results): the HBM stream and the staging of the digit fragments without the matrix core
+#pragma unroll
+      for (int t = 0; t < RQ; t++) acc[t][ks][0] += a[t][ks][0] ^ a[t][ks][3];
+#else
 #pragma unroll
       for (int q = 0; q < CH; q++) {
         const int it = ks * CH + q;
@@ -544,6 +548,7 @@ __global__ __launch_bounds__(SW * 64) void k_mmstream(const v4i *__restrict__ im
         for (int t = 0; t < RQ; t++) acc[t][q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[t][ks], b, acc[t][q], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);  // keep [refill one ring slot, RQ MFMAs] as written: the reads stay DEPTH fragments ahead
       }
+#endif
       // this k-step's share of the next stage's digit fragments (loaded a stage ago) -> the other LDS buffer; the A fragments of this
       // k-step are spent: their registers take the next stage's
 #pragma unroll
@@ -640,7 +645,7 @@ __global__ void k_ssp_frag(const uint32_t *__restrict__ ssp, uint32_t nrowsel, u
     frag[(((tile * 4 + w) * 64 + lane) << 2) + eg] = lo | hi;
   }
 }
-// grid = (d / 128, row chunks); block = 4 waves, one 32-coefficient tile each; MT = 1 or 2 tiles of 32 statements (the SSP is read
+// grid = (d / 128, row chunks); block = 4 waves, one 32-coefficient tile each; MT = 1, 2 or 4 tiles of 32 statements (the SSP is read
 // once per 32 MT statements).  part[((chunk * 4 + w) * 32 MT + stmt) * d + k].
 template <int MT>
 __global__ __launch_bounds__(256) void k_witness_mm(const v4i *__restrict__ sspfrag, const v4i *__restrict__ bitfrag, uint32_t nrowsel /* m - 1 */,
@@ -657,16 +662,31 @@ __global__ __launch_bounds__(256) void k_witness_mm(const v4i *__restrict__ sspf
     for (int w = 0; w < 4; w++)
 #pragma unroll
       for (int e = 0; e < 16; e++) acc[t][w][e] = 0;
-  for (uint32_t K = K0; K < K1; K++) {
+  if (K0 >= K1) return;  // (uniform)
+  // PF row steps of fragments in flight per wave (MT = 4 holds 256 accumulator registers: one wave per SIMD, so the stream has to be
+  // kept ahead by hand); loads past the chunk re-read its last step
+  constexpr int PF = 3;
+  v4i bq[PF][4], aq[PF][MT];
+  auto fetch = [&](int slot, uint32_t K) {
+    K = min(K, K1 - 1);
     const v4i *src = sspfrag + (((uint64_t)K * KT + kt) * 4) * 64 + lane;
-    const v4i b0 = src[0], b1 = src[64], b2 = src[128], b3 = src[192];
 #pragma unroll
-    for (int t = 0; t < MT; t++) {
-      const v4i a = bitfrag[((uint64_t)K * MT + t) * 64 + lane];
-      acc[t][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b0, acc[t][0], 0, 0, 0);
-      acc[t][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b1, acc[t][1], 0, 0, 0);
-      acc[t][2] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b2, acc[t][2], 0, 0, 0);
-      acc[t][3] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b3, acc[t][3], 0, 0, 0);
+    for (int w = 0; w < 4; w++) bq[slot][w] = src[64 * w];
+#pragma unroll
+    for (int t = 0; t < MT; t++) aq[slot][t] = bitfrag[((uint64_t)K * MT + t) * 64 + lane];
+  };
+#pragma unroll
+  for (int i = 0; i < PF; i++) fetch(i, K0 + i);
+  for (uint32_t K = K0; K < K1; K += PF) {
+#pragma unroll
+    for (int i = 0; i < PF; i++) {
+      if (K + i < K1) {
+#pragma unroll
+        for (int t = 0; t < MT; t++)
+#pragma unroll
+          for (int w = 0; w < 4; w++) acc[t][w] = __builtin_amdgcn_mfma_i32_32x32x32_i8(aq[i][t], bq[i][w], acc[t][w], 0, 0, 0);
+        fetch(i, K + i + PF);
+      }
     }
   }
 #pragma unroll
@@ -875,11 +895,11 @@ int mfh_crs_set_resident_mm(mfh_ctx *c, const uint8_t *d_image) {
   return MFH_OK;
 }
 
-// mfh_witness_poly for up to 64 statements in ONE read of the (dense) SSP, on the matrix cores: d_w = nstmt polynomials of d coefficients
+// mfh_witness_poly for up to 128 statements in ONE read of the (dense) SSP, on the matrix cores: d_w = nstmt polynomials of d coefficients
 int mfh_witness_poly_mm(mfh_ctx *c, const uint32_t *d_ssp, uint32_t nstmt, const uint8_t *h_bits, size_t bits_stride, const uint32_t *h_delta,
                         uint32_t *d_w) {
-  if (!c || !d_ssp || !h_bits || !h_delta || !d_w || nstmt == 0 || nstmt > 64) return MFH_EINVAL;
-  const uint32_t MT = nstmt > 32 ? 2 : 1;
+  if (!c || !d_ssp || !h_bits || !h_delta || !d_w || nstmt == 0 || nstmt > 128) return MFH_EINVAL;
+  const uint32_t MT = nstmt > 64 ? 4 : nstmt > 32 ? 2 : 1;
   const uint32_t d = c->P.d, m = c->P.m;
   if (d % 128 || m < 2) { c->err = "mfh_witness_poly_mm: d must be a multiple of 128"; return MFH_EUNSUPPORTED; }
   for (uint32_t b = 0; b < nstmt; b++)
@@ -900,7 +920,7 @@ int mfh_witness_poly_mm(mfh_ctx *c, const uint32_t *d_ssp, uint32_t nstmt, const
     HIP_TRY(c, hipGetLastError());
     c->ssp_frag_src = d_ssp;
   }
-  const size_t packed = (size_t)nstmt * bits_stride, head_b = ((packed + 64 * 8 + 255) & ~(size_t)255);
+  const size_t packed = (size_t)nstmt * bits_stride, head_b = ((packed + 8 + 128 * 8 + 255) & ~(size_t)255);
   const size_t frag_b = (size_t)ksteps * MT * 1024, part_b = (size_t)nchunks * 4 * 32 * MT * d * 4;
   int rc = wws_reserve(c, head_b + frag_b + part_b);
   if (rc) return rc;
@@ -911,7 +931,9 @@ int mfh_witness_poly_mm(mfh_ctx *c, const uint32_t *d_ssp, uint32_t nstmt, const
   uint32_t *cd = (uint32_t *)(stage + packed + ((8 - packed % 8) % 8));
   for (uint32_t b = 0; b < nstmt; b++) {
     uint32_t cnt = 0;
-    for (uint32_t r = 0; r < nrowsel; r++) cnt += (h_bits[b * bits_stride + (r >> 3)] >> (r & 7)) & 1;
+    const uint8_t *hb = h_bits + (size_t)b * bits_stride;
+    for (uint32_t r = 0; r + 8 <= nrowsel; r += 8) cnt += (uint32_t)__builtin_popcount(hb[r >> 3]);
+    for (uint32_t r = nrowsel & ~7u; r < nrowsel; r++) cnt += (hb[r >> 3] >> (r & 7)) & 1;
     cd[2 * b] = cnt;
     cd[2 * b + 1] = h_delta[b];
   }
@@ -925,8 +947,11 @@ int mfh_witness_poly_mm(mfh_ctx *c, const uint32_t *d_ssp, uint32_t nstmt, const
   if (MT == 1)
     hipLaunchKernelGGL(k_witness_mm<1>, dim3(d / 128, (ksteps + kpc - 1) / kpc), dim3(256), 0, c->stream, (const v4i *)c->ssp_frag, (const v4i *)d_frag,
                        nrowsel, kpc, d, d_part);
-  else
+  else if (MT == 2)
     hipLaunchKernelGGL(k_witness_mm<2>, dim3(d / 128, (ksteps + kpc - 1) / kpc), dim3(256), 0, c->stream, (const v4i *)c->ssp_frag, (const v4i *)d_frag,
+                       nrowsel, kpc, d, d_part);
+  else
+    hipLaunchKernelGGL(k_witness_mm<4>, dim3(d / 128, (ksteps + kpc - 1) / kpc), dim3(256), 0, c->stream, (const v4i *)c->ssp_frag, (const v4i *)d_frag,
                        nrowsel, kpc, d, d_part);
   hipLaunchKernelGGL(k_witness_mm_finish, dim3((d + 255) / 256, nstmt), dim3(256), 0, c->stream, d_part, (ksteps + kpc - 1) / kpc, d_ssp, d_cd, nstmt, 32 * MT,
                      d, d_w);
