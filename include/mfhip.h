@@ -191,7 +191,7 @@ int mfh_verify(mfh_ctx *ctx, const uint32_t *d_ssp, uint32_t alpha, uint32_t bet
 size_t mfh_crs_mm_image_bytes(const mfh_ctx *ctx);
 int mfh_crs_expand_mm(mfh_ctx *ctx, const uint8_t *d_crs_c8, uint8_t *d_image);
 int mfh_crs_set_resident_mm(mfh_ctx *ctx, const uint8_t *d_image);
-/* prover() for nproofs statements under ONE CRS and SSP.  The S and AS regions are expanded once per group of up to 31 proofs, the
+/* prover() for nproofs statements under ONE CRS and SSP.  The S and AS regions are expanded (or streamed from the image, below) once per group of up to 31 proofs, the
  * BT+BV region once per up to 248, and the multiply-accumulate of the coefficient vectors runs on the matrix cores (mfh_eval_rows_multi); proof b is bit-identical to
  * mfh_prove(witness b, delta b, smudging b).  h_witness_bits: nproofs bit strings, bits_stride bytes apart; h_delta: nproofs values
  * < p; h_smudge_mag: nproofs x 5 x maglen bytes; h_smudge_sign: nproofs x 5 bytes; d_proofs: nproofs x 5 ciphertexts.

@@ -22,7 +22,7 @@ f = one(f"{tag}_stats/*/*_kernel_stats.csv")
 if f:
     rows = list(csv.DictReader(open(f)))
     with open(os.path.join(out_dir, f"{tag}_kernel_stats.csv"), "w") as o:
-        o.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline   (MI355X, 1 GPU; default batch mode)\n")
+        o.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline   (MI355X, 1 GPU; default batch mode: the headline run, then the regenerate-per-group and resident-image variants of the same batch, then the single-proof path)\n")
         o.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
         for r in rows:
             o.write(",".join(['"' + r["Name"][:110].replace('"', "'") + '"', r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]]) + "\n")
