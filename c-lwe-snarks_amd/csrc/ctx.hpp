@@ -166,6 +166,10 @@ struct MmIo {
   uint64_t *out[2];
   uint32_t osplit;
   uint64_t ostride;
+  // bits != nullptr replaces coef: vector v is the packed witness bits of statement v (bits + v * bits_stride) as b_w's coefficients
+  // over the BT+BV rows -- row 0 (BT) -> 0, row i -> bit i - 1 (src/snark.c:143-155); coeff_bytes = 1
+  const uint8_t *bits;
+  uint32_t bits_stride;
 };
 int eval_rows_multi_io(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d_c8, const MmIo &io, uint32_t nvec, uint32_t coeff_bytes, int accumulate);
 

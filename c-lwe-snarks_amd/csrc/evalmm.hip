@@ -58,8 +58,9 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 // n = 32 q + r of rows 32 K + 16 h + e, e = 0..15, at cd[((K * NT + q) * 64 + 32 h + r) * 16 + e].  A unit's (RT rows) fragments are one
 // contiguous RT * N bytes.  Column n = ND v + w holds byte w of c_v[i] minus 128; column ND nvec is the ones column; every other
 // column, and every row >= nrows, is zero (such rows and columns then add nothing to G').
-__device__ __forceinline__ const uint32_t *coef_of(const MmIo &io, uint32_t v, uint32_t nrows) {
-  return v < io.csplit ? io.coef[0] + (uint64_t)v * nrows : io.coef[1] + (uint64_t)(v - io.csplit) * nrows;
+__device__ __forceinline__ uint32_t coef_at(const MmIo &io, uint32_t v, uint32_t nrows, uint32_t i) {
+  if (io.bits) return i ? (io.bits[(uint64_t)v * io.bits_stride + ((i - 1) >> 3)] >> ((i - 1) & 7)) & 1u : 0u;
+  return (v < io.csplit ? io.coef[0] + (uint64_t)v * nrows : io.coef[1] + (uint64_t)(v - io.csplit) * nrows)[i];
 }
 __global__ void k_mm_digits(MmIo io, uint32_t nvec, uint32_t ND, uint32_t nrows, uint32_t rpad, uint32_t NT, int wide, int8_t *__restrict__ cd) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
@@ -67,7 +68,7 @@ __global__ void k_mm_digits(MmIo io, uint32_t nvec, uint32_t ND, uint32_t nrows,
   const uint32_t v = n / ND, w = n % ND;
   int dgt = 0;
   if (i < nrows) {
-    if (v < nvec) dgt = (int)((coef_of(io, v, nrows)[i] >> (8 * w)) & 255u) - 128;
+    if (v < nvec) dgt = (int)((coef_at(io, v, nrows, i) >> (8 * w)) & 255u) - 128;
     else if (n == ND * nvec) dgt = 1;
   }
   const uint32_t e = i & 15;
@@ -84,10 +85,8 @@ __global__ void k_mm_colsum(MmIo io, uint32_t nvec, uint32_t ND, uint32_t nrows,
   __shared__ uint32_t red[256];
   const uint32_t n = blockIdx.x, v = n / ND, w = n % ND;
   uint32_t s = 0;
-  if (v < nvec) {
-    const uint32_t *coeff = coef_of(io, v, nrows);
-    for (uint32_t i = threadIdx.x; i < nrows; i += blockDim.x) s += (coeff[i] >> (8 * w)) & 255u;
-  }
+  if (v < nvec)
+    for (uint32_t i = threadIdx.x; i < nrows; i += blockDim.x) s += (coef_at(io, v, nrows, i) >> (8 * w)) & 255u;
   red[threadIdx.x] = s;
   __syncthreads();
   for (int o = 128; o; o >>= 1) {
@@ -743,7 +742,7 @@ static WideGeom wide_geom(const mfh_ctx *c) {
 int mfh_eval_rows_multi(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d_c8, const uint32_t *d_coeffs, uint32_t nvec, uint32_t coeff_bytes,
                         uint64_t *d_rops, int accumulate) {
   if (!c || !d_rops || !nvec || (nrows && (!d_c8 || !d_coeffs)) || (coeff_bytes != 1 && coeff_bytes != 4)) return MFH_EINVAL;
-  const MmIo io = {{d_coeffs, nullptr}, nvec, {d_rops, nullptr}, nvec, (uint64_t)(c->P.n + 1) * wide_geom(c).LL};
+  const MmIo io = {{d_coeffs, nullptr}, nvec, {d_rops, nullptr}, nvec, (uint64_t)(c->P.n + 1) * wide_geom(c).LL, nullptr, 0};
   return eval_rows_multi_io(c, off, nrows, d_c8, io, nvec, coeff_bytes, accumulate);
 }
 
@@ -751,7 +750,7 @@ int mfh_eval_rows_multi(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d
 
 int eval_rows_multi_io(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d_c8, const MmIo &io, uint32_t nvec, uint32_t coeff_bytes, int accumulate) {
   if (!c || !nvec || !io.out[0] || (io.osplit < nvec && !io.out[1]) || (coeff_bytes != 1 && coeff_bytes != 4)) return MFH_EINVAL;
-  if (nrows && (!d_c8 || !io.coef[0] || (io.csplit < nvec && !io.coef[1]))) return MFH_EINVAL;
+  if (nrows && (!d_c8 || (!io.bits && (!io.coef[0] || (io.csplit < nvec && !io.coef[1]))) || (io.bits && coeff_bytes != 1))) return MFH_EINVAL;
   const uint32_t ND = coeff_bytes;
   const uint32_t n = c->P.n;
   const bool q736 = c->P.logq == 736;

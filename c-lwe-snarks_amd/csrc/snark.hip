@@ -556,17 +556,15 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
     uint32_t *const WALL = WHV + (size_t)(sgi & 1) * 3 * SG * d, *const HALL = WALL + (size_t)SG * d, *const VALL = HALL + (size_t)SG * d;
     int rc = MFH_OK;
     // ---- b_w = delta ct_t + sum_{bit} ct_{v_i} (src/snark.c:143-155): the bits of all sg statements as byte coefficients over the BT+BV rows
-    uint32_t *h_cw = (uint32_t *)pin_acquire(c, c->pin_cw, (size_t)sg * m * 4);
+    // (the packed bits travel as they are, 2.7 KB per statement; the digit kernels unpack them)
+    const uint32_t bstride = (m + 6) / 8;  // the m - 1 bits of a statement, repacked densely (the CW area holds SG x m words)
+    const size_t packed = (size_t)sg * bstride;
+    uint8_t *h_cw = (uint8_t *)pin_acquire(c, c->pin_cw, packed);
     if (!h_cw) return MFH_ENOMEM;
-    for (uint32_t b = 0; b < sg; b++) {
-      const uint8_t *bits = h_witness_bits + (size_t)(s0 + b) * bits_stride;
-      uint32_t *cw = h_cw + (size_t)b * m;
-      cw[0] = 0;  // the BT row: delta can be any residue, its term is added below
-      for (uint32_t i = 1; i < m; i++) cw[i] = (bits[(i - 1) >> 3] >> ((i - 1) & 7)) & 1;
-    }
-    HIP_TRY(c, hipMemcpyAsync(CW, h_cw, (size_t)sg * m * 4, hipMemcpyHostToDevice, c->stream));
+    for (uint32_t b = 0; b < sg; b++) memcpy(h_cw + (size_t)b * bstride, h_witness_bits + (size_t)(s0 + b) * bits_stride, bstride);
+    HIP_TRY(c, hipMemcpyAsync(CW, h_cw, packed, hipMemcpyHostToDevice, c->stream));
     pin_release(c, c->pin_cw);
-    const MmIo io_bw = {{CW, nullptr}, sg, {sproofs + 4 * ctl, nullptr}, sg, pstride};
+    const MmIo io_bw = {{nullptr, nullptr}, sg, {sproofs + 4 * ctl, nullptr}, sg, pstride, (const uint8_t *)CW, bstride};
     rc = eval_rows_multi_io(c, ctr_ct * 2 * d, m, d_crs_c8 + (size_t)2 * d * ctb, io_bw, sg, 1, 0);
     if (rc) return rc;
     {  // + delta_b ct_t for the sg proofs in one launch; the deltas travel in the (now consumed) first words of the CW staging area
@@ -584,8 +582,8 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
       const uint32_t g = std::min(G, s0 + sg - g0);
       uint64_t *proofs = d_proofs + (size_t)g0 * 5 * ctl;
       const size_t o = (size_t)(g0 - s0) * d;
-      const MmIo io_s = {{WALL + o, HALL + o}, g, {proofs + 3 * ctl, proofs}, g, pstride};             // (w, h) -> (v_w, h)
-      const MmIo io_as = {{HALL + o, VALL + o}, g, {proofs + ctl, proofs + 2 * ctl}, g, pstride};  // (h, v) -> (hat_h, hat_v)
+      const MmIo io_s = {{WALL + o, HALL + o}, g, {proofs + 3 * ctl, proofs}, g, pstride, nullptr, 0};             // (w, h) -> (v_w, h)
+      const MmIo io_as = {{HALL + o, VALL + o}, g, {proofs + ctl, proofs + 2 * ctl}, g, pstride, nullptr, 0};  // (h, v) -> (hat_h, hat_v)
       rc = eval_rows_multi_io(c, 0, d, d_crs_c8, io_s, 2 * g, 4, 0);
       if (rc) return rc;
       {
