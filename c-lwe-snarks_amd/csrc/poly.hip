@@ -248,6 +248,121 @@ __global__ __launch_bounds__(256) void k_ntt_lds_mul(uint32_t *__restrict__ a, c
   for (uint32_t i = threadIdx.x; i < BL; i += 256) a[base + i] = sa[i];
 }
 
+// ---- the same for B = 11 (every transform of 2^11 points or more) with the stages in REGISTERS: a thread owns 8 of the block's 2048
+// points; three radix-8 passes and one radix-4 pass per direction, the block crosses LDS only between passes (6 exchanges and barriers
+// instead of 22 stage sweeps), the pointwise product and the first inverse pass stay in registers.  LDS index i lives at i + (i >> 5)
+// (every pass's 64 lanes then spread over the 32 banks twice, the minimum).  rhs: nullptr = squaring, else a cached full transform
+// (b_is_hat); two fresh operands keep the generic kernel above.
+__device__ __forceinline__ uint32_t lpad(uint32_t i) { return i + (i >> 5); }
+// K DIF stages (block lengths len, len/2, ...) on v[0 .. 2^K): element m sits at position j + m * qd of its block, qd = len >> K
+template <int K>
+__device__ __forceinline__ void dif_regs(uint32_t *v, uint32_t j, uint32_t qd, uint32_t len, const uint32_t *__restrict__ t, uint32_t half_max,
+                                         const NttPrime q) {
+  constexpr int R = 1 << K;
+#pragma unroll
+  for (int st = 0; st < K; st++) {
+    const int h = R >> (st + 1);
+    const uint32_t tstep = (half_max * 2) / (len >> st);
+#pragma unroll
+    for (int m = 0; m < R; m++) {
+      if ((m & h) == 0) {
+        const uint32_t w = t[(size_t)(j + (uint32_t)(m & (h - 1)) * qd) * tstep];
+        const uint32_t u = v[m], z = v[m + h];
+        v[m] = add_mod(u, z, q.p);
+        v[m + h] = mont_mul(sub_mod(u, z, q.p), w, q.p, q.ninv);
+      }
+    }
+  }
+}
+// K DIT stages (block lengths len, 2 len, ...; inverse twiddles): element m at position j + m * qd, qd = len / 2
+template <int K>
+__device__ __forceinline__ void dit_regs(uint32_t *v, uint32_t j, uint32_t qd, uint32_t len, const uint32_t *__restrict__ t, uint32_t half_max,
+                                         const NttPrime q) {
+  constexpr int R = 1 << K;
+#pragma unroll
+  for (int st = 0; st < K; st++) {
+    const int h = 1 << st;
+    const uint32_t tstep = (half_max * 2) / (len << st);
+#pragma unroll
+    for (int m = 0; m < R; m++) {
+      if ((m & h) == 0) {
+        const uint32_t w = t[(size_t)(j + (uint32_t)(m & (h - 1)) * qd) * tstep];
+        const uint32_t u = v[m], z = mont_mul(v[m + h], w, q.p, q.ninv);
+        v[m] = add_mod(u, z, q.p);
+        v[m + h] = sub_mod(u, z, q.p);
+      }
+    }
+  }
+}
+__global__ __launch_bounds__(256) void k_ntt_lds_mul8(uint32_t *__restrict__ a, const uint32_t *__restrict__ bhat, uint32_t N,
+                                                      const uint32_t *__restrict__ tw, const uint32_t *__restrict__ twi, uint32_t half_max, Primes3 P) {
+  __shared__ uint32_t sm[2048 + 64];
+  const NttPrime q = P.q[blockIdx.y % 3];
+  const uint32_t tid = threadIdx.x;
+  const size_t base = (size_t)blockIdx.y * N + (size_t)blockIdx.x * 2048;
+  const uint32_t *t = tw + (size_t)(blockIdx.y % 3) * half_max, *ti = twi + (size_t)(blockIdx.y % 3) * half_max;
+  uint32_t v[8];
+  // the three strided views of the block: element m of the thread at i1 + 256 m, i2 + 32 m, i3 + 4 m; and the contiguous one at 8 tid + m
+  const uint32_t i1 = tid, j2 = tid & 31, i2 = (tid >> 5) * 256 + j2, j3 = tid >> 6, i3 = (tid & 63) * 32 + j3;
+  // ---- forward: block lengths 2048 .. 2
+#pragma unroll
+  for (int m = 0; m < 8; m++) v[m] = a[base + i1 + 256 * m];
+  dif_regs<3>(v, tid, 256, 2048, t, half_max, q);
+#pragma unroll
+  for (int m = 0; m < 8; m++) sm[lpad(i1 + 256 * m)] = v[m];
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < 8; m++) v[m] = sm[lpad(i2 + 32 * m)];
+  dif_regs<3>(v, j2, 32, 256, t, half_max, q);
+#pragma unroll
+  for (int m = 0; m < 8; m++) sm[lpad(i2 + 32 * m)] = v[m];
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < 8; m++) v[m] = sm[lpad(i3 + 4 * m)];
+  dif_regs<3>(v, j3, 4, 32, t, half_max, q);
+#pragma unroll
+  for (int m = 0; m < 8; m++) sm[lpad(i3 + 4 * m)] = v[m];
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < 8; m++) v[m] = sm[lpad(8 * tid + m)];
+  dif_regs<2>(v, 0, 1, 4, t, half_max, q);
+  dif_regs<2>(v + 4, 0, 1, 4, t, half_max, q);
+  // ---- pointwise product with the right-hand side's transform (itself when squaring)
+  if (bhat) {
+    const uint4 *bp = reinterpret_cast<const uint4 *>(bhat + (size_t)(blockIdx.y % 3) * N + (size_t)blockIdx.x * 2048 + 8 * tid);
+    const uint4 b0 = bp[0], b1 = bp[1];
+    const uint32_t bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+    for (int m = 0; m < 8; m++) v[m] = mont_mul(v[m], bb[m], q.p, q.ninv);
+  } else {
+#pragma unroll
+    for (int m = 0; m < 8; m++) v[m] = mont_mul(v[m], v[m], q.p, q.ninv);
+  }
+  // ---- inverse: block lengths 2 .. 2048
+  dit_regs<2>(v, 0, 1, 2, ti, half_max, q);
+  dit_regs<2>(v + 4, 0, 1, 2, ti, half_max, q);
+#pragma unroll
+  for (int m = 0; m < 8; m++) sm[lpad(8 * tid + m)] = v[m];
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < 8; m++) v[m] = sm[lpad(i3 + 4 * m)];
+  dit_regs<3>(v, j3, 4, 8, ti, half_max, q);
+#pragma unroll
+  for (int m = 0; m < 8; m++) sm[lpad(i3 + 4 * m)] = v[m];
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < 8; m++) v[m] = sm[lpad(i2 + 32 * m)];
+  dit_regs<3>(v, j2, 32, 64, ti, half_max, q);
+#pragma unroll
+  for (int m = 0; m < 8; m++) sm[lpad(i2 + 32 * m)] = v[m];
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < 8; m++) v[m] = sm[lpad(i1 + 256 * m)];
+  dit_regs<3>(v, tid, 256, 512, ti, half_max, q);
+#pragma unroll
+  for (int m = 0; m < 8; m++) a[base + i1 + 256 * m] = v[m];
+}
+
 __global__ void k_pointwise(uint32_t *__restrict__ a, const uint32_t *__restrict__ b, uint32_t N, Primes3 P) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
@@ -502,7 +617,10 @@ int poly_mul(mfh_ctx *c, const uint32_t *a, uint32_t la, const uint32_t *b, uint
     }
   }
   // low forward stages of both operands, pointwise product, low inverse stages: one kernel, the block never leaves LDS
-  hipLaunchKernelGGL(k_ntt_lds_mul, dim3(N >> B, 3 * nb), dim3(256), 0, c->stream, S->d_bufA, rhs, is_hat, N, B, S->d_tw, S->d_twi, half_max, S->P);
+  if (B == 11 && (rhs == nullptr || is_hat))
+    hipLaunchKernelGGL(k_ntt_lds_mul8, dim3(N >> B, 3 * nb), dim3(256), 0, c->stream, S->d_bufA, rhs, N, S->d_tw, S->d_twi, half_max, S->P);
+  else
+    hipLaunchKernelGGL(k_ntt_lds_mul, dim3(N >> B, 3 * nb), dim3(256), 0, c->stream, S->d_bufA, rhs, is_hat, N, B, S->d_tw, S->d_twi, half_max, S->P);
   inverse_top(c, S->d_bufA, logN, nb);
   hipLaunchKernelGGL(k_crt, dim3((keep + 255) / 256, nb), dim3(256), 0, c->stream, S->d_bufA, N, keep, S->P, make_crt(S, logN), out, out_stride);
   HIP_TRY(c, hipGetLastError());

@@ -69,6 +69,25 @@ def test_poly_h_matches_oracle(ctx, oracle, mf, case):
     assert np.array_equal(got, oracle.poly_h(v, t))
 
 
+def test_poly_square_and_hat_paths_at_2048_point_blocks(gpu_ctx_factory, oracle, mf):
+    """Transforms of 2^11 points or more run their low 11 stages in registers (k_ntt_lds_mul8: squaring and cached-transform products):
+    a 1500-coefficient square against exact integer convolution, and h = (v^2 - 1) / t at d = 2048 against the oracle."""
+    p = mf.Params(logq=736, d=2048, m=64)
+    c = gpu_ctx_factory(p)
+    rng = np.random.default_rng(2048)
+    a = rng.integers(0, ol.P, size=1500, dtype=np.uint64)
+    a[0] = a[-1] = ol.P - 1
+    d_a = _u32(c, a)
+    got = c.to_host(c.poly_mul(d_a, 1500, d_a, 1500), np.uint32)
+    exp = np.convolve(a.astype(object), a.astype(object)) % ol.P
+    assert got.tolist() == [int(x) for x in exp]
+    v = rng.integers(0, ol.P, size=p.d, dtype=np.uint64)
+    t = rng.integers(0, ol.P, size=p.d, dtype=np.uint64)
+    c.poly_prepare_t(_u32(c, t))
+    got = c.to_host(c.poly_h(_u32(c, v)), np.uint32).astype(np.uint64)
+    assert np.array_equal(got, oracle.poly_h(v, t))
+
+
 def test_poly_prepare_rejects_zero_t(ctx, mf):
     with pytest.raises(mf.MfhError):
         ctx.poly_prepare_t(ctx.zeros(mf.DEBUG.d * 4))
