@@ -590,6 +590,8 @@ __global__ void k_evalmm_finish(const int *__restrict__ part, const int64_t *__r
   for (int w = 0; w < ND; w++) corr[w] = 128 * sc[ND * v + w] + 16384ll * nrows;
   unsigned __int128 run = 0;  // bits [32 l, ...) of the partial result
   const uint32_t KWv = sby / 4;  // 22 | 46 words survive modq
+  const bool wide4 = (LL & 1) == 0 && (io.ostride & 1) == 0 && ((reinterpret_cast<uintptr_t>(io.out[0]) | reinterpret_cast<uintptr_t>(io.out[1])) & 15) == 0;
+  uint32_t pend[4] = {0, 0, 0, 0};
   for (uint32_t l = 0; l < KWv; l++) {
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -612,10 +614,23 @@ __global__ void k_evalmm_finish(const int *__restrict__ part, const int64_t *__r
       run += (unsigned __int128)(word >> 32) << 32;  // carry of the accumulate into the next word
       word &= 0xffffffffu;
     }
-    out[l] = (uint32_t)word;
+    // the thread's ciphertext element is written in 16-byte (LL even: 96-byte elements) or 8-byte pieces, not word by word: the
+    // elements of neighbouring threads lie a ciphertext apart, so every store is its own memory transaction
+    pend[l & 3] = (uint32_t)word;
+    if (wide4 ? (l & 3) == 3 : (l & 1) == 1) {
+      if (wide4) *reinterpret_cast<uint4 *>(out + (l & ~3u)) = uint4{pend[0], pend[1], pend[2], pend[3]};
+      else *reinterpret_cast<uint2 *>(out + (l & ~1u)) = uint2{pend[(l & 2)], pend[(l & 2) + 1]};
+    }
     run >>= 32;
   }
-  for (uint32_t l = KWv; l < 2 * LL; l++) out[l] = 0;  // modq: limbs >= K dropped (src/lwe.h:107-118)
+  // modq: limbs >= K dropped (src/lwe.h:107-118); KWv = 2 mod 4 words are pending when wide4 (22 of 24 words at logq = 736)
+  if (wide4) {
+    if (KWv & 3) *reinterpret_cast<uint4 *>(out + (KWv & ~3u)) = uint4{pend[0], (KWv & 3) > 1 ? pend[1] : 0u, (KWv & 3) > 2 ? pend[2] : 0u, 0u};
+    for (uint32_t l = (KWv + 3) & ~3u; l < 2 * LL; l += 4) *reinterpret_cast<uint4 *>(out + l) = uint4{0u, 0u, 0u, 0u};
+  } else {
+    if (KWv & 1) *reinterpret_cast<uint2 *>(out + (KWv & ~1u)) = uint2{pend[(KWv & 2)], 0u};
+    for (uint32_t l = (KWv + 1) & ~1u; l < 2 * LL; l += 2) *reinterpret_cast<uint2 *>(out + l) = uint2{0u, 0u};
+  }
 }
 
 // ---- the witness pass of up to 32 statements as a GEMM over the SSP rows (one read of the SSP) ---------------------------------------
