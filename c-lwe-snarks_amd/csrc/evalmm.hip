@@ -22,7 +22,7 @@
 //   k_evalmm16<1>    expansion only: the rows written to HBM in MFMA A-fragment order (the resident image of the batch prover)
 //   k_mmstream       the same GEMM streamed from that image: no AES, HBM / matrix-core bound
 //   k_witness_mm     the witness pass of up to 128 statements as a GEMM of witness bits x SSP bytes (one read of the SSP)
-//   k_mm_digits / k_mm_colsum / k_evalmm_finish, k_ssp_frag / k_witness_bits / k_witness_mm_finish: operand preparation and epilogues
+//   k_mm_digits / k_evalmm_finish, k_ssp_frag / k_witness_bits / k_witness_mm_finish: operand preparation and epilogues
 //
 // k_evalmm: workgroup = 1024 threads, one column tile of CT = 4 coordinates (352 byte positions = 11 MFMA row tiles) x one row chunk.
 // Per unit of RT = 128 rows: (1) all 16 waves expand the 128 x 368-byte row segments into a row-major LDS tile (23-24 AES blocks
@@ -48,7 +48,6 @@ constexpr int MT = MB / 32;       // 11 MFMA row tiles
 constexpr int RT = 128;           // rows per unit
 constexpr int TSTRIDE = 384;      // tile row stride: 24 AES blocks
 constexpr int BLK_PER_ROW = 24;
-constexpr int NDMAX = 4;          // bytes per coefficient: 4 (any uint32) or 1 (coefficients < 256, e.g. b_w's witness bits)
 static_assert(MB % 32 == 0 && CT * VB + 15 <= TSTRIDE, "tile geometry");
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -62,38 +61,39 @@ __device__ __forceinline__ uint32_t coef_at(const MmIo &io, uint32_t v, uint32_t
   if (io.bits) return i ? (io.bits[(uint64_t)v * io.bits_stride + ((i - 1) >> 3)] >> ((i - 1) & 7)) & 1u : 0u;
   return (v < io.csplit ? io.coef[0] + (uint64_t)v * nrows : io.coef[1] + (uint64_t)(v - io.csplit) * nrows)[i];
 }
-__global__ void k_mm_digits(MmIo io, uint32_t nvec, uint32_t ND, uint32_t nrows, uint32_t rpad, uint32_t NT, int wide, int8_t *__restrict__ cd) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
-  if (i >= rpad) return;
+// block = the N digit columns (thread n) x RG consecutive groups of 16 rows: a thread builds whole 16-byte fragment elements (digit n of
+// 16 consecutive rows: its vector's 16 coefficients are one 64-byte line, shared by the ND byte columns of that vector) and adds its
+// column sum sc[n] = sum_i C'[i][n] (signed digits; sc zeroed by the caller) with one atomic per block.
+constexpr int DG_RG = 8;   // row groups per block: 128 rows
+__global__ void k_mm_digits(MmIo io, uint32_t nvec, uint32_t ND, uint32_t nrows, uint32_t rpad, uint32_t NT, int wide, int8_t *__restrict__ cd,
+                            int64_t *__restrict__ sc) {
+  const uint32_t n = threadIdx.x;  // blockDim.x = N
   const uint32_t v = n / ND, w = n % ND;
-  int dgt = 0;
-  if (i < nrows) {
-    if (v < nvec) dgt = (int)((coef_at(io, v, nrows, i) >> (8 * w)) & 255u) - 128;
-    else if (n == ND * nvec) dgt = 1;
+  const bool ones = n == ND * nvec;
+  int colsum = 0;
+  for (uint32_t rg = blockIdx.x * DG_RG; rg < (blockIdx.x + 1) * DG_RG && rg * 16 < rpad; rg++) {
+    const uint32_t i0 = rg * 16;
+    uint32_t pk[4] = {0, 0, 0, 0};
+    if (v < nvec || ones) {
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        int dgt = 0;
+        if (i0 + e < nrows) dgt = ones ? 1 : (int)((coef_at(io, v, nrows, i0 + e) >> (8 * w)) & 255u) - 128;
+        colsum += dgt;
+        pk[e >> 2] |= (uint32_t)(dgt & 255) << (8 * (e & 3));
+      }
+    }
+    uint64_t at;
+    if (!wide) {  // v_mfma_i32_32x32x32_i8: k-step = 32 rows, lane = 32 h + r
+      const uint32_t K = i0 >> 5, h = (i0 >> 4) & 1, q = n >> 5, r = n & 31;
+      at = ((uint64_t)K * NT + q) * 64 + 32 * h + r;
+    } else {      // v_mfma_i32_16x16x64_i8: k-step = 64 rows, lane = 16 g + c, NT column tiles of 16
+      const uint32_t K = i0 >> 6, g = (i0 >> 4) & 3, q = n >> 4, c = n & 15;
+      at = ((uint64_t)K * NT + q) * 64 + 16 * g + c;
+    }
+    reinterpret_cast<uint4 *>(cd)[at] = uint4{pk[0], pk[1], pk[2], pk[3]};
   }
-  const uint32_t e = i & 15;
-  if (!wide) {  // v_mfma_i32_32x32x32_i8: k-step = 32 rows, lane = 32 h + r
-    const uint32_t K = i >> 5, h = (i >> 4) & 1, q = n >> 5, r = n & 31;
-    cd[((((uint64_t)K * NT + q) * 64 + 32 * h + r) << 4) + e] = (int8_t)dgt;
-  } else {      // v_mfma_i32_16x16x64_i8: k-step = 64 rows, lane = 16 g + c, NT column tiles of 16
-    const uint32_t K = i >> 6, g = (i >> 4) & 3, q = n >> 4, c = n & 15;
-    cd[((((uint64_t)K * NT + q) * 64 + 16 * g + c) << 4) + e] = (int8_t)dgt;
-  }
-}
-// sc[n] = sum_i C'[i][n] = sum_i (byte w of c_v[i]) - 128 nrows, from the coefficient vectors (signed)
-__global__ void k_mm_colsum(MmIo io, uint32_t nvec, uint32_t ND, uint32_t nrows, int64_t *__restrict__ sc) {
-  __shared__ uint32_t red[256];
-  const uint32_t n = blockIdx.x, v = n / ND, w = n % ND;
-  uint32_t s = 0;
-  if (v < nvec)
-    for (uint32_t i = threadIdx.x; i < nrows; i += blockDim.x) s += (coef_at(io, v, nrows, i) >> (8 * w)) & 255u;
-  red[threadIdx.x] = s;
-  __syncthreads();
-  for (int o = 128; o; o >>= 1) {
-    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) sc[n] = (int64_t)red[0] - 128ll * nrows;
+  if (v < nvec && colsum) atomicAdd(reinterpret_cast<unsigned long long *>(sc + n), (unsigned long long)(long long)colsum);
 }
 
 struct RowGeom {
@@ -816,8 +816,8 @@ int eval_rows_multi_io(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d_
   int8_t *cd = (int8_t *)wsp;
   int64_t *sc = (int64_t *)(wsp + cd_bytes);
   int *part = (int *)(wsp + cd_bytes + sc_bytes);
-  hipLaunchKernelGGL(k_mm_digits, dim3((rpad + 255) / 256, N), dim3(256), 0, c->stream, io, nvec, ND, (uint32_t)nrows, rpad, NT, wide ? 1 : 0, cd);
-  hipLaunchKernelGGL(k_mm_colsum, dim3(N), dim3(256), 0, c->stream, io, nvec, ND, (uint32_t)nrows, sc);
+  HIP_TRY(c, hipMemsetAsync(sc, 0, sc_bytes, c->stream));
+  hipLaunchKernelGGL(k_mm_digits, dim3((rpad / 16 + DG_RG - 1) / DG_RG), dim3(N), 0, c->stream, io, nvec, ND, (uint32_t)nrows, rpad, NT, wide ? 1 : 0, cd, sc);
   AesKey keyx = c->key;
   for (int i = 56; i < 60; i++) keyx.rk[i] ^= 0x80808080u;  // the kernel's keystream bytes come out as A - 128
   {
