@@ -248,8 +248,8 @@ __global__ __launch_bounds__(1024) void k_evalmm(AesKey key /* rk[56..59] ^ 0x80
 // positions = 11.5 row tiles, padded to 12 (the last 8 positions are never read back).
 constexpr int RT2 = 256, TS2 = 192, BPR2 = 12, NQ2 = 16, N2 = 16 * NQ2;
 template <int LOGQ> struct W16;
-template <> struct W16<736> { static constexpr int CT = 2, SBY = 88, VBY = 92, MT = 11, MBP = 176, KW = 22, LL = 12; };
-template <> struct W16<1472> { static constexpr int CT = 1, SBY = 184, VBY = 184, MT = 12, MBP = 192, KW = 46, LL = 23; };
+template <> struct W16<736> { static constexpr int CT = 2, SBY = 88, VBY = 92, MT = 11, MBP = 176, LL = 12; };
+template <> struct W16<1472> { static constexpr int CT = 1, SBY = 184, VBY = 184, MT = 12, MBP = 192, LL = 23; };
 static_assert(RT2 * 4 == 1024 && BPR2 % 4 == 0 && RT2 * BPR2 == 3 * 1024 && W16<736>::CT * W16<736>::VBY + 8 <= TS2 && W16<1472>::CT * W16<1472>::VBY + 8 <= TS2, "wide tile geometry");
 
 // MODE 0: regenerate the keystream (AES) and multiply-accumulate.  MODE 1: regenerate and WRITE the rows to `image` in A-FRAGMENT order
@@ -573,57 +573,66 @@ __global__ __launch_bounds__(SW * 64) void k_mmstream(const v4i *__restrict__ im
 }
 
 // out_v[j] = sum_{u,w} G[(j,u)][(v,w)] 256^(u + w) mod 2^704 with G = G' + 128 SA[(j,u)] + 128 sc[(v,w)] + 16384 nrows, G' and
-// SA = G'[.][ones column] summed over the row chunks; thread = (vector v fastest, coordinate j)
+// SA = G'[.][ones column] summed over the row chunks.  Block = one coordinate j x 64 vectors x 4 word groups.  Thread (v, lq)
+// forms val_l = sum_k t_k 2^(8k) < 2^80 for its words l = lq, lq + 4, ... (no carries between them) and parks the three 32-bit pieces
+// in LDS; the lq = 0 threads then add, per output word, the pieces of val_l, val_(l-1), val_(l-2) with the running carry (22 | 46 adds
+// on LDS data) and write the element in 16-byte (LL even: 96-byte elements) or 8-byte pieces: the elements of neighbouring threads lie a
+// ciphertext apart, so every store is its own memory transaction.
 template <int ND>
-__global__ void k_evalmm_finish(const int *__restrict__ part, const int64_t *__restrict__ sc, uint32_t nchunks, uint32_t ntiles, uint32_t N,
-                                uint32_t nvec, uint32_t n, uint32_t nrows, uint32_t ct, uint32_t MBv /* byte positions per column tile, padded */,
-                                uint32_t sby /* significant bytes per value */, uint32_t LL /* limbs per value */,
-                                MmIo io /* out: (n+1) * LL words per vector */, int accumulate) {
-  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t v = gid % nvec, j = gid / nvec;
-  if (j > n) return;
-  const uint32_t tile = j / ct, jj = j % ct;  // ct coordinates per column tile (4: k_evalmm, 2 | 1: k_evalmm16)
+__global__ __launch_bounds__(256) void k_evalmm_finish(const int *__restrict__ part, const int64_t *__restrict__ sc, uint32_t nchunks, uint32_t ntiles,
+                                                        uint32_t N, uint32_t nvec, uint32_t n, uint32_t nrows, uint32_t ct, uint32_t MBv, uint32_t sby,
+                                                        uint32_t LL, MmIo io, int accumulate) {
+  __shared__ uint32_t sv[46][3][64];
+  const uint32_t vl = threadIdx.x & 63, lq = threadIdx.x >> 6;
+  const uint32_t v = blockIdx.y * 64 + vl, j = blockIdx.x;
+  const uint32_t tile = j / ct, jj = j % ct;
+  const uint32_t KWv = sby / 4;  // 22 | 46 words survive modq
+  if (v < nvec) {
+    int64_t corr[ND];
+#pragma unroll
+    for (int w = 0; w < ND; w++) corr[w] = 128 * sc[ND * v + w] + 16384ll * nrows;
+    for (uint32_t l = lq; l < KWv; l += 4) {
+      unsigned __int128 val = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t mm = jj * sby + 4 * l + k;
+        int64_t g[ND] = {}, sa = 0;
+        for (uint32_t ch = 0; ch < nchunks; ch++) {
+          const int *row = part + (((uint64_t)ch * ntiles + tile) * MBv + mm) * N;
+#pragma unroll
+          for (int w = 0; w < ND; w++) g[w] += row[ND * v + w];
+          sa += row[ND * nvec];
+        }
+        uint64_t t = 0;
+#pragma unroll
+        for (int w = 0; w < ND; w++) t += (uint64_t)(g[w] + 128 * sa + corr[w]) << (8 * w);  // each term is a true byte-product sum: >= 0, < 2^31
+        val += (unsigned __int128)t << (8 * k);
+      }
+      sv[l][0][vl] = (uint32_t)val;
+      sv[l][1][vl] = (uint32_t)(val >> 32);
+      sv[l][2][vl] = (uint32_t)(val >> 64);
+    }
+  }
+  __syncthreads();
+  if (lq != 0 || v >= nvec) return;
   uint32_t *out = reinterpret_cast<uint32_t *>((v < io.osplit ? io.out[0] + (uint64_t)v * io.ostride : io.out[1] + (uint64_t)(v - io.osplit) * io.ostride) +
                                                (uint64_t)j * LL);
-  int64_t corr[ND];
-#pragma unroll
-  for (int w = 0; w < ND; w++) corr[w] = 128 * sc[ND * v + w] + 16384ll * nrows;
-  unsigned __int128 run = 0;  // bits [32 l, ...) of the partial result
-  const uint32_t KWv = sby / 4;  // 22 | 46 words survive modq
   const bool wide4 = (LL & 1) == 0 && (io.ostride & 1) == 0 && ((reinterpret_cast<uintptr_t>(io.out[0]) | reinterpret_cast<uintptr_t>(io.out[1])) & 15) == 0;
   uint32_t pend[4] = {0, 0, 0, 0};
+  uint64_t carry = 0;
   for (uint32_t l = 0; l < KWv; l++) {
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const uint32_t mm = jj * sby + 4 * l + k;
-      int64_t g[ND] = {}, sa = 0;
-      for (uint32_t ch = 0; ch < nchunks; ch++) {
-        const int *row = part + (((uint64_t)ch * ntiles + tile) * MBv + mm) * N;
-#pragma unroll
-        for (int w = 0; w < ND; w++) g[w] += row[ND * v + w];
-        sa += row[ND * nvec];
-      }
-      uint64_t t = 0;
-#pragma unroll
-      for (int w = 0; w < ND; w++) t += (uint64_t)(g[w] + 128 * sa + corr[w]) << (8 * w);  // each term is a true byte-product sum: >= 0, < 2^31
-      run += (unsigned __int128)t << (8 * k);
-    }
-    uint64_t word = (uint64_t)run & 0xffffffffu;
-    if (accumulate) {
-      word += out[l];
-      run += (unsigned __int128)(word >> 32) << 32;  // carry of the accumulate into the next word
-      word &= 0xffffffffu;
-    }
-    // the thread's ciphertext element is written in 16-byte (LL even: 96-byte elements) or 8-byte pieces, not word by word: the
-    // elements of neighbouring threads lie a ciphertext apart, so every store is its own memory transaction
+    uint64_t word = carry + sv[l][0][vl];
+    if (l >= 1) word += sv[l - 1][1][vl];
+    if (l >= 2) word += sv[l - 2][2][vl];
+    if (accumulate) word += out[l];
+    carry = word >> 32;
     pend[l & 3] = (uint32_t)word;
     if (wide4 ? (l & 3) == 3 : (l & 1) == 1) {
       if (wide4) *reinterpret_cast<uint4 *>(out + (l & ~3u)) = uint4{pend[0], pend[1], pend[2], pend[3]};
       else *reinterpret_cast<uint2 *>(out + (l & ~1u)) = uint2{pend[(l & 2)], pend[(l & 2) + 1]};
     }
-    run >>= 32;
   }
-  // modq: limbs >= K dropped (src/lwe.h:107-118); KWv = 2 mod 4 words are pending when wide4 (22 of 24 words at logq = 736)
+  // modq: limbs >= K dropped (src/lwe.h:107-118)
   if (wide4) {
     if (KWv & 3) *reinterpret_cast<uint4 *>(out + (KWv & ~3u)) = uint4{pend[0], (KWv & 3) > 1 ? pend[1] : 0u, (KWv & 3) > 2 ? pend[2] : 0u, 0u};
     for (uint32_t l = (KWv + 3) & ~3u; l < 2 * LL; l += 4) *reinterpret_cast<uint4 *>(out + l) = uint4{0u, 0u, 0u, 0u};
@@ -840,14 +849,14 @@ int eval_rows_multi_io(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d_
                          part);
   }
   HIP_TRY(c, hipGetLastError());
-  const uint32_t total = (n + 1) * nvec;
   const uint32_t sby = wide ? wg.sby : SB;
+  const dim3 fgrid(n + 1, (nvec + 63) / 64);
   if (ND == 4)
-    hipLaunchKernelGGL(k_evalmm_finish<4>, dim3((total + 127) / 128), dim3(128), 0, c->stream, part, sc, nchunks, ntiles, N, nvec, n, (uint32_t)nrows, ct, mb,
-                       sby, wg.LL, io, accumulate);
+    hipLaunchKernelGGL(k_evalmm_finish<4>, fgrid, dim3(256), 0, c->stream, part, sc, nchunks, ntiles, N, nvec, n, (uint32_t)nrows, ct, mb, sby, wg.LL, io,
+                       accumulate);
   else
-    hipLaunchKernelGGL(k_evalmm_finish<1>, dim3((total + 127) / 128), dim3(128), 0, c->stream, part, sc, nchunks, ntiles, N, nvec, n, (uint32_t)nrows, ct, mb,
-                       sby, wg.LL, io, accumulate);
+    hipLaunchKernelGGL(k_evalmm_finish<1>, fgrid, dim3(256), 0, c->stream, part, sc, nchunks, ntiles, N, nvec, n, (uint32_t)nrows, ct, mb, sby, wg.LL, io,
+                       accumulate);
   HIP_TRY(c, hipGetLastError());
   return MFH_OK;
 }
