@@ -170,6 +170,9 @@ struct MmIo {
   // over the BT+BV rows -- row 0 (BT) -> 0, row i -> bit i - 1 (src/snark.c:143-155); coeff_bytes = 1
   const uint8_t *bits;
   uint32_t bits_stride;
+  // optional: 256 int64 column sums the CALLER has zeroed (mfh_prove_batch clears the slots of all its launches with one memset);
+  // nullptr: a slot of the workspace, cleared by a memset in front of the digit kernel
+  int64_t *sc_zeroed;
 };
 int eval_rows_multi_io(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d_c8, const MmIo &io, uint32_t nvec, uint32_t coeff_bytes, int accumulate);
 

@@ -766,7 +766,7 @@ static WideGeom wide_geom(const mfh_ctx *c) {
 int mfh_eval_rows_multi(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d_c8, const uint32_t *d_coeffs, uint32_t nvec, uint32_t coeff_bytes,
                         uint64_t *d_rops, int accumulate) {
   if (!c || !d_rops || !nvec || (nrows && (!d_c8 || !d_coeffs)) || (coeff_bytes != 1 && coeff_bytes != 4)) return MFH_EINVAL;
-  const MmIo io = {{d_coeffs, nullptr}, nvec, {d_rops, nullptr}, nvec, (uint64_t)(c->P.n + 1) * wide_geom(c).LL, nullptr, 0};
+  const MmIo io = {{d_coeffs, nullptr}, nvec, {d_rops, nullptr}, nvec, (uint64_t)(c->P.n + 1) * wide_geom(c).LL, nullptr, 0, nullptr};
   return eval_rows_multi_io(c, off, nrows, d_c8, io, nvec, coeff_bytes, accumulate);
 }
 
@@ -823,9 +823,9 @@ int eval_rows_multi_io(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d_
   if (rc) return rc;
   uint8_t *wsp = (uint8_t *)(c->mm_ws_sel ? c->ws2 : c->ws);  // the launch on the side stream of mfh_prove_batch has its own scratch
   int8_t *cd = (int8_t *)wsp;
-  int64_t *sc = (int64_t *)(wsp + cd_bytes);
+  int64_t *sc = io.sc_zeroed ? io.sc_zeroed : (int64_t *)(wsp + cd_bytes);
   int *part = (int *)(wsp + cd_bytes + sc_bytes);
-  HIP_TRY(c, hipMemsetAsync(sc, 0, sc_bytes, c->stream));
+  if (!io.sc_zeroed) HIP_TRY(c, hipMemsetAsync(sc, 0, sc_bytes, c->stream));
   hipLaunchKernelGGL(k_mm_digits, dim3((rpad / 16 + DG_RG - 1) / DG_RG), dim3(N), 0, c->stream, io, nvec, ND, (uint32_t)nrows, rpad, NT, wide ? 1 : 0, cd, sc);
   AesKey keyx = c->key;
   for (int i = 56; i < 60; i++) keyx.rk[i] ^= 0x80808080u;  // the kernel's keystream bytes come out as A - 128

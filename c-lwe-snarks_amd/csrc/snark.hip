@@ -447,7 +447,8 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
   HIP_TRY(c, hipSetDevice(c->device));
   // scratch: 2 x (WALL | HALL | VALL) (the w, h, v polynomials of a super-group, SG x d each), CW (SG x m), ONE, CT_T (1 ciphertext).  The
   // multi-vector launches read their coefficient vectors where the polynomial step left them and write the proof structs in place (MmIo).
-  const size_t words = (size_t)6 * SG * d + (size_t)SG * m + 64, need = words * 4 + ctl * 8;
+  const size_t nsg = ((size_t)nproofs + SG - 1) / SG, nslots = nsg * (1 + 2 * ((SG + G - 1) / G));  // multi-vector launches of the call
+  const size_t words = (size_t)6 * SG * d + (size_t)SG * m + 64, need = words * 4 + ctl * 8 + nslots * 2048;
   if (c->batch_bytes < need) {
     if (c->d_batch) { hipDeviceSynchronize(); hipFree(c->d_batch); c->d_batch = nullptr; c->batch_bytes = 0; }
     HIP_TRY(c, hipMalloc(&c->d_batch, need));
@@ -457,6 +458,9 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
   uint32_t *const WHV = (uint32_t *)c->d_batch;
   uint32_t *const CW = WHV + (size_t)6 * SG * d, *const ONE = CW + (size_t)SG * m;
   uint64_t *const CT_T = (uint64_t *)((uint8_t *)c->d_batch + words * 4);
+  int64_t *const SCZ = (int64_t *)((uint8_t *)c->d_batch + words * 4 + ctl * 8);  // the launches' column-sum slots (256 int64 each)
+  size_t slot = 0;
+  HIP_TRY(c, hipMemsetAsync(SCZ, 0, nslots * 2048, c->stream));
   // Two streams: the S-region launches of the groups run on the caller's stream, the AS-region launches on the side stream, so that the
   // last, partly filled round of workgroups of one launch (736 workgroups on 256 CUs) is filled by the next launch's first ones.
   if (!c->side) {
@@ -564,7 +568,7 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
     for (uint32_t b = 0; b < sg; b++) memcpy(h_cw + (size_t)b * bstride, h_witness_bits + (size_t)(s0 + b) * bits_stride, bstride);
     HIP_TRY(c, hipMemcpyAsync(CW, h_cw, packed, hipMemcpyHostToDevice, c->stream));
     pin_release(c, c->pin_cw);
-    const MmIo io_bw = {{nullptr, nullptr}, sg, {sproofs + 4 * ctl, nullptr}, sg, pstride, (const uint8_t *)CW, bstride};
+    const MmIo io_bw = {{nullptr, nullptr}, sg, {sproofs + 4 * ctl, nullptr}, sg, pstride, (const uint8_t *)CW, bstride, SCZ + 256 * slot++};
     rc = eval_rows_multi_io(c, ctr_ct * 2 * d, m, d_crs_c8 + (size_t)2 * d * ctb, io_bw, sg, 1, 0);
     if (rc) return rc;
     {  // + delta_b ct_t for the sg proofs in one launch; the deltas travel in the (now consumed) first words of the CW staging area
@@ -582,8 +586,8 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
       const uint32_t g = std::min(G, s0 + sg - g0);
       uint64_t *proofs = d_proofs + (size_t)g0 * 5 * ctl;
       const size_t o = (size_t)(g0 - s0) * d;
-      const MmIo io_s = {{WALL + o, HALL + o}, g, {proofs + 3 * ctl, proofs}, g, pstride, nullptr, 0};             // (w, h) -> (v_w, h)
-      const MmIo io_as = {{HALL + o, VALL + o}, g, {proofs + ctl, proofs + 2 * ctl}, g, pstride, nullptr, 0};  // (h, v) -> (hat_h, hat_v)
+      const MmIo io_s = {{WALL + o, HALL + o}, g, {proofs + 3 * ctl, proofs}, g, pstride, nullptr, 0, SCZ + 256 * slot++};             // (w, h) -> (v_w, h)
+      const MmIo io_as = {{HALL + o, VALL + o}, g, {proofs + ctl, proofs + 2 * ctl}, g, pstride, nullptr, 0, SCZ + 256 * slot++};  // (h, v) -> (hat_h, hat_v)
       rc = eval_rows_multi_io(c, 0, d, d_crs_c8, io_s, 2 * g, 4, 0);
       if (rc) return rc;
       {
