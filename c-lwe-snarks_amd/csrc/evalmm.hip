@@ -74,7 +74,23 @@ __global__ void k_mm_digits(MmIo io, uint32_t nvec, uint32_t ND, uint32_t nrows,
   for (uint32_t rg = blockIdx.x * DG_RG; rg < (blockIdx.x + 1) * DG_RG && rg * 16 < rpad; rg++) {
     const uint32_t i0 = rg * 16;
     uint32_t pk[4] = {0, 0, 0, 0};
-    if (v < nvec || ones) {
+    if (io.bits && v < nvec) {
+      // packed witness bits: rows i0 .. i0 + 15 are bits i0 - 1 .. i0 + 14 (row 0 -> 0): one 24-bit window instead of 16 byte loads
+      const uint8_t *bp = io.bits + (uint64_t)v * io.bits_stride;
+      const uint32_t first = i0 ? i0 - 1 : 0, b0 = first >> 3, nb = (nrows + 6) >> 3;  // bits 0 .. nrows - 2 exist
+      uint32_t win = 0;
+#pragma unroll
+      for (int k = 0; k < 3; k++)
+        if (b0 + k < nb) win |= (uint32_t)bp[b0 + k] << (8 * k);
+      win >>= first & 7;
+      if (!i0) win <<= 1;  // row 0 is the BT row: coefficient 0
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        const int dgt = i0 + e < nrows ? (int)((win >> e) & 1u) - 128 : 0;
+        colsum += dgt;
+        pk[e >> 2] |= (uint32_t)(dgt & 255) << (8 * (e & 3));
+      }
+    } else if (v < nvec || ones) {
 #pragma unroll
       for (int e = 0; e < 16; e++) {
         int dgt = 0;
