@@ -362,7 +362,10 @@ def main():
             return {"bound": "hbm", "kernel": "k_mmstream (A fragments of the expanded CRS streamed from HBM, digit fragments through LDS, i8 MFMA 16x16x64)",
                     "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic_of("traffic_mmstream.json"),
                     "bytes_read_per_row": tile_bytes_per_row, "launches": n_, "avg_launch_ms": avg, "busy_ms_per_launch": eff, "concurrency": avg / eff,
-                    "rows_per_launch": rows, "note": CONC_NOTE, "mfma_int8_tops": 2.0 * 129536 * 256 * rows / (eff * 1e-3) / 1e12}
+                    "rows_per_launch": rows, "note": CONC_NOTE, "mfma_int8_tops": 2.0 * 129536 * 256 * rows / (eff * 1e-3) / 1e12,
+                    # the second ceiling of this kernel (512 int8 ops per image byte): dense int8 peak ~5 POPS at 2.4 GHz; the chip holds
+                    # ~1.5 GHz under this load (GRBM_GUI_ACTIVE / 8 / duration), where the matrix pipes are ~70 % busy
+                    "mfma_frac_of_dense_peak": 2.0 * 129536 * 256 * rows / (eff * 1e-3) / 1e12 / 5000.0}
 
         def evalmm16_roofline(kt):
             n_, ms_, rows_, busy_ = kt
