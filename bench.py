@@ -563,6 +563,11 @@ def main():
             "mode": mode,
             "config": head["config"],
             "proof_accepted": head["proof_accepted"],
+            # SURVEY 8(d)'s per-proof accounting (every CRS row touched once per proof + the selected SSP rows): what the whole job
+            # "moves" by that count.  The batch kernels serve 31 proofs from one read of a row, so this exceeds the HBM peak; the
+            # roofline objects below count the bytes a launch actually streams
+            "algorithmic_bytes_per_proof": rows_crs * (p.n + 1) * p.ctb + (p.m // 2) * p.d * 4,
+            "effective_gbs_by_per_proof_accounting": head["value"] * (rows_crs * (p.n + 1) * p.ctb + (p.m // 2) * p.d * 4) / 1e9,
             "lwe_enc_per_s": enc_per_s,
             "setup_s": setup_s,
             "setup_enc_per_s": rows_crs / setup_s,
