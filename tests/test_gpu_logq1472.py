@@ -119,7 +119,7 @@ def test_matrix_core_eval_at_1472(setup, oracle, nrows, nvec, cb):
 
 
 def test_batch_prover_at_1472(gpu_ctx_factory, mf, oracle):
-    """mfh_prove_batch at logq = 1472, regenerate and resident (A-fragment image) regimes, against mfh_prove proof by proof"""
+    """mfh_prove_batch at logq = 1472: transient image (default), per-group regeneration and resident image, against mfh_prove proof by proof"""
     p = mf.Params(logq=1472, d=128, m=24)
     c = gpu_ctx_factory(p)
     c.set_seed(SEED)
@@ -142,6 +142,9 @@ def test_batch_prover_at_1472(gpu_ctx_factory, mf, oracle):
     for b in (0, 1, 17, 33):
         one = c.to_host(c.prove(d_crs, d_ssp, stmts[b], deltas[b], mags[b], signs[b]), np.uint64).reshape(-1)
         assert np.array_equal(got[b], one), f"proof {b}"
+    c.set_batch_image(False)  # (the call above expanded the CRS into its transient image; now every group regenerates the keystream)
+    assert np.array_equal(c.to_host(c.prove_batch(d_crs, d_ssp, stmts, deltas, mags, signs), np.uint64).reshape(nb, -1), got)
+    c.set_batch_image(True)
     image = c.crs_expand_mm(d_crs)
     c.set_resident_mm(image)
     try:
