@@ -29,6 +29,7 @@ import numpy as np  # noqa: E402
 
 ROW_BYTES = 1471 * 92  # algorithmic bytes of one expanded ciphertext row (keystream + b); x2 at logq 1472
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+MFMA_I8_PEAK_TOPS = 5000.0  # MI355X_MICROARCH.md: I8 = 2x BF16 per clock, dense BF16 ~2.5 PF -> ~5 POPS (no sparsity)
 CONC_NOTE = ("the batch prover queues a group's S launch on the caller's stream and its AS launch on a side stream, so two launches of this "
              "kernel share the GPU: avg_launch_ms is the start-to-end time of one launch (what HIP events and rocprofv3 report), "
              "busy_ms_per_launch the union of all launches' spans / launches (the time the GPU spends per launch); achieved = algorithmic "
@@ -346,7 +347,7 @@ def main():
             kt = {}
             for k in ("evalmm", "evalmm_resident", "expandmm"):
                 n_, ms_, rows_ = ctx.timing_drain(k)
-                kt[k] = (n_, ms_, rows_, ctx.timing_busy_ms())  # launches on two streams overlap: busy = union of their spans
+                kt[k] = (n_, ms_, rows_, ctx.timing_busy_ms(), ctx.timing_work_rows())  # launches on two streams overlap: busy = union of their spans
             if dist is not None:
                 tt = torch.tensor([el], dtype=torch.float64, device=ctx.device)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -354,21 +355,25 @@ def main():
             return out, el, kt
 
         def mmstream_roofline(kt):
-            n_, ms_, rows_, busy_ = kt
+            n_, ms_, rows_, busy_, work_ = kt
             if not n_:
                 return None
-            avg, eff, rows = ms_ / n_, busy_ / n_, rows_ / n_
-            gbs = rows * tile_bytes_per_row / (eff * 1e-3) / 1e9
-            return {"bound": "hbm", "kernel": "k_mmstream (A fragments of the expanded CRS streamed from HBM, digit fragments through LDS, i8 MFMA 16x16x64)",
-                    "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic_of("traffic_mmstream.json"),
-                    "bytes_read_per_row": tile_bytes_per_row, "launches": n_, "avg_launch_ms": avg, "busy_ms_per_launch": eff, "concurrency": avg / eff,
-                    "rows_per_launch": rows, "note": CONC_NOTE, "mfma_int8_tops": 2.0 * 129536 * 256 * rows / (eff * 1e-3) / 1e12,
-                    # the second ceiling of this kernel (512 int8 ops per image byte): dense int8 peak ~5 POPS at 2.4 GHz; the chip holds
-                    # ~1.5 GHz under this load (GRBM_GUI_ACTIVE / 8 / duration), where the matrix pipes are ~70 % busy
-                    "mfma_frac_of_dense_peak": 2.0 * 129536 * 256 * rows / (eff * 1e-3) / 1e12 / 5000.0}
+            avg, eff, rows, work = ms_ / n_, busy_ / n_, rows_ / n_, work_ / n_
+            tops = 2.0 * 129536 * 256 * work / (eff * 1e-3) / 1e12   # int8 multiply-adds x 2 on the matrix cores (M = 129536, N = 256, K = rows)
+            gbs = rows * tile_bytes_per_row / (eff * 1e-3) / 1e9      # the launch's one pass over the image
+            return {"bound": "mfma", "kernel": "k_mmstream (A fragments of the expanded CRS streamed once per launch for 4 groups of 31 proofs -- HBM for the "
+                                               "first workgroup of a row-tile set, that XCD's L2 for the other three --, digit fragments through LDS, "
+                                               "i8 MFMA 16x16x64)",
+                    "achieved": tops, "peak": MFMA_I8_PEAK_TOPS, "unit": "TFLOP/s", "frac": tops / MFMA_I8_PEAK_TOPS, "traffic": traffic_of("traffic_mmstream.json"),
+                    "launches": n_, "avg_launch_ms": avg, "busy_ms_per_launch": eff, "concurrency": avg / eff, "rows_per_launch": rows,
+                    "groups_per_launch": work / rows, "note": CONC_NOTE.replace("algorithmic bytes", "int8 operations"),
+                    "hbm": {"bytes_read_per_row": tile_bytes_per_row, "achieved_gbs": gbs, "peak_gbs": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS,
+                            "fragment_gbs_consumed_incl_l2": gbs * work / rows},
+                    "clock_note": "the chip holds ~1.5 GHz under this load (GRBM_GUI_ACTIVE / 8 / duration, DESIGN.md 4.2c); a bare register-only loop "
+                                  "of this MFMA sustains ~4050 TOPS (tools/mfma_i8_rate.hip)"}
 
         def evalmm16_roofline(kt):
-            n_, ms_, rows_, busy_ = kt
+            n_, ms_, rows_, busy_, _ = kt
             if not n_:
                 return None
             avg, eff, rows = ms_ / n_, busy_ / n_, rows_ / n_
@@ -384,7 +389,7 @@ def main():
                     "mfma_int8_tops": 2.0 * 129448 * 256 * rows / (eff * 1e-3) / 1e12}
 
         def expand_info(kt):
-            n_, ms_, rows_, busy_ = kt
+            n_, ms_, rows_, busy_, _ = kt
             if not n_:
                 return None
             avg, rows = ms_ / n_, rows_ / n_

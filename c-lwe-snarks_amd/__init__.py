@@ -86,7 +86,7 @@ EXPORTS = [
     "mfh_encrypt_rows", "mfh_decrypt", "mfh_ct_smudge", "mfh_ssp_upload", "mfh_witness_poly", "mfh_version",
     "mfh_workspace_bytes", "mfh_last_kernel_ms", "mfh_set_timing", "mfh_set_overlap", "mfh_eval_rows_multi", "mfh_prove_batch", "mfh_crs_mm_image_bytes", "mfh_crs_expand_mm", "mfh_crs_set_resident_mm", "mfh_witness_poly_multi", "mfh_witness_poly_mm", "mfh_poly_h_multi", "mfh_poly_mul", "mfh_poly_add", "mfh_poly_prepare_t",
     "mfh_ssp_prepare", "mfh_poly_h", "mfh_setup_messages", "mfh_setup", "mfh_prove",
-    "mfh_prove_partial", "mfh_prove_finish", "mfh_ct_to_lanes", "mfh_ct_from_lanes", "mfh_timing_drain", "mfh_timing_busy_ms", "mfh_set_batch_image", "mfh_add_dotp",
+    "mfh_prove_partial", "mfh_prove_finish", "mfh_ct_to_lanes", "mfh_ct_from_lanes", "mfh_timing_drain", "mfh_timing_busy_ms", "mfh_timing_work_rows", "mfh_set_batch_image", "mfh_add_dotp",
     "mfh_resident_row_bytes", "mfh_crs_expand", "mfh_eval_rows_resident", "mfh_crs_set_resident",
     "mfh_witness_lanes", "mfh_witness_from_lanes", "mfh_prove_partial_w", "mfh_verify",
     "mfh_ssp_set_prg", "mfh_ssp_prg_make_t", "mfh_ssp_prg_fill",
@@ -166,6 +166,7 @@ def load_library():
         "mfh_timing_drain": (i32, [vp, ctypes.c_char_p, ctypes.POINTER(u64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(u64),
                                    ctypes.POINTER(ctypes.c_float)]),
         "mfh_timing_busy_ms": (ctypes.c_double, [vp]),
+        "mfh_timing_work_rows": (u64, [vp]),
         "mfh_set_batch_image": (i32, [vp, i32]),
     }
     for name, (res, args) in sig.items():
@@ -259,6 +260,10 @@ class Context:
     def timing_busy_ms(self):
         """union of the spans of the launches the last timing_drain matched (ms): < total ms when two streams overlapped"""
         return float(self.lib.mfh_timing_busy_ms(self._h))
+
+    def timing_work_rows(self):
+        """rows x evaluations served by the launches the last timing_drain matched"""
+        return int(self.lib.mfh_timing_work_rows(self._h))
 
     def last_kernel_ms(self, which):
         return float(self.lib.mfh_last_kernel_ms(self._h, which.encode()))

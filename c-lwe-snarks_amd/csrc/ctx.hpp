@@ -64,9 +64,11 @@ struct mfh_ctx {
     hipEvent_t e0, e1;
     int kind;        // 0 keystream, 1/2 eval (1/2 coeff vectors), 3 encrypt, 4 expand, 5/6 resident MAC (1/2 vectors)
     uint64_t rows;   // rows handed to the launch
+    uint64_t work;   // rows x evaluations the launch serves (k_mmstream with several groups; = rows elsewhere)
   };
   std::vector<Timed> timed;
   double last_busy_ms = 0;  // union of the spans of the launches the last mfh_timing_drain matched
+  uint64_t last_work_rows = 0;
   std::vector<hipEvent_t> ev_pool;
   PolyState *poly = nullptr;  // NTT tables and per-SSP precomputation (poly.hip)
   void *aux = nullptr;        // small scratch that must survive an eval/encrypt launch (snark.hip)
@@ -89,6 +91,7 @@ struct mfh_ctx {
   void *batch_img = nullptr;
   size_t batch_img_bytes = 0;
   int batch_image = 1;
+  uint32_t batch_ngl = 4;  // groups of 31 proofs per streaming launch over the image (1..8)
   PinBuf pin_rows, pin_cw, pin_smudge;
   // generator-defined SSP (ssp_prg.hpp): used by every entry point that is handed d_ssp == NULL
   bool prg_on = false;
@@ -104,7 +107,7 @@ struct Timer {  // brackets one launch with events when timing is on; never sync
   mfh_ctx *c;
   mfh_ctx::Timed t{};
   bool on;
-  Timer(mfh_ctx *c_, int kind, uint64_t rows) : c(c_), on(c_->timing) {
+  Timer(mfh_ctx *c_, int kind, uint64_t rows, uint64_t work = 0) : c(c_), on(c_->timing) {
     if (!on) return;
     auto get = [&]() {
       hipEvent_t e;
@@ -112,7 +115,7 @@ struct Timer {  // brackets one launch with events when timing is on; never sync
       else hipEventCreate(&e);
       return e;
     };
-    t.e0 = get(); t.e1 = get(); t.kind = kind; t.rows = rows;
+    t.e0 = get(); t.e1 = get(); t.kind = kind; t.rows = rows; t.work = work ? work : rows;
     hipEventRecord(t.e0, c->stream);
   }
   ~Timer() {
@@ -175,6 +178,9 @@ struct MmIo {
   int64_t *sc_zeroed;
 };
 int eval_rows_multi_io(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d_c8, const MmIo &io, uint32_t nvec, uint32_t coeff_bytes, int accumulate);
+// ng of them over the same region in one streaming launch when the matrix-core image is registered (io.sc_zeroed required); else one by one
+int eval_rows_multi_io_set(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d_c8, const MmIo *ios, const uint32_t *nvecs, uint32_t ng,
+                           uint32_t coeff_bytes);
 
 inline int buf_reserve(mfh_ctx *c, void *&buf, size_t &have, size_t bytes) {
   if (bytes <= have) return MFH_OK;

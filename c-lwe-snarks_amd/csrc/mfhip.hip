@@ -1034,7 +1034,7 @@ int mfh_timing_drain(mfh_ctx *c, const char *which, uint64_t *count, double *tot
   if (kind < 0) return MFH_EINVAL;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (c->side) HIP_TRY(c, hipStreamSynchronize(c->side));
-  uint64_t n = 0, rows = 0;
+  uint64_t n = 0, rows = 0, work = 0;
   double tot = 0;
   float last = -1.f;
   std::vector<mfh_ctx::Timed> keep;
@@ -1045,7 +1045,7 @@ int mfh_timing_drain(mfh_ctx *c, const char *which, uint64_t *count, double *tot
     if (!match) { keep.push_back(t); continue; }
     float ms = 0;
     if (hipEventElapsedTime(&ms, t.e0, t.e1) == hipSuccess) {
-      n++; tot += ms; rows += t.rows; last = ms;
+      n++; tot += ms; rows += t.rows; work += t.work; last = ms;
       if (!base) base = t.e0;
       float s0 = 0;
       if (hipEventElapsedTime(&s0, base, t.e0) == hipSuccess) spans.emplace_back(s0, s0 + ms);
@@ -1061,6 +1061,7 @@ int mfh_timing_drain(mfh_ctx *c, const char *which, uint64_t *count, double *tot
     hi = sp.second;
   }
   c->last_busy_ms = busy;
+  c->last_work_rows = work;
   for (auto &t : c->timed) {
     const bool match = t.kind == kind || (kind == 12 && (t.kind == 1 || t.kind == 2));
     if (!match) continue;
@@ -1076,6 +1077,7 @@ int mfh_timing_drain(mfh_ctx *c, const char *which, uint64_t *count, double *tot
 }
 
 double mfh_timing_busy_ms(const mfh_ctx *c) { return c ? c->last_busy_ms : -1.0; }
+uint64_t mfh_timing_work_rows(const mfh_ctx *c) { return c ? c->last_work_rows : 0; }
 
 float mfh_last_kernel_ms(mfh_ctx *c, const char *which) {
   float last = -1.f;

@@ -582,17 +582,26 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
     HIP_TRY(c, hipStreamWaitEvent(side_stream, c->ev_fork, 0));
     // ---- S rows with (w, h) -> (v_w, h) on the caller's stream; AS rows with (h, v) -> (hat_h, hat_v) on the side stream: every row
     // expanded once per group of G proofs
-    for (uint32_t g0 = s0; g0 < s0 + sg; g0 += G) {
-      const uint32_t g = std::min(G, s0 + sg - g0);
-      uint64_t *proofs = d_proofs + (size_t)g0 * 5 * ctl;
-      const size_t o = (size_t)(g0 - s0) * d;
-      const MmIo io_s = {{WALL + o, HALL + o}, g, {proofs + 3 * ctl, proofs}, g, pstride, nullptr, 0, SCZ + 256 * slot++};             // (w, h) -> (v_w, h)
-      const MmIo io_as = {{HALL + o, VALL + o}, g, {proofs + ctl, proofs + 2 * ctl}, g, pstride, nullptr, 0, SCZ + 256 * slot++};  // (h, v) -> (hat_h, hat_v)
-      rc = eval_rows_multi_io(c, 0, d, d_crs_c8, io_s, 2 * g, 4, 0);
+    // with the image registered one streaming launch serves NGL = 4 groups: the image is then read from HBM once per 124 proofs (2 and 8
+    // groups per launch measured 2 % and 1 % slower, 1 group 10 % slower)
+    constexpr uint32_t NGLMAX = 8;
+    const uint32_t NGL = c->mm_image ? c->batch_ngl : 1u;
+    for (uint32_t g0 = s0; g0 < s0 + sg; g0 += NGL * G) {
+      MmIo io_s[NGLMAX], io_as[NGLMAX];
+      uint32_t nv[NGLMAX], ng = 0;
+      for (uint32_t k = 0; k < NGL && g0 + k * G < s0 + sg; k++, ng++) {
+        const uint32_t gg = g0 + k * G, g = std::min(G, s0 + sg - gg);
+        uint64_t *proofs = d_proofs + (size_t)gg * 5 * ctl;
+        const size_t o = (size_t)(gg - s0) * d;
+        io_s[k] = MmIo{{WALL + o, HALL + o}, g, {proofs + 3 * ctl, proofs}, g, pstride, nullptr, 0, SCZ + 256 * slot++};             // (w, h) -> (v_w, h)
+        io_as[k] = MmIo{{HALL + o, VALL + o}, g, {proofs + ctl, proofs + 2 * ctl}, g, pstride, nullptr, 0, SCZ + 256 * slot++};  // (h, v) -> (hat_h, hat_v)
+        nv[k] = 2 * g;
+      }
+      rc = eval_rows_multi_io_set(c, 0, d, d_crs_c8, io_s, nv, ng, 4);
       if (rc) return rc;
       {
         OnSide side(c, side_stream);
-        rc = eval_rows_multi_io(c, ctr_ct * d, d, d_crs_c8 + (size_t)d * ctb, io_as, 2 * g, 4, 0);
+        rc = eval_rows_multi_io_set(c, ctr_ct * d, d, d_crs_c8 + (size_t)d * ctb, io_as, nv, ng, 4);
         if (rc) return rc;
       }
     }

@@ -260,6 +260,9 @@ float mfh_last_kernel_ms(mfh_ctx *ctx, const char *which); /* = last_ms of mfh_t
 /* Union of the [start, end) spans of the launches the last mfh_timing_drain matched, in ms: equals total_ms when the launches
  * ran one after the other, less when launches of two streams overlapped (mfh_prove_batch). */
 double mfh_timing_busy_ms(const mfh_ctx *ctx);
+/* rows x evaluations served by the launches the last mfh_timing_drain matched: a streaming launch of mfh_prove_batch serves 4 groups of
+ * coefficient vectors from one pass over its rows (= total_rows for every other kind) */
+uint64_t mfh_timing_work_rows(const mfh_ctx *ctx);
 
 #ifdef __cplusplus
 }
