@@ -21,7 +21,7 @@
 //   k_evalmm16<0>    256 digit columns (v_mfma_i32_16x16x64_i8, 2-coordinate column tiles): 31 proofs' vector pairs per expansion
 //   k_evalmm16<1>    expansion only: the rows written to HBM in MFMA A-fragment order (the resident image of the batch prover)
 //   k_mmstream       the same GEMM streamed from that image: no AES, HBM / matrix-core bound
-//   k_witness_mm     the witness pass of up to 256 statements as a GEMM of witness bits x SSP bytes (one read of the SSP)
+//   k_witness_mm     the witness pass of up to 128 statements as a GEMM of witness bits x SSP bytes (one read of the SSP)
 //   k_mm_digits / k_evalmm_finish, k_ssp_frag / k_witness_bits / k_witness_mm_finish: operand preparation and epilogues
 //
 // k_evalmm: workgroup = 1024 threads, one column tile of CT = 4 coordinates (352 byte positions = 11 MFMA row tiles) x one row chunk.
@@ -695,16 +695,12 @@ __global__ void k_ssp_frag(const uint32_t *__restrict__ ssp, uint32_t nrowsel, u
 }
 // grid = (d / 128, row chunks); block = 4 waves, one 32-coefficient tile each; MT = 1, 2 or 4 tiles of 32 statements (the SSP is read
 // once per 32 MT statements).  part[((chunk * 4 + w) * 32 MT + stmt) * d + k].
-// With ng > 1 groups of MT statement tiles (MTtot = ng MT tiles in bitfrag and part) the workgroups b and b + 8 -- back to back on one
-// XCD -- take the same coefficient tiles for consecutive groups: the second finds the SSP fragments in that XCD's L2, the SSP is read
-// from HBM once for all groups (as k_mmstream does with the CRS image).  grid.x = ng d / 128, d / 128 a multiple of 8.
 template <int MT>
 __global__ __launch_bounds__(256) void k_witness_mm(const v4i *__restrict__ sspfrag, const v4i *__restrict__ bitfrag, uint32_t nrowsel /* m - 1 */,
-                                                    uint32_t ksteps_per_chunk, uint32_t d, int *__restrict__ part, uint32_t ng, uint32_t MTtot) {
+                                                    uint32_t ksteps_per_chunk, uint32_t d, int *__restrict__ part) {
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t r32 = lane & 31, h = lane >> 5;
-  const uint32_t grp = ng > 1 ? (blockIdx.x >> 3) % ng : 0, cb = ng > 1 ? ((blockIdx.x >> 3) / ng) * 8 + (blockIdx.x & 7) : blockIdx.x;
-  const uint32_t kt = cb * 4 + wave, KT = d / 32;
+  const uint32_t kt = blockIdx.x * 4 + wave, KT = d / 32;
   const uint32_t k = kt * 32 + r32;
   const uint32_t K0 = blockIdx.y * ksteps_per_chunk, K1 = min((nrowsel + 31) / 32, K0 + ksteps_per_chunk);
   v16i acc[MT][4];
@@ -725,7 +721,7 @@ __global__ __launch_bounds__(256) void k_witness_mm(const v4i *__restrict__ sspf
 #pragma unroll
     for (int w = 0; w < 4; w++) bq[slot][w] = src[64 * w];
 #pragma unroll
-    for (int t = 0; t < MT; t++) aq[slot][t] = bitfrag[((uint64_t)K * MTtot + grp * MT + t) * 64 + lane];
+    for (int t = 0; t < MT; t++) aq[slot][t] = bitfrag[((uint64_t)K * MT + t) * 64 + lane];
   };
 #pragma unroll
   for (int i = 0; i < PF; i++) fetch(i, K0 + i);
@@ -747,8 +743,8 @@ __global__ __launch_bounds__(256) void k_witness_mm(const v4i *__restrict__ sspf
     for (int w = 0; w < 4; w++)
 #pragma unroll
       for (int e = 0; e < 16; e++) {
-        const uint32_t stmt = 32 * (grp * MT + t) + (e & 3) + 8 * (e >> 2) + 4 * h;
-        part[(((uint64_t)blockIdx.y * 4 + w) * (32 * MTtot) + stmt) * d + k] = acc[t][w][e];
+        const uint32_t stmt = 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h;
+        part[(((uint64_t)blockIdx.y * 4 + w) * (32 * MT) + stmt) * d + k] = acc[t][w][e];
       }
 }
 // bits of nstmt statements (packed, bits_stride bytes apart) -> A fragments: bitfrag[K][t][lane (stmt = 32 t + (l & 31), h)][e] = bit
@@ -1001,17 +997,12 @@ int mfh_crs_set_resident_mm(mfh_ctx *c, const uint8_t *d_image) {
   return MFH_OK;
 }
 
-// mfh_witness_poly for up to 256 statements in ONE read of the (dense) SSP, on the matrix cores: d_w = nstmt polynomials of d coefficients
+// mfh_witness_poly for up to 128 statements in ONE read of the (dense) SSP, on the matrix cores: d_w = nstmt polynomials of d coefficients
 int mfh_witness_poly_mm(mfh_ctx *c, const uint32_t *d_ssp, uint32_t nstmt, const uint8_t *h_bits, size_t bits_stride, const uint32_t *h_delta,
                         uint32_t *d_w) {
-  if (!c || !d_ssp || !h_bits || !h_delta || !d_w || nstmt == 0 || nstmt > 256) return MFH_EINVAL;
+  if (!c || !d_ssp || !h_bits || !h_delta || !d_w || nstmt == 0 || nstmt > 128) return MFH_EINVAL;
+  const uint32_t MT = nstmt > 64 ? 4 : nstmt > 32 ? 2 : 1;
   const uint32_t d = c->P.d, m = c->P.m;
-  if (nstmt > 128 && (d / 128) % 8) {  // the grouped launch wants d / 128 workgroups per group in multiples of 8: two passes instead
-    int rc = mfh_witness_poly_mm(c, d_ssp, 128, h_bits, bits_stride, h_delta, d_w);
-    return rc ? rc : mfh_witness_poly_mm(c, d_ssp, nstmt - 128, h_bits + (size_t)128 * bits_stride, bits_stride, h_delta + 128, d_w + (size_t)128 * d);
-  }
-  const uint32_t ng = nstmt > 128 ? 2 : 1;                          // groups of 4 statement tiles in one launch
-  const uint32_t MT = ng > 1 ? 8 : nstmt > 64 ? 4 : nstmt > 32 ? 2 : 1;  // statement tiles in bitfrag / part
   if (d % 128 || m < 2) { c->err = "mfh_witness_poly_mm: d must be a multiple of 128"; return MFH_EUNSUPPORTED; }
   for (uint32_t b = 0; b < nstmt; b++)
     if (h_delta[b] >= MFH_P) { c->err = "delta must be < p"; return MFH_EINVAL; }
@@ -1031,7 +1022,7 @@ int mfh_witness_poly_mm(mfh_ctx *c, const uint32_t *d_ssp, uint32_t nstmt, const
     HIP_TRY(c, hipGetLastError());
     c->ssp_frag_src = d_ssp;
   }
-  const size_t packed = (size_t)nstmt * bits_stride, head_b = ((packed + 8 + 256 * 8 + 255) & ~(size_t)255);
+  const size_t packed = (size_t)nstmt * bits_stride, head_b = ((packed + 8 + 128 * 8 + 255) & ~(size_t)255);
   const size_t frag_b = (size_t)ksteps * MT * 1024, part_b = (size_t)nchunks * 4 * 32 * MT * d * 4;
   int rc = wws_reserve(c, head_b + frag_b + part_b);
   if (rc) return rc;
@@ -1055,13 +1046,15 @@ int mfh_witness_poly_mm(mfh_ctx *c, const uint32_t *d_ssp, uint32_t nstmt, const
   int8_t *d_frag = (int8_t *)(dev + head_b);
   int *d_part = (int *)(dev + head_b + frag_b);
   hipLaunchKernelGGL(k_witness_bits, dim3((uint32_t)((frag_b + 255) / 256)), dim3(256), 0, c->stream, dev, bits_stride, nstmt, nrowsel, ksteps, MT, d_frag);
-  const dim3 wgrid(d / 128 * ng, (ksteps + kpc - 1) / kpc);
   if (MT == 1)
-    hipLaunchKernelGGL(k_witness_mm<1>, wgrid, dim3(256), 0, c->stream, (const v4i *)c->ssp_frag, (const v4i *)d_frag, nrowsel, kpc, d, d_part, 1u, 1u);
+    hipLaunchKernelGGL(k_witness_mm<1>, dim3(d / 128, (ksteps + kpc - 1) / kpc), dim3(256), 0, c->stream, (const v4i *)c->ssp_frag, (const v4i *)d_frag,
+                       nrowsel, kpc, d, d_part);
   else if (MT == 2)
-    hipLaunchKernelGGL(k_witness_mm<2>, wgrid, dim3(256), 0, c->stream, (const v4i *)c->ssp_frag, (const v4i *)d_frag, nrowsel, kpc, d, d_part, 1u, 2u);
+    hipLaunchKernelGGL(k_witness_mm<2>, dim3(d / 128, (ksteps + kpc - 1) / kpc), dim3(256), 0, c->stream, (const v4i *)c->ssp_frag, (const v4i *)d_frag,
+                       nrowsel, kpc, d, d_part);
   else
-    hipLaunchKernelGGL(k_witness_mm<4>, wgrid, dim3(256), 0, c->stream, (const v4i *)c->ssp_frag, (const v4i *)d_frag, nrowsel, kpc, d, d_part, ng, MT);
+    hipLaunchKernelGGL(k_witness_mm<4>, dim3(d / 128, (ksteps + kpc - 1) / kpc), dim3(256), 0, c->stream, (const v4i *)c->ssp_frag, (const v4i *)d_frag,
+                       nrowsel, kpc, d, d_part);
   hipLaunchKernelGGL(k_witness_mm_finish, dim3((d + 255) / 256, nstmt), dim3(256), 0, c->stream, d_part, (ksteps + kpc - 1) / kpc, d_ssp, d_cd, nstmt, 32 * MT,
                      d, d_w);
   HIP_TRY(c, hipGetLastError());

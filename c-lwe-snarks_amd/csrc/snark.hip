@@ -496,11 +496,11 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
     HIP_TRY(c, hipStreamWaitEvent(chain_stream, c->ev_chain, 0));
     OnStream chain(c, chain_stream);
     int rc = MFH_OK;
-    // dense SSP with d % 128 == 0: a GEMM on the matrix cores, one read of the SSP per 248 statements (two groups of 128 in one launch); otherwise the VALU form, read
+    // dense SSP with d % 128 == 0: a GEMM on the matrix cores, one read of the SSP per 124 statements; otherwise the VALU form, read
     // (or generated) once per 12 statements
     if (src.dense && d % 128 == 0) {
-      for (uint32_t b0 = 0; b0 < sg; b0 += 248) {
-        rc = mfh_witness_poly_mm(c, d_ssp, std::min(248u, sg - b0), h_witness_bits + (size_t)(s0 + b0) * bits_stride, bits_stride, h_delta + s0 + b0,
+      for (uint32_t b0 = 0; b0 < sg; b0 += 124) {
+        rc = mfh_witness_poly_mm(c, d_ssp, std::min(124u, sg - b0), h_witness_bits + (size_t)(s0 + b0) * bits_stride, bits_stride, h_delta + s0 + b0,
                                  WALL + (size_t)b0 * d);
         if (rc) return rc;
       }

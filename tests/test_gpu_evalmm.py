@@ -192,17 +192,15 @@ def test_batch_prover_from_the_matrix_core_crs_image(gpu_ctx_factory, oracle):
     assert [bool(x) for x in ok] == [b % 2 == 0 for b in range(nb)]
 
 
-@pytest.mark.parametrize("nstmt,d", [(1, 256), (7, 256), (32, 256), (33, 256), (64, 256), (65, 256), (124, 256), (128, 256), (129, 256), (256, 256),
-                                     (130, 1024), (248, 1024), (256, 1024)])
-def test_witness_pass_on_the_matrix_cores(gpu_ctx_factory, nstmt, d):
+@pytest.mark.parametrize("nstmt", [1, 7, 32, 33, 64, 65, 124, 128])
+def test_witness_pass_on_the_matrix_cores(gpu_ctx_factory, nstmt):
     """mfh_witness_poly_mm (bits x SSP bytes as a GEMM, one read of the SSP) and mfh_witness_poly_multi (VALU, 12 at a time) give
     mfh_witness_poly's polynomials, also for all-zero / all-one witnesses and edge SSP values (0, p - 1)."""
     import c_lwe_snarks_amd as mf
 
-    # more than 128 statements: two groups of statement tiles in ONE launch when d / 128 is a multiple of 8 (d = 1024), else two passes
-    p = mf.DEBUG if d == 256 else mf.Params(logq=736, d=d, m=64)
+    p = mf.DEBUG
     c = gpu_ctx_factory(p)
-    rng = np.random.default_rng(900 + nstmt + d)
+    rng = np.random.default_rng(900 + nstmt)
     ssp = rng.integers(0, ol.P, size=(p.m + 3) * p.d, dtype=np.uint64)
     ssp[: 3 * p.d: 2] = ol.P - 1
     ssp[1: 3 * p.d: 2] = 0
