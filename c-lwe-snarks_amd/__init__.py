@@ -86,7 +86,8 @@ EXPORTS = [
     "mfh_encrypt_rows", "mfh_decrypt", "mfh_ct_smudge", "mfh_ssp_upload", "mfh_witness_poly", "mfh_version",
     "mfh_workspace_bytes", "mfh_last_kernel_ms", "mfh_set_timing", "mfh_set_overlap", "mfh_eval_rows_multi", "mfh_prove_batch", "mfh_crs_mm_image_bytes", "mfh_crs_expand_mm", "mfh_crs_set_resident_mm", "mfh_witness_poly_multi", "mfh_witness_poly_mm", "mfh_poly_h_multi", "mfh_poly_mul", "mfh_poly_add", "mfh_poly_prepare_t",
     "mfh_ssp_prepare", "mfh_poly_h", "mfh_setup_messages", "mfh_setup", "mfh_prove",
-    "mfh_prove_partial", "mfh_prove_finish", "mfh_ct_to_lanes", "mfh_ct_from_lanes", "mfh_timing_drain", "mfh_timing_busy_ms", "mfh_timing_work_rows", "mfh_set_batch_image", "mfh_add_dotp",
+    "mfh_prove_partial", "mfh_prove_finish", "mfh_ct_to_lanes", "mfh_ct_from_lanes", "mfh_timing_drain", "mfh_timing_busy_ms", "mfh_timing_work_rows", "mfh_set_batch_image", "mfh_set_mm_chunk_rows", "mfh_add_dotp",
+    "mfh_crs_mm_share_bytes", "mfh_crs_expand_mm_share", "mfh_crs_set_resident_mm_share", "mfh_batch_chain", "mfh_prove_batch_partial", "mfh_prove_batch_finish",
     "mfh_resident_row_bytes", "mfh_crs_expand", "mfh_eval_rows_resident", "mfh_crs_set_resident",
     "mfh_witness_lanes", "mfh_witness_from_lanes", "mfh_prove_partial_w", "mfh_verify",
     "mfh_ssp_set_prg", "mfh_ssp_prg_make_t", "mfh_ssp_prg_fill",
@@ -168,6 +169,13 @@ def load_library():
         "mfh_timing_busy_ms": (ctypes.c_double, [vp]),
         "mfh_timing_work_rows": (u64, [vp]),
         "mfh_set_batch_image": (i32, [vp, i32]),
+        "mfh_set_mm_chunk_rows": (i32, [vp, u32]),
+        "mfh_crs_mm_share_bytes": (sz, [vp, u32, u32]),
+        "mfh_crs_expand_mm_share": (i32, [vp, vp, u32, u32, vp]),
+        "mfh_crs_set_resident_mm_share": (i32, [vp, vp, u32, u32]),
+        "mfh_batch_chain": (i32, [vp, vp, u32, ctypes.c_char_p, sz, vp, vp, vp, vp]),
+        "mfh_prove_batch_partial": (i32, [vp, vp, u32, u32, u32, ctypes.c_char_p, sz, vp, vp, vp, sz, vp]),
+        "mfh_prove_batch_finish": (i32, [vp, vp, u32, vp, ctypes.c_char_p, sz, ctypes.c_char_p, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export what the header declares
@@ -250,6 +258,10 @@ class Context:
     def set_batch_image(self, on=True):
         """prove_batch with more than 31 proofs: expand the CRS once per call into a transient image and stream it per group (default) or not"""
         self._chk(self.lib.mfh_set_batch_image(self._h, 1 if on else 0))
+
+    def set_mm_chunk_rows(self, rows=0):
+        """rows per row chunk of the matrix-core launches (<= 131071; 0 = default): smaller values force several chunks"""
+        self._chk(self.lib.mfh_set_mm_chunk_rows(self._h, int(rows)))
 
     def timing_drain(self, which):
         """(launch count, total ms, total rows) of the launches of kind `which` since the last drain"""
@@ -355,6 +367,12 @@ class Context:
         self._chk(self.lib.mfh_poly_mul(self._h, _ptr(a), la, _ptr(b), lb, _ptr(out)))
         return out
 
+    def poly_add(self, a, b, count):
+        """a + b over F_p, `count` coefficients (nmod_poly_add, src/snark.c:161)"""
+        out = self.empty(count * 4)
+        self._chk(self.lib.mfh_poly_add(self._h, _ptr(a), _ptr(b), count, _ptr(out)))
+        return out
+
     def ssp_prepare(self, d_ssp):
         """per-SSP precomputation for the division by t(x) (src/snark.c:169)"""
         self._chk(self.lib.mfh_ssp_prepare(self._h, _ptr(d_ssp)))
@@ -425,6 +443,55 @@ class Context:
         self._chk(self.lib.mfh_prove_batch(self._h, _ptr(d_crs), _ptr(d_ssp), nb, bits, stride, ctypes.cast(dl, ctypes.c_void_p), mags, maglen,
                                            signs, _ptr(out)))
         return out
+
+    # -- row-sharded batch prover (one process per GPU; dist.prove_batch_sharded drives the sequence) ----------------
+    def _pack_bits(self, witness_bits_list):
+        stride = (self.params.m + 6) // 8
+        return b"".join(bytes(w[:stride]).ljust(stride, b"\0") for w in witness_bits_list), stride
+
+    def crs_expand_mm_share(self, d_crs, rank, world, out=None):
+        """rank's row shares of the S | AS | BT+BV regions expanded in MFMA A-fragment order (45 GB per GPU for the 2^20-constraint CRS on 8)"""
+        out = self.empty(int(self.lib.mfh_crs_mm_share_bytes(self._h, rank, world))) if out is None else out
+        self._chk(self.lib.mfh_crs_expand_mm_share(self._h, _ptr(d_crs), rank, world, _ptr(out)))
+        return out
+
+    def set_resident_mm_share(self, image, rank, world):
+        self._resident_mm = image
+        self._chk(self.lib.mfh_crs_set_resident_mm_share(self._h, _ptr(image), rank, world))
+
+    def batch_chain(self, d_ssp, witness_bits_list, deltas, out=None):
+        """w | h | v of the statements (src/snark.c:141-169): int32 tensor [3][len][d] (the uint32 coefficients' bit patterns)"""
+        p = self.params
+        nb = len(witness_bits_list)
+        out = self.torch.empty((3, nb, p.d), dtype=self.torch.int32, device=self.device) if out is None else out
+        if nb == 0:
+            return out
+        bits, stride = self._pack_bits(witness_bits_list)
+        dl = (ctypes.c_uint32 * nb)(*[int(x) for x in deltas])
+        self._chk(self.lib.mfh_batch_chain(self._h, _ptr(d_ssp), nb, bits, stride, ctypes.cast(dl, ctypes.c_void_p), _ptr(out[0]), _ptr(out[1]), _ptr(out[2])))
+        return out
+
+    def prove_batch_partial(self, d_crs, rank, world, witness_bits_list, d_w, d_h, d_v, coef_stride, out=None):
+        """rank's row shares of the five ciphertexts of every statement: len x 5 partial ciphertexts (no delta ct_t term, un-smudged)"""
+        p = self.params
+        nb = len(witness_bits_list)
+        out = self.empty(nb * 5 * p.ct_limbs * 8) if out is None else out
+        bits, stride = self._pack_bits(witness_bits_list)
+        self._chk(self.lib.mfh_prove_batch_partial(self._h, _ptr(d_crs), rank, world, nb, bits, stride, _ptr(d_w), _ptr(d_h), _ptr(d_v), int(coef_stride),
+                                                   _ptr(out)))
+        return out
+
+    def prove_batch_finish(self, d_crs, deltas, smudge_mags, smudge_signs, d_proofs, maglen=80):
+        """b_w += delta ct_t, then the smudging, on len(deltas) summed proofs in place"""
+        nb = len(deltas)
+        if nb == 0:
+            return d_proofs
+        dl = (ctypes.c_uint32 * nb)(*[int(x) for x in deltas])
+        mags = b"".join(bytes(x) for x in smudge_mags)
+        signs = b"".join(bytes(x) for x in smudge_signs)
+        assert len(mags) == nb * 5 * maglen and len(signs) == nb * 5
+        self._chk(self.lib.mfh_prove_batch_finish(self._h, _ptr(d_crs), nb, ctypes.cast(dl, ctypes.c_void_p), mags, maglen, signs, _ptr(d_proofs)))
+        return d_proofs
 
     # -- row-sharded prover (one process per GPU; see dist.py) ------------------------------------------------
     def prove_partial(self, d_crs, d_ssp, witness_bits: bytes, delta, rank, world, out=None):

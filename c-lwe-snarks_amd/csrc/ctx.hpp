@@ -79,6 +79,7 @@ struct mfh_ctx {
   size_t prover_words = 0;
   std::vector<uint32_t> h_cw;
   const uint8_t *mm_image = nullptr;  // CRS expanded for the matrix-core path (mfh_crs_expand_mm): S | AS | BT+BV regions
+  uint32_t mm_rank = 0, mm_world = 1;  // whose row shares the image holds (mfh_crs_set_resident_mm_share)
   uint64_t mm_off[3] = {0, 0, 0}, mm_rows[3] = {0, 0, 0};
   size_t mm_base[3] = {0, 0, 0};
   void *ssp_frag = nullptr;  // the dense SSP in MFMA B-fragment order (evalmm.hip: witness pass of the batch prover); built lazily
@@ -91,6 +92,7 @@ struct mfh_ctx {
   void *batch_img = nullptr;
   size_t batch_img_bytes = 0;
   int batch_image = 1;
+  uint32_t mm_chunk_rows = 131071;  // rows per row chunk of the matrix-core launches (int32 accumulators: |A'C'| <= 2^14 per row)
   uint32_t batch_ngl = 4;  // groups of 31 proofs per streaming launch over the image (1..8)
   PinBuf pin_rows, pin_cw, pin_smudge;
   // generator-defined SSP (ssp_prg.hpp): used by every entry point that is handed d_ssp == NULL
@@ -176,6 +178,11 @@ struct MmIo {
   // optional: 256 int64 column sums the CALLER has zeroed (mfh_prove_batch clears the slots of all its launches with one memset);
   // nullptr: a slot of the workspace, cleared by a memset in front of the digit kernel
   int64_t *sc_zeroed;
+  // words between consecutive coefficient vectors of coef[0] / coef[1]; 0 = nrows (vectors back to back).  The row-sharded batch prover
+  // hands over slices [statement][w | h | v][rows of the share] as they come out of the all-to-all.
+  uint64_t cstride;
+  // bits: the launch covers rows [bits_row0, bits_row0 + nrows) of the BT+BV region (a rank's share): local row i <-> bit bits_row0 + i - 1
+  uint32_t bits_row0;
 };
 int eval_rows_multi_io(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d_c8, const MmIo &io, uint32_t nvec, uint32_t coeff_bytes, int accumulate);
 // ng of them over the same region in one streaming launch when the matrix-core image is registered (io.sc_zeroed required); else one by one

@@ -58,8 +58,12 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 // contiguous RT * N bytes.  Column n = ND v + w holds byte w of c_v[i] minus 128; column ND nvec is the ones column; every other
 // column, and every row >= nrows, is zero (such rows and columns then add nothing to G').
 __device__ __forceinline__ uint32_t coef_at(const MmIo &io, uint32_t v, uint32_t nrows, uint32_t i) {
-  if (io.bits) return i ? (io.bits[(uint64_t)v * io.bits_stride + ((i - 1) >> 3)] >> ((i - 1) & 7)) & 1u : 0u;
-  return (v < io.csplit ? io.coef[0] + (uint64_t)v * nrows : io.coef[1] + (uint64_t)(v - io.csplit) * nrows)[i];
+  if (io.bits) {
+    const uint32_t a = io.bits_row0 + i;
+    return a ? (io.bits[(uint64_t)v * io.bits_stride + ((a - 1) >> 3)] >> ((a - 1) & 7)) & 1u : 0u;
+  }
+  const uint64_t cs = io.cstride ? io.cstride : nrows;
+  return (v < io.csplit ? io.coef[0] + (uint64_t)v * cs : io.coef[1] + (uint64_t)(v - io.csplit) * cs)[i];
 }
 // block = the N digit columns (thread n) x RG consecutive groups of 16 rows: a thread builds whole 16-byte fragment elements (digit n of
 // 16 consecutive rows: its vector's 16 coefficients are one 64-byte line, shared by the ND byte columns of that vector) and adds its
@@ -77,13 +81,14 @@ __global__ void k_mm_digits(MmIo io, uint32_t nvec, uint32_t ND, uint32_t nrows,
     if (io.bits && v < nvec) {
       // packed witness bits: rows i0 .. i0 + 15 are bits i0 - 1 .. i0 + 14 (row 0 -> 0): one 24-bit window instead of 16 byte loads
       const uint8_t *bp = io.bits + (uint64_t)v * io.bits_stride;
-      const uint32_t first = i0 ? i0 - 1 : 0, b0 = first >> 3, nb = (nrows + 6) >> 3;  // bits 0 .. nrows - 2 exist
+      const uint32_t a0 = io.bits_row0 + i0;  // row of the BT+BV region (the launch may cover a rank's share of it)
+      const uint32_t first = a0 ? a0 - 1 : 0, b0 = first >> 3, nb = io.bits_stride;  // a statement's bit string is bits_stride bytes
       uint32_t win = 0;
 #pragma unroll
       for (int k = 0; k < 3; k++)
         if (b0 + k < nb) win |= (uint32_t)bp[b0 + k] << (8 * k);
       win >>= first & 7;
-      if (!i0) win <<= 1;  // row 0 is the BT row: coefficient 0
+      if (!a0) win <<= 1;  // row 0 is the BT row: coefficient 0
 #pragma unroll
       for (int e = 0; e < 16; e++) {
         const int dgt = i0 + e < nrows ? (int)((win >> e) & 1u) - 128 : 0;
@@ -836,7 +841,7 @@ int eval_rows_multi_io(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d_
   // accumulator holds 131 071 rows
   // (the 256-column kernels have 736 (1471) column tiles / 506 workgroups of row-tile pairs: one chunk already fills the CUs as evenly)
   uint32_t nchunks = (!wide && nrows >= 8 * rt) ? 2 : 1;
-  nchunks = std::max<uint32_t>(nchunks, ((uint32_t)nrows + 131070) / 131071);
+  nchunks = std::max<uint32_t>(nchunks, ((uint32_t)nrows + c->mm_chunk_rows - 1) / c->mm_chunk_rows);
   uint32_t rpc = ((uint32_t)nrows + nchunks - 1) / nchunks;
   rpc = (rpc + rt - 1) / rt * rt;
   nchunks = ((uint32_t)nrows + rpc - 1) / rpc;
@@ -894,7 +899,7 @@ int eval_rows_multi_io_set(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t
   const uint8_t *img_region = nullptr;
   for (int r = 0; r < 3 && c->mm_image; r++)
     if (c->mm_off[r] == off && c->mm_rows[r] == nrows && nrows) img_region = c->mm_image + c->mm_base[r];
-  bool ok = img_region && ng > 1 && c->have_seed && nrows <= 131071;
+  bool ok = img_region && ng > 1 && c->have_seed && nrows <= 0xffffffffu - 256;
   for (uint32_t g = 0; g < ng && ok; g++)
     ok = nvecs[g] && nvecs[g] * coeff_bytes + 1 <= 256 && ios[g].out[0] && ios[g].sc_zeroed && (ios[g].bits || ios[g].coef[0]);
   if (!ok) {
@@ -908,9 +913,13 @@ int eval_rows_multi_io_set(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t
   const uint32_t ND = coeff_bytes, n = c->P.n;
   const WideGeom wg = wide_geom(c);
   const uint32_t ntiles = (n + 1 + wg.ct - 1) / wg.ct, mtiles = ntiles * wg.mt;
-  const uint32_t rpc = ((uint32_t)nrows + RT2 - 1) / RT2 * RT2, rpad = rpc;  // one row chunk
+  // row chunks: an int32 accumulator holds 131 071 rows (a rank's share of a 2^20-row region is 131 072)
+  uint32_t nchunks = ((uint32_t)nrows + c->mm_chunk_rows - 1) / c->mm_chunk_rows;
+  const uint32_t rpc = (((uint32_t)nrows + nchunks - 1) / nchunks + RT2 - 1) / RT2 * RT2;
+  nchunks = ((uint32_t)nrows + rpc - 1) / rpc;
+  const uint32_t rpad = nchunks * rpc;
   const size_t cd_bytes = ((size_t)N2 * rpad + 255) & ~(size_t)255;
-  const size_t part_bytes = ((size_t)ntiles * wg.mbp * N2 * 4 + 255) & ~(size_t)255;
+  const size_t part_bytes = ((size_t)nchunks * ntiles * wg.mbp * N2 * 4 + 255) & ~(size_t)255;
   int rc = c->mm_ws_sel ? ws2_reserve(c, ng * (cd_bytes + part_bytes)) : ws_reserve(c, ng * (cd_bytes + part_bytes));
   if (rc) return rc;
   uint8_t *wsp = (uint8_t *)(c->mm_ws_sel ? c->ws2 : c->ws);
@@ -922,7 +931,7 @@ int eval_rows_multi_io_set(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t
   {
     Timer t(c, 8, nrows, (uint64_t)nrows * ng);
     const uint32_t KS = ((uint32_t)nrows + RT2 - 1) / RT2 * (RT2 / 64), tgs = (mtiles + 2 * SW - 1) / (2 * SW);
-    hipLaunchKernelGGL(k_mmstream, dim3((tgs + 7) / 8 * 8 * ng, 1), dim3(SW * 64), 0, c->stream, (const v4i *)img_region, mtiles, KS, (uint32_t)nrows, rpc,
+    hipLaunchKernelGGL(k_mmstream, dim3((tgs + 7) / 8 * 8 * ng, nchunks), dim3(SW * 64), 0, c->stream, (const v4i *)img_region, mtiles, KS, (uint32_t)nrows, rpc,
                        (const v4i *)cd, part, ng, (uint64_t)(cd_bytes / 16), (uint64_t)(part_bytes / 4));
   }
   HIP_TRY(c, hipGetLastError());
@@ -930,10 +939,10 @@ int eval_rows_multi_io_set(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t
     const dim3 fgrid(n + 1, (nvecs[g] + 63) / 64);
     int *pg = part + g * (part_bytes / 4);
     if (ND == 4)
-      hipLaunchKernelGGL(k_evalmm_finish<4>, fgrid, dim3(256), 0, c->stream, pg, ios[g].sc_zeroed, 1u, ntiles, (uint32_t)N2, nvecs[g], n, (uint32_t)nrows,
+      hipLaunchKernelGGL(k_evalmm_finish<4>, fgrid, dim3(256), 0, c->stream, pg, ios[g].sc_zeroed, nchunks, ntiles, (uint32_t)N2, nvecs[g], n, (uint32_t)nrows,
                          wg.ct, wg.mbp, wg.sby, wg.LL, ios[g], 0);
     else
-      hipLaunchKernelGGL(k_evalmm_finish<1>, fgrid, dim3(256), 0, c->stream, pg, ios[g].sc_zeroed, 1u, ntiles, (uint32_t)N2, nvecs[g], n, (uint32_t)nrows,
+      hipLaunchKernelGGL(k_evalmm_finish<1>, fgrid, dim3(256), 0, c->stream, pg, ios[g].sc_zeroed, nchunks, ntiles, (uint32_t)N2, nvecs[g], n, (uint32_t)nrows,
                          wg.ct, wg.mbp, wg.sby, wg.LL, ios[g], 0);
   }
   HIP_TRY(c, hipGetLastError());
@@ -948,54 +957,79 @@ static size_t mm_region_bytes(const mfh_ctx *c, uint64_t rows) {  // row tiles x
   const uint64_t mtiles = (uint64_t)((c->P.n + 1 + wg.ct - 1) / wg.ct) * wg.mt, ksteps = (rows + RT2 - 1) / RT2 * (RT2 / 64);
   return (size_t)(mtiles * ksteps * 1024);
 }
-size_t mfh_crs_mm_image_bytes(const mfh_ctx *c) {
-  if (!c) return 0;
-  return 2 * mm_region_bytes(c, c->P.d) + mm_region_bytes(c, c->P.m);
+// the three row ranges (absolute stream rows) of rank `rank`'s shares: S share | AS share | BT+BV share (the whole regions when world == 1)
+struct MmShare { uint64_t row0[3], rows[3]; };
+static MmShare mm_share(const mfh_ctx *c, uint32_t rank, uint32_t world) {
+  const uint64_t d = c->P.d, m = c->P.m;
+  const uint64_t loS = d * rank / world, cS = d * (rank + 1) / world - loS, lo = m * rank / world, cnt = m * (rank + 1) / world - lo;
+  return MmShare{{loS, d + loS, 2 * d + lo}, {cS, cS, cnt}};
 }
-// expands the S, AS and BT+BV regions of the compressed CRS into d_image (mfh_crs_mm_image_bytes bytes), in MFMA A-fragment order
-int mfh_crs_expand_mm(mfh_ctx *c, const uint8_t *d_crs_c8, uint8_t *d_image) {
-  if (!c || !d_crs_c8 || !d_image) return MFH_EINVAL;
+size_t mfh_crs_mm_share_bytes(const mfh_ctx *c, uint32_t rank, uint32_t world) {
+  if (!c || !world || rank >= world) return 0;
+  const MmShare sh = mm_share(c, rank, world);
+  return mm_region_bytes(c, sh.rows[0]) + mm_region_bytes(c, sh.rows[1]) + mm_region_bytes(c, sh.rows[2]);
+}
+size_t mfh_crs_mm_image_bytes(const mfh_ctx *c) { return mfh_crs_mm_share_bytes(c, 0, 1); }
+// expands rank `rank`'s shares of the S, AS and BT+BV regions of the compressed CRS into d_image (mfh_crs_mm_share_bytes bytes), in MFMA
+// A-fragment order: every share is a region of its own (stream offset and row count), k-steps counted from its first row
+int mfh_crs_expand_mm_share(mfh_ctx *c, const uint8_t *d_crs_c8, uint32_t rank, uint32_t world, uint8_t *d_image) {
+  if (!c || !d_crs_c8 || !d_image || !world || rank >= world) return MFH_EINVAL;
   if (!c->have_seed) { c->err = "mfh_set_seed has not been called"; return MFH_EINVAL; }
   const WideGeom wg = wide_geom(c);
-  const uint32_t n = c->P.n, d = c->P.d, m = c->P.m;
+  const uint32_t n = c->P.n;
   if (((uint64_t)n * wg.vby) & 7) { c->err = "mfh_crs_expand_mm: the row length must be a multiple of 8"; return MFH_EUNSUPPORTED; }
   HIP_TRY(c, hipSetDevice(c->device));
   const uint64_t ctr_ct = (uint64_t)wg.vby * n;
-  const uint64_t offs[3] = {0, ctr_ct * d, ctr_ct * 2 * d};
-  const uint64_t rows[3] = {d, d, m};
-  const size_t c8off[3] = {0, (size_t)d * wg.vby, (size_t)2 * d * wg.vby};
+  const MmShare sh = mm_share(c, rank, world);
   AesKey keyx = c->key;
   for (int i = 56; i < 60; i++) keyx.rk[i] ^= 0x80808080u;
   const uint32_t ntiles = (n + 1 + wg.ct - 1) / wg.ct;
   size_t base = 0;
   for (int r = 0; r < 3; r++) {
-    const uint32_t units = (uint32_t)((rows[r] + RT2 - 1) / RT2);
+    if (!sh.rows[r]) continue;
+    const uint32_t units = (uint32_t)((sh.rows[r] + RT2 - 1) / RT2);
     const uint32_t nchunks = std::max(1u, std::min(units, 4u));
     const uint32_t rpc = (units + nchunks - 1) / nchunks * RT2;
-    Timer t(c, 9, rows[r]);
-    const dim3 grid(ntiles, (uint32_t)((rows[r] + rpc - 1) / rpc));
+    Timer t(c, 9, sh.rows[r]);
+    const dim3 grid(ntiles, (uint32_t)((sh.rows[r] + rpc - 1) / rpc));
+    const uint8_t *c8 = d_crs_c8 + (size_t)sh.row0[r] * wg.vby;
     if (c->P.logq == 736)
-      hipLaunchKernelGGL((k_evalmm16<1, 736>), grid, dim3(1024), 0, c->stream, keyx, c->d_t0, offs[r], n, (uint32_t)rows[r], rpc, d_crs_c8 + c8off[r],
+      hipLaunchKernelGGL((k_evalmm16<1, 736>), grid, dim3(1024), 0, c->stream, keyx, c->d_t0, ctr_ct * sh.row0[r], n, (uint32_t)sh.rows[r], rpc, c8,
                          (const int8_t *)nullptr, (int *)nullptr, d_image + base);
     else
-      hipLaunchKernelGGL((k_evalmm16<1, 1472>), grid, dim3(1024), 0, c->stream, keyx, c->d_t0, offs[r], n, (uint32_t)rows[r], rpc, d_crs_c8 + c8off[r],
+      hipLaunchKernelGGL((k_evalmm16<1, 1472>), grid, dim3(1024), 0, c->stream, keyx, c->d_t0, ctr_ct * sh.row0[r], n, (uint32_t)sh.rows[r], rpc, c8,
                          (const int8_t *)nullptr, (int *)nullptr, d_image + base);
-    base += mm_region_bytes(c, rows[r]);
+    base += mm_region_bytes(c, sh.rows[r]);
   }
   HIP_TRY(c, hipGetLastError());
   return MFH_OK;
 }
-// registers (or, with NULL, clears) the image: mfh_eval_rows_multi / mfh_prove_batch then stream the three CRS regions from it
-int mfh_crs_set_resident_mm(mfh_ctx *c, const uint8_t *d_image) {
-  if (!c) return MFH_EINVAL;
-  c->mm_image = d_image;
-  const uint32_t n = c->P.n, d = c->P.d, m = c->P.m;
-  const uint64_t ctr_ct = (uint64_t)wide_geom(c).vby * n;
-  c->mm_off[0] = 0; c->mm_off[1] = ctr_ct * d; c->mm_off[2] = ctr_ct * 2 * d;
-  c->mm_rows[0] = d; c->mm_rows[1] = d; c->mm_rows[2] = m;
-  c->mm_base[0] = 0; c->mm_base[1] = mm_region_bytes(c, d); c->mm_base[2] = 2 * mm_region_bytes(c, d);
+int mfh_crs_expand_mm(mfh_ctx *c, const uint8_t *d_crs_c8, uint8_t *d_image) { return mfh_crs_expand_mm_share(c, d_crs_c8, 0, 1, d_image); }
+// rows per row chunk of the matrix-core launches: an int32 accumulator holds at most 131 071 rows (the default); smaller values split
+// a region into more chunks (tuning / tests).  0 restores the default.
+int mfh_set_mm_chunk_rows(mfh_ctx *c, uint32_t rows) {
+  if (!c || rows > 131071) return MFH_EINVAL;
+  c->mm_chunk_rows = rows ? rows : 131071;
   return MFH_OK;
 }
+// registers (or, with NULL, clears) the image: mfh_eval_rows_multi / mfh_prove_batch* then stream the three row ranges it holds from it
+int mfh_crs_set_resident_mm_share(mfh_ctx *c, const uint8_t *d_image, uint32_t rank, uint32_t world) {
+  if (!c || !world || rank >= world) return MFH_EINVAL;
+  c->mm_image = d_image;
+  c->mm_rank = rank;
+  c->mm_world = world;
+  const uint64_t ctr_ct = (uint64_t)wide_geom(c).vby * c->P.n;
+  const MmShare sh = mm_share(c, rank, world);
+  size_t base = 0;
+  for (int r = 0; r < 3; r++) {
+    c->mm_off[r] = ctr_ct * sh.row0[r];
+    c->mm_rows[r] = sh.rows[r];
+    c->mm_base[r] = base;
+    base += mm_region_bytes(c, sh.rows[r]);
+  }
+  return MFH_OK;
+}
+int mfh_crs_set_resident_mm(mfh_ctx *c, const uint8_t *d_image) { return mfh_crs_set_resident_mm_share(c, d_image, 0, 1); }
 
 // mfh_witness_poly for up to 128 statements in ONE read of the (dense) SSP, on the matrix cores: d_w = nstmt polynomials of d coefficients
 int mfh_witness_poly_mm(mfh_ctx *c, const uint32_t *d_ssp, uint32_t nstmt, const uint8_t *h_bits, size_t bits_stride, const uint32_t *h_delta,

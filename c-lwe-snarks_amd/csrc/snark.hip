@@ -421,48 +421,69 @@ int mfh_prove(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, const 
   return mfh_prove_finish(c, d_proof, h_smudge_mag, maglen, h_smudge_sign);
 }
 
-// prover() for a batch of statements under one CRS and SSP.  The S and AS regions are expanded ONCE per group of up to 31 proofs and
-// the BT+BV region once per up to 248 (b_w's coefficients are witness bits: one byte-digit column per proof), the multiply-accumulate of
-// all their coefficient vectors runs on the matrix cores (mfh_eval_rows_multi, evalmm.hip); the witness pass reads the SSP once per 62
-// statements (as a GEMM of the witness bits with the SSP bytes on the matrix cores); the polynomial step and the smudging stay per proof.  Proof b is bit-identical to mfh_prove with the same inputs.
-int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, uint32_t nproofs, const uint8_t *h_witness_bits,
-                    size_t bits_stride, const uint32_t *h_delta, const uint8_t *h_smudge_mag, size_t maglen, const uint8_t *h_smudge_sign,
-                    uint64_t *d_proofs) {
-  if (!c || !d_crs_c8 || !h_witness_bits || !h_delta || !h_smudge_mag || !h_smudge_sign || !d_proofs) return MFH_EINVAL;
-  if (c->resident_rows) { c->err = "mfh_prove_batch regenerates the keystream: clear the resident CRS image first"; return MFH_EUNSUPPORTED; }
-  mf::SspSrc src;
-  {
-    int rc0 = ssp_src(c, d_ssp, src);
-    if (rc0) return rc0;
-  }
+// ---- prover() for a batch of statements under one CRS and SSP ---------------------------------------------------------------------
+// The S and AS regions are expanded ONCE per group of up to 31 proofs and the BT+BV region once per up to 248 (b_w's coefficients are
+// witness bits: one byte-digit column per proof), the multiply-accumulate of all their coefficient vectors runs on the matrix cores
+// (eval_rows_multi_io*, evalmm.hip); the witness pass reads the SSP once per 124 statements (a GEMM of the witness bits with the SSP
+// bytes on the matrix cores); the polynomial step and the smudging stay per proof.  Proof b is bit-identical to mfh_prove with the
+// same inputs.  Three building blocks, shared by the single-GPU call (mfh_prove_batch) and the row-sharded multi-GPU sequence
+// (mfh_batch_chain -> exchange -> mfh_prove_batch_partial -> lane reduction -> mfh_prove_batch_finish):
+//   batch_chain_launch      w = delta t + sum_bits v_i, v = w + v_0, h = (v^2 - 1) / t for a slab of statements   (src/snark.c:141-169)
+//   batch_rows_supergroup   b_w's BT+BV rows and the S / AS rows of up to 248 statements, restricted to a rank's row shares   (:143-174)
+//   batch_smudge            ct_smudge x 5 per proof in two launches                                               (:185-189)
+}  // extern "C"
+
+namespace {
+
+constexpr uint32_t BG = 31;    // proofs per S / AS expansion: 62 coefficient vectors x 4 bytes + the ones column = 249 of 256 digit columns
+constexpr uint32_t BSG = 248;  // proofs per BT+BV expansion: one byte column each + the ones column = 249 of 256 digit columns
+
+struct OnStream {  // helpers launch on c->stream
+  mfh_ctx *c;
+  hipStream_t keep;
+  OnStream(mfh_ctx *c_, hipStream_t s) : c(c_), keep(c_->stream) { c->stream = s; }
+  ~OnStream() { c->stream = keep; }
+};
+struct OnSide {  // eval_rows_multi_io* launch on c->stream with the workspace c->mm_ws_sel selects
+  mfh_ctx *c;
+  hipStream_t keep;
+  OnSide(mfh_ctx *c_, hipStream_t s) : c(c_), keep(c_->stream) { c->stream = s; c->mm_ws_sel = 1; }
+  ~OnSide() { c->stream = keep; c->mm_ws_sel = 0; }
+};
+
+// scratch of a batch call: [2 x (w | h | v) of a super-group] | CW (packed witness bits + deltas of a super-group) | ONE | CT_T | the
+// launches' column-sum slots (256 int64 each)
+struct BatchScratch {
+  uint32_t *WHV;
+  uint8_t *CW;
+  uint32_t *ONE;
+  uint64_t *CT_T;
+  int64_t *SCZ;
+  size_t nslots;
+};
+int batch_scratch(mfh_ctx *c, uint32_t nproofs, bool whv, BatchScratch &B) {
   const uint32_t d = c->P.d, m = c->P.m, n = c->P.n;
-  if (bits_stride < (m + 6) / 8) { c->err = "bits_stride shorter than the m - 1 witness bits"; return MFH_EINVAL; }
-  for (uint32_t b = 0; b < nproofs; b++)
-    if (h_delta[b] >= P32) { c->err = "delta must be < p"; return MFH_EINVAL; }
-  const uint32_t ctb = c->P.logq / 8;
   const size_t ctl = (size_t)(n + 1) * ((c->P.logq + 63) / 64);
-  const uint64_t ctr_ct = (uint64_t)ctb * n;
-  constexpr uint32_t G = 31;    // proofs per S / AS expansion: 62 coefficient vectors x 4 bytes + the ones column = 249 of 256 digit columns
-  constexpr uint32_t SG = 248;  // proofs per BT+BV expansion: one byte column each + the ones column = 249 of 256 digit columns
-  HIP_TRY(c, hipSetDevice(c->device));
-  // scratch: 2 x (WALL | HALL | VALL) (the w, h, v polynomials of a super-group, SG x d each), CW (SG x m), ONE, CT_T (1 ciphertext).  The
-  // multi-vector launches read their coefficient vectors where the polynomial step left them and write the proof structs in place (MmIo).
-  const size_t nsg = ((size_t)nproofs + SG - 1) / SG, nslots = nsg * (1 + 2 * ((SG + G - 1) / G));  // multi-vector launches of the call
-  const size_t words = (size_t)6 * SG * d + (size_t)SG * m + 64, need = words * 4 + ctl * 8 + nslots * 2048;
+  const size_t nsg = ((size_t)nproofs + BSG - 1) / BSG;
+  B.nslots = nsg * (1 + 2 * ((BSG + BG - 1) / BG));  // multi-vector launches of the call
+  const size_t whv_b = whv ? (size_t)6 * BSG * d * 4 : 0;
+  const size_t cw_b = (((size_t)BSG * ((m + 6) / 8) + 3) & ~(size_t)3) + (size_t)BSG * 4;
+  const size_t cw_pad = (cw_b + 255) & ~(size_t)255;
+  const size_t need = whv_b + cw_pad + 256 + ctl * 8 + B.nslots * 2048;
   if (c->batch_bytes < need) {
     if (c->d_batch) { hipDeviceSynchronize(); hipFree(c->d_batch); c->d_batch = nullptr; c->batch_bytes = 0; }
     HIP_TRY(c, hipMalloc(&c->d_batch, need));
     c->batch_bytes = need;
   }
-  // w | h | v twice: the chain (witness pass + polynomial step) of super-group k + 1 is queued while super-group k is still smudged
-  uint32_t *const WHV = (uint32_t *)c->d_batch;
-  uint32_t *const CW = WHV + (size_t)6 * SG * d, *const ONE = CW + (size_t)SG * m;
-  uint64_t *const CT_T = (uint64_t *)((uint8_t *)c->d_batch + words * 4);
-  int64_t *const SCZ = (int64_t *)((uint8_t *)c->d_batch + words * 4 + ctl * 8);  // the launches' column-sum slots (256 int64 each)
-  size_t slot = 0;
-  HIP_TRY(c, hipMemsetAsync(SCZ, 0, nslots * 2048, c->stream));
-  // Two streams: the S-region launches of the groups run on the caller's stream, the AS-region launches on the side stream, so that the
-  // last, partly filled round of workgroups of one launch (736 workgroups on 256 CUs) is filled by the next launch's first ones.
+  uint8_t *base = (uint8_t *)c->d_batch;
+  B.WHV = (uint32_t *)base;
+  B.CW = base + whv_b;
+  B.ONE = (uint32_t *)(base + whv_b + cw_pad);
+  B.CT_T = (uint64_t *)(base + whv_b + cw_pad + 256);
+  B.SCZ = (int64_t *)(base + whv_b + cw_pad + 256 + ctl * 8);
+  return MFH_OK;
+}
+int batch_streams(mfh_ctx *c) {
   if (!c->side) {
     HIP_TRY(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -473,165 +494,329 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_chain, hipEventDisableTiming));
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_chain_done, hipEventDisableTiming));
   }
-  hipStream_t const main_stream = c->stream, side_stream = c->side, chain_stream = c->side2;
-  struct OnStream {  // the witness pass and the polynomial step launch on c->stream and have their own scratch (wws, poly buffers)
-    mfh_ctx *c;
-    hipStream_t keep;
-    OnStream(mfh_ctx *c_, hipStream_t s) : c(c_), keep(c_->stream) { c->stream = s; }
-    ~OnStream() { c->stream = keep; }
-  };
-  struct OnSide {  // mfh_eval_rows_multi launches on c->stream with the workspace c->mm_ws_sel selects
-    mfh_ctx *c;
-    hipStream_t keep;
-    OnSide(mfh_ctx *c_, hipStream_t s) : c(c_), keep(c_->stream) { c->stream = s; c->mm_ws_sel = 1; }
-    ~OnSide() { c->stream = keep; c->mm_ws_sel = 0; }
-  };
-  // The chain of a super-group -- w = delta t + sum_bits v_i (src/snark.c:141,147-155), v = w + v_0, h = (v^2 - 1) / t
-  // (src/snark.c:161-169) -- on its own stream: the first one runs beside the CRS expansion, the chain of super-group k + 1 beside the
-  // smudging of super-group k and its own b_w rows.  The witness pass and the polynomial step have their own scratch (wws, the poly buffers).
+  return MFH_OK;
+}
+
+// The chain of sg <= 248 statements on c->stream: W = delta t + sum_bits v_i (src/snark.c:141,147-155), V = W + v_0, H = (V^2 - 1) / t
+// (src/snark.c:161-169); W, H, V are sg x d coefficients each.  The witness pass and the polynomial step have their own scratch (wws,
+// the poly buffers).
+int batch_chain_launch(mfh_ctx *c, const mf::SspSrc &src, const uint32_t *d_ssp, uint32_t sg, const uint8_t *h_bits, size_t bits_stride,
+                       const uint32_t *h_delta, uint32_t *W, uint32_t *H, uint32_t *V) {
+  const uint32_t d = c->P.d;
+  int rc = MFH_OK;
+  // dense SSP with d % 128 == 0: a GEMM on the matrix cores, one read of the SSP per 124 statements; otherwise the VALU form, read
+  // (or generated) once per 12 statements
+  if (src.dense && d % 128 == 0) {
+    for (uint32_t b0 = 0; b0 < sg; b0 += 124) {
+      rc = mfh_witness_poly_mm(c, d_ssp, std::min(124u, sg - b0), h_bits + (size_t)b0 * bits_stride, bits_stride, h_delta + b0, W + (size_t)b0 * d);
+      if (rc) return rc;
+    }
+  } else {
+    for (uint32_t b0 = 0; b0 < sg; b0 += 12) {
+      rc = mfh_witness_poly_multi(c, d_ssp, std::min(12u, sg - b0), h_bits + (size_t)b0 * bits_stride, bits_stride, h_delta + b0, W + (size_t)b0 * d);
+      if (rc) return rc;
+    }
+  }
+  hipLaunchKernelGGL(k_add_slot_multi, dim3((d + 255) / 256, sg), dim3(256), 0, c->stream, W, src, 1u, d, V);
+  HIP_TRY(c, hipGetLastError());
+  return mfh_poly_h_multi(c, V, H, sg);  // one set of launches, sg times the work each
+}
+
+// where the coefficient vectors of a super-group's statements are: statement b's w / h / v restricted to the S / AS rows of the share at
+// w / h / v + b * stride (mfh_prove_batch: the whole polynomials where the chain left them, stride d)
+struct BatchCoef {
+  const uint32_t *w, *h, *v;
+  uint64_t stride;
+};
+
+// The row work of one super-group of sg <= 248 statements over rank `rank`'s contiguous row shares (the whole regions when world == 1):
+//   b_w = [delta ct_t +] sum_{bit} ct_{v_i} over the share of the m BT+BV rows (src/snark.c:143-155), the bits of all sg statements as
+//   byte coefficients; S rows with (w, h) -> (v_w, h) on the caller's stream and AS rows with (h, v) -> (hat_h, hat_v) on the side
+//   stream, every row expanded (or streamed from the image) once per group of 31 proofs (src/snark.c:157-174).
+// sproofs: the sg proof structs (5 ciphertexts each, h | hat_h | hat_v | v_w | b_w).  h_delta == nullptr: no delta ct_t term (a partial
+// proof: the term is added once, after the ranks' shares have been summed).  wait_ev: awaited before the S / AS launches (the chain).
+int batch_rows_supergroup(mfh_ctx *c, const uint8_t *d_crs_c8, uint32_t rank, uint32_t world, uint32_t sg, const uint8_t *h_bits,
+                          size_t bits_stride, const BatchCoef &co, uint64_t *sproofs, const BatchScratch &B, size_t &slot,
+                          const uint32_t *h_delta, hipEvent_t wait_ev) {
+  const uint32_t d = c->P.d, m = c->P.m, n = c->P.n;
+  const uint32_t ctb = c->P.logq / 8;
+  const size_t ctl = (size_t)(n + 1) * ((c->P.logq + 63) / 64);
+  const uint64_t ctr_ct = (uint64_t)ctb * n;
+  const uint64_t pstride = 5 * ctl;  // component `slot` of consecutive proofs (struct order h | hat_h | hat_v | v_w | b_w)
+  hipStream_t const main_stream = c->stream, side_stream = c->side;
+  const uint32_t lo = (uint32_t)((uint64_t)m * rank / world), cnt = (uint32_t)((uint64_t)m * (rank + 1) / world) - lo;
+  const uint32_t loS = (uint32_t)((uint64_t)d * rank / world), cS = (uint32_t)((uint64_t)d * (rank + 1) / world) - loS;
+  int rc = MFH_OK;
+  // ---- b_w: the packed bits travel as they are (2.7 KB per statement at the default size; the digit kernel unpacks them), the deltas
+  // behind them, through one pinned staging buffer and one copy
+  const uint32_t bstride = (m + 6) / 8;  // the m - 1 bits of a statement, repacked densely
+  const size_t packed = ((size_t)sg * bstride + 3) & ~(size_t)3, staged = packed + (h_delta ? (size_t)sg * 4 : 0);
+  uint8_t *h_cw = (uint8_t *)pin_acquire(c, c->pin_cw, staged);
+  if (!h_cw) return MFH_ENOMEM;
+  for (uint32_t b = 0; b < sg; b++) memcpy(h_cw + (size_t)b * bstride, h_bits + (size_t)b * bits_stride, bstride);
+  if (h_delta) memcpy(h_cw + packed, h_delta, (size_t)sg * 4);
+  HIP_TRY(c, hipMemcpyAsync(B.CW, h_cw, staged, hipMemcpyHostToDevice, c->stream));
+  pin_release(c, c->pin_cw);
+  MmIo io_bw = {{nullptr, nullptr}, sg, {sproofs + 4 * ctl, nullptr}, sg, pstride, (const uint8_t *)B.CW, bstride, B.SCZ + 256 * slot++};
+  io_bw.bits_row0 = lo;
+  rc = eval_rows_multi_io(c, ctr_ct * ((uint64_t)2 * d + lo), cnt, d_crs_c8 + ((size_t)2 * d + lo) * ctb, io_bw, sg, 1, 0);
+  if (rc) return rc;
+  if (h_delta) {  // + delta_b ct_t for the sg proofs in one launch
+    hipLaunchKernelGGL(k_bw_add_delta_ct, dim3((n + 1 + 255) / 256, sg), dim3(256), 0, c->stream, sproofs, B.CT_T, (const uint32_t *)(B.CW + packed), n + 1,
+                       (c->P.logq + 63) / 64, 2 * (c->P.logq / 64));
+    HIP_TRY(c, hipGetLastError());
+  }
+  if (wait_ev) HIP_TRY(c, hipStreamWaitEvent(main_stream, wait_ev, 0));
+  HIP_TRY(c, hipEventRecord(c->ev_fork, main_stream));
+  HIP_TRY(c, hipStreamWaitEvent(side_stream, c->ev_fork, 0));
+  // with the image registered one streaming launch serves NGL = 4 groups: the image is then read from HBM once per 124 proofs (2 and 8
+  // groups per launch measured 2 % and 1 % slower, 1 group 10 % slower)
+  constexpr uint32_t NGLMAX = 8;
+  const uint32_t NGL = c->mm_image ? c->batch_ngl : 1u;
+  for (uint32_t g0 = 0; g0 < sg; g0 += NGL * BG) {
+    MmIo io_s[NGLMAX], io_as[NGLMAX];
+    uint32_t nv[NGLMAX], ng = 0;
+    for (uint32_t k = 0; k < NGL && g0 + k * BG < sg; k++, ng++) {
+      const uint32_t gg = g0 + k * BG, g = std::min(BG, sg - gg);
+      uint64_t *proofs = sproofs + (size_t)gg * 5 * ctl;
+      const uint64_t o = (uint64_t)gg * co.stride;
+      io_s[k] = MmIo{{co.w + o, co.h + o}, g, {proofs + 3 * ctl, proofs}, g, pstride, nullptr, 0, B.SCZ + 256 * slot++, co.stride, 0};             // (w, h) -> (v_w, h)
+      io_as[k] = MmIo{{co.h + o, co.v + o}, g, {proofs + ctl, proofs + 2 * ctl}, g, pstride, nullptr, 0, B.SCZ + 256 * slot++, co.stride, 0};  // (h, v) -> (hat_h, hat_v)
+      nv[k] = 2 * g;
+    }
+    rc = eval_rows_multi_io_set(c, ctr_ct * loS, cS, d_crs_c8 + (size_t)loS * ctb, io_s, nv, ng, 4);
+    if (rc) return rc;
+    {
+      OnSide side(c, side_stream);
+      rc = eval_rows_multi_io_set(c, ctr_ct * ((uint64_t)d + loS), cS, d_crs_c8 + ((size_t)d + loS) * ctb, io_as, nv, ng, 4);
+      if (rc) return rc;
+    }
+  }
+  HIP_TRY(c, hipEventRecord(c->ev_join, side_stream));
+  HIP_TRY(c, hipStreamWaitEvent(main_stream, c->ev_join, 0));
+  return MFH_OK;
+}
+
+// smudging of sg proofs in two launches: h, hat_h, hat_v, v_w with draws 0..3, then v_w AGAIN with draw 4; b_w never
+// (src/snark.c:185-189).  A zero magnitude leaves a ciphertext unchanged.
+int batch_smudge(mfh_ctx *c, uint64_t *sproofs, uint32_t sg, const uint8_t *h_smudge_mag, size_t maglen, const uint8_t *h_smudge_sign) {
+  std::vector<uint8_t> mags((size_t)sg * 5 * maglen), signs((size_t)sg * 5);
+  for (int pass = 0; pass < 2; pass++) {
+    std::fill(mags.begin(), mags.end(), 0);
+    std::fill(signs.begin(), signs.end(), 0);
+    for (uint32_t b = 0; b < sg; b++) {
+      const uint8_t *pm = h_smudge_mag + (size_t)b * 5 * maglen, *ps = h_smudge_sign + (size_t)b * 5;
+      if (pass == 0) {
+        memcpy(&mags[(size_t)b * 5 * maglen], pm, 4 * maglen);
+        memcpy(&signs[(size_t)b * 5], ps, 4);
+      } else {
+        memcpy(&mags[((size_t)b * 5 + 3) * maglen], pm + 4 * maglen, maglen);
+        signs[(size_t)b * 5 + 3] = ps[4];
+      }
+    }
+    int rc = mfh_ct_smudge(c, sproofs, (size_t)sg * 5, mags.data(), maglen, signs.data());
+    if (rc) return rc;
+  }
+  return MFH_OK;
+}
+
+// ct_t = the BT row as a ciphertext (eval_poly of one row with coefficient 1): b_w's delta * ct_t term (src/snark.c:143-145)
+int batch_ct_t(mfh_ctx *c, const uint8_t *d_crs_c8, const BatchScratch &B) {
+  const uint32_t d = c->P.d, ctb = c->P.logq / 8;
+  HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)B.ONE, 1, 1, c->stream));
+  return mfh_eval_rows(c, (uint64_t)ctb * c->P.n * 2 * d, 1, d_crs_c8 + (size_t)2 * d * ctb, B.ONE, nullptr, B.CT_T, nullptr, 0);
+}
+
+// More than one group and no image registered: expand this rank's row shares of the CRS once for the whole call into a transient image in
+// MFMA A-fragment order (scratch kept by the context) and stream it for every group, instead of running AES per group.
+struct ImageGuard {
+  mfh_ctx *c;
+  bool on;
+  ~ImageGuard() { if (on) mfh_crs_set_resident_mm(c, nullptr); }
+};
+int batch_transient_image(mfh_ctx *c, const uint8_t *d_crs_c8, uint32_t nproofs, uint32_t rank, uint32_t world, ImageGuard &guard) {
+  const uint32_t ctb = c->P.logq / 8;
+  if (c->mm_image || !c->batch_image || nproofs <= BG || (((uint64_t)c->P.n * ctb) & 7)) return MFH_OK;
+  const size_t ib = mfh_crs_mm_share_bytes(c, rank, world);
+  if (c->batch_img_bytes < ib) {
+    if (c->batch_img) { hipDeviceSynchronize(); hipFree(c->batch_img); c->batch_img = nullptr; c->batch_img_bytes = 0; }
+    size_t mem_free = 0, mem_total = 0;
+    if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) mem_free = 0;
+    // no room (the rest of the call and the caller need memory too): the groups regenerate the keystream
+    if (ib <= mem_free / 4 * 3 && hipMalloc(&c->batch_img, ib) == hipSuccess) c->batch_img_bytes = ib;
+    else { c->batch_img = nullptr; (void)hipGetLastError(); }
+  }
+  if (!c->batch_img) return MFH_OK;
+  int rc = mfh_crs_expand_mm_share(c, d_crs_c8, rank, world, (uint8_t *)c->batch_img);
+  if (rc) return rc;
+  mfh_crs_set_resident_mm_share(c, (const uint8_t *)c->batch_img, rank, world);
+  guard.on = true;
+  return MFH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, uint32_t nproofs, const uint8_t *h_witness_bits,
+                    size_t bits_stride, const uint32_t *h_delta, const uint8_t *h_smudge_mag, size_t maglen, const uint8_t *h_smudge_sign,
+                    uint64_t *d_proofs) {
+  if (!c) return MFH_EINVAL;
+  if (!nproofs) return MFH_OK;
+  if (!d_crs_c8 || !h_witness_bits || !h_delta || !h_smudge_mag || !h_smudge_sign || !d_proofs) return MFH_EINVAL;
+  if (c->resident_rows) { c->err = "mfh_prove_batch regenerates the keystream: clear the resident CRS image first"; return MFH_EUNSUPPORTED; }
+  if (c->mm_image && c->mm_world != 1) { c->err = "mfh_prove_batch: the registered matrix-core image holds one rank's row shares (use mfh_prove_batch_partial)"; return MFH_EINVAL; }
+  mf::SspSrc src;
+  {
+    int rc0 = ssp_src(c, d_ssp, src);
+    if (rc0) return rc0;
+  }
+  const uint32_t d = c->P.d, m = c->P.m, n = c->P.n;
+  if (bits_stride < (m + 6) / 8) { c->err = "bits_stride shorter than the m - 1 witness bits"; return MFH_EINVAL; }
+  for (uint32_t b = 0; b < nproofs; b++)
+    if (h_delta[b] >= P32) { c->err = "delta must be < p"; return MFH_EINVAL; }
+  const size_t ctl = (size_t)(n + 1) * ((c->P.logq + 63) / 64);
+  HIP_TRY(c, hipSetDevice(c->device));
+  BatchScratch B;
+  int rc = batch_scratch(c, nproofs, true, B);
+  if (rc) return rc;
+  // w | h | v twice: the chain (witness pass + polynomial step) of super-group k + 1 is queued while super-group k is still smudged.  The
+  // multi-vector launches read their coefficient vectors where the polynomial step left them and write the proof structs in place (MmIo).
+  size_t slot = 0;
+  HIP_TRY(c, hipMemsetAsync(B.SCZ, 0, B.nslots * 2048, c->stream));
+  // Two streams: the S-region launches of the groups run on the caller's stream, the AS-region launches on the side stream, so that the
+  // last, partly filled round of workgroups of one launch (736 workgroups on 256 CUs) is filled by the next launch's first ones.
+  rc = batch_streams(c);
+  if (rc) return rc;
+  hipStream_t const main_stream = c->stream, chain_stream = c->side2;
+  // The chain of a super-group on its own stream: the first one runs beside the CRS expansion, the chain of super-group k + 1 beside the
+  // smudging of super-group k and its own b_w rows.
   auto launch_chain = [&](uint32_t sgi) -> int {
-    const uint32_t s0 = sgi * SG, sg = std::min(SG, nproofs - s0);
-    uint32_t *const WALL = WHV + (size_t)(sgi & 1) * 3 * SG * d, *const HALL = WALL + (size_t)SG * d, *const VALL = HALL + (size_t)SG * d;
+    const uint32_t s0 = sgi * BSG, sg = std::min(BSG, nproofs - s0);
+    uint32_t *const WALL = B.WHV + (size_t)(sgi & 1) * 3 * BSG * d, *const HALL = WALL + (size_t)BSG * d, *const VALL = HALL + (size_t)BSG * d;
     HIP_TRY(c, hipEventRecord(c->ev_chain, main_stream));  // what the caller's stream has been given so far no longer reads these buffers
     HIP_TRY(c, hipStreamWaitEvent(chain_stream, c->ev_chain, 0));
     OnStream chain(c, chain_stream);
-    int rc = MFH_OK;
-    // dense SSP with d % 128 == 0: a GEMM on the matrix cores, one read of the SSP per 124 statements; otherwise the VALU form, read
-    // (or generated) once per 12 statements
-    if (src.dense && d % 128 == 0) {
-      for (uint32_t b0 = 0; b0 < sg; b0 += 124) {
-        rc = mfh_witness_poly_mm(c, d_ssp, std::min(124u, sg - b0), h_witness_bits + (size_t)(s0 + b0) * bits_stride, bits_stride, h_delta + s0 + b0,
-                                 WALL + (size_t)b0 * d);
-        if (rc) return rc;
-      }
-    } else {
-      for (uint32_t b0 = 0; b0 < sg; b0 += 12) {
-        rc = mfh_witness_poly_multi(c, d_ssp, std::min(12u, sg - b0), h_witness_bits + (size_t)(s0 + b0) * bits_stride, bits_stride, h_delta + s0 + b0,
-                                    WALL + (size_t)b0 * d);
-        if (rc) return rc;
-      }
-    }
-    hipLaunchKernelGGL(k_add_slot_multi, dim3((d + 255) / 256, sg), dim3(256), 0, c->stream, WALL, src, 1u, d, VALL);
-    HIP_TRY(c, hipGetLastError());
-    rc = mfh_poly_h_multi(c, VALL, HALL, sg);  // one set of launches, sg times the work each
-    if (rc) return rc;
+    int r = batch_chain_launch(c, src, d_ssp, sg, h_witness_bits + (size_t)s0 * bits_stride, bits_stride, h_delta + s0, WALL, HALL, VALL);
+    if (r) return r;
     HIP_TRY(c, hipEventRecord(c->ev_chain_done, chain_stream));
     return MFH_OK;
   };
-  {
-    int rc = launch_chain(0);
-    if (rc) return rc;
-  }
-  // More than one group: expand the CRS once for the whole call into a transient image in MFMA A-fragment order
-  // (mfh_crs_mm_image_bytes of scratch, kept by the context) and stream it for every group, instead of running AES per group.
-  struct ImageGuard {
-    mfh_ctx *c;
-    bool on;
-    ~ImageGuard() { if (on) mfh_crs_set_resident_mm(c, nullptr); }
-  } transient{c, false};
-  if (!c->mm_image && c->batch_image && nproofs > G && (((uint64_t)n * ctb) & 7) == 0) {
-    const size_t ib = mfh_crs_mm_image_bytes(c);
-    if (c->batch_img_bytes < ib) {
-      if (c->batch_img) { hipDeviceSynchronize(); hipFree(c->batch_img); c->batch_img = nullptr; c->batch_img_bytes = 0; }
-      size_t mem_free = 0, mem_total = 0;
-      if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) mem_free = 0;
-      // no room (the rest of the call and the caller need memory too): the groups regenerate the keystream
-      if (ib <= mem_free / 4 * 3 && hipMalloc(&c->batch_img, ib) == hipSuccess) c->batch_img_bytes = ib;
-      else { c->batch_img = nullptr; (void)hipGetLastError(); }
-    }
-    if (c->batch_img) {
-      int rc = mfh_crs_expand_mm(c, d_crs_c8, (uint8_t *)c->batch_img);
-      if (rc) return rc;
-      mfh_crs_set_resident_mm(c, (const uint8_t *)c->batch_img);
-      transient.on = true;
-    }
-  }
-  // ct_t = the BT row as a ciphertext (eval_poly of one row with coefficient 1): b_w's delta * ct_t term is added per proof below
-  {
-    const uint32_t one = 1;
-    HIP_TRY(c, hipMemcpyAsync(ONE, &one, 4, hipMemcpyHostToDevice, c->stream));
-    int rc = mfh_eval_rows(c, ctr_ct * 2 * d, 1, d_crs_c8 + (size_t)2 * d * ctb, ONE, nullptr, CT_T, nullptr, 0);
-    if (rc) return rc;
-  }
-  for (uint32_t s0 = 0, sgi = 0; s0 < nproofs; s0 += SG, sgi++) {
-    const uint32_t sg = std::min(SG, nproofs - s0);
+  rc = launch_chain(0);
+  if (rc) return rc;
+  ImageGuard transient{c, false};
+  rc = batch_transient_image(c, d_crs_c8, nproofs, 0, 1, transient);
+  if (rc) return rc;
+  rc = batch_ct_t(c, d_crs_c8, B);
+  if (rc) return rc;
+  for (uint32_t s0 = 0, sgi = 0; s0 < nproofs; s0 += BSG, sgi++) {
+    const uint32_t sg = std::min(BSG, nproofs - s0);
     uint64_t *sproofs = d_proofs + (size_t)s0 * 5 * ctl;
-    const uint64_t pstride = 5 * ctl;  // component `slot` of consecutive proofs (struct order h | hat_h | hat_v | v_w | b_w)
-    uint32_t *const WALL = WHV + (size_t)(sgi & 1) * 3 * SG * d, *const HALL = WALL + (size_t)SG * d, *const VALL = HALL + (size_t)SG * d;
-    int rc = MFH_OK;
-    // ---- b_w = delta ct_t + sum_{bit} ct_{v_i} (src/snark.c:143-155): the bits of all sg statements as byte coefficients over the BT+BV rows
-    // (the packed bits travel as they are, 2.7 KB per statement; the digit kernels unpack them)
-    const uint32_t bstride = (m + 6) / 8;  // the m - 1 bits of a statement, repacked densely (the CW area holds SG x m words)
-    const size_t packed = (size_t)sg * bstride;
-    uint8_t *h_cw = (uint8_t *)pin_acquire(c, c->pin_cw, packed);
-    if (!h_cw) return MFH_ENOMEM;
-    for (uint32_t b = 0; b < sg; b++) memcpy(h_cw + (size_t)b * bstride, h_witness_bits + (size_t)(s0 + b) * bits_stride, bstride);
-    HIP_TRY(c, hipMemcpyAsync(CW, h_cw, packed, hipMemcpyHostToDevice, c->stream));
-    pin_release(c, c->pin_cw);
-    const MmIo io_bw = {{nullptr, nullptr}, sg, {sproofs + 4 * ctl, nullptr}, sg, pstride, (const uint8_t *)CW, bstride, SCZ + 256 * slot++};
-    rc = eval_rows_multi_io(c, ctr_ct * 2 * d, m, d_crs_c8 + (size_t)2 * d * ctb, io_bw, sg, 1, 0);
+    uint32_t *const WALL = B.WHV + (size_t)(sgi & 1) * 3 * BSG * d, *const HALL = WALL + (size_t)BSG * d, *const VALL = HALL + (size_t)BSG * d;
+    const BatchCoef co = {WALL, HALL, VALL, d};
+    rc = batch_rows_supergroup(c, d_crs_c8, 0, 1, sg, h_witness_bits + (size_t)s0 * bits_stride, bits_stride, co, sproofs, B, slot, h_delta + s0,
+                               c->ev_chain_done);
     if (rc) return rc;
-    {  // + delta_b ct_t for the sg proofs in one launch; the deltas travel in the (now consumed) first words of the CW staging area
-      HIP_TRY(c, hipMemcpyAsync(CW, h_delta + s0, (size_t)sg * 4, hipMemcpyHostToDevice, c->stream));
-      hipLaunchKernelGGL(k_bw_add_delta_ct, dim3((n + 1 + 255) / 256, sg), dim3(256), 0, c->stream, sproofs, CT_T, CW, n + 1,
-                         (c->P.logq + 63) / 64, 2 * (c->P.logq / 64));
-      HIP_TRY(c, hipGetLastError());
-    }
-    HIP_TRY(c, hipStreamWaitEvent(main_stream, c->ev_chain_done, 0));
-    HIP_TRY(c, hipEventRecord(c->ev_fork, main_stream));
-    HIP_TRY(c, hipStreamWaitEvent(side_stream, c->ev_fork, 0));
-    // ---- S rows with (w, h) -> (v_w, h) on the caller's stream; AS rows with (h, v) -> (hat_h, hat_v) on the side stream: every row
-    // expanded once per group of G proofs
-    // with the image registered one streaming launch serves NGL = 4 groups: the image is then read from HBM once per 124 proofs (2 and 8
-    // groups per launch measured 2 % and 1 % slower, 1 group 10 % slower)
-    constexpr uint32_t NGLMAX = 8;
-    const uint32_t NGL = c->mm_image ? c->batch_ngl : 1u;
-    for (uint32_t g0 = s0; g0 < s0 + sg; g0 += NGL * G) {
-      MmIo io_s[NGLMAX], io_as[NGLMAX];
-      uint32_t nv[NGLMAX], ng = 0;
-      for (uint32_t k = 0; k < NGL && g0 + k * G < s0 + sg; k++, ng++) {
-        const uint32_t gg = g0 + k * G, g = std::min(G, s0 + sg - gg);
-        uint64_t *proofs = d_proofs + (size_t)gg * 5 * ctl;
-        const size_t o = (size_t)(gg - s0) * d;
-        io_s[k] = MmIo{{WALL + o, HALL + o}, g, {proofs + 3 * ctl, proofs}, g, pstride, nullptr, 0, SCZ + 256 * slot++};             // (w, h) -> (v_w, h)
-        io_as[k] = MmIo{{HALL + o, VALL + o}, g, {proofs + ctl, proofs + 2 * ctl}, g, pstride, nullptr, 0, SCZ + 256 * slot++};  // (h, v) -> (hat_h, hat_v)
-        nv[k] = 2 * g;
-      }
-      rc = eval_rows_multi_io_set(c, 0, d, d_crs_c8, io_s, nv, ng, 4);
-      if (rc) return rc;
-      {
-        OnSide side(c, side_stream);
-        rc = eval_rows_multi_io_set(c, ctr_ct * d, d, d_crs_c8 + (size_t)d * ctb, io_as, nv, ng, 4);
-        if (rc) return rc;
-      }
-    }
-    HIP_TRY(c, hipEventRecord(c->ev_join, side_stream));
-    HIP_TRY(c, hipStreamWaitEvent(main_stream, c->ev_join, 0));
     // the next super-group's chain (the other w | h | v buffers) runs beside this one's smudging and the next one's b_w rows; started
     // any earlier it would share the GPU with the HBM-bound S / AS launches, which costs more than it hides (measured)
-    if (s0 + SG < nproofs) {
+    if (s0 + BSG < nproofs) {
       rc = launch_chain(sgi + 1);
       if (rc) return rc;
     }
-    // ---- smudging of the super-group in two launches: h, hat_h, hat_v, v_w with draws 0..3, then v_w AGAIN with draw 4; b_w never
-    // (src/snark.c:185-189).  A zero magnitude leaves a ciphertext unchanged.
-    std::vector<uint8_t> mags((size_t)sg * 5 * maglen), signs((size_t)sg * 5);
-    for (int pass = 0; pass < 2; pass++) {
-      std::fill(mags.begin(), mags.end(), 0);
-      std::fill(signs.begin(), signs.end(), 0);
-      for (uint32_t b = 0; b < sg; b++) {
-        const uint8_t *pm = h_smudge_mag + (size_t)(s0 + b) * 5 * maglen, *ps = h_smudge_sign + (size_t)(s0 + b) * 5;
-        if (pass == 0) {
-          memcpy(&mags[(size_t)b * 5 * maglen], pm, 4 * maglen);
-          memcpy(&signs[(size_t)b * 5], ps, 4);
-        } else {
-          memcpy(&mags[((size_t)b * 5 + 3) * maglen], pm + 4 * maglen, maglen);
-          signs[(size_t)b * 5 + 3] = ps[4];
-        }
-      }
-      rc = mfh_ct_smudge(c, sproofs, (size_t)sg * 5, mags.data(), maglen, signs.data());
-      if (rc) return rc;
-    }
+    rc = batch_smudge(c, sproofs, sg, h_smudge_mag + (size_t)s0 * 5 * maglen, maglen, h_smudge_sign + (size_t)s0 * 5);
+    if (rc) return rc;
+  }
+  return MFH_OK;
+}
+
+// ---- the row-sharded batch prover (BASELINE configs 3/4): see include/mfhip.h ------------------------------------------
+int mfh_batch_chain(mfh_ctx *c, const uint32_t *d_ssp, uint32_t nstmt, const uint8_t *h_witness_bits, size_t bits_stride, const uint32_t *h_delta,
+                    uint32_t *d_w, uint32_t *d_h, uint32_t *d_v) {
+  if (!c) return MFH_EINVAL;
+  if (!nstmt) return MFH_OK;
+  if (!h_witness_bits || !h_delta || !d_w || !d_h || !d_v) return MFH_EINVAL;
+  mf::SspSrc src;
+  int rc = ssp_src(c, d_ssp, src);
+  if (rc) return rc;
+  const uint32_t d = c->P.d, m = c->P.m;
+  if (bits_stride < (m + 6) / 8) { c->err = "bits_stride shorter than the m - 1 witness bits"; return MFH_EINVAL; }
+  for (uint32_t b = 0; b < nstmt; b++)
+    if (h_delta[b] >= P32) { c->err = "delta must be < p"; return MFH_EINVAL; }
+  HIP_TRY(c, hipSetDevice(c->device));
+  for (uint32_t s0 = 0; s0 < nstmt; s0 += BSG) {
+    const size_t o = (size_t)s0 * d;
+    rc = batch_chain_launch(c, src, d_ssp, std::min(BSG, nstmt - s0), h_witness_bits + (size_t)s0 * bits_stride, bits_stride, h_delta + s0, d_w + o, d_h + o,
+                            d_v + o);
+    if (rc) return rc;
+  }
+  return MFH_OK;
+}
+
+int mfh_prove_batch_partial(mfh_ctx *c, const uint8_t *d_crs_c8, uint32_t rank, uint32_t world, uint32_t nstmt, const uint8_t *h_witness_bits,
+                            size_t bits_stride, const uint32_t *d_w, const uint32_t *d_h, const uint32_t *d_v, size_t coef_stride, uint64_t *d_partial) {
+  if (!c || !world || rank >= world) return MFH_EINVAL;
+  if (!nstmt) return MFH_OK;
+  if (!d_crs_c8 || !h_witness_bits || !d_w || !d_h || !d_v || !d_partial) return MFH_EINVAL;
+  if (c->resident_rows) { c->err = "mfh_prove_batch_partial: clear the single-proof resident CRS image first"; return MFH_EUNSUPPORTED; }
+  if (c->mm_image && (c->mm_rank != rank || c->mm_world != world)) {
+    c->err = "the registered matrix-core image holds the row shares of a different (rank, world)";
+    return MFH_EINVAL;
+  }
+  const uint32_t d = c->P.d, m = c->P.m, n = c->P.n;
+  const uint32_t cS = (uint32_t)((uint64_t)d * (rank + 1) / world) - (uint32_t)((uint64_t)d * rank / world);
+  if (bits_stride < (m + 6) / 8) { c->err = "bits_stride shorter than the m - 1 witness bits"; return MFH_EINVAL; }
+  if (coef_stride < cS) { c->err = "coef_stride shorter than the rank's share of the S / AS rows"; return MFH_EINVAL; }
+  const size_t ctl = (size_t)(n + 1) * ((c->P.logq + 63) / 64);
+  HIP_TRY(c, hipSetDevice(c->device));
+  BatchScratch B;
+  int rc = batch_scratch(c, nstmt, false, B);
+  if (rc) return rc;
+  size_t slot = 0;
+  HIP_TRY(c, hipMemsetAsync(B.SCZ, 0, B.nslots * 2048, c->stream));
+  rc = batch_streams(c);
+  if (rc) return rc;
+  ImageGuard transient{c, false};
+  rc = batch_transient_image(c, d_crs_c8, nstmt, rank, world, transient);
+  if (rc) return rc;
+  for (uint32_t s0 = 0; s0 < nstmt; s0 += BSG) {
+    const uint32_t sg = std::min(BSG, nstmt - s0);
+    const uint64_t o = (uint64_t)s0 * coef_stride;
+    const BatchCoef co = {d_w + o, d_h + o, d_v + o, coef_stride};
+    rc = batch_rows_supergroup(c, d_crs_c8, rank, world, sg, h_witness_bits + (size_t)s0 * bits_stride, bits_stride, co, d_partial + (size_t)s0 * 5 * ctl, B,
+                               slot, nullptr, nullptr);
+    if (rc) return rc;
+  }
+  return MFH_OK;
+}
+
+int mfh_prove_batch_finish(mfh_ctx *c, const uint8_t *d_crs_c8, uint32_t nstmt, const uint32_t *h_delta, const uint8_t *h_smudge_mag, size_t maglen,
+                           const uint8_t *h_smudge_sign, uint64_t *d_proofs) {
+  if (!c) return MFH_EINVAL;
+  if (!nstmt) return MFH_OK;
+  if (!d_crs_c8 || !h_delta || !h_smudge_mag || !h_smudge_sign || !d_proofs) return MFH_EINVAL;
+  for (uint32_t b = 0; b < nstmt; b++)
+    if (h_delta[b] >= P32) { c->err = "delta must be < p"; return MFH_EINVAL; }
+  const uint32_t n = c->P.n;
+  const size_t ctl = (size_t)(n + 1) * ((c->P.logq + 63) / 64);
+  HIP_TRY(c, hipSetDevice(c->device));
+  BatchScratch B;
+  int rc = batch_scratch(c, std::min(nstmt, BSG), false, B);
+  if (rc) return rc;
+  rc = batch_ct_t(c, d_crs_c8, B);
+  if (rc) return rc;
+  for (uint32_t s0 = 0; s0 < nstmt; s0 += BSG) {
+    const uint32_t sg = std::min(BSG, nstmt - s0);
+    uint64_t *sproofs = d_proofs + (size_t)s0 * 5 * ctl;
+    uint32_t *h_dl = (uint32_t *)pin_acquire(c, c->pin_cw, (size_t)sg * 4);
+    if (!h_dl) return MFH_ENOMEM;
+    memcpy(h_dl, h_delta + s0, (size_t)sg * 4);
+    HIP_TRY(c, hipMemcpyAsync(B.CW, h_dl, (size_t)sg * 4, hipMemcpyHostToDevice, c->stream));
+    pin_release(c, c->pin_cw);
+    hipLaunchKernelGGL(k_bw_add_delta_ct, dim3((n + 1 + 255) / 256, sg), dim3(256), 0, c->stream, sproofs, B.CT_T, (const uint32_t *)B.CW, n + 1,
+                       (c->P.logq + 63) / 64, 2 * (c->P.logq / 64));
+    HIP_TRY(c, hipGetLastError());
+    rc = batch_smudge(c, sproofs, sg, h_smudge_mag + (size_t)s0 * 5 * maglen, maglen, h_smudge_sign + (size_t)s0 * 5);
+    if (rc) return rc;
   }
   return MFH_OK;
 }

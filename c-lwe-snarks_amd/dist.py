@@ -15,7 +15,7 @@ def allreduce_lanes(lanes, group=None):
     import torch.distributed as dist
 
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(lanes, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(lanes, op=dist.ReduceOp.SUM, group=group)  # (gloo takes device tensors here and stages them itself)
     return lanes
 
 
@@ -39,6 +39,101 @@ def prove_sharded(ctx, d_crs, d_ssp, witness_bits, delta, smudge_mag, smudge_sig
     ctx.prove_finish(proof, smudge_mag, smudge_sign, maglen)
     bufs.update(wlanes=wl, partial=partial, lanes=lanes, proof=proof)
     return proof
+
+
+def _on_host_backend(t, group=None):
+    """gloo (the CPU rehearsal backend: tests, and two ranks sharing one GPU) is given host tensors; nccl (= RCCL) device tensors"""
+    import torch.distributed as dist
+
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def all_to_all_rows(recv, send, out_splits, in_splits, group=None):
+    import torch.distributed as dist
+
+    if _on_host_backend(send, group):
+        r = recv.cpu()
+        dist.all_to_all_single(r, send.cpu(), output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+        recv.copy_(r)
+    else:
+        dist.all_to_all_single(recv, send, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+    return recv
+
+
+def reduce_scatter_lanes(own, lanes, group=None):
+    """own = this rank's equal slab of the element-wise sum of `lanes` over the ranks (int64 stands in for uint64: two's-complement sums
+    are the same bits, and 2^32 ranks of 32-bit words fit)"""
+    import torch.distributed as dist
+
+    if _on_host_backend(lanes, group):
+        o = own.cpu()
+        dist.reduce_scatter_tensor(o, lanes.cpu(), op=dist.ReduceOp.SUM, group=group)
+        own.copy_(o)
+    else:
+        dist.reduce_scatter_tensor(own, lanes, op=dist.ReduceOp.SUM, group=group)
+    return own
+
+
+def row_shares(total, world):
+    """contiguous shares [total r / world, total (r+1) / world) -- the split every mfh_*_partial / *_share entry point uses"""
+    return [(total * r // world, total * (r + 1) // world) for r in range(world)]
+
+
+def statement_shares(nb, world):
+    """statements are owned in equal slabs of ceil(nb / world) (the last ranks may own fewer or none): the slab is the unit of the
+    reduce-scatter, which needs equal pieces"""
+    per = -(-nb // world) if nb else 0
+    return per, [(min(nb, r * per), min(nb, (r + 1) * per)) for r in range(world)]
+
+
+def prove_batch_sharded(ctx, d_crs, d_ssp, witness_bits_list, deltas, smudge_mags, smudge_signs, rank, world, maglen=80, group=None, bufs=None):
+    """prover() (reference src/snark.c:117-190) for len(witness_bits_list) statements with the CRS ROWS sharded over `world` ranks
+    (BASELINE configs 3/4: "ciphertexts sharded across 8 x MI355X + RCCL reduce"; include/mfhip.h, row-sharded batch prover).
+
+    Every rank is given the same statement list.  Data path per call:
+      chain (own statements)  ->  all-to-all of the w | h | v row slices (3 x 4 B x d x nb / world sent per rank)
+      ->  row shares of all five ciphertexts of all statements on the matrix cores
+      ->  ONE reduce-scatter (sum) of uint64 lanes, nb x 5 x (n+1) x 2K lanes of 8 B  ->  carries, modq, delta ct_t, smudging (own statements).
+    Returns (first, count, proofs): the rank's own statements [first, first + count) and their finished proofs (count x 5 ciphertexts,
+    bit-identical to prove_batch's).  world == 1 proves alone: no collective."""
+    import torch
+
+    nb = len(witness_bits_list)
+    if world == 1:
+        return 0, nb, ctx.prove_batch(d_crs, d_ssp, witness_bits_list, deltas, smudge_mags, smudge_signs, maglen)
+    p = ctx.params
+    bufs = {} if bufs is None else bufs
+    per, owned = statement_shares(nb, world)
+    first, last = owned[rank]
+    count = last - first
+    # 1. the chain of the rank's own statements: w | h | v, [3][count][d]
+    whv = ctx.batch_chain(d_ssp, witness_bits_list[first:last], deltas[first:last])
+    # 2. all-to-all: rank r gets rows [d r / world, d (r+1) / world) of w | h | v of every statement, laid out [statement][w | h | v][rows]
+    shares = row_shares(p.d, world)
+    lo, hi = shares[rank]
+    cs = hi - lo
+    send = torch.cat([whv[:, :, a:b].permute(1, 0, 2).reshape(-1) for a, b in shares]) if count else whv.reshape(-1)
+    in_splits = [count * 3 * (b - a) for a, b in shares]
+    out_splits = [(b - a) * 3 * cs for a, b in owned]
+    recv = torch.empty(nb * 3 * cs, dtype=send.dtype, device=send.device)
+    all_to_all_rows(recv, send, out_splits, in_splits, group)
+    # 3. the rank's row shares of every statement's five ciphertexts
+    partial = ctx.prove_batch_partial(d_crs, rank, world, witness_bits_list, recv, recv[cs:], recv[2 * cs:], 3 * cs, out=bufs.get("bpartial"))
+    # 4. one uint64 lane per surviving 32-bit word, statements padded to world equal slabs; reduce-scatter: the rank receives its slab summed
+    lps = 5 * (p.n + 1) * 2 * p.K  # lanes per statement
+    lanes = bufs.get("blanes")
+    if lanes is None or lanes.numel() != per * world * lps:
+        lanes = torch.zeros(per * world * lps, dtype=torch.int64, device=send.device)
+    ctx.ct_to_lanes(partial, nb * 5, out=lanes)
+    own = bufs.get("bown")
+    if own is None or own.numel() != per * lps:
+        own = torch.empty(per * lps, dtype=torch.int64, device=send.device)
+    reduce_scatter_lanes(own, lanes, group)
+    bufs.update(bpartial=partial, blanes=lanes, bown=own)
+    # 5. carries + modq, then delta ct_t and the smudging of the rank's own statements
+    proofs = ctx.ct_from_lanes(own, count * 5) if count else ctx.empty(0)
+    ctx.prove_batch_finish(d_crs, deltas[first:last], smudge_mags[first:last], smudge_signs[first:last], proofs, maglen)
+    return first, count, proofs
 
 
 def lanes_from_limbs_cpu(cts_u64, K):

@@ -201,9 +201,41 @@ int mfh_crs_set_resident_mm(mfh_ctx *ctx, const uint8_t *d_image);
  * running AES once per group; if that scratch cannot be allocated, or after mfh_set_batch_image(ctx, 0) (which also frees it), every
  * group regenerates the keystream.  Same proofs either way. */
 int mfh_set_batch_image(mfh_ctx *ctx, int enabled);
+/* rows per row chunk of the matrix-core launches (mfh_eval_rows_multi, mfh_prove_batch): the int32 accumulators hold at most
+ * 131071 rows (the default; 0 restores it); smaller values split every region into more chunks -- same results (tuning, tests). */
+int mfh_set_mm_chunk_rows(mfh_ctx *ctx, uint32_t rows);
 int mfh_prove_batch(mfh_ctx *ctx, const uint8_t *d_crs_c8, const uint32_t *d_ssp, uint32_t nproofs, const uint8_t *h_witness_bits,
                     size_t bits_stride, const uint32_t *h_delta, const uint8_t *h_smudge_mag, size_t maglen, const uint8_t *h_smudge_sign,
                     uint64_t *d_proofs);
+/* ---- multi-GPU: row-sharded BATCH prover (BASELINE configs 3/4: "ciphertexts sharded across 8 x MI355X + RCCL reduce") ------
+ * The loops that shard are src/snark.c:147-155 (b_w over the BT+BV rows) and :157-174 (the four eval_poly passes over the S / AS rows):
+ * rank r of `world` owns rows [R r / world, R (r+1) / world) of each region (R = d, d, m) and, for the steps that do not touch the CRS,
+ * a contiguous slice of the STATEMENTS.  One step over nstmt statements:
+ *   1. mfh_batch_chain on the rank's own statements: w = delta t + sum_bits v_i, v = w + v_0, h = (v^2 - 1) / t   (src/snark.c:141-169)
+ *   2. exchange (all-to-all): rank r receives rows [d r / world, ...) of w | h | v of ALL statements
+ *   3. mfh_prove_batch_partial: the rank's row shares of all five ciphertexts of all statements (no delta ct_t term, un-smudged),
+ *      streamed from the rank's share of the matrix-core image (mfh_crs_expand_mm_share: 45 GB per GPU for the 2^20-constraint CRS on 8)
+ *   4. mfh_ct_to_lanes -> ONE reduce-scatter (sum) of uint64 lanes per step: every rank receives the summed lanes of its own statements
+ *   5. mfh_ct_from_lanes (carries + modq) -> mfh_prove_batch_finish: + delta ct_t on b_w, smudging.
+ * Proofs are bit-identical to mfh_prove_batch's (sums mod 2^(64K) do not depend on the order).  world = 1 degenerates to mfh_prove_batch.
+ * c-lwe-snarks_amd/dist.py (prove_batch_sharded) drives the sequence over torch.distributed (backend nccl = RCCL). */
+size_t mfh_crs_mm_share_bytes(const mfh_ctx *ctx, uint32_t rank, uint32_t world);
+int mfh_crs_expand_mm_share(mfh_ctx *ctx, const uint8_t *d_crs_c8, uint32_t rank, uint32_t world, uint8_t *d_image);
+int mfh_crs_set_resident_mm_share(mfh_ctx *ctx, const uint8_t *d_image, uint32_t rank, uint32_t world);
+/* step 1: d_w, d_h, d_v = nstmt x d coefficients each (statement-major) */
+int mfh_batch_chain(mfh_ctx *ctx, const uint32_t *d_ssp, uint32_t nstmt, const uint8_t *h_witness_bits, size_t bits_stride, const uint32_t *h_delta,
+                    uint32_t *d_w, uint32_t *d_h, uint32_t *d_v);
+/* step 3: statement b's coefficients for the rank's S / AS rows [d rank / world, d (rank+1) / world) at d_w / d_h / d_v + b * coef_stride
+ * (uint32 words; with the whole polynomials in memory: d_w = W + d rank / world, coef_stride = d).  The witness bits select the rank's
+ * share of the BT+BV rows.  d_partial = nstmt x 5 partial ciphertexts (struct proof order).  With more than 31 statements and no image
+ * registered the call expands the rank's shares into a transient image first (see mfh_prove_batch). */
+int mfh_prove_batch_partial(mfh_ctx *ctx, const uint8_t *d_crs_c8, uint32_t rank, uint32_t world, uint32_t nstmt, const uint8_t *h_witness_bits,
+                            size_t bits_stride, const uint32_t *d_w, const uint32_t *d_h, const uint32_t *d_v, size_t coef_stride, uint64_t *d_partial);
+/* step 5: d_proofs = nstmt summed proofs (after mfh_ct_from_lanes): b_w += delta_b ct_t (src/snark.c:143-145), then the five smudging
+ * draws per proof in the order of mfh_prove (src/snark.c:185-189) */
+int mfh_prove_batch_finish(mfh_ctx *ctx, const uint8_t *d_crs_c8, uint32_t nstmt, const uint32_t *h_delta, const uint8_t *h_smudge_mag, size_t maglen,
+                           const uint8_t *h_smudge_sign, uint64_t *d_proofs);
+
 /* ---- multi-GPU: row-sharded prover -------------------------------------------------------------
  * Every proof element is sum_i coeff_i * row_i and the public stream is seekable, so the CRS rows of each region are
  * split into `world` contiguous shares.  mfh_prove_partial computes rank `rank`'s share of the five (un-smudged)

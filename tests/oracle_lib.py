@@ -86,6 +86,15 @@ class Oracle:
         return out
 
     # ---- lwe ----
+    def add_dotp(self, p, rop, a, b):
+        """mpz_add_dotp (src/lwe.c:20-28): rop + sum_j a[j] b[j], modq once at the end"""
+        rop = np.ascontiguousarray(rop, dtype=np.uint64).copy()
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        b = np.ascontiguousarray(b, dtype=np.uint64)
+        cp = self.cp(p)
+        self.lib.mfo_add_dotp(ctypes.byref(cp), _p(rop), _p(a), _p(b), ctypes.c_size_t(a.shape[0]))
+        return rop
+
     def sample_rows(self, p, seed, off, nrows):
         r = self.rng(seed, off)
         out = np.zeros((nrows, p.n + 1, p.L), dtype=np.uint64)

@@ -105,3 +105,109 @@ def test_prove_sharded_call_sequence(monkeypatch, world, expect):
     monkeypatch.setattr(mfdist, "allreduce_lanes", lambda lanes, group=None: ctx.calls.append("ALLREDUCE"))
     mfdist.prove_sharded(ctx, None, None, None, None, None, None, 0, world)
     assert ctx.calls == expect
+
+
+# ---- the row-sharded BATCH prover's host sequencing (dist.prove_batch_sharded) under a real gloo process group -----------------------
+class _LinearCtx:
+    """CPU stand-in for the C ABI with LINEAR arithmetic whose result exposes any mix-up of statements, rows or ownership:
+    chain: w | h | v [k][b][i] = 1000 k + 10 id_b + i  (id_b = the statement's delta);  partial: component k of statement b =
+    sum over the rank's rows i of coef_k[i] * (i + 1) (absolute row index), so the summed proof is a known closed form;
+    finish adds 7 id_b.  What is under test is prove_batch_sharded itself: split sizes and layout of the all-to-all, the padded
+    reduce-scatter, which statements a rank finishes."""
+
+    class _P:
+        d, m, n, K, L = 13, 9, 1, 1, 1
+
+    def __init__(self):
+        import torch
+
+        self.torch = torch
+        self.params = self._P()
+        self.finished = None
+
+    def empty(self, nbytes):
+        return self.torch.empty(int(nbytes), dtype=self.torch.uint8)
+
+    def batch_chain(self, d_ssp, bits_list, deltas):
+        t, p = self.torch, self.params
+        out = t.zeros((3, len(deltas), p.d), dtype=t.int32)
+        for k in range(3):
+            for b, idb in enumerate(deltas):
+                out[k, b] = 1000 * k + 10 * idb + t.arange(p.d, dtype=t.int32)
+        return out
+
+    def prove_batch_partial(self, d_crs, rank, world, bits_list, d_w, d_h, d_v, stride, out=None):
+        t, p = self.torch, self.params
+        lo, hi = p.d * rank // world, p.d * (rank + 1) // world
+        wts = t.arange(lo + 1, hi + 1, dtype=t.int64)
+        nb = len(bits_list)
+        part = t.zeros((nb, 5, p.n + 1, p.L), dtype=t.int64)
+        for b in range(nb):
+            for k, src in enumerate((d_w, d_h, d_v)):
+                part[b, k, 0, 0] = int((src[b * stride: b * stride + (hi - lo)].to(t.int64) * wts).sum())
+            part[b, 4, 1, 0] = sum((bits_list[b][i // 8] >> (i % 8)) & 1 for i in range(p.m * rank // world, p.m * (rank + 1) // world))
+        return part
+
+    def ct_to_lanes(self, partial, count, out=None):
+        from c_lwe_snarks_amd import dist as mfdist
+
+        p = self.params
+        lanes = self.torch.from_numpy(mfdist.lanes_from_limbs_cpu(partial.numpy().astype(np.uint64).reshape(-1, p.L), p.K)).reshape(-1)
+        out[: lanes.numel()] = lanes
+        return out
+
+    def ct_from_lanes(self, lanes, count):
+        from c_lwe_snarks_amd import dist as mfdist
+
+        p = self.params
+        n = count * (p.n + 1)
+        return self.torch.from_numpy(mfdist.limbs_from_lanes_cpu(lanes[: n * 2 * p.K].numpy().reshape(n, 2 * p.K), p.L, p.K).astype(np.int64)).reshape(-1)
+
+    def prove_batch_finish(self, d_crs, deltas, mags, signs, proofs, maglen=80):
+        p = self.params
+        v = proofs.view(len(deltas), 5, p.n + 1, p.L) if len(deltas) else proofs
+        for b, idb in enumerate(deltas):
+            v[b, 4, 0, 0] += 7 * idb
+        self.finished = list(deltas)
+        return proofs
+
+
+def _batch_worker(rank, world, port, out_dir, nb):
+    import torch.distributed as dist
+
+    from c_lwe_snarks_amd import dist as mfdist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ctx = _LinearCtx()
+    p = ctx.params
+    ids = [3 + 2 * b for b in range(nb)]
+    bits = [bytes([(37 * b + 1) & 0xFF, (11 * b) & 0xFF]) for b in range(nb)]
+    first, count, proofs = mfdist.prove_batch_sharded(ctx, None, None, bits, ids, [b""] * nb, [b""] * nb, rank, world)
+    per = -(-nb // world)
+    ok = first == min(nb, rank * per) and count == min(nb, first + per) - first and ctx.finished == ids[first:first + count]
+    got = proofs.view(count, 5, p.n + 1, p.L) if count else None
+    wsum = sum(i * (i + 1) for i in range(p.d))   # sum_i i (i + 1)
+    w1 = sum(i + 1 for i in range(p.d))
+    for b in range(count):
+        idb = ids[first + b]
+        for k in range(3):
+            ok = ok and int(got[b, k, 0, 0]) == (1000 * k + 10 * idb) * w1 + wsum
+        ok = ok and int(got[b, 3, 0, 0]) == 0
+        ok = ok and int(got[b, 4, 0, 0]) == 7 * idb
+        ok = ok and int(got[b, 4, 1, 0]) == sum((bits[first + b][i // 8] >> (i % 8)) & 1 for i in range(p.m))
+    with open(os.path.join(out_dir, f"brank{rank}.txt"), "w") as f:
+        f.write("ok" if ok else "MISMATCH")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,nb", [(2, 5), (2, 4), (3, 2)])
+def test_prove_batch_sharded_sequencing_gloo(tmp_path, world, nb):
+    """uneven statement slabs (5 over 2), even ones, and a rank that owns no statement (2 over 3; d = 13 and m = 9 never divide)"""
+    import torch.multiprocessing as mp
+
+    port = _free_port()
+    mp.spawn(_batch_worker, args=(world, port, str(tmp_path), nb), nprocs=world, join=True)
+    for r in range(world):
+        assert open(tmp_path / f"brank{r}.txt").read() == "ok"

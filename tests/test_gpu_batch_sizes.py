@@ -1,0 +1,179 @@
+"""The headline path (mfh_prove_batch: k_evalmm16<MODE 1> image writer -> k_mmstream -> k_evalmm_finish, witness GEMM, batched
+polynomial step) under ORACLE parity at sizes that exercise its loops, which the DEBUG-size tests of test_gpu_evalmm.py do not:
+
+  * the NDEBUG default size (D = 2^15, M = 21845): 128 stages of 256 rows per k_mmstream launch; proof 0 of a 130-statement batch is
+    the instance of tests/golden/make_default_size_golden.py and must reproduce the oracle's SHA-256s of all five ciphertexts;
+  * intermediate sizes with D and M chosen so that the row counts are multiples of neither 256 nor 64, with several row chunks forced
+    (mfh_set_mm_chunk_rows): k_mmstream's double-buffer swap, one-stage-ahead prefetch, `ulast` clamp, KS > 4 image addressing and
+    nchunks > 1 all run, compared with the oracle's prover (src/snark.c:117-190 restated) and with the single-proof VALU path.
+"""
+import hashlib
+import importlib.util
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SEED = bytes((13 * i + 5) & 0xFF for i in range(40))
+NAMES = ["h", "hat_h", "hat_v", "v_w", "b_w"]
+
+
+def _statements(rng, p, n, valid_bits=None):
+    nbytes = (p.m + 7) // 8
+    bits = [valid_bits if (valid_bits is not None and b % 3 != 2) else rng.integers(0, 256, size=nbytes, dtype=np.uint8).tobytes() for b in range(n)]
+    deltas = [int(x) for x in rng.integers(0, ol.P, size=n, dtype=np.uint64)]
+    mags = [rng.integers(0, 256, size=400, dtype=np.uint8).tobytes() for _ in range(n)]
+    signs = [bytes(rng.integers(0, 2, size=5, dtype=np.uint8).tolist()) for _ in range(n)]
+    return bits, deltas, mags, signs
+
+
+@pytest.fixture(scope="module")
+def golden():
+    gdir = os.path.join(ROOT, "tests", "golden")
+    gold = json.load(open(os.path.join(gdir, "default_size_proof.json")))
+    spec = importlib.util.spec_from_file_location("mk_gold", os.path.join(gdir, "make_default_size_golden.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    return gold, mk
+
+
+@pytest.mark.parametrize("mode", ["transient", "resident", "regenerate"])
+def test_default_size_batch_proof0_matches_oracle_hashes(gpu_ctx_factory, golden, mode):
+    """130 statements at mf.DEFAULT through mfh_prove_batch; statement 0 is the golden instance (oracle prover run, 111 s of CPU):
+    its five ciphertexts must hash to tests/golden/default_size_proof.json.  transient: the call expands the CRS into its own image
+    and streams it (k_mmstream, 4 groups per launch); resident: the image registered by the caller; regenerate: every group runs AES
+    again (k_evalmm16<MODE 0>, set_batch_image(False)) -- that mode on the generator-defined SSP (VALU witness pass), the other two
+    on the dense image of the same SSP (witness pass as a GEMM, 124 + 6 statements)."""
+    import torch
+
+    import c_lwe_snarks_amd as mf
+
+    gold, mk = golden
+    p = mf.DEFAULT
+    I = mk.instance(p)
+    ctx = gpu_ctx_factory(p)
+    ctx.set_seed(I["seed"])
+    d_t = ctx.ssp_prg_make_t(gold["prg_seed"], I["bits"])
+    if mode == "regenerate":
+        ctx.ssp_set_prg(gold["prg_seed"], d_t)
+        d_ssp = None
+    else:
+        d_ssp = torch.cat([d_t, ctx.ssp_prg_fill(gold["prg_seed"], 1, p.m + 2)])
+    ctx.ssp_prepare(d_ssp)
+    d_crs = ctx.to_device(I["c8"])
+    nb = 130
+    rng = np.random.default_rng(77)
+    bits, deltas, mags, signs = _statements(rng, p, nb)
+    bits[0], deltas[0], mags[0], signs[0] = I["bits"], I["delta"], I["mags"], I["signs"]
+    ctx.set_batch_image(mode != "regenerate")
+    image = None
+    if mode == "resident":
+        image = ctx.crs_expand_mm(d_crs)
+        ctx.set_resident_mm(image)
+    try:
+        out = ctx.prove_batch(d_crs, d_ssp, bits, deltas, mags, signs)
+    finally:
+        if image is not None:
+            ctx.set_resident_mm(None)
+    ctx.sync()
+    nbytes = p.ct_limbs * 8
+    proofs = out.view(nb, 5 * nbytes)
+    sha = lambda t: hashlib.sha256(ctx.to_host(t).tobytes()).hexdigest()
+    for k, nme in enumerate(NAMES):
+        assert sha(proofs[0][k * nbytes:(k + 1) * nbytes]) == gold["proof_sha256"][nme], nme
+    assert sha(proofs[0]) == gold["proof_all_sha256"]
+    # other positions of the batch against the single-proof path (itself pinned to the same golden in test_gpu_fullsize.py):
+    # last of the first group, first of the second, last of the first witness GEMM, first of the second, last statement
+    for b in (30, 31, 123, 124, nb - 1):
+        one = ctx.prove(d_crs, d_ssp, bits[b], deltas[b], mags[b], signs[b])
+        assert torch.equal(proofs[b], one), f"statement {b}"
+    del image, out
+    ctx.close()
+
+
+def _instance(mf, ctx, oracle, p, seed_int):
+    """valid SSP (oracle's random_ssp restatement), GPU setup -> CRS; returns what the oracle's prover / verifier need"""
+    rng = np.random.default_rng(seed_int)
+    nbytes = (p.m + 7) // 8
+    wit = rng.integers(0, 256, size=nbytes, dtype=np.uint8).tobytes()
+    ssp = oracle.ssp_from_tape(p, rng.integers(0, 256, size=p.m * 8 * p.d, dtype=np.uint8), wit)
+    alpha, beta, s = (int(x) for x in rng.integers(1, ol.P, size=3, dtype=np.uint64))
+    sk = ol.rand_values(rng, p.n, p.L, p.logq)
+    etape = ol.rand_values(rng, 2 * p.d + p.m, p.L, 559)
+    d_ssp = ctx.ssp_upload(ssp)
+    ctx.ssp_prepare(d_ssp)
+    d_crs = ctx.setup(d_ssp, alpha, beta, s, ctx.to_device(sk), ctx.to_device(etape))
+    c8 = ctx.to_host(d_crs)
+    cb = p.ctb
+    crs = dict(seed=SEED, s=c8[: p.d * cb].copy(), as_=c8[p.d * cb: 2 * p.d * cb].copy(), t=c8[2 * p.d * cb: (2 * p.d + 1) * cb].copy(),
+               v=np.concatenate([c8[(2 * p.d + 1) * cb:], np.zeros(cb, dtype=np.uint8)]))
+    return dict(rng=rng, wit=wit, ssp=ssp, alpha=alpha, beta=beta, s=s, sk=sk, d_ssp=d_ssp, d_crs=d_crs, crs=crs)
+
+
+@pytest.mark.parametrize("d,m,nproofs,chunk_rows,mode", [
+    (1152, 1000, 125, 0, "transient"),       # 4.5 stages per S / AS launch, 3.9 per BT+BV launch; 4 groups per launch + 1 single
+    (1152, 1000, 64, 512, "transient"),      # 3 row chunks of 512 / 512 / 128 rows (S, AS), 2 of 512 / 488 (BT+BV)
+    (3968, 777, 40, 1024, "resident"),       # 15.5 stages, 4 chunks, caller-registered image
+    (1152, 1000, 35, 512, "regenerate"),     # k_evalmm16<MODE 0> with several chunks
+    (2176, 321, 33, 0, "regenerate"),        # 8.5 units of 256 rows in one chunk of the AES kernel
+])
+def test_prove_batch_multistage_against_oracle(gpu_ctx_factory, oracle, d, m, nproofs, chunk_rows, mode):
+    import torch
+
+    import c_lwe_snarks_amd as mf
+
+    p = mf.Params(d=d, m=m)
+    ctx = gpu_ctx_factory(p)
+    ctx.set_seed(SEED)
+    W = _instance(mf, ctx, oracle, p, 31 * d + m)
+    bits, deltas, mags, signs = _statements(W["rng"], p, nproofs, valid_bits=W["wit"])
+    valid = [b % 3 != 2 for b in range(nproofs)]
+    ctx.set_mm_chunk_rows(chunk_rows)
+    ctx.set_batch_image(mode != "regenerate")
+    image = None
+    if mode == "resident":
+        image = ctx.crs_expand_mm(W["d_crs"])
+        ctx.set_resident_mm(image)
+    try:
+        out = ctx.prove_batch(W["d_crs"], W["d_ssp"], bits, deltas, mags, signs)
+        if image is not None:
+            # mfh_eval_rows_multi straight through the image against the oracle's eval_poly: the whole AS region, 3 vectors
+            co = W["rng"].integers(0, ol.P, size=(3, p.d), dtype=np.uint64).astype(np.uint32)
+            got = ctx.to_host(ctx.eval_rows_multi(p.ctr_as, p.d, W["d_crs"][p.d * p.ctb:], ctx.to_device(co), 3), np.uint64).reshape(3, p.n + 1, p.L)
+            for v in range(3):
+                exp = oracle.eval_poly(p, SEED, p.ctr_as, W["crs"]["as_"].tobytes(), co[v].astype(np.uint64))
+                assert np.array_equal(got[v], exp.reshape(p.n + 1, p.L)), f"eval_rows_multi through the image, vector {v}"
+    finally:
+        if image is not None:
+            ctx.set_resident_mm(None)
+        ctx.set_mm_chunk_rows(0)
+    got = ctx.to_host(out, np.uint64).reshape(nproofs, 5, p.n + 1, p.L).copy()
+    # the oracle's complete prover for a valid and an invalid statement (first group) and the last statement of the batch
+    for b in (0, 2, nproofs - 1):
+        stape = b"".join(mags[b][80 * k: 80 * k + 80] + signs[b][k: k + 1] for k in range(5))
+        ref = oracle.prover(p, W["crs"], W["ssp"], bits[b], deltas[b], stape, 80)
+        assert np.array_equal(got[b], np.stack(ref["proof"])), f"statement {b} differs from the oracle's prover"
+    for b in range(nproofs):
+        one = ctx.to_host(ctx.prove(W["d_crs"], W["d_ssp"], bits[b], deltas[b], mags[b], signs[b]), np.uint64).reshape(5, p.n + 1, p.L)
+        assert np.array_equal(got[b], one), f"proof {b} of the batch differs from the single-proof path"
+    ok = ctx.to_host(ctx.verify(W["d_ssp"], W["alpha"], W["beta"], W["s"], ctx.to_device(W["sk"]), ctx.to_device(got), nproofs))
+    assert [bool(x) for x in ok] == valid
+    assert oracle.verifier(p, W["ssp"], W["alpha"], W["beta"], W["s"], W["sk"], got[0])
+    del image, out
+    ctx.close()
+
+
+def test_chunk_rows_knob_rejects_overflowing_values(gpu_ctx_factory):
+    import c_lwe_snarks_amd as mf
+
+    ctx = gpu_ctx_factory(mf.DEBUG)
+    with pytest.raises(mf.MfhError):
+        ctx.set_mm_chunk_rows(131072)  # 131072 rows of -128 x -128 overflow an int32 accumulator
+    ctx.set_mm_chunk_rows(131071)
+    ctx.set_mm_chunk_rows(0)

@@ -178,7 +178,11 @@ def test_default_size_proof_matches_oracle_hashes(gpu_ctx_factory):
     assert sha(d_t) == gold["t_sha256"]
     ctx.ssp_set_prg(gold["prg_seed"], d_t)
     ctx.ssp_prepare(None)
-    assert sha(ctx.witness_poly(None, I["bits"], I["delta"])) == gold["w_sha256"]
+    d_w = ctx.witness_poly(None, I["bits"], I["delta"])
+    assert sha(d_w) == gold["w_sha256"]
+    # h = (v^2 - 1) / t with v = w + v_0 (src/snark.c:161-169): the polynomial step on its own against the oracle's h
+    d_v = ctx.poly_add(d_w, ctx.ssp_prg_fill(gold["prg_seed"], 1, 1), p.d)
+    assert sha(ctx.poly_h(d_v)) == gold["h_sha256"]
     d_crs = ctx.to_device(I["c8"])
     pre = ctx.prove_partial(d_crs, None, I["bits"], I["delta"], 0, 1)
     names = ["h", "hat_h", "hat_v", "v_w", "b_w"]

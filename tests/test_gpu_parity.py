@@ -191,6 +191,33 @@ def test_decrypt_matches_oracle_on_unreduced_b(ctx, oracle, mf):
         assert int(got[i]) == oracle.decrypt(p, sk, cts[i])
 
 
+@pytest.mark.parametrize("logq", [736, 1472])
+@pytest.mark.parametrize("length,rop_kind", [(1, "zero"), (1, "full"), (7, "full"), (257, "full"), (1470, "zero"), (1470, "full")])
+def test_add_dotp_matches_oracle(gpu_ctx_factory, oracle, mf, logq, length, rop_kind):
+    """mpz_add_dotp (src/lwe.c:20-28): rop + sum_j a[j] b[j] accumulated unreduced, one modq at the end.  Operands are full
+    logq-bit values (as sk and freshly sampled a_j are), rop either zero or an unreduced logq-bit value (its bits above 2^(64K) must
+    vanish); len 1 (no reduction tree), 257 (one lane of the 256 takes two terms), 1470 (= GAMMA_N, what regev_encrypt2 / regev_decrypt pass)."""
+    p = mf.Params(logq=logq, d=64, m=16)
+    c = gpu_ctx_factory(p)
+    rng = np.random.default_rng(1000 * logq + length)
+    a = ol.rand_values(rng, length, p.L, p.logq)
+    b = ol.rand_values(rng, length, p.L, p.logq)
+    if length >= 7:  # edge operands: all-ones (longest carry chains) and zero
+        a[0] = ol.int_to_limbs((1 << p.logq) - 1, p.L)
+        b[0] = a[0]
+        a[1] = 0
+        b[2] = ol.int_to_limbs(1, p.L)
+    rop = np.zeros(p.L, dtype=np.uint64) if rop_kind == "zero" else ol.rand_values(rng, 1, p.L, p.logq)[0]
+    exp = oracle.add_dotp(p, rop, a, b)
+    # independent check of the oracle's value itself: Python integers
+    want = (ol.limbs_to_int(rop) + sum(ol.limbs_to_int(a[j]) * ol.limbs_to_int(b[j]) for j in range(length))) % (1 << (64 * p.K))
+    assert ol.limbs_to_int(exp) == want
+    d_rop = c.to_device(rop)
+    c.add_dotp(d_rop, c.to_device(a), c.to_device(b), length)
+    got = c.to_host(d_rop, np.uint64)
+    assert np.array_equal(got, exp)
+
+
 def test_smudge(ctx, oracle, mf):
     # src/test_lwe.c:183-205: smudging preserves decryption; and bit-exact against the oracle
     p = mf.DEBUG
