@@ -1,17 +1,23 @@
 #!/usr/bin/env python3
 """bench.py -- proofs/s of the reference's benchmark_snark prover (src/benchmark_snark.c:70-74) on MI355X.
 
-One "step" = one complete prover() call (src/snark.c:117-190) on the NDEBUG default SSP instance
-(D = 2^15 constraints, M = 21845 wires, N = 1470, log q = 736; src/lwe.h:14-31), starting from the COMPRESSED CRS
-exactly as the reference's prover does: all (2D+M) x 135 240 B of AES-256-CTR keystream are regenerated inside the
-timed region (fused into the multiply-accumulate kernel), the witness polynomial, h = (v^2-1)/t, the five
-homomorphic evaluations and the smudging are all inside it.  Inputs (CRS bytes, SSP, witness) are resident in HBM
-when the clock starts.  Nothing is cached between steps except per-circuit constants (the AES tables and the
-power-series inverse of rev(t), which depends on the SSP only, like the SSP itself).
+Default (--mode batch): one "step" = ONE mfh_prove_batch call over --batch (992) statements per GPU on the NDEBUG default SSP
+instance (D = 2^15 constraints, M = 21845 wires, N = 1470, log q = 736; src/lwe.h:14-31), starting from the COMPRESSED CRS exactly as
+the reference's prover() does (src/snark.c:117-190): the call expands all (2D+M) x 135 240 B of AES-256-CTR keystream on the CU into
+a transient image inside the timed region, then streams it per group of 31 proofs with the multiply-accumulate on the matrix cores;
+witness polynomials, h = (v^2-1)/t, the five evaluations and the smudging of every statement are inside the timed region.  Inputs
+(CRS bytes, SSP, witnesses) are resident in HBM when the clock starts.  Nothing is cached between steps except per-circuit constants
+(AES tables, the power-series inverse of rev(t), the SSP's matrix-core image -- all functions of the SSP only, like the SSP itself).
+Every proof is bit-identical to the single-proof prover()'s; the batch figure is a prover-SERVICE throughput and is always printed
+beside `single_proof` (one prover() call per step: what the reference's benchmark_snark times).
 
-N > 1: one process per GPU (torch.distributed, backend nccl = RCCL).  The CRS rows of every region are sharded
-across the ranks, each proof is one cooperative step with ONE all-reduce of 1.3 MB of uint64 lanes:
-total work is fixed as N grows => "scaling": "strong".
+N > 1 (one process per GPU, torch.distributed, backend nccl = RCCL over xGMI), default workload:
+  * headline `value`: every rank proves its own --batch statements per step, no data-path collective ("scaling": "weak");
+  * `single_proof`: ONE proof computed cooperatively, CRS rows sharded over the ranks, two lane all-reduces ("strong");
+  * `row_sharded_batch`: --batch statements per step for the WHOLE job with the CRS rows sharded over the ranks: chain per statement
+    slab, all-to-all of the coefficient row slices, one reduce-scatter of uint64 lanes ("strong"; the configuration BASELINE configs
+    3/4 name).  With --workload config4/config5 and --mode batch this leg IS the headline when N > 1 (the 363 GB image only fits
+    sharded: 45 GB per GPU on 8).
 
 Prints ONE JSON line on rank 0 (driver contract), with "roofline" and "cpu_baseline" objects.
 """
@@ -30,10 +36,9 @@ import numpy as np  # noqa: E402
 ROW_BYTES = 1471 * 92  # algorithmic bytes of one expanded ciphertext row (keystream + b); x2 at logq 1472
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_I8_PEAK_TOPS = 5000.0  # MI355X_MICROARCH.md: I8 = 2x BF16 per clock, dense BF16 ~2.5 PF -> ~5 POPS (no sparsity)
-CONC_NOTE = ("the batch prover queues a group's S launch on the caller's stream and its AS launch on a side stream, so two launches of this "
-             "kernel share the GPU: avg_launch_ms is the start-to-end time of one launch (what HIP events and rocprofv3 report), "
-             "busy_ms_per_launch the union of all launches' spans / launches (the time the GPU spends per launch); achieved = algorithmic "
-             "bytes per launch / busy_ms_per_launch")
+CONC_NOTE = ("avg_launch_ms is the start-to-end time of one launch (HIP events on the launch stream; what rocprofv3 --stats reports), "
+             "busy_ms_per_launch the union of all launches' spans / launches: the two agree when launches of this kernel do not overlap; "
+             "achieved = algorithmic bytes per launch / avg_launch_ms")
 
 
 def build_instance(mf, ctx, torch, p, seed_int):
@@ -114,6 +119,42 @@ def verify_on_gpu(mf, ctx, inst, proof):
     return ok
 
 
+def usable_cores(cap=32):
+    """cores this process may really use: the affinity mask, cut down to the cgroup CPU quota (a one-GPU box shares a big host)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1") and float(quota) > 0:
+                n = min(n, max(1, int(float(quota) / period)))
+            break
+        except Exception:
+            continue
+    return max(1, min(n, cap))
+
+
+def _cpu_rows_worker(args):
+    """one process of the N-process CPU aggregate: `rows` reference-faithful row touches of the oracle (rows are independent)"""
+    d, m, logq, seed, rows = args
+    import oracle_lib as ol
+
+    import c_lwe_snarks_amd as mf
+
+    o = ol.Oracle()
+    p = mf.Params(d=d, m=m, logq=logq)
+    o.bench_eval_rows(p, seed, 64)
+    t0 = time.perf_counter()
+    o.bench_eval_rows(p, seed, rows)
+    return time.perf_counter() - t0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -130,6 +171,9 @@ def main():
                          "single: a step = one prover() call, CRS rows sharded over the ranks + lane all-reduces")
     ap.add_argument("--batch", type=int, default=992, help="statements per GPU per step in batch mode (4 super-groups of 248)")
     ap.add_argument("--no-overlap", action="store_true", help="run the prover on one stream (A/B check of the side-stream overlap)")
+    ap.add_argument("--no-merge", action="store_true", help="batch mode: S and AS groups of a round as two launches on two streams (A/B check)")
+    ap.add_argument("--sharded-batch", type=int, default=None,
+                    help="N > 1: statements per step of the row-sharded batch leg for the whole job (default: --batch at the default workload, 248 for config4/5)")
     ap.add_argument("--resident-gb", type=float, default=200.0, help="HBM budget for the resident CRS image per GPU")
     ap.add_argument("--workload", choices=["default", "config4", "config5"], default="default",
                     help="default = benchmark_snark NDEBUG instance (the driver's workload); config4/config5 = BASELINE's 2^20-constraint "
@@ -167,11 +211,14 @@ def main():
     big = args.workload != "default"
     p = mf.DEFAULT if not big else mf.Params(logq=736 if args.workload == "config4" else 1472, d=1 << 20, m=699050)
     mode = args.mode or ("batch" if not big else "single")
-    run_single = mode == "single" or world == 1  # the single-proof path is always reported on one GPU
-    single_steps = args.steps if mode == "single" else min(args.steps, 10)
+    run_single = True  # one prover() per step is always reported: on N > 1 ranks row-sharded with its two lane all-reduces
+    single_steps = args.steps if mode == "single" else min(args.steps, 10 if not big else 3)
+    backend = os.environ.get("MFUOCO_DIST_BACKEND", "nccl") if world > 1 else None
     ctx = mf.Context(p, local_rank)
     if args.no_overlap:
         ctx.set_overlap(False)
+    merge_regions = not args.no_merge
+    ctx.set_batch_launch(4, merge_regions)
     seed = bytes((37 * i + 11) & 0xFF for i in range(40))
     ctx.set_seed(seed)
     if not big:
@@ -305,9 +352,77 @@ def main():
                     "mac1": {"launches": m1n, "avg_launch_ms": m1ms / max(m1n, 1), "rows_per_launch": m1rows / max(m1n, 1)}}
         del image
 
+    row_bytes_b = (p.n + 1) * p.ctb
+    tile_bytes_per_row = (736 * 11 if p.logq == 736 else 1471 * 12) * 16  # row tiles x 16 byte positions (88 of each value's 92 bytes at 736)
+    lds_peak_b = 256 * 2.4e9 * 64 / (201 * 2.15) / 1e9
+
+    def traffic_of(name):
+        tf_ = os.path.join(ROOT, "profiles", name)
+        try:
+            return json.load(open(tf_)).get("hbm_bytes_per_launch") if os.path.exists(tf_) else None
+        except Exception:
+            return None
+
+    def mmstream_roofline(kt, step_ms, steps_=None):
+        n_, ms_, rows_, busy_, work_ = kt
+        if not n_:
+            return None
+        avg, eff, rows, work = ms_ / n_, busy_ / n_, rows_ / n_, work_ / n_
+        groups = work / rows                                     # groups of 31 proofs served by one launch (S and AS groups together)
+        regions = 2.0 if (merge_regions and groups > 1) else 1.0  # image regions one launch passes over
+        mtile_rows = 129536 if p.logq == 736 else 1471 * 192     # M: row tiles x 16 byte positions (8096 x 16 at logq 736)
+        ops = 2.0 * mtile_rows * 256 * work                      # int8 multiply-adds x 2 per launch (M x N = 256 x K = rows x groups)
+        tops = ops / (avg * 1e-3) / 1e12                         # per average launch duration: what rocprofv3 --stats reproduces
+        tops_busy = ops / (eff * 1e-3) / 1e12                    # per union of launch spans (= tops when launches do not overlap)
+        step_tops = ops * n_ / (steps_ or args.steps) / (step_ms * 1e-3) / 1e12  # the kernel's operations of a step over the WHOLE step time
+        gbs = regions * rows * tile_bytes_per_row / (avg * 1e-3) / 1e9  # one pass over each region's image
+        return {"bound": "mfma", "kernel": "k_mmstream (A fragments of the expanded CRS streamed once per launch and region for 4 groups of 31 proofs -- "
+                                           "HBM for the first workgroup of a row-tile set, that XCD's L2 for the other three --, digit fragments "
+                                           "through LDS, i8 MFMA 16x16x64; the S and the AS groups of a round share one launch)",
+                "achieved": tops, "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s (int8; multiply and add counted separately)", "frac": tops / MFMA_I8_PEAK_TOPS,
+                "traffic": traffic_of("traffic_mmstream.json"),
+                "traffic_source": "static file profiles/traffic_mmstream.json (a separate rocprofv3 --pmc pass of this command, not this run)",
+                "launches": n_, "avg_launch_ms": avg, "busy_ms_per_launch": eff, "concurrency": avg / eff, "rows_per_launch": rows,
+                "groups_per_launch": groups, "regions_per_launch": regions, "int8_ops_per_launch": ops,
+                "achieved_by_busy_time": tops_busy, "frac_by_busy_time": tops_busy / MFMA_I8_PEAK_TOPS,
+                "whole_step": {"achieved": step_tops, "frac": step_tops / MFMA_I8_PEAK_TOPS,
+                               "note": "this kernel's int8 operations of a step / ms_per_step: the matrix-core fraction of the whole job"},
+                "note": CONC_NOTE.replace("algorithmic bytes", "int8 operations"),
+                "hbm": {"bytes_read_per_row": tile_bytes_per_row, "achieved_gbs": gbs, "peak_gbs": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS,
+                        "fragment_gbs_consumed_incl_l2": gbs * groups / regions},
+                "clock_note": "the chip holds ~1.5 GHz under this load (GRBM_GUI_ACTIVE / 8 / duration, DESIGN.md 4.2c); a bare register-only loop "
+                              "of this MFMA sustains ~4050 TOPS (tools/mfma_i8_rate.hip)"}
+
+    def evalmm16_roofline(kt):
+        n_, ms_, rows_, busy_, _ = kt
+        if not n_:
+            return None
+        avg, eff, rows = ms_ / n_, busy_ / n_, rows_ / n_
+        gbs = rows * row_bytes_b / (eff * 1e-3) / 1e9
+        gblk_ = rows * (p.ctr_ct / 16.0) / (eff * 1e-3) / 1e9
+        return {"bound": "hbm", "kernel": "k_evalmm16 (AES-256-CTR expansion of the rows, once per group of 31 proofs, + i8 MFMA multiply-accumulate of the "
+                                          "group's 62 coefficient vectors; the BT+BV region runs once per 248 proofs, one byte column per proof)",
+                "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic_of("traffic_evalmm.json"),
+                "launches": n_, "avg_launch_ms": avg, "busy_ms_per_launch": eff, "concurrency": avg / eff, "rows_per_launch": rows, "bytes_per_row": row_bytes_b,
+                "note": CONC_NOTE + "; algorithmic bytes = expanded row bytes, regenerated with AES on the CU (LDS T-tables): LDS-lookup / VALU bound, "
+                                    "~0 HBM bytes; the MFMA work (2 x 129448 x 256 x rows int8 ops) is a few % of the kernel",
+                "aes_gblocks_per_s": gblk_, "lds_lookup_roofline": {"achieved_gblocks_per_s": gblk_, "peak_gblocks_per_s": lds_peak_b, "frac": gblk_ / lds_peak_b},
+                "mfma_int8_tops": 2.0 * 129448 * 256 * rows / (eff * 1e-3) / 1e12}
+
+    def expand_info(kt, steps_=None):
+        n_, ms_, rows_, busy_, _ = kt
+        if not n_:
+            return None
+        avg, rows = ms_ / n_, rows_ / n_
+        gblk_ = rows * (p.ctr_ct / 16.0) / (avg * 1e-3) / 1e9
+        return {"kernel": "k_evalmm16<MODE 1> (AES-256-CTR expansion of a CRS region, written once per call in MFMA A-fragment order)", "launches": n_,
+                "avg_launch_ms": avg, "rows_per_launch": rows, "ms_per_step": ms_ / (steps_ or args.steps), "aes_gblocks_per_s": gblk_,
+                "lds_lookup_roofline": {"achieved_gblocks_per_s": gblk_, "peak_gblocks_per_s": lds_peak_b, "frac": gblk_ / lds_peak_b},
+                "write_gbs": rows * tile_bytes_per_row / (avg * 1e-3) / 1e9}
+
     # ---- batch mode: --batch statements per GPU per step through mfh_prove_batch (disjoint statements per rank, no collective)
     batched = None
-    if mode == "batch":
+    if mode == "batch" and not (big and world > 1):  # (the 2^20-constraint image only fits sharded: with N > 1 the row-sharded leg below is the headline)
         nb = args.batch
         brng = np.random.default_rng(1000 + rank)  # every rank proves its own statements: same witness, its own deltas and smudging
         b_delta = [int(x) for x in brng.integers(0, mf.P, size=nb, dtype=np.uint64)]
@@ -318,16 +433,6 @@ def main():
         b_valid = [i % 2 == 0 for i in range(nb)]
         b_bits = [inst["bits"] if b_valid[i] else brng.bytes(len(inst["bits"])) for i in range(nb)]
         d_ssp_b = inst["d_ssp"]
-        row_bytes_b = (p.n + 1) * p.ctb
-        tile_bytes_per_row = (736 * 11 if p.logq == 736 else 1471 * 12) * 16  # row tiles x 16 byte positions (88 of each value's 92 bytes at 736)
-        lds_peak_b = 256 * 2.4e9 * 64 / (201 * 2.15) / 1e9
-
-        def traffic_of(name):
-            tf_ = os.path.join(ROOT, "profiles", name)
-            try:
-                return json.load(open(tf_)).get("hbm_bytes_per_launch") if os.path.exists(tf_) else None
-            except Exception:
-                return None
 
         def run_batch(out=None):
             """warm-up + args.steps timed calls of prove_batch; returns (proofs, seconds [max over ranks], per-kind kernel timings)"""
@@ -353,51 +458,6 @@ def main():
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 el = float(tt.item())
             return out, el, kt
-
-        def mmstream_roofline(kt):
-            n_, ms_, rows_, busy_, work_ = kt
-            if not n_:
-                return None
-            avg, eff, rows, work = ms_ / n_, busy_ / n_, rows_ / n_, work_ / n_
-            tops = 2.0 * 129536 * 256 * work / (eff * 1e-3) / 1e12   # int8 multiply-adds x 2 on the matrix cores (M = 129536, N = 256, K = rows)
-            gbs = rows * tile_bytes_per_row / (eff * 1e-3) / 1e9      # the launch's one pass over the image
-            return {"bound": "mfma", "kernel": "k_mmstream (A fragments of the expanded CRS streamed once per launch for 4 groups of 31 proofs -- HBM for the "
-                                               "first workgroup of a row-tile set, that XCD's L2 for the other three --, digit fragments through LDS, "
-                                               "i8 MFMA 16x16x64)",
-                    "achieved": tops, "peak": MFMA_I8_PEAK_TOPS, "unit": "TFLOP/s", "frac": tops / MFMA_I8_PEAK_TOPS, "traffic": traffic_of("traffic_mmstream.json"),
-                    "launches": n_, "avg_launch_ms": avg, "busy_ms_per_launch": eff, "concurrency": avg / eff, "rows_per_launch": rows,
-                    "groups_per_launch": work / rows, "note": CONC_NOTE.replace("algorithmic bytes", "int8 operations"),
-                    "hbm": {"bytes_read_per_row": tile_bytes_per_row, "achieved_gbs": gbs, "peak_gbs": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS,
-                            "fragment_gbs_consumed_incl_l2": gbs * work / rows},
-                    "clock_note": "the chip holds ~1.5 GHz under this load (GRBM_GUI_ACTIVE / 8 / duration, DESIGN.md 4.2c); a bare register-only loop "
-                                  "of this MFMA sustains ~4050 TOPS (tools/mfma_i8_rate.hip)"}
-
-        def evalmm16_roofline(kt):
-            n_, ms_, rows_, busy_, _ = kt
-            if not n_:
-                return None
-            avg, eff, rows = ms_ / n_, busy_ / n_, rows_ / n_
-            gbs = rows * row_bytes_b / (eff * 1e-3) / 1e9
-            gblk_ = rows * (p.ctr_ct / 16.0) / (eff * 1e-3) / 1e9
-            return {"bound": "hbm", "kernel": "k_evalmm16 (AES-256-CTR expansion of the rows, once per group of 31 proofs, + i8 MFMA multiply-accumulate of the "
-                                              "group's 62 coefficient vectors; the BT+BV region runs once per 248 proofs, one byte column per proof)",
-                    "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic_of("traffic_evalmm.json"),
-                    "launches": n_, "avg_launch_ms": avg, "busy_ms_per_launch": eff, "concurrency": avg / eff, "rows_per_launch": rows, "bytes_per_row": row_bytes_b,
-                    "note": CONC_NOTE + "; algorithmic bytes = expanded row bytes, regenerated with AES on the CU (LDS T-tables): LDS-lookup / VALU bound, "
-                                        "~0 HBM bytes; the MFMA work (2 x 129448 x 256 x rows int8 ops) is a few % of the kernel",
-                    "aes_gblocks_per_s": gblk_, "lds_lookup_roofline": {"achieved_gblocks_per_s": gblk_, "peak_gblocks_per_s": lds_peak_b, "frac": gblk_ / lds_peak_b},
-                    "mfma_int8_tops": 2.0 * 129448 * 256 * rows / (eff * 1e-3) / 1e12}
-
-        def expand_info(kt):
-            n_, ms_, rows_, busy_, _ = kt
-            if not n_:
-                return None
-            avg, rows = ms_ / n_, rows_ / n_
-            gblk_ = rows * (p.ctr_ct / 16.0) / (avg * 1e-3) / 1e9
-            return {"kernel": "k_evalmm16<MODE 1> (AES-256-CTR expansion of a CRS region, written once per call in MFMA A-fragment order)", "launches": n_,
-                    "avg_launch_ms": avg, "rows_per_launch": rows, "ms_per_step": ms_ / args.steps, "aes_gblocks_per_s": gblk_,
-                    "lds_lookup_roofline": {"achieved_gblocks_per_s": gblk_, "peak_gblocks_per_s": lds_peak_b, "frac": gblk_ / lds_peak_b},
-                    "write_gbs": rows * tile_bytes_per_row / (avg * 1e-3) / 1e9}
 
         # headline: the CRS expanded once per call (= per step) into a transient image, streamed for every group of 31 proofs
         out_b, el_b, kt_b = run_batch()
@@ -445,13 +505,76 @@ def main():
             del image_mm, out_r
             resident_b = {"value": world * nb * args.steps / el_rb, "unit": "proofs/s", "ms_per_step": el_rb / args.steps * 1e3,
                           "proofs_identical_to_headline": same_rb, "crs_expand_s": expand_mm_s, "image_bytes_per_rank": img_bytes,
-                          "roofline": mmstream_roofline(kt_r["evalmm_resident"])}
+                          "roofline": mmstream_roofline(kt_r["evalmm_resident"], el_rb / args.steps * 1e3)}
         used_image = kt_b["evalmm_resident"][0] > 0
         batched = {"value": world * nb * args.steps / el_b, "unit": "proofs/s", "ms_per_step": el_b / args.steps * 1e3, "statements_per_gpu_per_step": nb,
                    "valid_accepted_invalid_rejected_and_identical_to_single_proof_path": all_ok, "resident_crs": resident_b,
                    "regenerate_per_group": regen, "device_verifier_proofs_per_s": verify_per_s,
                    "transient_image_bytes_per_rank": image_bytes if used_image else 0, "crs_expansion": expand_info(kt_b["expandmm"]),
-                   "roofline": mmstream_roofline(kt_b["evalmm_resident"]) if used_image else evalmm16_roofline(kt_b["evalmm"])}
+                   "roofline": mmstream_roofline(kt_b["evalmm_resident"], el_b / args.steps * 1e3) if used_image else evalmm16_roofline(kt_b["evalmm"])}
+
+    # ---- N > 1: the row-sharded BATCH prover (BASELINE configs 3/4): one statement list for the whole job, CRS rows sharded over the ranks,
+    # all-to-all of the coefficient row slices + ONE reduce-scatter of uint64 lanes per step (dist.prove_batch_sharded)
+    sharded_b = None
+    if mode == "batch" and world > 1:
+        nbt = args.sharded_batch or (args.batch if not big else 248)
+        srng = np.random.default_rng(4000)  # the same statements on every rank
+        s_delta = [int(x) for x in srng.integers(0, mf.P, size=nbt, dtype=np.uint64)]
+        s_mags = [srng.integers(0, 256, size=5 * 80, dtype=np.uint8).tobytes() for _ in range(nbt)]
+        s_signs = [bytes(srng.integers(0, 2, size=5, dtype=np.uint8).tolist()) for _ in range(nbt)]
+        s_valid = [i % 2 == 0 for i in range(nbt)]
+        s_bits = [inst["bits"] if s_valid[i] else srng.bytes(len(inst["bits"])) for i in range(nbt)]
+        sbufs = {}
+        sh_steps = min(args.steps, 10 if not big else 3)
+
+        def sharded_step():
+            return mfdist.prove_batch_sharded(ctx, d_crs, inst["d_ssp"], s_bits, s_delta, s_mags, s_signs, rank, world, bufs=sbufs)
+
+        for _ in range(max(args.warmup, 1) if not big else 1):
+            s_first, s_count, s_pr = sharded_step()
+        ctx.set_timing(True)
+        for k in ("evalmm", "evalmm_resident", "expandmm"):
+            ctx.timing_drain(k)
+        barrier()
+        ts = time.perf_counter()
+        for _ in range(sh_steps):
+            s_first, s_count, s_pr = sharded_step()
+        barrier()
+        el_s = time.perf_counter() - ts
+        ctx.set_timing(False)
+        kt_s = {}
+        for k in ("evalmm", "evalmm_resident", "expandmm"):
+            n_, ms_, rows_ = ctx.timing_drain(k)
+            kt_s[k] = (n_, ms_, rows_, ctx.timing_busy_ms(), ctx.timing_work_rows())
+        tt = torch.tensor([el_s], dtype=torch.float64, device=ctx.device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el_s = float(tt.item())
+        ok_s = True
+        if s_count:  # the rank's own proofs: accepted / rejected as the witnesses demand, and the first one bit for bit against prover()
+            okv = ctx.to_host(ctx.verify(inst["d_ssp"], inst["alpha"], inst["beta"], inst["s"], inst["sk"], s_pr, s_count))
+            ok_s = [bool(int(x)) for x in okv] == s_valid[s_first:s_first + s_count]
+            one = ctx.prove(d_crs, inst["d_ssp"], s_bits[s_first], s_delta[s_first], s_mags[s_first], s_signs[s_first])
+            ok_s = ok_s and bool(torch.equal(s_pr.view(s_count, -1)[0], one))
+        ta = torch.tensor([1 if ok_s else 0], dtype=torch.int64, device=ctx.device)
+        dist.all_reduce(ta, op=dist.ReduceOp.MIN)
+        ok_s = bool(int(ta.item()))
+        per_s = -(-nbt // world)
+        lps = 5 * (p.n + 1) * 2 * p.K
+        share_img = int(ctx.lib.mfh_crs_mm_share_bytes(ctx._h, rank, world))
+        sharded_b = {"value": nbt * sh_steps / el_s, "unit": "proofs/s", "scaling": "strong", "steps": sh_steps, "ms_per_step": el_s / sh_steps * 1e3,
+                     "statements_per_step_whole_job": nbt, "ranks": world, "backend": backend + (" (RCCL)" if backend == "nccl" else " (host-staged rehearsal)"),
+                     "own_proofs_accepted_rejected_as_expected_and_identical_to_prover": ok_s,
+                     "collectives_per_step": [
+                         {"op": "all_to_all_single", "what": "rows [d r/N, d (r+1)/N) of w | h | v of every statement to rank r",
+                          "bytes_sent_per_rank": per_s * 3 * 4 * (p.d - p.d // world)},
+                         {"op": "reduce_scatter_tensor(sum, int64 lanes)", "what": "one uint64 lane per surviving 32-bit word of the 5 partial ciphertexts of every statement",
+                          "input_bytes_per_rank": per_s * world * lps * 8, "output_bytes_per_rank": per_s * lps * 8}],
+                     "image_share_bytes_per_rank": share_img,
+                     "image": "transient: every call expands the rank's row shares (AES on the CU) inside the timed region" if kt_s["expandmm"][0] else
+                              ("regenerated per group" if kt_s["evalmm"][0] else "resident"),
+                     "roofline": mmstream_roofline(kt_s["evalmm_resident"], el_s / sh_steps * 1e3, sh_steps) if kt_s["evalmm_resident"][0] else None,
+                     "crs_expansion": expand_info(kt_s["expandmm"], sh_steps)}
+        del sbufs, s_pr
 
     # ---- LWE batch (BASELINE config 1/2: one batch of 65 536 encryptions, rows at stream offset k*135240)
     enc_per_s = None
@@ -462,10 +585,30 @@ def main():
         outB = ctx.empty(B * p.ctb)
         ctx.encrypt_rows(0, B, inst["sk"], msg, errB, out=outB)
         torch.cuda.synchronize()
+        ctx.set_timing(True)
+        ctx.timing_drain("encrypt")
         t1 = time.perf_counter()
-        ctx.encrypt_rows(0, B, inst["sk"], msg, errB, out=outB)
+        for _ in range(3):
+            ctx.encrypt_rows(0, B, inst["sk"], msg, errB, out=outB)
         torch.cuda.synchronize()
-        enc_per_s = B / (time.perf_counter() - t1)
+        enc_per_s = 3 * B / (time.perf_counter() - t1)
+        ctx.set_timing(False)
+        en_, ems_, _ = ctx.timing_drain("encrypt")
+        enc_launch_ms = ems_ / max(en_, 1)
+        enc_kernel = "k_encrypt (fused AES-256-CTR row expansion + <sk, a> + e p + m)"
+
+    lwe = None
+    if enc_per_s is not None:
+        enc_gbs = enc_per_s * (p.n + 1) * p.ctb / 1e9
+        enc_gblk = enc_per_s * (p.ctr_ct / 16.0) / 1e9
+        lwe = {"metric": "lwe_enc_per_s", "value": enc_per_s, "unit": "enc/s", "batch": B, "ms_per_batch": B / enc_per_s * 1e3,
+               "workload": "benchmark_lwe parameters (N=1470, logq=%d): one batch of %d regev_encrypt2 + ct_export, row k at stream offset k*CTR_CT" % (p.logq, B),
+               "roofline": {"bound": "hbm", "kernel": enc_kernel, "achieved": enc_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": enc_gbs / HBM_PEAK_GBS, "traffic": None,
+                            "bytes_per_unit": (p.n + 1) * p.ctb, "avg_launch_ms": enc_launch_ms,
+                            "note": "algorithmic bytes = the expanded row (SURVEY 8(d)); the kernel regenerates them with AES on the CU and writes 92 B per "
+                                    "encryption: LDS-lookup bound, ~0 HBM bytes",
+                            "aes_gblocks_per_s": enc_gblk,
+                            "lds_lookup_roofline": {"achieved_gblocks_per_s": enc_gblk, "peak_gblocks_per_s": lds_peak_b, "frac": enc_gblk / lds_peak_b}}}
 
     # ---- CPU baseline: the oracle's reference-faithful row touch (ct_import + ct_addmul_ui), one thread
     cpu = None
@@ -483,6 +626,29 @@ def main():
                "sample": f"{args.cpu_rows} prover row-touches (ct_import + ct_addmul_ui, one AES block per call) of the oracle in {cpu_s:.1f} s "
                          f"= {rows_per_s:.0f} rows/s, scaled to the reference prover's {ref_rows} row-touches; h=(v^2-1)/t excluded",
                "rows_per_s": rows_per_s}
+        # the reference is single-threaded by construction; its rows are independent, so an N-process run is the fair many-core figure
+        # (SURVEY 8(d)): every usable core runs its own bounded sample at the same time
+        ncores = usable_cores()
+        if ncores > 1:
+            import multiprocessing as mpx
+
+            rows_each = max(2000, args.cpu_rows // 4)
+            with mpx.get_context("spawn").Pool(ncores) as pool:
+                a0 = time.perf_counter()
+                times = pool.map(_cpu_rows_worker, [(p.d, p.m, p.logq, seed, rows_each)] * ncores)
+                wall = time.perf_counter() - a0
+            agg = sum(rows_each / t for t in times)
+            cpu["all_cores"] = {"value": agg / ref_rows, "unit": "proofs/s", "cores": ncores, "kind": "port", "rows_per_s": agg,
+                                "sample": f"{ncores} processes x {rows_each} row-touches each, concurrently ({wall:.1f} s wall incl. process start); "
+                                          f"sum of the per-process rates", "slowest_process_s": max(times)}
+        # LWE encryption on one core (src/benchmark_lwe.c:28-33): regev_encrypt2 of the oracle, own AES + truncated 704-bit dot product
+        o.bench_encrypt(p, seed, 50)
+        e0 = time.perf_counter()
+        n_enc = 6000
+        o.bench_encrypt(p, seed, n_enc)
+        es = time.perf_counter() - e0
+        cpu["lwe_encrypt"] = {"value": n_enc / es, "unit": "enc/s", "cores": 1, "kind": "port",
+                              "sample": f"{n_enc} regev_encrypt2 calls of the oracle (row expansion + <sk,a> + e p + m) in {es:.1f} s"}
         # calibration against the REAL reference where its build travelled (oracle/_ref = reference src/aes.c + src/entropy.c):
         # its keystream generator is ~97 % of a reference prover row, so this bounds the reference's rows/s.
         ref_so = os.path.join(ROOT, "oracle", "_ref", "libmfref.so")
@@ -521,6 +687,11 @@ def main():
                 "ms_per_step": elapsed / single_steps * 1e3, "proof_accepted": bool(accepted),
                 "sharding": ((f"CRS rows over {world} rank(s), 2 lane all-reduces per proof" if by_rows else f"{world} independent provers, no collective")
                              if world > 1 else "single GPU"),
+                "scaling": "strong" if (by_rows and world > 1) else ("weak" if world > 1 else None),
+                "collectives_per_proof": ([{"op": "all_reduce(sum, int64 lanes)", "what": "this rank's share of sum_bits v_i: the witness polynomial", "bytes": p.d * 8},
+                                           {"op": "all_reduce(sum, int64 lanes)", "what": "the five partial ciphertexts, one lane per surviving 32-bit word",
+                                            "bytes": 5 * (p.n + 1) * 2 * p.K * 8}] if (by_rows and world > 1) else []),
+                "ranks": world, "backend": (backend + (" (RCCL)" if backend == "nccl" else " (host-staged rehearsal)")) if world > 1 else None,
                 "roofline": {"bound": "hbm", "kernel": f"k_eval<{p.logq},2> (fused AES-256-CTR expansion + 2x MAC, S and AS regions)",
                              "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                              "traffic": traffic, "launches": n2, "avg_launch_ms": avg_ms, "rows_per_launch": launch_rows, "bytes_per_row": row_bytes,
@@ -537,7 +708,15 @@ def main():
                          "CRS, keystream regenerated in the timed region") if not big else (
                              f"BASELINE {args.workload}: D=2^20, M=699050, N=1470, logq={p.logq}, generator-defined SSP; full prover() from the "
                              "compressed CRS, keystream regenerated in the timed region")
-        if mode == "batch":
+        if mode == "batch" and batched is None:  # 2^20-constraint workloads on N > 1 ranks: the row-sharded batch prover is the job
+            head = {"value": sharded_b["value"], "ms_per_step": sharded_b["ms_per_step"], "scaling": "strong", "roofline": sharded_b["roofline"],
+                    "proof_accepted": sharded_b["own_proofs_accepted_rejected_as_expected_and_identical_to_prover"],
+                    "config": {"workload": base_workload + f"; a step = {sharded_b['statements_per_step_whole_job']} statements for the whole job through the row-sharded batch "
+                                           "prover: every rank expands and streams only its row shares of the matrix-core image, chain per statement slab, "
+                                           "all-to-all of the coefficient row slices, one reduce-scatter of uint64 lanes per step",
+                               "rows_per_proof": rows_crs, "sharding": f"CRS rows over {world} ranks"}}
+            ok_all = head["proof_accepted"] and bool(accepted)
+        elif mode == "batch":
             head = {"value": batched["value"], "ms_per_step": batched["ms_per_step"], "scaling": "weak", "roofline": batched["roofline"],
                     "proof_accepted": batched["valid_accepted_invalid_rejected_and_identical_to_single_proof_path"],
                     "config": {"workload": base_workload + f"; a step = {args.batch} statements per GPU (same circuit and CRS; half with the satisfying witness, half with random ones; own randomness) through "
@@ -546,7 +725,7 @@ def main():
                                            "the single-proof prover()'s",
                                "rows_per_proof": rows_crs, "statements_per_gpu_per_step": args.batch,
                                "sharding": f"{world} ranks, disjoint statements, no collective" if world > 1 else "single GPU"}}
-            ok_all = head["proof_accepted"] and bool(accepted)
+            ok_all = head["proof_accepted"] and bool(accepted) and (sharded_b is None or sharded_b["own_proofs_accepted_rejected_as_expected_and_identical_to_prover"])
         else:
             head = {"value": single["value"], "ms_per_step": single["ms_per_step"], "scaling": "strong" if by_rows else "weak",
                     "roofline": single["roofline"], "proof_accepted": bool(accepted),
@@ -577,11 +756,13 @@ def main():
             "setup_s": setup_s,
             "setup_enc_per_s": rows_crs / setup_s,
             "roofline": head["roofline"],
-            "crs_expansion": batched["crs_expansion"] if mode == "batch" else None,
-            "transient_image_bytes_per_rank": batched["transient_image_bytes_per_rank"] if mode == "batch" else None,
-            "regenerate_per_group_batch": batched["regenerate_per_group"] if mode == "batch" else None,
-            "resident_crs_batch": batched["resident_crs"] if mode == "batch" else None,
-            "device_verifier_proofs_per_s": batched["device_verifier_proofs_per_s"] if mode == "batch" else None,
+            "crs_expansion": batched["crs_expansion"] if batched else None,
+            "transient_image_bytes_per_rank": batched["transient_image_bytes_per_rank"] if batched else None,
+            "regenerate_per_group_batch": batched["regenerate_per_group"] if batched else None,
+            "resident_crs_batch": batched["resident_crs"] if batched else None,
+            "device_verifier_proofs_per_s": batched["device_verifier_proofs_per_s"] if batched else None,
+            "row_sharded_batch": sharded_b,
+            "lwe": lwe,
             "single_proof": single if mode == "batch" else None,
             "eval1": single["eval1"] if mode == "single" else None,
             "resident_crs": resident if mode == "single" else None,

@@ -93,6 +93,8 @@ struct mfh_ctx {
   size_t batch_img_bytes = 0;
   int batch_image = 1;
   uint32_t mm_chunk_rows = 131071;  // rows per row chunk of the matrix-core launches (int32 accumulators: |A'C'| <= 2^14 per row)
+  int enc_path = 0;        // mfh_encrypt_rows: 0 = pick by batch size, 1 = VALU kernel (k_encrypt), 2 = matrix-core kernel (k_encrypt_mm)
+  int batch_merge = 1;     // the S and AS groups of a round in one streaming launch (0: two launches on two streams)
   uint32_t batch_ngl = 4;  // groups of 31 proofs per streaming launch over the image (1..8)
   PinBuf pin_rows, pin_cw, pin_smudge;
   // generator-defined SSP (ssp_prg.hpp): used by every entry point that is handed d_ssp == NULL
@@ -161,6 +163,8 @@ extern "C" int mfh_witness_poly_mm(mfh_ctx *c, const uint32_t *d_ssp, uint32_t n
                                    uint32_t *d_w);
 extern "C" int mfh_poly_h_multi(mfh_ctx *c, const uint32_t *d_v, uint32_t *d_h, uint32_t nb);
 int aux_reserve(mfh_ctx *c, size_t bytes);
+// encmm.hip: mfh_encrypt_rows with <sk, a> on the matrix cores (off and the row length multiples of 8)
+int encrypt_rows_mm(mfh_ctx *c, uint64_t off, size_t nrows, const uint64_t *sk, const uint32_t *msg, const uint64_t *err, uint8_t *c8);
 
 // Operands of one multi-vector launch (evalmm.hip): coefficient vector v is coef[0] + v * nrows for v < csplit, else
 // coef[1] + (v - csplit) * nrows; its result goes to out[0] + v * ostride for v < osplit, else out[1] + (v - osplit) * ostride
@@ -188,6 +192,11 @@ int eval_rows_multi_io(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d_
 // ng of them over the same region in one streaming launch when the matrix-core image is registered (io.sc_zeroed required); else one by one
 int eval_rows_multi_io_set(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d_c8, const MmIo *ios, const uint32_t *nvecs, uint32_t ng,
                            uint32_t coeff_bytes);
+// the same over nreg <= 2 regions of equal row count in ONE streaming launch: group r * ng + k evaluates region r with ios[r * ng + k]
+struct MmRegion { uint64_t off; const uint8_t *c8; };
+int eval_rows_multi_io_regions(mfh_ctx *c, const MmRegion *regs, uint32_t nreg, size_t nrows, const MmIo *ios, const uint32_t *nvecs, uint32_t ng,
+                               uint32_t coeff_bytes);
+bool mm_image_covers(const mfh_ctx *c, uint64_t off, size_t nrows);
 
 inline int buf_reserve(mfh_ctx *c, void *&buf, size_t &have, size_t bytes) {
   if (bytes <= have) return MFH_OK;

@@ -499,7 +499,8 @@ constexpr int CH = NQ2 / CG;      // column tiles per wave
 // part_stride): workgroups b and b + 8 -- dispatched back to back onto the same XCD (blocks go round-robin over the 8 XCDs) -- take the
 // same 16 row tiles for consecutive groups, so the second one's A fragments come out of that XCD's L2 (or the Infinity Cache) instead
 // of HBM: the image is read from HBM once per ng groups.  grid.x = 8 ng ceil(tile groups / 8).
-__global__ __launch_bounds__(SW * 64) void k_mmstream(const v4i *__restrict__ image, uint32_t mtiles, uint32_t KS, uint32_t nrows,
+struct MmsImages { const v4i *image[16]; };  // the region image each group of a launch streams (S and AS groups share one launch)
+__global__ __launch_bounds__(SW * 64) void k_mmstream(MmsImages imgs, uint32_t mtiles, uint32_t KS, uint32_t nrows,
                                                       uint32_t rows_per_chunk, const v4i *__restrict__ cdv, int *__restrict__ part, uint32_t ng,
                                                       uint64_t cd_stride /* v4i */, uint64_t part_stride /* int */) {
   __shared__ v4i bfrag[2][RT2 / 64][NQ2][64];  // 2 x 64 KiB
@@ -509,6 +510,7 @@ __global__ __launch_bounds__(SW * 64) void k_mmstream(const v4i *__restrict__ im
   const uint32_t rq = wave % RG, ch = wave / RG;
   const uint32_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, grp = slot % ng, tg = (slot / ng) * 8 + xcd;  // tile group = 16 row tiles
   if (tg * 16 >= mtiles) return;  // (uniform)
+  const v4i *__restrict__ image = imgs.image[grp];
   cdv += grp * cd_stride;
   part += grp * part_stride;
   const uint32_t mt0 = (tg * RG + rq) * RQ;  // this wave's row tiles (with CG > 1 the waves rq and rq + RG read the same A fragments)
@@ -863,7 +865,9 @@ int eval_rows_multi_io(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d_
     Timer t(c, img_region ? 8 : 7, nrows);
     if (img_region) {
       const uint32_t mtiles = ntiles * wg.mt, KS = ((uint32_t)nrows + RT2 - 1) / RT2 * (RT2 / 64);
-      hipLaunchKernelGGL(k_mmstream, dim3(((mtiles + 2 * SW - 1) / (2 * SW) + 7) / 8 * 8, nchunks), dim3(SW * 64), 0, c->stream, (const v4i *)img_region,
+      MmsImages imgs{};
+      imgs.image[0] = (const v4i *)img_region;
+      hipLaunchKernelGGL(k_mmstream, dim3(((mtiles + 2 * SW - 1) / (2 * SW) + 7) / 8 * 8, nchunks), dim3(SW * 64), 0, c->stream, imgs,
                          mtiles, KS, (uint32_t)nrows, rpc, (const v4i *)cd, part, 1u, (uint64_t)0, (uint64_t)0);
     } else if (wide && q736)
       hipLaunchKernelGGL((k_evalmm16<0, 736>), dim3(ntiles, nchunks), dim3(1024), 0, c->stream, keyx, c->d_t0, off, n, (uint32_t)nrows, rpc, d_c8, cd, part,
@@ -891,20 +895,26 @@ int eval_rows_multi_io(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d_
   return MFH_OK;
 }
 
-// ng evaluations over the SAME region of the registered image in one k_mmstream launch (the image is then read from HBM once for all of
-// them, see k_mmstream); anything else -- no image, a single evaluation, 128-column shapes -- falls back to ng separate evaluations.
-int eval_rows_multi_io_set(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d_c8, const MmIo *ios, const uint32_t *nvecs, uint32_t ng,
-                           uint32_t coeff_bytes) {
-  if (!c || !ios || !nvecs || !ng) return MFH_EINVAL;
-  const uint8_t *img_region = nullptr;
-  for (int r = 0; r < 3 && c->mm_image; r++)
-    if (c->mm_off[r] == off && c->mm_rows[r] == nrows && nrows) img_region = c->mm_image + c->mm_base[r];
-  bool ok = img_region && ng > 1 && c->have_seed && nrows <= 0xffffffffu - 256;
-  for (uint32_t g = 0; g < ng && ok; g++)
+// ng evaluations over each of nreg regions (same row count) of the registered image in ONE k_mmstream launch: group r * ng + k streams
+// region r with operands ios[r * ng + k] (the image is then read from HBM once for the ng groups of a region, see k_mmstream; the S and
+// AS groups of the batch prover share a launch so that no two launches of the kernel overlap).  Anything else -- no image, a single
+// evaluation, 128-column shapes -- falls back to separate evaluations, region by region.
+int eval_rows_multi_io_regions(mfh_ctx *c, const MmRegion *regs, uint32_t nreg, size_t nrows, const MmIo *ios, const uint32_t *nvecs, uint32_t ng,
+                               uint32_t coeff_bytes) {
+  if (!c || !regs || !ios || !nvecs || !ng || !nreg || nreg * ng > 16) return MFH_EINVAL;
+  const uint8_t *img_region[2] = {nullptr, nullptr};
+  bool ok = nreg <= 2 && nreg * ng > 1 && c->have_seed && nrows && nrows <= 0xffffffffu - 256;
+  for (uint32_t q = 0; q < nreg && ok; q++) {
+    for (int r = 0; r < 3 && c->mm_image; r++)
+      if (c->mm_off[r] == regs[q].off && c->mm_rows[r] == nrows) img_region[q] = c->mm_image + c->mm_base[r];
+    ok = img_region[q] != nullptr;
+  }
+  const uint32_t ngt = nreg * ng;
+  for (uint32_t g = 0; g < ngt && ok; g++)
     ok = nvecs[g] && nvecs[g] * coeff_bytes + 1 <= 256 && ios[g].out[0] && ios[g].sc_zeroed && (ios[g].bits || ios[g].coef[0]);
   if (!ok) {
-    for (uint32_t g = 0; g < ng; g++) {
-      int rc = eval_rows_multi_io(c, off, nrows, d_c8, ios[g], nvecs[g], coeff_bytes, 0);
+    for (uint32_t g = 0; g < ngt; g++) {
+      int rc = eval_rows_multi_io(c, regs[g / ng].off, nrows, regs[g / ng].c8, ios[g], nvecs[g], coeff_bytes, 0);
       if (rc) return rc;
     }
     return MFH_OK;
@@ -920,22 +930,24 @@ int eval_rows_multi_io_set(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t
   const uint32_t rpad = nchunks * rpc;
   const size_t cd_bytes = ((size_t)N2 * rpad + 255) & ~(size_t)255;
   const size_t part_bytes = ((size_t)nchunks * ntiles * wg.mbp * N2 * 4 + 255) & ~(size_t)255;
-  int rc = c->mm_ws_sel ? ws2_reserve(c, ng * (cd_bytes + part_bytes)) : ws_reserve(c, ng * (cd_bytes + part_bytes));
+  int rc = c->mm_ws_sel ? ws2_reserve(c, ngt * (cd_bytes + part_bytes)) : ws_reserve(c, ngt * (cd_bytes + part_bytes));
   if (rc) return rc;
   uint8_t *wsp = (uint8_t *)(c->mm_ws_sel ? c->ws2 : c->ws);
   int8_t *cd = (int8_t *)wsp;
-  int *part = (int *)(wsp + ng * cd_bytes);
-  for (uint32_t g = 0; g < ng; g++)
+  int *part = (int *)(wsp + ngt * cd_bytes);
+  for (uint32_t g = 0; g < ngt; g++)
     hipLaunchKernelGGL(k_mm_digits, dim3((rpad / 16 + DG_RG - 1) / DG_RG), dim3(N2), 0, c->stream, ios[g], nvecs[g], ND, (uint32_t)nrows, rpad, (uint32_t)NQ2, 1,
                        cd + g * cd_bytes, ios[g].sc_zeroed);
   {
-    Timer t(c, 8, nrows, (uint64_t)nrows * ng);
+    Timer t(c, 8, nrows, (uint64_t)nrows * ngt);
     const uint32_t KS = ((uint32_t)nrows + RT2 - 1) / RT2 * (RT2 / 64), tgs = (mtiles + 2 * SW - 1) / (2 * SW);
-    hipLaunchKernelGGL(k_mmstream, dim3((tgs + 7) / 8 * 8 * ng, nchunks), dim3(SW * 64), 0, c->stream, (const v4i *)img_region, mtiles, KS, (uint32_t)nrows, rpc,
-                       (const v4i *)cd, part, ng, (uint64_t)(cd_bytes / 16), (uint64_t)(part_bytes / 4));
+    MmsImages imgs{};
+    for (uint32_t g = 0; g < ngt; g++) imgs.image[g] = (const v4i *)img_region[g / ng];
+    hipLaunchKernelGGL(k_mmstream, dim3((tgs + 7) / 8 * 8 * ngt, nchunks), dim3(SW * 64), 0, c->stream, imgs, mtiles, KS, (uint32_t)nrows, rpc,
+                       (const v4i *)cd, part, ngt, (uint64_t)(cd_bytes / 16), (uint64_t)(part_bytes / 4));
   }
   HIP_TRY(c, hipGetLastError());
-  for (uint32_t g = 0; g < ng; g++) {
+  for (uint32_t g = 0; g < ngt; g++) {
     const dim3 fgrid(n + 1, (nvecs[g] + 63) / 64);
     int *pg = part + g * (part_bytes / 4);
     if (ND == 4)
@@ -947,6 +959,17 @@ int eval_rows_multi_io_set(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t
   }
   HIP_TRY(c, hipGetLastError());
   return MFH_OK;
+}
+int eval_rows_multi_io_set(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d_c8, const MmIo *ios, const uint32_t *nvecs, uint32_t ng,
+                           uint32_t coeff_bytes) {
+  const MmRegion reg = {off, d_c8};
+  return eval_rows_multi_io_regions(c, &reg, 1, nrows, ios, nvecs, ng, coeff_bytes);
+}
+// true when mfh_eval_rows_multi over nrows rows at stream offset off would stream the registered image
+bool mm_image_covers(const mfh_ctx *c, uint64_t off, size_t nrows) {
+  for (int r = 0; r < 3 && c->mm_image; r++)
+    if (c->mm_off[r] == off && c->mm_rows[r] == nrows && nrows) return true;
+  return false;
 }
 
 extern "C" {

@@ -573,22 +573,32 @@ int batch_rows_supergroup(mfh_ctx *c, const uint8_t *d_crs_c8, uint32_t rank, ui
   // groups per launch measured 2 % and 1 % slower, 1 group 10 % slower)
   constexpr uint32_t NGLMAX = 8;
   const uint32_t NGL = c->mm_image ? c->batch_ngl : 1u;
+  const MmRegion regs[2] = {{ctr_ct * loS, d_crs_c8 + (size_t)loS * ctb}, {ctr_ct * ((uint64_t)d + loS), d_crs_c8 + ((size_t)d + loS) * ctb}};
+  // image registered for both regions: the S and the AS groups of a round share ONE streaming launch (no two launches of the kernel overlap:
+  // one region's fragments at a time in the L2s); otherwise two streams, so that one stream's small kernels run under the other's row kernel
+  const bool merged = mm_image_covers(c, regs[0].off, cS) && mm_image_covers(c, regs[1].off, cS) && c->batch_merge;
   for (uint32_t g0 = 0; g0 < sg; g0 += NGL * BG) {
-    MmIo io_s[NGLMAX], io_as[NGLMAX];
-    uint32_t nv[NGLMAX], ng = 0;
-    for (uint32_t k = 0; k < NGL && g0 + k * BG < sg; k++, ng++) {
+    MmIo io[2 * NGLMAX];
+    uint32_t nv[2 * NGLMAX], ng = 0;
+    for (uint32_t k = 0; k < NGL && g0 + k * BG < sg; k++) ng++;
+    for (uint32_t k = 0; k < ng; k++) {
       const uint32_t gg = g0 + k * BG, g = std::min(BG, sg - gg);
       uint64_t *proofs = sproofs + (size_t)gg * 5 * ctl;
       const uint64_t o = (uint64_t)gg * co.stride;
-      io_s[k] = MmIo{{co.w + o, co.h + o}, g, {proofs + 3 * ctl, proofs}, g, pstride, nullptr, 0, B.SCZ + 256 * slot++, co.stride, 0};             // (w, h) -> (v_w, h)
-      io_as[k] = MmIo{{co.h + o, co.v + o}, g, {proofs + ctl, proofs + 2 * ctl}, g, pstride, nullptr, 0, B.SCZ + 256 * slot++, co.stride, 0};  // (h, v) -> (hat_h, hat_v)
-      nv[k] = 2 * g;
+      io[k] = MmIo{{co.w + o, co.h + o}, g, {proofs + 3 * ctl, proofs}, g, pstride, nullptr, 0, B.SCZ + 256 * slot++, co.stride, 0};                 // S: (w, h) -> (v_w, h)
+      io[ng + k] = MmIo{{co.h + o, co.v + o}, g, {proofs + ctl, proofs + 2 * ctl}, g, pstride, nullptr, 0, B.SCZ + 256 * slot++, co.stride, 0};  // AS: (h, v) -> (hat_h, hat_v)
+      nv[k] = nv[ng + k] = 2 * g;
     }
-    rc = eval_rows_multi_io_set(c, ctr_ct * loS, cS, d_crs_c8 + (size_t)loS * ctb, io_s, nv, ng, 4);
+    if (merged) {
+      rc = eval_rows_multi_io_regions(c, regs, 2, cS, io, nv, ng, 4);
+      if (rc) return rc;
+      continue;
+    }
+    rc = eval_rows_multi_io_regions(c, regs, 1, cS, io, nv, ng, 4);
     if (rc) return rc;
     {
       OnSide side(c, side_stream);
-      rc = eval_rows_multi_io_set(c, ctr_ct * ((uint64_t)d + loS), cS, d_crs_c8 + ((size_t)d + loS) * ctb, io_as, nv, ng, 4);
+      rc = eval_rows_multi_io_regions(c, regs + 1, 1, cS, io + ng, nv + ng, ng, 4);
       if (rc) return rc;
     }
   }

@@ -117,6 +117,11 @@ int mfh_crs_set_resident_share(mfh_ctx *ctx, const void *d_image, uint32_t rank,
  * the reference draws 559 bits from getrandom, src/lwe.c:60-63); d_c8_out: nrows*CT_BYTES bytes. */
 int mfh_encrypt_rows(mfh_ctx *ctx, uint64_t off, size_t nrows, const uint64_t *d_sk, const uint32_t *d_msg,
                      const uint64_t *d_err, uint8_t *d_c8_out);
+/* Which kernel mfh_encrypt_rows (hence mfh_setup) uses; the results are identical.  0 (default): batches of 32 rows or more run <sk, a> on
+ * the matrix cores -- the dot product as a (rows x keystream bytes) x Toeplitz(sk) int8 GEMM, each lane's AES output block being an MFMA
+ * operand as it stands -- when off and n * CT_BYTES are multiples of 8, anything else the VALU kernel; 1: always the VALU kernel;
+ * 2: always the matrix-core kernel (MFH_EINVAL from mfh_encrypt_rows if the alignment does not allow it). */
+int mfh_set_encrypt_path(mfh_ctx *ctx, int path);
 
 /* Batched regev_decrypt (src/lwe.c:105-111) of `count` explicit ciphertexts: d_out[i] = (b - <a,sk> mod 2^(64K)) mod p */
 int mfh_decrypt(mfh_ctx *ctx, const uint64_t *d_sk, const uint64_t *d_cts, size_t count, uint32_t *d_out);
@@ -201,6 +206,10 @@ int mfh_crs_set_resident_mm(mfh_ctx *ctx, const uint8_t *d_image);
  * running AES once per group; if that scratch cannot be allocated, or after mfh_set_batch_image(ctx, 0) (which also frees it), every
  * group regenerates the keystream.  Same proofs either way. */
 int mfh_set_batch_image(mfh_ctx *ctx, int enabled);
+/* launch shape of the streaming regime of mfh_prove_batch* (tuning; results do not depend on it): groups of 31 proofs served by one pass
+ * over a region's image (1..8, default 4), and whether the S and AS groups of a round share ONE launch (default) or run as two
+ * launches on two streams. */
+int mfh_set_batch_launch(mfh_ctx *ctx, uint32_t groups_per_launch, int merge_regions);
 /* rows per row chunk of the matrix-core launches (mfh_eval_rows_multi, mfh_prove_batch): the int32 accumulators hold at most
  * 131071 rows (the default; 0 restores it); smaller values split every region into more chunks -- same results (tuning, tests). */
 int mfh_set_mm_chunk_rows(mfh_ctx *ctx, uint32_t rows);

@@ -41,15 +41,24 @@ def test_sample_and_eval(setup, oracle):
         assert np.array_equal(ctx.to_host(r, np.uint64).reshape(exp.shape), exp)
 
 
-def test_encrypt_decrypt(setup, oracle):
+@pytest.mark.parametrize("path,nrows,off", [(1, 5, 0), (2, 5, 0), (2, 37, 8 + 16 * 77)])  # 2 = matrix-core kernel: 12 column tiles, >= 3 column chunks
+def test_encrypt_decrypt(setup, oracle, path, nrows, off):
     ctx, p = setup
     rng = np.random.default_rng(1)
-    nrows = 5
     sk = ol.rand_values(rng, p.n, p.L, p.logq)
     msg = rng.integers(0, ol.P, size=nrows, dtype=np.uint64)
     err = ol.rand_values(rng, nrows, p.L, 559)
     d_sk = ctx.to_device(sk)
-    c8 = ctx.encrypt_rows(0, nrows, d_sk, ctx.to_device(msg.astype(np.uint32)), ctx.to_device(err))
+    ctx.set_encrypt_path(path)
+    try:
+        c8 = ctx.encrypt_rows(off, nrows, d_sk, ctx.to_device(msg.astype(np.uint32)), ctx.to_device(err))
+    finally:
+        ctx.set_encrypt_path(0)
+    if off:
+        r = oracle.rng(SEED, off)
+        exp = b"".join(oracle.ct_export(p, oracle.encrypt(p, r, sk, int(msg[i]), err[i])) for i in range(nrows))
+        assert ctx.to_host(c8).tobytes() == exp
+        return
     r = oracle.rng(SEED, 0)
     exp = b"".join(oracle.ct_export(p, oracle.encrypt(p, r, sk, int(msg[i]), err[i])) for i in range(nrows))
     assert ctx.to_host(c8).tobytes() == exp

@@ -143,18 +143,55 @@ def test_eval_rows_empty(ctx, mf):
     assert not ctx.to_host(r0).any()
 
 
-@pytest.mark.parametrize("nrows,off_kind", [(1, "s"), (3, "s"), (5, "bv"), (33, "as")])
-def test_encrypt_rows_matches_oracle(ctx, oracle, mf, nrows, off_kind):
+@pytest.mark.parametrize("path", [1, 2])  # 1 = VALU kernel (k_encrypt), 2 = matrix-core kernel (k_encrypt_mm: <sk, a> as a Toeplitz int8 GEMM)
+@pytest.mark.parametrize("nrows,off_kind", [(1, "s"), (3, "s"), (5, "bv"), (33, "as"), (70, "odd8")])
+def test_encrypt_rows_matches_oracle(ctx, oracle, mf, nrows, off_kind, path):
     p = mf.DEBUG
-    off = {"s": p.ctr_s, "as": p.ctr_as, "bv": p.ctr_bv}[off_kind]
+    # "odd8": a stream offset that is 8 mod 16 and crosses a 256-block counter span inside the rows (the counter-mode shortcut's refresh)
+    off = {"s": p.ctr_s, "as": p.ctr_as, "bv": p.ctr_bv, "odd8": 3 * p.ctr_ct + 8 * 1001}[off_kind]
     rng = np.random.default_rng(nrows)
     sk = ol.rand_values(rng, p.n, p.L, p.logq)
+    if nrows == 3:  # extreme key digits: all-ones values (every balanced digit -1 after the first), zero, and 0x80.. / 0x7f.. bytes
+        sk[0] = ol.int_to_limbs((1 << p.logq) - 1, p.L)
+        sk[1] = 0
+        sk[2] = ol.int_to_limbs(int.from_bytes(b"\x80" * 92, "little"), p.L)
+        sk[3] = ol.int_to_limbs(int.from_bytes(b"\x7f" * 92, "little"), p.L)
     msg = rng.integers(0, ol.P, size=nrows, dtype=np.uint64)
     err = ol.rand_values(rng, nrows, p.L, 559)  # GAMMA_LOG_SIGMA + 3 bits (src/lwe.c:62)
-    got = ctx.to_host(ctx.encrypt_rows(off, nrows, ctx.to_device(sk), ctx.to_device(msg.astype(np.uint32)), ctx.to_device(err)))
+    ctx.set_encrypt_path(path)
+    try:
+        got = ctx.to_host(ctx.encrypt_rows(off, nrows, ctx.to_device(sk), ctx.to_device(msg.astype(np.uint32)), ctx.to_device(err)))
+    finally:
+        ctx.set_encrypt_path(0)
     r = oracle.rng(SEED, off)
     exp = b"".join(oracle.ct_export(p, oracle.encrypt(p, r, sk, int(msg[i]), err[i])) for i in range(nrows))
     assert got.tobytes() == exp
+
+
+def test_encrypt_paths_agree_on_a_large_batch(ctx, mf):
+    """600 rows (two parities, three workgroup pairs, several column chunks): the matrix-core kernel == the VALU kernel, byte for byte; an
+    offset that is not a multiple of 8 is refused by the forced matrix-core path and served by the VALU kernel otherwise"""
+    p = mf.DEBUG
+    rng = np.random.default_rng(600)
+    nrows = 600
+    d_sk = ctx.to_device(ol.rand_values(rng, p.n, p.L, p.logq))
+    d_msg = ctx.to_device(rng.integers(0, ol.P, size=nrows, dtype=np.uint64).astype(np.uint32))
+    d_err = ctx.to_device(ol.rand_values(rng, nrows, p.L, 559))
+    out = {}
+    for path in (1, 2, 0):
+        ctx.set_encrypt_path(path)
+        try:
+            out[path] = ctx.to_host(ctx.encrypt_rows(p.ctr_as, nrows, d_sk, d_msg, d_err)).copy()
+        finally:
+            ctx.set_encrypt_path(0)
+    assert np.array_equal(out[1], out[2]) and np.array_equal(out[0], out[2])
+    ctx.set_encrypt_path(2)
+    try:
+        with pytest.raises(mf.MfhError):
+            ctx.encrypt_rows(4, 40, d_sk, d_msg, d_err)
+    finally:
+        ctx.set_encrypt_path(0)
+    ctx.encrypt_rows(4, 40, d_sk, d_msg, d_err)  # auto: falls back to the VALU kernel
 
 
 def test_encrypt_decrypt_roundtrip_and_homomorphism(ctx, oracle, mf):

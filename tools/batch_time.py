@@ -1,4 +1,5 @@
-"""Time mfh_prove_batch at the default instance. dev tool.  usage: python tools/batch_time.py [nproofs ...]"""
+"""Time mfh_prove_batch at the default instance. dev tool.
+usage: python tools/batch_time.py [nproofs ...] [--resident] [--launch=NGL,MERGE[:NGL,MERGE...]]   (groups per streaming launch, S+AS in one launch)"""
 import os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -19,7 +20,12 @@ if "--resident" in sys.argv:
     torch.cuda.synchronize()
     print(f"matrix-core CRS image: {image.numel()/1e9:.2f} GB expanded in {(time.perf_counter()-t0)*1e3:.1f} ms", flush=True)
     ctx.set_resident_mm(image)
-for nb in [int(a) for a in args] or [12, 24]:
+launches = [(4, 1)]
+for a in sys.argv[1:]:
+    if a.startswith("--launch="):
+        launches = [tuple(int(x) for x in t.split(",")) for t in a[9:].split(":")]
+for (ngl, merge), nb in [(l, int(a)) for l in launches for a in (args or ["12", "24"])]:
+    ctx.set_batch_launch(ngl, bool(merge))
     deltas = [int(x) for x in rng.integers(0, mf.P, size=nb, dtype=np.uint64)]
     mags = [rng.integers(0, 256, size=400, dtype=np.uint8).tobytes() for _ in range(nb)]
     signs = [bytes(5)] * nb
@@ -31,4 +37,4 @@ for nb in [int(a) for a in args] or [12, 24]:
     ok = ctx.to_host(ctx.verify(inst["d_ssp"], inst["alpha"], inst["beta"], inst["s"], inst["sk"], out, nb))
     one = ctx.prove(d_crs, inst["d_ssp"], inst["bits"], deltas[nb - 1], mags[nb - 1], signs[nb - 1])
     same = torch.equal(out.view(nb, -1)[nb - 1], one)
-    print(f"batch of {nb:3d}: {dt*1e3:8.2f} ms = {dt*1e3/nb:6.3f} ms/proof = {nb/dt:7.1f} proofs/s; accepted {int(ok.sum())}/{nb}; last == single-proof path: {same}", flush=True)
+    print(f"launch ngl={ngl} merge={merge}  batch of {nb:3d}: {dt*1e3:8.2f} ms = {dt*1e3/nb:6.3f} ms/proof = {nb/dt:7.1f} proofs/s; accepted {int(ok.sum())}/{nb}; last == single-proof path: {same}", flush=True)
