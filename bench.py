@@ -595,7 +595,8 @@ def main():
         ctx.set_timing(False)
         en_, ems_, _ = ctx.timing_drain("encrypt")
         enc_launch_ms = ems_ / max(en_, 1)
-        enc_kernel = "k_encrypt (fused AES-256-CTR row expansion + <sk, a> + e p + m)"
+        enc_kernel = ("k_encrypt_mm (AES-256-CTR row expansion, one block per lane, fed straight to i8 MFMA 16x16x64 as the A operand of the "
+                      "(rows x keystream bytes) x Toeplitz(sk) product <sk, a>; e p + m in the finishing kernel)")
 
     lwe = None
     if enc_per_s is not None:

@@ -22,6 +22,7 @@
 // n * CT_BYTES being 8 mod 16 at logq = 736, alternates with the row's parity.  K is counted from the row's first block, so B exists in two
 // versions (head 0 / head 8) and a 16-row MFMA tile holds rows of one parity: workgroup (sb, par) takes rows 512 sb + par + 2 i, i < 256.
 #include <algorithm>
+#include <cstdlib>
 
 #include "ctx.hpp"
 
@@ -46,20 +47,20 @@ __global__ void k_sk_digits(const uint64_t *__restrict__ sk, uint32_t n, uint32_
     sb[(uint64_t)j * sby + w] = (int8_t)(v - 256 * carry);
   }
 }
-// ps[t] = sum_j sum_{w <= t} sb[j][w]   (one block of 256 threads)
-__global__ void k_sk_prefix(const int8_t *__restrict__ sb, uint32_t n, uint32_t sby, int64_t *__restrict__ ps) {
-  __shared__ int64_t col[256];
+// col[t] += sum over 64 coordinates of sb[j][t] (col zeroed by the caller); then ps[t] = sum_{w <= t} col[w] = sum_j sum_{w <= t} sb[j][w]
+__global__ void k_sk_colsum(const int8_t *__restrict__ sb, uint32_t n, uint32_t sby, long long *__restrict__ col) {
   const uint32_t t = threadIdx.x;
-  int64_t s = 0;
-  if (t < sby)
-    for (uint32_t j = 0; j < n; j++) s += sb[(uint64_t)j * sby + t];
-  col[t] = s;
-  __syncthreads();
-  if (t < sby) {
-    int64_t p = 0;
-    for (uint32_t w = 0; w <= t; w++) p += col[w];
-    ps[t] = p;
-  }
+  if (t >= sby) return;
+  long long s = 0;
+  for (uint32_t j = blockIdx.x * 64; j < min(n, (blockIdx.x + 1) * 64); j++) s += sb[(uint64_t)j * sby + t];
+  atomicAdd(reinterpret_cast<unsigned long long *>(col + t), (unsigned long long)s);
+}
+__global__ void k_sk_prefix(const long long *__restrict__ col, uint32_t sby, int64_t *__restrict__ ps) {
+  const uint32_t t = threadIdx.x;
+  if (t >= sby) return;
+  int64_t p = 0;
+  for (uint32_t w = 0; w <= t; w++) p += col[w];
+  ps[t] = p;
 }
 // B in MFMA B-fragment order for one head value: bf[(ks * NQ + q) * 64 + lane] = the 16 bytes B[64 ks + 16 g + e][16 q + c], e = 0..15,
 // lane = 16 g + c.  B[k][t]: x = k - head (byte of the row), j = x / ctb, u = x % ctb; sb[j][t - u] if 0 <= x < rowlen, u <= t < sby.
@@ -85,8 +86,13 @@ __global__ void k_toeplitz_frag(const int8_t *__restrict__ sb, uint32_t ctb, uin
 
 // grid = (column chunks, 2 x ceil(nrows / 512)); block = 16 waves, wave w = rows base + 2 (16 w + r), r = lane & 15.
 // part[(row * gridDim.x + chunk) * 16 NQ + t] = this chunk's sum_k A'[row][k] B[k][t]
+// Two workgroups per CU (2 x 64 KiB of table, 8 waves per SIMD) when the kernel fits 64 VGPRs: it does at logq = 736 (24 accumulator
+// registers), not at 1472 (48).  ENCMM_WPE_736=4 builds the one-workgroup variant for A/B timing.
+#ifndef ENCMM_WPE_736
+#define ENCMM_WPE_736 8
+#endif
 template <int LOGQ>
-__global__ __launch_bounds__(1024) void k_encrypt_mm(AesKey key /* rk[56..59] ^ 0x80808080 */, const uint32_t *__restrict__ g_t0, uint64_t off, uint32_t rowlen,
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(LOGQ == 736 ? ENCMM_WPE_736 : 4, LOGQ == 736 ? ENCMM_WPE_736 : 4))) void k_encrypt_mm(AesKey key /* rk[56..59] ^ 0x80808080 */, const uint32_t *__restrict__ g_t0, uint64_t off, uint32_t rowlen,
                                                      uint32_t nrows, uint32_t ksteps, uint32_t ks_per_chunk, const v4i *__restrict__ bf, int *__restrict__ part) {
   constexpr int NQ = EG<LOGQ>::NQ;
   __shared__ __attribute__((aligned(16))) uint32_t lt[mf::kTabBytes / 4];  // the only LDS object: address 0 (aes_dev.hpp)
@@ -152,31 +158,45 @@ __global__ __launch_bounds__(1024) void k_encrypt_mm(AesKey key /* rk[56..59] ^ 
 
 // b = (sum_t (G[t] + 128 PS[t]) 256^t + e p + m) mod 2^(64K)  ->  CT_BYTES little-endian bytes (ct_export, src/lwe.c:115-119).  The digit
 // sums are signed: the carry chain runs in two's complement, which is arithmetic mod 2^(64K) all the same.
+// One wave per row: the lanes sum the column chunks of "their" byte positions (coalesced), form the 32-bit-word values W_l = sum_k x[4l+k]
+// 256^k (|x| < 2^40: W fits 64 bits) and one lane runs the KW-step carry chain together with e p + m.
 template <int LOGQ>
-__global__ void k_encrypt_finish_mm(const int *__restrict__ part, uint32_t nchunks, uint32_t nrows, const int64_t *__restrict__ ps,
-                                    const uint32_t *__restrict__ msg, const uint64_t *__restrict__ err, uint8_t *__restrict__ c8) {
+__global__ __launch_bounds__(256) void k_encrypt_finish_mm(const int *__restrict__ part, uint32_t nchunks, uint32_t nrows, const int64_t *__restrict__ ps,
+                                                           const uint32_t *__restrict__ msg, const uint64_t *__restrict__ err, uint8_t *__restrict__ c8) {
   using G = EG<LOGQ>;
-  const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
-  if (row >= nrows) return;
-  const int *p = part + (uint64_t)row * nchunks * (16 * G::NQ);
+  constexpr int NC = 16 * G::NQ;
+  __shared__ int64_t xs[4][NC];
+  __shared__ int64_t ws[4][G::KW];
+  const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t row = blockIdx.x * 4 + wv;
+  if (row < nrows) {
+    const int *p = part + (uint64_t)row * nchunks * NC;
+    for (uint32_t t = lane; t < (uint32_t)G::SBY; t += 64) {
+      int64_t x = 128 * ps[t];
+      for (uint32_t ch = 0; ch < nchunks; ch++) x += p[(uint64_t)ch * NC + t];
+      xs[wv][t] = x;
+    }
+  }
+  __syncthreads();
+  if (row < nrows && lane < (uint32_t)G::KW) {
+    int64_t w = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) w += xs[wv][4 * lane + k] * ((int64_t)1 << (8 * k));
+    ws[wv][lane] = w;
+  }
+  __syncthreads();
+  if (row >= nrows || lane != 0) return;
   const uint32_t *e = reinterpret_cast<const uint32_t *>(err + (uint64_t)row * G::L);
   uint32_t *o = reinterpret_cast<uint32_t *>(c8 + (uint64_t)row * G::CTB);
-  int64_t dcarry = 0;          // carry of the signed byte-digit chain
+  int64_t dcarry = 0;          // carry of the signed digit chain
   uint64_t carry = msg[row];   // carry of the word chain (+ m)
   uint64_t mulc = 0;
   for (int l = 0; l < G::KW; l++) {
-    uint32_t word = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int t = 4 * l + k;
-      int64_t x = 128 * ps[t] + dcarry;
-      for (uint32_t ch = 0; ch < nchunks; ch++) x += p[(uint64_t)ch * (16 * G::NQ) + t];
-      word |= (uint32_t)(x & 255) << (8 * k);
-      dcarry = x >> 8;  // arithmetic
-    }
+    const int64_t x = ws[wv][l] + dcarry;
+    dcarry = x >> 32;  // arithmetic
     const uint64_t ep = (uint64_t)e[l] * MFH_P + mulc;  // e * p, word l
     mulc = ep >> 32;
-    const uint64_t tt = carry + (uint32_t)ep + word;
+    const uint64_t tt = carry + (uint32_t)ep + (uint32_t)x;
     o[l] = (uint32_t)tt;
     carry = tt >> 32;
   }
@@ -196,17 +216,25 @@ int encrypt_rows_mm_t(mfh_ctx *c, uint64_t off, size_t nrows, const uint64_t *sk
   const uint32_t nblk = 2 * (((uint32_t)nrows + 511) / 512);
   uint32_t kc_min = 1;
   if ((uint64_t)n * G::SBY > 131071) kc_min = (ksteps * 64 + 131070) / 131071;
-  // pick the chunk count that fills the 256 CUs most evenly (each workgroup owns a CU: 64 KiB table), preferring few chunks
-  uint32_t kc = kc_min;
+  // Column chunks also set the grain of the dispatch: with about four workgroups per workgroup slot (256 CUs x 1 or 2 workgroups of 64 KiB
+  // table) the CUs stay evenly loaded to the end (65 536 rows: 60 Gblock/s of AES with one chunk, 66 with 2, 74 with 8 -- measured), while
+  // a chunk stays long against the workgroup's start-up (the table fill is worth about half a k-step)
+  const uint32_t slots = 256 * ((LOGQ == 736 && ENCMM_WPE_736 == 8) ? 2 : 1);
+  // -- and among such counts the one whose last round of workgroups is fullest (87 381 rows: 65 Gblock/s with 6 chunks = 4.008 rounds, 73
+  // with 16 = 10.7 rounds)
+  const uint32_t k_lo = std::max(kc_min, (4 * slots + nblk - 1) / nblk), k_hi = std::max(k_lo, std::min(3 * k_lo, std::max(1u, ksteps / 32)));
+  uint32_t kc = std::min(k_lo, k_hi);
   double best = 0;
-  for (uint32_t k = kc_min; k <= 64 && ksteps / k >= 16; k++) {
-    const double wg = (double)nblk * k, eff = wg / (256.0 * (double)((uint64_t)(wg + 255) / 256));
-    if (eff > best + 0.02) { best = eff; kc = k; }
-    if (eff > 0.97) break;
+  for (uint32_t k = kc; k <= k_hi; k++) {
+    const uint64_t wg = (uint64_t)nblk * k, rounds = (wg + slots - 1) / slots;
+    const double eff = (double)wg / ((double)slots * (double)rounds);
+    if (eff > best + 1e-9) { best = eff; kc = k; }
   }
+  kc = std::max(kc_min, kc);
+  if (const char *ev = getenv("MFH_ENC_KC")) kc = std::max<uint32_t>(kc_min, (uint32_t)atoi(ev));  // tuning override (tools/encrypt_time.py)
   const uint32_t kpc = (ksteps + kc - 1) / kc;
   kc = (ksteps + kpc - 1) / kpc;
-  const size_t sb_b = ((size_t)n * G::SBY + 255) & ~(size_t)255, ps_b = 256 * 8;
+  const size_t sb_b = ((size_t)n * G::SBY + 255) & ~(size_t)255, ps_b = 2 * 256 * 8;  // ps | column sums
   const size_t bf_b = (size_t)2 * ksteps * G::NQ * 1024;
   const size_t part_b = (size_t)nrows * kc * 16 * G::NQ * 4;
   int rc = ws_reserve(c, sb_b + ps_b + bf_b + part_b);
@@ -217,7 +245,10 @@ int encrypt_rows_mm_t(mfh_ctx *c, uint64_t off, size_t nrows, const uint64_t *sk
   v4i *bf = (v4i *)(w + sb_b + ps_b);
   int *part = (int *)(w + sb_b + ps_b + bf_b);
   hipLaunchKernelGGL(k_sk_digits, dim3((n + 255) / 256), dim3(256), 0, c->stream, sk, n, (uint32_t)G::L, (uint32_t)G::SBY, sb);
-  hipLaunchKernelGGL(k_sk_prefix, dim3(1), dim3(256), 0, c->stream, sb, n, (uint32_t)G::SBY, ps);
+  long long *col = (long long *)(ps + 256);
+  HIP_TRY(c, hipMemsetAsync(col, 0, 256 * 8, c->stream));
+  hipLaunchKernelGGL(k_sk_colsum, dim3((n + 63) / 64), dim3(256), 0, c->stream, sb, n, (uint32_t)G::SBY, col);
+  hipLaunchKernelGGL(k_sk_prefix, dim3(1), dim3(256), 0, c->stream, col, (uint32_t)G::SBY, ps);
   const uint64_t nfr = (uint64_t)ksteps * G::NQ * 64;
   for (uint32_t h = 0; h < 2; h++)
     hipLaunchKernelGGL(k_toeplitz_frag, dim3((uint32_t)((nfr + 255) / 256)), dim3(256), 0, c->stream, sb, (uint32_t)G::CTB, (uint32_t)G::SBY, (uint32_t)G::NQ, ksteps,
@@ -229,7 +260,7 @@ int encrypt_rows_mm_t(mfh_ctx *c, uint64_t off, size_t nrows, const uint64_t *sk
     hipLaunchKernelGGL(k_encrypt_mm<LOGQ>, dim3(kc, nblk), dim3(1024), 0, c->stream, keyx, c->d_t0, off, rowlen, (uint32_t)nrows, ksteps, kpc, bf, part);
   }
   HIP_TRY(c, hipGetLastError());
-  hipLaunchKernelGGL(k_encrypt_finish_mm<LOGQ>, dim3(((uint32_t)nrows + 255) / 256), dim3(256), 0, c->stream, part, kc, (uint32_t)nrows, ps, msg, err, c8);
+  hipLaunchKernelGGL(k_encrypt_finish_mm<LOGQ>, dim3(((uint32_t)nrows + 3) / 4), dim3(256), 0, c->stream, part, kc, (uint32_t)nrows, ps, msg, err, c8);
   HIP_TRY(c, hipGetLastError());
   return MFH_OK;
 }

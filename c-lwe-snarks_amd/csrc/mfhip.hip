@@ -1441,12 +1441,12 @@ int mfh_encrypt_rows(mfh_ctx *c, uint64_t off, size_t nrows, const uint64_t *d_s
   if (nrows > 0xffffffffu) return MFH_EINVAL;
   HIP_TRY(c, hipSetDevice(c->device));
   // Batches: the dot product on the matrix cores (encmm.hip), one AES block per lane straight into the MFMA.  Needs every row to start at
-  // byte 0 or 8 of an AES block with one parity pattern (off and the row length multiples of 8); a handful of rows is cheaper on the VALU
-  // kernel (no per-key operand preparation).
+  // byte 0 or 8 of an AES block with one parity pattern (off and the row length multiples of 8); small batches are cheaper on the VALU
+  // kernel (no per-key operand preparation: 0.13 ms; measured break-even near 3000 rows).
   const uint64_t rowlen = (uint64_t)c->P.n * (c->P.logq / 8);
   const bool mm_ok = (off & 7) == 0 && (rowlen & 7) == 0;
   if (c->enc_path == 2 && !mm_ok) { c->err = "mfh_encrypt_rows: the matrix-core kernel needs off and the row length to be multiples of 8"; return MFH_EINVAL; }
-  if (mm_ok && (c->enc_path == 2 || (c->enc_path == 0 && nrows >= 32))) return encrypt_rows_mm(c, off, nrows, d_sk, d_msg, d_err, d_c8_out);
+  if (mm_ok && (c->enc_path == 2 || (c->enc_path == 0 && nrows >= 4096))) return encrypt_rows_mm(c, off, nrows, d_sk, d_msg, d_err, d_c8_out);
   DISPATCH_LOGQ(c, return encrypt_rows<736>(c, off, nrows, d_sk, d_msg, d_err, d_c8_out),
                 return encrypt_rows<1472>(c, off, nrows, d_sk, d_msg, d_err, d_c8_out));
 }

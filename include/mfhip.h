@@ -117,7 +117,7 @@ int mfh_crs_set_resident_share(mfh_ctx *ctx, const void *d_image, uint32_t rank,
  * the reference draws 559 bits from getrandom, src/lwe.c:60-63); d_c8_out: nrows*CT_BYTES bytes. */
 int mfh_encrypt_rows(mfh_ctx *ctx, uint64_t off, size_t nrows, const uint64_t *d_sk, const uint32_t *d_msg,
                      const uint64_t *d_err, uint8_t *d_c8_out);
-/* Which kernel mfh_encrypt_rows (hence mfh_setup) uses; the results are identical.  0 (default): batches of 32 rows or more run <sk, a> on
+/* Which kernel mfh_encrypt_rows (hence mfh_setup) uses; the results are identical.  0 (default): batches of 4096 rows or more run <sk, a> on
  * the matrix cores -- the dot product as a (rows x keystream bytes) x Toeplitz(sk) int8 GEMM, each lane's AES output block being an MFMA
  * operand as it stands -- when off and n * CT_BYTES are multiples of 8, anything else the VALU kernel; 1: always the VALU kernel;
  * 2: always the matrix-core kernel (MFH_EINVAL from mfh_encrypt_rows if the alignment does not allow it). */

@@ -169,11 +169,12 @@ def test_encrypt_rows_matches_oracle(ctx, oracle, mf, nrows, off_kind, path):
 
 
 def test_encrypt_paths_agree_on_a_large_batch(ctx, mf):
-    """600 rows (two parities, three workgroup pairs, several column chunks): the matrix-core kernel == the VALU kernel, byte for byte; an
-    offset that is not a multiple of 8 is refused by the forced matrix-core path and served by the VALU kernel otherwise"""
+    """4200 rows (two parities, nine workgroup pairs, many column chunks; the size from which the default picks the matrix-core kernel): the
+    matrix-core kernel == the VALU kernel, byte for byte; an offset that is not a multiple of 8 is refused by the forced matrix-core path
+    and served by the VALU kernel otherwise"""
     p = mf.DEBUG
     rng = np.random.default_rng(600)
-    nrows = 600
+    nrows = 4200
     d_sk = ctx.to_device(ol.rand_values(rng, p.n, p.L, p.logq))
     d_msg = ctx.to_device(rng.integers(0, ol.P, size=nrows, dtype=np.uint64).astype(np.uint32))
     d_err = ctx.to_device(ol.rand_values(rng, nrows, p.L, 559))
