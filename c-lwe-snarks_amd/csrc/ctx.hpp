@@ -93,6 +93,7 @@ struct mfh_ctx {
   size_t batch_img_bytes = 0;
   int batch_image = 1;
   uint32_t mm_chunk_rows = 131071;  // rows per row chunk of the matrix-core launches (int32 accumulators: |A'C'| <= 2^14 per row)
+  int expand_path = 0;     // mfh_crs_expand_mm*: 0 = k_expand_mm (lane = row, MFMA transposition, no LDS tile), 1 = k_evalmm16<MODE 1> (LDS tile + byte gathers)
   int enc_path = 0;        // mfh_encrypt_rows: 0 = pick by batch size, 1 = VALU kernel (k_encrypt), 2 = matrix-core kernel (k_encrypt_mm)
   int batch_merge = 1;     // the S and AS groups of a round in one streaming launch (0: two launches on two streams)
   uint32_t batch_ngl = 4;  // groups of 31 proofs per streaming launch over the image (1..8)
@@ -163,6 +164,8 @@ extern "C" int mfh_witness_poly_mm(mfh_ctx *c, const uint32_t *d_ssp, uint32_t n
                                    uint32_t *d_w);
 extern "C" int mfh_poly_h_multi(mfh_ctx *c, const uint32_t *d_v, uint32_t *d_h, uint32_t nb);
 int aux_reserve(mfh_ctx *c, size_t bytes);
+// expandmm.hip: one region of the matrix-core CRS image (rows at stream offset off, their compressed ciphertexts c8), barrier-free writer
+int expand_mm_region(mfh_ctx *c, uint64_t off, uint32_t nrows, const uint8_t *c8, uint8_t *image);
 // encmm.hip: mfh_encrypt_rows with <sk, a> on the matrix cores (off and the row length multiples of 8)
 int encrypt_rows_mm(mfh_ctx *c, uint64_t off, size_t nrows, const uint64_t *sk, const uint32_t *msg, const uint64_t *err, uint8_t *c8);
 

@@ -1016,6 +1016,12 @@ int mfh_crs_expand_mm_share(mfh_ctx *c, const uint8_t *d_crs_c8, uint32_t rank, 
     Timer t(c, 9, sh.rows[r]);
     const dim3 grid(ntiles, (uint32_t)((sh.rows[r] + rpc - 1) / rpc));
     const uint8_t *c8 = d_crs_c8 + (size_t)sh.row0[r] * wg.vby;
+    if (c->expand_path == 0 && ((ctr_ct * sh.row0[r]) & 7) == 0) {  // the barrier-free writer (expandmm.hip)
+      int rc = expand_mm_region(c, ctr_ct * sh.row0[r], (uint32_t)sh.rows[r], c8, d_image + base);
+      if (rc) return rc;
+      base += mm_region_bytes(c, sh.rows[r]);
+      continue;
+    }
     if (c->P.logq == 736)
       hipLaunchKernelGGL((k_evalmm16<1, 736>), grid, dim3(1024), 0, c->stream, keyx, c->d_t0, ctr_ct * sh.row0[r], n, (uint32_t)sh.rows[r], rpc, c8,
                          (const int8_t *)nullptr, (int *)nullptr, d_image + base);

@@ -996,6 +996,12 @@ int mfh_set_overlap(mfh_ctx *c, int en) {
   return MFH_OK;
 }
 
+int mfh_set_expand_path(mfh_ctx *c, int path) {
+  if (!c || path < 0 || path > 1) return MFH_EINVAL;
+  c->expand_path = path;
+  return MFH_OK;
+}
+
 int mfh_set_encrypt_path(mfh_ctx *c, int path) {
   if (!c || path < 0 || path > 2) return MFH_EINVAL;
   c->enc_path = path;

@@ -196,6 +196,9 @@ int mfh_verify(mfh_ctx *ctx, const uint32_t *d_ssp, uint32_t alpha, uint32_t bet
 size_t mfh_crs_mm_image_bytes(const mfh_ctx *ctx);
 int mfh_crs_expand_mm(mfh_ctx *ctx, const uint8_t *d_crs_c8, uint8_t *d_image);
 int mfh_crs_set_resident_mm(mfh_ctx *ctx, const uint8_t *d_image);
+/* Which kernel writes the image (same bytes for every row tile and row that exists; tuning / A-B): 0 (default) the barrier-free writer
+ * (lane = row, 16 x 16 byte transposition on the matrix cores, csrc/expandmm.hip), 1 the LDS-tile writer (k_evalmm16<MODE 1>). */
+int mfh_set_expand_path(mfh_ctx *ctx, int path);
 /* prover() for nproofs statements under ONE CRS and SSP.  The S and AS regions are expanded (or streamed from the image, below) once per group of up to 31 proofs, the
  * BT+BV region once per up to 248, and the multiply-accumulate of the coefficient vectors runs on the matrix cores (mfh_eval_rows_multi); proof b is bit-identical to
  * mfh_prove(witness b, delta b, smudging b).  h_witness_bits: nproofs bit strings, bits_stride bytes apart; h_delta: nproofs values

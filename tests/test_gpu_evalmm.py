@@ -220,3 +220,53 @@ def test_witness_pass_on_the_matrix_cores(gpu_ctx_factory, nstmt):
     if nstmt <= 12:
         got_v = c.to_host(c.witness_poly_many(d_ssp, wits, deltas, mm=False), np.uint32).reshape(nstmt, p.d)
         assert np.array_equal(got_v, got_mm)
+
+
+@pytest.mark.parametrize("logq,d,m", [(736, 256, 64), (736, 1152, 1000), (1472, 128, 24), (736, 320, 70)])
+def test_expansion_kernels_write_the_same_image(gpu_ctx_factory, logq, d, m):
+    """mfh_crs_expand_mm through the barrier-free writer (k_expand_mm: lane = row, 16 x 16 byte transposition on the matrix cores) and
+    through the LDS-tile writer (k_evalmm16<MODE 1>): the same bytes for every row tile, byte position and row that exists, in all three
+    regions (S and AS start at byte 0 / 8 of an AES block by row parity; BT+BV has m rows: not a multiple of 64), and for a rank's shares.
+    (Row tiles past the b coordinate and rows past the region are never read back and are left to each kernel.)"""
+    import c_lwe_snarks_amd as mf
+
+    p = mf.Params(logq=logq, d=d, m=m)
+    c = gpu_ctx_factory(p)
+    c.set_seed(SEED)
+    rng = np.random.default_rng(d + m)
+    d_crs = c.to_device(rng.integers(0, 256, size=(2 * p.d + p.m) * p.ctb, dtype=np.uint8))
+    mt_per_tile, ct = (11, 2) if logq == 736 else (12, 1)
+    mtiles = (p.n + 1 + ct - 1) // ct * mt_per_tile
+    for rank, world in ((0, 1), (1, 3)):
+        imgs = []
+        for path in (1, 0):
+            c.set_expand_path(path)
+            try:
+                imgs.append(c.to_host(c.crs_expand_mm_share(d_crs, rank, world)).copy())
+            finally:
+                c.set_expand_path(0)
+        old, new = imgs
+        assert old.size == new.size
+        base = 0
+        for total in (p.d, p.d, p.m):
+            rows = total * (rank + 1) // world - total * rank // world
+            KS = (rows + 255) // 256 * 4
+            nb = mtiles * KS * 1024
+            a = old[base:base + nb].reshape(mtiles, KS, 4, 16, 16)  # [row tile][k-step][row group g4][byte position c16][row e]
+            b = new[base:base + nb].reshape(mtiles, KS, 4, 16, 16)
+            base += nb
+            row_of = (64 * np.arange(KS)[:, None, None] + 16 * np.arange(4)[None, :, None] + np.arange(16)[None, None, :])  # [ks][g4][e]
+            rmask = (row_of < rows)[None, :, :, None, :]
+            if logq == 736:
+                pos_ok = np.ones((mtiles, 16), dtype=bool)
+                last = 11 * ((p.n + 1) // 2) + 5 if (p.n + 1) % 2 else None  # the tile holding b's bytes 80..87
+                full = 22 * (p.n // 4) + 11 * ((p.n % 4) // 2) + 5  # row tiles completely filled: keystream coordinates + 80 bytes of b
+                pos_ok[full + 1:] = False
+                pos_ok[full, 8:] = False
+                assert last is None or last == full
+            else:
+                pos_ok = np.ones((mtiles, 16), dtype=bool)
+                pos_ok[11::12, 8:] = False  # a coordinate's 12th row tile holds 8 bytes
+            mask = rmask & pos_ok[:, None, None, :, None]
+            assert np.array_equal(a[np.broadcast_to(mask, a.shape)], b[np.broadcast_to(mask, b.shape)]), (rank, world, total)
+    c.close()
