@@ -117,6 +117,65 @@ __global__ void k_mm_digits(MmIo io, uint32_t nvec, uint32_t ND, uint32_t nrows,
   if (v < nvec && colsum) atomicAdd(reinterpret_cast<unsigned long long *>(sc + n), (unsigned long long)(long long)colsum);
 }
 
+// The hot shape of the batch prover -- 256 digit columns, four-byte coefficients (62 vectors + the ones column) -- with the 16
+// coefficients of a fragment element fetched as four 16-byte loads, DG4 row groups in flight per thread and the byte column picked with
+// v_perm: thread = (vector n >> 2, byte n & 3).
+constexpr int DG4 = 4;
+__global__ __launch_bounds__(256) void k_mm_digits4w(MmIo io, uint32_t nvec, uint32_t nrows, uint32_t rpad, int8_t *__restrict__ cd, int64_t *__restrict__ sc) {
+  const uint32_t n = threadIdx.x, v = n >> 2, w = n & 3;
+  const bool ones = n == 4 * nvec;
+  const uint64_t cs = io.cstride ? io.cstride : nrows;
+  const uint32_t *cv = v < nvec ? (v < io.csplit ? io.coef[0] + (uint64_t)v * cs : io.coef[1] + (uint64_t)(v - io.csplit) * cs) : nullptr;
+  const uint32_t rg0 = blockIdx.x * DG4;
+  uint32_t x[DG4][16];
+#pragma unroll
+  for (int r = 0; r < DG4; r++) {
+    const uint32_t i0 = (rg0 + r) * 16;
+#pragma unroll
+    for (int e = 0; e < 16; e++) x[r][e] = 0;
+    if (!cv || i0 >= nrows) continue;
+    if (i0 + 16 <= nrows && ((reinterpret_cast<uintptr_t>(cv + i0) & 15) == 0)) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint4 t = reinterpret_cast<const uint4 *>(cv + i0)[k];
+        x[r][4 * k] = t.x; x[r][4 * k + 1] = t.y; x[r][4 * k + 2] = t.z; x[r][4 * k + 3] = t.w;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; e++)
+        if (i0 + e < nrows) x[r][e] = cv[i0 + e];
+    }
+  }
+  const uint32_t sel = 0x0c0c0400u + 0x00000101u * w;  // {a.byte w, b.byte w, 0, 0}
+  uint32_t bytesum = 0, nvalid = 0;
+#pragma unroll
+  for (int r = 0; r < DG4; r++) {
+    const uint32_t i0 = (rg0 + r) * 16;
+    if (i0 >= rpad) continue;
+    uint32_t pk[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t lo = __builtin_amdgcn_perm(x[r][4 * k + 1], x[r][4 * k], sel);
+      const uint32_t hi = __builtin_amdgcn_perm(x[r][4 * k + 3], x[r][4 * k + 2], sel);
+      uint32_t b4 = lo | (hi << 16);  // byte w of coefficients 4k .. 4k+3
+      // rows at or past nrows: digit 0 (not -128); valid rows: digit - 128 = byte ^ 0x80
+      uint32_t m = 0;
+#pragma unroll
+      for (int e = 0; e < 4; e++) m |= (i0 + 4 * k + e < nrows ? 0xffu : 0u) << (8 * e);
+      bytesum = __builtin_amdgcn_sad_u8(b4 & m, 0u, bytesum);
+      nvalid += __builtin_popcount(m) >> 3;
+      b4 = (b4 ^ 0x80808080u) & m;
+      pk[k] = cv ? b4 : (ones ? 0x01010101u & m : 0u);
+    }
+    const uint32_t K = i0 >> 6, g = (i0 >> 4) & 3, q = n >> 4, c = n & 15;
+    reinterpret_cast<uint4 *>(cd)[((uint64_t)K * 16 /* NQ2 column tiles */ + q) * 64 + 16 * g + c] = uint4{pk[0], pk[1], pk[2], pk[3]};
+  }
+  if (cv) {
+    const long long colsum = (long long)bytesum - 128ll * nvalid;
+    if (colsum) atomicAdd(reinterpret_cast<unsigned long long *>(sc + n), (unsigned long long)colsum);
+  }
+}
+
 struct RowGeom {
   uint64_t cb0;   // first AES block of the row's segment
   uint32_t head;  // byte offset of the segment inside that block
@@ -897,68 +956,103 @@ int eval_rows_multi_io(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d_
 
 // ng evaluations over each of nreg regions (same row count) of the registered image in ONE k_mmstream launch: group r * ng + k streams
 // region r with operands ios[r * ng + k] (the image is then read from HBM once for the ng groups of a region, see k_mmstream; the S and
-// AS groups of the batch prover share a launch so that no two launches of the kernel overlap).  Anything else -- no image, a single
-// evaluation, 128-column shapes -- falls back to separate evaluations, region by region.
+// AS groups of the batch prover share a launch so that no two launches of the kernel overlap).  Three phases -- operand preparation
+// (digit fragments + column sums), the streaming launch, the epilogues -- so that a caller can queue them on different streams
+// (mfh_prove_batch: the epilogues of round r run beside the launch of round r + 1).
+bool mms_plan(mfh_ctx *c, const MmRegion *regs, uint32_t nreg, size_t nrows, const MmIo *ios, const uint32_t *nvecs, uint32_t ng, uint32_t coeff_bytes,
+              MmsPlan &P) {
+  if (!c || !regs || !ios || !nvecs || !ng || !nreg || nreg > 2 || nreg * ng > 16) return false;
+  bool ok = nreg * ng > 1 && c->have_seed && nrows && nrows <= 0xffffffffu - 256;
+  for (uint32_t q = 0; q < nreg && ok; q++) {
+    P.img[q] = nullptr;
+    for (int r = 0; r < 3 && c->mm_image; r++)
+      if (c->mm_off[r] == regs[q].off && c->mm_rows[r] == nrows) P.img[q] = c->mm_image + c->mm_base[r];
+    ok = P.img[q] != nullptr;
+  }
+  P.ng = ng;
+  P.ngt = nreg * ng;
+  for (uint32_t g = 0; g < P.ngt && ok; g++)
+    ok = nvecs[g] && nvecs[g] * coeff_bytes + 1 <= 256 && ios[g].out[0] && ios[g].sc_zeroed && (ios[g].bits || ios[g].coef[0]);
+  if (!ok) return false;
+  const WideGeom wg = wide_geom(c);
+  P.ND = coeff_bytes;
+  P.nrows = (uint32_t)nrows;
+  P.ntiles = (c->P.n + 1 + wg.ct - 1) / wg.ct;
+  P.mtiles = P.ntiles * wg.mt;
+  // row chunks: an int32 accumulator holds 131 071 rows (a rank's share of a 2^20-row region is 131 072)
+  uint32_t nchunks = ((uint32_t)nrows + c->mm_chunk_rows - 1) / c->mm_chunk_rows;
+  P.rpc = (((uint32_t)nrows + nchunks - 1) / nchunks + RT2 - 1) / RT2 * RT2;
+  P.nchunks = ((uint32_t)nrows + P.rpc - 1) / P.rpc;
+  P.rpad = P.nchunks * P.rpc;
+  P.cd_bytes = ((size_t)N2 * P.rpad + 255) & ~(size_t)255;
+  P.part_bytes = ((size_t)P.nchunks * P.ntiles * wg.mbp * N2 * 4 + 255) & ~(size_t)255;
+  P.cd = nullptr;
+  P.part = nullptr;
+  return true;
+}
+size_t mms_ws_bytes(const MmsPlan &P) { return (size_t)P.ngt * (P.cd_bytes + P.part_bytes); }
+void mms_bind(MmsPlan &P, void *ws) {
+  P.cd = (int8_t *)ws;
+  P.part = (int *)((uint8_t *)ws + (size_t)P.ngt * P.cd_bytes);
+}
+int mms_digits(mfh_ctx *c, const MmsPlan &P, const MmIo *ios, const uint32_t *nvecs) {
+  for (uint32_t g = 0; g < P.ngt; g++) {
+    if (P.ND == 4 && !ios[g].bits)
+      hipLaunchKernelGGL(k_mm_digits4w, dim3((P.rpad / 16 + DG4 - 1) / DG4), dim3(256), 0, c->stream, ios[g], nvecs[g], P.nrows, P.rpad, P.cd + g * P.cd_bytes,
+                         ios[g].sc_zeroed);
+    else
+      hipLaunchKernelGGL(k_mm_digits, dim3((P.rpad / 16 + DG_RG - 1) / DG_RG), dim3(N2), 0, c->stream, ios[g], nvecs[g], P.ND, P.nrows, P.rpad, (uint32_t)NQ2, 1,
+                         P.cd + g * P.cd_bytes, ios[g].sc_zeroed);
+  }
+  HIP_TRY(c, hipGetLastError());
+  return MFH_OK;
+}
+int mms_stream(mfh_ctx *c, const MmsPlan &P) {
+  Timer t(c, 8, P.nrows, (uint64_t)P.nrows * P.ngt);
+  const uint32_t KS = (P.nrows + RT2 - 1) / RT2 * (RT2 / 64), tgs = (P.mtiles + 2 * SW - 1) / (2 * SW);
+  MmsImages imgs{};
+  for (uint32_t g = 0; g < P.ngt; g++) imgs.image[g] = (const v4i *)P.img[g / P.ng];
+  hipLaunchKernelGGL(k_mmstream, dim3((tgs + 7) / 8 * 8 * P.ngt, P.nchunks), dim3(SW * 64), 0, c->stream, imgs, P.mtiles, KS, P.nrows, P.rpc, (const v4i *)P.cd,
+                     P.part, P.ngt, (uint64_t)(P.cd_bytes / 16), (uint64_t)(P.part_bytes / 4));
+  HIP_TRY(c, hipGetLastError());
+  return MFH_OK;
+}
+int mms_finish(mfh_ctx *c, const MmsPlan &P, const MmIo *ios, const uint32_t *nvecs) {
+  const WideGeom wg = wide_geom(c);
+  const uint32_t n = c->P.n;
+  for (uint32_t g = 0; g < P.ngt; g++) {
+    const dim3 fgrid(n + 1, (nvecs[g] + 63) / 64);
+    int *pg = P.part + g * (P.part_bytes / 4);
+    if (P.ND == 4)
+      hipLaunchKernelGGL(k_evalmm_finish<4>, fgrid, dim3(256), 0, c->stream, pg, ios[g].sc_zeroed, P.nchunks, P.ntiles, (uint32_t)N2, nvecs[g], n, P.nrows, wg.ct,
+                         wg.mbp, wg.sby, wg.LL, ios[g], 0);
+    else
+      hipLaunchKernelGGL(k_evalmm_finish<1>, fgrid, dim3(256), 0, c->stream, pg, ios[g].sc_zeroed, P.nchunks, P.ntiles, (uint32_t)N2, nvecs[g], n, P.nrows, wg.ct,
+                         wg.mbp, wg.sby, wg.LL, ios[g], 0);
+  }
+  HIP_TRY(c, hipGetLastError());
+  return MFH_OK;
+}
 int eval_rows_multi_io_regions(mfh_ctx *c, const MmRegion *regs, uint32_t nreg, size_t nrows, const MmIo *ios, const uint32_t *nvecs, uint32_t ng,
                                uint32_t coeff_bytes) {
   if (!c || !regs || !ios || !nvecs || !ng || !nreg || nreg * ng > 16) return MFH_EINVAL;
-  const uint8_t *img_region[2] = {nullptr, nullptr};
-  bool ok = nreg <= 2 && nreg * ng > 1 && c->have_seed && nrows && nrows <= 0xffffffffu - 256;
-  for (uint32_t q = 0; q < nreg && ok; q++) {
-    for (int r = 0; r < 3 && c->mm_image; r++)
-      if (c->mm_off[r] == regs[q].off && c->mm_rows[r] == nrows) img_region[q] = c->mm_image + c->mm_base[r];
-    ok = img_region[q] != nullptr;
-  }
-  const uint32_t ngt = nreg * ng;
-  for (uint32_t g = 0; g < ngt && ok; g++)
-    ok = nvecs[g] && nvecs[g] * coeff_bytes + 1 <= 256 && ios[g].out[0] && ios[g].sc_zeroed && (ios[g].bits || ios[g].coef[0]);
-  if (!ok) {
-    for (uint32_t g = 0; g < ngt; g++) {
+  MmsPlan P;
+  if (!mms_plan(c, regs, nreg, nrows, ios, nvecs, ng, coeff_bytes, P)) {
+    // anything else -- no image, a single evaluation, 128-column shapes -- : separate evaluations, region by region
+    for (uint32_t g = 0; g < nreg * ng; g++) {
       int rc = eval_rows_multi_io(c, regs[g / ng].off, nrows, regs[g / ng].c8, ios[g], nvecs[g], coeff_bytes, 0);
       if (rc) return rc;
     }
     return MFH_OK;
   }
   HIP_TRY(c, hipSetDevice(c->device));
-  const uint32_t ND = coeff_bytes, n = c->P.n;
-  const WideGeom wg = wide_geom(c);
-  const uint32_t ntiles = (n + 1 + wg.ct - 1) / wg.ct, mtiles = ntiles * wg.mt;
-  // row chunks: an int32 accumulator holds 131 071 rows (a rank's share of a 2^20-row region is 131 072)
-  uint32_t nchunks = ((uint32_t)nrows + c->mm_chunk_rows - 1) / c->mm_chunk_rows;
-  const uint32_t rpc = (((uint32_t)nrows + nchunks - 1) / nchunks + RT2 - 1) / RT2 * RT2;
-  nchunks = ((uint32_t)nrows + rpc - 1) / rpc;
-  const uint32_t rpad = nchunks * rpc;
-  const size_t cd_bytes = ((size_t)N2 * rpad + 255) & ~(size_t)255;
-  const size_t part_bytes = ((size_t)nchunks * ntiles * wg.mbp * N2 * 4 + 255) & ~(size_t)255;
-  int rc = c->mm_ws_sel ? ws2_reserve(c, ngt * (cd_bytes + part_bytes)) : ws_reserve(c, ngt * (cd_bytes + part_bytes));
+  int rc = c->mm_ws_sel ? ws2_reserve(c, mms_ws_bytes(P)) : ws_reserve(c, mms_ws_bytes(P));
   if (rc) return rc;
-  uint8_t *wsp = (uint8_t *)(c->mm_ws_sel ? c->ws2 : c->ws);
-  int8_t *cd = (int8_t *)wsp;
-  int *part = (int *)(wsp + ngt * cd_bytes);
-  for (uint32_t g = 0; g < ngt; g++)
-    hipLaunchKernelGGL(k_mm_digits, dim3((rpad / 16 + DG_RG - 1) / DG_RG), dim3(N2), 0, c->stream, ios[g], nvecs[g], ND, (uint32_t)nrows, rpad, (uint32_t)NQ2, 1,
-                       cd + g * cd_bytes, ios[g].sc_zeroed);
-  {
-    Timer t(c, 8, nrows, (uint64_t)nrows * ngt);
-    const uint32_t KS = ((uint32_t)nrows + RT2 - 1) / RT2 * (RT2 / 64), tgs = (mtiles + 2 * SW - 1) / (2 * SW);
-    MmsImages imgs{};
-    for (uint32_t g = 0; g < ngt; g++) imgs.image[g] = (const v4i *)img_region[g / ng];
-    hipLaunchKernelGGL(k_mmstream, dim3((tgs + 7) / 8 * 8 * ngt, nchunks), dim3(SW * 64), 0, c->stream, imgs, mtiles, KS, (uint32_t)nrows, rpc,
-                       (const v4i *)cd, part, ngt, (uint64_t)(cd_bytes / 16), (uint64_t)(part_bytes / 4));
-  }
-  HIP_TRY(c, hipGetLastError());
-  for (uint32_t g = 0; g < ngt; g++) {
-    const dim3 fgrid(n + 1, (nvecs[g] + 63) / 64);
-    int *pg = part + g * (part_bytes / 4);
-    if (ND == 4)
-      hipLaunchKernelGGL(k_evalmm_finish<4>, fgrid, dim3(256), 0, c->stream, pg, ios[g].sc_zeroed, nchunks, ntiles, (uint32_t)N2, nvecs[g], n, (uint32_t)nrows,
-                         wg.ct, wg.mbp, wg.sby, wg.LL, ios[g], 0);
-    else
-      hipLaunchKernelGGL(k_evalmm_finish<1>, fgrid, dim3(256), 0, c->stream, pg, ios[g].sc_zeroed, nchunks, ntiles, (uint32_t)N2, nvecs[g], n, (uint32_t)nrows,
-                         wg.ct, wg.mbp, wg.sby, wg.LL, ios[g], 0);
-  }
-  HIP_TRY(c, hipGetLastError());
-  return MFH_OK;
+  mms_bind(P, c->mm_ws_sel ? c->ws2 : c->ws);
+  rc = mms_digits(c, P, ios, nvecs);
+  if (!rc) rc = mms_stream(c, P);
+  if (!rc) rc = mms_finish(c, P, ios, nvecs);
+  return rc;
 }
 int eval_rows_multi_io_set(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d_c8, const MmIo *ios, const uint32_t *nvecs, uint32_t ng,
                            uint32_t coeff_bytes) {

@@ -955,6 +955,10 @@ void mfh_ctx_destroy(mfh_ctx *c) {
   if (c->ws) hipFree(c->ws);
   if (c->wws) hipFree(c->wws);
   if (c->ws2) hipFree(c->ws2);
+  if (c->ws3) hipFree(c->ws3);
+  for (hipEvent_t e : c->ev_round) hipEventDestroy(e);
+  for (hipEvent_t e : c->ev_cdone) hipEventDestroy(e);
+  for (hipEvent_t e : c->ev_rdone) hipEventDestroy(e);
   if (c->lazy) hipFree(c->lazy);
   if (c->aux) hipFree(c->aux);
   if (c->ev_fork) hipEventDestroy(c->ev_fork);

@@ -5,6 +5,7 @@
 // of the stream offsets CTR_S / CTR_AS / CTR_BT / CTR_BV (src/snark.h:8-12).  The reference keeps four mallocs
 // (struct crs, src/snark.h:27-33); the host shim copies between the two.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -451,7 +452,7 @@ struct OnSide {  // eval_rows_multi_io* launch on c->stream with the workspace c
   ~OnSide() { c->stream = keep; c->mm_ws_sel = 0; }
 };
 
-// scratch of a batch call: [2 x (w | h | v) of a super-group] | CW (packed witness bits + deltas of a super-group) | ONE | CT_T | the
+// scratch of a batch call: [whv x (w | h | v) of a super-group] | CW (packed witness bits + deltas of a super-group) | ONE | CT_T | the
 // launches' column-sum slots (256 int64 each)
 struct BatchScratch {
   uint32_t *WHV;
@@ -461,12 +462,12 @@ struct BatchScratch {
   int64_t *SCZ;
   size_t nslots;
 };
-int batch_scratch(mfh_ctx *c, uint32_t nproofs, bool whv, BatchScratch &B) {
+int batch_scratch(mfh_ctx *c, uint32_t nproofs, uint32_t whv /* w | h | v areas of a super-group */, BatchScratch &B) {
   const uint32_t d = c->P.d, m = c->P.m, n = c->P.n;
   const size_t ctl = (size_t)(n + 1) * ((c->P.logq + 63) / 64);
   const size_t nsg = ((size_t)nproofs + BSG - 1) / BSG;
   B.nslots = nsg * (1 + 2 * ((BSG + BG - 1) / BG));  // multi-vector launches of the call
-  const size_t whv_b = whv ? (size_t)6 * BSG * d * 4 : 0;
+  const size_t whv_b = (size_t)whv * 3 * BSG * d * 4;
   const size_t cw_b = (((size_t)BSG * ((m + 6) / 8) + 3) & ~(size_t)3) + (size_t)BSG * 4;
   const size_t cw_pad = (cw_b + 255) & ~(size_t)255;
   const size_t need = whv_b + cw_pad + 256 + ctl * 8 + B.nslots * 2048;
@@ -577,29 +578,74 @@ int batch_rows_supergroup(mfh_ctx *c, const uint8_t *d_crs_c8, uint32_t rank, ui
   // image registered for both regions: the S and the AS groups of a round share ONE streaming launch (no two launches of the kernel overlap:
   // one region's fragments at a time in the L2s); otherwise two streams, so that one stream's small kernels run under the other's row kernel
   const bool merged = mm_image_covers(c, regs[0].off, cS) && mm_image_covers(c, regs[1].off, cS) && c->batch_merge;
-  for (uint32_t g0 = 0; g0 < sg; g0 += NGL * BG) {
-    MmIo io[2 * NGLMAX];
-    uint32_t nv[2 * NGLMAX], ng = 0;
-    for (uint32_t k = 0; k < NGL && g0 + k * BG < sg; k++) ng++;
-    for (uint32_t k = 0; k < ng; k++) {
-      const uint32_t gg = g0 + k * BG, g = std::min(BG, sg - gg);
-      uint64_t *proofs = sproofs + (size_t)gg * 5 * ctl;
-      const uint64_t o = (uint64_t)gg * co.stride;
-      io[k] = MmIo{{co.w + o, co.h + o}, g, {proofs + 3 * ctl, proofs}, g, pstride, nullptr, 0, B.SCZ + 256 * slot++, co.stride, 0};                 // S: (w, h) -> (v_w, h)
-      io[ng + k] = MmIo{{co.h + o, co.v + o}, g, {proofs + ctl, proofs + 2 * ctl}, g, pstride, nullptr, 0, B.SCZ + 256 * slot++, co.stride, 0};  // AS: (h, v) -> (hat_h, hat_v)
-      nv[k] = nv[ng + k] = 2 * g;
+  if (merged) {
+    // Streaming regime.  All rounds' operands (digit fragments, column sums) are prepared first; the streaming launches then run back to
+    // back on the caller's stream, and the epilogues of round r (partial products -> ciphertext words in the proof structs) run on the
+    // side stream beside the launch of round r + 1.  Every round has its own digit / partial-product area in ws3.
+    constexpr uint32_t RMAX = (BSG + BG - 1) / BG;  // rounds of a super-group with one group per launch
+    MmIo io[RMAX][2 * NGLMAX];
+    uint32_t nv[RMAX][2 * NGLMAX];
+    MmsPlan plan[RMAX];
+    uint32_t R = 0;
+    size_t ws_need = 0;
+    for (uint32_t g0 = 0; g0 < sg; g0 += NGL * BG, R++) {
+      uint32_t ng = 0;
+      for (uint32_t k = 0; k < NGL && g0 + k * BG < sg; k++) ng++;
+      for (uint32_t k = 0; k < ng; k++) {
+        const uint32_t gg = g0 + k * BG, g = std::min(BG, sg - gg);
+        uint64_t *proofs = sproofs + (size_t)gg * 5 * ctl;
+        const uint64_t o = (uint64_t)gg * co.stride;
+        io[R][k] = MmIo{{co.w + o, co.h + o}, g, {proofs + 3 * ctl, proofs}, g, pstride, nullptr, 0, B.SCZ + 256 * slot++, co.stride, 0};                 // S: (w, h) -> (v_w, h)
+        io[R][ng + k] = MmIo{{co.h + o, co.v + o}, g, {proofs + ctl, proofs + 2 * ctl}, g, pstride, nullptr, 0, B.SCZ + 256 * slot++, co.stride, 0};  // AS: (h, v) -> (hat_h, hat_v)
+        nv[R][k] = nv[R][ng + k] = 2 * g;
+      }
+      if (!mms_plan(c, regs, 2, cS, io[R], nv[R], ng, 4, plan[R])) { c->err = "mfh_prove_batch: the registered image does not serve the S / AS regions"; return MFH_EINVAL; }
+      ws_need += (mms_ws_bytes(plan[R]) + 255) & ~(size_t)255;
     }
-    if (merged) {
-      rc = eval_rows_multi_io_regions(c, regs, 2, cS, io, nv, ng, 4);
-      if (rc) return rc;
-      continue;
-    }
-    rc = eval_rows_multi_io_regions(c, regs, 1, cS, io, nv, ng, 4);
+    rc = buf_reserve(c, c->ws3, c->ws3_bytes, ws_need);
     if (rc) return rc;
-    {
-      OnSide side(c, side_stream);
-      rc = eval_rows_multi_io_regions(c, regs + 1, 1, cS, io + ng, nv + ng, ng, 4);
+    while (c->ev_round.size() < R) {
+      hipEvent_t e;
+      HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      c->ev_round.push_back(e);
+    }
+    size_t wo = 0;
+    for (uint32_t r = 0; r < R; r++) {
+      mms_bind(plan[r], (uint8_t *)c->ws3 + wo);
+      wo += (mms_ws_bytes(plan[r]) + 255) & ~(size_t)255;
+      rc = mms_digits(c, plan[r], io[r], nv[r]);
       if (rc) return rc;
+    }
+    for (uint32_t r = 0; r < R; r++) {
+      rc = mms_stream(c, plan[r]);
+      if (rc) return rc;
+      HIP_TRY(c, hipEventRecord(c->ev_round[r], main_stream));
+      OnStream side(c, side_stream);
+      HIP_TRY(c, hipStreamWaitEvent(side_stream, c->ev_round[r], 0));
+      rc = mms_finish(c, plan[r], io[r], nv[r]);
+      if (rc) return rc;
+    }
+  } else {
+    // Regenerating regime (or one group per launch): two streams, so that one stream's small kernels run under the other's row kernel
+    for (uint32_t g0 = 0; g0 < sg; g0 += NGL * BG) {
+      MmIo io[2 * NGLMAX];
+      uint32_t nv[2 * NGLMAX], ng = 0;
+      for (uint32_t k = 0; k < NGL && g0 + k * BG < sg; k++) ng++;
+      for (uint32_t k = 0; k < ng; k++) {
+        const uint32_t gg = g0 + k * BG, g = std::min(BG, sg - gg);
+        uint64_t *proofs = sproofs + (size_t)gg * 5 * ctl;
+        const uint64_t o = (uint64_t)gg * co.stride;
+        io[k] = MmIo{{co.w + o, co.h + o}, g, {proofs + 3 * ctl, proofs}, g, pstride, nullptr, 0, B.SCZ + 256 * slot++, co.stride, 0};                 // S: (w, h) -> (v_w, h)
+        io[ng + k] = MmIo{{co.h + o, co.v + o}, g, {proofs + ctl, proofs + 2 * ctl}, g, pstride, nullptr, 0, B.SCZ + 256 * slot++, co.stride, 0};  // AS: (h, v) -> (hat_h, hat_v)
+        nv[k] = nv[ng + k] = 2 * g;
+      }
+      rc = eval_rows_multi_io_regions(c, regs, 1, cS, io, nv, ng, 4);
+      if (rc) return rc;
+      {
+        OnSide side(c, side_stream);
+        rc = eval_rows_multi_io_regions(c, regs + 1, 1, cS, io + ng, nv + ng, ng, 4);
+        if (rc) return rc;
+      }
     }
   }
   HIP_TRY(c, hipEventRecord(c->ev_join, side_stream));
@@ -687,33 +733,52 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
     if (h_delta[b] >= P32) { c->err = "delta must be < p"; return MFH_EINVAL; }
   const size_t ctl = (size_t)(n + 1) * ((c->P.logq + 63) / 64);
   HIP_TRY(c, hipSetDevice(c->device));
+  // The chain (witness pass + polynomial step) of a super-group runs on its own stream, up to `nbuf` super-groups ahead of the row work
+  // (one w | h | v area each): the first chains run beside the CRS expansion, the later ones beside the previous super-groups' launches.
+  // How far ahead does not matter (measured: 2, 3, 4, 8 areas -> 88.2, 88.7, 89.4, 89.9 ms per 992 statements): every kernel of the call
+  // fills the CUs it gets (one k_mmstream workgroup owns a CU's registers and LDS, k_expand_mm runs 8 waves per SIMD), so concurrent
+  // streams time-share the GPU and the work is conserved; two areas are the least memory.
+  const uint32_t nsg = (nproofs + BSG - 1) / BSG;
+  uint32_t nbuf = c->batch_chain_ahead;
+  if (const char *ev = getenv("MFH_CHAIN_AHEAD")) nbuf = (uint32_t)atoi(ev);  // tuning override (tools/batch_time.py)
+  nbuf = std::max(2u, std::min(nbuf, nsg));
+  while (nbuf > 2 && (size_t)nbuf * 3 * BSG * d * 4 > ((size_t)8 << 30)) nbuf--;
   BatchScratch B;
-  int rc = batch_scratch(c, nproofs, true, B);
+  int rc = batch_scratch(c, nproofs, nbuf, B);
   if (rc) return rc;
-  // w | h | v twice: the chain (witness pass + polynomial step) of super-group k + 1 is queued while super-group k is still smudged.  The
-  // multi-vector launches read their coefficient vectors where the polynomial step left them and write the proof structs in place (MmIo).
   size_t slot = 0;
   HIP_TRY(c, hipMemsetAsync(B.SCZ, 0, B.nslots * 2048, c->stream));
-  // Two streams: the S-region launches of the groups run on the caller's stream, the AS-region launches on the side stream, so that the
-  // last, partly filled round of workgroups of one launch (736 workgroups on 256 CUs) is filled by the next launch's first ones.
   rc = batch_streams(c);
   if (rc) return rc;
+  while (c->ev_cdone.size() < nbuf) {
+    hipEvent_t e0, e1;
+    HIP_TRY(c, hipEventCreateWithFlags(&e0, hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+    c->ev_cdone.push_back(e0);
+    c->ev_rdone.push_back(e1);
+  }
   hipStream_t const main_stream = c->stream, chain_stream = c->side2;
-  // The chain of a super-group on its own stream: the first one runs beside the CRS expansion, the chain of super-group k + 1 beside the
-  // smudging of super-group k and its own b_w rows.
-  auto launch_chain = [&](uint32_t sgi) -> int {
+  auto whv_of = [&](uint32_t sgi, uint32_t *&W, uint32_t *&H, uint32_t *&V) {
+    W = B.WHV + (size_t)(sgi % nbuf) * 3 * BSG * d;
+    H = W + (size_t)BSG * d;
+    V = H + (size_t)BSG * d;
+  };
+  auto launch_chain = [&](uint32_t sgi) -> int {  // the chain stream has been told what to wait for
     const uint32_t s0 = sgi * BSG, sg = std::min(BSG, nproofs - s0);
-    uint32_t *const WALL = B.WHV + (size_t)(sgi & 1) * 3 * BSG * d, *const HALL = WALL + (size_t)BSG * d, *const VALL = HALL + (size_t)BSG * d;
-    HIP_TRY(c, hipEventRecord(c->ev_chain, main_stream));  // what the caller's stream has been given so far no longer reads these buffers
-    HIP_TRY(c, hipStreamWaitEvent(chain_stream, c->ev_chain, 0));
+    uint32_t *WALL, *HALL, *VALL;
+    whv_of(sgi, WALL, HALL, VALL);
     OnStream chain(c, chain_stream);
     int r = batch_chain_launch(c, src, d_ssp, sg, h_witness_bits + (size_t)s0 * bits_stride, bits_stride, h_delta + s0, WALL, HALL, VALL);
     if (r) return r;
-    HIP_TRY(c, hipEventRecord(c->ev_chain_done, chain_stream));
+    HIP_TRY(c, hipEventRecord(c->ev_cdone[sgi % nbuf], chain_stream));
     return MFH_OK;
   };
-  rc = launch_chain(0);
-  if (rc) return rc;
+  HIP_TRY(c, hipEventRecord(c->ev_chain, main_stream));  // what the caller's stream has been given so far no longer reads the scratch
+  HIP_TRY(c, hipStreamWaitEvent(chain_stream, c->ev_chain, 0));
+  for (uint32_t k = 0; k < nbuf && k < nsg; k++) {
+    rc = launch_chain(k);
+    if (rc) return rc;
+  }
   ImageGuard transient{c, false};
   rc = batch_transient_image(c, d_crs_c8, nproofs, 0, 1, transient);
   if (rc) return rc;
@@ -722,15 +787,17 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
   for (uint32_t s0 = 0, sgi = 0; s0 < nproofs; s0 += BSG, sgi++) {
     const uint32_t sg = std::min(BSG, nproofs - s0);
     uint64_t *sproofs = d_proofs + (size_t)s0 * 5 * ctl;
-    uint32_t *const WALL = B.WHV + (size_t)(sgi & 1) * 3 * BSG * d, *const HALL = WALL + (size_t)BSG * d, *const VALL = HALL + (size_t)BSG * d;
+    uint32_t *WALL, *HALL, *VALL;
+    whv_of(sgi, WALL, HALL, VALL);
     const BatchCoef co = {WALL, HALL, VALL, d};
+    // the multi-vector launches read their coefficient vectors where the polynomial step left them and write the proof structs in place (MmIo)
     rc = batch_rows_supergroup(c, d_crs_c8, 0, 1, sg, h_witness_bits + (size_t)s0 * bits_stride, bits_stride, co, sproofs, B, slot, h_delta + s0,
-                               c->ev_chain_done);
+                               c->ev_cdone[sgi % nbuf]);
     if (rc) return rc;
-    // the next super-group's chain (the other w | h | v buffers) runs beside this one's smudging and the next one's b_w rows; started
-    // any earlier it would share the GPU with the HBM-bound S / AS launches, which costs more than it hides (measured)
-    if (s0 + BSG < nproofs) {
-      rc = launch_chain(sgi + 1);
+    if (sgi + nbuf < nsg) {  // this super-group's w | h | v area is free again: the chain of super-group sgi + nbuf
+      HIP_TRY(c, hipEventRecord(c->ev_rdone[sgi % nbuf], main_stream));
+      HIP_TRY(c, hipStreamWaitEvent(chain_stream, c->ev_rdone[sgi % nbuf], 0));
+      rc = launch_chain(sgi + nbuf);
       if (rc) return rc;
     }
     rc = batch_smudge(c, sproofs, sg, h_smudge_mag + (size_t)s0 * 5 * maglen, maglen, h_smudge_sign + (size_t)s0 * 5);
@@ -779,7 +846,7 @@ int mfh_prove_batch_partial(mfh_ctx *c, const uint8_t *d_crs_c8, uint32_t rank, 
   const size_t ctl = (size_t)(n + 1) * ((c->P.logq + 63) / 64);
   HIP_TRY(c, hipSetDevice(c->device));
   BatchScratch B;
-  int rc = batch_scratch(c, nstmt, false, B);
+  int rc = batch_scratch(c, nstmt, 0, B);
   if (rc) return rc;
   size_t slot = 0;
   HIP_TRY(c, hipMemsetAsync(B.SCZ, 0, B.nslots * 2048, c->stream));
@@ -810,7 +877,7 @@ int mfh_prove_batch_finish(mfh_ctx *c, const uint8_t *d_crs_c8, uint32_t nstmt, 
   const size_t ctl = (size_t)(n + 1) * ((c->P.logq + 63) / 64);
   HIP_TRY(c, hipSetDevice(c->device));
   BatchScratch B;
-  int rc = batch_scratch(c, std::min(nstmt, BSG), false, B);
+  int rc = batch_scratch(c, std::min(nstmt, BSG), 0, B);
   if (rc) return rc;
   rc = batch_ct_t(c, d_crs_c8, B);
   if (rc) return rc;

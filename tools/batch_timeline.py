@@ -5,7 +5,7 @@ f = max(glob.glob(sys.argv[1]), key=lambda p: len(open(p).read()))
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 # a step of the transient-image path starts with the three expansion launches k_evalmm16<1, ...>
-ex = [i for i, r in enumerate(rows) if "k_evalmm16<1" in r["Kernel_Name"]]
+ex = [i for i, r in enumerate(rows) if "k_evalmm16<1" in r["Kernel_Name"] or "k_expand_mm" in r["Kernel_Name"]]
 starts = ex[::3]  # three expansion launches (S, AS, BT+BV) per call
 s0 = starts[-back - 1]; s1 = starts[-back]
 t0 = int(rows[s0]["Start_Timestamp"])
