@@ -363,7 +363,12 @@ def main():
         except Exception:
             return None
 
-    def mmstream_roofline(kt, step_ms, steps_=None):
+    def mmstream_roofline(ktd, step_ms, steps_=None):
+        """roofline of k_mmstream from the launches that serve several groups (the S / AS rounds: the dominant shape); the single-group
+        launches of the same kernel (b_w over the BT+BV rows: HBM-bound) are listed beside it and counted in whole_step"""
+        kt, other = ktd["mmstream_rounds"], ktd["evalmm_resident"]
+        if not kt[0]:
+            kt, other = other, (0, 0.0, 0, 0.0, 0)
         n_, ms_, rows_, busy_, work_ = kt
         if not n_:
             return None
@@ -374,7 +379,8 @@ def main():
         ops = 2.0 * mtile_rows * 256 * work                      # int8 multiply-adds x 2 per launch (M x N = 256 x K = rows x groups)
         tops = ops / (avg * 1e-3) / 1e12                         # per average launch duration: what rocprofv3 --stats reproduces
         tops_busy = ops / (eff * 1e-3) / 1e12                    # per union of launch spans (= tops when launches do not overlap)
-        step_tops = ops * n_ / (steps_ or args.steps) / (step_ms * 1e-3) / 1e12  # the kernel's operations of a step over the WHOLE step time
+        ops_other = 2.0 * mtile_rows * 256 * other[4]               # (all single-group launches together)
+        step_tops = (ops * n_ + ops_other) / (steps_ or args.steps) / (step_ms * 1e-3) / 1e12  # the kernel's operations of a step over the WHOLE step time
         gbs = regions * rows * tile_bytes_per_row / (avg * 1e-3) / 1e9  # one pass over each region's image
         return {"bound": "mfma", "kernel": "k_mmstream (A fragments of the expanded CRS streamed once per launch and region for 4 groups of 31 proofs -- "
                                            "HBM for the first workgroup of a row-tile set, that XCD's L2 for the other three --, digit fragments "
@@ -384,6 +390,9 @@ def main():
                 "traffic_source": "static file profiles/traffic_mmstream.json (a separate rocprofv3 --pmc pass of this command, not this run)",
                 "launches": n_, "avg_launch_ms": avg, "busy_ms_per_launch": eff, "concurrency": avg / eff, "rows_per_launch": rows,
                 "groups_per_launch": groups, "regions_per_launch": regions, "int8_ops_per_launch": ops,
+                "single_group_launches": ({"launches": other[0], "avg_launch_ms": other[1] / other[0], "rows_per_launch": other[2] / other[0],
+                                           "what": "b_w: one byte column per proof over the BT+BV rows, one pass over that region's image per 248 proofs (HBM-bound)",
+                                           "image_gbs": other[2] / other[0] * tile_bytes_per_row / (other[1] / other[0] * 1e-3) / 1e9} if other[0] else None),
                 "achieved_by_busy_time": tops_busy, "frac_by_busy_time": tops_busy / MFMA_I8_PEAK_TOPS,
                 "whole_step": {"achieved": step_tops, "frac": step_tops / MFMA_I8_PEAK_TOPS,
                                "note": "this kernel's int8 operations of a step / ms_per_step: the matrix-core fraction of the whole job"},
@@ -440,7 +449,7 @@ def main():
             for _ in range(max(args.warmup - 1, 0)):
                 ctx.prove_batch(d_crs, d_ssp_b, b_bits, b_delta, b_mags, b_signs, out=out)
             ctx.set_timing(True)
-            for k in ("evalmm", "evalmm_resident", "expandmm"):
+            for k in ("evalmm", "mmstream_rounds", "evalmm_resident", "expandmm"):
                 ctx.timing_drain(k)
             barrier()
             t_ = time.perf_counter()
@@ -450,7 +459,7 @@ def main():
             el = time.perf_counter() - t_
             ctx.set_timing(False)
             kt = {}
-            for k in ("evalmm", "evalmm_resident", "expandmm"):
+            for k in ("evalmm", "mmstream_rounds", "evalmm_resident", "expandmm"):  # (rounds first: "evalmm_resident" then holds the single-group launches, b_w's)
                 n_, ms_, rows_ = ctx.timing_drain(k)
                 kt[k] = (n_, ms_, rows_, ctx.timing_busy_ms(), ctx.timing_work_rows())  # launches on two streams overlap: busy = union of their spans
             if dist is not None:
@@ -505,13 +514,13 @@ def main():
             del image_mm, out_r
             resident_b = {"value": world * nb * args.steps / el_rb, "unit": "proofs/s", "ms_per_step": el_rb / args.steps * 1e3,
                           "proofs_identical_to_headline": same_rb, "crs_expand_s": expand_mm_s, "image_bytes_per_rank": img_bytes,
-                          "roofline": mmstream_roofline(kt_r["evalmm_resident"], el_rb / args.steps * 1e3)}
-        used_image = kt_b["evalmm_resident"][0] > 0
+                          "roofline": mmstream_roofline(kt_r, el_rb / args.steps * 1e3)}
+        used_image = kt_b["evalmm_resident"][0] + kt_b["mmstream_rounds"][0] > 0
         batched = {"value": world * nb * args.steps / el_b, "unit": "proofs/s", "ms_per_step": el_b / args.steps * 1e3, "statements_per_gpu_per_step": nb,
                    "valid_accepted_invalid_rejected_and_identical_to_single_proof_path": all_ok, "resident_crs": resident_b,
                    "regenerate_per_group": regen, "device_verifier_proofs_per_s": verify_per_s,
                    "transient_image_bytes_per_rank": image_bytes if used_image else 0, "crs_expansion": expand_info(kt_b["expandmm"]),
-                   "roofline": mmstream_roofline(kt_b["evalmm_resident"], el_b / args.steps * 1e3) if used_image else evalmm16_roofline(kt_b["evalmm"])}
+                   "roofline": mmstream_roofline(kt_b, el_b / args.steps * 1e3) if used_image else evalmm16_roofline(kt_b["evalmm"])}
 
     # ---- N > 1: the row-sharded BATCH prover (BASELINE configs 3/4): one statement list for the whole job, CRS rows sharded over the ranks,
     # all-to-all of the coefficient row slices + ONE reduce-scatter of uint64 lanes per step (dist.prove_batch_sharded)
@@ -533,7 +542,7 @@ def main():
         for _ in range(max(args.warmup, 1) if not big else 1):
             s_first, s_count, s_pr = sharded_step()
         ctx.set_timing(True)
-        for k in ("evalmm", "evalmm_resident", "expandmm"):
+        for k in ("evalmm", "mmstream_rounds", "evalmm_resident", "expandmm"):
             ctx.timing_drain(k)
         barrier()
         ts = time.perf_counter()
@@ -543,7 +552,7 @@ def main():
         el_s = time.perf_counter() - ts
         ctx.set_timing(False)
         kt_s = {}
-        for k in ("evalmm", "evalmm_resident", "expandmm"):
+        for k in ("evalmm", "mmstream_rounds", "evalmm_resident", "expandmm"):
             n_, ms_, rows_ = ctx.timing_drain(k)
             kt_s[k] = (n_, ms_, rows_, ctx.timing_busy_ms(), ctx.timing_work_rows())
         tt = torch.tensor([el_s], dtype=torch.float64, device=ctx.device)
@@ -572,7 +581,7 @@ def main():
                      "image_share_bytes_per_rank": share_img,
                      "image": "transient: every call expands the rank's row shares (AES on the CU) inside the timed region" if kt_s["expandmm"][0] else
                               ("regenerated per group" if kt_s["evalmm"][0] else "resident"),
-                     "roofline": mmstream_roofline(kt_s["evalmm_resident"], el_s / sh_steps * 1e3, sh_steps) if kt_s["evalmm_resident"][0] else None,
+                     "roofline": mmstream_roofline(kt_s, el_s / sh_steps * 1e3, sh_steps) if (kt_s["evalmm_resident"][0] + kt_s["mmstream_rounds"][0]) else None,
                      "crs_expansion": expand_info(kt_s["expandmm"], sh_steps)}
         del sbufs, s_pr
 

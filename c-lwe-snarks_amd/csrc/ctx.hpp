@@ -46,7 +46,6 @@ struct mfh_ctx {
   void *ws3 = nullptr;       // mfh_prove_batch, streaming regime: digit fragments and partial products of all rounds of a super-group
   size_t ws3_bytes = 0;
   std::vector<hipEvent_t> ev_cdone, ev_rdone;  // mfh_prove_batch: chain of super-group k done / its w | h | v area read (per area)
-  uint32_t batch_chain_ahead = 2;             // w | h | v areas: how many super-groups the chains may run ahead of the row work (2, 3, 4, 8 measured: 88.2, 88.7, 89.4, 89.9 ms per 992 statements)
   std::vector<hipEvent_t> ev_round;  // one per round: its streaming launch has finished
   void *wws = nullptr;       // scratch of the witness pass (its own buffer: the pass may run beside an eval launch that owns `ws`)
   size_t wws_bytes = 0;

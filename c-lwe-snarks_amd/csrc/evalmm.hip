@@ -1008,7 +1008,7 @@ int mms_digits(mfh_ctx *c, const MmsPlan &P, const MmIo *ios, const uint32_t *nv
   return MFH_OK;
 }
 int mms_stream(mfh_ctx *c, const MmsPlan &P) {
-  Timer t(c, 8, P.nrows, (uint64_t)P.nrows * P.ngt);
+  Timer t(c, P.ngt > 1 ? 10 : 8, P.nrows, (uint64_t)P.nrows * P.ngt);  // kind 10 ("mmstream_rounds"): several groups per launch
   const uint32_t KS = (P.nrows + RT2 - 1) / RT2 * (RT2 / 64), tgs = (P.mtiles + 2 * SW - 1) / (2 * SW);
   MmsImages imgs{};
   for (uint32_t g = 0; g < P.ngt; g++) imgs.image[g] = (const v4i *)P.img[g / P.ng];

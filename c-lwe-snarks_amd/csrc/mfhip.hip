@@ -1048,6 +1048,7 @@ static int timing_kind(const char *which) {
   if (!strcmp(which, "evalmm")) return 7;
   if (!strcmp(which, "evalmm_resident")) return 8;
   if (!strcmp(which, "expandmm")) return 9;
+  if (!strcmp(which, "mmstream_rounds")) return 10;  // the streaming launches that serve several groups (a subset of "evalmm_resident")
   return -1;
 }
 
@@ -1064,7 +1065,7 @@ int mfh_timing_drain(mfh_ctx *c, const char *which, uint64_t *count, double *tot
   std::vector<std::pair<float, float>> spans;  // [start, end) of every matching launch, relative to the first one's start event
   hipEvent_t base = nullptr;
   for (auto &t : c->timed) {
-    const bool match = t.kind == kind || (kind == 12 && (t.kind == 1 || t.kind == 2));
+    const bool match = t.kind == kind || (kind == 12 && (t.kind == 1 || t.kind == 2)) || (kind == 8 && t.kind == 10);
     if (!match) { keep.push_back(t); continue; }
     float ms = 0;
     if (hipEventElapsedTime(&ms, t.e0, t.e1) == hipSuccess) {
@@ -1086,7 +1087,7 @@ int mfh_timing_drain(mfh_ctx *c, const char *which, uint64_t *count, double *tot
   c->last_busy_ms = busy;
   c->last_work_rows = work;
   for (auto &t : c->timed) {
-    const bool match = t.kind == kind || (kind == 12 && (t.kind == 1 || t.kind == 2));
+    const bool match = t.kind == kind || (kind == 12 && (t.kind == 1 || t.kind == 2)) || (kind == 8 && t.kind == 10);
     if (!match) continue;
     c->ev_pool.push_back(t.e0);
     c->ev_pool.push_back(t.e1);

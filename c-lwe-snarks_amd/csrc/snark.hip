@@ -579,9 +579,9 @@ int batch_rows_supergroup(mfh_ctx *c, const uint8_t *d_crs_c8, uint32_t rank, ui
   // one region's fragments at a time in the L2s); otherwise two streams, so that one stream's small kernels run under the other's row kernel
   const bool merged = mm_image_covers(c, regs[0].off, cS) && mm_image_covers(c, regs[1].off, cS) && c->batch_merge;
   if (merged) {
-    // Streaming regime.  All rounds' operands (digit fragments, column sums) are prepared first; the streaming launches then run back to
-    // back on the caller's stream, and the epilogues of round r (partial products -> ciphertext words in the proof structs) run on the
-    // side stream beside the launch of round r + 1.  Every round has its own digit / partial-product area in ws3.
+    // Streaming regime, everything on the caller's stream: all rounds' operands (digit fragments, column sums: 0.02 ms per group) first,
+    // then per round the streaming launch and its epilogues (partial products -> ciphertext words in the proof structs: 0.05 ms per group).
+    // Every round has its own digit / partial-product area in ws3.
     constexpr uint32_t RMAX = (BSG + BG - 1) / BG;  // rounds of a super-group with one group per launch
     MmIo io[RMAX][2 * NGLMAX];
     uint32_t nv[RMAX][2 * NGLMAX];
@@ -604,11 +604,6 @@ int batch_rows_supergroup(mfh_ctx *c, const uint8_t *d_crs_c8, uint32_t rank, ui
     }
     rc = buf_reserve(c, c->ws3, c->ws3_bytes, ws_need);
     if (rc) return rc;
-    while (c->ev_round.size() < R) {
-      hipEvent_t e;
-      HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-      c->ev_round.push_back(e);
-    }
     size_t wo = 0;
     for (uint32_t r = 0; r < R; r++) {
       mms_bind(plan[r], (uint8_t *)c->ws3 + wo);
@@ -619,10 +614,7 @@ int batch_rows_supergroup(mfh_ctx *c, const uint8_t *d_crs_c8, uint32_t rank, ui
     for (uint32_t r = 0; r < R; r++) {
       rc = mms_stream(c, plan[r]);
       if (rc) return rc;
-      HIP_TRY(c, hipEventRecord(c->ev_round[r], main_stream));
-      OnStream side(c, side_stream);
-      HIP_TRY(c, hipStreamWaitEvent(side_stream, c->ev_round[r], 0));
-      rc = mms_finish(c, plan[r], io[r], nv[r]);
+      rc = mms_finish(c, plan[r], io[r], nv[r]);  // (on a side stream beside the next launch the epilogues starve -- 0.5 ms each instead of 0.05 -- and slow that launch by more than they take alone)
       if (rc) return rc;
     }
   } else {
@@ -733,16 +725,14 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
     if (h_delta[b] >= P32) { c->err = "delta must be < p"; return MFH_EINVAL; }
   const size_t ctl = (size_t)(n + 1) * ((c->P.logq + 63) / 64);
   HIP_TRY(c, hipSetDevice(c->device));
-  // The chain (witness pass + polynomial step) of a super-group runs on its own stream, up to `nbuf` super-groups ahead of the row work
-  // (one w | h | v area each): the first chains run beside the CRS expansion, the later ones beside the previous super-groups' launches.
-  // How far ahead does not matter (measured: 2, 3, 4, 8 areas -> 88.2, 88.7, 89.4, 89.9 ms per 992 statements): every kernel of the call
-  // fills the CUs it gets (one k_mmstream workgroup owns a CU's registers and LDS, k_expand_mm runs 8 waves per SIMD), so concurrent
-  // streams time-share the GPU and the work is conserved; two areas are the least memory.
+  // The chain (witness pass + polynomial step) of a super-group runs on its own stream: the first one beside the CRS expansion, the chain
+  // of super-group k + 1 after the row work of super-group k (beside its smudging), into the other of two w | h | v areas.  Queued further
+  // ahead (one area per super-group, chains beside the previous super-groups' streaming launches) the call takes the same time --
+  // measured with 2, 3, 4, 8 areas: 88.2, 88.7, 89.4, 89.9 ms per 992 statements -- because every kernel of the call fills the CUs it
+  // gets (one k_mmstream workgroup owns a CU's registers and LDS, k_expand_mm runs 8 waves per SIMD): concurrent streams time-share
+  // the GPU and the work is conserved.  In turn keeps the streaming launches' durations clean.
   const uint32_t nsg = (nproofs + BSG - 1) / BSG;
-  uint32_t nbuf = c->batch_chain_ahead;
-  if (const char *ev = getenv("MFH_CHAIN_AHEAD")) nbuf = (uint32_t)atoi(ev);  // tuning override (tools/batch_time.py)
-  nbuf = std::max(2u, std::min(nbuf, nsg));
-  while (nbuf > 2 && (size_t)nbuf * 3 * BSG * d * 4 > ((size_t)8 << 30)) nbuf--;
+  const uint32_t nbuf = 2;
   BatchScratch B;
   int rc = batch_scratch(c, nproofs, nbuf, B);
   if (rc) return rc;
@@ -775,10 +765,8 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
   };
   HIP_TRY(c, hipEventRecord(c->ev_chain, main_stream));  // what the caller's stream has been given so far no longer reads the scratch
   HIP_TRY(c, hipStreamWaitEvent(chain_stream, c->ev_chain, 0));
-  for (uint32_t k = 0; k < nbuf && k < nsg; k++) {
-    rc = launch_chain(k);
-    if (rc) return rc;
-  }
+  rc = launch_chain(0);
+  if (rc) return rc;
   ImageGuard transient{c, false};
   rc = batch_transient_image(c, d_crs_c8, nproofs, 0, 1, transient);
   if (rc) return rc;
@@ -794,10 +782,10 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
     rc = batch_rows_supergroup(c, d_crs_c8, 0, 1, sg, h_witness_bits + (size_t)s0 * bits_stride, bits_stride, co, sproofs, B, slot, h_delta + s0,
                                c->ev_cdone[sgi % nbuf]);
     if (rc) return rc;
-    if (sgi + nbuf < nsg) {  // this super-group's w | h | v area is free again: the chain of super-group sgi + nbuf
+    if (sgi + 1 < nsg) {  // the next super-group's chain, into the other area (last read by super-group sgi - 1)
       HIP_TRY(c, hipEventRecord(c->ev_rdone[sgi % nbuf], main_stream));
       HIP_TRY(c, hipStreamWaitEvent(chain_stream, c->ev_rdone[sgi % nbuf], 0));
-      rc = launch_chain(sgi + nbuf);
+      rc = launch_chain(sgi + 1);
       if (rc) return rc;
     }
     rc = batch_smudge(c, sproofs, sg, h_smudge_mag + (size_t)s0 * 5 * maglen, maglen, h_smudge_sign + (size_t)s0 * 5);

@@ -293,7 +293,7 @@ int mfh_eval_rows_multi(mfh_ctx *ctx, uint64_t off, size_t nrows, const uint8_t 
 /* Kernel timing for the roofline leg of bench.py.  With timing enabled every launch of a hot kernel is bracketed by
  * HIP events on the context's stream (no synchronisation is added).  mfh_timing_drain waits for the stream, then
  * reports and forgets the launches of kind `which`: "eval2" / "eval1" (k_eval with 2 / 1 coefficient vectors),
- * "eval" (both), "encrypt", "keystream", "expand", "mac2" / "mac1" (resident MAC), "evalmm" / "evalmm_resident" (mfh_eval_rows_multi from the seed / from the image), "expandmm" (mfh_crs_expand_mm, one launch per region).  total_rows = rows handed to those launches (AES blocks for "keystream"). */
+ * "eval" (both), "encrypt", "keystream", "expand", "mac2" / "mac1" (resident MAC), "evalmm" / "evalmm_resident" (mfh_eval_rows_multi from the seed / from the image), "mmstream_rounds" (those of "evalmm_resident" that serve several groups of a batch: the S / AS rounds of mfh_prove_batch; drain it first), "expandmm" (mfh_crs_expand_mm, one launch per region).  total_rows = rows handed to those launches (AES blocks for "keystream"). */
 int mfh_set_timing(mfh_ctx *ctx, int enabled);
 /* prover scheduling: mfh_prove* run the witness pass + polynomial step on an internal stream beside the evaluation of
  * b_w's rows and join before the S / AS regions; results are identical in every mode.  0 = one stream, 1 (default) = two

@@ -15,7 +15,9 @@
  *     pinned by (i) a second restatement that performs the same GMP calls the reference
  *     performs (oracle/gmp_check.c, real libgmp 6.2.1), and (ii) the reference's own test
  *     properties (src/test_lwe.c, src/test_snark.c, src/test_ssp.c) restated in tests/.
- *     No reference-generated KAT exists for those layers: "parity pinned by properties".
+ *     No reference-generated KAT exists for those layers and the reference cannot be built for
+ *     them here: in the task's vocabulary these layers are "PARITY UNPINNED" -- what stands in
+ *     for the missing pin is (i) and (ii), nothing more is claimed.
  *
  * Conventions.  A "value" is L = ceil(logq/64) little-endian uint64 limbs (12 at logq=736,
  * 23 at logq=1472).  K = logq/64 limbs survive modq (11 -> the reference's effective

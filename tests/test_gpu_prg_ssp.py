@@ -117,3 +117,89 @@ def test_full_2pow20_config_shape(gpu_ctx_factory, mf, logq):
     bad[1000] ^= 8
     assert int(ctx.to_host(ctx.verify(None, alpha, beta, s, d_sk, ctx.prove(d_crs, None, bytes(bad), delta, mags, signs), 1))[0]) == 0
     ctx.close()
+
+
+def test_config4_row_sharded_batch_emulated_on_one_gpu(gpu_ctx_factory, mf):
+    """BASELINE config 4 at its full shape through the ROW-SHARDED batch prover, the 8 ranks emulated one after the other on one GPU:
+    every rank expands its own 45 GB share of the matrix-core image (350 K rows; a 2^20 / 8 = 131 072-row S / AS share is one row more
+    than an int32 accumulator holds: two row chunks), streams it for a group of 31 statements and contributes uint64 lanes; the summed
+    proofs must equal mfh_prove_batch's (which regenerates the keystream: the 363 GB image fits no single GPU) bit for bit, verify for
+    the satisfying witnesses and fail for the others."""
+    import time
+
+    import torch
+
+    from c_lwe_snarks_amd import dist as mfdist
+
+    p = mf.Params(d=1 << 20, m=699050)
+    ctx = gpu_ctx_factory(p)
+    ctx.set_seed(SEED)
+    rng = np.random.default_rng(4)
+    bits0 = rng.bytes((p.m + 7) // 8)
+    d_t = ctx.ssp_prg_make_t(PRG_SEED, bits0)
+    ctx.ssp_set_prg(PRG_SEED, d_t)
+    ctx.ssp_prepare(None)
+    alpha, beta, s = (int(x) for x in rng.integers(1, ol.P, size=3, dtype=np.uint64))
+    g = torch.Generator(device=ctx.device)
+    g.manual_seed(4)
+    sk = torch.randint(-(2 ** 63), 2 ** 63 - 1, (p.n, p.L), dtype=torch.int64, device=ctx.device, generator=g)
+    sk[:, p.L - 1] &= (1 << (p.logq - 64 * (p.L - 1))) - 1
+    rows = 2 * p.d + p.m
+    err = torch.randint(-(2 ** 63), 2 ** 63 - 1, (rows, p.L), dtype=torch.int64, device=ctx.device, generator=g)
+    err[:, 8] &= (1 << 47) - 1
+    err[:, 9:] = 0
+    d_sk = sk.view(torch.uint8).reshape(-1)
+    d_crs = ctx.setup(None, alpha, beta, s, d_sk, err.view(torch.uint8).reshape(-1))
+    del err
+    nb, world = 31, 8
+    stmts = [bits0 if b % 2 == 0 else rng.bytes(len(bits0)) for b in range(nb)]
+    deltas = [int(x) for x in rng.integers(0, ol.P, size=nb, dtype=np.uint64)]
+    mags = [rng.integers(0, 256, size=400, dtype=np.uint8).tobytes() for _ in range(nb)]
+    signs = [bytes(rng.integers(0, 2, size=5, dtype=np.uint8).tolist()) for _ in range(nb)]
+    want = ctx.prove_batch(d_crs, None, stmts, deltas, mags, signs).clone()
+    per, owned = mfdist.statement_shares(nb, world)
+    shares = mfdist.row_shares(p.d, world)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    whv = [ctx.batch_chain(None, stmts[a:b], deltas[a:b]) for a, b in owned]
+    torch.cuda.synchronize()
+    t_chain = time.perf_counter() - t0
+    lps = 5 * (p.n + 1) * 2 * p.K
+    total = torch.zeros(per * world * lps, dtype=torch.int64, device=ctx.device)
+    image = ctx.empty(max(int(ctx.lib.mfh_crs_mm_share_bytes(ctx._h, r, world)) for r in range(world)))
+    t_exp = t_rows = 0.0
+    for r in range(world):
+        lo, hi = shares[r]
+        cs = hi - lo
+        recv = torch.cat([w[:, :, lo:hi].permute(1, 0, 2).reshape(-1) for w in whv])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ctx.crs_expand_mm_share(d_crs, r, world, out=image)
+        torch.cuda.synchronize()
+        t_exp += time.perf_counter() - t0
+        ctx.set_resident_mm_share(image, r, world)
+        try:
+            t0 = time.perf_counter()
+            partial = ctx.prove_batch_partial(d_crs, r, world, stmts, recv, recv[cs:], recv[2 * cs:], 3 * cs)
+            torch.cuda.synchronize()
+            t_rows += time.perf_counter() - t0
+        finally:
+            ctx.set_resident_mm_share(None, 0, 1)
+        lanes = torch.zeros_like(total)
+        ctx.ct_to_lanes(partial, nb * 5, out=lanes)
+        total += lanes
+        del recv, partial, lanes
+    got = []
+    for r, (a, b) in enumerate(owned):
+        if b > a:
+            proofs = ctx.ct_from_lanes(total[r * per * lps:(r * per + (b - a)) * lps], (b - a) * 5)
+            ctx.prove_batch_finish(d_crs, deltas[a:b], mags[a:b], signs[a:b], proofs)
+            got.append(proofs)
+    got = torch.cat(got)
+    print(f"\n[config 4, row-sharded batch, 8 ranks emulated on one GPU, {nb} statements] per rank: share image {image.numel() / 1e9:.1f} GB expanded in "
+          f"{t_exp / world * 1e3:.0f} ms, row work {t_rows / world * 1e3:.0f} ms; chains of all statements {t_chain * 1e3:.0f} ms")
+    assert torch.equal(got, want)
+    ok = ctx.to_host(ctx.verify(None, alpha, beta, s, d_sk, got, nb))
+    assert [bool(x) for x in ok] == [b % 2 == 0 for b in range(nb)]
+    del image
+    ctx.close()

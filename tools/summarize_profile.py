@@ -22,7 +22,7 @@ f = one(f"{tag}_stats/*/*_kernel_stats.csv")
 if f:
     rows = list(csv.DictReader(open(f)))
     with open(os.path.join(out_dir, f"{tag}_kernel_stats.csv"), "w") as o:
-        o.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline   (MI355X, 1 GPU; default batch mode: the headline run, then the regenerate-per-group and resident-image variants of the same batch, then the single-proof path)\n")
+        o.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline   (MI355X, 1 GPU; default batch mode: the single-proof path (regenerated and resident), then the headline run, then the regenerate-per-group and resident-image variants of the same batch, then the LWE batch)\n")
         o.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
         for r in rows:
             o.write(",".join(['"' + r["Name"][:110].replace('"', "'") + '"', r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]]) + "\n")
@@ -70,12 +70,22 @@ if ms and "FETCH_SIZE" in ms and "WRITE_SIZE" in ms:
     fetch = ms["FETCH_SIZE"]["mean_of_large_launches"] * 1024 * 2
     write = ms["WRITE_SIZE"]["mean_of_large_launches"] * 1024
     json.dump({"kernel": "k_mmstream", "fetch_bytes_x2_corrected": fetch, "write_bytes": write, "hbm_bytes_per_launch": fetch + write,
-               "note": "separate --pmc passes; FETCH_SIZE doubled per the gfx950 correction for wide coalesced streaming reads; launches over a "
-                       "whole S / AS region for 4 groups of 31 proofs (the b_w launches, one group over the shorter BT+BV region, excluded). "
-                       "Algorithmic: 4.24 GB of A fragments once + 4 x 8 MB of digits read, 4 x 133 MB of int32 partial products written; the "
-                       "workgroups consume 4 x 4.24 GB of fragments, the rest of which L2 serves"},
+               "note": "separate --pmc passes; FETCH_SIZE doubled per the gfx950 correction for wide coalesced streaming reads; launches over the "
+                       "whole S and AS regions for 4 + 4 groups of 31 proofs (the b_w launches, one group over the shorter BT+BV region, excluded). "
+                       "Algorithmic: 2 x 4.24 GB of A fragments once + 8 x 8 MB of digits read, 8 x 133 MB of int32 partial products written; the "
+                       "workgroups consume 8 x 4.24 GB of fragments, the rest of which L2 serves"},
               open(os.path.join(out_dir, "traffic_mmstream.json"), "w"), indent=1)
     print("traffic mmstream", fetch + write)
+for key, fname, note in (("k_expand_mm", "traffic_expandmm.json", "the barrier-free CRS expansion: reads the compressed CRS region (92 B per row), writes the image region (129 536 B per row)"),
+                         ("k_encrypt_mm", "traffic_encryptmm.json", "reads the Toeplitz(sk) fragments (12.7 MB per head value, from L2 after the first workgroups), writes 384 B of int32 partial sums per row and column chunk")):
+    kk = next((v for k, v in res.items() if key in k), None)
+    if kk and "FETCH_SIZE" in kk and "WRITE_SIZE" in kk:
+        fetch = kk["FETCH_SIZE"]["mean_of_large_launches"] * 1024 * 2
+        write = kk["WRITE_SIZE"]["mean_of_large_launches"] * 1024
+        json.dump({"kernel": key, "fetch_bytes_x2_corrected": fetch, "write_bytes": write, "hbm_bytes_per_launch": fetch + write,
+                   "note": "separate --pmc passes; FETCH_SIZE doubled per the gfx950 correction (an upper bound where reads are not wide streams); " + note},
+                  open(os.path.join(out_dir, fname), "w"), indent=1)
+        print("traffic", key, fetch + write)
 mr = next((v for k, v in res.items() if k.startswith("void k_mac_resident<736, 2>")), None)
 if mr and "FETCH_SIZE" in mr and "WRITE_SIZE" in mr:
     fetch = mr["FETCH_SIZE"]["mean"] * 1024 * 2
