@@ -546,7 +546,11 @@ __global__ __launch_bounds__(1024) void k_evalmm16(AesKey key /* rk[56..59] ^ 0x
 // the stage's digit fragments (64 KiB) are shared by the 8 waves of the workgroup through LDS, double buffered, one barrier per 256
 // rows.  HBM-bound by construction: per stage and CU 64 KiB of A against 128 x 8 MFMAs (1.7 us of matrix core) and 512 KiB of LDS
 // fragment reads.  grid = (row-tile pairs / 8, row chunks); part[((chunk * Mtot) + m) * 256 + n] as k_evalmm16 writes it.
-constexpr int SW = 8;   // waves per workgroup: RG row groups x CG column groups
+#ifndef MMS_SW
+#define MMS_SW 8
+#endif
+constexpr int SW = MMS_SW;   // waves per workgroup: RG row groups x CG column groups (MMS_SW=4 MMS_RQ=4: one wave per SIMD, 256 accumulators)
+constexpr int TPW = 16;      // row tiles per workgroup
 #ifndef MMS_RQ
 #define MMS_RQ 2
 #endif
@@ -813,6 +817,78 @@ __global__ __launch_bounds__(256) void k_witness_mm(const v4i *__restrict__ sspf
         part[(((uint64_t)blockIdx.y * 4 + w) * (32 * MT) + stmt) * d + k] = acc[t][w][e];
       }
 }
+// The same pass over a GENERATOR-DEFINED SSP (csrc/ssp_prg.hpp; BASELINE configs 3/4, where the dense SSP would be 5.9 TB): the B
+// fragments are not loaded but generated -- lane (coefficient k, row half h) hashes its 16 (row, k) pairs (9 integer operations each; the
+// un-reduced 32-bit hash: sums of raw values and sums of coefficients agree mod p) and picks the four byte planes with v_perm -- so that a
+// selected row is generated once per 32 MT statements instead of once per 12 (the VALU form, k_witness_partial_multi_prg): at 2^20
+// constraints the witness pass of a statement drops from 19 ms to about 2.  rowkeys[r] = ssp_prg_rowkey(seed, slot r + 2), padded to a
+// multiple of 32 rows.
+__global__ void k_prg_rowkeys(uint64_t seed, uint32_t nrows_pad, uint32_t *__restrict__ rk) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < nrows_pad) rk[r] = mf::ssp_prg_rowkey(seed, r + 2);
+}
+template <int MT>
+__global__ __launch_bounds__(256) void k_witness_mm_prg(const uint32_t *__restrict__ rowkeys, const v4i *__restrict__ bitfrag, uint32_t nrowsel /* m - 1 */,
+                                                        uint32_t ksteps_per_chunk, uint32_t d, int *__restrict__ part) {
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t r32 = lane & 31, h = lane >> 5;
+  const uint32_t kt = blockIdx.x * 4 + wave;
+  const uint32_t k = kt * 32 + r32;
+  const uint32_t K0 = blockIdx.y * ksteps_per_chunk, K1 = min((nrowsel + 31) / 32, K0 + ksteps_per_chunk);
+  v16i acc[MT][4];
+#pragma unroll
+  for (int t = 0; t < MT; t++)
+#pragma unroll
+    for (int w = 0; w < 4; w++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[t][w][e] = 0;
+  if (K0 >= K1) return;  // (uniform)
+  const uint32_t kc = k + 0x632BE5ABu;
+  for (uint32_t K = K0; K < K1; K++) {
+    v4i aq[MT];
+#pragma unroll
+    for (int t = 0; t < MT; t++) aq[t] = bitfrag[((uint64_t)K * MT + t) * 64 + lane];
+    const uint4 *rk4 = reinterpret_cast<const uint4 *>(rowkeys + 32 * K + 16 * h);
+    uint32_t x[16];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const uint4 r = rk4[q];
+      x[4 * q] = r.x; x[4 * q + 1] = r.y; x[4 * q + 2] = r.z; x[4 * q + 3] = r.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 16; e++) {  // mf::ssp_prg_raw(rowkey, k)
+      uint32_t y = kc * x[e];
+      y ^= y >> 16;
+      y *= 0x7FEB352Du;
+      y ^= y >> 15;
+      y *= 0x846CA68Bu;
+      y ^= y >> 16;
+      x[e] = y;
+    }
+    v4i bq[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const uint32_t lo = __builtin_amdgcn_perm(x[4 * j + 1], x[4 * j], 0x0c0c0400u + 0x00000101u * w);  // {x0.bw, x1.bw, 0, 0}
+        const uint32_t hi = __builtin_amdgcn_perm(x[4 * j + 3], x[4 * j + 2], 0x04000c0cu + 0x01010000u * w);  // {0, 0, x2.bw, x3.bw}
+        bq[w][j] = (int)((lo | hi) ^ 0x80808080u);
+      }
+#pragma unroll
+    for (int t = 0; t < MT; t++)
+#pragma unroll
+      for (int w = 0; w < 4; w++) acc[t][w] = __builtin_amdgcn_mfma_i32_32x32x32_i8(aq[t], bq[w], acc[t][w], 0, 0, 0);
+  }
+#pragma unroll
+  for (int t = 0; t < MT; t++)
+#pragma unroll
+    for (int w = 0; w < 4; w++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        const uint32_t stmt = 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h;
+        part[(((uint64_t)blockIdx.y * 4 + w) * (32 * MT) + stmt) * d + k] = acc[t][w][e];
+      }
+}
 // bits of nstmt statements (packed, bits_stride bytes apart) -> A fragments: bitfrag[K][t][lane (stmt = 32 t + (l & 31), h)][e] = bit
 // (32 K + 16 h + e) of that statement
 __global__ void k_witness_bits(const uint8_t *__restrict__ bits, size_t bits_stride, uint32_t nstmt, uint32_t nrowsel, uint32_t ksteps, uint32_t MT,
@@ -926,7 +1002,7 @@ int eval_rows_multi_io(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d_
       const uint32_t mtiles = ntiles * wg.mt, KS = ((uint32_t)nrows + RT2 - 1) / RT2 * (RT2 / 64);
       MmsImages imgs{};
       imgs.image[0] = (const v4i *)img_region;
-      hipLaunchKernelGGL(k_mmstream, dim3(((mtiles + 2 * SW - 1) / (2 * SW) + 7) / 8 * 8, nchunks), dim3(SW * 64), 0, c->stream, imgs,
+      hipLaunchKernelGGL(k_mmstream, dim3(((mtiles + TPW - 1) / TPW + 7) / 8 * 8, nchunks), dim3(SW * 64), 0, c->stream, imgs,
                          mtiles, KS, (uint32_t)nrows, rpc, (const v4i *)cd, part, 1u, (uint64_t)0, (uint64_t)0);
     } else if (wide && q736)
       hipLaunchKernelGGL((k_evalmm16<0, 736>), dim3(ntiles, nchunks), dim3(1024), 0, c->stream, keyx, c->d_t0, off, n, (uint32_t)nrows, rpc, d_c8, cd, part,
@@ -1009,7 +1085,7 @@ int mms_digits(mfh_ctx *c, const MmsPlan &P, const MmIo *ios, const uint32_t *nv
 }
 int mms_stream(mfh_ctx *c, const MmsPlan &P) {
   Timer t(c, P.ngt > 1 ? 10 : 8, P.nrows, (uint64_t)P.nrows * P.ngt);  // kind 10 ("mmstream_rounds"): several groups per launch
-  const uint32_t KS = (P.nrows + RT2 - 1) / RT2 * (RT2 / 64), tgs = (P.mtiles + 2 * SW - 1) / (2 * SW);
+  const uint32_t KS = (P.nrows + RT2 - 1) / RT2 * (RT2 / 64), tgs = (P.mtiles + TPW - 1) / TPW;
   MmsImages imgs{};
   for (uint32_t g = 0; g < P.ngt; g++) imgs.image[g] = (const v4i *)P.img[g / P.ng];
   hipLaunchKernelGGL(k_mmstream, dim3((tgs + 7) / 8 * 8 * P.ngt, P.nchunks), dim3(SW * 64), 0, c->stream, imgs, P.mtiles, KS, P.nrows, P.rpc, (const v4i *)P.cd,
@@ -1157,7 +1233,12 @@ int mfh_crs_set_resident_mm(mfh_ctx *c, const uint8_t *d_image) { return mfh_crs
 // mfh_witness_poly for up to 128 statements in ONE read of the (dense) SSP, on the matrix cores: d_w = nstmt polynomials of d coefficients
 int mfh_witness_poly_mm(mfh_ctx *c, const uint32_t *d_ssp, uint32_t nstmt, const uint8_t *h_bits, size_t bits_stride, const uint32_t *h_delta,
                         uint32_t *d_w) {
-  if (!c || !d_ssp || !h_bits || !h_delta || !d_w || nstmt == 0 || nstmt > 128) return MFH_EINVAL;
+  if (!c || !h_bits || !h_delta || !d_w || nstmt == 0 || nstmt > 128) return MFH_EINVAL;
+  mf::SspSrc src;  // d_ssp == NULL: the registered generator-defined SSP (B fragments generated in the kernel)
+  {
+    int rc0 = ssp_src(c, d_ssp, src);
+    if (rc0) return rc0;
+  }
   const uint32_t MT = nstmt > 64 ? 4 : nstmt > 32 ? 2 : 1;
   const uint32_t d = c->P.d, m = c->P.m;
   if (d % 128 || m < 2) { c->err = "mfh_witness_poly_mm: d must be a multiple of 128"; return MFH_EUNSUPPORTED; }
@@ -1168,7 +1249,7 @@ int mfh_witness_poly_mm(mfh_ctx *c, const uint32_t *d_ssp, uint32_t nstmt, const
   const uint32_t nchunks = std::min(ksteps, 4u), kpc = (ksteps + nchunks - 1) / nchunks;
   // the SSP in B-fragment order: built on first use per SSP (mfh_ssp_prepare invalidates it), kept beside the uint32 image
   const size_t sfrag_b = (size_t)ksteps * 32 * d * 4;
-  if (c->ssp_frag_src != d_ssp || c->ssp_frag_bytes < sfrag_b) {
+  if (src.dense && (c->ssp_frag_src != d_ssp || c->ssp_frag_bytes < sfrag_b)) {
     if (c->ssp_frag_bytes < sfrag_b) {
       if (c->ssp_frag) { hipStreamSynchronize(c->stream); hipFree(c->ssp_frag); c->ssp_frag = nullptr; c->ssp_frag_bytes = 0; }
       HIP_TRY(c, hipMalloc(&c->ssp_frag, sfrag_b));
@@ -1181,7 +1262,8 @@ int mfh_witness_poly_mm(mfh_ctx *c, const uint32_t *d_ssp, uint32_t nstmt, const
   }
   const size_t packed = (size_t)nstmt * bits_stride, head_b = ((packed + 8 + 128 * 8 + 255) & ~(size_t)255);
   const size_t frag_b = (size_t)ksteps * MT * 1024, part_b = (size_t)nchunks * 4 * 32 * MT * d * 4;
-  int rc = wws_reserve(c, head_b + frag_b + part_b);
+  const size_t rk_b = src.dense ? 0 : (((size_t)ksteps * 32 * 4 + 255) & ~(size_t)255);
+  int rc = wws_reserve(c, head_b + frag_b + part_b + rk_b);
   if (rc) return rc;
   // staged: packed bits, then (count of selected rows, delta) per statement
   uint8_t *stage = (uint8_t *)pin_acquire(c, c->pin_rows, head_b);
@@ -1203,7 +1285,14 @@ int mfh_witness_poly_mm(mfh_ctx *c, const uint32_t *d_ssp, uint32_t nstmt, const
   int8_t *d_frag = (int8_t *)(dev + head_b);
   int *d_part = (int *)(dev + head_b + frag_b);
   hipLaunchKernelGGL(k_witness_bits, dim3((uint32_t)((frag_b + 255) / 256)), dim3(256), 0, c->stream, dev, bits_stride, nstmt, nrowsel, ksteps, MT, d_frag);
-  if (MT == 1)
+  if (!src.dense) {
+    uint32_t *d_rk = (uint32_t *)(dev + head_b + frag_b + part_b);
+    const dim3 grid(d / 128, (ksteps + kpc - 1) / kpc);
+    hipLaunchKernelGGL(k_prg_rowkeys, dim3((ksteps * 32 + 255) / 256), dim3(256), 0, c->stream, src.seed, ksteps * 32, d_rk);
+    if (MT == 1) hipLaunchKernelGGL(k_witness_mm_prg<1>, grid, dim3(256), 0, c->stream, d_rk, (const v4i *)d_frag, nrowsel, kpc, d, d_part);
+    else if (MT == 2) hipLaunchKernelGGL(k_witness_mm_prg<2>, grid, dim3(256), 0, c->stream, d_rk, (const v4i *)d_frag, nrowsel, kpc, d, d_part);
+    else hipLaunchKernelGGL(k_witness_mm_prg<4>, grid, dim3(256), 0, c->stream, d_rk, (const v4i *)d_frag, nrowsel, kpc, d, d_part);
+  } else if (MT == 1)
     hipLaunchKernelGGL(k_witness_mm<1>, dim3(d / 128, (ksteps + kpc - 1) / kpc), dim3(256), 0, c->stream, (const v4i *)c->ssp_frag, (const v4i *)d_frag,
                        nrowsel, kpc, d, d_part);
   else if (MT == 2)
@@ -1212,7 +1301,7 @@ int mfh_witness_poly_mm(mfh_ctx *c, const uint32_t *d_ssp, uint32_t nstmt, const
   else
     hipLaunchKernelGGL(k_witness_mm<4>, dim3(d / 128, (ksteps + kpc - 1) / kpc), dim3(256), 0, c->stream, (const v4i *)c->ssp_frag, (const v4i *)d_frag,
                        nrowsel, kpc, d, d_part);
-  hipLaunchKernelGGL(k_witness_mm_finish, dim3((d + 255) / 256, nstmt), dim3(256), 0, c->stream, d_part, (ksteps + kpc - 1) / kpc, d_ssp, d_cd, nstmt, 32 * MT,
+  hipLaunchKernelGGL(k_witness_mm_finish, dim3((d + 255) / 256, nstmt), dim3(256), 0, c->stream, d_part, (ksteps + kpc - 1) / kpc, src.t, d_cd, nstmt, 32 * MT,
                      d, d_w);
   HIP_TRY(c, hipGetLastError());
   return MFH_OK;

@@ -505,9 +505,9 @@ int batch_chain_launch(mfh_ctx *c, const mf::SspSrc &src, const uint32_t *d_ssp,
                        const uint32_t *h_delta, uint32_t *W, uint32_t *H, uint32_t *V) {
   const uint32_t d = c->P.d;
   int rc = MFH_OK;
-  // dense SSP with d % 128 == 0: a GEMM on the matrix cores, one read of the SSP per 124 statements; otherwise the VALU form, read
-  // (or generated) once per 12 statements
-  if (src.dense && d % 128 == 0) {
+  // d % 128 == 0: a GEMM on the matrix cores, one read (dense SSP) or one generation (generator-defined SSP) of the selected rows per
+  // 124 statements; otherwise the VALU form, read or generated once per 12 statements
+  if (d % 128 == 0) {
     for (uint32_t b0 = 0; b0 < sg; b0 += 124) {
       rc = mfh_witness_poly_mm(c, d_ssp, std::min(124u, sg - b0), h_bits + (size_t)b0 * bits_stride, bits_stride, h_delta + b0, W + (size_t)b0 * d);
       if (rc) return rc;

@@ -177,3 +177,38 @@ def test_chunk_rows_knob_rejects_overflowing_values(gpu_ctx_factory):
         ctx.set_mm_chunk_rows(131072)  # 131072 rows of -128 x -128 overflow an int32 accumulator
     ctx.set_mm_chunk_rows(131071)
     ctx.set_mm_chunk_rows(0)
+
+
+@pytest.mark.parametrize("ngl,merge", [(1, True), (2, True), (8, True), (4, False), (1, False)])
+def test_batch_launch_shapes_give_identical_proofs(gpu_ctx_factory, ngl, merge):
+    """mfh_set_batch_launch: groups per streaming launch and S + AS in one launch or two change the launch geometry of k_mmstream (per-group
+    image pointers, up to 16 groups in a grid), never the proofs.  250 statements = two super-groups, 9 groups: every shape has a ragged
+    last round."""
+    import torch
+
+    import c_lwe_snarks_amd as mf
+    import oracle_lib  # noqa: F401
+
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+
+    p = mf.Params(d=1152, m=1000)
+    ctx = gpu_ctx_factory(p)
+    ctx.set_seed(SEED)
+    inst = bench.build_instance(mf, ctx, torch, p, 99)
+    ctx.ssp_prepare(inst["d_ssp"])
+    d_crs = ctx.setup(inst["d_ssp"], inst["alpha"], inst["beta"], inst["s"], inst["sk"], inst["err"])
+    rng = np.random.default_rng(5)
+    nb = 250
+    bits, deltas, mags, signs = _statements(rng, p, nb, valid_bits=inst["bits"])
+    want = ctx.prove_batch(d_crs, inst["d_ssp"], bits, deltas, mags, signs).clone()  # default shape: 4 groups, merged
+    ctx.set_batch_launch(ngl, merge)
+    try:
+        got = ctx.prove_batch(d_crs, inst["d_ssp"], bits, deltas, mags, signs)
+    finally:
+        ctx.set_batch_launch(4, True)
+    assert torch.equal(got, want)
+    one = ctx.prove(d_crs, inst["d_ssp"], bits[249], deltas[249], mags[249], signs[249])
+    assert torch.equal(want.view(nb, -1)[249], one)
+    ctx.close()

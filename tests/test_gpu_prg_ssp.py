@@ -203,3 +203,29 @@ def test_config4_row_sharded_batch_emulated_on_one_gpu(gpu_ctx_factory, mf):
     assert [bool(x) for x in ok] == [b % 2 == 0 for b in range(nb)]
     del image
     ctx.close()
+
+
+@pytest.mark.parametrize("d,m,nstmt", [(256, 70, 1), (256, 70, 33), (384, 1000, 65), (128, 333, 124)])
+def test_generator_defined_witness_pass_on_the_matrix_cores(gpu_ctx_factory, mf, d, m, nstmt):
+    """mfh_witness_poly_mm with d_ssp = NULL: the B fragments of the bits x SSP-bytes GEMM are generated in the kernel (k_witness_mm_prg)
+    instead of loaded.  Same polynomials as the single-statement VALU pass over the generator (mfh_witness_poly) and as the GEMM over the
+    dense image of the same SSP, also for all-zero / all-one witnesses."""
+    import torch
+
+    p = mf.Params(d=d, m=m)
+    c = gpu_ctx_factory(p)
+    rng = np.random.default_rng(d + m + nstmt)
+    nbytes = (p.m + 7) // 8
+    wits = [rng.integers(0, 256, size=nbytes, dtype=np.uint8).tobytes() for _ in range(nstmt)]
+    wits[0] = bytes(nbytes)
+    if nstmt > 1:
+        wits[1] = b"\xff" * nbytes
+    deltas = [int(x) for x in rng.integers(0, ol.P, size=nstmt, dtype=np.uint64)]
+    d_t = c.ssp_prg_make_t(PRG_SEED, wits[-1])
+    c.ssp_set_prg(PRG_SEED, d_t)
+    got = c.to_host(c.witness_poly_many(None, wits, deltas, mm=True), np.uint32).reshape(nstmt, p.d)
+    for b in range(nstmt):
+        assert np.array_equal(got[b], c.to_host(c.witness_poly(None, wits[b], deltas[b]), np.uint32)), f"statement {b}"
+    dense = torch.cat([d_t, c.ssp_prg_fill(PRG_SEED, 1, p.m + 2)])
+    assert np.array_equal(got, c.to_host(c.witness_poly_many(dense, wits, deltas, mm=True), np.uint32).reshape(nstmt, p.d))
+    c.close()
