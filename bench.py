@@ -424,7 +424,7 @@ def main():
             return None
         avg, rows = ms_ / n_, rows_ / n_
         gblk_ = rows * (p.ctr_ct / 16.0) / (avg * 1e-3) / 1e9
-        return {"kernel": "k_evalmm16<MODE 1> (AES-256-CTR expansion of a CRS region, written once per call in MFMA A-fragment order)", "launches": n_,
+        return {"kernel": "k_expand_mm (AES-256-CTR expansion of a CRS region or row slab, written in MFMA A-fragment order: lane = row, transposition on the matrix cores)", "launches": n_,
                 "avg_launch_ms": avg, "rows_per_launch": rows, "ms_per_step": ms_ / (steps_ or args.steps), "aes_gblocks_per_s": gblk_,
                 "lds_lookup_roofline": {"achieved_gblocks_per_s": gblk_, "peak_gblocks_per_s": lds_peak_b, "frac": gblk_ / lds_peak_b},
                 "write_gbs": rows * tile_bytes_per_row / (avg * 1e-3) / 1e9}

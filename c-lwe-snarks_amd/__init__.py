@@ -86,7 +86,7 @@ EXPORTS = [
     "mfh_encrypt_rows", "mfh_decrypt", "mfh_ct_smudge", "mfh_ssp_upload", "mfh_witness_poly", "mfh_version",
     "mfh_workspace_bytes", "mfh_last_kernel_ms", "mfh_set_timing", "mfh_set_overlap", "mfh_eval_rows_multi", "mfh_prove_batch", "mfh_crs_mm_image_bytes", "mfh_crs_expand_mm", "mfh_crs_set_resident_mm", "mfh_witness_poly_multi", "mfh_witness_poly_mm", "mfh_poly_h_multi", "mfh_poly_mul", "mfh_poly_add", "mfh_poly_prepare_t",
     "mfh_ssp_prepare", "mfh_poly_h", "mfh_setup_messages", "mfh_setup", "mfh_prove",
-    "mfh_prove_partial", "mfh_prove_finish", "mfh_ct_to_lanes", "mfh_ct_from_lanes", "mfh_timing_drain", "mfh_timing_busy_ms", "mfh_timing_work_rows", "mfh_set_batch_image", "mfh_set_expand_path", "mfh_set_encrypt_path", "mfh_set_batch_launch", "mfh_set_mm_chunk_rows", "mfh_add_dotp",
+    "mfh_prove_partial", "mfh_prove_finish", "mfh_ct_to_lanes", "mfh_ct_from_lanes", "mfh_timing_drain", "mfh_timing_busy_ms", "mfh_timing_work_rows", "mfh_set_batch_image", "mfh_set_batch_slabs", "mfh_set_expand_path", "mfh_set_encrypt_path", "mfh_set_batch_launch", "mfh_set_mm_chunk_rows", "mfh_add_dotp",
     "mfh_crs_mm_share_bytes", "mfh_crs_expand_mm_share", "mfh_crs_set_resident_mm_share", "mfh_batch_chain", "mfh_prove_batch_partial", "mfh_prove_batch_finish",
     "mfh_resident_row_bytes", "mfh_crs_expand", "mfh_eval_rows_resident", "mfh_crs_set_resident",
     "mfh_witness_lanes", "mfh_witness_from_lanes", "mfh_prove_partial_w", "mfh_verify",
@@ -173,6 +173,7 @@ def load_library():
         "mfh_set_batch_launch": (i32, [vp, u32, i32]),
         "mfh_set_encrypt_path": (i32, [vp, i32]),
         "mfh_set_expand_path": (i32, [vp, i32]),
+        "mfh_set_batch_slabs": (i32, [vp, u32]),
         "mfh_crs_mm_share_bytes": (sz, [vp, u32, u32]),
         "mfh_crs_expand_mm_share": (i32, [vp, vp, u32, u32, vp]),
         "mfh_crs_set_resident_mm_share": (i32, [vp, vp, u32, u32]),
@@ -261,6 +262,10 @@ class Context:
     def set_batch_image(self, on=True):
         """prove_batch with more than 31 proofs: expand the CRS once per call into a transient image and stream it per group (default) or not"""
         self._chk(self.lib.mfh_set_batch_image(self._h, 1 if on else 0))
+
+    def set_batch_slabs(self, nslabs=0):
+        """prove_batch: 0 = row slabs only when the image does not fit HBM, n = always n slabs (each expanded once and streamed for every group)"""
+        self._chk(self.lib.mfh_set_batch_slabs(self._h, int(nslabs)))
 
     def set_expand_path(self, path=0):
         """crs_expand_mm*: 0 = barrier-free writer (MFMA transposition), 1 = LDS-tile writer"""

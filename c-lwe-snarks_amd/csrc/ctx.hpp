@@ -99,6 +99,7 @@ struct mfh_ctx {
   uint32_t mm_chunk_rows = 131071;  // rows per row chunk of the matrix-core launches (int32 accumulators: |A'C'| <= 2^14 per row)
   int expand_path = 0;     // mfh_crs_expand_mm*: 0 = k_expand_mm (lane = row, MFMA transposition, no LDS tile), 1 = k_evalmm16<MODE 1> (LDS tile + byte gathers)
   int enc_path = 0;        // mfh_encrypt_rows: 0 = pick by batch size, 1 = VALU kernel (k_encrypt), 2 = matrix-core kernel (k_encrypt_mm)
+  uint32_t batch_slabs = 0;  // mfh_prove_batch: 0 = row slabs only when the image does not fit HBM (count picked from free memory), n = always n slabs
   int batch_merge = 1;     // the S and AS groups of a round in one streaming launch (0: two launches on two streams)
   uint32_t batch_ngl = 4;  // groups of 31 proofs per streaming launch over the image (1..8)
   PinBuf pin_rows, pin_cw, pin_smudge;
@@ -202,7 +203,7 @@ int eval_rows_multi_io_set(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t
 // the same over nreg <= 2 regions of equal row count in ONE streaming launch: group r * ng + k evaluates region r with ios[r * ng + k]
 struct MmRegion { uint64_t off; const uint8_t *c8; };
 int eval_rows_multi_io_regions(mfh_ctx *c, const MmRegion *regs, uint32_t nreg, size_t nrows, const MmIo *ios, const uint32_t *nvecs, uint32_t ng,
-                               uint32_t coeff_bytes);
+                               uint32_t coeff_bytes, int accumulate);
 bool mm_image_covers(const mfh_ctx *c, uint64_t off, size_t nrows);
 // the phases of such a launch (evalmm.hip), for callers that queue them on different streams
 struct MmsPlan {
@@ -218,7 +219,7 @@ size_t mms_ws_bytes(const MmsPlan &P);
 void mms_bind(MmsPlan &P, void *ws);              // the launch's digit fragments and partial products live in ws (mms_ws_bytes)
 int mms_digits(mfh_ctx *c, const MmsPlan &P, const MmIo *ios, const uint32_t *nvecs);
 int mms_stream(mfh_ctx *c, const MmsPlan &P);
-int mms_finish(mfh_ctx *c, const MmsPlan &P, const MmIo *ios, const uint32_t *nvecs);
+int mms_finish(mfh_ctx *c, const MmsPlan &P, const MmIo *ios, const uint32_t *nvecs, int accumulate);
 
 inline int buf_reserve(mfh_ctx *c, void *&buf, size_t &have, size_t bytes) {
   if (bytes <= have) return MFH_OK;

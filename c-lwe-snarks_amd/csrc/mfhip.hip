@@ -1012,6 +1012,12 @@ int mfh_set_encrypt_path(mfh_ctx *c, int path) {
   return MFH_OK;
 }
 
+int mfh_set_batch_slabs(mfh_ctx *c, uint32_t nslabs) {
+  if (!c || nslabs > 256) return MFH_EINVAL;
+  c->batch_slabs = nslabs;
+  return MFH_OK;
+}
+
 int mfh_set_batch_launch(mfh_ctx *c, uint32_t groups_per_launch, int merge_regions) {
   if (!c || groups_per_launch < 1 || groups_per_launch > 8) return MFH_EINVAL;
   c->batch_ngl = groups_per_launch;

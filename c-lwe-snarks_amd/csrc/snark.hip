@@ -508,8 +508,9 @@ int batch_chain_launch(mfh_ctx *c, const mf::SspSrc &src, const uint32_t *d_ssp,
   // d % 128 == 0: a GEMM on the matrix cores, one read (dense SSP) or one generation (generator-defined SSP) of the selected rows per
   // 124 statements; otherwise the VALU form, read or generated once per 12 statements
   if (d % 128 == 0) {
-    for (uint32_t b0 = 0; b0 < sg; b0 += 124) {
-      rc = mfh_witness_poly_mm(c, d_ssp, std::min(124u, sg - b0), h_bits + (size_t)b0 * bits_stride, bits_stride, h_delta + b0, W + (size_t)b0 * d);
+    const uint32_t per = src.dense ? 256u : 124u;  // statements per pass: the dense SSP in one read per super-group; generated rows 4 x 32 at a time
+    for (uint32_t b0 = 0; b0 < sg; b0 += per) {
+      rc = mfh_witness_poly_mm(c, d_ssp, std::min(per, sg - b0), h_bits + (size_t)b0 * bits_stride, bits_stride, h_delta + b0, W + (size_t)b0 * d);
       if (rc) return rc;
     }
   } else {
@@ -536,9 +537,10 @@ struct BatchCoef {
 //   stream, every row expanded (or streamed from the image) once per group of 31 proofs (src/snark.c:157-174).
 // sproofs: the sg proof structs (5 ciphertexts each, h | hat_h | hat_v | v_w | b_w).  h_delta == nullptr: no delta ct_t term (a partial
 // proof: the term is added once, after the ranks' shares have been summed).  wait_ev: awaited before the S / AS launches (the chain).
+// accumulate: add onto what sproofs holds (mod 2^(64K)) -- the row slabs of mfh_prove_batch when the image does not fit HBM.
 int batch_rows_supergroup(mfh_ctx *c, const uint8_t *d_crs_c8, uint32_t rank, uint32_t world, uint32_t sg, const uint8_t *h_bits,
                           size_t bits_stride, const BatchCoef &co, uint64_t *sproofs, const BatchScratch &B, size_t &slot,
-                          const uint32_t *h_delta, hipEvent_t wait_ev) {
+                          const uint32_t *h_delta, hipEvent_t wait_ev, int accumulate = 0) {
   const uint32_t d = c->P.d, m = c->P.m, n = c->P.n;
   const uint32_t ctb = c->P.logq / 8;
   const size_t ctl = (size_t)(n + 1) * ((c->P.logq + 63) / 64);
@@ -560,7 +562,7 @@ int batch_rows_supergroup(mfh_ctx *c, const uint8_t *d_crs_c8, uint32_t rank, ui
   pin_release(c, c->pin_cw);
   MmIo io_bw = {{nullptr, nullptr}, sg, {sproofs + 4 * ctl, nullptr}, sg, pstride, (const uint8_t *)B.CW, bstride, B.SCZ + 256 * slot++};
   io_bw.bits_row0 = lo;
-  rc = eval_rows_multi_io(c, ctr_ct * ((uint64_t)2 * d + lo), cnt, d_crs_c8 + ((size_t)2 * d + lo) * ctb, io_bw, sg, 1, 0);
+  rc = eval_rows_multi_io(c, ctr_ct * ((uint64_t)2 * d + lo), cnt, d_crs_c8 + ((size_t)2 * d + lo) * ctb, io_bw, sg, 1, accumulate);
   if (rc) return rc;
   if (h_delta) {  // + delta_b ct_t for the sg proofs in one launch
     hipLaunchKernelGGL(k_bw_add_delta_ct, dim3((n + 1 + 255) / 256, sg), dim3(256), 0, c->stream, sproofs, B.CT_T, (const uint32_t *)(B.CW + packed), n + 1,
@@ -614,7 +616,7 @@ int batch_rows_supergroup(mfh_ctx *c, const uint8_t *d_crs_c8, uint32_t rank, ui
     for (uint32_t r = 0; r < R; r++) {
       rc = mms_stream(c, plan[r]);
       if (rc) return rc;
-      rc = mms_finish(c, plan[r], io[r], nv[r]);  // (on a side stream beside the next launch the epilogues starve -- 0.5 ms each instead of 0.05 -- and slow that launch by more than they take alone)
+      rc = mms_finish(c, plan[r], io[r], nv[r], accumulate);  // (on a side stream beside the next launch the epilogues starve -- 0.5 ms each instead of 0.05 -- and slow that launch by more than they take alone)
       if (rc) return rc;
     }
   } else {
@@ -631,11 +633,11 @@ int batch_rows_supergroup(mfh_ctx *c, const uint8_t *d_crs_c8, uint32_t rank, ui
         io[ng + k] = MmIo{{co.h + o, co.v + o}, g, {proofs + ctl, proofs + 2 * ctl}, g, pstride, nullptr, 0, B.SCZ + 256 * slot++, co.stride, 0};  // AS: (h, v) -> (hat_h, hat_v)
         nv[k] = nv[ng + k] = 2 * g;
       }
-      rc = eval_rows_multi_io_regions(c, regs, 1, cS, io, nv, ng, 4);
+      rc = eval_rows_multi_io_regions(c, regs, 1, cS, io, nv, ng, 4, accumulate);
       if (rc) return rc;
       {
         OnSide side(c, side_stream);
-        rc = eval_rows_multi_io_regions(c, regs + 1, 1, cS, io + ng, nv + ng, ng, 4);
+        rc = eval_rows_multi_io_regions(c, regs + 1, 1, cS, io + ng, nv + ng, ng, 4, accumulate);
         if (rc) return rc;
       }
     }
@@ -732,7 +734,36 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
   // gets (one k_mmstream workgroup owns a CU's registers and LDS, k_expand_mm runs 8 waves per SIMD): concurrent streams time-share
   // the GPU and the work is conserved.  In turn keeps the streaming launches' durations clean.
   const uint32_t nsg = (nproofs + BSG - 1) / BSG;
-  const uint32_t nbuf = 2;
+  // Row slabs.  When the call would stream an image that does not fit HBM (363 GB at 2^20 constraints), the CRS rows are cut into
+  // `nsl` slabs -- exactly the row shares of the multi-GPU prover, one after the other on this GPU: a slab's image is expanded once and
+  // streamed for EVERY group of the call (results accumulated mod 2^(64K)), so the keystream is generated once per call instead of
+  // once per group of 31 proofs.  All chains run first (one w | h | v area per super-group).
+  uint32_t nsl = 1;
+  const uint32_t ctb0 = c->P.logq / 8;
+  const bool slabs_ok = !c->mm_image && c->batch_image && nproofs > BG && (((uint64_t)n * ctb0) & 7) == 0;
+  if (slabs_ok && c->batch_slabs) nsl = std::min(c->batch_slabs, std::max(1u, std::min(d, m)));  // forced (tests, tuning)
+  else if (slabs_ok) {
+    size_t mem_free = 0, mem_total = 0;
+    if (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess) {
+      const size_t ib = mfh_crs_mm_image_bytes(c), avail = mem_free + c->batch_img_bytes + c->batch_bytes;  // (what the context holds is re-used)
+      if (ib > avail / 4 * 3) {
+        const size_t budget = std::max<size_t>(avail / 3, (size_t)1 << 30);
+        nsl = (uint32_t)std::min<size_t>(256, (ib + budget - 1) / budget);
+        const size_t area = (size_t)3 * BSG * d * 4, maxsg = std::max<size_t>(1, avail / 4 / area);
+        if (nsg > maxsg) {  // the w | h | v areas of the whole call would not fit: sub-calls of maxsg super-groups
+          const size_t ctl0 = (size_t)(n + 1) * ((c->P.logq + 63) / 64);
+          for (uint32_t s0 = 0; s0 < nproofs; s0 += (uint32_t)maxsg * BSG) {
+            const uint32_t cnt = std::min<uint32_t>((uint32_t)maxsg * BSG, nproofs - s0);
+            int r = mfh_prove_batch(c, d_crs_c8, d_ssp, cnt, h_witness_bits + (size_t)s0 * bits_stride, bits_stride, h_delta + s0,
+                                    h_smudge_mag + (size_t)s0 * 5 * maglen, maglen, h_smudge_sign + (size_t)s0 * 5, d_proofs + (size_t)s0 * 5 * ctl0);
+            if (r) return r;
+          }
+          return MFH_OK;
+        }
+      }
+    }
+  }
+  const uint32_t nbuf = nsl > 1 ? nsg : 2;
   BatchScratch B;
   int rc = batch_scratch(c, nproofs, nbuf, B);
   if (rc) return rc;
@@ -767,6 +798,44 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
   HIP_TRY(c, hipStreamWaitEvent(chain_stream, c->ev_chain, 0));
   rc = launch_chain(0);
   if (rc) return rc;
+  if (nsl > 1) {
+    for (uint32_t k = 1; k < nsg; k++) {
+      rc = launch_chain(k);
+      if (rc) return rc;
+    }
+    size_t ib = 0;
+    for (uint32_t r = 0; r < nsl; r++) ib = std::max(ib, mfh_crs_mm_share_bytes(c, r, nsl));
+    if (c->batch_img_bytes < ib) {
+      if (c->batch_img) { hipDeviceSynchronize(); hipFree(c->batch_img); c->batch_img = nullptr; c->batch_img_bytes = 0; }
+      if (hipMalloc(&c->batch_img, ib) != hipSuccess) { c->batch_img = nullptr; (void)hipGetLastError(); c->err = "mfh_prove_batch: no room for a row slab of the CRS image"; return MFH_ENOMEM; }
+      c->batch_img_bytes = ib;
+    }
+    rc = batch_ct_t(c, d_crs_c8, B);
+    if (rc) return rc;
+    ImageGuard slab{c, true};
+    for (uint32_t r = 0; r < nsl; r++) {
+      rc = mfh_crs_expand_mm_share(c, d_crs_c8, r, nsl, (uint8_t *)c->batch_img);  // (queued behind the previous slab's launches on the caller's stream)
+      if (rc) return rc;
+      mfh_crs_set_resident_mm_share(c, (const uint8_t *)c->batch_img, r, nsl);
+      HIP_TRY(c, hipMemsetAsync(B.SCZ, 0, B.nslots * 2048, c->stream));
+      slot = 0;
+      const uint32_t loS = (uint32_t)((uint64_t)d * r / nsl);
+      for (uint32_t s0 = 0, sgi = 0; s0 < nproofs; s0 += BSG, sgi++) {
+        const uint32_t sg = std::min(BSG, nproofs - s0);
+        uint32_t *WALL, *HALL, *VALL;
+        whv_of(sgi, WALL, HALL, VALL);
+        const BatchCoef co = {WALL + loS, HALL + loS, VALL + loS, d};
+        rc = batch_rows_supergroup(c, d_crs_c8, r, nsl, sg, h_witness_bits + (size_t)s0 * bits_stride, bits_stride, co, d_proofs + (size_t)s0 * 5 * ctl, B, slot,
+                                   r == 0 ? h_delta + s0 : nullptr, r == 0 ? c->ev_cdone[sgi % nbuf] : nullptr, r > 0);
+        if (rc) return rc;
+      }
+    }
+    for (uint32_t s0 = 0; s0 < nproofs; s0 += BSG) {
+      rc = batch_smudge(c, d_proofs + (size_t)s0 * 5 * ctl, std::min(BSG, nproofs - s0), h_smudge_mag + (size_t)s0 * 5 * maglen, maglen, h_smudge_sign + (size_t)s0 * 5);
+      if (rc) return rc;
+    }
+    return MFH_OK;
+  }
   ImageGuard transient{c, false};
   rc = batch_transient_image(c, d_crs_c8, nproofs, 0, 1, transient);
   if (rc) return rc;

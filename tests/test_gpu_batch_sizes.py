@@ -212,3 +212,43 @@ def test_batch_launch_shapes_give_identical_proofs(gpu_ctx_factory, ngl, merge):
     one = ctx.prove(d_crs, inst["d_ssp"], bits[249], deltas[249], mags[249], signs[249])
     assert torch.equal(want.view(nb, -1)[249], one)
     ctx.close()
+
+
+@pytest.mark.parametrize("d,m,nb,nslabs,chunk_rows", [(256, 64, 40, 3, 0), (1152, 1000, 270, 5, 0), (1152, 1000, 64, 2, 256), (256, 10, 33, 12, 0)])
+def test_row_slabs_give_identical_proofs(gpu_ctx_factory, d, m, nb, nslabs, chunk_rows):
+    """mfh_set_batch_slabs: the out-of-core form of mfh_prove_batch (what a 2^20-constraint CRS needs on one GPU) -- the CRS rows cut into
+    slabs, each slab's image expanded once and streamed for every group of the call, results accumulated mod 2^(64K), all chains first.
+    Forced here at small sizes: 3 / 5 / 2 / 12 slabs (the last with fewer BT+BV rows than slabs), two super-groups, row chunks inside a
+    slab; bit-identical to the in-core call, accepted / rejected as the witnesses demand."""
+    import sys
+
+    import torch
+
+    import c_lwe_snarks_amd as mf
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    p = mf.Params(d=d, m=m)
+    ctx = gpu_ctx_factory(p)
+    ctx.set_seed(SEED)
+    inst = bench.build_instance(mf, ctx, torch, p, 7 * d + m)
+    ctx.ssp_prepare(inst["d_ssp"])
+    d_crs = ctx.setup(inst["d_ssp"], inst["alpha"], inst["beta"], inst["s"], inst["sk"], inst["err"])
+    rng = np.random.default_rng(nb)
+    bits, deltas, mags, signs = _statements(rng, p, nb, valid_bits=inst["bits"])
+    want = ctx.prove_batch(d_crs, inst["d_ssp"], bits, deltas, mags, signs).clone()
+    ctx.set_batch_slabs(nslabs)
+    ctx.set_mm_chunk_rows(chunk_rows)
+    ctx.set_timing(True)
+    try:
+        got = ctx.prove_batch(d_crs, inst["d_ssp"], bits, deltas, mags, signs)
+    finally:
+        ctx.set_timing(False)
+        ctx.set_batch_slabs(0)
+        ctx.set_mm_chunk_rows(0)
+    assert ctx.timing_drain("expandmm")[0] > 0 and ctx.timing_drain("evalmm")[0] == 0  # slabs expanded and streamed, nothing regenerated per group
+    assert torch.equal(got, want)
+    ok = ctx.to_host(ctx.verify(inst["d_ssp"], inst["alpha"], inst["beta"], inst["s"], inst["sk"], got, nb))
+    assert [bool(x) for x in ok] == [b % 3 != 2 for b in range(nb)]
+    ctx.close()
