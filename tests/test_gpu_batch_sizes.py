@@ -1,4 +1,4 @@
-"""The headline path (mfh_prove_batch: k_evalmm16<MODE 1> image writer -> k_mmstream -> k_evalmm_finish, witness GEMM, batched
+"""The headline path (mfh_prove_batch: k_expand_mm image writer -> k_mmstream -> k_evalmm_finish, witness GEMM, batched
 polynomial step) under ORACLE parity at sizes that exercise its loops, which the DEBUG-size tests of test_gpu_evalmm.py do not:
 
   * the NDEBUG default size (D = 2^15, M = 21845): 128 stages of 256 rows per k_mmstream launch; proof 0 of a 130-statement batch is
