@@ -97,9 +97,12 @@ __global__ void k_ntt_dit(uint32_t *__restrict__ a, uint32_t N, uint32_t len, co
 // ---- fused stages ---------------------------------------------------------------------------------------------
 // K consecutive DIF stages (block lengths len, len/2, ..., len>>(K-1)) in registers: a thread owns the 2^K elements
 // {s + j + m*q}, q = len >> K.  grid = (N >> K) threads x 3 primes.
+// in != nullptr (the first pass of a transform): the elements are taken from the coefficient array `in` (`in_len` coefficients mod p32 per
+// polynomial, `in_stride` apart, zero padded) and converted to Montgomery residues on the way -- k_ntt_load's pass over the buffer saved.
 template <int K>
 __global__ __launch_bounds__(256) void k_ntt_dif_multi(uint32_t *__restrict__ a, uint32_t N, uint32_t len, const uint32_t *__restrict__ tw,
-                                                       uint32_t half_max, Primes3 P) {
+                                                       uint32_t half_max, Primes3 P, const uint32_t *__restrict__ in = nullptr, uint32_t in_len = 0,
+                                                       size_t in_stride = 0) {
   constexpr int R = 1 << K;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (N >> K)) return;
@@ -110,8 +113,17 @@ __global__ __launch_bounds__(256) void k_ntt_dif_multi(uint32_t *__restrict__ a,
   uint32_t *x = a + (size_t)blockIdx.y * N + s + j;
   const uint32_t *t = tw + (size_t)(blockIdx.y % 3) * half_max;
   uint32_t v[R];
+  if (in) {
+    const uint32_t *src = in + (size_t)(blockIdx.y / 3) * in_stride;
 #pragma unroll
-  for (int m = 0; m < R; m++) v[m] = x[(size_t)m * qd];
+    for (int m = 0; m < R; m++) {
+      const uint32_t e = s + j + (uint32_t)m * qd;
+      v[m] = e < in_len ? mont_mul(src[e], q.r2, q.p, q.ninv) : 0u;  // x * R mod p
+    }
+  } else {
+#pragma unroll
+    for (int m = 0; m < R; m++) v[m] = x[(size_t)m * qd];
+  }
 #pragma unroll
   for (int st = 0; st < K; st++) {
     const int h = R >> (st + 1);             // pair distance in register index
@@ -543,19 +555,28 @@ uint32_t ceil_log2(size_t x) {
 }
 
 // the top (register) stages of a forward / inverse transform; the low B = min(logN, 11) stages run in LDS
-void forward_top(mfh_ctx *c, uint32_t *buf, uint32_t logN, uint32_t nb = 1) {
+// (up to five stages per pass: 32 elements per thread; 2^16 -> one pass of 5, 2^21 -> two.  `in`: the coefficients to load in the first
+// pass instead of a separate k_ntt_load; returns false when there is no register pass to fuse the load into)
+bool forward_top(mfh_ctx *c, uint32_t *buf, uint32_t logN, uint32_t nb = 1, const uint32_t *in = nullptr, uint32_t in_len = 0, size_t in_stride = 0) {
   PolyState *S = c->poly;
   const uint32_t N = 1u << logN, half_max = 1u << (S->logmax - 1);
   uint32_t top = logN - std::min(logN, 11u), len = N;
+  if (!top) return false;
   while (top) {
-    const uint32_t k = std::min(top, 3u);
+    const uint32_t k = top > 5 ? std::min(top - 3, 5u) : top;  // never leave a pass of fewer than three stages behind a full one
     dim3 g(((N >> k) + 255) / 256, 3 * nb);
-    if (k == 3) hipLaunchKernelGGL(k_ntt_dif_multi<3>, g, dim3(256), 0, c->stream, buf, N, len, S->d_tw, half_max, S->P);
-    else if (k == 2) hipLaunchKernelGGL(k_ntt_dif_multi<2>, g, dim3(256), 0, c->stream, buf, N, len, S->d_tw, half_max, S->P);
-    else hipLaunchKernelGGL(k_ntt_dif_multi<1>, g, dim3(256), 0, c->stream, buf, N, len, S->d_tw, half_max, S->P);
+    switch (k) {
+      case 5: hipLaunchKernelGGL(k_ntt_dif_multi<5>, g, dim3(256), 0, c->stream, buf, N, len, S->d_tw, half_max, S->P, in, in_len, in_stride); break;
+      case 4: hipLaunchKernelGGL(k_ntt_dif_multi<4>, g, dim3(256), 0, c->stream, buf, N, len, S->d_tw, half_max, S->P, in, in_len, in_stride); break;
+      case 3: hipLaunchKernelGGL(k_ntt_dif_multi<3>, g, dim3(256), 0, c->stream, buf, N, len, S->d_tw, half_max, S->P, in, in_len, in_stride); break;
+      case 2: hipLaunchKernelGGL(k_ntt_dif_multi<2>, g, dim3(256), 0, c->stream, buf, N, len, S->d_tw, half_max, S->P, in, in_len, in_stride); break;
+      default: hipLaunchKernelGGL(k_ntt_dif_multi<1>, g, dim3(256), 0, c->stream, buf, N, len, S->d_tw, half_max, S->P, in, in_len, in_stride); break;
+    }
+    in = nullptr;
     len >>= k;
     top -= k;
   }
+  return true;
 }
 void inverse_top(mfh_ctx *c, uint32_t *buf, uint32_t logN, uint32_t nb = 1) {
   PolyState *S = c->poly;
@@ -563,11 +584,15 @@ void inverse_top(mfh_ctx *c, uint32_t *buf, uint32_t logN, uint32_t nb = 1) {
   const uint32_t B = std::min(logN, 11u);
   uint32_t top = logN - B, len = 2u << B;
   while (top) {
-    const uint32_t k = std::min(top, 3u);
+    const uint32_t k = top > 5 ? std::min(top - 3, 5u) : top;
     dim3 g(((N >> k) + 255) / 256, 3 * nb);
-    if (k == 3) hipLaunchKernelGGL(k_ntt_dit_multi<3>, g, dim3(256), 0, c->stream, buf, N, len, S->d_twi, half_max, S->P);
-    else if (k == 2) hipLaunchKernelGGL(k_ntt_dit_multi<2>, g, dim3(256), 0, c->stream, buf, N, len, S->d_twi, half_max, S->P);
-    else hipLaunchKernelGGL(k_ntt_dit_multi<1>, g, dim3(256), 0, c->stream, buf, N, len, S->d_twi, half_max, S->P);
+    switch (k) {
+      case 5: hipLaunchKernelGGL(k_ntt_dit_multi<5>, g, dim3(256), 0, c->stream, buf, N, len, S->d_twi, half_max, S->P); break;
+      case 4: hipLaunchKernelGGL(k_ntt_dit_multi<4>, g, dim3(256), 0, c->stream, buf, N, len, S->d_twi, half_max, S->P); break;
+      case 3: hipLaunchKernelGGL(k_ntt_dit_multi<3>, g, dim3(256), 0, c->stream, buf, N, len, S->d_twi, half_max, S->P); break;
+      case 2: hipLaunchKernelGGL(k_ntt_dit_multi<2>, g, dim3(256), 0, c->stream, buf, N, len, S->d_twi, half_max, S->P); break;
+      default: hipLaunchKernelGGL(k_ntt_dit_multi<1>, g, dim3(256), 0, c->stream, buf, N, len, S->d_twi, half_max, S->P); break;
+    }
     len <<= k;
     top -= k;
   }
@@ -602,8 +627,9 @@ int poly_mul(mfh_ctx *c, const uint32_t *a, uint32_t la, const uint32_t *b, uint
     return MFH_EINVAL;
   }
   const uint32_t N = 1u << logN, half_max = 1u << (S->logmax - 1), B = std::min(logN, 11u);
-  hipLaunchKernelGGL(k_ntt_load, dim3((N + 255) / 256, 3 * nb), dim3(256), 0, c->stream, a, la, N, S->P, S->d_bufA, a_stride);
-  forward_top(c, S->d_bufA, logN, nb);
+  if (!forward_top(c, S->d_bufA, logN, nb, a, la, a_stride)) {  // (no register pass at this size: load on its own)
+    hipLaunchKernelGGL(k_ntt_load, dim3((N + 255) / 256, 3 * nb), dim3(256), 0, c->stream, a, la, N, S->P, S->d_bufA, a_stride);
+  }
   const uint32_t *rhs = bhat;  // already fully transformed
   int is_hat = 1;
   if (!bhat) {
@@ -611,8 +637,8 @@ int poly_mul(mfh_ctx *c, const uint32_t *a, uint32_t la, const uint32_t *b, uint
     if (b == a && lb == la) {
       rhs = nullptr;  // square
     } else {
-      hipLaunchKernelGGL(k_ntt_load, dim3((N + 255) / 256, 3 * nb), dim3(256), 0, c->stream, b, lb, N, S->P, S->d_bufB, a_stride);
-      forward_top(c, S->d_bufB, logN, nb);
+      if (!forward_top(c, S->d_bufB, logN, nb, b, lb, a_stride))
+        hipLaunchKernelGGL(k_ntt_load, dim3((N + 255) / 256, 3 * nb), dim3(256), 0, c->stream, b, lb, N, S->P, S->d_bufB, a_stride);
       rhs = S->d_bufB;
     }
   }
