@@ -121,7 +121,11 @@ __global__ void k_mm_digits(MmIo io, uint32_t nvec, uint32_t ND, uint32_t nrows,
 // coefficients of a fragment element fetched as four 16-byte loads, DG4 row groups in flight per thread and the byte column picked with
 // v_perm: thread = (vector n >> 2, byte n & 3).
 constexpr int DG4 = 4;
-__global__ __launch_bounds__(256) void k_mm_digits4w(MmIo io, uint32_t nvec, uint32_t nrows, uint32_t rpad, int8_t *__restrict__ cd, int64_t *__restrict__ sc) {
+struct MmGroupArgs {  // the operands of up to 16 groups of one round (kernel argument: 1.6 KB)
+  MmIo io[16];
+  uint32_t nvec[16];
+};
+__device__ __forceinline__ void mm_digits4w_body(const MmIo &io, uint32_t nvec, uint32_t nrows, uint32_t rpad, int8_t *__restrict__ cd, int64_t *__restrict__ sc) {
   const uint32_t n = threadIdx.x, v = n >> 2, w = n & 3;
   const bool ones = n == 4 * nvec;
   const uint64_t cs = io.cstride ? io.cstride : nrows;
@@ -174,6 +178,14 @@ __global__ __launch_bounds__(256) void k_mm_digits4w(MmIo io, uint32_t nvec, uin
     const long long colsum = (long long)bytesum - 128ll * nvalid;
     if (colsum) atomicAdd(reinterpret_cast<unsigned long long *>(sc + n), (unsigned long long)colsum);
   }
+}
+__global__ __launch_bounds__(256) void k_mm_digits4w(MmIo io, uint32_t nvec, uint32_t nrows, uint32_t rpad, int8_t *__restrict__ cd, int64_t *__restrict__ sc) {
+  mm_digits4w_body(io, nvec, nrows, rpad, cd, sc);
+}
+// all groups of a round in one launch: blockIdx.y = group, its fragments at cd + group * cd_stride, its column sums in io.sc_zeroed
+__global__ __launch_bounds__(256) void k_mm_digits4w_groups(MmGroupArgs A, uint32_t nrows, uint32_t rpad, int8_t *__restrict__ cd, uint64_t cd_stride) {
+  const uint32_t g = blockIdx.y;
+  mm_digits4w_body(A.io[g], A.nvec[g], nrows, rpad, cd + g * cd_stride, A.io[g].sc_zeroed);
 }
 
 struct RowGeom {
@@ -674,9 +686,9 @@ __global__ __launch_bounds__(SW * 64) void k_mmstream(MmsImages imgs, uint32_t m
 // on LDS data) and write the element in 16-byte (LL even: 96-byte elements) or 8-byte pieces: the elements of neighbouring threads lie a
 // ciphertext apart, so every store is its own memory transaction.
 template <int ND>
-__global__ __launch_bounds__(256) void k_evalmm_finish(const int *__restrict__ part, const int64_t *__restrict__ sc, uint32_t nchunks, uint32_t ntiles,
-                                                        uint32_t N, uint32_t nvec, uint32_t n, uint32_t nrows, uint32_t ct, uint32_t MBv, uint32_t sby,
-                                                        uint32_t LL, MmIo io, int accumulate) {
+__device__ __forceinline__ void evalmm_finish_body(const int *__restrict__ part, const int64_t *__restrict__ sc, uint32_t nchunks, uint32_t ntiles, uint32_t N,
+                                                   uint32_t nvec, uint32_t n, uint32_t nrows, uint32_t ct, uint32_t MBv, uint32_t sby, uint32_t LL,
+                                                   const MmIo &io, int accumulate) {
   __shared__ uint32_t sv[46][3][64];
   const uint32_t vl = threadIdx.x & 63, lq = threadIdx.x >> 6;
   const uint32_t v = blockIdx.y * 64 + vl, j = blockIdx.x;
@@ -735,6 +747,21 @@ __global__ __launch_bounds__(256) void k_evalmm_finish(const int *__restrict__ p
     if (KWv & 1) *reinterpret_cast<uint2 *>(out + (KWv & ~1u)) = uint2{pend[(KWv & 2)], 0u};
     for (uint32_t l = (KWv + 1) & ~1u; l < 2 * LL; l += 2) *reinterpret_cast<uint2 *>(out + l) = uint2{0u, 0u};
   }
+}
+
+template <int ND>
+__global__ __launch_bounds__(256) void k_evalmm_finish(const int *__restrict__ part, const int64_t *__restrict__ sc, uint32_t nchunks, uint32_t ntiles,
+                                                        uint32_t N, uint32_t nvec, uint32_t n, uint32_t nrows, uint32_t ct, uint32_t MBv, uint32_t sby,
+                                                        uint32_t LL, MmIo io, int accumulate) {
+  evalmm_finish_body<ND>(part, sc, nchunks, ntiles, N, nvec, n, nrows, ct, MBv, sby, LL, io, accumulate);
+}
+// all groups of a round in one launch: blockIdx.z = group, its partial products at part + group * part_stride
+template <int ND>
+__global__ __launch_bounds__(256) void k_evalmm_finish_groups(const int *__restrict__ part, uint64_t part_stride, uint32_t nchunks, uint32_t ntiles, uint32_t N,
+                                                               uint32_t n, uint32_t nrows, uint32_t ct, uint32_t MBv, uint32_t sby, uint32_t LL, MmGroupArgs A,
+                                                               int accumulate) {
+  const uint32_t g = blockIdx.z;
+  evalmm_finish_body<ND>(part + g * part_stride, A.io[g].sc_zeroed, nchunks, ntiles, N, A.nvec[g], n, nrows, ct, MBv, sby, LL, A.io[g], accumulate);
 }
 
 // ---- the witness pass of up to 32 statements as a GEMM over the SSP rows (one read of the SSP) ---------------------------------------
@@ -1071,7 +1098,22 @@ void mms_bind(MmsPlan &P, void *ws) {
   P.cd = (int8_t *)ws;
   P.part = (int *)((uint8_t *)ws + (size_t)P.ngt * P.cd_bytes);
 }
+static bool mms_group_args(const MmsPlan &P, const MmIo *ios, const uint32_t *nvecs, MmGroupArgs &A) {
+  if (P.ND != 4) return false;
+  for (uint32_t g = 0; g < P.ngt; g++) {
+    if (ios[g].bits) return false;
+    A.io[g] = ios[g];
+    A.nvec[g] = nvecs[g];
+  }
+  return true;
+}
 int mms_digits(mfh_ctx *c, const MmsPlan &P, const MmIo *ios, const uint32_t *nvecs) {
+  MmGroupArgs A;
+  if (mms_group_args(P, ios, nvecs, A)) {  // one launch for the round's groups (8 launches of 21 us -> one of ~60)
+    hipLaunchKernelGGL(k_mm_digits4w_groups, dim3((P.rpad / 16 + DG4 - 1) / DG4, P.ngt), dim3(256), 0, c->stream, A, P.nrows, P.rpad, P.cd, (uint64_t)P.cd_bytes);
+    HIP_TRY(c, hipGetLastError());
+    return MFH_OK;
+  }
   for (uint32_t g = 0; g < P.ngt; g++) {
     if (P.ND == 4 && !ios[g].bits)
       hipLaunchKernelGGL(k_mm_digits4w, dim3((P.rpad / 16 + DG4 - 1) / DG4), dim3(256), 0, c->stream, ios[g], nvecs[g], P.nrows, P.rpad, P.cd + g * P.cd_bytes,
@@ -1096,6 +1138,15 @@ int mms_stream(mfh_ctx *c, const MmsPlan &P) {
 int mms_finish(mfh_ctx *c, const MmsPlan &P, const MmIo *ios, const uint32_t *nvecs, int accumulate) {
   const WideGeom wg = wide_geom(c);
   const uint32_t n = c->P.n;
+  MmGroupArgs A;
+  if (mms_group_args(P, ios, nvecs, A)) {
+    uint32_t nvmax = 0;
+    for (uint32_t g = 0; g < P.ngt; g++) nvmax = std::max(nvmax, nvecs[g]);
+    hipLaunchKernelGGL(k_evalmm_finish_groups<4>, dim3(n + 1, (nvmax + 63) / 64, P.ngt), dim3(256), 0, c->stream, P.part, (uint64_t)(P.part_bytes / 4), P.nchunks,
+                       P.ntiles, (uint32_t)N2, n, P.nrows, wg.ct, wg.mbp, wg.sby, wg.LL, A, accumulate);
+    HIP_TRY(c, hipGetLastError());
+    return MFH_OK;
+  }
   for (uint32_t g = 0; g < P.ngt; g++) {
     const dim3 fgrid(n + 1, (nvecs[g] + 63) / 64);
     int *pg = P.part + g * (P.part_bytes / 4);
