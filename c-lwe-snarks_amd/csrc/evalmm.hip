@@ -606,8 +606,11 @@ __global__ __launch_bounds__(SW * 64) void k_mmstream(MmsImages imgs, uint32_t m
 #ifdef MMS_SKIP_A  // timing-only build: no HBM stream (wrong results)
     return v4i{(int)u0, ks, t, (int)lane};
 #endif
-    const v4i *ap = image + ((uint64_t)(mt0 + t) * KS + (u0 >> 6) + ks) * 64;  // scalar
-    return mt0 + t < mtiles ? ap[lane] : zero;
+    // (a row tile past the end is clamped to the last one and its products are dropped at the end: the load is UNCONDITIONAL.  A branch
+    // around it makes the number of younger loads unknown to the compiler's s_waitcnt vmcnt accounting, which then waits for far too
+    // many: vmcnt(1) in the first k-step of a stage, i.e. the previous stage's last loads awaited one k-step after their issue)
+    const v4i *ap = image + ((uint64_t)min(mt0 + t, mtiles - 1) * KS + (u0 >> 6) + ks) * 64;  // scalar
+    return ap[lane];
   };
   v4i a[RQ][KSN];
   // Vector-memory operations complete in issue order (s_waitcnt vmcnt), so every load of the loop is used exactly one stage after it was
@@ -622,12 +625,18 @@ __global__ __launch_bounds__(SW * 64) void k_mmstream(MmsImages imgs, uint32_t m
   const uint32_t ulast = r0 + (r1 - r0 - 1) / RT2 * RT2;  // first row of the chunk's last stage: prefetches past it re-read it (no branches in the loop)
 #pragma unroll
   for (int i = 0; i < KSN * BPK; i++) (&bfrag[0][0][0][0])[tid + SW * 64 * i] = cdv[(uint64_t)(r0 >> 6) * NQ2 * 64 + tid + SW * 64 * i];
+  // The prologue issues its loads in EXACTLY the order the loop does (pinned: the scheduler must not move them).  s_waitcnt vmcnt(n) is a
+  // static count of younger loads, and the compiler takes the minimum over the paths into the loop: with the prologue's loads in another
+  // order it emitted vmcnt(8) at the head of a stage and vmcnt(1) in its first k-step -- the loads of the previous stage's LAST k-step
+  // awaited one k-step after their issue instead of one stage after it.
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int ks = 0; ks < KSN; ks++) {
 #pragma unroll
     for (int t = 0; t < RQ; t++) a[t][ks] = a_load(t, r0, ks);
 #pragma unroll
     for (int i = 0; i < BPK; i++) bnr[ks][i] = b_load(min(r0 + RT2, ulast), ks, i);
+    __builtin_amdgcn_sched_barrier(0);
   }
   __syncthreads();
   uint32_t buf = 0;
