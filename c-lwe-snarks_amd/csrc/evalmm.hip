@@ -601,7 +601,6 @@ __global__ __launch_bounds__(SW * 64) void k_mmstream(MmsImages imgs, uint32_t m
 #define MMS_DEPTH 6
 #endif
   constexpr int DEPTH = MMS_DEPTH;                       // digit fragments in flight from LDS ahead of the MFMAs
-  const v4i zero = {0, 0, 0, 0};
   auto a_load = [&](int t, uint32_t u0, int ks) -> v4i {
 #ifdef MMS_SKIP_A  // timing-only build: no HBM stream (wrong results)
     return v4i{(int)u0, ks, t, (int)lane};
