@@ -1028,7 +1028,10 @@ int eval_rows_multi_io(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d_
   int64_t *sc = io.sc_zeroed ? io.sc_zeroed : (int64_t *)(wsp + cd_bytes);
   int *part = (int *)(wsp + cd_bytes + sc_bytes);
   if (!io.sc_zeroed) HIP_TRY(c, hipMemsetAsync(sc, 0, sc_bytes, c->stream));
-  hipLaunchKernelGGL(k_mm_digits, dim3((rpad / 16 + DG_RG - 1) / DG_RG), dim3(N), 0, c->stream, io, nvec, ND, (uint32_t)nrows, rpad, NT, wide ? 1 : 0, cd, sc);
+  if (wide && ND == 4 && !io.bits)
+    hipLaunchKernelGGL(k_mm_digits4w, dim3((rpad / 16 + DG4 - 1) / DG4), dim3(256), 0, c->stream, io, nvec, (uint32_t)nrows, rpad, cd, sc);
+  else
+    hipLaunchKernelGGL(k_mm_digits, dim3((rpad / 16 + DG_RG - 1) / DG_RG), dim3(N), 0, c->stream, io, nvec, ND, (uint32_t)nrows, rpad, NT, wide ? 1 : 0, cd, sc);
   AesKey keyx = c->key;
   for (int i = 56; i < 60; i++) keyx.rk[i] ^= 0x80808080u;  // the kernel's keystream bytes come out as A - 128
   {
