@@ -438,7 +438,7 @@ class Context:
         self._chk(self.lib.mfh_crs_set_resident_mm(self._h, _ptr(image)))
 
     def witness_poly_many(self, d_ssp, witness_bits_list, deltas, mm=True):
-        """w polynomials of up to 128 (mm) / 12 statements in one read of the SSP -> len x d uint32 on the device"""
+        """w polynomials of up to 256 (mm; 128 for a generator-defined SSP) / 12 statements in one read of the SSP -> len x d uint32 on the device"""
         p = self.params
         nb = len(witness_bits_list)
         stride = (p.m + 6) // 8

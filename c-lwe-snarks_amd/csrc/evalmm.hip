@@ -852,6 +852,91 @@ __global__ __launch_bounds__(256) void k_witness_mm(const v4i *__restrict__ sspf
         part[(((uint64_t)blockIdx.y * 4 + w) * (32 * MT) + stmt) * d + k] = acc[t][w][e];
       }
 }
+// 256 statements (a whole super-group of 248) in ONE read of the SSP.  A wave cannot hold 8 statement tiles x 4 byte planes (512
+// accumulator registers): the planes are split over a wave pair -- wave w of the workgroup takes coefficient tile w >> 1 and byte planes
+// 2 (w & 1), 2 (w & 1) + 1 (8 x 2 accumulator tiles = 256 registers, one wave per SIMD) -- and the eight bit fragments of a row step (8
+// KiB, the same for all four waves) go through a four-slot LDS ring, two steps ahead (fetched straight from L2 by every wave they made
+// the pass L1-bound: 2.26 ms against 2 x 0.59 for two 124-statement passes).  The SSP fragments (2 KiB per wave and step: the HBM
+// stream) are prefetched four steps ahead in registers.  grid = (d / 64, row chunks).
+__global__ __launch_bounds__(256) void k_witness_mm8(const v4i *__restrict__ sspfrag, const v4i *__restrict__ bitfrag, uint32_t nrowsel /* m - 1 */,
+                                                     uint32_t ksteps_per_chunk, uint32_t d, int *__restrict__ part) {
+  constexpr int MT = 8, RING = 4, PF = 4;
+  __shared__ v4i bits[RING][MT][64];
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t r32 = lane & 31, h = lane >> 5;
+  const uint32_t kt = blockIdx.x * 2 + (wave >> 1), KT = d / 32, w0 = 2 * (wave & 1);
+  const uint32_t K0 = blockIdx.y * ksteps_per_chunk, K1 = min((nrowsel + 31) / 32, K0 + ksteps_per_chunk);
+  v16i acc[MT][2];
+#pragma unroll
+  for (int t = 0; t < MT; t++)
+#pragma unroll
+    for (int w = 0; w < 2; w++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[t][w][e] = 0;
+  if (K0 >= K1) return;  // (uniform)
+  // a row step's 8 bit fragments = 512 elements of 16 bytes: two per thread (loads past the chunk re-read its last step)
+  auto bits_load = [&](uint32_t K, v4i (&st)[2]) {
+    K = min(K, K1 - 1);
+    const v4i *src = bitfrag + (uint64_t)K * MT * 64;
+    st[0] = src[tid];
+    st[1] = src[tid + 256];
+  };
+  auto bits_store = [&](uint32_t K, const v4i (&st)[2]) {
+    v4i *dst = &bits[K % RING][0][0];
+    dst[tid] = st[0];
+    dst[tid + 256] = st[1];
+  };
+  auto ssp_load = [&](uint32_t K, v4i (&bq)[2]) {
+    K = min(K, K1 - 1);
+    const v4i *src = sspfrag + (((uint64_t)K * KT + kt) * 4 + w0) * 64 + lane;
+    bq[0] = src[0];
+    bq[1] = src[64];
+  };
+  v4i sta[2], stb[2];  // the bit fragments of steps K + 1 / K + 2 on their way to the ring
+  v4i bq[PF][2];
+  bits_load(K0, sta);
+  bits_store(K0, sta);
+  bits_load(K0 + 1, sta);
+  bits_load(K0 + 2, stb);
+#pragma unroll
+  for (int i = 0; i < PF; i++) ssp_load(K0 + i, bq[i]);
+  __syncthreads();
+  uint32_t K = K0;
+  auto step = [&](int slot, v4i (&st)[2]) {  // st: the bit fragments of step K + 1 (loaded two steps ago); refilled with those of step K + 3
+    bits_store(K + 1, st);
+    const v4i *aq = &bits[K % RING][0][lane];
+#pragma unroll
+    for (int t = 0; t < MT; t++) {
+      const v4i a = aq[t * 64];
+#pragma unroll
+      for (int w = 0; w < 2; w++) acc[t][w] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[slot][w], acc[t][w], 0, 0, 0);
+    }
+    ssp_load(K + PF, bq[slot]);
+    bits_load(K + 3, st);
+    __syncthreads();  // slot (K + 1) % RING is complete for the next step; slot K % RING may be rewritten from the step after next on
+    K++;
+  };
+  for (; K + 4 <= K1;) {
+    step(0, sta);
+    step(1, stb);
+    step(2, sta);
+    step(3, stb);
+  }
+  if (K < K1) step(0, sta);
+  if (K < K1) step(1, stb);
+  if (K < K1) step(2, sta);
+  uint32_t dd = d;
+  asm volatile("" : "+s"(dd));  // (keeps the 256 store addresses from being computed -- and spilled -- ahead of the loop)
+  int *dst = part + ((uint64_t)blockIdx.y * 4 + w0) * (32 * MT) * dd + kt * 32 + r32 + (uint64_t)(4 * h) * dd;
+#pragma unroll
+  for (int w = 0; w < 2; w++)
+#pragma unroll
+    for (int t = 0; t < MT; t++) {
+#pragma unroll
+      for (int e = 0; e < 16; e++) dst[(uint64_t)((e & 3) + 8 * (e >> 2)) * dd] = acc[t][w][e];
+      dst += (uint64_t)32 * dd;
+    }
+}
 // The same pass over a GENERATOR-DEFINED SSP (csrc/ssp_prg.hpp; BASELINE configs 3/4, where the dense SSP would be 5.9 TB): the B
 // fragments are not loaded but generated -- lane (coefficient k, row half h) hashes its 16 (row, k) pairs (9 integer operations each; the
 // un-reduced 32-bit hash: sums of raw values and sums of coefficients agree mod p) and picks the four byte planes with v_perm -- so that a
@@ -1295,13 +1380,14 @@ int mfh_crs_set_resident_mm(mfh_ctx *c, const uint8_t *d_image) { return mfh_crs
 // mfh_witness_poly for up to 128 statements in ONE read of the (dense) SSP, on the matrix cores: d_w = nstmt polynomials of d coefficients
 int mfh_witness_poly_mm(mfh_ctx *c, const uint32_t *d_ssp, uint32_t nstmt, const uint8_t *h_bits, size_t bits_stride, const uint32_t *h_delta,
                         uint32_t *d_w) {
-  if (!c || !h_bits || !h_delta || !d_w || nstmt == 0 || nstmt > 128) return MFH_EINVAL;
+  if (!c || !h_bits || !h_delta || !d_w || nstmt == 0 || nstmt > 256) return MFH_EINVAL;
+  if (nstmt > 128 && !d_ssp) { c->err = "mfh_witness_poly_mm: more than 128 statements per pass need the dense SSP"; return MFH_EINVAL; }
   mf::SspSrc src;  // d_ssp == NULL: the registered generator-defined SSP (B fragments generated in the kernel)
   {
     int rc0 = ssp_src(c, d_ssp, src);
     if (rc0) return rc0;
   }
-  const uint32_t MT = nstmt > 64 ? 4 : nstmt > 32 ? 2 : 1;
+  const uint32_t MT = nstmt > 128 ? 8 : nstmt > 64 ? 4 : nstmt > 32 ? 2 : 1;
   const uint32_t d = c->P.d, m = c->P.m;
   if (d % 128 || m < 2) { c->err = "mfh_witness_poly_mm: d must be a multiple of 128"; return MFH_EUNSUPPORTED; }
   for (uint32_t b = 0; b < nstmt; b++)
@@ -1322,7 +1408,7 @@ int mfh_witness_poly_mm(mfh_ctx *c, const uint32_t *d_ssp, uint32_t nstmt, const
     HIP_TRY(c, hipGetLastError());
     c->ssp_frag_src = d_ssp;
   }
-  const size_t packed = (size_t)nstmt * bits_stride, head_b = ((packed + 8 + 128 * 8 + 255) & ~(size_t)255);
+  const size_t packed = (size_t)nstmt * bits_stride, head_b = ((packed + 8 + 256 * 8 + 255) & ~(size_t)255);
   const size_t frag_b = (size_t)ksteps * MT * 1024, part_b = (size_t)nchunks * 4 * 32 * MT * d * 4;
   const size_t rk_b = src.dense ? 0 : (((size_t)ksteps * 32 * 4 + 255) & ~(size_t)255);
   int rc = wws_reserve(c, head_b + frag_b + part_b + rk_b);
@@ -1354,7 +1440,10 @@ int mfh_witness_poly_mm(mfh_ctx *c, const uint32_t *d_ssp, uint32_t nstmt, const
     if (MT == 1) hipLaunchKernelGGL(k_witness_mm_prg<1>, grid, dim3(256), 0, c->stream, d_rk, (const v4i *)d_frag, nrowsel, kpc, d, d_part);
     else if (MT == 2) hipLaunchKernelGGL(k_witness_mm_prg<2>, grid, dim3(256), 0, c->stream, d_rk, (const v4i *)d_frag, nrowsel, kpc, d, d_part);
     else hipLaunchKernelGGL(k_witness_mm_prg<4>, grid, dim3(256), 0, c->stream, d_rk, (const v4i *)d_frag, nrowsel, kpc, d, d_part);
-  } else if (MT == 1)
+  } else if (MT == 8)
+    hipLaunchKernelGGL(k_witness_mm8, dim3(d / 64, (ksteps + kpc - 1) / kpc), dim3(256), 0, c->stream, (const v4i *)c->ssp_frag, (const v4i *)d_frag, nrowsel, kpc, d,
+                       d_part);
+  else if (MT == 1)
     hipLaunchKernelGGL(k_witness_mm<1>, dim3(d / 128, (ksteps + kpc - 1) / kpc), dim3(256), 0, c->stream, (const v4i *)c->ssp_frag, (const v4i *)d_frag,
                        nrowsel, kpc, d, d_part);
   else if (MT == 2)

@@ -508,9 +508,9 @@ int batch_chain_launch(mfh_ctx *c, const mf::SspSrc &src, const uint32_t *d_ssp,
   // d % 128 == 0: a GEMM on the matrix cores, one read (dense SSP) or one generation (generator-defined SSP) of the selected rows per
   // 124 statements; otherwise the VALU form, read or generated once per 12 statements
   if (d % 128 == 0) {
-    // (one pass per 124 statements: a 256-statement pass -- byte planes split over wave pairs, 8 statement tiles per wave -- was built
-    // and measured at 2.26 ms per super-group against 2 x 0.59: eight bit fragments per wave and row step make it L1-bound)
-    const uint32_t per = 124u;
+    // dense SSP: the whole super-group (248 statements) in one read (k_witness_mm8); generator-defined: 124 statements per generation
+    static const uint32_t per_env = [] { const char *e = getenv("MFH_WITNESS_PER"); return e ? (uint32_t)atoi(e) : 0u; }();  // (A/B knob)
+    const uint32_t per = per_env ? std::min(per_env, src.dense ? 256u : 128u) : (src.dense ? 248u : 124u);
     for (uint32_t b0 = 0; b0 < sg; b0 += per) {
       rc = mfh_witness_poly_mm(c, d_ssp, std::min(per, sg - b0), h_bits + (size_t)b0 * bits_stride, bits_stride, h_delta + b0, W + (size_t)b0 * d);
       if (rc) return rc;

@@ -265,7 +265,7 @@ int mfh_prove_finish(mfh_ctx *ctx, uint64_t *d_proof, const uint8_t *h_smudge_ma
  * added into the polynomials of the statements whose bit selects it.  h_bits: nstmt bit strings bits_stride bytes apart; d_w: nstmt x d coefficients. */
 int mfh_witness_poly_multi(mfh_ctx *ctx, const uint32_t *d_ssp, uint32_t nstmt, const uint8_t *h_bits, size_t bits_stride, const uint32_t *h_delta,
                            uint32_t *d_w);
-/* The same for nstmt <= 128 statements in ONE read of the SSP, as a GEMM on the matrix cores (bits x SSP bytes, exact); d a multiple
+/* The same for nstmt <= 256 statements (128 for a generator-defined SSP) in ONE read of the SSP, as a GEMM on the matrix cores (bits x SSP bytes, exact); d a multiple
  * of 128 (d_ssp == NULL, the generator-defined SSP: the SSP bytes are generated in the kernel).  Keeps a second image of the SSP in MFMA fragment order (same size), built on first use and rebuilt after
  * mfh_ssp_upload / mfh_ssp_prepare.  Used by mfh_prove_batch. */
 int mfh_witness_poly_mm(mfh_ctx *ctx, const uint32_t *d_ssp, uint32_t nstmt, const uint8_t *h_bits, size_t bits_stride, const uint32_t *h_delta,

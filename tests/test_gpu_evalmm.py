@@ -192,7 +192,7 @@ def test_batch_prover_from_the_matrix_core_crs_image(gpu_ctx_factory, oracle):
     assert [bool(x) for x in ok] == [b % 2 == 0 for b in range(nb)]
 
 
-@pytest.mark.parametrize("nstmt", [1, 7, 32, 33, 64, 65, 124, 128])
+@pytest.mark.parametrize("nstmt", [1, 7, 32, 33, 64, 65, 124, 128, 129, 200, 248, 256])
 def test_witness_pass_on_the_matrix_cores(gpu_ctx_factory, nstmt):
     """mfh_witness_poly_mm (bits x SSP bytes as a GEMM, one read of the SSP) and mfh_witness_poly_multi (VALU, 12 at a time) give
     mfh_witness_poly's polynomials, also for all-zero / all-one witnesses and edge SSP values (0, p - 1)."""
@@ -220,6 +220,31 @@ def test_witness_pass_on_the_matrix_cores(gpu_ctx_factory, nstmt):
     if nstmt <= 12:
         got_v = c.to_host(c.witness_poly_many(d_ssp, wits, deltas, mm=False), np.uint32).reshape(nstmt, p.d)
         assert np.array_equal(got_v, got_mm)
+
+
+@pytest.mark.parametrize("nstmt,d,m", [(248, 256, 1100), (130, 384, 1000), (256, 128, 777), (124, 256, 1100)])
+def test_witness_pass_row_steps_and_chunks(gpu_ctx_factory, nstmt, d, m):
+    """The same at sizes where a row chunk has several 4-step rounds and a 1..3-step tail (the 256-statement pass keeps its bit fragments
+    in an LDS ring two steps ahead and its SSP fragments four steps ahead), against the VALU form 12 statements at a time."""
+    import c_lwe_snarks_amd as mf
+
+    p = mf.Params(d=d, m=m)
+    c = gpu_ctx_factory(p)
+    rng = np.random.default_rng(7000 + nstmt + m)
+    ssp = rng.integers(0, ol.P, size=(p.m + 3) * p.d, dtype=np.uint64)
+    ssp[7 * p.d: 8 * p.d] = ol.P - 1
+    d_ssp = c.ssp_upload(ssp)
+    nbytes = (p.m + 7) // 8
+    wits = [rng.integers(0, 256, size=nbytes, dtype=np.uint8).tobytes() for _ in range(nstmt)]
+    wits[nstmt - 1] = b"\xff" * nbytes
+    deltas = [int(x) for x in rng.integers(0, ol.P, size=nstmt, dtype=np.uint64)]
+    got_mm = c.to_host(c.witness_poly_many(d_ssp, wits, deltas, mm=True), np.uint32).reshape(nstmt, p.d)
+    for b0 in range(0, nstmt, 12):
+        b1 = min(nstmt, b0 + 12)
+        ref = c.to_host(c.witness_poly_many(d_ssp, wits[b0:b1], deltas[b0:b1], mm=False), np.uint32).reshape(b1 - b0, p.d)
+        assert np.array_equal(got_mm[b0:b1], ref), f"statements {b0}..{b1}"
+    one = c.to_host(c.witness_poly(d_ssp, wits[nstmt - 1], deltas[nstmt - 1]), np.uint32)
+    assert np.array_equal(got_mm[nstmt - 1], one)
 
 
 @pytest.mark.parametrize("logq,d,m", [(736, 256, 64), (736, 1152, 1000), (1472, 128, 24), (736, 320, 70)])
