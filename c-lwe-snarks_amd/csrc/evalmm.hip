@@ -858,8 +858,12 @@ __global__ __launch_bounds__(256) void k_witness_mm(const v4i *__restrict__ sspf
 // KiB, the same for all four waves) go through a four-slot LDS ring, two steps ahead (fetched straight from L2 by every wave they made
 // the pass L1-bound: 2.26 ms against 2 x 0.59 for two 124-statement passes).  The SSP fragments (2 KiB per wave and step: the HBM
 // stream) are prefetched four steps ahead in registers.  grid = (d / 64, row chunks).
+// part == nullptr (one row chunk, m < 2^16): the chunk partials never leave the workgroup -- the two waves of a pair exchange their
+// half sums (planes 0-1 / planes 2-3, 32 bits each) through the ring's LDS and write w_b[k] = delta_b t[k] + the byte sum mod p directly
+// (what k_witness_mm_finish does from the partials: 0.5 GB written and read back per 248 statements otherwise).
 __global__ __launch_bounds__(256) void k_witness_mm8(const v4i *__restrict__ sspfrag, const v4i *__restrict__ bitfrag, uint32_t nrowsel /* m - 1 */,
-                                                     uint32_t ksteps_per_chunk, uint32_t d, int *__restrict__ part) {
+                                                     uint32_t ksteps_per_chunk, uint32_t d, int *__restrict__ part, const uint32_t *__restrict__ tpoly,
+                                                     const uint32_t *__restrict__ cnt_delta, uint32_t nstmt, uint32_t *__restrict__ w_out) {
   constexpr int MT = 8, RING = 4, PF = 4;
   __shared__ v4i bits[RING][MT][64];
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -927,6 +931,59 @@ __global__ __launch_bounds__(256) void k_witness_mm8(const v4i *__restrict__ ssp
   if (K < K1) step(2, sta);
   uint32_t dd = d;
   asm volatile("" : "+s"(dd));  // (keeps the 256 store addresses from being computed -- and spilled -- ahead of the loop)
+  if (!part) {
+    // wave A (planes 0, 1) finishes statement tiles 0..3, wave B (planes 2, 3) tiles 4..7: four rounds, one tile each way per round
+    uint32_t *xch = reinterpret_cast<uint32_t *>(&bits[0][0][0]) + (wave >> 1) * 2048;  // [2 directions][16][64] per pair
+    const uint32_t isB = wave & 1, k = kt * 32 + r32;
+    asm volatile("" : "+s"(cnt_delta), "+s"(tpoly));  // (as above: no loads of the epilogue ahead of the loop)
+    const uint64_t tk = tpoly[k];
+    const uint64_t P = MFH_P;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      // hand over my half of the OTHER wave's tile
+      if (isB) {
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+          const uint32_t b = 32 * r + (e & 3) + 8 * (e >> 2) + 4 * h;
+          const uint32_t corr = b < nstmt ? 128u * cnt_delta[2 * b] : 0u;
+          xch[1024 + e * 64 + lane] = ((uint32_t)acc[r][0][e] + corr) + (((uint32_t)acc[r][1][e] + corr) << 8);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+          const uint32_t b = 32 * (4 + r) + (e & 3) + 8 * (e >> 2) + 4 * h;
+          const uint32_t corr = b < nstmt ? 128u * cnt_delta[2 * b] : 0u;
+          xch[e * 64 + lane] = ((uint32_t)acc[4 + r][0][e] + corr) + (((uint32_t)acc[4 + r][1][e] + corr) << 8);
+        }
+      }
+      __syncthreads();
+      if (isB) {
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+          const uint32_t b = 32 * (4 + r) + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (b < nstmt) {
+            const uint32_t corr = 128u * cnt_delta[2 * b], delta = cnt_delta[2 * b + 1];
+            const uint64_t hi = ((uint32_t)acc[4 + r][0][e] + corr) + (((uint32_t)acc[4 + r][1][e] + corr) << 8);
+            const uint64_t val = (uint64_t)xch[e * 64 + lane] + (hi << 16);
+            w_out[(uint64_t)b * dd + k] = (uint32_t)((val % P + tk * delta % P) % P);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+          const uint32_t b = 32 * r + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (b < nstmt) {
+            const uint32_t corr = 128u * cnt_delta[2 * b], delta = cnt_delta[2 * b + 1];
+            const uint64_t lo = ((uint32_t)acc[r][0][e] + corr) + (((uint32_t)acc[r][1][e] + corr) << 8);
+            const uint64_t val = lo + ((uint64_t)xch[1024 + e * 64 + lane] << 16);
+            w_out[(uint64_t)b * dd + k] = (uint32_t)((val % P + tk * delta % P) % P);
+          }
+        }
+      }
+      __syncthreads();
+    }
+    return;
+  }
   int *dst = part + ((uint64_t)blockIdx.y * 4 + w0) * (32 * MT) * dd + kt * 32 + r32 + (uint64_t)(4 * h) * dd;
 #pragma unroll
   for (int w = 0; w < 2; w++)
@@ -1394,7 +1451,10 @@ int mfh_witness_poly_mm(mfh_ctx *c, const uint32_t *d_ssp, uint32_t nstmt, const
     if (h_delta[b] >= MFH_P) { c->err = "delta must be < p"; return MFH_EINVAL; }
   HIP_TRY(c, hipSetDevice(c->device));
   const uint32_t nrowsel = m - 1, ksteps = (nrowsel + 31) / 32;
-  const uint32_t nchunks = std::min(ksteps, 4u), kpc = (ksteps + nchunks - 1) / nchunks;
+  // (the 256-statement pass has d / 64 workgroups of one wave per SIMD: one row chunk fills the chip at d >= 2^14, and with one chunk --
+  // and byte sums that fit 32 bits per plane pair -- it finishes in the kernel)
+  const bool fused = MT == 8 && m < 65536 && (d >= 16384 || ksteps <= 64);  // (small instances: nothing to fill either way)
+  const uint32_t nchunks = fused ? 1u : std::min(ksteps, 4u), kpc = (ksteps + nchunks - 1) / nchunks;
   // the SSP in B-fragment order: built on first use per SSP (mfh_ssp_prepare invalidates it), kept beside the uint32 image
   const size_t sfrag_b = (size_t)ksteps * 32 * d * 4;
   if (src.dense && (c->ssp_frag_src != d_ssp || c->ssp_frag_bytes < sfrag_b)) {
@@ -1440,10 +1500,14 @@ int mfh_witness_poly_mm(mfh_ctx *c, const uint32_t *d_ssp, uint32_t nstmt, const
     if (MT == 1) hipLaunchKernelGGL(k_witness_mm_prg<1>, grid, dim3(256), 0, c->stream, d_rk, (const v4i *)d_frag, nrowsel, kpc, d, d_part);
     else if (MT == 2) hipLaunchKernelGGL(k_witness_mm_prg<2>, grid, dim3(256), 0, c->stream, d_rk, (const v4i *)d_frag, nrowsel, kpc, d, d_part);
     else hipLaunchKernelGGL(k_witness_mm_prg<4>, grid, dim3(256), 0, c->stream, d_rk, (const v4i *)d_frag, nrowsel, kpc, d, d_part);
-  } else if (MT == 8)
+  } else if (MT == 8) {
     hipLaunchKernelGGL(k_witness_mm8, dim3(d / 64, (ksteps + kpc - 1) / kpc), dim3(256), 0, c->stream, (const v4i *)c->ssp_frag, (const v4i *)d_frag, nrowsel, kpc, d,
-                       d_part);
-  else if (MT == 1)
+                       fused ? (int *)nullptr : d_part, src.t, d_cd, nstmt, d_w);
+    if (fused) {
+      HIP_TRY(c, hipGetLastError());
+      return MFH_OK;
+    }
+  } else if (MT == 1)
     hipLaunchKernelGGL(k_witness_mm<1>, dim3(d / 128, (ksteps + kpc - 1) / kpc), dim3(256), 0, c->stream, (const v4i *)c->ssp_frag, (const v4i *)d_frag,
                        nrowsel, kpc, d, d_part);
   else if (MT == 2)

@@ -222,10 +222,11 @@ def test_witness_pass_on_the_matrix_cores(gpu_ctx_factory, nstmt):
         assert np.array_equal(got_v, got_mm)
 
 
-@pytest.mark.parametrize("nstmt,d,m", [(248, 256, 1100), (130, 384, 1000), (256, 128, 777), (124, 256, 1100)])
+@pytest.mark.parametrize("nstmt,d,m", [(248, 256, 1100), (130, 384, 1000), (256, 128, 777), (124, 256, 1100), (248, 128, 2300), (129, 128, 4000)])
 def test_witness_pass_row_steps_and_chunks(gpu_ctx_factory, nstmt, d, m):
     """The same at sizes where a row chunk has several 4-step rounds and a 1..3-step tail (the 256-statement pass keeps its bit fragments
-    in an LDS ring two steps ahead and its SSP fragments four steps ahead), against the VALU form 12 statements at a time."""
+    in an LDS ring two steps ahead and its SSP fragments four steps ahead; up to 64 row steps -- or at d >= 2^14 -- it has one row chunk and
+    finishes in the kernel, else it leaves chunk partials to k_witness_mm_finish), against the VALU form 12 statements at a time."""
     import c_lwe_snarks_amd as mf
 
     p = mf.Params(d=d, m=m)
