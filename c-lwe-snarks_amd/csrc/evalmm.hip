@@ -672,7 +672,9 @@ __global__ __launch_bounds__(SW * 64) void k_mmstream(MmsImages imgs, uint32_t m
 #pragma unroll
       for (int i = 0; i < BPK; i++) bnr[ks][i] = b_load(un2, ks, i);
     }
+#ifndef MMS_NOSYNC  // (timing-only build without it: wrong results -- what the stage barrier costs)
     __syncthreads();  // the other buffer is complete; everyone is done with this one
+#endif
     buf ^= 1;
   }
   const uint64_t Mtot = (uint64_t)mtiles * 16;

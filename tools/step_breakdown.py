@@ -5,7 +5,7 @@ Prints per kernel: launches, summed duration, and the time during which ONLY tha
 import csv, glob, re, sys
 from collections import defaultdict
 
-f = max(glob.glob(sys.argv[1]), key=lambda p: len(open(p).read()))
+f = max(glob.glob(sys.argv[1], recursive=True), key=lambda p: len(open(p).read()))
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 ex = [i for i, r in enumerate(rows) if "k_evalmm16<1" in r["Kernel_Name"] or "k_expand_mm" in r["Kernel_Name"]]
