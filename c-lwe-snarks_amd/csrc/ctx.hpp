@@ -45,7 +45,7 @@ struct mfh_ctx {
   int mm_ws_sel = 0;         // 0: ws, 1: ws2
   void *ws3 = nullptr;       // mfh_prove_batch, streaming regime: digit fragments and partial products of all rounds of a super-group
   size_t ws3_bytes = 0;
-  std::vector<hipEvent_t> ev_cdone, ev_rdone;  // mfh_prove_batch: chain of super-group k done / its w | h | v area read (per area)
+  std::vector<hipEvent_t> ev_cdone, ev_rdone, ev_wdone;  // mfh_prove_batch: chain of super-group k done / its w | h | v area read / its witness pass done (per area)
   std::vector<hipEvent_t> ev_round;  // one per round: its streaming launch has finished
   void *wws = nullptr;       // scratch of the witness pass (its own buffer: the pass may run beside an eval launch that owns `ws`)
   size_t wws_bytes = 0;

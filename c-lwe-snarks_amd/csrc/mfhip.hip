@@ -959,6 +959,7 @@ void mfh_ctx_destroy(mfh_ctx *c) {
   for (hipEvent_t e : c->ev_round) hipEventDestroy(e);
   for (hipEvent_t e : c->ev_cdone) hipEventDestroy(e);
   for (hipEvent_t e : c->ev_rdone) hipEventDestroy(e);
+  for (hipEvent_t e : c->ev_wdone) hipEventDestroy(e);
   if (c->lazy) hipFree(c->lazy);
   if (c->aux) hipFree(c->aux);
   if (c->ev_fork) hipEventDestroy(c->ev_fork);

@@ -456,21 +456,28 @@ struct OnSide {  // eval_rows_multi_io* launch on c->stream with the workspace c
 // launches' column-sum slots (256 int64 each)
 struct BatchScratch {
   uint32_t *WHV;
-  uint8_t *CW;
+  uint8_t *CW;      // ncw areas of cw_stride bytes: the packed witness bits of a super-group, then its deltas
+  size_t cw_stride, cw_delta_off;
+  uint32_t *SMU;    // staged smudging terms u p of the call: [proof][5][KW] words, then the signs [proof][5]
+  uint8_t *SMS;
   uint32_t *ONE;
   uint64_t *CT_T;
   int64_t *SCZ;
   size_t nslots;
 };
-int batch_scratch(mfh_ctx *c, uint32_t nproofs, uint32_t whv /* w | h | v areas of a super-group */, BatchScratch &B) {
+int batch_scratch(mfh_ctx *c, uint32_t nproofs, uint32_t whv /* w | h | v areas of a super-group */, BatchScratch &B, uint32_t ncw = 1,
+                  uint32_t nsmudge = 0 /* proofs whose smudging terms are staged */) {
   const uint32_t d = c->P.d, m = c->P.m, n = c->P.n;
   const size_t ctl = (size_t)(n + 1) * ((c->P.logq + 63) / 64);
   const size_t nsg = ((size_t)nproofs + BSG - 1) / BSG;
   B.nslots = nsg * (1 + 2 * ((BSG + BG - 1) / BG));  // multi-vector launches of the call
   const size_t whv_b = (size_t)whv * 3 * BSG * d * 4;
-  const size_t cw_b = (((size_t)BSG * ((m + 6) / 8) + 3) & ~(size_t)3) + (size_t)BSG * 4;
+  const size_t packed = ((size_t)BSG * ((m + 6) / 8) + 3) & ~(size_t)3;
+  const size_t cw_b = packed + (size_t)BSG * 4;
   const size_t cw_pad = (cw_b + 255) & ~(size_t)255;
-  const size_t need = whv_b + cw_pad + 256 + ctl * 8 + B.nslots * 2048;
+  const size_t KW = 2 * (c->P.logq / 64);
+  const size_t sm_b = ((size_t)nsmudge * 5 * (KW * 4 + 1) + 255) & ~(size_t)255;
+  const size_t need = whv_b + cw_pad * ncw + sm_b + 256 + ctl * 8 + B.nslots * 2048;
   if (c->batch_bytes < need) {
     if (c->d_batch) { hipDeviceSynchronize(); hipFree(c->d_batch); c->d_batch = nullptr; c->batch_bytes = 0; }
     HIP_TRY(c, hipMalloc(&c->d_batch, need));
@@ -479,9 +486,83 @@ int batch_scratch(mfh_ctx *c, uint32_t nproofs, uint32_t whv /* w | h | v areas 
   uint8_t *base = (uint8_t *)c->d_batch;
   B.WHV = (uint32_t *)base;
   B.CW = base + whv_b;
-  B.ONE = (uint32_t *)(base + whv_b + cw_pad);
-  B.CT_T = (uint64_t *)(base + whv_b + cw_pad + 256);
-  B.SCZ = (int64_t *)(base + whv_b + cw_pad + 256 + ctl * 8);
+  B.cw_stride = cw_pad;
+  B.cw_delta_off = packed;
+  B.SMU = (uint32_t *)(base + whv_b + cw_pad * ncw);
+  B.SMS = (uint8_t *)B.SMU + (size_t)nsmudge * 5 * KW * 4;
+  B.ONE = (uint32_t *)(base + whv_b + cw_pad * ncw + sm_b);
+  B.CT_T = (uint64_t *)(base + whv_b + cw_pad * ncw + sm_b + 256);
+  B.SCZ = (int64_t *)(base + whv_b + cw_pad * ncw + sm_b + 256 + ctl * 8);
+  return MFH_OK;
+}
+// Everything the host contributes to a call, staged in one pinned buffer and copied once, on c->stream: per super-group the packed
+// witness bits (the m - 1 bits of a statement repacked densely) and the deltas, then the smudging terms u p of all five draws of every
+// proof (schoolbook by 32-bit words: src/lwe.c:65-76) and their signs.  B was sized with ncw = super-groups, nsmudge = nproofs.
+int batch_stage_host(mfh_ctx *c, const BatchScratch &B, uint32_t nproofs, const uint8_t *h_bits, size_t bits_stride, const uint32_t *h_delta,
+                     const uint8_t *h_mag, size_t maglen, const uint8_t *h_sign) {
+  const uint32_t m = c->P.m, nsg = (nproofs + BSG - 1) / BSG;
+  const uint32_t bstride = (m + 6) / 8, KW = 2 * (c->P.logq / 64);
+  if (maglen + 4 > (size_t)KW * 4) { c->err = "smudge magnitude too wide"; return MFH_EINVAL; }
+  const size_t total = (size_t)((uint8_t *)B.SMS - B.CW) + (size_t)nproofs * 5;
+  uint8_t *st = (uint8_t *)pin_acquire(c, c->pin_cw, total);
+  if (!st) return MFH_ENOMEM;
+  for (uint32_t g = 0; g < nsg; g++) {
+    const uint32_t s0 = g * BSG, sg = std::min(BSG, nproofs - s0);
+    uint8_t *a = st + (size_t)g * B.cw_stride;
+    for (uint32_t b = 0; b < sg; b++) memcpy(a + (size_t)b * bstride, h_bits + (size_t)(s0 + b) * bits_stride, bstride);
+    memcpy(a + B.cw_delta_off, h_delta + s0, (size_t)sg * 4);
+  }
+  uint32_t *up = (uint32_t *)(st + ((uint8_t *)B.SMU - B.CW));
+  for (size_t i = 0; i < (size_t)nproofs * 5; i++) {
+    uint64_t carry = 0;
+    for (uint32_t l = 0; l < KW; l++) {
+      uint32_t w = 0;
+      const size_t o = (size_t)l * 4;
+      if (o < maglen) memcpy(&w, h_mag + i * maglen + o, std::min<size_t>(4, maglen - o));
+      const uint64_t t = (uint64_t)w * P32 + carry;
+      up[i * KW + l] = (uint32_t)t;
+      carry = t >> 32;
+    }
+  }
+  memcpy(st + ((uint8_t *)B.SMS - B.CW), h_sign, (size_t)nproofs * 5);
+  HIP_TRY(c, hipMemcpyAsync(B.CW, st, total, hipMemcpyHostToDevice, c->stream));
+  pin_release(c, c->pin_cw);
+  return MFH_OK;
+}
+// b += +-(u p) on the b coordinate of ciphertext (i / per) * 5 + slot0 + i % per of a super-group's proof structs, with staged term
+// (i / per) * 5 + uslot0 + i % per (ct_smudge, src/lwe.c:65-76): per = 4, slots 0.. and terms 0..: h, hat_h, hat_v, v_w; per = 1, slot 3,
+// term 4: v_w AGAIN (src/snark.c:185-189).  b_w's ciphertext is never touched.
+__global__ void k_smudge_batch(uint64_t *cts, uint32_t n, uint32_t L, uint32_t KW, const uint32_t *__restrict__ up, const uint8_t *__restrict__ sign,
+                               uint32_t count, uint32_t per, uint32_t slot0, uint32_t uslot0) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const uint32_t pb = i / per, j = i % per;
+  uint32_t *b = reinterpret_cast<uint32_t *>(cts + ((uint64_t)(pb * 5 + slot0 + j) * (n + 1) + n) * L);
+  const uint32_t *u = up + (uint64_t)(pb * 5 + uslot0 + j) * KW;
+  if (sign[pb * 5 + uslot0 + j] & 1) {
+    uint32_t borrow = 0;
+    for (uint32_t l = 0; l < KW; l++) {
+      const uint64_t t = (uint64_t)b[l] - u[l] - borrow;
+      b[l] = (uint32_t)t;
+      borrow = (uint32_t)(t >> 63);
+    }
+  } else {
+    uint32_t carry = 0;
+    for (uint32_t l = 0; l < KW; l++) {
+      const uint64_t t = (uint64_t)b[l] + u[l] + carry;
+      b[l] = (uint32_t)t;
+      carry = (uint32_t)(t >> 32);
+    }
+  }
+  for (uint32_t l = KW; l < 2 * L; l++) b[l] = 0;
+}
+int batch_smudge_staged(mfh_ctx *c, const BatchScratch &B, uint64_t *sproofs, uint32_t s0, uint32_t sg) {
+  const uint32_t L = (c->P.logq + 63) / 64, KW = 2 * (c->P.logq / 64);
+  const uint32_t *up = B.SMU + (size_t)s0 * 5 * KW;
+  const uint8_t *sn = B.SMS + (size_t)s0 * 5;
+  hipLaunchKernelGGL(k_smudge_batch, dim3((sg * 4 + 63) / 64), dim3(64), 0, c->stream, sproofs, c->P.n, L, KW, up, sn, sg * 4, 4u, 0u, 0u);
+  hipLaunchKernelGGL(k_smudge_batch, dim3((sg + 63) / 64), dim3(64), 0, c->stream, sproofs, c->P.n, L, KW, up, sn, sg, 1u, 3u, 4u);
+  HIP_TRY(c, hipGetLastError());
   return MFH_OK;
 }
 int batch_streams(mfh_ctx *c) {
@@ -502,7 +583,7 @@ int batch_streams(mfh_ctx *c) {
 // (src/snark.c:161-169); W, H, V are sg x d coefficients each.  The witness pass and the polynomial step have their own scratch (wws,
 // the poly buffers).
 int batch_chain_launch(mfh_ctx *c, const mf::SspSrc &src, const uint32_t *d_ssp, uint32_t sg, const uint8_t *h_bits, size_t bits_stride,
-                       const uint32_t *h_delta, uint32_t *W, uint32_t *H, uint32_t *V) {
+                       const uint32_t *h_delta, uint32_t *W, uint32_t *H, uint32_t *V, hipEvent_t ev_witness = nullptr) {
   const uint32_t d = c->P.d;
   int rc = MFH_OK;
   // d % 128 == 0: a GEMM on the matrix cores, one read (dense SSP) or one generation (generator-defined SSP) of the selected rows per
@@ -521,6 +602,7 @@ int batch_chain_launch(mfh_ctx *c, const mf::SspSrc &src, const uint32_t *d_ssp,
       if (rc) return rc;
     }
   }
+  if (ev_witness) HIP_TRY(c, hipEventRecord(ev_witness, c->stream));  // the HBM-bound part of the chain is over
   hipLaunchKernelGGL(k_add_slot_multi, dim3((d + 255) / 256, sg), dim3(256), 0, c->stream, W, src, 1u, d, V);
   HIP_TRY(c, hipGetLastError());
   return mfh_poly_h_multi(c, V, H, sg);  // one set of launches, sg times the work each
@@ -540,36 +622,55 @@ struct BatchCoef {
 // sproofs: the sg proof structs (5 ciphertexts each, h | hat_h | hat_v | v_w | b_w).  h_delta == nullptr: no delta ct_t term (a partial
 // proof: the term is added once, after the ranks' shares have been summed).  wait_ev: awaited before the S / AS launches (the chain).
 // accumulate: add onto what sproofs holds (mod 2^(64K)) -- the row slabs of mfh_prove_batch when the image does not fit HBM.
+// b_w of a super-group on c->stream from the staged area d_cw (packed bits, then -- has_delta -- the deltas at B.cw_delta_off)
+int batch_bw(mfh_ctx *c, const uint8_t *d_crs_c8, uint32_t rank, uint32_t world, uint32_t sg, const uint8_t *d_cw, bool has_delta, uint64_t *sproofs,
+             const BatchScratch &B, size_t &slot, int accumulate) {
+  const uint32_t d = c->P.d, m = c->P.m, n = c->P.n;
+  const uint32_t ctb = c->P.logq / 8;
+  const size_t ctl = (size_t)(n + 1) * ((c->P.logq + 63) / 64);
+  const uint64_t ctr_ct = (uint64_t)ctb * n;
+  const uint64_t pstride = 5 * ctl;
+  const uint32_t lo = (uint32_t)((uint64_t)m * rank / world), cnt = (uint32_t)((uint64_t)m * (rank + 1) / world) - lo;
+  const uint32_t bstride = (m + 6) / 8;
+  MmIo io_bw = {{nullptr, nullptr}, sg, {sproofs + 4 * ctl, nullptr}, sg, pstride, d_cw, bstride, B.SCZ + 256 * slot++};
+  io_bw.bits_row0 = lo;
+  int rc = eval_rows_multi_io(c, ctr_ct * ((uint64_t)2 * d + lo), cnt, d_crs_c8 + ((size_t)2 * d + lo) * ctb, io_bw, sg, 1, accumulate);
+  if (rc) return rc;
+  if (has_delta) {  // + delta_b ct_t for the sg proofs in one launch
+    hipLaunchKernelGGL(k_bw_add_delta_ct, dim3((n + 1 + 255) / 256, sg), dim3(256), 0, c->stream, sproofs, B.CT_T, (const uint32_t *)(d_cw + B.cw_delta_off), n + 1,
+                       (c->P.logq + 63) / 64, 2 * (c->P.logq / 64));
+    HIP_TRY(c, hipGetLastError());
+  }
+  return MFH_OK;
+}
+// d_cw: the super-group's staged area (batch_stage_host), or nullptr: staged here from h_bits / h_delta.
 int batch_rows_supergroup(mfh_ctx *c, const uint8_t *d_crs_c8, uint32_t rank, uint32_t world, uint32_t sg, const uint8_t *h_bits,
                           size_t bits_stride, const BatchCoef &co, uint64_t *sproofs, const BatchScratch &B, size_t &slot,
-                          const uint32_t *h_delta, hipEvent_t wait_ev, int accumulate = 0) {
+                          const uint32_t *h_delta, hipEvent_t wait_ev, int accumulate = 0, const uint8_t *d_cw = nullptr) {
   const uint32_t d = c->P.d, m = c->P.m, n = c->P.n;
   const uint32_t ctb = c->P.logq / 8;
   const size_t ctl = (size_t)(n + 1) * ((c->P.logq + 63) / 64);
   const uint64_t ctr_ct = (uint64_t)ctb * n;
   const uint64_t pstride = 5 * ctl;  // component `slot` of consecutive proofs (struct order h | hat_h | hat_v | v_w | b_w)
   hipStream_t const main_stream = c->stream, side_stream = c->side;
-  const uint32_t lo = (uint32_t)((uint64_t)m * rank / world), cnt = (uint32_t)((uint64_t)m * (rank + 1) / world) - lo;
   const uint32_t loS = (uint32_t)((uint64_t)d * rank / world), cS = (uint32_t)((uint64_t)d * (rank + 1) / world) - loS;
   int rc = MFH_OK;
-  // ---- b_w: the packed bits travel as they are (2.7 KB per statement at the default size; the digit kernel unpacks them), the deltas
-  // behind them, through one pinned staging buffer and one copy
-  const uint32_t bstride = (m + 6) / 8;  // the m - 1 bits of a statement, repacked densely
-  const size_t packed = ((size_t)sg * bstride + 3) & ~(size_t)3, staged = packed + (h_delta ? (size_t)sg * 4 : 0);
-  uint8_t *h_cw = (uint8_t *)pin_acquire(c, c->pin_cw, staged);
-  if (!h_cw) return MFH_ENOMEM;
-  for (uint32_t b = 0; b < sg; b++) memcpy(h_cw + (size_t)b * bstride, h_bits + (size_t)b * bits_stride, bstride);
-  if (h_delta) memcpy(h_cw + packed, h_delta, (size_t)sg * 4);
-  HIP_TRY(c, hipMemcpyAsync(B.CW, h_cw, staged, hipMemcpyHostToDevice, c->stream));
-  pin_release(c, c->pin_cw);
-  MmIo io_bw = {{nullptr, nullptr}, sg, {sproofs + 4 * ctl, nullptr}, sg, pstride, (const uint8_t *)B.CW, bstride, B.SCZ + 256 * slot++};
-  io_bw.bits_row0 = lo;
-  rc = eval_rows_multi_io(c, ctr_ct * ((uint64_t)2 * d + lo), cnt, d_crs_c8 + ((size_t)2 * d + lo) * ctb, io_bw, sg, 1, accumulate);
-  if (rc) return rc;
-  if (h_delta) {  // + delta_b ct_t for the sg proofs in one launch
-    hipLaunchKernelGGL(k_bw_add_delta_ct, dim3((n + 1 + 255) / 256, sg), dim3(256), 0, c->stream, sproofs, B.CT_T, (const uint32_t *)(B.CW + packed), n + 1,
-                       (c->P.logq + 63) / 64, 2 * (c->P.logq / 64));
-    HIP_TRY(c, hipGetLastError());
+  {
+    if (!d_cw) {
+      // ---- b_w: the packed bits travel as they are (2.7 KB per statement at the default size; the digit kernel unpacks them), the deltas
+      // behind them, through one pinned staging buffer and one copy
+      const uint32_t bstride = (m + 6) / 8;  // the m - 1 bits of a statement, repacked densely
+      const size_t staged = B.cw_delta_off + (h_delta ? (size_t)sg * 4 : 0);
+      uint8_t *h_cw = (uint8_t *)pin_acquire(c, c->pin_cw, staged);
+      if (!h_cw) return MFH_ENOMEM;
+      for (uint32_t b = 0; b < sg; b++) memcpy(h_cw + (size_t)b * bstride, h_bits + (size_t)b * bits_stride, bstride);
+      if (h_delta) memcpy(h_cw + B.cw_delta_off, h_delta, (size_t)sg * 4);
+      HIP_TRY(c, hipMemcpyAsync(B.CW, h_cw, staged, hipMemcpyHostToDevice, c->stream));
+      pin_release(c, c->pin_cw);
+      d_cw = B.CW;
+    }
+    rc = batch_bw(c, d_crs_c8, rank, world, sg, d_cw, h_delta != nullptr, sproofs, B, slot, accumulate);
+    if (rc) return rc;
   }
   if (wait_ev) HIP_TRY(c, hipStreamWaitEvent(main_stream, wait_ev, 0));
   HIP_TRY(c, hipEventRecord(c->ev_fork, main_stream));
@@ -767,18 +868,20 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
   }
   const uint32_t nbuf = nsl > 1 ? nsg : 2;
   BatchScratch B;
-  int rc = batch_scratch(c, nproofs, nbuf, B);
+  int rc = batch_scratch(c, nproofs, nbuf, B, nsl > 1 ? 1 : nsg, nsl > 1 ? 0 : nproofs);
   if (rc) return rc;
   size_t slot = 0;
   HIP_TRY(c, hipMemsetAsync(B.SCZ, 0, B.nslots * 2048, c->stream));
   rc = batch_streams(c);
   if (rc) return rc;
   while (c->ev_cdone.size() < nbuf) {
-    hipEvent_t e0, e1;
+    hipEvent_t e0, e1, e2;
     HIP_TRY(c, hipEventCreateWithFlags(&e0, hipEventDisableTiming));
     HIP_TRY(c, hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&e2, hipEventDisableTiming));
     c->ev_cdone.push_back(e0);
     c->ev_rdone.push_back(e1);
+    c->ev_wdone.push_back(e2);
   }
   hipStream_t const main_stream = c->stream, chain_stream = c->side2;
   auto whv_of = [&](uint32_t sgi, uint32_t *&W, uint32_t *&H, uint32_t *&V) {
@@ -791,7 +894,7 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
     uint32_t *WALL, *HALL, *VALL;
     whv_of(sgi, WALL, HALL, VALL);
     OnStream chain(c, chain_stream);
-    int r = batch_chain_launch(c, src, d_ssp, sg, h_witness_bits + (size_t)s0 * bits_stride, bits_stride, h_delta + s0, WALL, HALL, VALL);
+    int r = batch_chain_launch(c, src, d_ssp, sg, h_witness_bits + (size_t)s0 * bits_stride, bits_stride, h_delta + s0, WALL, HALL, VALL, c->ev_wdone[sgi % nbuf]);
     if (r) return r;
     HIP_TRY(c, hipEventRecord(c->ev_cdone[sgi % nbuf], chain_stream));
     return MFH_OK;
@@ -841,17 +944,27 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
   ImageGuard transient{c, false};
   rc = batch_transient_image(c, d_crs_c8, nproofs, 0, 1, transient);
   if (rc) return rc;
+  // everything the host contributes, in one copy (no host-side wait between the super-groups), staged while the GPU expands the CRS
+  rc = batch_stage_host(c, B, nproofs, h_witness_bits, bits_stride, h_delta, h_smudge_mag, maglen, h_smudge_sign);
+  if (rc) return rc;
   rc = batch_ct_t(c, d_crs_c8, B);
   if (rc) return rc;
+  // (b_w needs nothing of the chain and nothing needs b_w before the call ends, so all b_w launches of a call -- HBM-bound passes over the
+  // BT+BV image -- could run in the background under the matrix-core bound S / AS launches.  Built and measured: on an unrestricted side
+  // stream the call takes the same 81.5 ms, on a stream masked to 64 / 32 / 16 CUs 88.5 / 98.1 / 116.3 ms -- a k_mmstream workgroup pulls
+  // ~18 GB/s whether 16 or 256 CUs stream, so fewer CUs only stretch the pass.  b_w stays in line.)
   for (uint32_t s0 = 0, sgi = 0; s0 < nproofs; s0 += BSG, sgi++) {
     const uint32_t sg = std::min(BSG, nproofs - s0);
     uint64_t *sproofs = d_proofs + (size_t)s0 * 5 * ctl;
     uint32_t *WALL, *HALL, *VALL;
     whv_of(sgi, WALL, HALL, VALL);
     const BatchCoef co = {WALL, HALL, VALL, d};
+    // b_w's pass over the BT+BV image is HBM-bound like the chain's witness pass, and the chain is what the S / AS launches wait for: b_w
+    // starts when the witness pass is over and runs beside the polynomial step (NTT: VALU / LDS)
+    HIP_TRY(c, hipStreamWaitEvent(main_stream, c->ev_wdone[sgi % nbuf], 0));
     // the multi-vector launches read their coefficient vectors where the polynomial step left them and write the proof structs in place (MmIo)
     rc = batch_rows_supergroup(c, d_crs_c8, 0, 1, sg, h_witness_bits + (size_t)s0 * bits_stride, bits_stride, co, sproofs, B, slot, h_delta + s0,
-                               c->ev_cdone[sgi % nbuf]);
+                               c->ev_cdone[sgi % nbuf], 0, B.CW + (size_t)sgi * B.cw_stride);
     if (rc) return rc;
     if (sgi + 1 < nsg) {  // the next super-group's chain, into the other area (last read by super-group sgi - 1)
       HIP_TRY(c, hipEventRecord(c->ev_rdone[sgi % nbuf], main_stream));
@@ -859,7 +972,7 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
       rc = launch_chain(sgi + 1);
       if (rc) return rc;
     }
-    rc = batch_smudge(c, sproofs, sg, h_smudge_mag + (size_t)s0 * 5 * maglen, maglen, h_smudge_sign + (size_t)s0 * 5);
+    rc = batch_smudge_staged(c, B, sproofs, s0, sg);
     if (rc) return rc;
   }
   return MFH_OK;
