@@ -4,17 +4,28 @@ import os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import oracle_lib as ol
 import c_lwe_snarks_amd as mf
+
+
+def rand_values(rng, count, L, bits):
+    """count random values of `bits` bits as (count, L) uint64 limbs"""
+    nb = (bits + 7) // 8
+    raw = rng.integers(0, 256, size=(count, nb), dtype=np.uint8)
+    if bits % 8:
+        raw[:, -1] &= (1 << (bits % 8)) - 1
+    out = np.zeros((count, L * 8), dtype=np.uint8)
+    out[:, :nb] = raw
+    return out.view(np.uint64).reshape(count, L)
+
 logq = int(os.environ.get("LOGQ", "736"))
 p = mf.Params(logq=logq)
 ctx = mf.Context(p, 0)
 ctx.set_seed(bytes(range(40)))
 rng = np.random.default_rng(1)
-d_sk = ctx.to_device(ol.rand_values(rng, p.n, p.L, p.logq))
+d_sk = ctx.to_device(rand_values(rng, p.n, p.L, p.logq))
 for B in [int(a) for a in sys.argv[1:]] or [65536, 87381, 8192, 1000]:
     d_msg = ctx.to_device(rng.integers(0, mf.P, size=B, dtype=np.uint64).astype(np.uint32))
-    d_err = ctx.to_device(ol.rand_values(rng, B, p.L, 559))
+    d_err = ctx.to_device(rand_values(rng, B, p.L, 559))
     outs = {}
     for path in (1, 2):
         ctx.set_encrypt_path(path)
