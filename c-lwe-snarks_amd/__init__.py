@@ -87,7 +87,7 @@ EXPORTS = [
     "mfh_workspace_bytes", "mfh_last_kernel_ms", "mfh_set_timing", "mfh_set_overlap", "mfh_eval_rows_multi", "mfh_prove_batch", "mfh_crs_mm_image_bytes", "mfh_crs_expand_mm", "mfh_crs_set_resident_mm", "mfh_witness_poly_multi", "mfh_witness_poly_mm", "mfh_poly_h_multi", "mfh_poly_mul", "mfh_poly_add", "mfh_poly_prepare_t",
     "mfh_ssp_prepare", "mfh_poly_h", "mfh_setup_messages", "mfh_setup", "mfh_prove",
     "mfh_prove_partial", "mfh_prove_finish", "mfh_ct_to_lanes", "mfh_ct_from_lanes", "mfh_timing_drain", "mfh_timing_busy_ms", "mfh_timing_work_rows", "mfh_set_batch_image", "mfh_set_batch_slabs", "mfh_set_expand_path", "mfh_set_encrypt_path", "mfh_set_batch_launch", "mfh_set_mm_chunk_rows", "mfh_add_dotp",
-    "mfh_crs_mm_share_bytes", "mfh_crs_expand_mm_share", "mfh_crs_set_resident_mm_share", "mfh_batch_chain", "mfh_prove_batch_partial", "mfh_prove_batch_finish",
+    "mfh_crs_mm_share_bytes", "mfh_crs_expand_mm_share", "mfh_crs_set_resident_mm_share", "mfh_batch_chain", "mfh_batch_witness_cols", "mfh_batch_chain_from_w", "mfh_witness_poly_mm_cols", "mfh_prove_batch_partial", "mfh_prove_batch_finish",
     "mfh_resident_row_bytes", "mfh_crs_expand", "mfh_eval_rows_resident", "mfh_crs_set_resident",
     "mfh_witness_lanes", "mfh_witness_from_lanes", "mfh_prove_partial_w", "mfh_verify",
     "mfh_ssp_set_prg", "mfh_ssp_prg_make_t", "mfh_ssp_prg_fill",
@@ -178,6 +178,9 @@ def load_library():
         "mfh_crs_expand_mm_share": (i32, [vp, vp, u32, u32, vp]),
         "mfh_crs_set_resident_mm_share": (i32, [vp, vp, u32, u32]),
         "mfh_batch_chain": (i32, [vp, vp, u32, ctypes.c_char_p, sz, vp, vp, vp, vp]),
+        "mfh_batch_witness_cols": (i32, [vp, vp, u32, ctypes.c_char_p, sz, vp, u32, u32, vp, sz]),
+        "mfh_batch_chain_from_w": (i32, [vp, vp, u32, vp, vp, vp]),
+        "mfh_witness_poly_mm_cols": (i32, [vp, vp, u32, ctypes.c_char_p, sz, vp, u32, u32, vp, sz]),
         "mfh_prove_batch_partial": (i32, [vp, vp, u32, u32, u32, ctypes.c_char_p, sz, vp, vp, vp, sz, vp]),
         "mfh_prove_batch_finish": (i32, [vp, vp, u32, vp, ctypes.c_char_p, sz, ctypes.c_char_p, vp]),
     }
@@ -490,6 +493,24 @@ class Context:
         dl = (ctypes.c_uint32 * nb)(*[int(x) for x in deltas])
         self._chk(self.lib.mfh_batch_chain(self._h, _ptr(d_ssp), nb, bits, stride, ctypes.cast(dl, ctypes.c_void_p), _ptr(out[0]), _ptr(out[1]), _ptr(out[2])))
         return out
+
+    def batch_witness_cols(self, d_ssp, witness_bits_list, deltas, col0, ncols, out=None):
+        """coefficients [col0, col0 + ncols) of w of every statement: int32 tensor [len][ncols]"""
+        nb = len(witness_bits_list)
+        out = self.torch.empty((nb, ncols), dtype=self.torch.int32, device=self.device) if out is None else out
+        if nb == 0 or ncols == 0:
+            return out
+        bits, stride = self._pack_bits(witness_bits_list)
+        dl = (ctypes.c_uint32 * nb)(*[int(x) for x in deltas])
+        self._chk(self.lib.mfh_batch_witness_cols(self._h, _ptr(d_ssp), nb, bits, stride, ctypes.cast(dl, ctypes.c_void_p), int(col0), int(ncols), _ptr(out), int(ncols)))
+        return out
+
+    def batch_chain_from_w(self, d_ssp, whv):
+        """whv: int32 [3][n][d] with the whole w polynomials in whv[0]; fills whv[1] = h and whv[2] = v"""
+        n = whv.shape[1]
+        if n:
+            self._chk(self.lib.mfh_batch_chain_from_w(self._h, _ptr(d_ssp), n, _ptr(whv[0]), _ptr(whv[1]), _ptr(whv[2])))
+        return whv
 
     def prove_batch_partial(self, d_crs, rank, world, witness_bits_list, d_w, d_h, d_v, coef_stride, out=None):
         """rank's row shares of the five ciphertexts of every statement: len x 5 partial ciphertexts (no delta ct_t term, un-smudged)"""

@@ -167,6 +167,8 @@ inline int ssp_src(mfh_ctx *c, const uint32_t *d_ssp, mf::SspSrc &src) {
 void mfh_poly_destroy(mfh_ctx *c);
 extern "C" int mfh_witness_poly_mm(mfh_ctx *c, const uint32_t *d_ssp, uint32_t nstmt, const uint8_t *h_bits, size_t bits_stride, const uint32_t *h_delta,
                                    uint32_t *d_w);
+extern "C" int mfh_witness_poly_mm_cols(mfh_ctx *c, const uint32_t *d_ssp, uint32_t nstmt, const uint8_t *h_bits, size_t bits_stride, const uint32_t *h_delta,
+                                        uint32_t col0, uint32_t ncols, uint32_t *d_w, size_t w_stride);
 extern "C" int mfh_poly_h_multi(mfh_ctx *c, const uint32_t *d_v, uint32_t *d_h, uint32_t nb);
 int aux_reserve(mfh_ctx *c, size_t bytes);
 // expandmm.hip: one region of the matrix-core CRS image (rows at stream offset off, their compressed ciphertexts c8), barrier-free writer

@@ -800,15 +800,23 @@ __global__ void k_ssp_frag(const uint32_t *__restrict__ ssp, uint32_t nrowsel, u
     frag[(((tile * 4 + w) * 64 + lane) << 2) + eg] = lo | hi;
   }
 }
+// The witness kernels work on a RANGE of coefficients [col0, col0 + d) of the polynomials (the whole polynomial: col0 = 0, d = the SSP's
+// d; a rank of the row-sharded batch prover computes its slice of every statement's w: mfh_witness_poly_mm_cols): `d` below is the width
+// of the range (and of the partial arrays), WCols carries where it starts.
+struct WCols {
+  uint32_t kt0;      // col0 / 32: first 32-coefficient tile
+  uint32_t KT;       // 32-coefficient tiles of the whole SSP (the fragment image's tile stride)
+  uint64_t wstride;  // coefficients between consecutive statements of the output
+};
 // grid = (d / 128, row chunks); block = 4 waves, one 32-coefficient tile each; MT = 1, 2 or 4 tiles of 32 statements (the SSP is read
 // once per 32 MT statements).  part[((chunk * 4 + w) * 32 MT + stmt) * d + k].
 template <int MT>
 __global__ __launch_bounds__(256) void k_witness_mm(const v4i *__restrict__ sspfrag, const v4i *__restrict__ bitfrag, uint32_t nrowsel /* m - 1 */,
-                                                    uint32_t ksteps_per_chunk, uint32_t d, int *__restrict__ part) {
+                                                    uint32_t ksteps_per_chunk, uint32_t d, int *__restrict__ part, WCols wc) {
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t r32 = lane & 31, h = lane >> 5;
-  const uint32_t kt = blockIdx.x * 4 + wave, KT = d / 32;
-  const uint32_t k = kt * 32 + r32;
+  const uint32_t ktl = blockIdx.x * 4 + wave, kt = wc.kt0 + ktl, KT = wc.KT;
+  const uint32_t k = ktl * 32 + r32;  // (within the range)
   const uint32_t K0 = blockIdx.y * ksteps_per_chunk, K1 = min((nrowsel + 31) / 32, K0 + ksteps_per_chunk);
   v16i acc[MT][4];
 #pragma unroll
@@ -863,14 +871,56 @@ __global__ __launch_bounds__(256) void k_witness_mm(const v4i *__restrict__ sspf
 // part == nullptr (one row chunk, m < 2^16): the chunk partials never leave the workgroup -- the two waves of a pair exchange their
 // half sums (planes 0-1 / planes 2-3, 32 bits each) through the ring's LDS and write w_b[k] = delta_b t[k] + the byte sum mod p directly
 // (what k_witness_mm_finish does from the partials: 0.5 GB written and read back per 248 statements otherwise).
-__global__ __launch_bounds__(256) void k_witness_mm8(const v4i *__restrict__ sspfrag, const v4i *__restrict__ bitfrag, uint32_t nrowsel /* m - 1 */,
-                                                     uint32_t ksteps_per_chunk, uint32_t d, int *__restrict__ part, const uint32_t *__restrict__ tpoly,
-                                                     const uint32_t *__restrict__ cnt_delta, uint32_t nstmt, uint32_t *__restrict__ w_out) {
-  constexpr int MT = 8, RING = 4, PF = 4;
+// PRG (a generator-defined SSP, src = the row keys of k_prg_rowkeys): the B fragments are generated in the kernel as in k_witness_mm_prg,
+// and the pair SHARES the generation -- a lane of wave A hashes rows 0..7 of its 16, the same lane of wave B rows 8..15, each keeps the
+// two byte planes it multiplies and hands the other two to its partner through LDS (16 bytes per lane and step each way, double
+// buffered, behind the step's barrier): 8 hashes per lane and step serve 256 statements, against 16 per 128 in k_witness_mm_prg<4>.
+template <bool PRG>
+__global__ __launch_bounds__(256) void k_witness_mm8(const void *__restrict__ src, const v4i *__restrict__ bitfrag, uint32_t nrowsel /* m - 1 */,
+                                                     uint32_t ksteps_per_chunk, uint32_t d, int *__restrict__ part, const uint32_t *__restrict__ tpoly /* + col0 */,
+                                                     const uint32_t *__restrict__ cnt_delta, uint32_t nstmt, uint32_t *__restrict__ w_out, WCols wc) {
+  constexpr int MT = 8, RING = 4, PF = PRG ? 1 : 4;
   __shared__ v4i bits[RING][MT][64];
+  __shared__ uint4 xch[PRG ? 3 : 1][PRG ? 4 : 1][PRG ? 64 : 1];  // PRG: [step % 3][writing wave][lane]
+  const v4i *__restrict__ sspfrag = static_cast<const v4i *>(src);
+  const uint32_t *__restrict__ rowkeys = static_cast<const uint32_t *>(src);
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t r32 = lane & 31, h = lane >> 5;
-  const uint32_t kt = blockIdx.x * 2 + (wave >> 1), KT = d / 32, w0 = 2 * (wave & 1);
+  const uint32_t ktl = blockIdx.x * 2 + (wave >> 1), kt = wc.kt0 + ktl, KT = wc.KT, w0 = 2 * (wave & 1);
+  const uint32_t kc = kt * 32 + r32 + 0x632BE5ABu;
+  // the 8 rows this lane hashes of step K: their two dwords per byte plane; own = planes w0, w0 + 1, give = the partner's two planes
+  auto rk_load = [&](uint32_t K, uint4 (&rk)[2]) {  // the row keys of the 8 rows this lane hashes of step K (w0 = 2 * (wave & 1): rows 8 (wave & 1) ..)
+    const uint4 *rk4 = reinterpret_cast<const uint4 *>(rowkeys + 32 * (uint64_t)K + 16 * h + 4 * w0);
+    rk[0] = rk4[0];
+    rk[1] = rk4[1];
+  };
+  auto hash1 = [&](uint32_t rowkey) -> uint32_t {  // mf::ssp_prg_raw(rowkey, k)
+    uint32_t y = kc * rowkey;
+    y ^= y >> 16;
+    y *= 0x7FEB352Du;
+    y ^= y >> 15;
+    y *= 0x846CA68Bu;
+    y ^= y >> 16;
+    return y;
+  };
+  auto pack = [&](const uint32_t (&x)[8], uint32_t (&own)[4], uint4 &give) {
+    uint32_t dw[4][2];
+#pragma unroll
+    for (int w = 0; w < 4; w++)
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const uint32_t lo = __builtin_amdgcn_perm(x[4 * j + 1], x[4 * j], 0x0c0c0400u + 0x00000101u * w);      // {x0.bw, x1.bw, 0, 0}
+        const uint32_t hi = __builtin_amdgcn_perm(x[4 * j + 3], x[4 * j + 2], 0x04000c0cu + 0x01010000u * w);  // {0, 0, x2.bw, x3.bw}
+        dw[w][j] = (lo | hi) ^ 0x80808080u;
+      }
+    if (w0) {  // (wave-uniform)
+      own[0] = dw[2][0]; own[1] = dw[2][1]; own[2] = dw[3][0]; own[3] = dw[3][1];
+      give = uint4{dw[0][0], dw[0][1], dw[1][0], dw[1][1]};
+    } else {
+      own[0] = dw[0][0]; own[1] = dw[0][1]; own[2] = dw[1][0]; own[3] = dw[1][1];
+      give = uint4{dw[2][0], dw[2][1], dw[3][0], dw[3][1]};
+    }
+  };
   const uint32_t K0 = blockIdx.y * ksteps_per_chunk, K1 = min((nrowsel + 31) / 32, K0 + ksteps_per_chunk);
   v16i acc[MT][2];
 #pragma unroll
@@ -900,24 +950,82 @@ __global__ __launch_bounds__(256) void k_witness_mm8(const v4i *__restrict__ ssp
   };
   v4i sta[2], stb[2];  // the bit fragments of steps K + 1 / K + 2 on their way to the ring
   v4i bq[PF][2];
+  uint32_t own[4];     // PRG: this wave's planes of the 8 rows it hashed of the step about to be multiplied
   bits_load(K0, sta);
   bits_store(K0, sta);
   bits_load(K0 + 1, sta);
   bits_load(K0 + 2, stb);
+  uint4 rkr[4][2];     // PRG: the row keys of steps K + 2 .. K + 5 (a load consumed in the step it is issued in costs its whole latency)
+  if constexpr (PRG) {
+    // the pipeline runs two steps ahead: step K multiplies fragments assembled during step K - 1 from hashes made during step K - 2
+    uint4 give;
+    uint32_t own0[4];
+    rk_load(K0, rkr[0]);
+    rk_load(min(K0 + 1, K1 - 1), rkr[1]);
+    {
+      const uint32_t r0[8] = {rkr[0][0].x, rkr[0][0].y, rkr[0][0].z, rkr[0][0].w, rkr[0][1].x, rkr[0][1].y, rkr[0][1].z, rkr[0][1].w};
+      const uint32_t r1[8] = {rkr[1][0].x, rkr[1][0].y, rkr[1][0].z, rkr[1][0].w, rkr[1][1].x, rkr[1][1].y, rkr[1][1].z, rkr[1][1].w};
+      uint32_t x0[8], x1[8];
 #pragma unroll
-  for (int i = 0; i < PF; i++) ssp_load(K0 + i, bq[i]);
+      for (int e = 0; e < 8; e++) { x0[e] = hash1(r0[e]); x1[e] = hash1(r1[e]); }
+      pack(x0, own0, give);
+      xch[K0 % 3][wave][lane] = give;
+      pack(x1, own, give);
+      xch[(K0 + 1) % 3][wave][lane] = give;
+    }
+#pragma unroll
+    for (int i = 2; i <= 5; i++) rk_load(min(K0 + i, K1 - 1), rkr[i & 3]);
+    __syncthreads();
+    const uint4 recv = xch[K0 % 3][wave ^ 1][lane];
+    if (w0) {
+      bq[0][0] = v4i{(int)recv.x, (int)recv.y, (int)own0[0], (int)own0[1]};
+      bq[0][1] = v4i{(int)recv.z, (int)recv.w, (int)own0[2], (int)own0[3]};
+    } else {
+      bq[0][0] = v4i{(int)own0[0], (int)own0[1], (int)recv.x, (int)recv.y};
+      bq[0][1] = v4i{(int)own0[2], (int)own0[3], (int)recv.z, (int)recv.w};
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < PF; i++) ssp_load(K0 + i, bq[i]);
+  }
   __syncthreads();
   uint32_t K = K0;
   auto step = [&](int slot, v4i (&st)[2]) {  // st: the bit fragments of step K + 1 (loaded two steps ago); refilled with those of step K + 3
+    uint32_t own_next[4];
+    uint4 recv;
+    uint32_t hx[8], hr[8];
+    if constexpr (PRG) {
+      recv = xch[(K + 1) % 3][wave ^ 1][lane];  // the partner's half of step K + 1 (written a step ago, before the barrier)
+      const uint4 (&rk)[2] = rkr[(slot + 2) & 3];  // step K + 2 (clamped to the chunk's last step)
+      hr[0] = rk[0].x; hr[1] = rk[0].y; hr[2] = rk[0].z; hr[3] = rk[0].w; hr[4] = rk[1].x; hr[5] = rk[1].y; hr[6] = rk[1].z; hr[7] = rk[1].w;
+    }
     bits_store(K + 1, st);
     const v4i *aq = &bits[K % RING][0][lane];
 #pragma unroll
     for (int t = 0; t < MT; t++) {
       const v4i a = aq[t * 64];
 #pragma unroll
-      for (int w = 0; w < 2; w++) acc[t][w] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[slot][w], acc[t][w], 0, 0, 0);
+      for (int w = 0; w < 2; w++) acc[t][w] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[PRG ? 0 : slot][w], acc[t][w], 0, 0, 0);
+      if constexpr (PRG) hx[t] = hash1(hr[t]);  // (one hash of the next-but-one step between the MFMA pairs: one wave per SIMD, nothing else overlaps the matrix pipe)
     }
-    ssp_load(K + PF, bq[slot]);
+    if constexpr (PRG) {
+      uint4 give;
+      pack(hx, own_next, give);
+      xch[(K + 2) % 3][wave][lane] = give;  // (slot last read during step K - 2, two barriers ago)
+      rk_load(min(K + 6, K1 - 1), rkr[(slot + 2) & 3]);
+    }
+    if constexpr (PRG) {  // step K + 1's fragments: own rows (hashed during step K - 1) + the partner's
+      if (w0) {  // wave B hashed rows 8..15
+        bq[0][0] = v4i{(int)recv.x, (int)recv.y, (int)own[0], (int)own[1]};
+        bq[0][1] = v4i{(int)recv.z, (int)recv.w, (int)own[2], (int)own[3]};
+      } else {
+        bq[0][0] = v4i{(int)own[0], (int)own[1], (int)recv.x, (int)recv.y};
+        bq[0][1] = v4i{(int)own[2], (int)own[3], (int)recv.z, (int)recv.w};
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++) own[i] = own_next[i];
+    } else
+      ssp_load(K + PF, bq[slot]);
     bits_load(K + 3, st);
     __syncthreads();  // slot (K + 1) % RING is complete for the next step; slot K % RING may be rewritten from the step after next on
     K++;
@@ -936,7 +1044,8 @@ __global__ __launch_bounds__(256) void k_witness_mm8(const v4i *__restrict__ ssp
   if (!part) {
     // wave A (planes 0, 1) finishes statement tiles 0..3, wave B (planes 2, 3) tiles 4..7: four rounds, one tile each way per round
     uint32_t *xch = reinterpret_cast<uint32_t *>(&bits[0][0][0]) + (wave >> 1) * 2048;  // [2 directions][16][64] per pair
-    const uint32_t isB = wave & 1, k = kt * 32 + r32;
+    const uint32_t isB = wave & 1, k = ktl * 32 + r32;
+    const uint64_t ws = wc.wstride;
     asm volatile("" : "+s"(cnt_delta), "+s"(tpoly));  // (as above: no loads of the epilogue ahead of the loop)
     const uint64_t tk = tpoly[k];
     const uint64_t P = MFH_P;
@@ -967,7 +1076,7 @@ __global__ __launch_bounds__(256) void k_witness_mm8(const v4i *__restrict__ ssp
             const uint32_t corr = 128u * cnt_delta[2 * b], delta = cnt_delta[2 * b + 1];
             const uint64_t hi = ((uint32_t)acc[4 + r][0][e] + corr) + (((uint32_t)acc[4 + r][1][e] + corr) << 8);
             const uint64_t val = (uint64_t)xch[e * 64 + lane] + (hi << 16);
-            w_out[(uint64_t)b * dd + k] = (uint32_t)((val % P + tk * delta % P) % P);
+            w_out[(uint64_t)b * ws + k] = (uint32_t)((val % P + tk * delta % P) % P);
           }
         }
       } else {
@@ -978,7 +1087,7 @@ __global__ __launch_bounds__(256) void k_witness_mm8(const v4i *__restrict__ ssp
             const uint32_t corr = 128u * cnt_delta[2 * b], delta = cnt_delta[2 * b + 1];
             const uint64_t lo = ((uint32_t)acc[r][0][e] + corr) + (((uint32_t)acc[r][1][e] + corr) << 8);
             const uint64_t val = lo + ((uint64_t)xch[1024 + e * 64 + lane] << 16);
-            w_out[(uint64_t)b * dd + k] = (uint32_t)((val % P + tk * delta % P) % P);
+            w_out[(uint64_t)b * ws + k] = (uint32_t)((val % P + tk * delta % P) % P);
           }
         }
       }
@@ -986,7 +1095,7 @@ __global__ __launch_bounds__(256) void k_witness_mm8(const v4i *__restrict__ ssp
     }
     return;
   }
-  int *dst = part + ((uint64_t)blockIdx.y * 4 + w0) * (32 * MT) * dd + kt * 32 + r32 + (uint64_t)(4 * h) * dd;
+  int *dst = part + ((uint64_t)blockIdx.y * 4 + w0) * (32 * MT) * dd + ktl * 32 + r32 + (uint64_t)(4 * h) * dd;
 #pragma unroll
   for (int w = 0; w < 2; w++)
 #pragma unroll
@@ -1008,11 +1117,11 @@ __global__ void k_prg_rowkeys(uint64_t seed, uint32_t nrows_pad, uint32_t *__res
 }
 template <int MT>
 __global__ __launch_bounds__(256) void k_witness_mm_prg(const uint32_t *__restrict__ rowkeys, const v4i *__restrict__ bitfrag, uint32_t nrowsel /* m - 1 */,
-                                                        uint32_t ksteps_per_chunk, uint32_t d, int *__restrict__ part) {
+                                                        uint32_t ksteps_per_chunk, uint32_t d, int *__restrict__ part, WCols wc) {
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t r32 = lane & 31, h = lane >> 5;
   const uint32_t kt = blockIdx.x * 4 + wave;
-  const uint32_t k = kt * 32 + r32;
+  const uint32_t k = kt * 32 + r32;  // (within the range)
   const uint32_t K0 = blockIdx.y * ksteps_per_chunk, K1 = min((nrowsel + 31) / 32, K0 + ksteps_per_chunk);
   v16i acc[MT][4];
 #pragma unroll
@@ -1022,18 +1131,33 @@ __global__ __launch_bounds__(256) void k_witness_mm_prg(const uint32_t *__restri
 #pragma unroll
       for (int e = 0; e < 16; e++) acc[t][w][e] = 0;
   if (K0 >= K1) return;  // (uniform)
-  const uint32_t kc = k + 0x632BE5ABu;
-  for (uint32_t K = K0; K < K1; K++) {
+  const uint32_t kc = wc.kt0 * 32 + k + 0x632BE5ABu;
+  // the bit fragments and the row keys of a step are loaded two steps ahead (consumed in the step that issues them, the loads cost their
+  // whole latency every step: 0.85 us per step against 0.35 of arithmetic); loads past the chunk re-read its last step
+  constexpr int PF = 2;
+  v4i aqr[PF][MT];
+  uint4 rkr[PF][4];
+  auto fetch = [&](uint32_t K, int slot) {
+    K = min(K, K1 - 1);
+#pragma unroll
+    for (int t = 0; t < MT; t++) aqr[slot][t] = bitfrag[((uint64_t)K * MT + t) * 64 + lane];
+    const uint4 *rk4 = reinterpret_cast<const uint4 *>(rowkeys + 32 * (uint64_t)K + 16 * h);
+#pragma unroll
+    for (int q = 0; q < 4; q++) rkr[slot][q] = rk4[q];
+  };
+  fetch(K0, 0);
+  fetch(K0 + 1, 1);
+  auto step = [&](uint32_t K, int slot) {
     v4i aq[MT];
 #pragma unroll
-    for (int t = 0; t < MT; t++) aq[t] = bitfrag[((uint64_t)K * MT + t) * 64 + lane];
-    const uint4 *rk4 = reinterpret_cast<const uint4 *>(rowkeys + 32 * K + 16 * h);
+    for (int t = 0; t < MT; t++) aq[t] = aqr[slot][t];
     uint32_t x[16];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-      const uint4 r = rk4[q];
+      const uint4 r = rkr[slot][q];
       x[4 * q] = r.x; x[4 * q + 1] = r.y; x[4 * q + 2] = r.z; x[4 * q + 3] = r.w;
     }
+    fetch(K + PF, slot);
 #pragma unroll
     for (int e = 0; e < 16; e++) {  // mf::ssp_prg_raw(rowkey, k)
       uint32_t y = kc * x[e];
@@ -1057,7 +1181,13 @@ __global__ __launch_bounds__(256) void k_witness_mm_prg(const uint32_t *__restri
     for (int t = 0; t < MT; t++)
 #pragma unroll
       for (int w = 0; w < 4; w++) acc[t][w] = __builtin_amdgcn_mfma_i32_32x32x32_i8(aq[t], bq[w], acc[t][w], 0, 0, 0);
+  };
+  uint32_t K = K0;
+  for (; K + 2 <= K1; K += 2) {
+    step(K, 0);
+    step(K + 1, 1);
   }
+  if (K < K1) step(K, 0);
 #pragma unroll
   for (int t = 0; t < MT; t++)
 #pragma unroll
@@ -1082,7 +1212,7 @@ __global__ void k_witness_bits(const uint8_t *__restrict__ bits, size_t bits_str
 }
 // w_b[k] = delta_b t[k] + sum_i bit_b[i] v_i[k] mod p from the chunk partials: sum_w 256^w (G'_w + 128 cnt_b)
 __global__ void k_witness_mm_finish(const int *__restrict__ part, uint32_t nchunks, const uint32_t *__restrict__ t, const uint32_t *__restrict__ cnt_delta,
-                                    uint32_t nstmt, uint32_t mrows /* 32 MT */, uint32_t d, uint32_t *__restrict__ w_out) {
+                                    uint32_t nstmt, uint32_t mrows /* 32 MT */, uint32_t d, uint32_t *__restrict__ w_out, uint64_t wstride) {
   const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
   if (k >= d || b >= nstmt) return;
   const uint64_t corr = 128ull * cnt_delta[2 * b];
@@ -1095,7 +1225,7 @@ __global__ void k_witness_mm_finish(const int *__restrict__ part, uint32_t nchun
     val += (uint64_t)(g + (int64_t)corr) << (8 * w);  // the true byte sum: >= 0
   }
   const uint64_t P = MFH_P;
-  w_out[(uint64_t)b * d + k] = (uint32_t)((val % P + (uint64_t)t[k] * delta % P) % P);
+  w_out[(uint64_t)b * wstride + k] = (uint32_t)((val % P + (uint64_t)t[k] * delta % P) % P);
 }
 
 }  // namespace
@@ -1436,11 +1566,11 @@ int mfh_crs_set_resident_mm_share(mfh_ctx *c, const uint8_t *d_image, uint32_t r
 }
 int mfh_crs_set_resident_mm(mfh_ctx *c, const uint8_t *d_image) { return mfh_crs_set_resident_mm_share(c, d_image, 0, 1); }
 
-// mfh_witness_poly for up to 128 statements in ONE read of the (dense) SSP, on the matrix cores: d_w = nstmt polynomials of d coefficients
-int mfh_witness_poly_mm(mfh_ctx *c, const uint32_t *d_ssp, uint32_t nstmt, const uint8_t *h_bits, size_t bits_stride, const uint32_t *h_delta,
-                        uint32_t *d_w) {
+// mfh_witness_poly for up to 256 statements in ONE read (dense SSP) or one generation (generator-defined SSP) of the selected rows, on the
+// matrix cores, restricted to the coefficients [col0, col0 + ncols): d_w[b * w_stride + (k - col0)]
+int mfh_witness_poly_mm_cols(mfh_ctx *c, const uint32_t *d_ssp, uint32_t nstmt, const uint8_t *h_bits, size_t bits_stride, const uint32_t *h_delta,
+                             uint32_t col0, uint32_t ncols, uint32_t *d_w, size_t w_stride) {
   if (!c || !h_bits || !h_delta || !d_w || nstmt == 0 || nstmt > 256) return MFH_EINVAL;
-  if (nstmt > 128 && !d_ssp) { c->err = "mfh_witness_poly_mm: more than 128 statements per pass need the dense SSP"; return MFH_EINVAL; }
   mf::SspSrc src;  // d_ssp == NULL: the registered generator-defined SSP (B fragments generated in the kernel)
   {
     int rc0 = ssp_src(c, d_ssp, src);
@@ -1449,13 +1579,19 @@ int mfh_witness_poly_mm(mfh_ctx *c, const uint32_t *d_ssp, uint32_t nstmt, const
   const uint32_t MT = nstmt > 128 ? 8 : nstmt > 64 ? 4 : nstmt > 32 ? 2 : 1;
   const uint32_t d = c->P.d, m = c->P.m;
   if (d % 128 || m < 2) { c->err = "mfh_witness_poly_mm: d must be a multiple of 128"; return MFH_EUNSUPPORTED; }
+  if ((uint64_t)col0 + ncols > d || w_stride < ncols) return MFH_EINVAL;
+  if (ncols == 0) return MFH_OK;
+  if (col0 % 128 || ncols % 128) { c->err = "mfh_witness_poly_mm_cols: the coefficient range must start and end at multiples of 128"; return MFH_EUNSUPPORTED; }
+  const uint32_t nc = ncols;
+  const WCols wc = {col0 / 32, d / 32, (uint64_t)w_stride};
+  const uint32_t *tpoly = src.t + col0;
   for (uint32_t b = 0; b < nstmt; b++)
     if (h_delta[b] >= MFH_P) { c->err = "delta must be < p"; return MFH_EINVAL; }
   HIP_TRY(c, hipSetDevice(c->device));
   const uint32_t nrowsel = m - 1, ksteps = (nrowsel + 31) / 32;
   // (the 256-statement pass has d / 64 workgroups of one wave per SIMD: one row chunk fills the chip at d >= 2^14, and with one chunk --
   // and byte sums that fit 32 bits per plane pair -- it finishes in the kernel)
-  const bool fused = MT == 8 && m < 65536 && (d >= 16384 || ksteps <= 64);  // (small instances: nothing to fill either way)
+  const bool fused = MT == 8 && m < 65536 && (nc >= 16384 || ksteps <= 64);  // (small instances: nothing to fill either way)
   const uint32_t nchunks = fused ? 1u : std::min(ksteps, 4u), kpc = (ksteps + nchunks - 1) / nchunks;
   // the SSP in B-fragment order: built on first use per SSP (mfh_ssp_prepare invalidates it), kept beside the uint32 image
   const size_t sfrag_b = (size_t)ksteps * 32 * d * 4;
@@ -1471,7 +1607,7 @@ int mfh_witness_poly_mm(mfh_ctx *c, const uint32_t *d_ssp, uint32_t nstmt, const
     c->ssp_frag_src = d_ssp;
   }
   const size_t packed = (size_t)nstmt * bits_stride, head_b = ((packed + 8 + 256 * 8 + 255) & ~(size_t)255);
-  const size_t frag_b = (size_t)ksteps * MT * 1024, part_b = (size_t)nchunks * 4 * 32 * MT * d * 4;
+  const size_t frag_b = (size_t)ksteps * MT * 1024, part_b = (size_t)nchunks * 4 * 32 * MT * nc * 4;
   const size_t rk_b = src.dense ? 0 : (((size_t)ksteps * 32 * 4 + 255) & ~(size_t)255);
   int rc = wws_reserve(c, head_b + frag_b + part_b + rk_b);
   if (rc) return rc;
@@ -1497,31 +1633,44 @@ int mfh_witness_poly_mm(mfh_ctx *c, const uint32_t *d_ssp, uint32_t nstmt, const
   hipLaunchKernelGGL(k_witness_bits, dim3((uint32_t)((frag_b + 255) / 256)), dim3(256), 0, c->stream, dev, bits_stride, nstmt, nrowsel, ksteps, MT, d_frag);
   if (!src.dense) {
     uint32_t *d_rk = (uint32_t *)(dev + head_b + frag_b + part_b);
-    const dim3 grid(d / 128, (ksteps + kpc - 1) / kpc);
+    const dim3 grid(nc / 128, (ksteps + kpc - 1) / kpc);
     hipLaunchKernelGGL(k_prg_rowkeys, dim3((ksteps * 32 + 255) / 256), dim3(256), 0, c->stream, src.seed, ksteps * 32, d_rk);
-    if (MT == 1) hipLaunchKernelGGL(k_witness_mm_prg<1>, grid, dim3(256), 0, c->stream, d_rk, (const v4i *)d_frag, nrowsel, kpc, d, d_part);
-    else if (MT == 2) hipLaunchKernelGGL(k_witness_mm_prg<2>, grid, dim3(256), 0, c->stream, d_rk, (const v4i *)d_frag, nrowsel, kpc, d, d_part);
-    else hipLaunchKernelGGL(k_witness_mm_prg<4>, grid, dim3(256), 0, c->stream, d_rk, (const v4i *)d_frag, nrowsel, kpc, d, d_part);
+    if (MT == 8) {
+      hipLaunchKernelGGL(k_witness_mm8<true>, dim3(nc / 64, (ksteps + kpc - 1) / kpc), dim3(256), 0, c->stream, (const void *)d_rk, (const v4i *)d_frag, nrowsel, kpc, nc,
+                         fused ? (int *)nullptr : d_part, tpoly, d_cd, nstmt, d_w, wc);
+      if (fused) {
+        HIP_TRY(c, hipGetLastError());
+        return MFH_OK;
+      }
+    } else if (MT == 1) hipLaunchKernelGGL(k_witness_mm_prg<1>, grid, dim3(256), 0, c->stream, d_rk, (const v4i *)d_frag, nrowsel, kpc, nc, d_part, wc);
+    else if (MT == 2) hipLaunchKernelGGL(k_witness_mm_prg<2>, grid, dim3(256), 0, c->stream, d_rk, (const v4i *)d_frag, nrowsel, kpc, nc, d_part, wc);
+    else hipLaunchKernelGGL(k_witness_mm_prg<4>, grid, dim3(256), 0, c->stream, d_rk, (const v4i *)d_frag, nrowsel, kpc, nc, d_part, wc);
   } else if (MT == 8) {
-    hipLaunchKernelGGL(k_witness_mm8, dim3(d / 64, (ksteps + kpc - 1) / kpc), dim3(256), 0, c->stream, (const v4i *)c->ssp_frag, (const v4i *)d_frag, nrowsel, kpc, d,
-                       fused ? (int *)nullptr : d_part, src.t, d_cd, nstmt, d_w);
+    hipLaunchKernelGGL(k_witness_mm8<false>, dim3(nc / 64, (ksteps + kpc - 1) / kpc), dim3(256), 0, c->stream, (const void *)c->ssp_frag, (const v4i *)d_frag, nrowsel, kpc, nc,
+                       fused ? (int *)nullptr : d_part, tpoly, d_cd, nstmt, d_w, wc);
     if (fused) {
       HIP_TRY(c, hipGetLastError());
       return MFH_OK;
     }
   } else if (MT == 1)
-    hipLaunchKernelGGL(k_witness_mm<1>, dim3(d / 128, (ksteps + kpc - 1) / kpc), dim3(256), 0, c->stream, (const v4i *)c->ssp_frag, (const v4i *)d_frag,
-                       nrowsel, kpc, d, d_part);
+    hipLaunchKernelGGL(k_witness_mm<1>, dim3(nc / 128, (ksteps + kpc - 1) / kpc), dim3(256), 0, c->stream, (const v4i *)c->ssp_frag, (const v4i *)d_frag,
+                       nrowsel, kpc, nc, d_part, wc);
   else if (MT == 2)
-    hipLaunchKernelGGL(k_witness_mm<2>, dim3(d / 128, (ksteps + kpc - 1) / kpc), dim3(256), 0, c->stream, (const v4i *)c->ssp_frag, (const v4i *)d_frag,
-                       nrowsel, kpc, d, d_part);
+    hipLaunchKernelGGL(k_witness_mm<2>, dim3(nc / 128, (ksteps + kpc - 1) / kpc), dim3(256), 0, c->stream, (const v4i *)c->ssp_frag, (const v4i *)d_frag,
+                       nrowsel, kpc, nc, d_part, wc);
   else
-    hipLaunchKernelGGL(k_witness_mm<4>, dim3(d / 128, (ksteps + kpc - 1) / kpc), dim3(256), 0, c->stream, (const v4i *)c->ssp_frag, (const v4i *)d_frag,
-                       nrowsel, kpc, d, d_part);
-  hipLaunchKernelGGL(k_witness_mm_finish, dim3((d + 255) / 256, nstmt), dim3(256), 0, c->stream, d_part, (ksteps + kpc - 1) / kpc, src.t, d_cd, nstmt, 32 * MT,
-                     d, d_w);
+    hipLaunchKernelGGL(k_witness_mm<4>, dim3(nc / 128, (ksteps + kpc - 1) / kpc), dim3(256), 0, c->stream, (const v4i *)c->ssp_frag, (const v4i *)d_frag,
+                       nrowsel, kpc, nc, d_part, wc);
+  hipLaunchKernelGGL(k_witness_mm_finish, dim3((nc + 255) / 256, nstmt), dim3(256), 0, c->stream, d_part, (ksteps + kpc - 1) / kpc, tpoly, d_cd, nstmt, 32 * MT,
+                     nc, d_w, (uint64_t)w_stride);
   HIP_TRY(c, hipGetLastError());
   return MFH_OK;
+}
+
+int mfh_witness_poly_mm(mfh_ctx *c, const uint32_t *d_ssp, uint32_t nstmt, const uint8_t *h_bits, size_t bits_stride, const uint32_t *h_delta,
+                        uint32_t *d_w) {
+  if (!c) return MFH_EINVAL;
+  return mfh_witness_poly_mm_cols(c, d_ssp, nstmt, h_bits, bits_stride, h_delta, 0, c->P.d, d_w, c->P.d);
 }
 
 }  // extern "C"

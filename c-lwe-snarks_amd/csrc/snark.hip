@@ -589,9 +589,9 @@ int batch_chain_launch(mfh_ctx *c, const mf::SspSrc &src, const uint32_t *d_ssp,
   // d % 128 == 0: a GEMM on the matrix cores, one read (dense SSP) or one generation (generator-defined SSP) of the selected rows per
   // 124 statements; otherwise the VALU form, read or generated once per 12 statements
   if (d % 128 == 0) {
-    // dense SSP: the whole super-group (248 statements) in one read (k_witness_mm8); generator-defined: 124 statements per generation
+    // the whole super-group (248 statements) in one read (dense SSP) or one generation (generator-defined SSP) of the rows: k_witness_mm8
     static const uint32_t per_env = [] { const char *e = getenv("MFH_WITNESS_PER"); return e ? (uint32_t)atoi(e) : 0u; }();  // (A/B knob)
-    const uint32_t per = per_env ? std::min(per_env, src.dense ? 256u : 128u) : (src.dense ? 248u : 124u);
+    const uint32_t per = per_env ? std::min(per_env, 256u) : 248u;
     for (uint32_t b0 = 0; b0 < sg; b0 += per) {
       rc = mfh_witness_poly_mm(c, d_ssp, std::min(per, sg - b0), h_bits + (size_t)b0 * bits_stride, bits_stride, h_delta + b0, W + (size_t)b0 * d);
       if (rc) return rc;
@@ -996,6 +996,43 @@ int mfh_batch_chain(mfh_ctx *c, const uint32_t *d_ssp, uint32_t nstmt, const uin
     const size_t o = (size_t)s0 * d;
     rc = batch_chain_launch(c, src, d_ssp, std::min(BSG, nstmt - s0), h_witness_bits + (size_t)s0 * bits_stride, bits_stride, h_delta + s0, d_w + o, d_h + o,
                             d_v + o);
+    if (rc) return rc;
+  }
+  return MFH_OK;
+}
+
+// The chain cut in two for the row-sharded prover of a generator-defined (or very large) SSP, where the witness pass IS the chain's cost
+// and shards by COEFFICIENT RANGE without any reduction: every rank computes the coefficients [col0, col0 + ncols) of w of ALL statements
+// (1 / world of the rows' generation or read), the slices are exchanged (all-to-all), and the owner of a statement finishes its chain.
+int mfh_batch_witness_cols(mfh_ctx *c, const uint32_t *d_ssp, uint32_t nstmt, const uint8_t *h_witness_bits, size_t bits_stride, const uint32_t *h_delta,
+                           uint32_t col0, uint32_t ncols, uint32_t *d_w, size_t w_stride) {
+  if (!c) return MFH_EINVAL;
+  if (!nstmt || !ncols) return MFH_OK;
+  if (!h_witness_bits || !h_delta || !d_w) return MFH_EINVAL;
+  if (bits_stride < (c->P.m + 6) / 8) { c->err = "bits_stride shorter than the m - 1 witness bits"; return MFH_EINVAL; }
+  for (uint32_t s0 = 0; s0 < nstmt; s0 += BSG) {
+    int rc = mfh_witness_poly_mm_cols(c, d_ssp, std::min(BSG, nstmt - s0), h_witness_bits + (size_t)s0 * bits_stride, bits_stride, h_delta + s0, col0, ncols,
+                                      d_w + (size_t)s0 * w_stride, w_stride);
+    if (rc) return rc;
+  }
+  return MFH_OK;
+}
+// d_v = d_w + v_0, d_h = (d_v^2 - 1) / t for nstmt statements whose whole w polynomials are in d_w (src/snark.c:161-169)
+int mfh_batch_chain_from_w(mfh_ctx *c, const uint32_t *d_ssp, uint32_t nstmt, const uint32_t *d_w, uint32_t *d_h, uint32_t *d_v) {
+  if (!c) return MFH_EINVAL;
+  if (!nstmt) return MFH_OK;
+  if (!d_w || !d_h || !d_v) return MFH_EINVAL;
+  mf::SspSrc src;
+  int rc = ssp_src(c, d_ssp, src);
+  if (rc) return rc;
+  const uint32_t d = c->P.d;
+  HIP_TRY(c, hipSetDevice(c->device));
+  for (uint32_t s0 = 0; s0 < nstmt; s0 += BSG) {
+    const uint32_t sg = std::min(BSG, nstmt - s0);
+    const size_t o = (size_t)s0 * d;
+    hipLaunchKernelGGL(k_add_slot_multi, dim3((d + 255) / 256, sg), dim3(256), 0, c->stream, d_w + o, src, 1u, d, d_v + o);
+    HIP_TRY(c, hipGetLastError());
+    rc = mfh_poly_h_multi(c, d_v + o, d_h + o, sg);
     if (rc) return rc;
   }
   return MFH_OK;

@@ -86,7 +86,8 @@ def statement_shares(nb, world):
     return per, [(min(nb, r * per), min(nb, (r + 1) * per)) for r in range(world)]
 
 
-def prove_batch_sharded(ctx, d_crs, d_ssp, witness_bits_list, deltas, smudge_mags, smudge_signs, rank, world, maglen=80, group=None, bufs=None):
+def prove_batch_sharded(ctx, d_crs, d_ssp, witness_bits_list, deltas, smudge_mags, smudge_signs, rank, world, maglen=80, group=None, bufs=None,
+                        witness_by_cols=None):
     """prover() (reference src/snark.c:117-190) for len(witness_bits_list) statements with the CRS ROWS sharded over `world` ranks
     (BASELINE configs 3/4: "ciphertexts sharded across 8 x MI355X + RCCL reduce"; include/mfhip.h, row-sharded batch prover).
 
@@ -94,6 +95,10 @@ def prove_batch_sharded(ctx, d_crs, d_ssp, witness_bits_list, deltas, smudge_mag
       chain (own statements)  ->  all-to-all of the w | h | v row slices (3 x 4 B x d x nb / world sent per rank)
       ->  row shares of all five ciphertexts of all statements on the matrix cores
       ->  ONE reduce-scatter (sum) of uint64 lanes, nb x 5 x (n+1) x 2K lanes of 8 B  ->  carries, modq, delta ct_t, smudging (own statements).
+    witness_by_cols (default: on for a generator-defined SSP, d_ssp = None, where the witness pass is the chain's cost): the chain is cut
+    in two -- every rank computes its COEFFICIENT RANGE [d r / world, d (r+1) / world) of w of ALL statements (1 / world of the
+    generation of the selected rows, no reduction), one more all-to-all (4 B x d x nb / world sent per rank) hands every statement's
+    slices to its owner, who finishes the chain (v = w + v_0, h = (v^2 - 1) / t).  Needs the ranges to start at multiples of 128.
     Returns (first, count, proofs): the rank's own statements [first, first + count) and their finished proofs (count x 5 ciphertexts,
     bit-identical to prove_batch's).  world == 1 proves alone: no collective."""
     import torch
@@ -106,12 +111,28 @@ def prove_batch_sharded(ctx, d_crs, d_ssp, witness_bits_list, deltas, smudge_mag
     per, owned = statement_shares(nb, world)
     first, last = owned[rank]
     count = last - first
-    # 1. the chain of the rank's own statements: w | h | v, [3][count][d]
-    whv = ctx.batch_chain(d_ssp, witness_bits_list[first:last], deltas[first:last])
-    # 2. all-to-all: rank r gets rows [d r / world, d (r+1) / world) of w | h | v of every statement, laid out [statement][w | h | v][rows]
     shares = row_shares(p.d, world)
     lo, hi = shares[rank]
     cs = hi - lo
+    align = getattr(ctx, "witness_cols_align", 128)
+    use_cols = (d_ssp is None) if witness_by_cols is None else bool(witness_by_cols)
+    use_cols = use_cols and all(a % align == 0 and b % align == 0 for a, b in shares)
+    # 1. the chain of the rank's own statements: w | h | v, [3][count][d]
+    if use_cols:
+        # 1a. this rank's coefficient range of w of ALL statements; 1b. all-to-all by statement owner; 1c. the owner finishes the chain
+        wsl = ctx.batch_witness_cols(d_ssp, witness_bits_list, deltas, lo, cs)  # [nb][cs]
+        wrecv = torch.empty(count * p.d, dtype=wsl.dtype, device=wsl.device)
+        all_to_all_rows(wrecv, wsl.reshape(-1), [count * (b - a) for a, b in shares], [(b - a) * cs for a, b in owned], group)
+        whv = torch.empty((3, count, p.d), dtype=wsl.dtype, device=wsl.device)
+        off = 0
+        for a, b in shares:  # the block from rank q: [count][its range]
+            whv[0][:, a:b] = wrecv[off:off + count * (b - a)].view(count, b - a)
+            off += count * (b - a)
+        del wsl, wrecv
+        ctx.batch_chain_from_w(d_ssp, whv)
+    else:
+        whv = ctx.batch_chain(d_ssp, witness_bits_list[first:last], deltas[first:last])
+    # 2. all-to-all: rank r gets rows [d r / world, d (r+1) / world) of w | h | v of every statement, laid out [statement][w | h | v][rows]
     send = torch.cat([whv[:, :, a:b].permute(1, 0, 2).reshape(-1) for a, b in shares]) if count else whv.reshape(-1)
     in_splits = [count * 3 * (b - a) for a, b in shares]
     out_splits = [(b - a) * 3 * cs for a, b in owned]

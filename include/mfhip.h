@@ -242,6 +242,14 @@ int mfh_crs_set_resident_mm_share(mfh_ctx *ctx, const uint8_t *d_image, uint32_t
 /* step 1: d_w, d_h, d_v = nstmt x d coefficients each (statement-major) */
 int mfh_batch_chain(mfh_ctx *ctx, const uint32_t *d_ssp, uint32_t nstmt, const uint8_t *h_witness_bits, size_t bits_stride, const uint32_t *h_delta,
                     uint32_t *d_w, uint32_t *d_h, uint32_t *d_v);
+/* step 1 in two halves, for SSPs whose witness pass dominates the chain (generator-defined: 2^20 constraints): (1a) every rank computes
+ * the coefficients [col0, col0 + ncols) of w of ALL nstmt statements -- 1 / world of the generation (or read) of the selected rows, no
+ * reduction -- into d_w[b * w_stride + (k - col0)] (col0, ncols multiples of 128, else MFH_EUNSUPPORTED: use mfh_batch_chain);
+ * the slices are exchanged (all-to-all by statement owner); (1b) the owner finishes the chain of its statements from their whole w:
+ * d_v = d_w + v_0, d_h = (d_v^2 - 1) / t. */
+int mfh_batch_witness_cols(mfh_ctx *ctx, const uint32_t *d_ssp, uint32_t nstmt, const uint8_t *h_witness_bits, size_t bits_stride, const uint32_t *h_delta,
+                           uint32_t col0, uint32_t ncols, uint32_t *d_w, size_t w_stride);
+int mfh_batch_chain_from_w(mfh_ctx *ctx, const uint32_t *d_ssp, uint32_t nstmt, const uint32_t *d_w, uint32_t *d_h, uint32_t *d_v);
 /* step 3: statement b's coefficients for the rank's S / AS rows [d rank / world, d (rank+1) / world) at d_w / d_h / d_v + b * coef_stride
  * (uint32 words; with the whole polynomials in memory: d_w = W + d rank / world, coef_stride = d).  The witness bits select the rank's
  * share of the BT+BV rows.  d_partial = nstmt x 5 partial ciphertexts (struct proof order).  With more than 31 statements and no image
@@ -270,6 +278,10 @@ int mfh_witness_poly_multi(mfh_ctx *ctx, const uint32_t *d_ssp, uint32_t nstmt, 
  * mfh_ssp_upload / mfh_ssp_prepare.  Used by mfh_prove_batch. */
 int mfh_witness_poly_mm(mfh_ctx *ctx, const uint32_t *d_ssp, uint32_t nstmt, const uint8_t *h_bits, size_t bits_stride, const uint32_t *h_delta,
                         uint32_t *d_w);
+/* The same restricted to the coefficients [col0, col0 + ncols) of the polynomials: d_w[b * w_stride + (k - col0)] (col0 and ncols
+ * multiples of 128, else MFH_EUNSUPPORTED).  The cost is the range's share of the read / generation of the selected rows. */
+int mfh_witness_poly_mm_cols(mfh_ctx *ctx, const uint32_t *d_ssp, uint32_t nstmt, const uint8_t *h_bits, size_t bits_stride, const uint32_t *h_delta,
+                             uint32_t col0, uint32_t ncols, uint32_t *d_w, size_t w_stride);
 /* Optional second exchange that also shards the witness polynomial (the SSP pass, 1.4 GB per proof at the default size):
  * mfh_witness_lanes = this rank's share of sum_{bit} v_i as d uint64 lanes (each < p) -> all-reduce (sum) ->
  * mfh_prove_partial_w takes the summed lanes instead of recomputing w on every rank.  mfh_witness_from_lanes: w = delta t + lanes mod p. */

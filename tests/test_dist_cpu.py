@@ -136,6 +136,20 @@ class _LinearCtx:
                 out[k, b] = 1000 * k + 10 * idb + t.arange(p.d, dtype=t.int32)
         return out
 
+    witness_cols_align = 1  # (the C ABI wants coefficient ranges at multiples of 128; the stand-in takes any)
+
+    def batch_witness_cols(self, d_ssp, bits_list, deltas, col0, ncols):
+        t = self.torch
+        out = t.zeros((len(deltas), ncols), dtype=t.int32)
+        for b, idb in enumerate(deltas):
+            out[b] = 10 * idb + t.arange(col0, col0 + ncols, dtype=t.int32)
+        return out
+
+    def batch_chain_from_w(self, d_ssp, whv):
+        whv[1] = whv[0] + 1000
+        whv[2] = whv[0] + 2000
+        return whv
+
     def prove_batch_partial(self, d_crs, rank, world, bits_list, d_w, d_h, d_v, stride, out=None):
         t, p = self.torch, self.params
         lo, hi = p.d * rank // world, p.d * (rank + 1) // world
@@ -172,7 +186,7 @@ class _LinearCtx:
         return proofs
 
 
-def _batch_worker(rank, world, port, out_dir, nb):
+def _batch_worker(rank, world, port, out_dir, nb, by_cols=False):
     import torch.distributed as dist
 
     from c_lwe_snarks_amd import dist as mfdist
@@ -184,7 +198,7 @@ def _batch_worker(rank, world, port, out_dir, nb):
     p = ctx.params
     ids = [3 + 2 * b for b in range(nb)]
     bits = [bytes([(37 * b + 1) & 0xFF, (11 * b) & 0xFF]) for b in range(nb)]
-    first, count, proofs = mfdist.prove_batch_sharded(ctx, None, None, bits, ids, [b""] * nb, [b""] * nb, rank, world)
+    first, count, proofs = mfdist.prove_batch_sharded(ctx, None, None, bits, ids, [b""] * nb, [b""] * nb, rank, world, witness_by_cols=by_cols)
     per = -(-nb // world)
     ok = first == min(nb, rank * per) and count == min(nb, first + per) - first and ctx.finished == ids[first:first + count]
     got = proofs.view(count, 5, p.n + 1, p.L) if count else None
@@ -202,12 +216,13 @@ def _batch_worker(rank, world, port, out_dir, nb):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,nb", [(2, 5), (2, 4), (3, 2)])
-def test_prove_batch_sharded_sequencing_gloo(tmp_path, world, nb):
-    """uneven statement slabs (5 over 2), even ones, and a rank that owns no statement (2 over 3; d = 13 and m = 9 never divide)"""
+@pytest.mark.parametrize("world,nb,by_cols", [(2, 5, False), (2, 4, False), (3, 2, False), (2, 5, True), (3, 2, True), (3, 7, True)])
+def test_prove_batch_sharded_sequencing_gloo(tmp_path, world, nb, by_cols):
+    """uneven statement slabs (5 over 2), even ones, and a rank that owns no statement (2 over 3; d = 13 and m = 9 never divide);
+    by_cols: the chain cut in two -- coefficient ranges of w of all statements per rank, a first all-to-all to the statement owners"""
     import torch.multiprocessing as mp
 
     port = _free_port()
-    mp.spawn(_batch_worker, args=(world, port, str(tmp_path), nb), nprocs=world, join=True)
+    mp.spawn(_batch_worker, args=(world, port, str(tmp_path), nb, by_cols), nprocs=world, join=True)
     for r in range(world):
         assert open(tmp_path / f"brank{r}.txt").read() == "ok"

@@ -166,15 +166,26 @@ def _rank_main(rank, world, port, out_dir):
     # the single-proof row-sharded path with its two lane all-reduces, same process group
     one = mfdist.prove_sharded(ctx, d_crs, inst["d_ssp"], bits[0], deltas[0], mags[0], signs[0], rank, world)
     ok = ok and bool(torch.equal(one, ctx.prove(d_crs, inst["d_ssp"], bits[0], deltas[0], mags[0], signs[0])))
+    ctx.close()
+    # the chain cut in two (coefficient ranges of w of all statements per rank + a first all-to-all to the statement owners): d = 1024, so
+    # that the ranges start at multiples of 128
+    p2 = mf.Params(d=1024, m=700)
+    ctx2 = mf.Context(p2, 0)
+    ctx2.set_seed(SEED)
+    nb2 = 35
+    inst2, d_crs2, bits2, deltas2, mags2, signs2 = _world(mf, ctx2, p2, 78, nb2)
+    first2, count2, proofs2 = mfdist.prove_batch_sharded(ctx2, d_crs2, inst2["d_ssp"], bits2, deltas2, mags2, signs2, rank, world, witness_by_cols=True)
+    want2 = ctx2.prove_batch(d_crs2, inst2["d_ssp"], bits2, deltas2, mags2, signs2).view(nb2, -1)[first2:first2 + count2].reshape(-1)
+    ok = ok and bool(torch.equal(proofs2, want2)) and count2 > 0
     with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
         f.write("ok" if ok else "MISMATCH")
-    ctx.close()
+    ctx2.close()
     dist.destroy_process_group()
 
 
 def test_prove_batch_sharded_two_processes_one_gpu(tmp_path):
     """dist.prove_batch_sharded end to end: 2 ranks (processes) share cuda:0, collectives over gloo (host staged); every rank's own
-    proofs equal mfh_prove_batch's"""
+    proofs equal mfh_prove_batch's -- with the chain per statement owner, and with the witness pass sharded by coefficient range"""
     import torch.multiprocessing as mp
 
     world = 2

@@ -205,10 +205,11 @@ def test_config4_row_sharded_batch_emulated_on_one_gpu(gpu_ctx_factory, mf):
     ctx.close()
 
 
-@pytest.mark.parametrize("d,m,nstmt", [(256, 70, 1), (256, 70, 33), (384, 1000, 65), (128, 333, 124)])
+@pytest.mark.parametrize("d,m,nstmt", [(256, 70, 1), (256, 70, 33), (384, 1000, 65), (128, 333, 124), (256, 70, 129), (128, 1100, 248), (256, 2300, 256), (128, 4001, 200)])
 def test_generator_defined_witness_pass_on_the_matrix_cores(gpu_ctx_factory, mf, d, m, nstmt):
     """mfh_witness_poly_mm with d_ssp = NULL: the B fragments of the bits x SSP-bytes GEMM are generated in the kernel (k_witness_mm_prg)
-    instead of loaded.  Same polynomials as the single-statement VALU pass over the generator (mfh_witness_poly) and as the GEMM over the
+    instead of loaded; above 128 statements by k_witness_mm8<PRG>, whose wave pairs share the generation through LDS -- one row chunk
+    finished in the kernel up to 64 row steps, several chunks and a finishing kernel above.  Same polynomials as the single-statement VALU pass over the generator (mfh_witness_poly) and as the GEMM over the
     dense image of the same SSP, also for all-zero / all-one witnesses."""
     import torch
 
@@ -228,4 +229,37 @@ def test_generator_defined_witness_pass_on_the_matrix_cores(gpu_ctx_factory, mf,
         assert np.array_equal(got[b], c.to_host(c.witness_poly(None, wits[b], deltas[b]), np.uint32)), f"statement {b}"
     dense = torch.cat([d_t, c.ssp_prg_fill(PRG_SEED, 1, p.m + 2)])
     assert np.array_equal(got, c.to_host(c.witness_poly_many(dense, wits, deltas, mm=True), np.uint32).reshape(nstmt, p.d))
+    c.close()
+
+
+@pytest.mark.parametrize("d,m,nstmt,dense", [(512, 300, 40, False), (512, 2300, 250, False), (384, 1000, 130, True), (1024, 700, 31, True)])
+def test_witness_pass_by_coefficient_range(gpu_ctx_factory, mf, d, m, nstmt, dense):
+    """mfh_batch_witness_cols: the coefficients [col0, col0 + ncols) of w of every statement (what a rank of the row-sharded prover computes
+    -- 1 / world of the rows' generation or read), for ranges that tile the polynomial, equal mfh_batch_chain's w restricted to the range;
+    mfh_batch_chain_from_w on the assembled w gives the same h and v.  Generator-defined and dense SSP, all kernels of the pass (32 .. 256
+    statements per pass, one row chunk finished in the kernel / several chunks)."""
+    import torch
+
+    p = mf.Params(d=d, m=m)
+    c = gpu_ctx_factory(p)
+    rng = np.random.default_rng(d + m + nstmt)
+    nbytes = (p.m + 7) // 8
+    wits = [rng.integers(0, 256, size=nbytes, dtype=np.uint8).tobytes() for _ in range(nstmt)]
+    wits[0] = bytes(nbytes)
+    deltas = [int(x) for x in rng.integers(0, ol.P, size=nstmt, dtype=np.uint64)]
+    d_t = c.ssp_prg_make_t(PRG_SEED, wits[-1])
+    c.ssp_set_prg(PRG_SEED, d_t)
+    d_ssp = torch.cat([d_t, c.ssp_prg_fill(PRG_SEED, 1, p.m + 2)]) if dense else None
+    c.ssp_prepare(d_ssp)
+    want = c.batch_chain(d_ssp, wits, deltas)
+    cuts = [0, 128, 128, d - 128, d]  # (an empty range included)
+    whv = torch.empty_like(want)
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        got = c.batch_witness_cols(d_ssp, wits, deltas, a, b - a)
+        assert torch.equal(got, want[0][:, a:b]), f"coefficients {a}..{b}"
+        whv[0][:, a:b] = got
+    c.batch_chain_from_w(d_ssp, whv)
+    assert torch.equal(whv, want)
+    with pytest.raises(mf.MfhError):
+        c.batch_witness_cols(d_ssp, wits, deltas, 64, 128)  # a range must start at a multiple of 128
     c.close()

@@ -1,17 +1,22 @@
 """The statement chain (witness GEMM + polynomial step) of one super-group of 248 statements at the default instance, alone on the GPU:
 wall time per call, and -- under rocprofv3 --kernel-trace --stats -- its kernels.  dev tool.
-usage: python tools/chain_prof.py [nstmt=248] [reps=5]"""
+usage: python tools/chain_prof.py [nstmt=248] [reps=5] [config4|config5]   (generator-defined SSP at 2^20 constraints)"""
 import os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench
 import c_lwe_snarks_amd as mf
-p = mf.DEFAULT
+big = [a for a in sys.argv[1:] if a.startswith("config")]
+p = mf.DEFAULT if not big else mf.Params(logq=736 if big[0] == "config4" else 1472, d=1 << 20, m=699050)
 ctx = mf.Context(p, 0)
 ctx.set_seed(bytes((37 * i + 11) & 0xFF for i in range(40)))
-inst = bench.build_instance(mf, ctx, torch, p, 20260101)
-ctx.ssp_prepare(inst["d_ssp"])
+if big:
+    inst = bench.build_prg_instance(mf, ctx, torch, p, 20260101)
+    ctx.ssp_prepare(None)
+else:
+    inst = bench.build_instance(mf, ctx, torch, p, 20260101)
+    ctx.ssp_prepare(inst["d_ssp"])
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 248
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 rng = np.random.default_rng(5)
