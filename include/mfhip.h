@@ -235,7 +235,8 @@ int mfh_prove_batch(mfh_ctx *ctx, const uint8_t *d_crs_c8, const uint32_t *d_ssp
  *   4. mfh_ct_to_lanes -> ONE reduce-scatter (sum) of uint64 lanes per step: every rank receives the summed lanes of its own statements
  *   5. mfh_ct_from_lanes (carries + modq) -> mfh_prove_batch_finish: + delta ct_t on b_w, smudging.
  * Proofs are bit-identical to mfh_prove_batch's (sums mod 2^(64K) do not depend on the order).  world = 1 degenerates to mfh_prove_batch.
- * c-lwe-snarks_amd/dist.py (prove_batch_sharded) drives the sequence over torch.distributed (backend nccl = RCCL). */
+ * c-lwe-snarks_amd/dist.py (prove_batch_sharded) drives the sequence over torch.distributed (backend nccl = RCCL); for a generator-defined
+ * SSP it runs step 1 in two halves (mfh_batch_witness_cols / mfh_batch_chain_from_w below, one more all-to-all). */
 size_t mfh_crs_mm_share_bytes(const mfh_ctx *ctx, uint32_t rank, uint32_t world);
 int mfh_crs_expand_mm_share(mfh_ctx *ctx, const uint8_t *d_crs_c8, uint32_t rank, uint32_t world, uint8_t *d_image);
 int mfh_crs_set_resident_mm_share(mfh_ctx *ctx, const uint8_t *d_image, uint32_t rank, uint32_t world);

@@ -159,11 +159,26 @@ def test_config4_row_sharded_batch_emulated_on_one_gpu(gpu_ctx_factory, mf):
     want = ctx.prove_batch(d_crs, None, stmts, deltas, mags, signs).clone()
     per, owned = mfdist.statement_shares(nb, world)
     shares = mfdist.row_shares(p.d, world)
+    # the chain as dist.prove_batch_sharded runs it for a generator-defined SSP: every rank its coefficient range of w of ALL statements
+    # (1 / 8 of the generation of the selected rows), the ranges handed to the statement owners, who finish the chain
+    w_all = torch.empty((nb, p.d), dtype=torch.int32, device=ctx.device)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    whv = [ctx.batch_chain(None, stmts[a:b], deltas[a:b]) for a, b in owned]
+    for lo, hi in shares:
+        w_all[:, lo:hi] = ctx.batch_witness_cols(None, stmts, deltas, lo, hi - lo)
     torch.cuda.synchronize()
-    t_chain = time.perf_counter() - t0
+    t_wit = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    whv = []
+    for a, b in owned:
+        x = torch.empty((3, b - a, p.d), dtype=torch.int32, device=ctx.device)
+        x[0] = w_all[a:b]
+        whv.append(ctx.batch_chain_from_w(None, x))
+    torch.cuda.synchronize()
+    t_fin = time.perf_counter() - t0
+    del w_all
+    one = ctx.batch_chain(None, stmts[:2], deltas[:2])
+    assert torch.equal(one, whv[0][:, :2])  # (the per-owner chain gives the same polynomials)
     lps = 5 * (p.n + 1) * 2 * p.K
     total = torch.zeros(per * world * lps, dtype=torch.int64, device=ctx.device)
     image = ctx.empty(max(int(ctx.lib.mfh_crs_mm_share_bytes(ctx._h, r, world)) for r in range(world)))
@@ -197,7 +212,8 @@ def test_config4_row_sharded_batch_emulated_on_one_gpu(gpu_ctx_factory, mf):
             got.append(proofs)
     got = torch.cat(got)
     print(f"\n[config 4, row-sharded batch, 8 ranks emulated on one GPU, {nb} statements] per rank: share image {image.numel() / 1e9:.1f} GB expanded in "
-          f"{t_exp / world * 1e3:.0f} ms, row work {t_rows / world * 1e3:.0f} ms; chains of all statements {t_chain * 1e3:.0f} ms")
+          f"{t_exp / world * 1e3:.0f} ms, row work {t_rows / world * 1e3:.0f} ms, its coefficient range of w of all statements "
+          f"{t_wit / world * 1e3:.0f} ms; the rest of the chains of all statements {t_fin * 1e3:.0f} ms")
     assert torch.equal(got, want)
     ok = ctx.to_host(ctx.verify(None, alpha, beta, s, d_sk, got, nb))
     assert [bool(x) for x in ok] == [b % 2 == 0 for b in range(nb)]
