@@ -582,7 +582,10 @@ def main():
         sharded_b = {"value": nbt * sh_steps / el_s, "unit": "proofs/s", "scaling": "strong", "steps": sh_steps, "ms_per_step": el_s / sh_steps * 1e3,
                      "statements_per_step_whole_job": nbt, "ranks": world, "backend": backend + (" (RCCL)" if backend == "nccl" else " (host-staged rehearsal)"),
                      "own_proofs_accepted_rejected_as_expected_and_identical_to_prover": ok_s,
-                     "collectives_per_step": [
+                     "collectives_per_step": ([{"op": "all_to_all_single", "what": "generator-defined SSP: the rank's coefficient range of w of every statement to the statement's owner "
+                                                                                    "(the witness pass sharded by coefficient range: 1/N of the generation per rank)",
+                                                "bytes_sent_per_rank": nbt * 4 * (p.d // world) * (world - 1) // world}] if inst["d_ssp"] is None and all(
+                                                    (p.d * r // world) % 128 == 0 for r in range(world + 1)) else []) + [
                          {"op": "all_to_all_single", "what": "rows [d r/N, d (r+1)/N) of w | h | v of every statement to rank r",
                           "bytes_sent_per_rank": per_s * 3 * 4 * (p.d - p.d // world)},
                          {"op": "reduce_scatter_tensor(sum, int64 lanes)", "what": "one uint64 lane per surviving 32-bit word of the 5 partial ciphertexts of every statement",

@@ -871,56 +871,14 @@ __global__ __launch_bounds__(256) void k_witness_mm(const v4i *__restrict__ sspf
 // part == nullptr (one row chunk, m < 2^16): the chunk partials never leave the workgroup -- the two waves of a pair exchange their
 // half sums (planes 0-1 / planes 2-3, 32 bits each) through the ring's LDS and write w_b[k] = delta_b t[k] + the byte sum mod p directly
 // (what k_witness_mm_finish does from the partials: 0.5 GB written and read back per 248 statements otherwise).
-// PRG (a generator-defined SSP, src = the row keys of k_prg_rowkeys): the B fragments are generated in the kernel as in k_witness_mm_prg,
-// and the pair SHARES the generation -- a lane of wave A hashes rows 0..7 of its 16, the same lane of wave B rows 8..15, each keeps the
-// two byte planes it multiplies and hands the other two to its partner through LDS (16 bytes per lane and step each way, double
-// buffered, behind the step's barrier): 8 hashes per lane and step serve 256 statements, against 16 per 128 in k_witness_mm_prg<4>.
-template <bool PRG>
-__global__ __launch_bounds__(256) void k_witness_mm8(const void *__restrict__ src, const v4i *__restrict__ bitfrag, uint32_t nrowsel /* m - 1 */,
+__global__ __launch_bounds__(256) void k_witness_mm8(const v4i *__restrict__ sspfrag, const v4i *__restrict__ bitfrag, uint32_t nrowsel /* m - 1 */,
                                                      uint32_t ksteps_per_chunk, uint32_t d, int *__restrict__ part, const uint32_t *__restrict__ tpoly /* + col0 */,
                                                      const uint32_t *__restrict__ cnt_delta, uint32_t nstmt, uint32_t *__restrict__ w_out, WCols wc) {
-  constexpr int MT = 8, RING = 4, PF = PRG ? 1 : 4;
+  constexpr int MT = 8, RING = 4, PF = 4;
   __shared__ v4i bits[RING][MT][64];
-  __shared__ uint4 xch[PRG ? 3 : 1][PRG ? 4 : 1][PRG ? 64 : 1];  // PRG: [step % 3][writing wave][lane]
-  const v4i *__restrict__ sspfrag = static_cast<const v4i *>(src);
-  const uint32_t *__restrict__ rowkeys = static_cast<const uint32_t *>(src);
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t r32 = lane & 31, h = lane >> 5;
   const uint32_t ktl = blockIdx.x * 2 + (wave >> 1), kt = wc.kt0 + ktl, KT = wc.KT, w0 = 2 * (wave & 1);
-  const uint32_t kc = kt * 32 + r32 + 0x632BE5ABu;
-  // the 8 rows this lane hashes of step K: their two dwords per byte plane; own = planes w0, w0 + 1, give = the partner's two planes
-  auto rk_load = [&](uint32_t K, uint4 (&rk)[2]) {  // the row keys of the 8 rows this lane hashes of step K (w0 = 2 * (wave & 1): rows 8 (wave & 1) ..)
-    const uint4 *rk4 = reinterpret_cast<const uint4 *>(rowkeys + 32 * (uint64_t)K + 16 * h + 4 * w0);
-    rk[0] = rk4[0];
-    rk[1] = rk4[1];
-  };
-  auto hash1 = [&](uint32_t rowkey) -> uint32_t {  // mf::ssp_prg_raw(rowkey, k)
-    uint32_t y = kc * rowkey;
-    y ^= y >> 16;
-    y *= 0x7FEB352Du;
-    y ^= y >> 15;
-    y *= 0x846CA68Bu;
-    y ^= y >> 16;
-    return y;
-  };
-  auto pack = [&](const uint32_t (&x)[8], uint32_t (&own)[4], uint4 &give) {
-    uint32_t dw[4][2];
-#pragma unroll
-    for (int w = 0; w < 4; w++)
-#pragma unroll
-      for (int j = 0; j < 2; j++) {
-        const uint32_t lo = __builtin_amdgcn_perm(x[4 * j + 1], x[4 * j], 0x0c0c0400u + 0x00000101u * w);      // {x0.bw, x1.bw, 0, 0}
-        const uint32_t hi = __builtin_amdgcn_perm(x[4 * j + 3], x[4 * j + 2], 0x04000c0cu + 0x01010000u * w);  // {0, 0, x2.bw, x3.bw}
-        dw[w][j] = (lo | hi) ^ 0x80808080u;
-      }
-    if (w0) {  // (wave-uniform)
-      own[0] = dw[2][0]; own[1] = dw[2][1]; own[2] = dw[3][0]; own[3] = dw[3][1];
-      give = uint4{dw[0][0], dw[0][1], dw[1][0], dw[1][1]};
-    } else {
-      own[0] = dw[0][0]; own[1] = dw[0][1]; own[2] = dw[1][0]; own[3] = dw[1][1];
-      give = uint4{dw[2][0], dw[2][1], dw[3][0], dw[3][1]};
-    }
-  };
   const uint32_t K0 = blockIdx.y * ksteps_per_chunk, K1 = min((nrowsel + 31) / 32, K0 + ksteps_per_chunk);
   v16i acc[MT][2];
 #pragma unroll
@@ -950,82 +908,24 @@ __global__ __launch_bounds__(256) void k_witness_mm8(const void *__restrict__ sr
   };
   v4i sta[2], stb[2];  // the bit fragments of steps K + 1 / K + 2 on their way to the ring
   v4i bq[PF][2];
-  uint32_t own[4];     // PRG: this wave's planes of the 8 rows it hashed of the step about to be multiplied
   bits_load(K0, sta);
   bits_store(K0, sta);
   bits_load(K0 + 1, sta);
   bits_load(K0 + 2, stb);
-  uint4 rkr[4][2];     // PRG: the row keys of steps K + 2 .. K + 5 (a load consumed in the step it is issued in costs its whole latency)
-  if constexpr (PRG) {
-    // the pipeline runs two steps ahead: step K multiplies fragments assembled during step K - 1 from hashes made during step K - 2
-    uint4 give;
-    uint32_t own0[4];
-    rk_load(K0, rkr[0]);
-    rk_load(min(K0 + 1, K1 - 1), rkr[1]);
-    {
-      const uint32_t r0[8] = {rkr[0][0].x, rkr[0][0].y, rkr[0][0].z, rkr[0][0].w, rkr[0][1].x, rkr[0][1].y, rkr[0][1].z, rkr[0][1].w};
-      const uint32_t r1[8] = {rkr[1][0].x, rkr[1][0].y, rkr[1][0].z, rkr[1][0].w, rkr[1][1].x, rkr[1][1].y, rkr[1][1].z, rkr[1][1].w};
-      uint32_t x0[8], x1[8];
 #pragma unroll
-      for (int e = 0; e < 8; e++) { x0[e] = hash1(r0[e]); x1[e] = hash1(r1[e]); }
-      pack(x0, own0, give);
-      xch[K0 % 3][wave][lane] = give;
-      pack(x1, own, give);
-      xch[(K0 + 1) % 3][wave][lane] = give;
-    }
-#pragma unroll
-    for (int i = 2; i <= 5; i++) rk_load(min(K0 + i, K1 - 1), rkr[i & 3]);
-    __syncthreads();
-    const uint4 recv = xch[K0 % 3][wave ^ 1][lane];
-    if (w0) {
-      bq[0][0] = v4i{(int)recv.x, (int)recv.y, (int)own0[0], (int)own0[1]};
-      bq[0][1] = v4i{(int)recv.z, (int)recv.w, (int)own0[2], (int)own0[3]};
-    } else {
-      bq[0][0] = v4i{(int)own0[0], (int)own0[1], (int)recv.x, (int)recv.y};
-      bq[0][1] = v4i{(int)own0[2], (int)own0[3], (int)recv.z, (int)recv.w};
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < PF; i++) ssp_load(K0 + i, bq[i]);
-  }
+  for (int i = 0; i < PF; i++) ssp_load(K0 + i, bq[i]);
   __syncthreads();
   uint32_t K = K0;
   auto step = [&](int slot, v4i (&st)[2]) {  // st: the bit fragments of step K + 1 (loaded two steps ago); refilled with those of step K + 3
-    uint32_t own_next[4];
-    uint4 recv;
-    uint32_t hx[8], hr[8];
-    if constexpr (PRG) {
-      recv = xch[(K + 1) % 3][wave ^ 1][lane];  // the partner's half of step K + 1 (written a step ago, before the barrier)
-      const uint4 (&rk)[2] = rkr[(slot + 2) & 3];  // step K + 2 (clamped to the chunk's last step)
-      hr[0] = rk[0].x; hr[1] = rk[0].y; hr[2] = rk[0].z; hr[3] = rk[0].w; hr[4] = rk[1].x; hr[5] = rk[1].y; hr[6] = rk[1].z; hr[7] = rk[1].w;
-    }
     bits_store(K + 1, st);
     const v4i *aq = &bits[K % RING][0][lane];
 #pragma unroll
     for (int t = 0; t < MT; t++) {
       const v4i a = aq[t * 64];
 #pragma unroll
-      for (int w = 0; w < 2; w++) acc[t][w] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[PRG ? 0 : slot][w], acc[t][w], 0, 0, 0);
-      if constexpr (PRG) hx[t] = hash1(hr[t]);  // (one hash of the next-but-one step between the MFMA pairs: one wave per SIMD, nothing else overlaps the matrix pipe)
+      for (int w = 0; w < 2; w++) acc[t][w] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[slot][w], acc[t][w], 0, 0, 0);
     }
-    if constexpr (PRG) {
-      uint4 give;
-      pack(hx, own_next, give);
-      xch[(K + 2) % 3][wave][lane] = give;  // (slot last read during step K - 2, two barriers ago)
-      rk_load(min(K + 6, K1 - 1), rkr[(slot + 2) & 3]);
-    }
-    if constexpr (PRG) {  // step K + 1's fragments: own rows (hashed during step K - 1) + the partner's
-      if (w0) {  // wave B hashed rows 8..15
-        bq[0][0] = v4i{(int)recv.x, (int)recv.y, (int)own[0], (int)own[1]};
-        bq[0][1] = v4i{(int)recv.z, (int)recv.w, (int)own[2], (int)own[3]};
-      } else {
-        bq[0][0] = v4i{(int)own[0], (int)own[1], (int)recv.x, (int)recv.y};
-        bq[0][1] = v4i{(int)own[2], (int)own[3], (int)recv.z, (int)recv.w};
-      }
-#pragma unroll
-      for (int i = 0; i < 4; i++) own[i] = own_next[i];
-    } else
-      ssp_load(K + PF, bq[slot]);
+    ssp_load(K + PF, bq[slot]);
     bits_load(K + 3, st);
     __syncthreads();  // slot (K + 1) % RING is complete for the next step; slot K % RING may be rewritten from the step after next on
     K++;
@@ -1197,6 +1097,108 @@ __global__ __launch_bounds__(256) void k_witness_mm_prg(const uint32_t *__restri
         const uint32_t stmt = 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h;
         part[(((uint64_t)blockIdx.y * 4 + w) * (32 * MT) + stmt) * d + k] = acc[t][w][e];
       }
+}
+// 256 statements per generation with TWO waves per SIMD: a coefficient tile's four byte planes go to four waves (8 statement tiles x 1
+// plane = 128 accumulator registers each), which SHARE the hashes four ways -- wave j hashes rows 4 j .. 4 j + 3 of a lane's 16 and
+// publishes dword j of all four planes' fragments through LDS (a three-slot ring: the hashes of step K + 2 are issued between the MFMAs
+// of step K, the fragment of step K + 1 is read during step K; the row keys are loaded four steps ahead), wave w
+// reads plane w's fragment with one 16-byte load.  4 hashes and 8 MFMAs per wave and step, and with two waves per SIMD one wave's
+// hashes run under the other's MFMAs (a first version on k_witness_mm8's wave pairs, one wave per SIMD with 256 accumulators and the
+// hashes shared two ways, took 0.89 s per 248 statements at 2^20 constraints against 0.83: nothing overlaps the matrix pipe there).
+// Chunk partials only (k_witness_mm_finish).  grid = (d / 64, row chunks), block = 8 waves = 2 coefficient tiles x 4 planes.
+__global__ __launch_bounds__(512) void k_witness_mm8q_prg(const uint32_t *__restrict__ rowkeys, const v4i *__restrict__ bitfrag, uint32_t nrowsel /* m - 1 */,
+                                                          uint32_t ksteps_per_chunk, uint32_t d, int *__restrict__ part, WCols wc) {
+  constexpr int MT = 8, RING = 4;
+  __shared__ v4i bits[RING][MT][64];
+  __shared__ uint32_t xch[3][2][4][64][4];  // [step % 3][tile][plane][lane][hashing wave]
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t r32 = lane & 31, h = lane >> 5;
+  const uint32_t tile = wave >> 2, pl = wave & 3;
+  const uint32_t ktl = blockIdx.x * 2 + tile, kt = wc.kt0 + ktl;
+  const uint32_t kc = kt * 32 + r32 + 0x632BE5ABu;
+  const uint32_t K0 = blockIdx.y * ksteps_per_chunk, K1 = min((nrowsel + 31) / 32, K0 + ksteps_per_chunk);
+  v16i acc[MT];
+#pragma unroll
+  for (int t = 0; t < MT; t++)
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[t][e] = 0;
+  if (K0 >= K1) return;  // (uniform)
+  auto bits_load = [&](uint32_t K) -> v4i { return bitfrag[(uint64_t)min(K, K1 - 1) * MT * 64 + tid]; };  // 512 elements per step: one per thread
+  auto bits_store = [&](uint32_t K, v4i st) { (&bits[K % RING][0][0])[tid] = st; };
+  auto rk_load = [&](uint32_t K) -> uint4 { return *reinterpret_cast<const uint4 *>(rowkeys + 32 * (uint64_t)min(K, K1 - 1) + 16 * h + 4 * pl); };
+  auto hash1 = [&](uint32_t rowkey) -> uint32_t {  // mf::ssp_prg_raw(rowkey, k)
+    uint32_t y = kc * rowkey;
+    y ^= y >> 16;
+    y *= 0x7FEB352Du;
+    y ^= y >> 15;
+    y *= 0x846CA68Bu;
+    y ^= y >> 16;
+    return y;
+  };
+  auto publish = [&](uint32_t K, const uint32_t (&x)[4]) {  // dword `pl` of the four planes' fragments of step K
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      const uint32_t lo = __builtin_amdgcn_perm(x[1], x[0], 0x0c0c0400u + 0x00000101u * w);  // {x0.bw, x1.bw, 0, 0}
+      const uint32_t hi = __builtin_amdgcn_perm(x[3], x[2], 0x04000c0cu + 0x01010000u * w);  // {0, 0, x2.bw, x3.bw}
+      xch[K % 3][tile][w][lane][pl] = (lo | hi) ^ 0x80808080u;
+    }
+  };
+  auto fragment = [&](uint32_t K) -> v4i { return *reinterpret_cast<const v4i *>(&xch[K % 3][tile][pl][lane][0]); };
+  uint4 rkr[4];  // the row keys of steps K + 2 .. K + 5
+  v4i sta, stb;  // the bit fragments of steps K + 1 / K + 2 on their way to the ring
+  sta = bits_load(K0);
+  bits_store(K0, sta);
+  sta = bits_load(K0 + 1);
+  stb = bits_load(K0 + 2);
+  {
+    const uint4 r0 = rk_load(K0), r1 = rk_load(K0 + 1);
+    const uint32_t x0[4] = {hash1(r0.x), hash1(r0.y), hash1(r0.z), hash1(r0.w)};
+    const uint32_t x1[4] = {hash1(r1.x), hash1(r1.y), hash1(r1.z), hash1(r1.w)};
+    publish(K0, x0);
+    publish(K0 + 1, x1);
+  }
+#pragma unroll
+  for (int i = 2; i <= 5; i++) rkr[i & 3] = rk_load(K0 + i);
+  __syncthreads();
+  v4i bq = fragment(K0);
+  uint32_t K = K0;
+  auto step = [&](int slot, v4i &st) {  // st: the bit fragment of step K + 1 (loaded two steps ago); refilled with that of step K + 3
+    const v4i bnext = fragment(K + 1);  // (published a step ago, before the barrier)
+    const uint4 rk = rkr[(slot + 2) & 3];  // step K + 2
+    const uint32_t hr[4] = {rk.x, rk.y, rk.z, rk.w};
+    uint32_t hx[4];
+    bits_store(K + 1, st);
+    const v4i *aq = &bits[K % RING][0][lane];
+#pragma unroll
+    for (int t = 0; t < MT; t++) {
+      acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(aq[t * 64], bq, acc[t], 0, 0, 0);
+      if (t & 1) hx[t >> 1] = hash1(hr[t >> 1]);
+    }
+    publish(K + 2, hx);  // (slot last read during step K - 2, two barriers ago)
+    rkr[(slot + 2) & 3] = rk_load(K + 6);
+    bq = bnext;
+    st = bits_load(K + 3);
+    __syncthreads();
+    K++;
+  };
+  for (; K + 4 <= K1;) {
+    step(0, sta);
+    step(1, stb);
+    step(2, sta);
+    step(3, stb);
+  }
+  if (K < K1) step(0, sta);
+  if (K < K1) step(1, stb);
+  if (K < K1) step(2, sta);
+  uint32_t dd = d;
+  asm volatile("" : "+s"(dd));  // (keeps the store addresses from being computed ahead of the loop)
+  int *dst = part + ((uint64_t)blockIdx.y * 4 + pl) * (32 * MT) * dd + ktl * 32 + r32 + (uint64_t)(4 * h) * dd;
+#pragma unroll
+  for (int t = 0; t < MT; t++) {
+#pragma unroll
+    for (int e = 0; e < 16; e++) dst[(uint64_t)((e & 3) + 8 * (e >> 2)) * dd] = acc[t][e];
+    dst += (uint64_t)32 * dd;
+  }
 }
 // bits of nstmt statements (packed, bits_stride bytes apart) -> A fragments: bitfrag[K][t][lane (stmt = 32 t + (l & 31), h)][e] = bit
 // (32 K + 16 h + e) of that statement
@@ -1591,7 +1593,7 @@ int mfh_witness_poly_mm_cols(mfh_ctx *c, const uint32_t *d_ssp, uint32_t nstmt, 
   const uint32_t nrowsel = m - 1, ksteps = (nrowsel + 31) / 32;
   // (the 256-statement pass has d / 64 workgroups of one wave per SIMD: one row chunk fills the chip at d >= 2^14, and with one chunk --
   // and byte sums that fit 32 bits per plane pair -- it finishes in the kernel)
-  const bool fused = MT == 8 && m < 65536 && (nc >= 16384 || ksteps <= 64);  // (small instances: nothing to fill either way)
+  const bool fused = MT == 8 && src.dense && m < 65536 && (nc >= 16384 || ksteps <= 64);  // (small instances: nothing to fill either way)
   const uint32_t nchunks = fused ? 1u : std::min(ksteps, 4u), kpc = (ksteps + nchunks - 1) / nchunks;
   // the SSP in B-fragment order: built on first use per SSP (mfh_ssp_prepare invalidates it), kept beside the uint32 image
   const size_t sfrag_b = (size_t)ksteps * 32 * d * 4;
@@ -1635,18 +1637,13 @@ int mfh_witness_poly_mm_cols(mfh_ctx *c, const uint32_t *d_ssp, uint32_t nstmt, 
     uint32_t *d_rk = (uint32_t *)(dev + head_b + frag_b + part_b);
     const dim3 grid(nc / 128, (ksteps + kpc - 1) / kpc);
     hipLaunchKernelGGL(k_prg_rowkeys, dim3((ksteps * 32 + 255) / 256), dim3(256), 0, c->stream, src.seed, ksteps * 32, d_rk);
-    if (MT == 8) {
-      hipLaunchKernelGGL(k_witness_mm8<true>, dim3(nc / 64, (ksteps + kpc - 1) / kpc), dim3(256), 0, c->stream, (const void *)d_rk, (const v4i *)d_frag, nrowsel, kpc, nc,
-                         fused ? (int *)nullptr : d_part, tpoly, d_cd, nstmt, d_w, wc);
-      if (fused) {
-        HIP_TRY(c, hipGetLastError());
-        return MFH_OK;
-      }
-    } else if (MT == 1) hipLaunchKernelGGL(k_witness_mm_prg<1>, grid, dim3(256), 0, c->stream, d_rk, (const v4i *)d_frag, nrowsel, kpc, nc, d_part, wc);
+    if (MT == 8)
+      hipLaunchKernelGGL(k_witness_mm8q_prg, dim3(nc / 64, (ksteps + kpc - 1) / kpc), dim3(512), 0, c->stream, d_rk, (const v4i *)d_frag, nrowsel, kpc, nc, d_part, wc);
+    else if (MT == 1) hipLaunchKernelGGL(k_witness_mm_prg<1>, grid, dim3(256), 0, c->stream, d_rk, (const v4i *)d_frag, nrowsel, kpc, nc, d_part, wc);
     else if (MT == 2) hipLaunchKernelGGL(k_witness_mm_prg<2>, grid, dim3(256), 0, c->stream, d_rk, (const v4i *)d_frag, nrowsel, kpc, nc, d_part, wc);
     else hipLaunchKernelGGL(k_witness_mm_prg<4>, grid, dim3(256), 0, c->stream, d_rk, (const v4i *)d_frag, nrowsel, kpc, nc, d_part, wc);
   } else if (MT == 8) {
-    hipLaunchKernelGGL(k_witness_mm8<false>, dim3(nc / 64, (ksteps + kpc - 1) / kpc), dim3(256), 0, c->stream, (const void *)c->ssp_frag, (const v4i *)d_frag, nrowsel, kpc, nc,
+    hipLaunchKernelGGL(k_witness_mm8, dim3(nc / 64, (ksteps + kpc - 1) / kpc), dim3(256), 0, c->stream, (const v4i *)c->ssp_frag, (const v4i *)d_frag, nrowsel, kpc, nc,
                        fused ? (int *)nullptr : d_part, tpoly, d_cd, nstmt, d_w, wc);
     if (fused) {
       HIP_TRY(c, hipGetLastError());
