@@ -252,3 +252,29 @@ def test_row_slabs_give_identical_proofs(gpu_ctx_factory, d, m, nb, nslabs, chun
     ok = ctx.to_host(ctx.verify(inst["d_ssp"], inst["alpha"], inst["beta"], inst["s"], inst["sk"], got, nb))
     assert [bool(x) for x in ok] == [b % 3 != 2 for b in range(nb)]
     ctx.close()
+
+
+def test_more_than_four_super_groups(gpu_ctx_factory, oracle):
+    """1300 statements in one call: 6 super-groups of 248 (the staged host inputs -- witness bits, deltas, smudging terms -- of all
+    super-groups travel in one copy, one staging area per super-group; the chain alternates between two w | h | v areas): proofs at the
+    super-group boundaries equal the single-proof prover's, statement 0 the oracle's, and the verifier accepts exactly the valid ones."""
+    import torch
+
+    import c_lwe_snarks_amd as mf
+
+    p = mf.Params(d=256, m=200)
+    ctx = gpu_ctx_factory(p)
+    ctx.set_seed(SEED)
+    inst = _instance(mf, ctx, oracle, p, 31)
+    nb = 1300
+    bits, deltas, mags, signs = _statements(inst["rng"], p, nb, inst["wit"])
+    out = ctx.prove_batch(inst["d_crs"], inst["d_ssp"], bits, deltas, mags, signs).view(nb, -1)
+    d_sk = ctx.to_device(inst["sk"])
+    ok = ctx.to_host(ctx.verify(inst["d_ssp"], inst["alpha"], inst["beta"], inst["s"], d_sk, out.reshape(-1), nb))
+    assert [bool(x) for x in ok] == [b % 3 != 2 for b in range(nb)]
+    for b in (0, 247, 248, 495, 496, 991, 992, 1239, 1240, nb - 1):
+        assert torch.equal(out[b], ctx.prove(inst["d_crs"], inst["d_ssp"], bits[b], deltas[b], mags[b], signs[b])), f"statement {b}"
+    for b in (0, 1240):
+        stape = b"".join(mags[b][80 * k: 80 * k + 80] + signs[b][k: k + 1] for k in range(5))
+        ref = oracle.prover(p, inst["crs"], inst["ssp"], bits[b], deltas[b], stape, 80)
+        assert np.array_equal(ctx.to_host(out[b], np.uint64).reshape(5, p.n + 1, p.L), np.stack(ref["proof"])), f"statement {b} differs from the oracle's prover"
