@@ -309,16 +309,30 @@ __device__ __forceinline__ void dit_regs(uint32_t *v, uint32_t j, uint32_t qd, u
 __global__ __launch_bounds__(256) void k_ntt_lds_mul8(uint32_t *__restrict__ a, const uint32_t *__restrict__ bhat, uint32_t N,
                                                       const uint32_t *__restrict__ tw, const uint32_t *__restrict__ twi, uint32_t half_max, Primes3 P) {
   __shared__ uint32_t sm[2048 + 64];
+  // the block's stages use every (half_max / 1024)-th entry of the twiddle tables: 2 x 1024 words, staged in LDS once per workgroup -- the
+  // 88 twiddle reads per thread are then LDS gathers instead of global ones (64 different cache lines per wave-load)
+  __shared__ uint32_t tws[2][1024];
   const NttPrime q = P.q[blockIdx.y % 3];
   const uint32_t tid = threadIdx.x;
   const size_t base = (size_t)blockIdx.y * N + (size_t)blockIdx.x * 2048;
-  const uint32_t *t = tw + (size_t)(blockIdx.y % 3) * half_max, *ti = twi + (size_t)(blockIdx.y % 3) * half_max;
+  {
+    const uint32_t *tg = tw + (size_t)(blockIdx.y % 3) * half_max, *tig = twi + (size_t)(blockIdx.y % 3) * half_max;
+    const uint32_t sc = half_max >> 10;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      tws[0][tid + 256 * i] = tg[(size_t)(tid + 256 * i) * sc];
+      tws[1][tid + 256 * i] = tig[(size_t)(tid + 256 * i) * sc];
+    }
+  }
+  const uint32_t *t = tws[0], *ti = tws[1];
+  half_max = 1024;
   uint32_t v[8];
   // the three strided views of the block: element m of the thread at i1 + 256 m, i2 + 32 m, i3 + 4 m; and the contiguous one at 8 tid + m
   const uint32_t i1 = tid, j2 = tid & 31, i2 = (tid >> 5) * 256 + j2, j3 = tid >> 6, i3 = (tid & 63) * 32 + j3;
   // ---- forward: block lengths 2048 .. 2
 #pragma unroll
   for (int m = 0; m < 8; m++) v[m] = a[base + i1 + 256 * m];
+  __syncthreads();  // the staged twiddles
   dif_regs<3>(v, tid, 256, 2048, t, half_max, q);
 #pragma unroll
   for (int m = 0; m < 8; m++) sm[lpad(i1 + 256 * m)] = v[m];
