@@ -779,7 +779,8 @@ __global__ __launch_bounds__(256) void k_evalmm_finish_groups(const int *__restr
 // The SSP is row-major (v_i[k], k fastest) but the MFMA wants 16 consecutive ROWS per lane, so a second image of the SSP in B-fragment
 // order is built once per SSP (k_ssp_frag, same size as the uint32 SSP): for row step K (32 rows), coefficient tile kt (32
 // coefficients), byte w and lane (k = 32 kt + (l & 31), h = l >> 5): the 16 bytes [byte w of v_{32K+16h+e+1}[k]] ^ 0x80, e = 0..15, at
-// frag[(((K * KT + kt) * 4 + w) * 64 + l) * 16 + e].  The pass is then a pure stream: four 16-byte loads and four 32x32x32 MFMAs
+// frag[(((kt * KS + K) * 4 + w) * 64 + l) * 16 + e] (KS row steps: a coefficient tile's fragments are contiguous, so a wave reads one
+// sequential stream -- with the row step outermost, 8 KiB pieces 4 MiB apart, the pass ran at 3.75 TB/s).  The pass is then a pure stream: four 16-byte loads and four 32x32x32 MFMAs
 // (M = 32 statements) per wave and row step.
 __global__ void k_ssp_frag(const uint32_t *__restrict__ ssp, uint32_t nrowsel, uint32_t d, uint32_t *__restrict__ frag) {
   // one thread = 4 rows x 1 coefficient -> one dword of each of the four byte columns
@@ -788,7 +789,8 @@ __global__ void k_ssp_frag(const uint32_t *__restrict__ ssp, uint32_t nrowsel, u
   const uint32_t lane = gid & 63, eg = (gid >> 6) & 3;
   const uint64_t tile = gid >> 8;  // K * KT + kt
   const uint32_t kt = (uint32_t)(tile % KT), K = (uint32_t)(tile / KT);
-  if ((uint64_t)K * 32 >= ((uint64_t)nrowsel + 31) / 32 * 32) return;
+  const uint32_t KSt = (nrowsel + 31) / 32;
+  if (K >= KSt) return;
   const uint32_t k = kt * 32 + (lane & 31), rb = K * 32 + 16 * (lane >> 5) + 4 * eg;
   uint32_t x[4];
 #pragma unroll
@@ -797,7 +799,7 @@ __global__ void k_ssp_frag(const uint32_t *__restrict__ ssp, uint32_t nrowsel, u
   for (int w = 0; w < 4; w++) {
     const uint32_t lo = __builtin_amdgcn_perm(x[1], x[0], 0x0c0c0400u + 0x00000101u * w);  // {x0.bw, x1.bw, 0, 0}
     const uint32_t hi = __builtin_amdgcn_perm(x[3], x[2], 0x04000c0cu + 0x01010000u * w);  // {0, 0, x2.bw, x3.bw}
-    frag[(((tile * 4 + w) * 64 + lane) << 2) + eg] = lo | hi;
+    frag[(((((uint64_t)kt * KSt + K) * 4 + w) * 64 + lane) << 2) + eg] = lo | hi;
   }
 }
 // The witness kernels work on a RANGE of coefficients [col0, col0 + d) of the polynomials (the whole polynomial: col0 = 0, d = the SSP's
@@ -805,7 +807,7 @@ __global__ void k_ssp_frag(const uint32_t *__restrict__ ssp, uint32_t nrowsel, u
 // of the range (and of the partial arrays), WCols carries where it starts.
 struct WCols {
   uint32_t kt0;      // col0 / 32: first 32-coefficient tile
-  uint32_t KT;       // 32-coefficient tiles of the whole SSP (the fragment image's tile stride)
+  uint32_t KS;       // row steps of the whole SSP (the fragment image's tile stride)
   uint64_t wstride;  // coefficients between consecutive statements of the output
 };
 // grid = (d / 128, row chunks); block = 4 waves, one 32-coefficient tile each; MT = 1, 2 or 4 tiles of 32 statements (the SSP is read
@@ -815,7 +817,7 @@ __global__ __launch_bounds__(256) void k_witness_mm(const v4i *__restrict__ sspf
                                                     uint32_t ksteps_per_chunk, uint32_t d, int *__restrict__ part, WCols wc) {
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t r32 = lane & 31, h = lane >> 5;
-  const uint32_t ktl = blockIdx.x * 4 + wave, kt = wc.kt0 + ktl, KT = wc.KT;
+  const uint32_t ktl = blockIdx.x * 4 + wave, kt = wc.kt0 + ktl;
   const uint32_t k = ktl * 32 + r32;  // (within the range)
   const uint32_t K0 = blockIdx.y * ksteps_per_chunk, K1 = min((nrowsel + 31) / 32, K0 + ksteps_per_chunk);
   v16i acc[MT][4];
@@ -832,7 +834,7 @@ __global__ __launch_bounds__(256) void k_witness_mm(const v4i *__restrict__ sspf
   v4i bq[PF][4], aq[PF][MT];
   auto fetch = [&](int slot, uint32_t K) {
     K = min(K, K1 - 1);
-    const v4i *src = sspfrag + (((uint64_t)K * KT + kt) * 4) * 64 + lane;
+    const v4i *src = sspfrag + (((uint64_t)kt * wc.KS + K) * 4) * 64 + lane;
 #pragma unroll
     for (int w = 0; w < 4; w++) bq[slot][w] = src[64 * w];
 #pragma unroll
@@ -861,149 +863,6 @@ __global__ __launch_bounds__(256) void k_witness_mm(const v4i *__restrict__ sspf
         const uint32_t stmt = 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h;
         part[(((uint64_t)blockIdx.y * 4 + w) * (32 * MT) + stmt) * d + k] = acc[t][w][e];
       }
-}
-// 256 statements (a whole super-group of 248) in ONE read of the SSP.  A wave cannot hold 8 statement tiles x 4 byte planes (512
-// accumulator registers): the planes are split over a wave pair -- wave w of the workgroup takes coefficient tile w >> 1 and byte planes
-// 2 (w & 1), 2 (w & 1) + 1 (8 x 2 accumulator tiles = 256 registers, one wave per SIMD) -- and the eight bit fragments of a row step (8
-// KiB, the same for all four waves) go through a four-slot LDS ring, two steps ahead (fetched straight from L2 by every wave they made
-// the pass L1-bound: 2.26 ms against 2 x 0.59 for two 124-statement passes).  The SSP fragments (2 KiB per wave and step: the HBM
-// stream) are prefetched four steps ahead in registers.  grid = (d / 64, row chunks).
-// part == nullptr (one row chunk, m < 2^16): the chunk partials never leave the workgroup -- the two waves of a pair exchange their
-// half sums (planes 0-1 / planes 2-3, 32 bits each) through the ring's LDS and write w_b[k] = delta_b t[k] + the byte sum mod p directly
-// (what k_witness_mm_finish does from the partials: 0.5 GB written and read back per 248 statements otherwise).
-__global__ __launch_bounds__(256) void k_witness_mm8(const v4i *__restrict__ sspfrag, const v4i *__restrict__ bitfrag, uint32_t nrowsel /* m - 1 */,
-                                                     uint32_t ksteps_per_chunk, uint32_t d, int *__restrict__ part, const uint32_t *__restrict__ tpoly /* + col0 */,
-                                                     const uint32_t *__restrict__ cnt_delta, uint32_t nstmt, uint32_t *__restrict__ w_out, WCols wc) {
-  constexpr int MT = 8, RING = 4, PF = 4;
-  __shared__ v4i bits[RING][MT][64];
-  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint32_t r32 = lane & 31, h = lane >> 5;
-  const uint32_t ktl = blockIdx.x * 2 + (wave >> 1), kt = wc.kt0 + ktl, KT = wc.KT, w0 = 2 * (wave & 1);
-  const uint32_t K0 = blockIdx.y * ksteps_per_chunk, K1 = min((nrowsel + 31) / 32, K0 + ksteps_per_chunk);
-  v16i acc[MT][2];
-#pragma unroll
-  for (int t = 0; t < MT; t++)
-#pragma unroll
-    for (int w = 0; w < 2; w++)
-#pragma unroll
-      for (int e = 0; e < 16; e++) acc[t][w][e] = 0;
-  if (K0 >= K1) return;  // (uniform)
-  // a row step's 8 bit fragments = 512 elements of 16 bytes: two per thread (loads past the chunk re-read its last step)
-  auto bits_load = [&](uint32_t K, v4i (&st)[2]) {
-    K = min(K, K1 - 1);
-    const v4i *src = bitfrag + (uint64_t)K * MT * 64;
-    st[0] = src[tid];
-    st[1] = src[tid + 256];
-  };
-  auto bits_store = [&](uint32_t K, const v4i (&st)[2]) {
-    v4i *dst = &bits[K % RING][0][0];
-    dst[tid] = st[0];
-    dst[tid + 256] = st[1];
-  };
-  auto ssp_load = [&](uint32_t K, v4i (&bq)[2]) {
-    K = min(K, K1 - 1);
-    const v4i *src = sspfrag + (((uint64_t)K * KT + kt) * 4 + w0) * 64 + lane;
-    bq[0] = src[0];
-    bq[1] = src[64];
-  };
-  v4i sta[2], stb[2];  // the bit fragments of steps K + 1 / K + 2 on their way to the ring
-  v4i bq[PF][2];
-  bits_load(K0, sta);
-  bits_store(K0, sta);
-  bits_load(K0 + 1, sta);
-  bits_load(K0 + 2, stb);
-#pragma unroll
-  for (int i = 0; i < PF; i++) ssp_load(K0 + i, bq[i]);
-  __syncthreads();
-  uint32_t K = K0;
-  auto step = [&](int slot, v4i (&st)[2]) {  // st: the bit fragments of step K + 1 (loaded two steps ago); refilled with those of step K + 3
-    bits_store(K + 1, st);
-    const v4i *aq = &bits[K % RING][0][lane];
-#pragma unroll
-    for (int t = 0; t < MT; t++) {
-      const v4i a = aq[t * 64];
-#pragma unroll
-      for (int w = 0; w < 2; w++) acc[t][w] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[slot][w], acc[t][w], 0, 0, 0);
-    }
-    ssp_load(K + PF, bq[slot]);
-    bits_load(K + 3, st);
-    __syncthreads();  // slot (K + 1) % RING is complete for the next step; slot K % RING may be rewritten from the step after next on
-    K++;
-  };
-  for (; K + 4 <= K1;) {
-    step(0, sta);
-    step(1, stb);
-    step(2, sta);
-    step(3, stb);
-  }
-  if (K < K1) step(0, sta);
-  if (K < K1) step(1, stb);
-  if (K < K1) step(2, sta);
-  uint32_t dd = d;
-  asm volatile("" : "+s"(dd));  // (keeps the 256 store addresses from being computed -- and spilled -- ahead of the loop)
-  if (!part) {
-    // wave A (planes 0, 1) finishes statement tiles 0..3, wave B (planes 2, 3) tiles 4..7: four rounds, one tile each way per round
-    uint32_t *xch = reinterpret_cast<uint32_t *>(&bits[0][0][0]) + (wave >> 1) * 2048;  // [2 directions][16][64] per pair
-    const uint32_t isB = wave & 1, k = ktl * 32 + r32;
-    const uint64_t ws = wc.wstride;
-    asm volatile("" : "+s"(cnt_delta), "+s"(tpoly));  // (as above: no loads of the epilogue ahead of the loop)
-    const uint64_t tk = tpoly[k];
-    const uint64_t P = MFH_P;
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      // hand over my half of the OTHER wave's tile
-      if (isB) {
-#pragma unroll
-        for (int e = 0; e < 16; e++) {
-          const uint32_t b = 32 * r + (e & 3) + 8 * (e >> 2) + 4 * h;
-          const uint32_t corr = b < nstmt ? 128u * cnt_delta[2 * b] : 0u;
-          xch[1024 + e * 64 + lane] = ((uint32_t)acc[r][0][e] + corr) + (((uint32_t)acc[r][1][e] + corr) << 8);
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 16; e++) {
-          const uint32_t b = 32 * (4 + r) + (e & 3) + 8 * (e >> 2) + 4 * h;
-          const uint32_t corr = b < nstmt ? 128u * cnt_delta[2 * b] : 0u;
-          xch[e * 64 + lane] = ((uint32_t)acc[4 + r][0][e] + corr) + (((uint32_t)acc[4 + r][1][e] + corr) << 8);
-        }
-      }
-      __syncthreads();
-      if (isB) {
-#pragma unroll
-        for (int e = 0; e < 16; e++) {
-          const uint32_t b = 32 * (4 + r) + (e & 3) + 8 * (e >> 2) + 4 * h;
-          if (b < nstmt) {
-            const uint32_t corr = 128u * cnt_delta[2 * b], delta = cnt_delta[2 * b + 1];
-            const uint64_t hi = ((uint32_t)acc[4 + r][0][e] + corr) + (((uint32_t)acc[4 + r][1][e] + corr) << 8);
-            const uint64_t val = (uint64_t)xch[e * 64 + lane] + (hi << 16);
-            w_out[(uint64_t)b * ws + k] = (uint32_t)((val % P + tk * delta % P) % P);
-          }
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 16; e++) {
-          const uint32_t b = 32 * r + (e & 3) + 8 * (e >> 2) + 4 * h;
-          if (b < nstmt) {
-            const uint32_t corr = 128u * cnt_delta[2 * b], delta = cnt_delta[2 * b + 1];
-            const uint64_t lo = ((uint32_t)acc[r][0][e] + corr) + (((uint32_t)acc[r][1][e] + corr) << 8);
-            const uint64_t val = lo + ((uint64_t)xch[1024 + e * 64 + lane] << 16);
-            w_out[(uint64_t)b * ws + k] = (uint32_t)((val % P + tk * delta % P) % P);
-          }
-        }
-      }
-      __syncthreads();
-    }
-    return;
-  }
-  int *dst = part + ((uint64_t)blockIdx.y * 4 + w0) * (32 * MT) * dd + ktl * 32 + r32 + (uint64_t)(4 * h) * dd;
-#pragma unroll
-  for (int w = 0; w < 2; w++)
-#pragma unroll
-    for (int t = 0; t < MT; t++) {
-#pragma unroll
-      for (int e = 0; e < 16; e++) dst[(uint64_t)((e & 3) + 8 * (e >> 2)) * dd] = acc[t][w][e];
-      dst += (uint64_t)32 * dd;
-    }
 }
 // The same pass over a GENERATOR-DEFINED SSP (csrc/ssp_prg.hpp; BASELINE configs 3/4, where the dense SSP would be 5.9 TB): the B
 // fragments are not loaded but generated -- lane (coefficient k, row half h) hashes its 16 (row, k) pairs (9 integer operations each; the
@@ -1103,7 +962,7 @@ __global__ __launch_bounds__(256) void k_witness_mm_prg(const uint32_t *__restri
 // publishes dword j of all four planes' fragments through LDS (a three-slot ring: the hashes of step K + 2 are issued between the MFMAs
 // of step K, the fragment of step K + 1 is read during step K; the row keys are loaded four steps ahead), wave w
 // reads plane w's fragment with one 16-byte load.  4 hashes and 8 MFMAs per wave and step, and with two waves per SIMD one wave's
-// hashes run under the other's MFMAs (a first version on k_witness_mm8's wave pairs, one wave per SIMD with 256 accumulators and the
+// hashes run under the other's MFMAs (a first version on wave pairs, one wave per SIMD with 256 accumulators and the
 // hashes shared two ways, took 0.89 s per 248 statements at 2^20 constraints against 0.83: nothing overlaps the matrix pipe there).
 // Chunk partials only (k_witness_mm_finish).  grid = (d / 64, row chunks), block = 8 waves = 2 coefficient tiles x 4 planes.
 __global__ __launch_bounds__(512) void k_witness_mm8q_prg(const uint32_t *__restrict__ rowkeys, const v4i *__restrict__ bitfrag, uint32_t nrowsel /* m - 1 */,
@@ -1198,6 +1057,131 @@ __global__ __launch_bounds__(512) void k_witness_mm8q_prg(const uint32_t *__rest
 #pragma unroll
     for (int e = 0; e < 16; e++) dst[(uint64_t)((e & 3) + 8 * (e >> 2)) * dd] = acc[t][e];
     dst += (uint64_t)32 * dd;
+  }
+}
+// 256 statements (a whole super-group of 248) in ONE read of the dense SSP.  8 statement tiles x 4 byte planes are 512 accumulator
+// registers per 32-coefficient tile: the four planes go to four waves (128 registers each, two waves per SIMD; a workgroup = 2
+// coefficient tiles x 4 planes), the eight bit fragments of a row step -- 8 KiB, the same for all eight waves -- go through a four-slot
+// LDS ring (fetched straight from L2 by every wave they made a first version L1-bound: 2.26 ms against 2 x 0.59 for two 124-statement
+// passes) and are read from it a step ahead, under the previous step's MFMAs.  Vector-memory operations complete in issue order, so
+// EVERY load of the loop is consumed exactly PF steps after its issue (the plane's fragment of step K + PF, the bit fragment of step
+// K + 2 + PF, staged in registers and stored to the ring two steps ahead of its use), and the prologue issues its loads in the order
+// the loop does, pinned: s_waitcnt vmcnt(n) is a static count of younger loads and the compiler takes the minimum over the paths into
+// the loop (with the bit fragments staged two steps ahead, or all of them loaded first, it emitted vmcnt(4..9) where the steady state
+// allows 12: the stream was awaited one or two steps after its issue whatever PF).  Timing-only builds split the pass: the stream
+// alone 0.53 ms per 248 statements (5.4 TB/s), MFMAs + LDS alone 0.54, together 0.77 -- with one wave per SIMD (wave pairs, two
+// planes each: the first version) as with two; the chip does not hold its clock under both.
+// part == nullptr (one row chunk, m < 2^16): the four waves exchange their plane sums through LDS, one statement tile per round, and the
+// tile's owner writes w_b[k] = delta_b t[k] + the byte sum mod p (what k_witness_mm_finish does from chunk partials: 0.5 GB written and
+// read back per 248 statements otherwise).  grid = (d / 64, row chunks), block = 8 waves.
+__global__ __launch_bounds__(512) void k_witness_mm8q(const v4i *__restrict__ sspfrag, const v4i *__restrict__ bitfrag, uint32_t nrowsel /* m - 1 */,
+                                                      uint32_t ksteps_per_chunk, uint32_t d, int *__restrict__ part, const uint32_t *__restrict__ tpoly /* + col0 */,
+                                                      const uint32_t *__restrict__ cnt_delta, uint32_t nstmt, uint32_t *__restrict__ w_out, WCols wc) {
+  constexpr int MT = 8, RING = 4, PF = 4;
+  __shared__ v4i bits[RING][MT][64];      // 32 KiB
+  __shared__ uint32_t xch[2][3][16][64];  // the epilogue's exchange: [coefficient tile][sending wave (owner skipped)][e][lane], 24 KiB
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t r32 = lane & 31, h = lane >> 5;
+  const uint32_t tile = wave >> 2, pl = wave & 3;
+  const uint32_t ktl = blockIdx.x * 2 + tile, kt = wc.kt0 + ktl;
+  const uint32_t K0 = blockIdx.y * ksteps_per_chunk, K1 = min((nrowsel + 31) / 32, K0 + ksteps_per_chunk);
+  v16i acc[MT];
+#pragma unroll
+  for (int t = 0; t < MT; t++)
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[t][e] = 0;
+  if (K0 >= K1) return;  // (uniform)
+  auto bits_load = [&](uint32_t K) -> v4i { return bitfrag[(uint64_t)min(K, K1 - 1) * MT * 64 + tid]; };  // 512 elements per step: one per thread
+  auto bits_store = [&](uint32_t K, v4i st) { (&bits[K % RING][0][0])[tid] = st; };
+  auto ssp_load = [&](uint32_t K) -> v4i { return sspfrag[(((uint64_t)kt * wc.KS + min(K, K1 - 1)) * 4 + pl) * 64 + lane]; };
+  v4i stg[PF], bq[PF];
+  {
+    const v4i s0 = bits_load(K0), s1 = bits_load(K0 + 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < PF; i++) {  // (in the order the loop issues them)
+      bq[i] = ssp_load(K0 + i);
+      stg[i] = bits_load(K0 + 2 + i);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    bits_store(K0, s0);
+    bits_store(K0 + 1, s1);
+  }
+  __syncthreads();
+  v4i acur[MT];
+#pragma unroll
+  for (int t = 0; t < MT; t++) acur[t] = bits[K0 % RING][t][lane];
+  uint32_t K = K0;
+  auto step = [&](int slot) {
+    bits_store(K + 2, stg[slot]);
+    v4i anext[MT];
+    const v4i *aq = &bits[(K + 1) % RING][0][lane];
+#pragma unroll
+    for (int t = 0; t < MT; t++) anext[t] = aq[t * 64];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < MT; t++) acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(acur[t], bq[slot], acc[t], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    bq[slot] = ssp_load(K + PF);
+    stg[slot] = bits_load(K + 2 + PF);
+#pragma unroll
+    for (int t = 0; t < MT; t++) acur[t] = anext[t];
+    __syncthreads();
+    K++;
+  };
+  for (; K + PF <= K1;) {
+#pragma unroll
+    for (int i = 0; i < PF; i++) step(i);
+  }
+#pragma unroll
+  for (int i = 0; i + 1 < PF; i++)
+    if (K < K1) step(i);
+  uint32_t dd = d;
+  asm volatile("" : "+s"(dd));  // (keeps the store addresses from being computed ahead of the loop)
+  if (part) {
+    int *dst = part + ((uint64_t)blockIdx.y * 4 + pl) * (32 * MT) * dd + ktl * 32 + r32 + (uint64_t)(4 * h) * dd;
+#pragma unroll
+    for (int t = 0; t < MT; t++) {
+#pragma unroll
+      for (int e = 0; e < 16; e++) dst[(uint64_t)((e & 3) + 8 * (e >> 2)) * dd] = acc[t][e];
+      dst += (uint64_t)32 * dd;
+    }
+    return;
+  }
+  // statement tile t is finished by wave t >> 1 of the coefficient tile: the other three hand over their plane sums (acc + 128 cnt_b:
+  // the true byte sum, < 2^24 for m < 2^16), one statement tile per round
+  asm volatile("" : "+s"(cnt_delta), "+s"(tpoly));
+  const uint32_t k = ktl * 32 + r32;
+  const uint64_t tk = tpoly[k], ws = wc.wstride, P = MFH_P;
+#pragma unroll
+  for (int t = 0; t < MT; t++) {
+    const uint32_t owner = t >> 1;
+    uint32_t mine[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+      const uint32_t b = 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h;
+      mine[e] = (uint32_t)acc[t][e] + (b < nstmt ? 128u * cnt_delta[2 * b] : 0u);
+    }
+    if (pl != owner) {  // (wave-uniform)
+      const uint32_t sidx = pl - (pl > owner);
+#pragma unroll
+      for (int e = 0; e < 16; e++) xch[tile][sidx][e][lane] = mine[e];
+    }
+    __syncthreads();
+    if (pl == owner) {
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        const uint32_t b = 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (b < nstmt) {
+          uint64_t val = (uint64_t)mine[e] << (8 * owner);
+#pragma unroll
+          for (int o = 0; o < 4; o++)
+            if (o != (int)owner) val += (uint64_t)xch[tile][o - (o > (int)owner)][e][lane] << (8 * o);
+          w_out[(uint64_t)b * ws + k] = (uint32_t)((val % P + tk * cnt_delta[2 * b + 1] % P) % P);
+        }
+      }
+    }
+    __syncthreads();
   }
 }
 // bits of nstmt statements (packed, bits_stride bytes apart) -> A fragments: bitfrag[K][t][lane (stmt = 32 t + (l & 31), h)][e] = bit
@@ -1585,7 +1569,7 @@ int mfh_witness_poly_mm_cols(mfh_ctx *c, const uint32_t *d_ssp, uint32_t nstmt, 
   if (ncols == 0) return MFH_OK;
   if (col0 % 128 || ncols % 128) { c->err = "mfh_witness_poly_mm_cols: the coefficient range must start and end at multiples of 128"; return MFH_EUNSUPPORTED; }
   const uint32_t nc = ncols;
-  const WCols wc = {col0 / 32, d / 32, (uint64_t)w_stride};
+  const WCols wc = {col0 / 32, (m - 1 + 31) / 32, (uint64_t)w_stride};
   const uint32_t *tpoly = src.t + col0;
   for (uint32_t b = 0; b < nstmt; b++)
     if (h_delta[b] >= MFH_P) { c->err = "delta must be < p"; return MFH_EINVAL; }
@@ -1643,7 +1627,7 @@ int mfh_witness_poly_mm_cols(mfh_ctx *c, const uint32_t *d_ssp, uint32_t nstmt, 
     else if (MT == 2) hipLaunchKernelGGL(k_witness_mm_prg<2>, grid, dim3(256), 0, c->stream, d_rk, (const v4i *)d_frag, nrowsel, kpc, nc, d_part, wc);
     else hipLaunchKernelGGL(k_witness_mm_prg<4>, grid, dim3(256), 0, c->stream, d_rk, (const v4i *)d_frag, nrowsel, kpc, nc, d_part, wc);
   } else if (MT == 8) {
-    hipLaunchKernelGGL(k_witness_mm8, dim3(nc / 64, (ksteps + kpc - 1) / kpc), dim3(256), 0, c->stream, (const v4i *)c->ssp_frag, (const v4i *)d_frag, nrowsel, kpc, nc,
+    hipLaunchKernelGGL(k_witness_mm8q, dim3(nc / 64, (ksteps + kpc - 1) / kpc), dim3(512), 0, c->stream, (const v4i *)c->ssp_frag, (const v4i *)d_frag, nrowsel, kpc, nc,
                        fused ? (int *)nullptr : d_part, tpoly, d_cd, nstmt, d_w, wc);
     if (fused) {
       HIP_TRY(c, hipGetLastError());
