@@ -589,7 +589,7 @@ int batch_chain_launch(mfh_ctx *c, const mf::SspSrc &src, const uint32_t *d_ssp,
   // d % 128 == 0: a GEMM on the matrix cores, one read (dense SSP) or one generation (generator-defined SSP) of the selected rows per
   // 124 statements; otherwise the VALU form, read or generated once per 12 statements
   if (d % 128 == 0) {
-    // the whole super-group (248 statements) in one read (dense SSP) or one generation (generator-defined SSP) of the rows: k_witness_mm8
+    // the whole super-group (248 statements) in one read (dense SSP) or one generation (generator-defined SSP) of the rows: k_witness_mm8q / k_witness_mm8q_prg
     static const uint32_t per_env = [] { const char *e = getenv("MFH_WITNESS_PER"); return e ? (uint32_t)atoi(e) : 0u; }();  // (A/B knob)
     const uint32_t per = per_env ? std::min(per_env, 256u) : 248u;
     for (uint32_t b0 = 0; b0 < sg; b0 += per) {

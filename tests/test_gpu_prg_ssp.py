@@ -224,8 +224,8 @@ def test_config4_row_sharded_batch_emulated_on_one_gpu(gpu_ctx_factory, mf):
 @pytest.mark.parametrize("d,m,nstmt", [(256, 70, 1), (256, 70, 33), (384, 1000, 65), (128, 333, 124), (256, 70, 129), (128, 1100, 248), (256, 2300, 256), (128, 4001, 200)])
 def test_generator_defined_witness_pass_on_the_matrix_cores(gpu_ctx_factory, mf, d, m, nstmt):
     """mfh_witness_poly_mm with d_ssp = NULL: the B fragments of the bits x SSP-bytes GEMM are generated in the kernel (k_witness_mm_prg)
-    instead of loaded; above 128 statements by k_witness_mm8<PRG>, whose wave pairs share the generation through LDS -- one row chunk
-    finished in the kernel up to 64 row steps, several chunks and a finishing kernel above.  Same polynomials as the single-statement VALU pass over the generator (mfh_witness_poly) and as the GEMM over the
+    instead of loaded; above 128 statements by k_witness_mm8q_prg, whose four waves per coefficient tile share the hashes through LDS
+    (chunk partials + finishing kernel).  Same polynomials as the single-statement VALU pass over the generator (mfh_witness_poly) and as the GEMM over the
     dense image of the same SSP, also for all-zero / all-one witnesses."""
     import torch
 
