@@ -695,11 +695,11 @@ __global__ __launch_bounds__(SW * 64) void k_mmstream(MmsImages imgs, uint32_t m
 // in LDS; the lq = 0 threads then add, per output word, the pieces of val_l, val_(l-1), val_(l-2) with the running carry (22 | 46 adds
 // on LDS data) and write the element in 16-byte (LL even: 96-byte elements) or 8-byte pieces: the elements of neighbouring threads lie a
 // ciphertext apart, so every store is its own memory transaction.
-template <int ND>
+template <int ND, int KWM /* 32-bit words of a value that survive modq, at most: sizes the LDS exchange (22 at logq 736, 46 at 1472) */>
 __device__ __forceinline__ void evalmm_finish_body(const int *__restrict__ part, const int64_t *__restrict__ sc, uint32_t nchunks, uint32_t ntiles, uint32_t N,
                                                    uint32_t nvec, uint32_t n, uint32_t nrows, uint32_t ct, uint32_t MBv, uint32_t sby, uint32_t LL,
                                                    const MmIo &io, int accumulate) {
-  __shared__ uint32_t sv[46][3][64];
+  __shared__ uint32_t sv[KWM][3][64];  // (17 KiB at logq 736: six workgroups per CU instead of the four that 35 KiB allow)
   const uint32_t vl = threadIdx.x & 63, lq = threadIdx.x >> 6;
   const uint32_t v = blockIdx.y * 64 + vl, j = blockIdx.x;
   const uint32_t tile = j / ct, jj = j % ct;
@@ -759,19 +759,19 @@ __device__ __forceinline__ void evalmm_finish_body(const int *__restrict__ part,
   }
 }
 
-template <int ND>
+template <int ND, int KWM>
 __global__ __launch_bounds__(256) void k_evalmm_finish(const int *__restrict__ part, const int64_t *__restrict__ sc, uint32_t nchunks, uint32_t ntiles,
                                                         uint32_t N, uint32_t nvec, uint32_t n, uint32_t nrows, uint32_t ct, uint32_t MBv, uint32_t sby,
                                                         uint32_t LL, MmIo io, int accumulate) {
-  evalmm_finish_body<ND>(part, sc, nchunks, ntiles, N, nvec, n, nrows, ct, MBv, sby, LL, io, accumulate);
+  evalmm_finish_body<ND, KWM>(part, sc, nchunks, ntiles, N, nvec, n, nrows, ct, MBv, sby, LL, io, accumulate);
 }
 // all groups of a round in one launch: blockIdx.z = group, its partial products at part + group * part_stride
-template <int ND>
+template <int ND, int KWM>
 __global__ __launch_bounds__(256) void k_evalmm_finish_groups(const int *__restrict__ part, uint64_t part_stride, uint32_t nchunks, uint32_t ntiles, uint32_t N,
                                                                uint32_t n, uint32_t nrows, uint32_t ct, uint32_t MBv, uint32_t sby, uint32_t LL, MmGroupArgs A,
                                                                int accumulate) {
   const uint32_t g = blockIdx.z;
-  evalmm_finish_body<ND>(part + g * part_stride, A.io[g].sc_zeroed, nchunks, ntiles, N, A.nvec[g], n, nrows, ct, MBv, sby, LL, A.io[g], accumulate);
+  evalmm_finish_body<ND, KWM>(part + g * part_stride, A.io[g].sc_zeroed, nchunks, ntiles, N, A.nvec[g], n, nrows, ct, MBv, sby, LL, A.io[g], accumulate);
 }
 
 // ---- the witness pass of up to 32 statements as a GEMM over the SSP rows (one read of the SSP) ---------------------------------------
@@ -1225,6 +1225,13 @@ static WideGeom wide_geom(const mfh_ctx *c) {
   return {W16<1472>::CT, W16<1472>::SBY, W16<1472>::VBY, W16<1472>::MT, W16<1472>::MBP, W16<1472>::LL};
 }
 
+// the epilogue kernels are instantiated per modulus: the LDS exchange holds 22 (logq 736) or 46 (1472) words per value
+#define FINISH_LAUNCH(kern, ND_, grid, ...)                                                                         \
+  do {                                                                                                              \
+    if (wg.sby / 4 <= 22) hipLaunchKernelGGL((kern<ND_, 22>), grid, dim3(256), 0, c->stream, __VA_ARGS__);          \
+    else hipLaunchKernelGGL((kern<ND_, 46>), grid, dim3(256), 0, c->stream, __VA_ARGS__);                           \
+  } while (0)
+
 int mfh_eval_rows_multi(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d_c8, const uint32_t *d_coeffs, uint32_t nvec, uint32_t coeff_bytes,
                         uint64_t *d_rops, int accumulate) {
   if (!c || !d_rops || !nvec || (nrows && (!d_c8 || !d_coeffs)) || (coeff_bytes != 1 && coeff_bytes != 4)) return MFH_EINVAL;
@@ -1319,11 +1326,9 @@ int eval_rows_multi_io(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d_
   const uint32_t sby = wide ? wg.sby : SB;
   const dim3 fgrid(n + 1, (nvec + 63) / 64);
   if (ND == 4)
-    hipLaunchKernelGGL(k_evalmm_finish<4>, fgrid, dim3(256), 0, c->stream, part, sc, nchunks, ntiles, N, nvec, n, (uint32_t)nrows, ct, mb, sby, wg.LL, io,
-                       accumulate);
+    FINISH_LAUNCH(k_evalmm_finish, 4, fgrid, part, sc, nchunks, ntiles, N, nvec, n, (uint32_t)nrows, ct, mb, sby, wg.LL, io, accumulate);
   else
-    hipLaunchKernelGGL(k_evalmm_finish<1>, fgrid, dim3(256), 0, c->stream, part, sc, nchunks, ntiles, N, nvec, n, (uint32_t)nrows, ct, mb, sby, wg.LL, io,
-                       accumulate);
+    FINISH_LAUNCH(k_evalmm_finish, 1, fgrid, part, sc, nchunks, ntiles, N, nvec, n, (uint32_t)nrows, ct, mb, sby, wg.LL, io, accumulate);
   HIP_TRY(c, hipGetLastError());
   return MFH_OK;
 }
@@ -1413,8 +1418,8 @@ int mms_finish(mfh_ctx *c, const MmsPlan &P, const MmIo *ios, const uint32_t *nv
   if (mms_group_args(P, ios, nvecs, A)) {
     uint32_t nvmax = 0;
     for (uint32_t g = 0; g < P.ngt; g++) nvmax = std::max(nvmax, nvecs[g]);
-    hipLaunchKernelGGL(k_evalmm_finish_groups<4>, dim3(n + 1, (nvmax + 63) / 64, P.ngt), dim3(256), 0, c->stream, P.part, (uint64_t)(P.part_bytes / 4), P.nchunks,
-                       P.ntiles, (uint32_t)N2, n, P.nrows, wg.ct, wg.mbp, wg.sby, wg.LL, A, accumulate);
+    FINISH_LAUNCH(k_evalmm_finish_groups, 4, dim3(n + 1, (nvmax + 63) / 64, P.ngt), P.part, (uint64_t)(P.part_bytes / 4), P.nchunks, P.ntiles, (uint32_t)N2, n, P.nrows,
+                  wg.ct, wg.mbp, wg.sby, wg.LL, A, accumulate);
     HIP_TRY(c, hipGetLastError());
     return MFH_OK;
   }
@@ -1422,11 +1427,11 @@ int mms_finish(mfh_ctx *c, const MmsPlan &P, const MmIo *ios, const uint32_t *nv
     const dim3 fgrid(n + 1, (nvecs[g] + 63) / 64);
     int *pg = P.part + g * (P.part_bytes / 4);
     if (P.ND == 4)
-      hipLaunchKernelGGL(k_evalmm_finish<4>, fgrid, dim3(256), 0, c->stream, pg, ios[g].sc_zeroed, P.nchunks, P.ntiles, (uint32_t)N2, nvecs[g], n, P.nrows, wg.ct,
-                         wg.mbp, wg.sby, wg.LL, ios[g], accumulate);
+      FINISH_LAUNCH(k_evalmm_finish, 4, fgrid, pg, ios[g].sc_zeroed, P.nchunks, P.ntiles, (uint32_t)N2, nvecs[g], n, P.nrows, wg.ct, wg.mbp, wg.sby, wg.LL, ios[g],
+                    accumulate);
     else
-      hipLaunchKernelGGL(k_evalmm_finish<1>, fgrid, dim3(256), 0, c->stream, pg, ios[g].sc_zeroed, P.nchunks, P.ntiles, (uint32_t)N2, nvecs[g], n, P.nrows, wg.ct,
-                         wg.mbp, wg.sby, wg.LL, ios[g], accumulate);
+      FINISH_LAUNCH(k_evalmm_finish, 1, fgrid, pg, ios[g].sc_zeroed, P.nchunks, P.ntiles, (uint32_t)N2, nvecs[g], n, P.nrows, wg.ct, wg.mbp, wg.sby, wg.LL, ios[g],
+                    accumulate);
   }
   HIP_TRY(c, hipGetLastError());
   return MFH_OK;
