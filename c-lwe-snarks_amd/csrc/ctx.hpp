@@ -197,6 +197,10 @@ struct MmIo {
   uint64_t cstride;
   // bits: the launch covers rows [bits_row0, bits_row0 + nrows) of the BT+BV region (a rank's share): local row i <-> bit bits_row0 + i - 1
   uint32_t bits_row0;
+  // optional: out_v += scale[v] * ct (ct_addmul_ui, src/lwe.c:141-149) in the epilogue, before the carries are resolved -- b_w's
+  // delta_b * ct_t term (src/snark.c:143-145); add_ct = one ciphertext (n + 1 values of L limbs), add_scale = one uint32 < p per vector
+  const uint64_t *add_ct;
+  const uint32_t *add_scale;
 };
 int eval_rows_multi_io(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d_c8, const MmIo &io, uint32_t nvec, uint32_t coeff_bytes, int accumulate);
 // ng of them over the same region in one streaming launch when the matrix-core image is registered (io.sc_zeroed required); else one by one

@@ -737,11 +737,19 @@ __device__ __forceinline__ void evalmm_finish_body(const int *__restrict__ part,
   const bool wide4 = (LL & 1) == 0 && (io.ostride & 1) == 0 && ((reinterpret_cast<uintptr_t>(io.out[0]) | reinterpret_cast<uintptr_t>(io.out[1])) & 15) == 0;
   uint32_t pend[4] = {0, 0, 0, 0};
   uint64_t carry = 0;
+  const uint32_t *actw = io.add_ct ? reinterpret_cast<const uint32_t *>(io.add_ct + (uint64_t)j * LL) : nullptr;
+  const uint64_t ax = io.add_ct ? io.add_scale[v] : 0;
+  uint64_t acarry = 0;
   for (uint32_t l = 0; l < KWv; l++) {
     uint64_t word = carry + sv[l][0][vl];
     if (l >= 1) word += sv[l - 1][1][vl];
     if (l >= 2) word += sv[l - 2][2][vl];
     if (accumulate) word += out[l];
+    if (actw) {  // + scale * ct: one 32 x 32 product per word, its high half carried into the next word
+      const uint64_t t = (uint64_t)actw[l] * ax + acarry;
+      word += (uint32_t)t;
+      acarry = t >> 32;
+    }
     carry = word >> 32;
     pend[l & 3] = (uint32_t)word;
     if (wide4 ? (l & 3) == 3 : (l & 1) == 1) {

@@ -634,14 +634,11 @@ int batch_bw(mfh_ctx *c, const uint8_t *d_crs_c8, uint32_t rank, uint32_t world,
   const uint32_t bstride = (m + 6) / 8;
   MmIo io_bw = {{nullptr, nullptr}, sg, {sproofs + 4 * ctl, nullptr}, sg, pstride, d_cw, bstride, B.SCZ + 256 * slot++};
   io_bw.bits_row0 = lo;
-  int rc = eval_rows_multi_io(c, ctr_ct * ((uint64_t)2 * d + lo), cnt, d_crs_c8 + ((size_t)2 * d + lo) * ctb, io_bw, sg, 1, accumulate);
-  if (rc) return rc;
-  if (has_delta) {  // + delta_b ct_t for the sg proofs in one launch
-    hipLaunchKernelGGL(k_bw_add_delta_ct, dim3((n + 1 + 255) / 256, sg), dim3(256), 0, c->stream, sproofs, B.CT_T, (const uint32_t *)(d_cw + B.cw_delta_off), n + 1,
-                       (c->P.logq + 63) / 64, 2 * (c->P.logq / 64));
-    HIP_TRY(c, hipGetLastError());
+  if (has_delta) {  // + delta_b ct_t (src/snark.c:143-145) in the launch's epilogue
+    io_bw.add_ct = B.CT_T;
+    io_bw.add_scale = (const uint32_t *)(d_cw + B.cw_delta_off);
   }
-  return MFH_OK;
+  return eval_rows_multi_io(c, ctr_ct * ((uint64_t)2 * d + lo), cnt, d_crs_c8 + ((size_t)2 * d + lo) * ctb, io_bw, sg, 1, accumulate);
 }
 // d_cw: the super-group's staged area (batch_stage_host), or nullptr: staged here from h_bits / h_delta.
 int batch_rows_supergroup(mfh_ctx *c, const uint8_t *d_crs_c8, uint32_t rank, uint32_t world, uint32_t sg, const uint8_t *h_bits,
