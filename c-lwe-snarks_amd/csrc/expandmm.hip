@@ -133,7 +133,13 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     }
     if (P < mtiles) {
       char *frag = reinterpret_cast<char *>(image) + ((uint64_t)P * KS + ks) * 1024;  // (scalar)
-      *reinterpret_cast<v4i *>(frag + lane16) = v4i{(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
+      // (the lane's 16-byte offset is RECOMPUTED for every piece, from an opaque zero: kept live -- alone or, hoisted by the optimiser, as
+      // the 64-bit pair image + 16 lane -- it is what the register allocator spills at 64 VGPRs, and the reload sat before every store
+      // behind an s_waitcnt vmcnt(0): every piece waited for all stores before it)
+      uint32_t z = 0;
+      asm volatile("" : "+s"(z));
+      const uint32_t l16 = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z)) << 4;
+      *reinterpret_cast<v4i *>(frag + l16) = v4i{(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
     }
   };
 
