@@ -710,11 +710,23 @@ __device__ __forceinline__ void evalmm_finish_body(const int *__restrict__ part,
     for (int w = 0; w < ND; w++) corr[w] = 128 * sc[ND * v + w] + 16384ll * nrows;
     for (uint32_t l = lq; l < KWv; l += 4) {
       unsigned __int128 val = 0;
+      // the first chunk's partial products of the word's four byte positions are loaded TOGETHER (eight loads in flight per thread; read
+      // position by position, each pair of loads was awaited before the next was issued), further chunks -- rare -- one by one
+      int g0[4][ND], sa0[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int *row = part + ((uint64_t)tile * MBv + (jj * sby + 4 * l + k)) * N;
+#pragma unroll
+        for (int w = 0; w < ND; w++) g0[k][w] = row[ND * v + w];
+        sa0[k] = row[ND * nvec];
+      }
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         const uint32_t mm = jj * sby + 4 * l + k;
-        int64_t g[ND] = {}, sa = 0;
-        for (uint32_t ch = 0; ch < nchunks; ch++) {
+        int64_t g[ND], sa = sa0[k];
+#pragma unroll
+        for (int w = 0; w < ND; w++) g[w] = g0[k][w];
+        for (uint32_t ch = 1; ch < nchunks; ch++) {
           const int *row = part + (((uint64_t)ch * ntiles + tile) * MBv + mm) * N;
 #pragma unroll
           for (int w = 0; w < ND; w++) g[w] += row[ND * v + w];
