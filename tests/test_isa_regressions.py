@@ -63,3 +63,78 @@ def test_aes_kernels_do_not_spill_in_the_loop(asm):
     body = _kernel(asm, "_Z6k_evalILi736ELi2E")
     ops = _hottest_loop(body)
     assert not any(o.startswith("scratch_") for o in ops)
+
+
+# ---- round 2: guards on the waits and spills that cost measurable time when they regressed -------------------
+def _asm_of(tmp_path_factory, name):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("isa_" + name) / (name + ".s")
+    src = os.path.join(ROOT, "c-lwe-snarks_amd", "csrc", name + ".hip")
+    subprocess.check_call([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"),
+                           "-I" + os.path.join(ROOT, "c-lwe-snarks_amd", "csrc"), "-S", "--cuda-device-only", "-o", str(out), src],
+                          stderr=subprocess.DEVNULL)
+    return out.read_text()
+
+
+@pytest.fixture(scope="module")
+def asm_evalmm(tmp_path_factory):
+    return _asm_of(tmp_path_factory, "evalmm")
+
+
+def _loops(body):
+    """(label, [instruction lines]) of every single-block loop of a kernel"""
+    lines = body.splitlines()
+    out = []
+    for i, ln in enumerate(lines):
+        m = re.match(r"^(\.LBB\d+_\d+):", ln)
+        if not m:
+            continue
+        for k in range(i + 1, len(lines)):
+            if re.match(r"^\.LBB\d+_\d+:", lines[k]):
+                break
+            if re.search(r"s_cbranch_\w+\s+%s\b" % re.escape(m.group(1)), lines[k]):
+                out.append((m.group(1), [x.strip() for x in lines[i + 1:k] if x.strip() and not x.strip().startswith(";")]))
+                break
+    return out
+
+
+def _mfma_loop(body, min_mfma):
+    best = max((l for _, l in _loops(body)), key=lambda l: sum("v_mfma" in x for x in l), default=[])
+    assert sum("v_mfma" in x for x in best) >= min_mfma, "the kernel's MFMA loop was not found"
+    return best
+
+
+def test_witness_gemm_loads_are_awaited_four_steps_after_issue(asm_evalmm):
+    """k_witness_mm8q: per step a wave issues one SSP fragment load and one bit fragment load, both consumed four steps later, so the
+    only vector-memory waits of the loop are s_waitcnt vmcnt(6) / vmcnt(7) (two loads per step x 3 younger steps, + the step's own);
+    smaller counts mean the compiler fell back to awaiting the stream a step or two after its issue (0.76 ms per 248 statements whatever
+    the prefetch depth).  And nothing of the loop lives in scratch."""
+    loop = _mfma_loop(_kernel(asm_evalmm, "_ZN12_GLOBAL__N_114k_witness_mm8qE"), 32)
+    waits = [int(m.group(1)) for x in loop for m in [re.search(r"s_waitcnt vmcnt\((\d+)\)", x)] if m]
+    assert waits and min(waits) >= 6, waits
+    assert not any(x.startswith("scratch_") for x in loop)
+
+
+def test_streaming_gemm_waits_one_stage_behind(asm_evalmm):
+    """k_mmstream: the A fragments of stage s + 1 and the digit fragments of stage s + 2 are awaited one stage (16 younger loads minus the
+    k-step's own) after their issue: vmcnt(12) / vmcnt(13), never a single-digit count inside the stage loop"""
+    loop = _mfma_loop(_kernel(asm_evalmm, "_ZN12_GLOBAL__N_110k_mmstreamE"), 128)
+    waits = [int(m.group(1)) for x in loop for m in [re.search(r"s_waitcnt vmcnt\((\d+)\)", x)] if m]
+    assert waits and min(waits) >= 12, waits
+    assert not any(x.startswith("scratch_") for x in loop)
+
+
+def test_expansion_kernel_has_no_scratch(tmp_path_factory):
+    """k_expand_mm at 64 VGPRs (8 waves per SIMD): the lane offset of a piece's store is recomputed per piece; kept live it was spilled and
+    reloaded before every store behind s_waitcnt vmcnt(0)"""
+    asm = _asm_of(tmp_path_factory, "expandmm")
+    for k in ("_ZN12_GLOBAL__N_111k_expand_mmILi736E", "_ZN12_GLOBAL__N_111k_expand_mmILi1472E"):
+        assert "scratch_" not in _kernel(asm, k), k
+
+
+def test_ntt_block_kernel_reads_its_twiddles_from_lds(tmp_path_factory):
+    """k_ntt_lds_mul8: 8 point loads (+ the cached transform of the other factor) and the twiddle staging are its only global loads -- the
+    88 twiddle reads per thread come from LDS (as global gathers they bound the kernel: 0.43 against 0.27 ms per 248 x 3 transforms)"""
+    body = _kernel(_asm_of(tmp_path_factory, "poly"), "_ZN12_GLOBAL__N_114k_ntt_lds_mul8E")
+    assert len(re.findall(r"^\s+global_load_dword\b", body, re.M)) <= 20
