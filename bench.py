@@ -155,6 +155,40 @@ def _cpu_rows_worker(args):
     return time.perf_counter() - t0
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU) and wait for them.  This parent has
+    not touched the GPU (no torch import, no HIP call) and never does: every child is a new interpreter that reads RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* like a rank started by `python -m torch.distributed.run`.  Rank 0 prints the JSON line on the inherited
+    stdout.  Exit code: 0 only if every rank exited 0; when one fails the others are ended (by PID) and its code is returned."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk_:
+        sk_.bind(("127.0.0.1", 0))
+        port = sk_.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), MFUOCO_BENCH_LAUNCHER="self")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    live = list(procs)
+    while live:
+        for pr in list(live):
+            code = pr.poll()
+            if code is None:
+                continue
+            live.remove(pr)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"[bench] rank process {procs.index(pr)} exited with {code}: ending the other ranks", file=sys.stderr, flush=True)
+                for other in live:
+                    other.terminate()
+        time.sleep(0.05)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -181,14 +215,21 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=20000, help="rows of the CPU baseline sample (~0.65 ms each on one core)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args.gpus)  # no launcher: be one (before anything touches the GPU)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:  # the line would claim a rank count the job does not have
+        if rank == 0:
+            print(f"[bench] error: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr, flush=True)
+        return 2
+
     import torch
 
     import c_lwe_snarks_amd as mf
     from c_lwe_snarks_amd import dist as mfdist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         import torch.distributed as dist
 
@@ -205,8 +246,9 @@ def main():
     else:
         dist = None
         torch.cuda.set_device(0)
-    if world != args.gpus and rank == 0:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if dist is not None and dist.get_world_size() != args.gpus:
+        print(f"[bench] error: {dist.get_world_size()} ranks joined the process group, --gpus {args.gpus}", file=sys.stderr, flush=True)
+        return 2
 
     big = args.workload != "default"
     p = mf.DEFAULT if not big else mf.Params(logq=736 if args.workload == "config4" else 1472, d=1 << 20, m=699050)
@@ -590,6 +632,10 @@ def main():
                           "bytes_sent_per_rank": per_s * 3 * 4 * (p.d - p.d // world)},
                          {"op": "reduce_scatter_tensor(sum, int64 lanes)", "what": "one uint64 lane per surviving 32-bit word of the 5 partial ciphertexts of every statement",
                           "input_bytes_per_rank": per_s * world * lps * 8, "output_bytes_per_rank": per_s * lps * 8}],
+                     "reduce_scatter_bytes_per_rank_per_step": {"in": per_s * world * lps * 8, "out": per_s * lps * 8},
+                     "note": ("the reduce-scatter carries 1.29 MB of uint64 lanes per statement into every rank whatever the instance size, while the row work per "
+                              "rank shrinks with D / N: at the default instance (D = 2^15) this leg is collective-bound and REPLICAS (the headline `value`) are "
+                              "the better use of N GPUs; row sharding is for CRS images that do not fit one GPU (config 4/5: 45 / 90 GB per GPU on 8)"),
                      "image_share_bytes_per_rank": share_img,
                      "image": "transient: every call expands the rank's row shares (AES on the CU) inside the timed region" if kt_s["expandmm"][0] else
                               ("regenerated per group" if kt_s["evalmm"][0] else "resident"),
@@ -758,6 +804,16 @@ def main():
             "value": head["value"],
             "unit": "proofs/s",
             "n_gpus": world,
+            "ranks": world,
+            "launcher": os.environ.get("MFUOCO_BENCH_LAUNCHER", "external (torch.distributed.run)" if world > 1 else None),
+            "backend": (backend + (" (RCCL over xGMI, device tensors)" if backend == "nccl" else " (host-staged rehearsal)")) if world > 1 else None,
+            "collectives": {
+                "in_value": ([c["op"] for c in sharded_b["collectives_per_step"]] if (mode == "batch" and batched is None and sharded_b and not sharded_b.get("error"))
+                             else ([c["op"] for c in single["collectives_per_proof"]] if mode == "single" and single else [])),
+                "timing_only": (["barrier before and after the timed steps", "all_reduce(MAX) of the elapsed time", "all_reduce(MIN) of the acceptance flag"] if world > 1 else []),
+                "data_path_calls_on_rank0_all_legs": mfdist.collectives_snapshot(),
+                "note": ("value = replicas: ranks prove disjoint statements, nothing is exchanged inside the timed steps" if (mode == "batch" and batched is not None and world > 1)
+                         else None)},
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": head["ms_per_step"],

@@ -516,7 +516,10 @@ class Context:
         """rank's row shares of the five ciphertexts of every statement: len x 5 partial ciphertexts (no delta ct_t term, un-smudged)"""
         p = self.params
         nb = len(witness_bits_list)
-        out = self.empty(nb * 5 * p.ct_limbs * 8) if out is None else out
+        need = nb * 5 * p.ct_limbs * 8
+        out = self.empty(need) if out is None else out
+        if out.numel() * out.element_size() < need:
+            raise MfhError(f"prove_batch_partial: `out` holds {out.numel() * out.element_size()} bytes, {nb} statements need {need}")
         bits, stride = self._pack_bits(witness_bits_list)
         self._chk(self.lib.mfh_prove_batch_partial(self._h, _ptr(d_crs), rank, world, nb, bits, stride, _ptr(d_w), _ptr(d_h), _ptr(d_v), int(coef_stride),
                                                    _ptr(out)))

@@ -9,32 +9,53 @@ and because sums mod 2^704 are order-independent the result is bit-identical to 
 """
 from __future__ import annotations
 
+# what actually went through the backend in this process: {op: [calls, bytes handed to the backend]} -- bench.py prints it at the top
+# level of its JSON line so that a run shows which collectives its number contains
+COLLECTIVES = {}
 
-def allreduce_lanes(lanes, group=None):
-    """Sum the int64 lane tensor over all ranks in place (no-op outside a process group)."""
+
+def _count(op, nbytes):
+    c = COLLECTIVES.setdefault(op, [0, 0])
+    c[0] += 1
+    c[1] += int(nbytes)
+
+
+def collectives_snapshot(reset=False):
+    snap = {k: {"calls": v[0], "bytes": v[1]} for k, v in COLLECTIVES.items()}
+    if reset:
+        COLLECTIVES.clear()
+    return snap
+
+
+def allreduce_lanes(lanes, group=None, force=False):
+    """Sum the int64 lane tensor over all ranks in place (no-op outside a process group; inside a one-rank group only with `force`)."""
     import torch.distributed as dist
 
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized() and (force or dist.get_world_size(group) > 1):
         dist.all_reduce(lanes, op=dist.ReduceOp.SUM, group=group)  # (gloo takes device tensors here and stages them itself)
+        _count("all_reduce", lanes.numel() * lanes.element_size())
     return lanes
 
 
-def prove_sharded(ctx, d_crs, d_ssp, witness_bits, delta, smudge_mag, smudge_sign, rank, world, maglen=80, bufs=None, group=None):
+def prove_sharded(ctx, d_crs, d_ssp, witness_bits, delta, smudge_mag, smudge_sign, rank, world, maglen=80, bufs=None, group=None,
+                  force_collectives=False):
     """prover() (reference src/snark.c:117-190) with the CRS rows sharded over `world` ranks.  Every rank returns the
     complete proof.  `bufs` may hold reusable device buffers {"partial", "lanes", "proof"}.  world == 1 proves alone: no
-    collective is issued even inside a process group (independent provers per rank)."""
+    collective is issued even inside a process group (independent provers per rank) -- unless `force_collectives`, which
+    runs the whole N-rank sequence (lane conversion, both all-reduces) through the backend of a one-rank group: how the RCCL
+    branch is exercised on a one-GPU box."""
     bufs = {} if bufs is None else bufs
-    if world == 1:  # nothing to exchange: the partial proof is the proof (mfh_prove = mfh_prove_partial + mfh_prove_finish)
+    if world == 1 and not force_collectives:  # nothing to exchange: the partial proof is the proof (mfh_prove = mfh_prove_partial + mfh_prove_finish)
         proof = ctx.prove(d_crs, d_ssp, witness_bits, delta, smudge_mag, smudge_sign, maglen, out=bufs.get("proof"))
         bufs["proof"] = proof
         return proof
     # first exchange: the SSP pass is sharded too (each rank sums its share of the selected v_i), d uint64 lanes
     wl = ctx.witness_lanes(d_ssp, witness_bits, rank, world, out=bufs.get("wlanes"))
-    allreduce_lanes(wl, group)
+    allreduce_lanes(wl, group, force_collectives)
     partial = ctx.prove_partial_w(d_crs, d_ssp, witness_bits, delta, rank, world, wl, out=bufs.get("partial"))
     # second exchange: the five partial ciphertexts, one 32-bit word per uint64 lane
     lanes = ctx.ct_to_lanes(partial, 5, out=bufs.get("lanes"))
-    allreduce_lanes(lanes, group)
+    allreduce_lanes(lanes, group, force_collectives)
     proof = ctx.ct_from_lanes(lanes, 5, out=bufs.get("proof"))
     ctx.prove_finish(proof, smudge_mag, smudge_sign, maglen)
     bufs.update(wlanes=wl, partial=partial, lanes=lanes, proof=proof)
@@ -57,6 +78,7 @@ def all_to_all_rows(recv, send, out_splits, in_splits, group=None):
         recv.copy_(r)
     else:
         dist.all_to_all_single(recv, send, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+    _count("all_to_all_single", send.numel() * send.element_size())
     return recv
 
 
@@ -71,6 +93,7 @@ def reduce_scatter_lanes(own, lanes, group=None):
         own.copy_(o)
     else:
         dist.reduce_scatter_tensor(own, lanes, op=dist.ReduceOp.SUM, group=group)
+    _count("reduce_scatter_tensor", lanes.numel() * lanes.element_size())
     return own
 
 
@@ -87,7 +110,7 @@ def statement_shares(nb, world):
 
 
 def prove_batch_sharded(ctx, d_crs, d_ssp, witness_bits_list, deltas, smudge_mags, smudge_signs, rank, world, maglen=80, group=None, bufs=None,
-                        witness_by_cols=None):
+                        witness_by_cols=None, force_collectives=False):
     """prover() (reference src/snark.c:117-190) for len(witness_bits_list) statements with the CRS ROWS sharded over `world` ranks
     (BASELINE configs 3/4: "ciphertexts sharded across 8 x MI355X + RCCL reduce"; include/mfhip.h, row-sharded batch prover).
 
@@ -100,11 +123,12 @@ def prove_batch_sharded(ctx, d_crs, d_ssp, witness_bits_list, deltas, smudge_mag
     generation of the selected rows, no reduction), one more all-to-all (4 B x d x nb / world sent per rank) hands every statement's
     slices to its owner, who finishes the chain (v = w + v_0, h = (v^2 - 1) / t).  Needs the ranges to start at multiples of 128.
     Returns (first, count, proofs): the rank's own statements [first, first + count) and their finished proofs (count x 5 ciphertexts,
-    bit-identical to prove_batch's).  world == 1 proves alone: no collective."""
+    bit-identical to prove_batch's).  world == 1 proves alone: no collective -- unless `force_collectives`, which runs the whole
+    sequence (chain, all-to-all with split lists, row shares, lane conversion, reduce-scatter, finish) through a one-rank group."""
     import torch
 
     nb = len(witness_bits_list)
-    if world == 1:
+    if world == 1 and not force_collectives:
         return 0, nb, ctx.prove_batch(d_crs, d_ssp, witness_bits_list, deltas, smudge_mags, smudge_signs, maglen)
     p = ctx.params
     bufs = {} if bufs is None else bufs
@@ -139,7 +163,10 @@ def prove_batch_sharded(ctx, d_crs, d_ssp, witness_bits_list, deltas, smudge_mag
     recv = torch.empty(nb * 3 * cs, dtype=send.dtype, device=send.device)
     all_to_all_rows(recv, send, out_splits, in_splits, group)
     # 3. the rank's row shares of every statement's five ciphertexts
-    partial = ctx.prove_batch_partial(d_crs, rank, world, witness_bits_list, recv, recv[cs:], recv[2 * cs:], 3 * cs, out=bufs.get("bpartial"))
+    partial = bufs.get("bpartial")
+    if partial is not None and partial.numel() * partial.element_size() < nb * 5 * p.ct_limbs * 8:
+        partial = None  # a buffer kept from a smaller call: mfh_prove_batch_partial writes nb x 5 ciphertexts
+    partial = ctx.prove_batch_partial(d_crs, rank, world, witness_bits_list, recv, recv[cs:], recv[2 * cs:], 3 * cs, out=partial)
     # 4. one uint64 lane per surviving 32-bit word, statements padded to world equal slabs; reduce-scatter: the rank receives its slab summed
     lps = 5 * (p.n + 1) * 2 * p.K  # lanes per statement
     lanes = bufs.get("blanes")
