@@ -86,7 +86,7 @@ EXPORTS = [
     "mfh_encrypt_rows", "mfh_decrypt", "mfh_ct_smudge", "mfh_ssp_upload", "mfh_witness_poly", "mfh_version",
     "mfh_workspace_bytes", "mfh_last_kernel_ms", "mfh_set_timing", "mfh_set_overlap", "mfh_eval_rows_multi", "mfh_prove_batch", "mfh_crs_mm_image_bytes", "mfh_crs_expand_mm", "mfh_crs_set_resident_mm", "mfh_witness_poly_multi", "mfh_witness_poly_mm", "mfh_poly_h_multi", "mfh_poly_mul", "mfh_poly_add", "mfh_poly_prepare_t",
     "mfh_ssp_prepare", "mfh_poly_h", "mfh_setup_messages", "mfh_setup", "mfh_prove",
-    "mfh_prove_partial", "mfh_prove_finish", "mfh_ct_to_lanes", "mfh_ct_from_lanes", "mfh_timing_drain", "mfh_timing_busy_ms", "mfh_timing_work_rows", "mfh_set_batch_image", "mfh_set_batch_slabs", "mfh_set_expand_path", "mfh_set_encrypt_path", "mfh_set_batch_launch", "mfh_set_mm_chunk_rows", "mfh_add_dotp",
+    "mfh_prove_partial", "mfh_prove_finish", "mfh_ct_to_lanes", "mfh_ct_from_lanes", "mfh_timing_drain", "mfh_timing_busy_ms", "mfh_timing_work_rows", "mfh_set_batch_image", "mfh_set_batch_slabs", "mfh_set_expand_path", "mfh_set_encrypt_path", "mfh_set_batch_launch", "mfh_set_mm_chunk_rows", "mfh_add_dotp", "mfh_set_encrypt_chunks", "mfh_set_witness_per",
     "mfh_crs_mm_share_bytes", "mfh_crs_expand_mm_share", "mfh_crs_set_resident_mm_share", "mfh_batch_chain", "mfh_batch_witness_cols", "mfh_batch_chain_from_w", "mfh_witness_poly_mm_cols", "mfh_prove_batch_partial", "mfh_prove_batch_finish",
     "mfh_resident_row_bytes", "mfh_crs_expand", "mfh_eval_rows_resident", "mfh_crs_set_resident",
     "mfh_witness_lanes", "mfh_witness_from_lanes", "mfh_prove_partial_w", "mfh_verify",
@@ -174,6 +174,8 @@ def load_library():
         "mfh_set_encrypt_path": (i32, [vp, i32]),
         "mfh_set_expand_path": (i32, [vp, i32]),
         "mfh_set_batch_slabs": (i32, [vp, u32]),
+        "mfh_set_encrypt_chunks": (i32, [vp, u32]),
+        "mfh_set_witness_per": (i32, [vp, u32]),
         "mfh_crs_mm_share_bytes": (sz, [vp, u32, u32]),
         "mfh_crs_expand_mm_share": (i32, [vp, vp, u32, u32, vp]),
         "mfh_crs_set_resident_mm_share": (i32, [vp, vp, u32, u32]),
@@ -277,6 +279,14 @@ class Context:
     def set_encrypt_path(self, path=0):
         """encrypt_rows / setup: 0 = by batch size, 1 = VALU kernel, 2 = matrix-core kernel (<sk, a> as a Toeplitz int8 GEMM)"""
         self._chk(self.lib.mfh_set_encrypt_path(self._h, int(path)))
+
+    def set_encrypt_chunks(self, chunks=0):
+        """k_encrypt_mm: column chunks per row (0 = picked from the batch size)"""
+        self._chk(self.lib.mfh_set_encrypt_chunks(self._h, int(chunks)))
+
+    def set_witness_per(self, statements=0):
+        """statements per witness GEMM pass of the batch chain (0 = 248)"""
+        self._chk(self.lib.mfh_set_witness_per(self._h, int(statements)))
 
     def set_batch_launch(self, groups_per_launch=4, merge_regions=True):
         """streaming regime of prove_batch: groups of 31 proofs per pass over a region's image; S and AS groups in one launch or two"""
@@ -441,7 +451,7 @@ class Context:
         self._chk(self.lib.mfh_crs_set_resident_mm(self._h, _ptr(image)))
 
     def witness_poly_many(self, d_ssp, witness_bits_list, deltas, mm=True):
-        """w polynomials of up to 256 (mm; 128 for a generator-defined SSP) / 12 statements in one read of the SSP -> len x d uint32 on the device"""
+        """w polynomials of up to 256 (mm) / 12 statements in one read of the SSP -> len x d uint32 on the device"""
         p = self.params
         nb = len(witness_bits_list)
         stride = (p.m + 6) // 8

@@ -99,6 +99,8 @@ struct mfh_ctx {
   uint32_t mm_chunk_rows = 131071;  // rows per row chunk of the matrix-core launches (int32 accumulators: |A'C'| <= 2^14 per row)
   int expand_path = 0;     // mfh_crs_expand_mm*: 0 = k_expand_mm (lane = row, MFMA transposition, no LDS tile), 1 = k_evalmm16<MODE 1> (LDS tile + byte gathers)
   int enc_path = 0;        // mfh_encrypt_rows: 0 = pick by batch size, 1 = VALU kernel (k_encrypt), 2 = matrix-core kernel (k_encrypt_mm)
+  uint32_t enc_chunks = 0;   // k_encrypt_mm: 0 = column chunks per row picked from the batch size, n = forced (mfh_set_encrypt_chunks; tuning)
+  uint32_t witness_per = 0;  // batch chain: statements per witness GEMM pass, 0 = 248 (mfh_set_witness_per; A/B knob)
   uint32_t batch_slabs = 0;  // mfh_prove_batch: 0 = row slabs only when the image does not fit HBM (count picked from free memory), n = always n slabs
   int batch_merge = 1;     // the S and AS groups of a round in one streaming launch (0: two launches on two streams)
   uint32_t batch_ngl = 4;  // groups of 31 proofs per streaming launch over the image (1..8)

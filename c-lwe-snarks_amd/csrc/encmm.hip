@@ -231,7 +231,7 @@ int encrypt_rows_mm_t(mfh_ctx *c, uint64_t off, size_t nrows, const uint64_t *sk
     if (eff > best + 1e-9) { best = eff; kc = k; }
   }
   kc = std::max(kc_min, kc);
-  if (const char *ev = getenv("MFH_ENC_KC")) kc = std::max<uint32_t>(kc_min, (uint32_t)atoi(ev));  // tuning override (tools/encrypt_time.py)
+  if (c->enc_chunks) kc = std::max<uint32_t>(kc_min, c->enc_chunks);  // tuning override (mfh_set_encrypt_chunks: at most 64)
   const uint32_t kpc = (ksteps + kc - 1) / kc;
   kc = (ksteps + kpc - 1) / kpc;
   const size_t sb_b = ((size_t)n * G::SBY + 255) & ~(size_t)255, ps_b = 2 * 256 * 8;  // ps | column sums
@@ -262,6 +262,8 @@ int encrypt_rows_mm_t(mfh_ctx *c, uint64_t off, size_t nrows, const uint64_t *sk
   HIP_TRY(c, hipGetLastError());
   hipLaunchKernelGGL(k_encrypt_finish_mm<LOGQ>, dim3(((uint32_t)nrows + 3) / 4), dim3(256), 0, c->stream, part, kc, (uint32_t)nrows, ps, msg, err, c8);
   HIP_TRY(c, hipGetLastError());
+  // the balanced digits of the secret key, their prefix sums and Toeplitz fragments do not outlive the call in the shared scratch
+  HIP_TRY(c, hipMemsetAsync(w, 0, sb_b + ps_b + bf_b, c->stream));
   return MFH_OK;
 }
 

@@ -575,9 +575,9 @@ constexpr int CH = NQ2 / CG;      // column tiles per wave
 // same 16 row tiles for consecutive groups, so the second one's A fragments come out of that XCD's L2 (or the Infinity Cache) instead
 // of HBM: the image is read from HBM once per ng groups.  grid.x = 8 ng ceil(tile groups / 8).
 struct MmsImages { const v4i *image[16]; };  // the region image each group of a launch streams (S and AS groups share one launch)
-__global__ __launch_bounds__(SW * 64) void k_mmstream(MmsImages imgs, uint32_t mtiles, uint32_t KS, uint32_t nrows,
-                                                      uint32_t rows_per_chunk, const v4i *__restrict__ cdv, int *__restrict__ part, uint32_t ng,
-                                                      uint64_t cd_stride /* v4i */, uint64_t part_stride /* int */) {
+__device__ __forceinline__ void mmstream_body(const MmsImages &imgs, uint32_t mtiles, uint32_t KS, uint32_t nrows, uint32_t rows_per_chunk,
+                                              const v4i *__restrict__ cdv, int *__restrict__ part, uint32_t ng, uint64_t cd_stride /* v4i */,
+                                              uint64_t part_stride /* int */) {
   __shared__ v4i bfrag[2][RT2 / 64][NQ2][64];  // 2 x 64 KiB
   const uint32_t tid = threadIdx.x, lane = tid & 63;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // uniform: the fragment addresses are a scalar base + the lane's 16 bytes
@@ -687,6 +687,19 @@ __global__ __launch_bounds__(SW * 64) void k_mmstream(MmsImages imgs, uint32_t m
 #pragma unroll
       for (int e = 0; e < 4; e++) p[(uint64_t)(4 * g4 + e) * N2 + 16 * (ch * CH + q) + c16] = acc[t][q][e];
   }
+}
+
+// Two entry points over the one body so that profiles tell the two launch shapes apart: k_mmstream = several groups per launch (the S / AS
+// rounds of the batch prover: matrix-core bound, the kernel bench.py's roofline describes), k_mmstream1 = one group per launch (b_w's pass
+// over the BT+BV image, mfh_eval_rows_multi from a registered image: HBM-bound).
+__global__ __launch_bounds__(SW * 64) void k_mmstream(MmsImages imgs, uint32_t mtiles, uint32_t KS, uint32_t nrows, uint32_t rows_per_chunk,
+                                                      const v4i *__restrict__ cdv, int *__restrict__ part, uint32_t ng, uint64_t cd_stride,
+                                                      uint64_t part_stride) {
+  mmstream_body(imgs, mtiles, KS, nrows, rows_per_chunk, cdv, part, ng, cd_stride, part_stride);
+}
+__global__ __launch_bounds__(SW * 64) void k_mmstream1(MmsImages imgs, uint32_t mtiles, uint32_t KS, uint32_t nrows, uint32_t rows_per_chunk,
+                                                       const v4i *__restrict__ cdv, int *__restrict__ part) {
+  mmstream_body(imgs, mtiles, KS, nrows, rows_per_chunk, cdv, part, 1u, 0, 0);
 }
 
 // out_v[j] = sum_{u,w} G[(j,u)][(v,w)] 256^(u + w) mod 2^704 with G = G' + 128 SA[(j,u)] + 128 sc[(v,w)] + 16384 nrows, G' and
@@ -1300,9 +1313,11 @@ int eval_rows_multi_io(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d_
   // accumulator holds 131 071 rows
   // (the 256-column kernels have 736 (1471) column tiles / 506 workgroups of row-tile pairs: one chunk already fills the CUs as evenly)
   uint32_t nchunks = (!wide && nrows >= 8 * rt) ? 2 : 1;
-  nchunks = std::max<uint32_t>(nchunks, ((uint32_t)nrows + c->mm_chunk_rows - 1) / c->mm_chunk_rows);
+  // (the limit rounded DOWN to whole units first: rounding a chunk of <= 131 071 rows up to a unit afterwards could reach 131 072)
+  const uint32_t lim = std::max(rt, c->mm_chunk_rows / rt * rt);
+  nchunks = std::max<uint32_t>(nchunks, ((uint32_t)nrows + lim - 1) / lim);
   uint32_t rpc = ((uint32_t)nrows + nchunks - 1) / nchunks;
-  rpc = (rpc + rt - 1) / rt * rt;
+  rpc = (rpc + rt - 1) / rt * rt;  // <= lim
   nchunks = ((uint32_t)nrows + rpc - 1) / rpc;
   const uint32_t rpad = nchunks * rpc;  // a multiple of the unit: digit rows past nrows are zero
   const size_t cd_bytes = ((size_t)N * rpad + 255) & ~(size_t)255;
@@ -1327,8 +1342,8 @@ int eval_rows_multi_io(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d_
       const uint32_t mtiles = ntiles * wg.mt, KS = ((uint32_t)nrows + RT2 - 1) / RT2 * (RT2 / 64);
       MmsImages imgs{};
       imgs.image[0] = (const v4i *)img_region;
-      hipLaunchKernelGGL(k_mmstream, dim3(((mtiles + TPW - 1) / TPW + 7) / 8 * 8, nchunks), dim3(SW * 64), 0, c->stream, imgs,
-                         mtiles, KS, (uint32_t)nrows, rpc, (const v4i *)cd, part, 1u, (uint64_t)0, (uint64_t)0);
+      hipLaunchKernelGGL(k_mmstream1, dim3(((mtiles + TPW - 1) / TPW + 7) / 8 * 8, nchunks), dim3(SW * 64), 0, c->stream, imgs,
+                         mtiles, KS, (uint32_t)nrows, rpc, (const v4i *)cd, part);
     } else if (wide && q736)
       hipLaunchKernelGGL((k_evalmm16<0, 736>), dim3(ntiles, nchunks), dim3(1024), 0, c->stream, keyx, c->d_t0, off, n, (uint32_t)nrows, rpc, d_c8, cd, part,
                          (uint8_t *)nullptr);
@@ -1379,8 +1394,10 @@ bool mms_plan(mfh_ctx *c, const MmRegion *regs, uint32_t nreg, size_t nrows, con
   P.ntiles = (c->P.n + 1 + wg.ct - 1) / wg.ct;
   P.mtiles = P.ntiles * wg.mt;
   // row chunks: an int32 accumulator holds 131 071 rows (a rank's share of a 2^20-row region is 131 072)
-  uint32_t nchunks = ((uint32_t)nrows + c->mm_chunk_rows - 1) / c->mm_chunk_rows;
-  P.rpc = (((uint32_t)nrows + nchunks - 1) / nchunks + RT2 - 1) / RT2 * RT2;
+  // (the limit rounded down to whole stages first, so that the rounded-up chunk cannot exceed it: 2 x 131 071 rows are three chunks)
+  const uint32_t lim = std::max<uint32_t>(RT2, c->mm_chunk_rows / RT2 * RT2);
+  uint32_t nchunks = ((uint32_t)nrows + lim - 1) / lim;
+  P.rpc = (((uint32_t)nrows + nchunks - 1) / nchunks + RT2 - 1) / RT2 * RT2;  // <= lim
   P.nchunks = ((uint32_t)nrows + P.rpc - 1) / P.rpc;
   P.rpad = P.nchunks * P.rpc;
   P.cd_bytes = ((size_t)N2 * P.rpad + 255) & ~(size_t)255;
@@ -1426,8 +1443,11 @@ int mms_stream(mfh_ctx *c, const MmsPlan &P) {
   const uint32_t KS = (P.nrows + RT2 - 1) / RT2 * (RT2 / 64), tgs = (P.mtiles + TPW - 1) / TPW;
   MmsImages imgs{};
   for (uint32_t g = 0; g < P.ngt; g++) imgs.image[g] = (const v4i *)P.img[g / P.ng];
-  hipLaunchKernelGGL(k_mmstream, dim3((tgs + 7) / 8 * 8 * P.ngt, P.nchunks), dim3(SW * 64), 0, c->stream, imgs, P.mtiles, KS, P.nrows, P.rpc, (const v4i *)P.cd,
-                     P.part, P.ngt, (uint64_t)(P.cd_bytes / 16), (uint64_t)(P.part_bytes / 4));
+  if (P.ngt > 1)
+    hipLaunchKernelGGL(k_mmstream, dim3((tgs + 7) / 8 * 8 * P.ngt, P.nchunks), dim3(SW * 64), 0, c->stream, imgs, P.mtiles, KS, P.nrows, P.rpc, (const v4i *)P.cd,
+                       P.part, P.ngt, (uint64_t)(P.cd_bytes / 16), (uint64_t)(P.part_bytes / 4));
+  else
+    hipLaunchKernelGGL(k_mmstream1, dim3((tgs + 7) / 8 * 8, P.nchunks), dim3(SW * 64), 0, c->stream, imgs, P.mtiles, KS, P.nrows, P.rpc, (const v4i *)P.cd, P.part);
   HIP_TRY(c, hipGetLastError());
   return MFH_OK;
 }

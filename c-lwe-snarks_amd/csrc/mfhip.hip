@@ -1013,6 +1013,16 @@ int mfh_set_encrypt_path(mfh_ctx *c, int path) {
   return MFH_OK;
 }
 
+int mfh_set_encrypt_chunks(mfh_ctx *c, uint32_t chunks) {
+  if (!c || chunks > 64) return MFH_EINVAL;
+  c->enc_chunks = chunks;
+  return MFH_OK;
+}
+int mfh_set_witness_per(mfh_ctx *c, uint32_t statements) {
+  if (!c || (statements && (statements < 32 || statements > 256))) return MFH_EINVAL;
+  c->witness_per = statements;
+  return MFH_OK;
+}
 int mfh_set_batch_slabs(mfh_ctx *c, uint32_t nslabs) {
   if (!c || nslabs > 256) return MFH_EINVAL;
   c->batch_slabs = nslabs;

@@ -590,8 +590,7 @@ int batch_chain_launch(mfh_ctx *c, const mf::SspSrc &src, const uint32_t *d_ssp,
   // 124 statements; otherwise the VALU form, read or generated once per 12 statements
   if (d % 128 == 0) {
     // the whole super-group (248 statements) in one read (dense SSP) or one generation (generator-defined SSP) of the rows: k_witness_mm8q / k_witness_mm8q_prg
-    static const uint32_t per_env = [] { const char *e = getenv("MFH_WITNESS_PER"); return e ? (uint32_t)atoi(e) : 0u; }();  // (A/B knob)
-    const uint32_t per = per_env ? std::min(per_env, 256u) : 248u;
+    const uint32_t per = c->witness_per ? c->witness_per : 248u;  // (mfh_set_witness_per: A/B knob)
     for (uint32_t b0 = 0; b0 < sg; b0 += per) {
       rc = mfh_witness_poly_mm(c, d_ssp, std::min(per, sg - b0), h_bits + (size_t)b0 * bits_stride, bits_stride, h_delta + b0, W + (size_t)b0 * d);
       if (rc) return rc;
@@ -825,6 +824,8 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
   if (bits_stride < (m + 6) / 8) { c->err = "bits_stride shorter than the m - 1 witness bits"; return MFH_EINVAL; }
   for (uint32_t b = 0; b < nproofs; b++)
     if (h_delta[b] >= P32) { c->err = "delta must be < p"; return MFH_EINVAL; }
+  // (checked before any GPU work in every regime: the row-slab path smudges only after all its launches)
+  if (maglen + 4 > (size_t)(c->P.logq / 64) * 8) { c->err = "smudge magnitude too wide"; return MFH_EINVAL; }
   const size_t ctl = (size_t)(n + 1) * ((c->P.logq + 63) / 64);
   HIP_TRY(c, hipSetDevice(c->device));
   // The chain (witness pass + polynomial step) of a super-group runs on its own stream: the first one beside the CRS expansion, the chain
@@ -1079,6 +1080,7 @@ int mfh_prove_batch_finish(mfh_ctx *c, const uint8_t *d_crs_c8, uint32_t nstmt, 
   if (!d_crs_c8 || !h_delta || !h_smudge_mag || !h_smudge_sign || !d_proofs) return MFH_EINVAL;
   for (uint32_t b = 0; b < nstmt; b++)
     if (h_delta[b] >= P32) { c->err = "delta must be < p"; return MFH_EINVAL; }
+  if (maglen + 4 > (size_t)(c->P.logq / 64) * 8) { c->err = "smudge magnitude too wide"; return MFH_EINVAL; }  // before delta ct_t is added
   const uint32_t n = c->P.n;
   const size_t ctl = (size_t)(n + 1) * ((c->P.logq + 63) / 64);
   HIP_TRY(c, hipSetDevice(c->device));

@@ -446,30 +446,67 @@ void setup(crs_t crs, vrs_t vrs, ssp_t ssp)
   HK(hipMemcpy(crs->v, G.d_crs + (2 * GAMMA_D + 1) * CT_BYTES, CT_BYTES * (GAMMA_M - 1), hipMemcpyDeviceToHost));
 }
 
-void prover(proof_t pi, crs_t crs, ssp_t ssp, mpz_t witness)
+/* ---- pieces shared with the multi-GPU entry points (host/mfuoco_dist.c, libmfuoco_gpu_dist): not part of the reference interface ---- */
+mfh_ctx *mfuoco_gpu_ctx(void) { return gpu(); }
+
+/* the CRS in keystream order s | as | t | v on the device (the order setup() encrypts in, src/snark.c:75-110) */
+const uint8_t *mfuoco_gpu_stage_crs(crs_t crs)
 {
   gpu();
   use_seed(crs->seed);
-  ssp_resident(ssp);
   HK(hipMemcpy(G.d_crs, crs->s, CT_BYTES * GAMMA_D, hipMemcpyHostToDevice));
   HK(hipMemcpy(G.d_crs + CT_BYTES * GAMMA_D, crs->as, CT_BYTES * GAMMA_D, hipMemcpyHostToDevice));
   HK(hipMemcpy(G.d_crs + 2 * CT_BYTES * GAMMA_D, crs->t, CT_BYTES, hipMemcpyHostToDevice));
   HK(hipMemcpy(G.d_crs + (2 * GAMMA_D + 1) * CT_BYTES, crs->v, CT_BYTES * (GAMMA_M - 1), hipMemcpyHostToDevice));
-  uint8_t bits[(GAMMA_M + 7) / 8 + 8] = { 0 };
+  return G.d_crs;
+}
+
+const uint32_t *mfuoco_gpu_stage_ssp(ssp_t ssp)
+{
+  gpu();
+  ssp_resident(ssp);
+  return G.d_ssp;
+}
+
+size_t mfuoco_gpu_bits_stride(void) { return (GAMMA_M + 7) / 8 + 8; }
+
+/* the witness as the little-endian bit string mfh_prove* take (bit i-1 selects v_i, src/snark.c:150) */
+void mfuoco_gpu_witness_bits(uint8_t *bits, mpz_t witness)
+{
   if (mpz_sizeinbase(witness, 2) > GAMMA_M + 8) die("prover: witness wider than M bits");
   mpz_export(bits, NULL, -1, 1, -1, 0, witness);
-  /* entropy in the reference's order: delta (8 B), then 5 x [80 B magnitude, 1 B sign] (src/snark.c:140,185-189) */
-  uint32_t delta = (uint32_t)rand_modp_();
+}
+
+/* entropy of one prover() call in the reference's order: delta (8 B), then 5 x [80 B magnitude, 1 B sign] (src/snark.c:140,185-189) */
+void mfuoco_gpu_prover_entropy(uint32_t *delta, uint8_t *mag, uint8_t *sign)
+{
+  const size_t maglen = GAMMA_LOG_SMUDGING / 8;
+  *delta = (uint32_t)rand_modp_();
+  for (int q = 0; q < 5; q++)
+    if (getrandom(mag + q * maglen, maglen, GRND_NONBLOCK) < 0 || getrandom(sign + q, 1, GRND_NONBLOCK) < 0) perror("getrandom");
+}
+
+/* count proofs (5 ciphertexts each, struct proof order) from device limbs into initialised proof_t's */
+void mfuoco_gpu_proofs_to_host(proof_t *pis, const uint64_t *d_proofs, size_t count)
+{
+  for (size_t k = 0; k < count; k++) {
+    mpz_t *cts[5] = { pis[k]->h, pis[k]->hat_h, pis[k]->hat_v, pis[k]->v_w, pis[k]->b_w };
+    for (int q = 0; q < 5; q++) ct_from_dev(cts[q], d_proofs + (k * 5 + q) * CTL, GAMMA_N + 1);
+  }
+}
+
+void prover(proof_t pi, crs_t crs, ssp_t ssp, mpz_t witness)
+{
+  const uint8_t *d_crs = mfuoco_gpu_stage_crs(crs);
+  const uint32_t *d_ssp = mfuoco_gpu_stage_ssp(ssp);
+  uint8_t bits[(GAMMA_M + 7) / 8 + 8] = { 0 };
+  mfuoco_gpu_witness_bits(bits, witness);
+  uint32_t delta;
   uint8_t mag[5 * (GAMMA_LOG_SMUDGING / 8)], sign[5];
-  for (int k = 0; k < 5; k++)
-    if (getrandom(mag + k * (GAMMA_LOG_SMUDGING / 8), GAMMA_LOG_SMUDGING / 8, GRND_NONBLOCK) < 0 || getrandom(sign + k, 1, GRND_NONBLOCK) < 0)
-      perror("getrandom");
-  CK(mfh_prove(G.ctx, G.d_crs, G.d_ssp, bits, delta, mag, GAMMA_LOG_SMUDGING / 8, sign, G.d_proof));
-  ct_from_dev(pi->h, G.d_proof, GAMMA_N + 1);
-  ct_from_dev(pi->hat_h, G.d_proof + CTL, GAMMA_N + 1);
-  ct_from_dev(pi->hat_v, G.d_proof + 2 * CTL, GAMMA_N + 1);
-  ct_from_dev(pi->v_w, G.d_proof + 3 * CTL, GAMMA_N + 1);
-  ct_from_dev(pi->b_w, G.d_proof + 4 * CTL, GAMMA_N + 1);
+  mfuoco_gpu_prover_entropy(&delta, mag, sign);
+  CK(mfh_prove(G.ctx, d_crs, d_ssp, bits, delta, mag, GAMMA_LOG_SMUDGING / 8, sign, G.d_proof));
+  proof_t *one = (proof_t *)pi; /* proof_t is struct proof[1]: pi is the address of the one element */
+  mfuoco_gpu_proofs_to_host(one, G.d_proof, 1);
 }
 
 /* prover() for `count` statements under one CRS and SSP (not in the reference): the CRS rows are expanded once per group of proofs
@@ -478,30 +515,19 @@ void prover(proof_t pi, crs_t crs, ssp_t ssp, mpz_t witness)
 void mfuoco_prover_batch(proof_t *pis, crs_t crs, ssp_t ssp, mpz_t *witnesses, size_t count)
 {
   if (!count) return;
-  gpu();
-  use_seed(crs->seed);
-  ssp_resident(ssp);
-  HK(hipMemcpy(G.d_crs, crs->s, CT_BYTES * GAMMA_D, hipMemcpyHostToDevice));
-  HK(hipMemcpy(G.d_crs + CT_BYTES * GAMMA_D, crs->as, CT_BYTES * GAMMA_D, hipMemcpyHostToDevice));
-  HK(hipMemcpy(G.d_crs + 2 * CT_BYTES * GAMMA_D, crs->t, CT_BYTES, hipMemcpyHostToDevice));
-  HK(hipMemcpy(G.d_crs + (2 * GAMMA_D + 1) * CT_BYTES, crs->v, CT_BYTES * (GAMMA_M - 1), hipMemcpyHostToDevice));
-  const size_t stride = (GAMMA_M + 7) / 8 + 8, maglen = GAMMA_LOG_SMUDGING / 8;
+  const uint8_t *d_crs = mfuoco_gpu_stage_crs(crs);
+  const uint32_t *d_ssp = mfuoco_gpu_stage_ssp(ssp);
+  const size_t stride = mfuoco_gpu_bits_stride(), maglen = GAMMA_LOG_SMUDGING / 8;
   uint8_t *bits = calloc(count, stride), *mag = malloc(count * 5 * maglen), *sign = malloc(count * 5);
   uint32_t *delta = malloc(count * 4);
   uint64_t *d_out = NULL;
   HK(hipMalloc((void **)&d_out, count * 5 * CTL * 8));
   for (size_t k = 0; k < count; k++) {
-    if (mpz_sizeinbase(witnesses[k], 2) > GAMMA_M + 8) die("prover: witness wider than M bits");
-    mpz_export(bits + k * stride, NULL, -1, 1, -1, 0, witnesses[k]);
-    delta[k] = (uint32_t)rand_modp_();
-    for (int q = 0; q < 5; q++)
-      if (getrandom(mag + (k * 5 + q) * maglen, maglen, GRND_NONBLOCK) < 0 || getrandom(sign + k * 5 + q, 1, GRND_NONBLOCK) < 0) perror("getrandom");
+    mfuoco_gpu_witness_bits(bits + k * stride, witnesses[k]);
+    mfuoco_gpu_prover_entropy(delta + k, mag + k * 5 * maglen, sign + k * 5);
   }
-  CK(mfh_prove_batch(G.ctx, G.d_crs, G.d_ssp, (uint32_t)count, bits, stride, delta, mag, maglen, sign, d_out));
-  for (size_t k = 0; k < count; k++) {
-    mpz_t *cts[5] = { pis[k]->h, pis[k]->hat_h, pis[k]->hat_v, pis[k]->v_w, pis[k]->b_w };
-    for (int q = 0; q < 5; q++) ct_from_dev(cts[q], d_out + (k * 5 + q) * CTL, GAMMA_N + 1);
-  }
+  CK(mfh_prove_batch(G.ctx, d_crs, d_ssp, (uint32_t)count, bits, stride, delta, mag, maglen, sign, d_out));
+  mfuoco_gpu_proofs_to_host(pis, d_out, count);
   HK(hipFree(d_out));
   free(bits); free(mag); free(sign); free(delta);
 }

@@ -214,6 +214,10 @@ int mfh_set_batch_image(mfh_ctx *ctx, int enabled);
  * for every group of the call, accumulating mod 2^(64K): the keystream is generated once per call instead of once per group of 31 proofs.
  * 0 (default): slabs only when needed, their number from the free memory; n: always n slabs (tests, tuning).  Same proofs. */
 int mfh_set_batch_slabs(mfh_ctx *ctx, uint32_t nslabs);
+/* tuning knobs (results do not depend on them; MFH_EINVAL outside the range): column chunks per row of the matrix-core encryption kernel
+ * (0 = picked from the batch size, at most 64); statements per witness GEMM pass of the batch chain (0 = 248, else 32..256). */
+int mfh_set_encrypt_chunks(mfh_ctx *ctx, uint32_t chunks);
+int mfh_set_witness_per(mfh_ctx *ctx, uint32_t statements);
 /* launch shape of the streaming regime of mfh_prove_batch* (tuning; results do not depend on it): groups of 31 proofs served by one pass
  * over a region's image (1..8, default 4), and whether the S and AS groups of a round share ONE launch (default) or run as two
  * launches on two streams. */
@@ -274,7 +278,7 @@ int mfh_prove_finish(mfh_ctx *ctx, uint64_t *d_proof, const uint8_t *h_smudge_ma
  * added into the polynomials of the statements whose bit selects it.  h_bits: nstmt bit strings bits_stride bytes apart; d_w: nstmt x d coefficients. */
 int mfh_witness_poly_multi(mfh_ctx *ctx, const uint32_t *d_ssp, uint32_t nstmt, const uint8_t *h_bits, size_t bits_stride, const uint32_t *h_delta,
                            uint32_t *d_w);
-/* The same for nstmt <= 256 statements (128 for a generator-defined SSP) in ONE read of the SSP, as a GEMM on the matrix cores (bits x SSP bytes, exact); d a multiple
+/* The same for nstmt <= 256 statements (dense and generator-defined SSP alike) in ONE read of the SSP, as a GEMM on the matrix cores (bits x SSP bytes, exact); d a multiple
  * of 128 (d_ssp == NULL, the generator-defined SSP: the SSP bytes are generated in the kernel).  Keeps a second image of the SSP in MFMA fragment order (same size), built on first use and rebuilt after
  * mfh_ssp_upload / mfh_ssp_prepare.  Used by mfh_prove_batch. */
 int mfh_witness_poly_mm(mfh_ctx *ctx, const uint32_t *d_ssp, uint32_t nstmt, const uint8_t *h_bits, size_t bits_stride, const uint32_t *h_delta,

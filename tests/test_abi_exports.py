@@ -45,3 +45,25 @@ def test_product_does_not_link_the_oracle():
     for fn in os.listdir(os.path.join(ROOT, "c-lwe-snarks_amd", "csrc")):
         src = open(os.path.join(ROOT, "c-lwe-snarks_amd", "csrc", fn)).read()
         assert "mf_oracle" not in src and "oracle/" not in src
+
+
+def test_dist_header_symbols_are_exported():
+    """libmfuoco_gpu_dist.so (C entry points for N GPUs, RCCL called directly) exports what host/include/mfuoco/mfuoco_dist.h declares
+    and really links librccl"""
+    import subprocess
+
+    hdr = open(os.path.join(ROOT, "c-lwe-snarks_amd", "host", "include", "mfuoco", "mfuoco_dist.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)  # declarations only
+    declared = sorted(set(re.findall(r"\b(mfuoco_[a-z0-9_]+)\s*\(", hdr)))
+    assert "mfuoco_prover_batch_sharded" in declared and "mfuoco_comm_create" in declared
+    for so in ("libmfuoco_gpu_dist.so", "libmfuoco_gpu_dist_debug.so"):
+        path = os.path.join(ROOT, "c-lwe-snarks_amd", so)
+        if not os.path.exists(path):
+            pytest.fail(f"{so} has not been built (make -C c-lwe-snarks_amd dist)")
+        syms = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True).stdout
+        for name in declared:
+            assert re.search(rf"\bT {name}\b", syms), f"{name} not exported by {so}"
+        und = subprocess.run(["nm", "-D", "--undefined-only", path], capture_output=True, text=True).stdout
+        for name in ("ncclReduceScatter", "ncclSend", "ncclRecv", "ncclGroupStart", "ncclAllReduce", "ncclCommInitRank", "mfh_prove_batch_partial"):
+            assert name in und, f"{so} does not call {name}"
+        assert "librccl" in subprocess.run(["ldd", path], capture_output=True, text=True).stdout

@@ -102,7 +102,7 @@ def test_prove_sharded_call_sequence(monkeypatch, world, expect):
     from c_lwe_snarks_amd import dist as mfdist
 
     ctx = _FakeCtx()
-    monkeypatch.setattr(mfdist, "allreduce_lanes", lambda lanes, group=None: ctx.calls.append("ALLREDUCE"))
+    monkeypatch.setattr(mfdist, "allreduce_lanes", lambda lanes, group=None, force=False: ctx.calls.append("ALLREDUCE"))
     mfdist.prove_sharded(ctx, None, None, None, None, None, None, 0, world)
     assert ctx.calls == expect
 

@@ -278,3 +278,34 @@ def test_more_than_four_super_groups(gpu_ctx_factory, oracle):
         stape = b"".join(mags[b][80 * k: 80 * k + 80] + signs[b][k: k + 1] for k in range(5))
         ref = oracle.prover(p, inst["crs"], inst["ssp"], bits[b], deltas[b], stape, 80)
         assert np.array_equal(ctx.to_host(out[b], np.uint64).reshape(5, p.n + 1, p.L), np.stack(ref["proof"])), f"statement {b} differs from the oracle's prover"
+
+
+@pytest.mark.parametrize("nslabs", [0, 3])
+def test_too_wide_smudge_is_rejected_before_any_gpu_work(gpu_ctx_factory, oracle, nslabs):
+    """the row-slab regime of mfh_prove_batch (and mfh_prove_batch_finish) checked maglen only in the smudging at the very end,
+    after d_proofs had been overwritten; now every regime rejects it up front and leaves the output untouched"""
+    import torch
+
+    import c_lwe_snarks_amd as mf
+
+    p = mf.DEBUG
+    ctx = gpu_ctx_factory(p)
+    ctx.set_seed(SEED)
+    W = _instance(mf, ctx, oracle, p, 4242)
+    nb, maglen = 40, 88  # 88 + 4 > 88 surviving bytes
+    rng = np.random.default_rng(5)
+    bits = [W["wit"]] * nb
+    deltas = [int(x) for x in rng.integers(0, ol.P, size=nb, dtype=np.uint64)]
+    mags = [rng.integers(0, 256, size=5 * maglen, dtype=np.uint8).tobytes() for _ in range(nb)]
+    signs = [bytes(5)] * nb
+    out = torch.full((nb * 5 * p.ct_limbs * 8,), 0x5A, dtype=torch.uint8, device=ctx.device)
+    ctx.set_batch_slabs(nslabs)
+    try:
+        with pytest.raises(mf.MfhError, match="too wide"):
+            ctx.prove_batch(W["d_crs"], W["d_ssp"], bits, deltas, mags, signs, maglen=maglen, out=out)
+        assert bool((out == 0x5A).all())
+        with pytest.raises(mf.MfhError, match="too wide"):
+            ctx.prove_batch_finish(W["d_crs"], deltas, mags, signs, out, maglen=maglen)
+        assert bool((out == 0x5A).all())
+    finally:
+        ctx.set_batch_slabs(0)

@@ -296,3 +296,38 @@ def test_expansion_kernels_write_the_same_image(gpu_ctx_factory, logq, d, m):
             mask = rmask & pos_ok[:, None, None, :, None]
             assert np.array_equal(a[np.broadcast_to(mask, a.shape)], b[np.broadcast_to(mask, b.shape)]), (rank, world, total)
     c.close()
+
+
+@pytest.mark.parametrize("nrows,chunk_rows,nvec,cb", [(2 * 131071, 0, 3, 4), (2 * 131071, 0, 40, 4), (1100, 500, 3, 4)])
+def test_row_chunks_stay_within_the_int32_bound(ctx, nrows, chunk_rows, nvec, cb):
+    """a chunk of <= 131 071 rows rounded UP to whole 256-row stages could reach 131 072 (nrows = 2 x 131 071: two chunks of
+    131 072).  The limit is now rounded DOWN to whole stages before dividing (three chunks here; 500 -> chunks of 256); both the
+    128-column (3 vectors) and the 256-column kernel (40 vectors), compared with the VALU path (k_eval) over the same rows."""
+    p = ctx.params
+    rng = np.random.default_rng(nrows + nvec)
+    c8 = ctx.to_device(rng.integers(0, 256, size=nrows * p.ctb, dtype=np.uint8))
+    co = rng.integers(0, ol.P, size=(nvec, nrows), dtype=np.uint64).astype(np.uint32)
+    co[0, :] = 0xFFFFFFFA  # p - 1 everywhere: the largest digits
+    ctx.set_mm_chunk_rows(chunk_rows)
+    try:
+        got = ctx.to_host(ctx.eval_rows_multi(p.ctr_s, nrows, c8, ctx.to_device(co), nvec, coeff_bytes=cb), np.uint64).reshape(nvec, p.n + 1, p.L)
+    finally:
+        ctx.set_mm_chunk_rows(0)
+    for v in (0, 1, nvec - 1):
+        ref, _ = ctx.eval_rows(p.ctr_s, nrows, c8, ctx.to_device(co[v]))
+        assert np.array_equal(got[v], ctx.to_host(ref, np.uint64).reshape(p.n + 1, p.L)), f"vector {v}"
+
+
+def test_tuning_setters_check_their_ranges(ctx):
+    import c_lwe_snarks_amd as mf
+
+    for bad in (65, 1000):
+        with pytest.raises(mf.MfhError):
+            ctx.set_encrypt_chunks(bad)
+    for bad in (1, 31, 257):
+        with pytest.raises(mf.MfhError):
+            ctx.set_witness_per(bad)
+    ctx.set_encrypt_chunks(8)
+    ctx.set_encrypt_chunks(0)
+    ctx.set_witness_per(124)
+    ctx.set_witness_per(0)

@@ -16,3 +16,45 @@ def test_c_shim_properties():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "snark ok" in r.stdout
+
+
+def _sharded_exe():
+    exe = os.path.join(ROOT, "c-lwe-snarks_amd", "host", "test_sharded")
+    if not os.path.exists(exe):
+        pytest.fail("host/test_sharded has not been built (make -C c-lwe-snarks_amd dist)")
+    return exe
+
+
+def _rank_env(rank, world, **extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MFUOCO_REHEARSAL_SHM")}
+    env.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0", **extra)
+    return env
+
+
+def test_c_sharded_prover_one_rank_rccl(tmp_path):
+    """mfuoco_prover_batch_sharded / mfuoco_prover_sharded (host/mfuoco_dist.c) through librccl called from C: a one-rank communicator still
+    sends the all-to-all (ncclSend/ncclRecv to itself), the ncclReduceScatter, both ncclAllReduce and the ncclBroadcast; proofs must equal
+    mfuoco_prover_batch's / prover()'s bit for bit on the same entropy tape and verify"""
+    r = subprocess.run([_sharded_exe(), "40"], env=_rank_env(0, 1, MFUOCO_COMM_ID_FILE=str(tmp_path / "id")), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "backend=rccl" in r.stdout and "sharded ok" in r.stdout
+
+
+@pytest.mark.parametrize("world,count", [(2, 9), (3, 40)])
+def test_c_sharded_prover_rehearsal_ranks_share_the_gpu(world, count):
+    """the same C sequence with `world` PROCESSES on the one GPU, collectives staged through host shared memory (rehearsal backend): uneven
+    statement slabs and row shares (256 rows over 3 ranks), a second call in which the last rank owns no statement"""
+    name = "mfuoco_test_%d_%d" % (os.getpid(), world)
+    procs = [subprocess.Popen([_sharded_exe(), str(count)], env=_rank_env(rk, world, MFUOCO_REHEARSAL_SHM=name, MFUOCO_SHARE_GPU="1"),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for rk in range(world)]
+    outs = []
+    try:
+        for pr in procs:
+            outs.append(pr.communicate(timeout=600))
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    for rk, (pr, (so, se)) in enumerate(zip(procs, outs)):
+        assert pr.returncode == 0, (rk, so, se)
+        assert "sharded ok" in so and "rehearsal" in so
