@@ -16,7 +16,7 @@ from dataclasses import dataclass
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmfhip.so")
+LIB_PATH = os.environ.get("MFHIP_LIB") or os.path.join(_HERE, "libmfhip.so")  # ($MFHIP_LIB: another build of the same ABI, for same-box A/B runs of the tools)
 P = 0xFFFFFFFB  # GAMMA_P, reference src/lwe.h:25
 
 
@@ -86,7 +86,7 @@ EXPORTS = [
     "mfh_encrypt_rows", "mfh_decrypt", "mfh_ct_smudge", "mfh_ssp_upload", "mfh_witness_poly", "mfh_version",
     "mfh_workspace_bytes", "mfh_last_kernel_ms", "mfh_set_timing", "mfh_set_overlap", "mfh_eval_rows_multi", "mfh_prove_batch", "mfh_crs_mm_image_bytes", "mfh_crs_expand_mm", "mfh_crs_set_resident_mm", "mfh_witness_poly_multi", "mfh_witness_poly_mm", "mfh_poly_h_multi", "mfh_poly_mul", "mfh_poly_add", "mfh_poly_prepare_t",
     "mfh_ssp_prepare", "mfh_poly_h", "mfh_setup_messages", "mfh_setup", "mfh_prove",
-    "mfh_prove_partial", "mfh_prove_finish", "mfh_ct_to_lanes", "mfh_ct_from_lanes", "mfh_timing_drain", "mfh_timing_busy_ms", "mfh_timing_work_rows", "mfh_set_batch_image", "mfh_set_batch_slabs", "mfh_set_expand_path", "mfh_set_encrypt_path", "mfh_set_batch_launch", "mfh_set_mm_chunk_rows", "mfh_add_dotp", "mfh_set_encrypt_chunks", "mfh_set_witness_per",
+    "mfh_prove_partial", "mfh_prove_finish", "mfh_ct_to_lanes", "mfh_ct_from_lanes", "mfh_timing_drain", "mfh_timing_busy_ms", "mfh_timing_work_rows", "mfh_set_batch_image", "mfh_set_batch_slabs", "mfh_set_expand_path", "mfh_set_encrypt_path", "mfh_set_batch_launch", "mfh_set_mm_chunk_rows", "mfh_add_dotp", "mfh_set_encrypt_chunks", "mfh_set_witness_per", "mfh_set_eval_path", "mfh_set_decrypt_path", "mfh_decrypt_rows",
     "mfh_crs_mm_share_bytes", "mfh_crs_expand_mm_share", "mfh_crs_set_resident_mm_share", "mfh_batch_chain", "mfh_batch_witness_cols", "mfh_batch_chain_from_w", "mfh_witness_poly_mm_cols", "mfh_prove_batch_partial", "mfh_prove_batch_finish",
     "mfh_resident_row_bytes", "mfh_crs_expand", "mfh_eval_rows_resident", "mfh_crs_set_resident",
     "mfh_witness_lanes", "mfh_witness_from_lanes", "mfh_prove_partial_w", "mfh_verify",
@@ -175,6 +175,9 @@ def load_library():
         "mfh_set_expand_path": (i32, [vp, i32]),
         "mfh_set_batch_slabs": (i32, [vp, u32]),
         "mfh_set_encrypt_chunks": (i32, [vp, u32]),
+        "mfh_set_eval_path": (i32, [vp, i32]),
+        "mfh_set_decrypt_path": (i32, [vp, i32]),
+        "mfh_decrypt_rows": (i32, [vp, u64, sz, vp, vp, vp]),
         "mfh_set_witness_per": (i32, [vp, u32]),
         "mfh_crs_mm_share_bytes": (sz, [vp, u32, u32]),
         "mfh_crs_expand_mm_share": (i32, [vp, vp, u32, u32, vp]),
@@ -280,6 +283,10 @@ class Context:
         """encrypt_rows / setup: 0 = by batch size, 1 = VALU kernel, 2 = matrix-core kernel (<sk, a> as a Toeplitz int8 GEMM)"""
         self._chk(self.lib.mfh_set_encrypt_path(self._h, int(path)))
 
+    def set_eval_path(self, path=0):
+        """eval_rows / prove: 0 = tile kernel (k_eval, default), 1 = wave-autonomous kernel (k_eval_w, logq 736; measured 4 % slower)"""
+        self._chk(self.lib.mfh_set_eval_path(self._h, int(path)))
+
     def set_encrypt_chunks(self, chunks=0):
         """k_encrypt_mm: column chunks per row (0 = picked from the batch size)"""
         self._chk(self.lib.mfh_set_encrypt_chunks(self._h, int(chunks)))
@@ -371,9 +378,20 @@ class Context:
         self._chk(self.lib.mfh_encrypt_rows(self._h, off, nrows, _ptr(sk), _ptr(msg), _ptr(err), _ptr(out)))
         return out
 
-    def decrypt(self, sk, cts, count):
-        out = self.empty(4 * count)
+    def decrypt(self, sk, cts, count, out=None):
+        """regev_decrypt (src/lwe.c:105-111) of `count` full ciphertexts -> count uint32"""
+        out = self.empty(4 * count) if out is None else out
         self._chk(self.lib.mfh_decrypt(self._h, _ptr(sk), _ptr(cts), count, _ptr(out)))
+        return out
+
+    def set_decrypt_path(self, path=0):
+        """decrypt: 0 = by batch size, 1 = VALU kernel, 2 = matrix-core kernel"""
+        self._chk(self.lib.mfh_set_decrypt_path(self._h, int(path)))
+
+    def decrypt_rows(self, off, nrows, sk, c8, out=None):
+        """regev_decrypt of nrows seed-compressed ciphertexts (a regenerated from the stream at off + i * CTR_CT, b = c8[i]) -> nrows uint32"""
+        out = self.empty(4 * nrows) if out is None else out
+        self._chk(self.lib.mfh_decrypt_rows(self._h, off, nrows, _ptr(sk), _ptr(c8), _ptr(out)))
         return out
 
     def ct_smudge(self, cts, count, mag: bytes, maglen, sign: bytes):

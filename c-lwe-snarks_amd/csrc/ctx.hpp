@@ -99,6 +99,9 @@ struct mfh_ctx {
   uint32_t mm_chunk_rows = 131071;  // rows per row chunk of the matrix-core launches (int32 accumulators: |A'C'| <= 2^14 per row)
   int expand_path = 0;     // mfh_crs_expand_mm*: 0 = k_expand_mm (lane = row, MFMA transposition, no LDS tile), 1 = k_evalmm16<MODE 1> (LDS tile + byte gathers)
   int enc_path = 0;        // mfh_encrypt_rows: 0 = pick by batch size, 1 = VALU kernel (k_encrypt), 2 = matrix-core kernel (k_encrypt_mm)
+  uint32_t ncu = 256;        // compute units of the device (launch sizing)
+  int dec_path = 0;          // mfh_decrypt: 0 = by batch size, 1 = VALU kernel (k_decrypt), 2 = matrix-core kernel (k_decrypt_mm)
+  int eval_path = 0;         // mfh_eval_rows / mfh_prove: 0 = tile kernel (k_eval), 1 = wave-autonomous kernel (k_eval_w, logq 736 only; measured 4 % slower)
   uint32_t enc_chunks = 0;   // k_encrypt_mm: 0 = column chunks per row picked from the batch size, n = forced (mfh_set_encrypt_chunks; tuning)
   uint32_t witness_per = 0;  // batch chain: statements per witness GEMM pass, 0 = 248 (mfh_set_witness_per; A/B knob)
   uint32_t batch_slabs = 0;  // mfh_prove_batch: 0 = row slabs only when the image does not fit HBM (count picked from free memory), n = always n slabs
@@ -177,6 +180,9 @@ int aux_reserve(mfh_ctx *c, size_t bytes);
 int expand_mm_region(mfh_ctx *c, uint64_t off, uint32_t nrows, const uint8_t *c8, uint8_t *image);
 // encmm.hip: mfh_encrypt_rows with <sk, a> on the matrix cores (off and the row length multiples of 8)
 int encrypt_rows_mm(mfh_ctx *c, uint64_t off, size_t nrows, const uint64_t *sk, const uint32_t *msg, const uint64_t *err, uint8_t *c8);
+// encmm.hip: regev_decrypt batches with <a, sk> on the matrix cores: full ciphertexts in HBM / seed-compressed ciphertexts (a regenerated)
+int decrypt_mm(mfh_ctx *c, const uint64_t *sk, const uint64_t *cts, size_t count, uint32_t *out);
+int decrypt_rows_mm(mfh_ctx *c, uint64_t off, size_t nrows, const uint64_t *sk, const uint8_t *c8, uint32_t *out);
 
 // Operands of one multi-vector launch (evalmm.hip): coefficient vector v is coef[0] + v * nrows for v < csplit, else
 // coef[1] + (v - csplit) * nrows; its result goes to out[0] + v * ostride for v < osplit, else out[1] + (v - osplit) * ostride

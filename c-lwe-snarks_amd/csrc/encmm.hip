@@ -203,8 +203,258 @@ __global__ __launch_bounds__(256) void k_encrypt_finish_mm(const int *__restrict
   for (int l = G::KW; l < G::CTB / 4; l++) o[l] = 0;
 }
 
+// ---- regev_decrypt (src/lwe.c:105-111) for batches: m = (b - (<a, sk> mod 2^(64K))) mod p, the dot product as the same Toeplitz int8 GEMM ---------------
+// (1) FULL ciphertexts resident in HBM ((n + 1) values of L limbs): k_decrypt_mm.  G[i][t] = sum_k A[i][k] B[k][t] with K = the bytes of the
+//     ciphertext's a part as they lie in memory (n x 8L: 96-byte elements at logq 736, the top 8 bytes of each meeting zero rows of B) -- the A operand of
+//     v_mfma_i32_16x16x64_i8 is "16 consecutive K bytes of one row per lane" = one 16-byte global load.  HBM-bound by construction (141 KB
+//     per decryption against 1.7 10^7 int8 multiply-adds); what has to be kept off the memory pipe is B: 6 KiB per 64 K-bytes, the same for every
+//     row, staged through LDS once per workgroup and group of 4 k-steps and read from there by its 8 waves (one row tile = 16 rows per wave).
+//     Vector-memory loads return in order, so every global load of the loop is consumed exactly one group after its issue: the A fragments
+//     of group s + 1 and the B staging words of group s + 2 are issued at the top of group s.  Measured (65 536 ciphertexts, 9.25 GB): 1.89 ms =
+//     4.9 TB/s; row tiles per wave x k-steps per group = 2 x 2: 2.10, 2 x 4: 1.95, 1 x 4: 1.89 ms; non-temporal loads 2.6-2.9 ms (a lane's
+//     64-byte half lines want the cache to keep the other half); without the ds_bpermute below 2.05 ms.
+//     Signedness: A' = A ^ 0x80 (= A - 128), Sb balanced; sum A Sb = sum A' Sb + 128 PS[t] as in k_encrypt_mm (the pad bytes meet B = 0).
+// (2) SEED-COMPRESSED ciphertexts (stream offset + the 92-byte b of ct_export, what the CRS holds): the a part is regenerated -- that is
+//     k_encrypt_mm as it stands (AES-bound), with a finishing kernel that subtracts instead of adding e p + m.
+#ifndef DEC_RT  /* timing variants: tools/build_variant.sh encmm "-DDEC_RT=1 -DDEC_GK=4" */
+#define DEC_RT 1
+#endif
+#ifndef DEC_GK
+#define DEC_GK 4
+#endif
+#ifndef DEC_WAVES
+#define DEC_WAVES 8
+#endif
 template <int LOGQ>
-int encrypt_rows_mm_t(mfh_ctx *c, uint64_t off, size_t nrows, const uint64_t *sk, const uint32_t *msg, const uint64_t *err, uint8_t *c8) {
+struct DG {
+  static constexpr int ELB = EG<LOGQ>::L * 8;          // bytes of a value in memory (96 | 184)
+  static constexpr int RT = LOGQ == 736 ? DEC_RT : 1;  // row tiles (16 rows) per wave
+  static constexpr int WAVES = DEC_WAVES, ROWS = WAVES * RT * 16, GK = DEC_GK;  // k-steps per group
+};
+
+template <int LOGQ>
+__global__ __launch_bounds__(DG<LOGQ>::WAVES * 64) void k_decrypt_mm(const uint8_t *__restrict__ cts, uint64_t ct_stride, uint32_t nrows, uint32_t ksteps,
+                                                                     uint32_t ks_per_chunk, const v4i *__restrict__ bf, int *__restrict__ part) {
+  using D = DG<LOGQ>;
+  constexpr int NQ = EG<LOGQ>::NQ, RT = D::RT, GK = D::GK, NT = D::WAVES * 64;
+  constexpr int BPG = GK * NQ * 64;                 // v4i of B per group
+  constexpr int SPT = (BPG + NT - 1) / NT;          // staging words per thread and group
+  __shared__ v4i bs[2][BPG];
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t r = lane & 15, g = lane >> 4;
+  const uint32_t row0 = blockIdx.y * D::ROWS + wave * (RT * 16);
+  const uint32_t ks0 = blockIdx.x * ks_per_chunk, ks1 = min(ksteps, ks0 + ks_per_chunk);
+  if (ks0 >= ks1) return;  // (uniform; the host launches no empty chunk)
+  const uint32_t ngroups = (ks1 - ks0 + GK - 1) / GK;
+  const uint8_t *ap[RT];
+#pragma unroll
+  for (int t = 0; t < RT; t++) ap[t] = cts + (uint64_t)min(row0 + 16 * t + r, nrows - 1) * ct_stride + 16 * g;  // (rows past the end: clamped, dropped at the end)
+  // k-steps past ks1 - 1 are clamped to it for the loads (no branches around loads: s_waitcnt counts stay static) and skipped in the MFMAs
+  // The MFMA wants lane (g, r) to hold K bytes 16 g .. 16 g + 15 of row r: neighbouring lanes are neighbouring ROWS, 141 KB apart, and a load in that
+  // shape is 64 separate 16-byte requests (measured: 2.05 ms per 65 536 ciphertexts whatever the prefetch depth).  So the load is issued in a coalesced
+  // shape -- lane l takes segment l & 3 of row l >> 2: a quad reads 64 contiguous bytes -- and the four dwords are moved to their MFMA lanes with
+  // ds_bpermute_b32 (lane 16 g + r reads lane 16 (r >> 2) + 4 (r & 3) + g): a wave-local pass through the LDS crossbar, no LDS memory, no barrier.
+#ifdef DEC_NO_BPERM
+  constexpr bool kBperm = false;
+#else
+  constexpr bool kBperm = true;
+#endif
+  if (kBperm) {
+#pragma unroll
+    for (int t = 0; t < RT; t++) ap[t] = cts + (uint64_t)min(row0 + 16 * t + (lane >> 2), nrows - 1) * ct_stride + 16 * (lane & 3);
+  }
+  const int bperm_src = (int)(4 * (16 * (r >> 2) + 4 * (r & 3) + g));
+  auto to_mfma_lanes = [&](v4i x) -> v4i {
+    x ^= v4i{(int)0x80808080u, (int)0x80808080u, (int)0x80808080u, (int)0x80808080u};  // A - 128
+    if (!kBperm) return x;
+    return v4i{__builtin_amdgcn_ds_bpermute(bperm_src, x[0]), __builtin_amdgcn_ds_bpermute(bperm_src, x[1]), __builtin_amdgcn_ds_bpermute(bperm_src, x[2]),
+               __builtin_amdgcn_ds_bpermute(bperm_src, x[3])};
+  };
+  auto a_load = [&](int t, uint32_t ks) -> v4i { return *reinterpret_cast<const v4i *>(ap[t] + (uint64_t)min(ks, ks1 - 1) * 64); };
+  auto b_load = [&](uint32_t grp, int i) -> v4i {
+    const uint32_t w = tid + NT * i;  // word of the group: (k-step of the group, q, lane)
+    const uint32_t ks = min(ks0 + grp * GK + w / (NQ * 64), ks1 - 1);
+    return bf[(uint64_t)ks * NQ * 64 + w % (NQ * 64)];
+  };
+  v4i acc[RT][NQ];
+#pragma unroll
+  for (int t = 0; t < RT; t++)
+#pragma unroll
+    for (int q = 0; q < NQ; q++) acc[t][q] = v4i{0, 0, 0, 0};
+  v4i a[GK][RT], bst[SPT];
+#pragma unroll
+  for (int i = 0; i < SPT; i++)
+    if (tid + NT * i < BPG) bs[0][tid + NT * i] = b_load(0, i);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < SPT; i++) bst[i] = b_load(1 < ngroups ? 1 : 0, i);
+#pragma unroll
+  for (int k = 0; k < GK; k++)
+#pragma unroll
+    for (int t = 0; t < RT; t++) a[k][t] = a_load(t, ks0 + k);
+  __builtin_amdgcn_sched_barrier(0);
+  __syncthreads();
+  for (uint32_t grp = 0; grp < ngroups; grp++) {
+    const v4i *bcur = bs[grp & 1];
+    v4i acur[GK][RT];
+#pragma unroll
+    for (int k = 0; k < GK; k++)
+#pragma unroll
+      for (int t = 0; t < RT; t++) acur[k][t] = to_mfma_lanes(a[k][t]);
+    // the staging words of group grp + 1 (loaded a group ago) go to the other buffer, which group grp - 1 has finished with (barrier below)
+#pragma unroll
+    for (int i = 0; i < SPT; i++)
+      if (tid + NT * i < BPG) bs[(grp & 1) ^ 1][tid + NT * i] = bst[i];
+    // issue: staging words of group grp + 2, then the A fragments of group grp + 1 -- all consumed one group from now
+    const uint32_t g2 = min(grp + 2, ngroups - 1), g1 = grp + 1;
+#pragma unroll
+    for (int i = 0; i < SPT; i++) bst[i] = b_load(g2, i);
+#pragma unroll
+    for (int k = 0; k < GK; k++)
+#pragma unroll
+      for (int t = 0; t < RT; t++) a[k][t] = a_load(t, ks0 + g1 * GK + k);
+#pragma unroll
+    for (int k = 0; k < GK; k++) {
+      if (ks0 + grp * GK + k < ks1) {  // (uniform)
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+          const v4i b = bcur[(k * NQ + q) * 64 + lane];
+#pragma unroll
+          for (int t = 0; t < RT; t++) acc[t][q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(acur[k][t], b, acc[t][q], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // D: register e of lane (c = r, g) = row 4 g + e of the tile, column c
+#pragma unroll
+  for (int t = 0; t < RT; t++)
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const uint32_t orow = row0 + 16 * t + 4 * g + e;
+      if (orow >= nrows) continue;
+      int *p = part + ((uint64_t)orow * gridDim.x + blockIdx.x) * (16 * NQ) + r;
+#pragma unroll
+      for (int q = 0; q < NQ; q++) p[16 * q] = acc[t][q][e];
+    }
+}
+
+__device__ __forceinline__ uint32_t words_mod_p_(const uint32_t *w, int nw) {  // 2^32 = 5 (mod p): Horner from the top word
+  uint64_t r = 0;
+  for (int l = nw - 1; l >= 0; l--) r = (r * 5 + w[l]) % MFH_P;
+  return (uint32_t)r;
+}
+// out[row] = (b - dot) mod p with dot = sum_t (G[t] + 128 PS[t]) 256^t mod 2^(64K) and b the row's last value: FULL = 1: the L limbs at
+// bsrc + row * bstride (taken whole: ct_import does not reduce it, src/lwe.c:125), FULL = 0: the CT_BYTES of ct_export.  One wave per row.
+template <int LOGQ, int FULL>
+__global__ __launch_bounds__(256) void k_decrypt_finish_mm(const int *__restrict__ part, uint32_t nchunks, uint32_t nrows, const int64_t *__restrict__ ps,
+                                                           const uint8_t *__restrict__ bsrc, uint64_t bstride, uint32_t *__restrict__ out) {
+  using G = EG<LOGQ>;
+  constexpr int NC = 16 * G::NQ;
+  __shared__ int64_t xs[4][NC];
+  __shared__ int64_t ws[4][G::KW];
+  const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t row = blockIdx.x * 4 + wv;
+  if (row < nrows) {
+    const int *p = part + (uint64_t)row * nchunks * NC;
+    for (uint32_t t = lane; t < (uint32_t)G::SBY; t += 64) {
+      int64_t x = 128 * ps[t];
+      for (uint32_t ch = 0; ch < nchunks; ch++) x += p[(uint64_t)ch * NC + t];
+      xs[wv][t] = x;
+    }
+  }
+  __syncthreads();
+  if (row < nrows && lane < (uint32_t)G::KW) {
+    int64_t w = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) w += xs[wv][4 * lane + k] * ((int64_t)1 << (8 * k));
+    ws[wv][lane] = w;
+  }
+  __syncthreads();
+  if (row >= nrows || lane != 0) return;
+  uint32_t dot[G::KW];
+  int64_t dcarry = 0;  // signed digit chain: two's complement is arithmetic mod 2^(64K) all the same
+  for (int l = 0; l < G::KW; l++) {
+    const int64_t x = ws[wv][l] + dcarry;
+    dcarry = x >> 32;  // arithmetic
+    dot[l] = (uint32_t)x;
+  }
+  constexpr int BW = FULL ? 2 * G::L : G::CTB / 4;
+  uint32_t b[BW];
+  const uint32_t *bp = reinterpret_cast<const uint32_t *>(bsrc + (uint64_t)row * bstride);
+  for (int l = 0; l < BW; l++) b[l] = bp[l];
+  const uint32_t bm = words_mod_p_(b, BW), dm = words_mod_p_(dot, G::KW);
+  out[row] = (uint32_t)(((uint64_t)bm + MFH_P - dm) % MFH_P);
+}
+
+// per-key operands shared by the three matrix-core forms: balanced digits, prefix sums, Toeplitz fragments for element stride `ctb` (heads 0 and, for
+// stream rows, 8).  Returns the scratch layout in w / sb / ps / bf / part; the caller zeroes [w, w + keyed) after its launches.
+struct KeyOps { uint8_t *w; int8_t *sb; int64_t *ps; v4i *bf; int *part; size_t keyed; };
+template <int LOGQ>
+int key_operands(mfh_ctx *c, const uint64_t *sk, uint32_t ctb, uint32_t rowlen, uint32_t ksteps, int nheads, size_t part_b, KeyOps &K) {
+  using G = EG<LOGQ>;
+  const uint32_t n = c->P.n;
+  const size_t sb_b = ((size_t)n * G::SBY + 255) & ~(size_t)255, ps_b = 2 * 256 * 8;  // ps | column sums
+  const size_t bf_b = (size_t)nheads * ksteps * G::NQ * 1024;
+  int rc = ws_reserve(c, sb_b + ps_b + bf_b + part_b);
+  if (rc) return rc;
+  K.w = (uint8_t *)c->ws;
+  K.sb = (int8_t *)K.w;
+  K.ps = (int64_t *)(K.w + sb_b);
+  K.bf = (v4i *)(K.w + sb_b + ps_b);
+  K.part = (int *)(K.w + sb_b + ps_b + bf_b);
+  K.keyed = sb_b + ps_b + bf_b;
+  hipLaunchKernelGGL(k_sk_digits, dim3((n + 255) / 256), dim3(256), 0, c->stream, sk, n, (uint32_t)G::L, (uint32_t)G::SBY, K.sb);
+  long long *col = (long long *)(K.ps + 256);
+  HIP_TRY(c, hipMemsetAsync(col, 0, 256 * 8, c->stream));
+  hipLaunchKernelGGL(k_sk_colsum, dim3((n + 63) / 64), dim3(256), 0, c->stream, K.sb, n, (uint32_t)G::SBY, col);
+  hipLaunchKernelGGL(k_sk_prefix, dim3(1), dim3(256), 0, c->stream, col, (uint32_t)G::SBY, K.ps);
+  const uint64_t nfr = (uint64_t)ksteps * G::NQ * 64;
+  for (int h = 0; h < nheads; h++)
+    hipLaunchKernelGGL(k_toeplitz_frag, dim3((uint32_t)((nfr + 255) / 256)), dim3(256), 0, c->stream, K.sb, ctb, (uint32_t)G::SBY, (uint32_t)G::NQ, ksteps, rowlen,
+                       8u * h, K.bf + (size_t)h * nfr);
+  HIP_TRY(c, hipGetLastError());
+  return MFH_OK;
+}
+
+template <int LOGQ>
+int decrypt_mm_t(mfh_ctx *c, const uint64_t *sk, const uint64_t *cts, size_t count, uint32_t *out) {
+  using G = EG<LOGQ>;
+  using D = DG<LOGQ>;
+  const uint32_t n = c->P.n;
+  const uint64_t klen = (uint64_t)n * D::ELB;  // K: the bytes of the a part as they lie in memory
+  if (klen > 0x7fffffffu || count > 0x7fffffffu) return MFH_EUNSUPPORTED;
+  const uint32_t ksteps = (uint32_t)((klen + 63) / 64);
+  // K chunks: no int32 accumulator may see more than 131 071 products of magnitude <= 2^14 (n x SBY non-zero B entries per column at most), and
+  // the chunks set the dispatch grain: about four workgroups per workgroup slot (2 per CU) keep the CUs evenly loaded to the end
+  uint32_t kc = 1;
+  if ((uint64_t)n * G::SBY > 131071) kc = (ksteps * 64 + 131070) / 131071;
+  const uint32_t nblk = ((uint32_t)count + D::ROWS - 1) / D::ROWS;
+  kc = std::max(kc, std::min(std::max(1u, ksteps / 64), (8u * c->ncu + nblk - 1) / nblk));
+  uint32_t kpc = (ksteps + kc - 1) / kc;
+  kpc = (kpc + D::GK - 1) / D::GK * D::GK;
+  kc = (ksteps + kpc - 1) / kpc;
+  KeyOps K;
+  int rc = key_operands<LOGQ>(c, sk, (uint32_t)D::ELB, (uint32_t)klen, ksteps, 1, (size_t)count * kc * 16 * G::NQ * 4, K);
+  if (rc) return rc;
+  const uint64_t ct_stride = (uint64_t)(n + 1) * D::ELB;
+  {
+    Timer t(c, 11, count);
+    hipLaunchKernelGGL(k_decrypt_mm<LOGQ>, dim3(kc, nblk), dim3(D::WAVES * 64), 0, c->stream, reinterpret_cast<const uint8_t *>(cts), ct_stride, (uint32_t)count, ksteps,
+                       kpc, K.bf, K.part);
+  }
+  HIP_TRY(c, hipGetLastError());
+  hipLaunchKernelGGL((k_decrypt_finish_mm<LOGQ, 1>), dim3(((uint32_t)count + 3) / 4), dim3(256), 0, c->stream, K.part, kc, (uint32_t)count, K.ps,
+                     reinterpret_cast<const uint8_t *>(cts) + (uint64_t)n * D::ELB, ct_stride, out);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemsetAsync(K.w, 0, K.keyed, c->stream));  // nothing derived from the secret key outlives the call in the shared scratch
+  return MFH_OK;
+}
+
+// column chunks of a k_encrypt_mm launch over nrows stream rows
+struct EncPlan { uint32_t rowlen, ksteps, nblk, kc, kpc; };
+template <int LOGQ>
+int enc_plan(mfh_ctx *c, size_t nrows, EncPlan &P) {
   using G = EG<LOGQ>;
   const uint32_t n = c->P.n;
   const uint64_t rowlen64 = (uint64_t)n * G::CTB;
@@ -234,36 +484,53 @@ int encrypt_rows_mm_t(mfh_ctx *c, uint64_t off, size_t nrows, const uint64_t *sk
   if (c->enc_chunks) kc = std::max<uint32_t>(kc_min, c->enc_chunks);  // tuning override (mfh_set_encrypt_chunks: at most 64)
   const uint32_t kpc = (ksteps + kc - 1) / kc;
   kc = (ksteps + kpc - 1) / kpc;
-  const size_t sb_b = ((size_t)n * G::SBY + 255) & ~(size_t)255, ps_b = 2 * 256 * 8;  // ps | column sums
-  const size_t bf_b = (size_t)2 * ksteps * G::NQ * 1024;
-  const size_t part_b = (size_t)nrows * kc * 16 * G::NQ * 4;
-  int rc = ws_reserve(c, sb_b + ps_b + bf_b + part_b);
+  P = EncPlan{rowlen, ksteps, nblk, kc, kpc};
+  return MFH_OK;
+}
+
+template <int LOGQ>
+int encrypt_rows_mm_t(mfh_ctx *c, uint64_t off, size_t nrows, const uint64_t *sk, const uint32_t *msg, const uint64_t *err, uint8_t *c8) {
+  using G = EG<LOGQ>;
+  EncPlan P;
+  int rc = enc_plan<LOGQ>(c, nrows, P);
   if (rc) return rc;
-  uint8_t *w = (uint8_t *)c->ws;
-  int8_t *sb = (int8_t *)w;
-  int64_t *ps = (int64_t *)(w + sb_b);
-  v4i *bf = (v4i *)(w + sb_b + ps_b);
-  int *part = (int *)(w + sb_b + ps_b + bf_b);
-  hipLaunchKernelGGL(k_sk_digits, dim3((n + 255) / 256), dim3(256), 0, c->stream, sk, n, (uint32_t)G::L, (uint32_t)G::SBY, sb);
-  long long *col = (long long *)(ps + 256);
-  HIP_TRY(c, hipMemsetAsync(col, 0, 256 * 8, c->stream));
-  hipLaunchKernelGGL(k_sk_colsum, dim3((n + 63) / 64), dim3(256), 0, c->stream, sb, n, (uint32_t)G::SBY, col);
-  hipLaunchKernelGGL(k_sk_prefix, dim3(1), dim3(256), 0, c->stream, col, (uint32_t)G::SBY, ps);
-  const uint64_t nfr = (uint64_t)ksteps * G::NQ * 64;
-  for (uint32_t h = 0; h < 2; h++)
-    hipLaunchKernelGGL(k_toeplitz_frag, dim3((uint32_t)((nfr + 255) / 256)), dim3(256), 0, c->stream, sb, (uint32_t)G::CTB, (uint32_t)G::SBY, (uint32_t)G::NQ, ksteps,
-                       rowlen, 8 * h, bf + (size_t)h * nfr);
+  KeyOps K;
+  rc = key_operands<LOGQ>(c, sk, (uint32_t)G::CTB, P.rowlen, P.ksteps, 2, (size_t)nrows * P.kc * 16 * G::NQ * 4, K);
+  if (rc) return rc;
   AesKey keyx = c->key;
   for (int i = 56; i < 60; i++) keyx.rk[i] ^= 0x80808080u;  // the keystream bytes come out as A - 128
   {
     Timer t(c, 3, nrows);
-    hipLaunchKernelGGL(k_encrypt_mm<LOGQ>, dim3(kc, nblk), dim3(1024), 0, c->stream, keyx, c->d_t0, off, rowlen, (uint32_t)nrows, ksteps, kpc, bf, part);
+    hipLaunchKernelGGL(k_encrypt_mm<LOGQ>, dim3(P.kc, P.nblk), dim3(1024), 0, c->stream, keyx, c->d_t0, off, P.rowlen, (uint32_t)nrows, P.ksteps, P.kpc, K.bf, K.part);
   }
   HIP_TRY(c, hipGetLastError());
-  hipLaunchKernelGGL(k_encrypt_finish_mm<LOGQ>, dim3(((uint32_t)nrows + 3) / 4), dim3(256), 0, c->stream, part, kc, (uint32_t)nrows, ps, msg, err, c8);
+  hipLaunchKernelGGL(k_encrypt_finish_mm<LOGQ>, dim3(((uint32_t)nrows + 3) / 4), dim3(256), 0, c->stream, K.part, P.kc, (uint32_t)nrows, K.ps, msg, err, c8);
   HIP_TRY(c, hipGetLastError());
   // the balanced digits of the secret key, their prefix sums and Toeplitz fragments do not outlive the call in the shared scratch
-  HIP_TRY(c, hipMemsetAsync(w, 0, sb_b + ps_b + bf_b, c->stream));
+  HIP_TRY(c, hipMemsetAsync(K.w, 0, K.keyed, c->stream));
+  return MFH_OK;
+}
+
+// regev_decrypt of nrows SEED-COMPRESSED ciphertexts (row i: the a part at stream offset off + i * n * CT_BYTES, b = the CT_BYTES at c8): the same launch
+template <int LOGQ>
+int decrypt_rows_mm_t(mfh_ctx *c, uint64_t off, size_t nrows, const uint64_t *sk, const uint8_t *c8, uint32_t *out) {
+  using G = EG<LOGQ>;
+  EncPlan P;
+  int rc = enc_plan<LOGQ>(c, nrows, P);
+  if (rc) return rc;
+  KeyOps K;
+  rc = key_operands<LOGQ>(c, sk, (uint32_t)G::CTB, P.rowlen, P.ksteps, 2, (size_t)nrows * P.kc * 16 * G::NQ * 4, K);
+  if (rc) return rc;
+  AesKey keyx = c->key;
+  for (int i = 56; i < 60; i++) keyx.rk[i] ^= 0x80808080u;
+  {
+    Timer t(c, 13, nrows);
+    hipLaunchKernelGGL(k_encrypt_mm<LOGQ>, dim3(P.kc, P.nblk), dim3(1024), 0, c->stream, keyx, c->d_t0, off, P.rowlen, (uint32_t)nrows, P.ksteps, P.kpc, K.bf, K.part);
+  }
+  HIP_TRY(c, hipGetLastError());
+  hipLaunchKernelGGL((k_decrypt_finish_mm<LOGQ, 0>), dim3(((uint32_t)nrows + 3) / 4), dim3(256), 0, c->stream, K.part, P.kc, (uint32_t)nrows, K.ps, c8, (uint64_t)G::CTB, out);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemsetAsync(K.w, 0, K.keyed, c->stream));
   return MFH_OK;
 }
 
@@ -273,4 +540,15 @@ int encrypt_rows_mm_t(mfh_ctx *c, uint64_t off, size_t nrows, const uint64_t *sk
 int encrypt_rows_mm(mfh_ctx *c, uint64_t off, size_t nrows, const uint64_t *sk, const uint32_t *msg, const uint64_t *err, uint8_t *c8) {
   if (c->P.logq == 736) return encrypt_rows_mm_t<736>(c, off, nrows, sk, msg, err, c8);
   return encrypt_rows_mm_t<1472>(c, off, nrows, sk, msg, err, c8);
+}
+
+// the matrix-core form of mfh_decrypt: count full ciphertexts in HBM
+int decrypt_mm(mfh_ctx *c, const uint64_t *sk, const uint64_t *cts, size_t count, uint32_t *out) {
+  if (c->P.logq == 736) return decrypt_mm_t<736>(c, sk, cts, count, out);
+  return decrypt_mm_t<1472>(c, sk, cts, count, out);
+}
+// regev_decrypt of seed-compressed ciphertexts (needs off and the row length to be multiples of 8, like encrypt_rows_mm)
+int decrypt_rows_mm(mfh_ctx *c, uint64_t off, size_t nrows, const uint64_t *sk, const uint8_t *c8, uint32_t *out) {
+  if (c->P.logq == 736) return decrypt_rows_mm_t<736>(c, off, nrows, sk, c8, out);
+  return decrypt_rows_mm_t<1472>(c, off, nrows, sk, c8, out);
 }

@@ -153,6 +153,20 @@ __device__ __forceinline__ void expand_tile_to_lds(const uint8_t *tab, const mf:
   }
 }
 
+// the same for ONE wave and its private tile: lane l takes blocks l, l + 64, ...
+__device__ __forceinline__ void expand_tile_wave(const uint8_t *tab, const mf::AesLane &L, const AesKey &key, uint8_t *ks, const TileGeom &g, uint32_t lane,
+                                                 const uint32_t (*spanc)[8]) {
+  const uint64_t sp0 = g.cb0 >> 8;
+  for (uint32_t b = lane; b < g.nblk; b += 64) {
+    const uint64_t ctr = g.cb0 + b;
+    const uint32_t *scp = spanc[(uint32_t)((ctr >> 8) - sp0)];
+    uint32_t sc[5] = {scp[0], scp[1], scp[2], scp[3], scp[4]};
+    uint32_t w[4];
+    mf::aes256_ctr_block_sc(tab, L, key, ctr, sc, w);
+    *reinterpret_cast<uint4 *>(ks + 16 * b) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // eval kernel: fused ct_import + ct_addmul_ui over the active rows, 1 or 2 coefficient vectors.
 // grid = (ntiles, nchunks); block = ROWS x TILE threads; thread (rs, t) owns coordinate j0 + t for the rows
@@ -276,6 +290,104 @@ __global__ __launch_bounds__(PS<LOGQ>::THREADS) void k_eval(AesKey key, const ui
       }
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// k_eval_w: the same fused ct_import + ct_addmul_ui (src/lwe.c:122-126,141-149,176-186) with WAVE-autonomous work: no workgroup
+// barrier after the table fill.  An EXPERIMENT that answers "do k_eval's barriers and phases cost its 66.6 Gblock/s against the bare loop's
+// 73 at the same occupancy?" -- they do not: this kernel, bit-identical, runs at 63.7 Gblock/s (single proof 10.25 against 9.83 ms, same box,
+// tools/eval_ab.py).  k_eval's tile of 2944 blocks is exactly 46 wave-rounds of 64 blocks (whole waves take whole rounds: 92 per iteration and
+// CU); a wave-private chunk of 368 blocks is 5.75 rounds, i.e. 6 with the last three quarters full: 96 per CU -- 4.3 % more LDS lookups, and the
+// kernel is 4.4 % slower: the AES kernels are bound by the LDS pipe (32 bank accesses per clock and CU; k_eval sustains 22.9 LDS operations per
+// clock, the bare loop at 8 waves per SIMD 29.7), not by their barriers.  Kept behind mfh_set_eval_path(ctx, 1) as the measured alternative.
+// A wave owns 64 coordinates (64 x 92 B = exactly 368 AES blocks) of a row chunk and a PRIVATE 5.9 KB tile: it computes its 2-3
+// span constants (3 lanes), expands its 368 (369 when the row starts mid-block) blocks, reads its coordinates back (stride 23 words:
+// conflict-free) and multiplies, row after row, never waiting for another wave; the 16 waves of a CU drift apart, so one wave's
+// multiply-accumulate (VALU) runs under the others' table lookups (LDS).  LDS operations of one wave complete in order, so the
+// tile needs no barrier, only s_waitcnt.  23 column chunks (1472 = n + 1 coordinates + 1 pad) x nrc row chunks = one wave each;
+// 16 waves per workgroup share the table: 64 KiB + 16 x 5904 B + span constants = 158.3 KB, one workgroup per CU, 4 waves per SIMD.
+// logq = 736 only (at 1472 a wave's tile is 11.8 KB: the LDS holds 8 of them; k_eval stays).
+// partials: part[((row chunk * NACC + a) * KW + l) * NJ + j], NJ = 64 x column chunks: what k_eval_reduce_sum / _carry read.
+// ------------------------------------------------------------------------------------------------------
+constexpr int kEvalwWaves = 16;
+template <int NACC>
+__global__ __launch_bounds__(kEvalwWaves * 64) void k_eval_w(AesKey key, const uint32_t *__restrict__ g_t0, uint64_t off, uint32_t n,
+                                                             const uint32_t *__restrict__ idx, const uint32_t *__restrict__ cnt, uint32_t nrows_dense,
+                                                             const uint8_t *__restrict__ c8, const uint32_t *__restrict__ coeff0,
+                                                             const uint32_t *__restrict__ coeff1, uint32_t ncc /* column chunks */, uint32_t nrc /* row chunks */,
+                                                             uint32_t *__restrict__ part) {
+  using S = PS<736>;
+  constexpr int WBLK = 64 * S::CTB / 16 + 1;  // 369 blocks: 64 coordinates, +1 when the row starts at byte 8 of a block
+  struct __attribute__((aligned(16))) Lds {   // AES table first => LDS address 0 (see k_eval)
+    uint32_t lt[mf::kTabBytes / 4];
+    uint8_t tile[kEvalwWaves][WBLK * 16];
+    uint32_t spanc[kEvalwWaves][4][8];
+  };
+  __shared__ Lds lds;
+  mf::lds_fill_tab(lds.lt, g_t0);
+  __syncthreads();  // the only workgroup barrier
+  const uint8_t *tab = reinterpret_cast<const uint8_t *>(lds.lt);
+  const mf::AesLane L = mf::aes_lane();
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t gw = blockIdx.x * kEvalwWaves + wave;  // wave of the launch: column chunk fastest, so that a workgroup's waves work on the same rows
+  const uint32_t cc = gw % ncc, rc = gw / ncc;
+  if (rc >= nrc) return;
+  uint8_t *ks = lds.tile[wave];
+  uint32_t(*spanc)[8] = lds.spanc[wave];
+  const uint32_t j0 = cc * 64, j = j0 + lane;
+  const uint32_t nelem = j0 >= n ? 0u : min(64u, n - j0);  // keystream-backed coordinates of this chunk
+  const uint32_t nact = idx ? cnt[0] : nrows_dense;
+  const uint32_t per = (nact + nrc - 1) / nrc;
+  const uint32_t k0 = rc * per, k1 = min(nact, k0 + per);
+  const uint32_t NJ = ncc * 64;
+  uint32_t acc[NACC][S::KW];
+#pragma unroll
+  for (int a = 0; a < NACC; a++)
+#pragma unroll
+    for (int l = 0; l < S::KW; l++) acc[a][l] = 0;
+  for (uint32_t k = k0; k < k1; k++) {
+    const uint32_t row = idx ? idx[k] : k;  // (wave-uniform)
+    const TileGeom g = tile_geom<736>(off + (uint64_t)row * n * S::CTB, j0, nelem);
+    uint32_t c[NACC];
+    c[0] = coeff0[row];
+    if constexpr (NACC > 1) c[1] = coeff1[row];
+    // span constants of this row's blocks (at most 3 spans of 256 counters), one lane each; every lane then reads them back
+    fill_span_table(tab, L, key, g, lane, spanc);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    expand_tile_wave(tab, L, key, ks, g, lane, spanc);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (j <= n) {
+      uint32_t a[S::KW];
+      if (j < n) {
+        const uint32_t *kw = reinterpret_cast<const uint32_t *>(ks + g.head) + lane * S::EW;
+#pragma unroll
+        for (int l = 0; l < S::KW; l++) a[l] = kw[l];
+      } else {
+        const uint32_t *bw = reinterpret_cast<const uint32_t *>(c8 + (uint64_t)row * S::CTB);
+#pragma unroll
+        for (int l = 0; l < S::KW; l++) a[l] = bw[l];
+      }
+#pragma unroll
+      for (int q = 0; q < NACC; q++) {
+        uint32_t carry = 0;
+#pragma unroll
+        for (int l = 0; l < S::KW; l++) {
+          uint64_t tt = (uint64_t)a[l] * c[q] + acc[q][l] + carry;
+          acc[q][l] = (uint32_t)tt;
+          carry = (uint32_t)(tt >> 32);
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the tile and the span constants are rewritten by the next row
+    __builtin_amdgcn_wave_barrier();
+  }
+#pragma unroll
+  for (int a = 0; a < NACC; a++)
+#pragma unroll
+    for (int l = 0; l < S::KW; l++) part[(((uint64_t)rc * NACC + a) * S::KW + l) * NJ + j] = acc[a][l];
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -928,6 +1040,10 @@ int mfh_ctx_create(mfh_ctx **out, int device, const mfh_params *P) {
   mfh_ctx *c = new mfh_ctx();
   c->P = *P;
   c->device = device;
+  {
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) c->ncu = (uint32_t)ncu;
+  }
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
     delete c;
     return MFH_EDEVICE;
@@ -1013,6 +1129,11 @@ int mfh_set_encrypt_path(mfh_ctx *c, int path) {
   return MFH_OK;
 }
 
+int mfh_set_eval_path(mfh_ctx *c, int path) {
+  if (!c || path < 0 || path > 1) return MFH_EINVAL;
+  c->eval_path = path;
+  return MFH_OK;
+}
 int mfh_set_encrypt_chunks(mfh_ctx *c, uint32_t chunks) {
   if (!c || chunks > 64) return MFH_EINVAL;
   c->enc_chunks = chunks;
@@ -1065,6 +1186,8 @@ static int timing_kind(const char *which) {
   if (!strcmp(which, "evalmm")) return 7;
   if (!strcmp(which, "evalmm_resident")) return 8;
   if (!strcmp(which, "expandmm")) return 9;
+  if (!strcmp(which, "decrypt")) return 11;       // k_decrypt_mm (full ciphertexts from HBM)
+  if (!strcmp(which, "decrypt_rows")) return 13;  // k_encrypt_mm run for mfh_decrypt_rows (seed-compressed ciphertexts)
   if (!strcmp(which, "mmstream_rounds")) return 10;  // the streaming launches that serve several groups (a subset of "evalmm_resident")
   return -1;
 }
@@ -1230,17 +1353,23 @@ static int eval_rows(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *c8, 
                      uint64_t *rop1, int accumulate) {
   using S = PS<LOGQ>;
   const uint32_t n = c->P.n;
-  const uint32_t ntiles = (n + 1 + S::TILE - 1) / S::TILE;
   const int nacc = c1 ? 2 : 1;
+  // the tile kernel (k_eval) by default; mfh_set_eval_path(ctx, 1) at logq 736: the wave-autonomous kernel (k_eval_w) -- 64-coordinate column chunks x
+  // row chunks, one wave each, 16 waves per workgroup, the launch sized to one workgroup per CU (the LDS admits one).  Measured 4 % slower (see k_eval_w).
+  const bool wavek = LOGQ == 736 && c->eval_path == 1;
+  const uint32_t ncc = (n + 1 + 63) / 64;
+  uint32_t nrc = std::max(1u, (uint32_t)((uint64_t)c->ncu * kEvalwWaves / ncc));
+  nrc = std::min(nrc, std::max(1u, ((uint32_t)nrows + 7) / 8));  // >= 8 rows per wave
+  const uint32_t ntiles = (n + 1 + S::TILE - 1) / S::TILE;
   const uint32_t nchunks = pick_chunks((uint32_t)nrows, ntiles, S::ROWS);
-  const uint32_t nslabs = nchunks;  // the two row halves of a workgroup are folded before they leave the kernel
-  const uint32_t NJ = ntiles * S::TILE;
+  const uint32_t nslabs = wavek ? nrc : nchunks;  // (k_eval folds the two row halves of a workgroup before they leave the kernel)
+  const uint32_t NJ = wavek ? ncc * 64 : ntiles * S::TILE;
   const size_t part_bytes = (size_t)nslabs * nacc * S::KW * NJ * 4;
   const uint32_t NG = 8;  // slab groups of the first reduction stage
   const size_t idx_bytes = (((size_t)nrows + 1) * 4 + 255) & ~(size_t)255;
   int rc = ws_reserve(c, part_bytes + idx_bytes);
   if (rc) return rc;
-  rc = lazy_reserve(c, (size_t)nacc * S::KW * NJ * 8);
+  rc = lazy_reserve(c, (size_t)nacc * S::KW * (size_t)std::max(NJ, ntiles * S::TILE) * 8);
   if (rc) return rc;
   uint32_t *part = (uint32_t *)c->ws;
   uint64_t *lazy = c->lazy;
@@ -1253,7 +1382,13 @@ static int eval_rows(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *c8, 
   }
   {
     Timer t(c, nacc, nrows);
-    if (nacc == 2)
+    if (wavek) {
+      const dim3 grid((ncc * nrc + kEvalwWaves - 1) / kEvalwWaves);
+      if (nacc == 2)
+        hipLaunchKernelGGL(k_eval_w<2>, grid, dim3(kEvalwWaves * 64), 0, c->stream, c->key, c->d_t0, off, n, idx, cnt, (uint32_t)nrows, c8, c0, c1, ncc, nrc, part);
+      else
+        hipLaunchKernelGGL(k_eval_w<1>, grid, dim3(kEvalwWaves * 64), 0, c->stream, c->key, c->d_t0, off, n, idx, cnt, (uint32_t)nrows, c8, c0, c1, ncc, nrc, part);
+    } else if (nacc == 2)
       hipLaunchKernelGGL((k_eval<LOGQ, 2>), dim3(ntiles, nchunks), dim3(S::THREADS), 0, c->stream, c->key, c->d_t0, off, n, idx, cnt,
                          (uint32_t)nrows, c8, c0, c1, part);
     else
@@ -1483,9 +1618,28 @@ int mfh_decrypt(mfh_ctx *c, const uint64_t *d_sk, const uint64_t *d_cts, size_t 
   if (!c || (count && (!d_sk || !d_cts || !d_out))) return MFH_EINVAL;
   if (!count) return MFH_OK;
   HIP_TRY(c, hipSetDevice(c->device));
+  // batches: <a, sk> as a Toeplitz int8 GEMM on the matrix cores (encmm.hip), HBM-bound; small counts stay on the VALU kernel (no per-key operand
+  // preparation: 0.13 ms)
+  if (c->dec_path == 2 || (c->dec_path == 0 && count >= 4096)) return decrypt_mm(c, d_sk, d_cts, count, d_out);
   DISPATCH_LOGQ(c, hipLaunchKernelGGL(k_decrypt<736>, dim3((uint32_t)count), dim3(256), 0, c->stream, d_sk, d_cts, c->P.n, d_out),
                 hipLaunchKernelGGL(k_decrypt<1472>, dim3((uint32_t)count), dim3(256), 0, c->stream, d_sk, d_cts, c->P.n, d_out));
   HIP_TRY(c, hipGetLastError());
+  return MFH_OK;
+}
+
+int mfh_decrypt_rows(mfh_ctx *c, uint64_t off, size_t nrows, const uint64_t *d_sk, const uint8_t *d_c8, uint32_t *d_out) {
+  if (!c || (nrows && (!d_sk || !d_c8 || !d_out)) || nrows > 0x7fffffffu) return MFH_EINVAL;
+  NEED_SEED(c);
+  if (!nrows) return MFH_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint64_t rowlen = (uint64_t)c->P.n * (c->P.logq / 8);
+  if ((off & 7) != 0 || (rowlen & 7) != 0) { c->err = "mfh_decrypt_rows: off and the row length must be multiples of 8"; return MFH_EUNSUPPORTED; }
+  return decrypt_rows_mm(c, off, nrows, d_sk, d_c8, d_out);
+}
+
+int mfh_set_decrypt_path(mfh_ctx *c, int path) {
+  if (!c || path < 0 || path > 2) return MFH_EINVAL;
+  c->dec_path = path;
   return MFH_OK;
 }
 

@@ -125,6 +125,13 @@ int mfh_set_encrypt_path(mfh_ctx *ctx, int path);
 
 /* Batched regev_decrypt (src/lwe.c:105-111) of `count` explicit ciphertexts: d_out[i] = (b - <a,sk> mod 2^(64K)) mod p */
 int mfh_decrypt(mfh_ctx *ctx, const uint64_t *d_sk, const uint64_t *d_cts, size_t count, uint32_t *d_out);
+/* mfh_decrypt: 0 (default) = by batch size (from 4096 ciphertexts <a, sk> runs as a Toeplitz int8 GEMM on the matrix cores, HBM-bound), 1 = VALU kernel,
+ * 2 = matrix-core kernel.  Same results. */
+int mfh_set_decrypt_path(mfh_ctx *ctx, int path);
+/* regev_decrypt (src/lwe.c:105-111) of nrows SEED-COMPRESSED ciphertexts -- the form ct_export / the CRS hold (src/lwe.c:115-126): row i's a part is
+ * regenerated from the public stream at off + i * n * CT_BYTES (ct_import), d_c8 holds its CT_BYTES little-endian b.  d_out[i] = (b - <a, sk>) mod p.
+ * off and n * CT_BYTES must be multiples of 8 (MFH_EUNSUPPORTED otherwise).  AES-bound like mfh_encrypt_rows. */
+int mfh_decrypt_rows(mfh_ctx *ctx, uint64_t off, size_t nrows, const uint64_t *d_sk, const uint8_t *d_c8, uint32_t *d_out);
 
 /* mpz_add_dotp (src/lwe.c:20-28): rop = (rop + sum_{j<len} a[j]*b[j]) mod 2^(64K); rop is one value, a and b are len values */
 int mfh_add_dotp(mfh_ctx *ctx, uint64_t *d_rop, const uint64_t *d_a, const uint64_t *d_b, size_t len);
@@ -217,6 +224,9 @@ int mfh_set_batch_slabs(mfh_ctx *ctx, uint32_t nslabs);
 /* tuning knobs (results do not depend on them; MFH_EINVAL outside the range): column chunks per row of the matrix-core encryption kernel
  * (0 = picked from the batch size, at most 64); statements per witness GEMM pass of the batch chain (0 = 248, else 32..256). */
 int mfh_set_encrypt_chunks(mfh_ctx *ctx, uint32_t chunks);
+/* mfh_eval_rows / mfh_prove*: 0 (default) = tile kernel (k_eval: two 512-coordinate row tiles per workgroup), 1 = at logq = 736 the wave-autonomous
+ * kernel (k_eval_w: a wave owns 64 coordinates and a private keystream tile, no workgroup barriers; measured 4 % slower).  Same results (A/B, tests). */
+int mfh_set_eval_path(mfh_ctx *ctx, int path);
 int mfh_set_witness_per(mfh_ctx *ctx, uint32_t statements);
 /* launch shape of the streaming regime of mfh_prove_batch* (tuning; results do not depend on it): groups of 31 proofs served by one pass
  * over a region's image (1..8, default 4), and whether the S and AS groups of a round share ONE launch (default) or run as two

@@ -604,3 +604,25 @@ uint64_t mfo_bench_encrypt(const mfo_params *P, const uint8_t seed[40], size_t c
   free(sk); free(ct);
   return x;
 }
+
+/* `count` regev_decrypt calls (src/lwe.c:105-111, what src/benchmark_lwe.c:35-38 times) on one sampled ciphertext and key */
+uint64_t mfo_bench_decrypt(const mfo_params *P, const uint8_t seed[40], size_t count)
+{
+  uint32_t L = mfo_L(P);
+  size_t ctl = (size_t)(P->n + 1) * L;
+  uint64_t *sk = malloc((size_t)P->n * L * 8), *ct = calloc(ctl, 8);
+  mfo_rng rng, krng;
+  uint8_t kseed[40];
+  for (int i = 0; i < 40; i++) kseed[i] = (uint8_t)(seed[i] ^ 0xa5);
+  mfo_rng_init(&krng, kseed);
+  mfo_sample_a(P, sk, &krng);
+  mfo_rng_init(&rng, seed);
+  mfo_sample_a(P, ct, &rng);
+  uint64_t x = 0;
+  for (size_t i = 0; i < count; i++) {
+    ct[(size_t)P->n * L] = i; /* b */
+    x ^= mfo_decrypt(P, sk, ct) + i;
+  }
+  free(sk); free(ct);
+  return x;
+}

@@ -132,6 +132,7 @@ int mfo_verifier(const mfo_params *P, const uint8_t *ssp, uint64_t alpha, uint64
 /* one prover row-touch: ct_import + ct_addmul_ui, repeated `rows` times; returns a checksum */
 uint64_t mfo_bench_eval_rows(const mfo_params *P, const uint8_t seed[40], size_t rows);
 uint64_t mfo_bench_encrypt(const mfo_params *P, const uint8_t seed[40], size_t count);
+uint64_t mfo_bench_decrypt(const mfo_params *P, const uint8_t seed[40], size_t count);
 
 #ifdef __cplusplus
 }

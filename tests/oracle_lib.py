@@ -53,6 +53,7 @@ class Oracle:
         L.mfo_poly_divides.restype = ctypes.c_int
         L.mfo_bench_eval_rows.restype = ctypes.c_uint64
         L.mfo_bench_encrypt.restype = ctypes.c_uint64
+        L.mfo_bench_decrypt.restype = ctypes.c_uint64
 
     # ---- params ----
     @staticmethod
@@ -224,6 +225,10 @@ class Oracle:
     def bench_eval_rows(self, p, seed, rows):
         cp = self.cp(p)
         return int(self.lib.mfo_bench_eval_rows(ctypes.byref(cp), ctypes.c_char_p(bytes(seed)), ctypes.c_size_t(rows)))
+
+    def bench_decrypt(self, p, seed, count):
+        cp = self.cp(p)
+        return int(self.lib.mfo_bench_decrypt(ctypes.byref(cp), ctypes.c_char_p(bytes(seed)), ctypes.c_size_t(count)))
 
     def bench_encrypt(self, p, seed, count):
         cp = self.cp(p)

@@ -99,8 +99,17 @@ def test_ct_mul_ui_rejects_scalar_ge_p(ctx, mf):
         ctx.ct_mul_ui(d, 0xFFFFFFFB)  # the reference asserts b < GAMMA_P (src/lwe.c:133)
 
 
-@pytest.mark.parametrize("nrows,nacc,off_kind", [(1, 1, "s"), (2, 1, "s"), (37, 2, "s"), (100, 1, "as"), (9, 2, "bv"), (64, 2, "odd")])
-def test_eval_rows_matches_oracle(ctx, oracle, mf, nrows, nacc, off_kind):
+@pytest.mark.parametrize("path", [0, 1])  # 0 = tile kernel (k_eval), 1 = wave-autonomous kernel (k_eval_w)
+@pytest.mark.parametrize("nrows,nacc,off_kind", [(1, 1, "s"), (2, 1, "s"), (37, 2, "s"), (100, 1, "as"), (9, 2, "bv"), (64, 2, "odd"), (700, 2, "as")])
+def test_eval_rows_matches_oracle(ctx, oracle, mf, nrows, nacc, off_kind, path):
+    ctx.set_eval_path(path)
+    try:
+        _eval_rows_case(ctx, oracle, mf, nrows, nacc, off_kind)
+    finally:
+        ctx.set_eval_path(0)
+
+
+def _eval_rows_case(ctx, oracle, mf, nrows, nacc, off_kind):
     p = mf.DEBUG
     off = {"s": p.ctr_s, "as": p.ctr_as, "bv": p.ctr_bv, "odd": p.ctr_ct * 3 + 0}[off_kind]
     rng = np.random.default_rng(nrows * 10 + nacc)
@@ -373,3 +382,73 @@ def test_degenerate_inputs(ctx, mf):
     d_ssp = ctx.ssp_upload(ssp)
     w = ctx.to_host(ctx.witness_poly(d_ssp, bytes((p.m + 7) // 8), 3), np.uint32)
     assert np.array_equal(w.astype(np.uint64), ssp[: p.d] * np.uint64(3) % np.uint64(ol.P))
+
+
+# ---------------------------------------------------------------- regev_decrypt as a batch on the matrix cores (encmm.hip)
+@pytest.mark.parametrize("logq", [736, 1472])
+def test_decrypt_matrix_core_path_matches_oracle(gpu_ctx_factory, oracle, mf, logq):
+    """mfh_decrypt with <a, sk> as a Toeplitz int8 GEMM (k_decrypt_mm) against the oracle's regev_decrypt (src/lwe.c:105-111) on ciphertexts with
+    unreduced b (as after a raw ct_import), all-ones / zero values and a key with extreme balanced digits; counts that are multiples of neither
+    the 32-row wave tile nor the 256-row workgroup; both paths against each other"""
+    p = mf.Params(logq=logq, d=64, m=16)
+    c = gpu_ctx_factory(p)
+    rng = np.random.default_rng(logq)
+    sk = ol.rand_values(rng, p.n, p.L, p.logq)
+    sk[0] = ol.int_to_limbs((1 << p.logq) - 1, p.L)      # digits 0xff ... : every balanced digit carries
+    sk[1] = ol.int_to_limbs(int("80" * p.ctb, 16), p.L)  # digits 0x80: the most negative balanced digit
+    sk[2] = 0
+    count = 37
+    cts = _rand_ct(rng, p, count=count)
+    cts[0, :p.n] = ol.int_to_limbs((1 << p.logq) - 1, p.L)
+    cts[1, :p.n] = 0
+    cts[2, 5] = ol.int_to_limbs((1 << (64 * p.L)) - 1, p.L)  # bits above logq set in memory (an unreduced value): only the low 64K bits may matter
+    d_sk, d_ct = c.to_device(sk), c.to_device(cts)
+    c.set_decrypt_path(2)
+    try:
+        got = c.to_host(c.decrypt(d_sk, d_ct, count), np.uint32)
+    finally:
+        c.set_decrypt_path(0)
+    c.set_decrypt_path(1)
+    try:
+        valu = c.to_host(c.decrypt(d_sk, d_ct, count), np.uint32)
+    finally:
+        c.set_decrypt_path(0)
+    for i in range(count):
+        want = oracle.decrypt(p, sk, cts[i])
+        assert int(got[i]) == want, f"ciphertext {i}: matrix-core path"
+        assert int(valu[i]) == want, f"ciphertext {i}: VALU path"
+
+
+def test_decrypt_paths_agree_on_a_batch_and_recover_the_messages(gpu_ctx_factory, mf):
+    """4200 real encryptions (rows of the public stream): the full ciphertexts through k_decrypt (VALU) and k_decrypt_mm (default from 4096 on),
+    and their seed-compressed form through mfh_decrypt_rows (a regenerated from the stream): all three return the messages"""
+    import torch
+
+    p = mf.DEBUG
+    c = gpu_ctx_factory(p)
+    c.set_seed(SEED)
+    rng = np.random.default_rng(4200)
+    B = 4200
+    sk = ol.rand_values(rng, p.n, p.L, p.logq)
+    msg = rng.integers(0, ol.P, size=B, dtype=np.uint64).astype(np.uint32)
+    err = ol.rand_values(rng, B, p.L, 559)
+    off = 8 * 12345
+    d_sk = c.to_device(sk)
+    c8 = c.encrypt_rows(off, B, d_sk, c.to_device(msg), c.to_device(err))
+    cts = torch.zeros((B, p.n + 1, p.L), dtype=torch.int64, device=c.device)
+    cts[:, : p.n] = c.sample_rows(off, B).view(torch.int64).view(B, p.n, p.L)
+    bpad = torch.zeros((B, p.L * 8), dtype=torch.uint8, device=c.device)
+    bpad[:, : p.ctb] = c8.view(B, p.ctb)
+    cts[:, p.n] = bpad.view(torch.int64)
+    flat = cts.view(torch.uint8).reshape(-1)
+    want = torch.from_numpy(msg.view(np.int32)).to(c.device)
+    auto = c.decrypt(d_sk, flat, B).view(torch.int32)
+    c.set_decrypt_path(1)
+    try:
+        valu = c.decrypt(d_sk, flat, B).view(torch.int32)
+    finally:
+        c.set_decrypt_path(0)
+    rows = c.decrypt_rows(off, B, d_sk, c8).view(torch.int32)
+    assert torch.equal(auto, want) and torch.equal(valu, want) and torch.equal(rows, want)
+    with pytest.raises(mf.MfhError):
+        c.decrypt_rows(off + 4, B, d_sk, c8)  # rows must start at byte 0 or 8 of an AES block
