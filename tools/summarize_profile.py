@@ -8,12 +8,13 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-out_dir = os.path.join(ROOT, "profiles")
+RAW = os.environ.get("PROF_RAW", os.path.join(ROOT, "gpurun_out"))  # where the rocprofv3 output directories are (on the GPU box: /tmp, the raw CSVs exceed what gpurun copies back)
+out_dir = os.environ.get("PROF_OUT", os.path.join(ROOT, "profiles"))
 os.makedirs(out_dir, exist_ok=True)
 
 
 def one(pattern):
-    g = glob.glob(os.path.join(ROOT, "gpurun_out", pattern))
+    g = glob.glob(os.path.join(RAW, pattern))
     return max(g, key=os.path.getmtime) if g else None   # gpurun merges outputs of earlier calls: take the newest
 
 
@@ -22,7 +23,8 @@ f = one(f"{tag}_stats/*/*_kernel_stats.csv")
 if f:
     rows = list(csv.DictReader(open(f)))
     with open(os.path.join(out_dir, f"{tag}_kernel_stats.csv"), "w") as o:
-        o.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline   (MI355X, 1 GPU; default batch mode: the single-proof path (regenerated and resident), then the headline run, then the regenerate-per-group and resident-image variants of the same batch, then the LWE batch)\n")
+        commit_ = sys.argv[2] if len(sys.argv) > 2 else os.popen("git -C %s rev-parse --short HEAD" % ROOT).read().strip()
+        o.write(f"# commit {commit_}: rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline   (MI355X, 1 GPU; default batch mode: the single-proof path (regenerated and resident), then the headline run, then the regenerate-per-group and resident-image variants of the same batch, then the LWE encryption and decryption batches).  k_mmstream = the 8-group S / AS rounds (bench.py's roofline kernel), k_mmstream1 = single-group launches (b_w)\n")
         o.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
         for r in rows:
             o.write(",".join(['"' + r["Name"][:110].replace('"', "'") + '"', r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]]) + "\n")
@@ -32,68 +34,49 @@ if f:
             if line.startswith("{"):
                 open(os.path.join(out_dir, f"{tag}_bench_under_rocprof.json"), "w").write(line)
 
-# PMC
+# PMC: separate passes per counter group (fetch / write / sq) and per program (batch = the headline call, enc = the LWE batch, dec = the decryption batch;
+# round 1/2 layout: one directory per counter group)
+commit = sys.argv[2] if len(sys.argv) > 2 else os.popen("git -C %s rev-parse --short HEAD" % ROOT).read().strip()
 res = {}
 for name in ("fetch", "write", "sq"):
-    f = one(f"{tag}_pmc_{name}/*/*_counter_collection.csv")
-    if not f:
-        continue
-    agg = defaultdict(lambda: defaultdict(list))
-    for r in csv.DictReader(open(f)):
-        agg[r["Kernel_Name"][:80]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    for k, cs in agg.items():
-        for c, v in cs.items():
-            big = [x for x in v if x >= 0.5 * max(v)] if max(v) > 0 else v  # the launches of the larger shape (S / AS regions, 4 groups)
-            res.setdefault(k, {})[c] = {"launches": len(v), "mean": sum(v) / len(v), "max": max(v), "mean_of_large_launches": sum(big) / len(big),
-                                        "large_launches": len(big)}
-json.dump(res, open(os.path.join(out_dir, f"{tag}_pmc_by_kernel.json"), "w"), indent=1)
-ev2 = next((v for k, v in res.items() if k.startswith("void k_eval<736, 2>")), None)
-if ev2 and "FETCH_SIZE" in ev2 and "WRITE_SIZE" in ev2:
-    # MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are in KiB-like units (x1024 -> bytes); on gfx950 FETCH_SIZE reports 1/2 of a wide
-    # coalesced read stream -> doubled (upper bound for this kernel, whose reads are 4-byte gathers of the CRS b's and coefficients).
-    fetch = ev2["FETCH_SIZE"]["mean"] * 1024 * 2
-    write = ev2["WRITE_SIZE"]["mean"] * 1024
-    json.dump({"kernel": "k_eval<736,2>", "fetch_bytes_x2_corrected": fetch, "write_bytes": write, "hbm_bytes_per_launch": fetch + write,
-               "note": "separate --pmc passes; FETCH_SIZE doubled per the gfx950 correction"}, open(os.path.join(out_dir, "traffic_eval2.json"), "w"), indent=1)
-    print("traffic", fetch + write)
-mm = next((v for k, v in res.items() if "k_evalmm16" in k), None)
-if mm and "FETCH_SIZE" in mm and "WRITE_SIZE" in mm:
-    fetch = mm["FETCH_SIZE"]["mean"] * 1024 * 2
-    write = mm["WRITE_SIZE"]["mean"] * 1024
-    json.dump({"kernel": "k_evalmm16", "fetch_bytes_x2_corrected": fetch, "write_bytes": write, "hbm_bytes_per_launch": fetch + write,
-               "note": "separate --pmc passes; FETCH_SIZE doubled per the gfx950 correction (upper bound: the kernel reads the 3 MB compressed CRS "
-                       "region and the 8 MB digit matrix, and writes 132 MB of int32 partial products)"},
-              open(os.path.join(out_dir, "traffic_evalmm.json"), "w"), indent=1)
-    print("traffic evalmm", fetch + write)
-ms = next((v for k, v in res.items() if "k_mmstream" in k), None)
-if ms and "FETCH_SIZE" in ms and "WRITE_SIZE" in ms:
-    fetch = ms["FETCH_SIZE"]["mean_of_large_launches"] * 1024 * 2
-    write = ms["WRITE_SIZE"]["mean_of_large_launches"] * 1024
-    json.dump({"kernel": "k_mmstream", "fetch_bytes_x2_corrected": fetch, "write_bytes": write, "hbm_bytes_per_launch": fetch + write,
-               "note": "separate --pmc passes; FETCH_SIZE doubled per the gfx950 correction for wide coalesced streaming reads; launches over the "
-                       "whole S and AS regions for 4 + 4 groups of 31 proofs (the b_w launches, one group over the shorter BT+BV region, excluded). "
-                       "Algorithmic: 2 x 4.24 GB of A fragments once + 8 x 8 MB of digits read, 8 x 133 MB of int32 partial products written; the "
-                       "workgroups consume 8 x 4.24 GB of fragments, the rest of which L2 serves"},
-              open(os.path.join(out_dir, "traffic_mmstream.json"), "w"), indent=1)
-    print("traffic mmstream", fetch + write)
-for key, fname, note in (("k_expand_mm", "traffic_expandmm.json", "the barrier-free CRS expansion: reads the compressed CRS region (92 B per row), writes the image region (129 536 B per row)"),
-                         ("k_encrypt_mm", "traffic_encryptmm.json", "reads the Toeplitz(sk) fragments (12.7 MB per head value, from L2 after the first workgroups), writes 384 B of int32 partial sums per row and column chunk")):
+    files = glob.glob(os.path.join(RAW, f"{tag}_pmc_{name}*/*/*_counter_collection.csv"))
+    for f in files:
+        agg = defaultdict(lambda: defaultdict(list))
+        for r in csv.DictReader(open(f)):
+            agg[r["Kernel_Name"][:80]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, cs in agg.items():
+            for c, v in cs.items():
+                big = [x for x in v if x >= 0.5 * max(v)] if max(v) > 0 else v  # the launches of the larger shape
+                res.setdefault(k, {})[c] = {"launches": len(v), "mean": sum(v) / len(v), "max": max(v), "mean_of_large_launches": sum(big) / len(big),
+                                            "large_launches": len(big)}
+json.dump({"commit": commit, "kernels": res}, open(os.path.join(out_dir, f"{tag}_pmc_by_kernel.json"), "w"), indent=1)
+
+# HBM traffic per launch (MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE in KiB; on gfx950 FETCH_SIZE reports half the bytes of a wide coalesced read stream:
+# doubled -- an upper bound where the reads are not wide streams)
+TRAFFIC = [
+    ("k_mmstream(", "traffic_mmstream.json", "k_mmstream", "launches over the whole S and AS regions for 4 + 4 groups of 31 proofs.  Algorithmic: 2 x 4.24 GB of A fragments once + 8 x 8 MB of "
+     "digits read, 8 x 133 MB of int32 partial products written; the workgroups consume 8 x 4.24 GB of fragments, the rest of which L2 / Infinity Cache serve"),
+    ("k_mmstream1(", "traffic_mmstream1.json", "k_mmstream1", "one group per launch: b_w's pass over the BT+BV image (2.83 GB of fragments), HBM-bound"),
+    ("k_expand_mm", "traffic_expandmm.json", "k_expand_mm", "the barrier-free CRS expansion: reads the compressed CRS region (92 B per row), writes the image region (129 536 B per row)"),
+    ("k_encrypt_mm", "traffic_encryptmm.json", "k_encrypt_mm", "reads the Toeplitz(sk) fragments (12.7 MB per head value, from L2 after the first workgroups), writes 384 B of int32 partial sums per row and column chunk"),
+    ("k_decrypt_mm", "traffic_decryptmm.json", "k_decrypt_mm", "65 536 full ciphertexts of 141 216 B streamed once (9.25 GB), Toeplitz(sk) fragments through LDS (13.2 MB, L2), 384 B of int32 partial sums "
+     "written per row and column chunk"),
+    ("k_witness_mm8q(", "traffic_witnessmm.json", "k_witness_mm8q", "one read of the SSP image in fragment order (2.86 GB) per 248 statements, 248 x 128 KB of w written"),
+    ("k_evalmm_finish_groups", "traffic_evalmm_finish.json", "k_evalmm_finish_groups", "reads the int32 partial products of a round's 8 groups (8 x 133 MB), writes their ciphertexts"),
+    ("k_ntt_lds_mul8", "traffic_ntt_lds.json", "k_ntt_lds_mul8", "2048-point blocks of 248 x 3 transforms: forward low stages, pointwise product, inverse low stages"),
+    ("void k_eval<736, 2>", "traffic_eval2.json", "k_eval<736,2>", "the single-proof kernel: ~0 HBM bytes by construction (CRS b's, coefficients, partials)"),
+    ("void k_mac_resident<736, 2>", "traffic_mac2.json", "k_mac_resident<736,2>", "the resident single-proof regime: one read of the expanded region"),
+]
+for key, fname, kname, note in TRAFFIC:
     kk = next((v for k, v in res.items() if key in k), None)
     if kk and "FETCH_SIZE" in kk and "WRITE_SIZE" in kk:
         fetch = kk["FETCH_SIZE"]["mean_of_large_launches"] * 1024 * 2
         write = kk["WRITE_SIZE"]["mean_of_large_launches"] * 1024
-        json.dump({"kernel": key, "fetch_bytes_x2_corrected": fetch, "write_bytes": write, "hbm_bytes_per_launch": fetch + write,
-                   "note": "separate --pmc passes; FETCH_SIZE doubled per the gfx950 correction (an upper bound where reads are not wide streams); " + note},
+        json.dump({"kernel": kname, "commit": commit, "profile": f"{tag}_pmc_by_kernel.json", "fetch_bytes_x2_corrected": fetch, "write_bytes": write, "hbm_bytes_per_launch": fetch + write,
+                   "launches": kk["FETCH_SIZE"]["large_launches"],
+                   "note": "separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE); FETCH_SIZE doubled per the gfx950 correction for wide coalesced reads; " + note},
                   open(os.path.join(out_dir, fname), "w"), indent=1)
-        print("traffic", key, fetch + write)
-mr = next((v for k, v in res.items() if k.startswith("void k_mac_resident<736, 2>")), None)
-if mr and "FETCH_SIZE" in mr and "WRITE_SIZE" in mr:
-    fetch = mr["FETCH_SIZE"]["mean"] * 1024 * 2
-    write = mr["WRITE_SIZE"]["mean"] * 1024
-    json.dump({"kernel": "k_mac_resident<736,2>", "fetch_bytes_x2_corrected": fetch, "write_bytes": write, "hbm_bytes_per_launch": fetch + write,
-               "note": "separate --pmc passes; FETCH_SIZE doubled per the gfx950 correction for wide coalesced streaming reads"},
-              open(os.path.join(out_dir, "traffic_mac2.json"), "w"), indent=1)
-    print("traffic mac2", fetch + write)
+        print("traffic", kname, f"{(fetch + write) / 1e9:.3f} GB per launch")
 for k, v in res.items():
-    if "k_mac_resident" in k or "k_eval<736, 2>" in k or "k_encrypt<736>" in k or "k_keystream" in k:
-        print(k, {c: round(x["mean"]) for c, x in v.items()})
+    if "SQ_INSTS_VALU_MFMA_I8" in v:
+        print(k[:60], {c: round(x["mean_of_large_launches"]) for c, x in v.items()})
