@@ -208,10 +208,10 @@ __global__ __launch_bounds__(256) void k_encrypt_finish_mm(const int *__restrict
 //     ciphertext's a part as they lie in memory (n x 8L: 96-byte elements at logq 736, the top 8 bytes of each meeting zero rows of B) -- the A operand of
 //     v_mfma_i32_16x16x64_i8 is "16 consecutive K bytes of one row per lane" = one 16-byte global load.  HBM-bound by construction (141 KB
 //     per decryption against 1.7 10^7 int8 multiply-adds); what has to be kept off the memory pipe is B: 6 KiB per 64 K-bytes, the same for every
-//     row, staged through LDS once per workgroup and group of 4 k-steps and read from there by its 8 waves (one row tile = 16 rows per wave).
+//     row, staged through LDS once per workgroup and group of 4 k-steps and read from there by its 16 waves (one row tile = 16 rows per wave).
 //     Vector-memory loads return in order, so every global load of the loop is consumed exactly one group after its issue: the A fragments
 //     of group s + 1 and the B staging words of group s + 2 are issued at the top of group s.  Measured (65 536 ciphertexts, 9.25 GB): 1.89 ms =
-//     4.9 TB/s; row tiles per wave x k-steps per group = 2 x 2: 2.10, 2 x 4: 1.95, 1 x 4: 1.89 ms; non-temporal loads 2.6-2.9 ms (a lane's
+//     4.9 TB/s with 8 waves per workgroup, 1.82 - 1.87 ms with 16 (4 waves: 2.29: the more rows share a staged B, the better); row tiles per wave x k-steps per group = 2 x 2: 2.10, 2 x 4: 1.95, 1 x 4: 1.89 ms; non-temporal loads 2.6-2.9 ms (a lane's
 //     64-byte half lines want the cache to keep the other half); without the ds_bpermute below 2.05 ms.
 //     Signedness: A' = A ^ 0x80 (= A - 128), Sb balanced; sum A Sb = sum A' Sb + 128 PS[t] as in k_encrypt_mm (the pad bytes meet B = 0).
 // (2) SEED-COMPRESSED ciphertexts (stream offset + the 92-byte b of ct_export, what the CRS holds): the a part is regenerated -- that is
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void k_encrypt_finish_mm(const int *__restrict
 #define DEC_GK 4
 #endif
 #ifndef DEC_WAVES
-#define DEC_WAVES 8
+#define DEC_WAVES 16
 #endif
 template <int LOGQ>
 struct DG {

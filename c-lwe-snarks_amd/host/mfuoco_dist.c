@@ -250,6 +250,7 @@ int mfuoco_comm_create_rehearsal(mfuoco_comm **out, int rank, int world, int dev
     if (c->shm->world != (uint32_t)world) dist_die("rehearsal segment", "world size differs from rank 0's");
   }
   shm_barrier(c);
+  if (rank == 0) shm_unlink(c->shm_name); /* every rank has mapped it: the name can go now, so that a rank that dies later leaks nothing in /dev/shm */
   *out = c;
   return 0;
 }
@@ -264,7 +265,6 @@ void mfuoco_comm_destroy(mfuoco_comm *c)
   if (c->kind == KIND_SHM) {
     shm_barrier(c);
     munmap(c->shm, c->shm_total);
-    if (c->rank == 0) shm_unlink(c->shm_name);
   }
   free(c);
 }
