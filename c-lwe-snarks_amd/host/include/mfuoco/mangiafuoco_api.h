@@ -111,6 +111,10 @@ void mfuoco_gpu_invalidate(void);
 /* prover() for `count` statements under one CRS and SSP: rows expanded once per group of proofs, multiply-accumulate on the matrix
  * cores; every proof is what prover() would produce with the same randomness.  pis[k] initialised by proof_init. */
 void mfuoco_prover_batch(proof_t *pis, crs_t crs, ssp_t ssp, mpz_t *witnesses, size_t count);
+/* verifier() for `count` proofs under one SSP and key, on the device: ok[k] = 1 iff pis[k] is accepted (src/snark.c:192-250 per proof) */
+void mfuoco_verifier_batch(ssp_t ssp, vrs_t vrs, proof_t *pis, size_t count, uint8_t *ok);
+/* regev_decrypt for `count` ciphertexts under one key (src/lwe.c:105-111 per ciphertext); ms[k] initialised by the caller */
+void mfuoco_decrypt_batch(mpz_t *ms, sk_t sk, ct_t *cts, size_t count);
 /* select the GPU (default 0, or $MFUOCO_GPU); must precede the first call */
 void mfuoco_gpu_set_device(int device);
 

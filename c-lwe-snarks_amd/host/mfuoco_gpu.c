@@ -566,3 +566,51 @@ bool verifier(ssp_t ssp, vrs_t vrs, proof_t pi)
   /* the reference's "test-error" bound (src/snark.c:238-241) can never reject: SIZ of a non-positive value is <= 0 */
   return true;
 }
+
+/* verifier() (src/snark.c:192-250) for `count` proofs under one SSP and verification key, entirely on the device (mfh_verify: t(s), v_0(s), the
+ * 5 x count decryptions on the matrix cores from 820 proofs on, the four equations): ok[k] = 1 iff proof k is accepted.  Not in the reference. */
+void mfuoco_verifier_batch(ssp_t ssp, vrs_t vrs, proof_t *pis, size_t count, uint8_t *ok)
+{
+  if (!count) return;
+  gpu();
+  ssp_resident(ssp);
+  ct_to_dev(G.d_sk, vrs->sk, GAMMA_N);
+  uint64_t *d_proofs = NULL, *h = malloc(count * 5 * CTL * 8);
+  uint8_t *d_ok = NULL;
+  HK(hipMalloc((void **)&d_proofs, count * 5 * CTL * 8));
+  HK(hipMalloc((void **)&d_ok, count));
+  for (size_t k = 0; k < count; k++) {
+    mpz_t *cts[5] = { pis[k]->h, pis[k]->hat_h, pis[k]->hat_v, pis[k]->v_w, pis[k]->b_w };
+    for (int q = 0; q < 5; q++)
+      for (size_t j = 0; j <= GAMMA_N; j++) to_limbs(h + ((k * 5 + q) * (GAMMA_N + 1) + j) * L_LIMBS, cts[q][j]);
+  }
+  HK(hipMemcpy(d_proofs, h, count * 5 * CTL * 8, hipMemcpyHostToDevice));
+  free(h);
+  CK(mfh_verify(G.ctx, G.d_ssp, (uint32_t)vrs->alpha, (uint32_t)vrs->beta, (uint32_t)vrs->s, G.d_sk, d_proofs, count, d_ok));
+  HK(hipMemcpy(ok, d_ok, count, hipMemcpyDeviceToHost));
+  HK(hipFree(d_proofs));
+  HK(hipFree(d_ok));
+}
+
+/* regev_decrypt (src/lwe.c:105-111) for `count` ciphertexts under one key: ms[k] initialised by the caller.  From 4096 ciphertexts the dot products run
+ * as a Toeplitz int8 GEMM on the matrix cores (mfh_decrypt).  Not in the reference (src/benchmark_lwe.c:35-38 decrypts one at a time). */
+void mfuoco_decrypt_batch(mpz_t *ms, sk_t sk, ct_t *cts, size_t count)
+{
+  if (!count) return;
+  gpu();
+  ct_to_dev(G.d_sk, sk, GAMMA_N);
+  uint64_t *d_cts = NULL, *h = malloc(count * CTL * 8);
+  uint32_t *d_m = NULL, *hm = malloc(count * 4);
+  HK(hipMalloc((void **)&d_cts, count * CTL * 8));
+  HK(hipMalloc((void **)&d_m, count * 4));
+  for (size_t k = 0; k < count; k++)
+    for (size_t j = 0; j <= GAMMA_N; j++) to_limbs(h + (k * (GAMMA_N + 1) + j) * L_LIMBS, cts[k][j]);
+  HK(hipMemcpy(d_cts, h, count * CTL * 8, hipMemcpyHostToDevice));
+  free(h);
+  CK(mfh_decrypt(G.ctx, G.d_sk, d_cts, count, d_m));
+  HK(hipMemcpy(hm, d_m, count * 4, hipMemcpyDeviceToHost));
+  for (size_t k = 0; k < count; k++) mpz_set_ui(ms[k], hm[k]);
+  free(hm);
+  HK(hipFree(d_cts));
+  HK(hipFree(d_m));
+}

@@ -174,6 +174,27 @@ static void t_snark(void)
     mpz_combit(wit[1], 3);
     mfuoco_prover_batch(pb, crs, ssp, wit, 3);
     CHECK(verifier(ssp, vrs, pb[0]) && !verifier(ssp, vrs, pb[1]) && verifier(ssp, vrs, pb[2]));
+    uint8_t okb[3] = { 9, 9, 9 };
+    mfuoco_verifier_batch(ssp, vrs, pb, 3, okb); /* the same three through the device verifier */
+    CHECK(okb[0] == 1 && okb[1] == 0 && okb[2] == 1);
+    { /* and their h ciphertexts through the batched decryption: what regev_decrypt returns one by one */
+      mpz_t mb[3], one;
+      ct_t cb[3];
+      mpz_init(one);
+      for (int k = 0; k < 3; k++) {
+        mpz_init(mb[k]);
+        ct_init(cb[k]);
+        for (size_t j = 0; j <= GAMMA_N; j++) mpz_set(cb[k][j], pb[k]->h[j]);
+      }
+      mfuoco_decrypt_batch(mb, vrs->sk, cb, 3);
+      for (int k = 0; k < 3; k++) {
+        regev_decrypt(one, vrs->sk, pb[k]->h);
+        CHECK(!mpz_cmp(one, mb[k]));
+        mpz_clear(mb[k]);
+        ct_clear(cb[k]);
+      }
+      mpz_clear(one);
+    }
     for (int k = 0; k < 3; k++) { proof_clear(pb[k]); mpz_clear(wit[k]); }
   }
   proof_clear(pi);
