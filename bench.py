@@ -225,6 +225,11 @@ def main():
             print(f"[bench] error: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr, flush=True)
         return 2
 
+    # stdout carries the ONE JSON line and nothing else: whatever the libraries print there (gloo's connection messages, for one) goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
 
     import c_lwe_snarks_amd as mf
@@ -928,7 +933,8 @@ def main():
             "resident_crs": resident if mode == "single" else None,
             "cpu_baseline": cpu,
         }
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
         accepted = ok_all
     if dist is not None:
         dist.barrier()
