@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """bench.py -- proofs/s of the reference's benchmark_snark prover (src/benchmark_snark.c:70-74) on MI355X.
 
-Default (--mode batch): one "step" = ONE mfh_prove_batch call over --batch (992) statements per GPU on the NDEBUG default SSP
+Default (--mode batch): one "step" = ONE mfh_prove_batch call over --batch (1020 = 4 super-groups of 255) statements per GPU on the NDEBUG default SSP
 instance (D = 2^15 constraints, M = 21845 wires, N = 1470, log q = 736; src/lwe.h:14-31), starting from the COMPRESSED CRS exactly as
 the reference's prover() does (src/snark.c:117-190): the call expands all (2D+M) x 135 240 B of AES-256-CTR keystream on the CU into
-a transient image inside the timed region, then streams it per group of 31 proofs with the multiply-accumulate on the matrix cores;
+a transient image inside the timed region, then streams it -- two passes over a region's image per 255 proofs -- with the multiply-accumulate on the matrix cores;
 witness polynomials, h = (v^2-1)/t, the five evaluations and the smudging of every statement are inside the timed region.  Inputs
 (CRS bytes, SSP, witnesses) are resident in HBM when the clock starts.  Nothing is cached between steps except per-circuit constants
 (AES tables, the power-series inverse of rev(t), the SSP's matrix-core image -- all functions of the SSP only, like the SSP itself).
@@ -203,11 +203,11 @@ def main():
                     help="batch (default at the default workload): a step = --batch statements per GPU proved by mfh_prove_batch (CRS regions "
                          "expanded once per group of 31, MAC on the matrix cores), ranks take disjoint statements, no collective; "
                          "single: a step = one prover() call, CRS rows sharded over the ranks + lane all-reduces")
-    ap.add_argument("--batch", type=int, default=992, help="statements per GPU per step in batch mode (4 super-groups of 248)")
+    ap.add_argument("--batch", type=int, default=1020, help="statements per GPU per step in batch mode (4 super-groups of 255)")
     ap.add_argument("--no-overlap", action="store_true", help="run the prover on one stream (A/B check of the side-stream overlap)")
     ap.add_argument("--no-merge", action="store_true", help="batch mode: S and AS groups of a round as two launches on two streams (A/B check)")
     ap.add_argument("--sharded-batch", type=int, default=None,
-                    help="N > 1: statements per step of the row-sharded batch leg for the whole job (default: --batch at the default workload, 248 for config4/5)")
+                    help="N > 1: statements per step of the row-sharded batch leg for the whole job (default: --batch at the default workload, 255 for config4/5)")
     ap.add_argument("--resident-gb", type=float, default=200.0, help="HBM budget for the resident CRS image per GPU")
     ap.add_argument("--workload", choices=["default", "config4", "config5"], default="default",
                     help="default = benchmark_snark NDEBUG instance (the driver's workload); config4/config5 = BASELINE's 2^20-constraint "
@@ -432,7 +432,7 @@ def main():
         if not n_:
             return None
         avg, eff, rows, work = ms_ / n_, busy_ / n_, rows_ / n_, work_ / n_
-        groups = work / rows                                     # groups of 31 proofs served by one launch (S and AS groups together)
+        groups = work / rows                                     # groups of 63 / 64 coefficient vectors served by one launch (S and AS groups together)
         regions = 2.0 if (merge_regions and groups > 1) else 1.0  # image regions one launch passes over
         mtile_rows = 129536 if p.logq == 736 else 1471 * 192     # M: row tiles x 16 byte positions (8096 x 16 at logq 736)
         ops = 2.0 * mtile_rows * 256 * work                      # int8 multiply-adds x 2 per launch (M x N = 256 x K = rows x groups)
@@ -441,7 +441,7 @@ def main():
         ops_other = 2.0 * mtile_rows * 256 * other[4]               # (all single-group launches together)
         step_tops = (ops * n_ + ops_other) / (steps_ or args.steps) / (step_ms * 1e-3) / 1e12  # the kernel's operations of a step over the WHOLE step time
         gbs = regions * rows * tile_bytes_per_row / (avg * 1e-3) / 1e9  # one pass over each region's image
-        return {"bound": "mfma", "kernel": "k_mmstream (A fragments of the expanded CRS streamed once per launch and region for 4 groups of 31 proofs -- "
+        return {"bound": "mfma", "kernel": "k_mmstream (A fragments of the expanded CRS streamed once per launch and region for 4 groups of 63 + 64 + 64 + 64 coefficient vectors (127.5 proofs) -- "
                                            "HBM for the first workgroup of a row-tile set, that XCD's L2 for the other three --, digit fragments "
                                            "through LDS, i8 MFMA 16x16x64; the S and the AS groups of a round share one launch)",
                 "achieved": tops, "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s (int8; multiply and add counted separately)", "frac": tops / MFMA_I8_PEAK_TOPS,
@@ -450,7 +450,7 @@ def main():
                 "launches": n_, "avg_launch_ms": avg, "busy_ms_per_launch": eff, "concurrency": avg / eff, "rows_per_launch": rows,
                 "groups_per_launch": groups, "regions_per_launch": regions, "int8_ops_per_launch": ops,
                 "single_group_launches": ({"launches": other[0], "avg_launch_ms": other[1] / other[0], "rows_per_launch": other[2] / other[0],
-                                           "what": "b_w: one byte column per proof over the BT+BV rows, one pass over that region's image per 248 proofs (HBM-bound)",
+                                           "what": "b_w: one byte column per proof over the BT+BV rows, one pass over that region's image per 255 proofs (HBM-bound)",
                                            "image_gbs": other[2] / other[0] * tile_bytes_per_row / (other[1] / other[0] * 1e-3) / 1e9} if other[0] else None),
                 "achieved_by_busy_time": tops_busy, "frac_by_busy_time": tops_busy / MFMA_I8_PEAK_TOPS,
                 "whole_step": {"achieved": step_tops, "frac": step_tops / MFMA_I8_PEAK_TOPS,
@@ -469,7 +469,7 @@ def main():
         gbs = rows * row_bytes_b / (eff * 1e-3) / 1e9
         gblk_ = rows * (p.ctr_ct / 16.0) / (eff * 1e-3) / 1e9
         return {"bound": "hbm", "kernel": "k_evalmm16 (AES-256-CTR expansion of the rows, once per group of 31 proofs, + i8 MFMA multiply-accumulate of the "
-                                          "group's 62 coefficient vectors; the BT+BV region runs once per 248 proofs, one byte column per proof)",
+                                          "group's 62 coefficient vectors; the BT+BV region runs once per 255 proofs, one byte column per proof)",
                 "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic_of("traffic_evalmm.json"),
                 "launches": n_, "avg_launch_ms": avg, "busy_ms_per_launch": eff, "concurrency": avg / eff, "rows_per_launch": rows, "bytes_per_row": row_bytes_b,
                 "note": CONC_NOTE + "; algorithmic bytes = expanded row bytes, regenerated with AES on the CU (LDS T-tables): LDS-lookup / VALU bound, "
@@ -527,7 +527,7 @@ def main():
                 el = float(tt.item())
             return out, el, kt
 
-        # headline: the CRS expanded once per call (= per step) into a transient image, streamed for every group of 31 proofs
+        # headline: the CRS expanded once per call (= per step) into a transient image, streamed for every super-group of 255 proofs
         out_b, el_b, kt_b = run_batch()
         ok_b = ctx.to_host(ctx.verify(d_ssp_b, inst["alpha"], inst["beta"], inst["s"], inst["sk"], out_b, nb))
         torch.cuda.synchronize()
@@ -585,7 +585,7 @@ def main():
     # all-to-all of the coefficient row slices + ONE reduce-scatter of uint64 lanes per step (dist.prove_batch_sharded)
     sharded_b = None
     if mode == "batch" and world > 1:
-        nbt = args.sharded_batch or (args.batch if not big else 248)
+        nbt = args.sharded_batch or (args.batch if not big else 255)
         srng = np.random.default_rng(4000)  # the same statements on every rank
         s_delta = [int(x) for x in srng.integers(0, mf.P, size=nbt, dtype=np.uint64)]
         s_mags = [srng.integers(0, 256, size=5 * 80, dtype=np.uint8).tobytes() for _ in range(nbt)]
@@ -874,7 +874,8 @@ def main():
                     "proof_accepted": batched["valid_accepted_invalid_rejected_and_identical_to_single_proof_path"],
                     "config": {"workload": base_workload + f"; a step = {args.batch} statements per GPU (same circuit and CRS; half with the satisfying witness, half with random ones; own randomness) through "
                                            "mfh_prove_batch: every call expands the compressed CRS once (AES on the CU) into a transient image in HBM and streams it for every "
-                                           "group of 31 proofs (BT+BV: 248), the groups' multiply-accumulate on the matrix cores; every proof is bit-identical to "
+                                           "super-group of 255 proofs (two launches of 4 + 4 groups of 63 / 64 coefficient vectors over the S / AS images, one over BT+BV), "
+                                           "the groups' multiply-accumulate on the matrix cores; every proof is bit-identical to "
                                            "the single-proof prover()'s",
                                "rows_per_proof": rows_crs, "statements_per_gpu_per_step": args.batch,
                                "sharding": f"{world} ranks, disjoint statements, no collective" if world > 1 else "single GPU"}}
@@ -911,7 +912,7 @@ def main():
             "config": head["config"],
             "proof_accepted": head["proof_accepted"],
             # SURVEY 8(d)'s per-proof accounting (every CRS row touched once per proof + the selected SSP rows): what the whole job
-            # "moves" by that count.  The batch kernels serve 31 proofs from one read of a row, so this exceeds the HBM peak; the
+            # "moves" by that count.  The batch kernels serve 31 - 32 proofs from one read of a row, so this exceeds the HBM peak; the
             # roofline objects below count the bytes a launch actually streams
             "algorithmic_bytes_per_proof": rows_crs * (p.n + 1) * p.ctb + (p.m // 2) * p.d * 4,
             "effective_gbs_by_per_proof_accounting": head["value"] * (rows_crs * (p.n + 1) * p.ctb + (p.m // 2) * p.d * 4) / 1e9,

@@ -292,7 +292,7 @@ class Context:
         self._chk(self.lib.mfh_set_encrypt_chunks(self._h, int(chunks)))
 
     def set_witness_per(self, statements=0):
-        """statements per witness GEMM pass of the batch chain (0 = 248)"""
+        """statements per witness GEMM pass of the batch chain (0 = one pass per super-group of up to 255)"""
         self._chk(self.lib.mfh_set_witness_per(self._h, int(statements)))
 
     def set_batch_launch(self, groups_per_launch=4, merge_regions=True):

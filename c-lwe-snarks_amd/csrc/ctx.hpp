@@ -103,7 +103,7 @@ struct mfh_ctx {
   int dec_path = 0;          // mfh_decrypt: 0 = by batch size, 1 = VALU kernel (k_decrypt), 2 = matrix-core kernel (k_decrypt_mm)
   int eval_path = 0;         // mfh_eval_rows / mfh_prove: 0 = tile kernel (k_eval), 1 = wave-autonomous kernel (k_eval_w, logq 736 only; measured 4 % slower)
   uint32_t enc_chunks = 0;   // k_encrypt_mm: 0 = column chunks per row picked from the batch size, n = forced (mfh_set_encrypt_chunks; tuning)
-  uint32_t witness_per = 0;  // batch chain: statements per witness GEMM pass, 0 = 248 (mfh_set_witness_per; A/B knob)
+  uint32_t witness_per = 0;  // batch chain: statements per witness GEMM pass, 0 = one pass per super-group (mfh_set_witness_per; A/B knob)
   uint32_t batch_slabs = 0;  // mfh_prove_batch: 0 = row slabs only when the image does not fit HBM (count picked from free memory), n = always n slabs
   int batch_merge = 1;     // the S and AS groups of a round in one streaming launch (0: two launches on two streams)
   uint32_t batch_ngl = 4;  // groups of 31 proofs per streaming launch over the image (1..8)
@@ -209,6 +209,9 @@ struct MmIo {
   // delta_b * ct_t term (src/snark.c:143-145); add_ct = one ciphertext (n + 1 values of L limbs), add_scale = one uint32 < p per vector
   const uint64_t *add_ct;
   const uint32_t *add_scale;
+  // streaming launches of several groups (mms_*): 0 = the group carries its own ones column (sum_i A'[i][m], one of its 256 digit columns: at most 63
+  // four-byte vectors); g + 1 = it borrows the ones column of group g of the same launch and region (the same rows: the same sums) and may hold 64 vectors
+  uint32_t sa_from1;
 };
 int eval_rows_multi_io(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d_c8, const MmIo &io, uint32_t nvec, uint32_t coeff_bytes, int accumulate);
 // ng of them over the same region in one streaming launch when the matrix-core image is registered (io.sc_zeroed required); else one by one

@@ -711,7 +711,7 @@ __global__ __launch_bounds__(SW * 64) void k_mmstream1(MmsImages imgs, uint32_t 
 template <int ND, int KWM /* 32-bit words of a value that survive modq, at most: sizes the LDS exchange (22 at logq 736, 46 at 1472) */>
 __device__ __forceinline__ void evalmm_finish_body(const int *__restrict__ part, const int64_t *__restrict__ sc, uint32_t nchunks, uint32_t ntiles, uint32_t N,
                                                    uint32_t nvec, uint32_t n, uint32_t nrows, uint32_t ct, uint32_t MBv, uint32_t sby, uint32_t LL,
-                                                   const MmIo &io, int accumulate) {
+                                                   const MmIo &io, int accumulate, const int *__restrict__ sa_part, uint32_t sa_col) {
   __shared__ uint32_t sv[KWM][3][64];  // (17 KiB at logq 736: six workgroups per CU instead of the four that 35 KiB allow)
   const uint32_t vl = threadIdx.x & 63, lq = threadIdx.x >> 6;
   const uint32_t v = blockIdx.y * 64 + vl, j = blockIdx.x;
@@ -731,7 +731,7 @@ __device__ __forceinline__ void evalmm_finish_body(const int *__restrict__ part,
         const int *row = part + ((uint64_t)tile * MBv + (jj * sby + 4 * l + k)) * N;
 #pragma unroll
         for (int w = 0; w < ND; w++) g0[k][w] = row[ND * v + w];
-        sa0[k] = row[ND * nvec];
+        sa0[k] = (sa_part + ((uint64_t)tile * MBv + (jj * sby + 4 * l + k)) * N)[sa_col];  // the ones column: this group's, or the lender's (same rows)
       }
 #pragma unroll
       for (int k = 0; k < 4; k++) {
@@ -743,7 +743,7 @@ __device__ __forceinline__ void evalmm_finish_body(const int *__restrict__ part,
           const int *row = part + (((uint64_t)ch * ntiles + tile) * MBv + mm) * N;
 #pragma unroll
           for (int w = 0; w < ND; w++) g[w] += row[ND * v + w];
-          sa += row[ND * nvec];
+          sa += (sa_part + (((uint64_t)ch * ntiles + tile) * MBv + mm) * N)[sa_col];
         }
         uint64_t t = 0;
 #pragma unroll
@@ -796,15 +796,16 @@ template <int ND, int KWM>
 __global__ __launch_bounds__(256) void k_evalmm_finish(const int *__restrict__ part, const int64_t *__restrict__ sc, uint32_t nchunks, uint32_t ntiles,
                                                         uint32_t N, uint32_t nvec, uint32_t n, uint32_t nrows, uint32_t ct, uint32_t MBv, uint32_t sby,
                                                         uint32_t LL, MmIo io, int accumulate) {
-  evalmm_finish_body<ND, KWM>(part, sc, nchunks, ntiles, N, nvec, n, nrows, ct, MBv, sby, LL, io, accumulate);
+  evalmm_finish_body<ND, KWM>(part, sc, nchunks, ntiles, N, nvec, n, nrows, ct, MBv, sby, LL, io, accumulate, part, ND * nvec);
 }
 // all groups of a round in one launch: blockIdx.z = group, its partial products at part + group * part_stride
 template <int ND, int KWM>
 __global__ __launch_bounds__(256) void k_evalmm_finish_groups(const int *__restrict__ part, uint64_t part_stride, uint32_t nchunks, uint32_t ntiles, uint32_t N,
                                                                uint32_t n, uint32_t nrows, uint32_t ct, uint32_t MBv, uint32_t sby, uint32_t LL, MmGroupArgs A,
                                                                int accumulate) {
-  const uint32_t g = blockIdx.z;
-  evalmm_finish_body<ND, KWM>(part + g * part_stride, A.io[g].sc_zeroed, nchunks, ntiles, N, A.nvec[g], n, nrows, ct, MBv, sby, LL, A.io[g], accumulate);
+  const uint32_t g = blockIdx.z, lender = A.io[g].sa_from1 ? A.io[g].sa_from1 - 1 : g;
+  evalmm_finish_body<ND, KWM>(part + g * part_stride, A.io[g].sc_zeroed, nchunks, ntiles, N, A.nvec[g], n, nrows, ct, MBv, sby, LL, A.io[g], accumulate,
+                              part + lender * part_stride, ND * A.nvec[lender]);
 }
 
 // ---- the witness pass of up to 32 statements as a GEMM over the SSP rows (one read of the SSP) ---------------------------------------
@@ -1385,8 +1386,14 @@ bool mms_plan(mfh_ctx *c, const MmRegion *regs, uint32_t nreg, size_t nrows, con
   }
   P.ng = ng;
   P.ngt = nreg * ng;
-  for (uint32_t g = 0; g < P.ngt && ok; g++)
-    ok = nvecs[g] && nvecs[g] * coeff_bytes + 1 <= 256 && ios[g].out[0] && ios[g].sc_zeroed && (ios[g].bits || ios[g].coef[0]);
+  for (uint32_t g = 0; g < P.ngt && ok; g++) {
+    ok = nvecs[g] && nvecs[g] * coeff_bytes + (ios[g].sa_from1 ? 0 : 1) <= 256 && ios[g].out[0] && ios[g].sc_zeroed && (ios[g].bits || ios[g].coef[0]);
+    if (ok && ios[g].sa_from1) {  // borrowed ones column: a group of the same launch and region that carries its own; only the grouped digit / epilogue kernels know it
+      const uint32_t l = ios[g].sa_from1 - 1;
+      ok = l < P.ngt && l / ng == g / ng && !ios[l].sa_from1 && coeff_bytes == 4;
+      for (uint32_t x = 0; x < P.ngt && ok; x++) ok = !ios[x].bits;  // (the per-group fallback kernels do not know about lenders)
+    }
+  }
   if (!ok) return false;
   const WideGeom wg = wide_geom(c);
   P.ND = coeff_bytes;

@@ -423,21 +423,24 @@ int mfh_prove(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, const 
 }
 
 // ---- prover() for a batch of statements under one CRS and SSP ---------------------------------------------------------------------
-// The S and AS regions are expanded ONCE per group of up to 31 proofs and the BT+BV region once per up to 248 (b_w's coefficients are
+// The S and AS regions are expanded ONCE per group of up to 31 proofs and the BT+BV region once per up to 255 (b_w's coefficients are
 // witness bits: one byte-digit column per proof), the multiply-accumulate of all their coefficient vectors runs on the matrix cores
 // (eval_rows_multi_io*, evalmm.hip); the witness pass reads the SSP once per 124 statements (a GEMM of the witness bits with the SSP
 // bytes on the matrix cores); the polynomial step and the smudging stay per proof.  Proof b is bit-identical to mfh_prove with the
 // same inputs.  Three building blocks, shared by the single-GPU call (mfh_prove_batch) and the row-sharded multi-GPU sequence
 // (mfh_batch_chain -> exchange -> mfh_prove_batch_partial -> lane reduction -> mfh_prove_batch_finish):
 //   batch_chain_launch      w = delta t + sum_bits v_i, v = w + v_0, h = (v^2 - 1) / t for a slab of statements   (src/snark.c:141-169)
-//   batch_rows_supergroup   b_w's BT+BV rows and the S / AS rows of up to 248 statements, restricted to a rank's row shares   (:143-174)
+//   batch_rows_supergroup   b_w's BT+BV rows and the S / AS rows of up to BSG statements, restricted to a rank's row shares   (:143-174)
 //   batch_smudge            ct_smudge x 5 per proof in two launches                                               (:185-189)
 }  // extern "C"
 
 namespace {
 
-constexpr uint32_t BG = 31;    // proofs per S / AS expansion: 62 coefficient vectors x 4 bytes + the ones column = 249 of 256 digit columns
-constexpr uint32_t BSG = 248;  // proofs per BT+BV expansion: one byte column each + the ones column = 249 of 256 digit columns
+constexpr uint32_t BG = 31;    // proofs per S / AS expansion when every group carries its own ones column: 62 coefficient vectors x 4 bytes + 1 = 249 of 256 digit columns
+// proofs per super-group = per BT+BV expansion: one byte column each + the ones column = 256 digit columns.  The S / AS launches of the streaming regime
+// serve the super-group's 2 x 255 coefficient vectors per region in two launches of 4 groups: 63 + 64 + 64 + 64 vectors, the first group carrying the ones
+// column (sum_i A'[i][m] depends on the rows only) for the other three (MmIo::sa_from1) -- 255 proofs per two passes over a region's image instead of 248.
+constexpr uint32_t BSG = 255;
 
 struct OnStream {  // helpers launch on c->stream
   mfh_ctx *c;
@@ -579,7 +582,7 @@ int batch_streams(mfh_ctx *c) {
   return MFH_OK;
 }
 
-// The chain of sg <= 248 statements on c->stream: W = delta t + sum_bits v_i (src/snark.c:141,147-155), V = W + v_0, H = (V^2 - 1) / t
+// The chain of sg <= BSG statements on c->stream: W = delta t + sum_bits v_i (src/snark.c:141,147-155), V = W + v_0, H = (V^2 - 1) / t
 // (src/snark.c:161-169); W, H, V are sg x d coefficients each.  The witness pass and the polynomial step have their own scratch (wws,
 // the poly buffers).
 int batch_chain_launch(mfh_ctx *c, const mf::SspSrc &src, const uint32_t *d_ssp, uint32_t sg, const uint8_t *h_bits, size_t bits_stride,
@@ -589,8 +592,8 @@ int batch_chain_launch(mfh_ctx *c, const mf::SspSrc &src, const uint32_t *d_ssp,
   // d % 128 == 0: a GEMM on the matrix cores, one read (dense SSP) or one generation (generator-defined SSP) of the selected rows per
   // 124 statements; otherwise the VALU form, read or generated once per 12 statements
   if (d % 128 == 0) {
-    // the whole super-group (248 statements) in one read (dense SSP) or one generation (generator-defined SSP) of the rows: k_witness_mm8q / k_witness_mm8q_prg
-    const uint32_t per = c->witness_per ? c->witness_per : 248u;  // (mfh_set_witness_per: A/B knob)
+    // the whole super-group (up to 255 statements) in one read (dense SSP) or one generation (generator-defined SSP) of the rows: k_witness_mm8q / k_witness_mm8q_prg
+    const uint32_t per = c->witness_per ? c->witness_per : 256u;  // (mfh_set_witness_per: A/B knob; a super-group is at most BSG = 255 statements)
     for (uint32_t b0 = 0; b0 < sg; b0 += per) {
       rc = mfh_witness_poly_mm(c, d_ssp, std::min(per, sg - b0), h_bits + (size_t)b0 * bits_stride, bits_stride, h_delta + b0, W + (size_t)b0 * d);
       if (rc) return rc;
@@ -614,7 +617,7 @@ struct BatchCoef {
   uint64_t stride;
 };
 
-// The row work of one super-group of sg <= 248 statements over rank `rank`'s contiguous row shares (the whole regions when world == 1):
+// The row work of one super-group of sg <= BSG statements over rank `rank`'s contiguous row shares (the whole regions when world == 1):
 //   b_w = [delta ct_t +] sum_{bit} ct_{v_i} over the share of the m BT+BV rows (src/snark.c:143-155), the bits of all sg statements as
 //   byte coefficients; S rows with (w, h) -> (v_w, h) on the caller's stream and AS rows with (h, v) -> (hat_h, hat_v) on the side
 //   stream, every row expanded (or streamed from the image) once per group of 31 proofs (src/snark.c:157-174).
@@ -683,23 +686,38 @@ int batch_rows_supergroup(mfh_ctx *c, const uint8_t *d_crs_c8, uint32_t rank, ui
     // Streaming regime, everything on the caller's stream: all rounds' operands (digit fragments, column sums: 0.02 ms per group) first,
     // then per round the streaming launch and its epilogues (partial products -> ciphertext words in the proof structs: 0.05 ms per group).
     // Every round has its own digit / partial-product area in ws3.
-    constexpr uint32_t RMAX = (BSG + BG - 1) / BG;  // rounds of a super-group with one group per launch
+    constexpr uint32_t RMAX = (2 * BSG + 62) / 63;  // rounds of a super-group with one group per launch and region
     MmIo io[RMAX][2 * NGLMAX];
     uint32_t nv[RMAX][2 * NGLMAX];
     MmsPlan plan[RMAX];
     uint32_t R = 0;
     size_t ws_need = 0;
-    for (uint32_t g0 = 0; g0 < sg; g0 += NGL * BG, R++) {
-      uint32_t ng = 0;
-      for (uint32_t k = 0; k < NGL && g0 + k * BG < sg; k++) ng++;
-      for (uint32_t k = 0; k < ng; k++) {
-        const uint32_t gg = g0 + k * BG, g = std::min(BG, sg - gg);
-        uint64_t *proofs = sproofs + (size_t)gg * 5 * ctl;
-        const uint64_t o = (uint64_t)gg * co.stride;
-        io[R][k] = MmIo{{co.w + o, co.h + o}, g, {proofs + 3 * ctl, proofs}, g, pstride, nullptr, 0, B.SCZ + 256 * slot++, co.stride, 0};                 // S: (w, h) -> (v_w, h)
-        io[R][ng + k] = MmIo{{co.h + o, co.v + o}, g, {proofs + ctl, proofs + 2 * ctl}, g, pstride, nullptr, 0, B.SCZ + 256 * slot++, co.stride, 0};  // AS: (h, v) -> (hat_h, hat_v)
-        nv[R][k] = nv[R][ng + k] = 2 * g;
+    // A region's coefficient vectors of the super-group as one list [X_0 .. X_(sg-1), Y_0 .. Y_(sg-1)] (S: X = w -> v_w, Y = h -> h; AS: X = h -> hat_h,
+    // Y = v -> hat_v), cut into consecutive runs: per launch the first group of a region takes 63 vectors and carries the ones column, the others 64 each and
+    // borrow it.  A run crosses the X | Y boundary at most once, which is what MmIo's two operand / result arrays express.
+    const uint32_t nvtot = 2 * sg;
+    auto run_io = [&](int region, uint32_t p, uint32_t cnt, uint32_t lender1) -> MmIo {
+      const uint32_t x0 = std::min(p, sg), x1 = std::min(p + cnt, sg), y0 = std::max(p, sg) - sg;
+      const uint32_t *X = region == 0 ? co.w : co.h, *Y = region == 0 ? co.h : co.v;
+      uint64_t *OX = sproofs + (region == 0 ? 3 : 1) * ctl, *OY = sproofs + (region == 0 ? 0 : 2) * ctl;
+      MmIo m = MmIo{{X + (uint64_t)x0 * co.stride, Y + (uint64_t)y0 * co.stride}, x1 - x0, {OX + (uint64_t)x0 * pstride, OY + (uint64_t)y0 * pstride}, x1 - x0, pstride,
+                    nullptr, 0, B.SCZ + 256 * slot++, co.stride, 0};
+      m.sa_from1 = lender1;
+      return m;
+    };
+    for (uint32_t p0 = 0; p0 < nvtot; R++) {
+      uint32_t cnt[NGLMAX], pos[NGLMAX], ng = 0, p = p0;
+      for (; ng < NGL && p < nvtot; ng++) {
+        pos[ng] = p;
+        cnt[ng] = std::min(ng == 0 ? 63u : 64u, nvtot - p);
+        p += cnt[ng];
       }
+      for (uint32_t k = 0; k < ng; k++) {
+        io[R][k] = run_io(0, pos[k], cnt[k], k ? 1 : 0);            // S groups: lender = group 0 of the launch
+        io[R][ng + k] = run_io(1, pos[k], cnt[k], k ? ng + 1 : 0);  // AS groups: lender = group ng
+        nv[R][k] = nv[R][ng + k] = cnt[k];
+      }
+      p0 = p;
       if (!mms_plan(c, regs, 2, cS, io[R], nv[R], ng, 4, plan[R])) { c->err = "mfh_prove_batch: the registered image does not serve the S / AS regions"; return MFH_EINVAL; }
       ws_need += (mms_ws_bytes(plan[R]) + 255) & ~(size_t)255;
     }

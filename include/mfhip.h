@@ -207,7 +207,7 @@ int mfh_crs_set_resident_mm(mfh_ctx *ctx, const uint8_t *d_image);
  * (lane = row, 16 x 16 byte transposition on the matrix cores, csrc/expandmm.hip), 1 the LDS-tile writer (k_evalmm16<MODE 1>). */
 int mfh_set_expand_path(mfh_ctx *ctx, int path);
 /* prover() for nproofs statements under ONE CRS and SSP.  The S and AS regions are expanded (or streamed from the image, below) once per group of up to 31 proofs, the
- * BT+BV region once per up to 248, and the multiply-accumulate of the coefficient vectors runs on the matrix cores (mfh_eval_rows_multi); proof b is bit-identical to
+ * BT+BV region once per up to 255 (the S / AS launches of the streaming regime: 255 proofs per two passes over a region), and the multiply-accumulate of the coefficient vectors runs on the matrix cores (mfh_eval_rows_multi); proof b is bit-identical to
  * mfh_prove(witness b, delta b, smudging b).  h_witness_bits: nproofs bit strings, bits_stride bytes apart; h_delta: nproofs values
  * < p; h_smudge_mag: nproofs x 5 x maglen bytes; h_smudge_sign: nproofs x 5 bytes; d_proofs: nproofs x 5 ciphertexts.
  * The single-proof resident image (mfh_crs_set_resident) must not be set; the matrix-core image (mfh_crs_set_resident_mm) may.
@@ -222,7 +222,7 @@ int mfh_set_batch_image(mfh_ctx *ctx, int enabled);
  * 0 (default): slabs only when needed, their number from the free memory; n: always n slabs (tests, tuning).  Same proofs. */
 int mfh_set_batch_slabs(mfh_ctx *ctx, uint32_t nslabs);
 /* tuning knobs (results do not depend on them; MFH_EINVAL outside the range): column chunks per row of the matrix-core encryption kernel
- * (0 = picked from the batch size, at most 64); statements per witness GEMM pass of the batch chain (0 = 248, else 32..256). */
+ * (0 = picked from the batch size, at most 64); statements per witness GEMM pass of the batch chain (0 = one pass per super-group of up to 255, else 32..256). */
 int mfh_set_encrypt_chunks(mfh_ctx *ctx, uint32_t chunks);
 /* mfh_eval_rows / mfh_prove*: 0 (default) = tile kernel (k_eval: two 512-coordinate row tiles per workgroup), 1 = at logq = 736 the wave-autonomous
  * kernel (k_eval_w: a wave owns 64 coordinates and a private keystream tile, no workgroup barriers; measured 4 % slower).  Same results (A/B, tests). */

@@ -255,7 +255,7 @@ def test_row_slabs_give_identical_proofs(gpu_ctx_factory, d, m, nb, nslabs, chun
 
 
 def test_more_than_four_super_groups(gpu_ctx_factory, oracle):
-    """1300 statements in one call: 6 super-groups of 248 (the staged host inputs -- witness bits, deltas, smudging terms -- of all
+    """1300 statements in one call: 6 super-groups of 255 (the staged host inputs -- witness bits, deltas, smudging terms -- of all
     super-groups travel in one copy, one staging area per super-group; the chain alternates between two w | h | v areas): proofs at the
     super-group boundaries equal the single-proof prover's, statement 0 the oracle's, and the verifier accepts exactly the valid ones."""
     import torch
@@ -272,7 +272,7 @@ def test_more_than_four_super_groups(gpu_ctx_factory, oracle):
     d_sk = ctx.to_device(inst["sk"])
     ok = ctx.to_host(ctx.verify(inst["d_ssp"], inst["alpha"], inst["beta"], inst["s"], d_sk, out.reshape(-1), nb))
     assert [bool(x) for x in ok] == [b % 3 != 2 for b in range(nb)]
-    for b in (0, 247, 248, 495, 496, 991, 992, 1239, 1240, nb - 1):
+    for b in (0, 247, 248, 254, 255, 256, 509, 510, 764, 765, 1019, 1020, 1274, 1275, nb - 1):
         assert torch.equal(out[b], ctx.prove(inst["d_crs"], inst["d_ssp"], bits[b], deltas[b], mags[b], signs[b])), f"statement {b}"
     for b in (0, 1240):
         stape = b"".join(mags[b][80 * k: 80 * k + 80] + signs[b][k: k + 1] for k in range(5))
