@@ -100,7 +100,7 @@ def test_multi_argument_checks(ctx):
 
 @pytest.mark.parametrize("nproofs,transient_image", [(1, True), (5, True), (16, True), (33, True), (33, False), (126, False), (250, True), (250, False), (500, True)])
 def test_prove_batch_equals_single_proofs(gpu_ctx_factory, oracle, nproofs, transient_image):
-    """mfh_prove_batch: proof b of the batch == mfh_prove(statement b), bit for bit (S / AS groups of 31 on the 256-column kernel, smaller groups on the 128-column one, BT+BV groups of 248 (128-column kernel up to 127 proofs, 256-column kernel above): 33 = one
+    """mfh_prove_batch: proof b of the batch == mfh_prove(statement b), bit for bit (S / AS groups of 63 - 64 coefficient vectors on the 256-column kernel when the image is streamed, of 31 proofs when it is regenerated, smaller groups on the 128-column one, BT+BV super-groups of 255 (128-column kernel up to 127 proofs, 256-column kernel above): 33 = one
     full + one partial S / AS group, 250 = two BT+BV groups, 500 = three, so the double-buffered w / h / v scratch of the chain is reused); the first proof is also checked against the oracle's prover and every proof is accepted by the device verifier.
     transient_image: calls with more than 31 proofs expand the CRS once per call into a scratch image and stream it for every group
     (the default), or (mfh_set_batch_image 0) regenerate the keystream per group."""
