@@ -441,6 +441,9 @@ constexpr uint32_t BG = 31;    // proofs per S / AS expansion when every group c
 // serve the super-group's 2 x 255 coefficient vectors per region in two launches of 4 groups: 63 + 64 + 64 + 64 vectors, the first group carrying the ones
 // column (sum_i A'[i][m] depends on the rows only) for the other three (MmIo::sa_from1) -- 255 proofs per two passes over a region's image instead of 248.
 constexpr uint32_t BSG = 255;
+// ... and when every group regenerates the keystream (no image: one group of 31 proofs = 62 vectors + its own ones column per expansion) a super-group is 8 x 31
+// statements, so that no expansion runs for a handful of left-over vectors
+constexpr uint32_t BSG_REGEN = 248;
 
 struct OnStream {  // helpers launch on c->stream
   mfh_ctx *c;
@@ -472,7 +475,7 @@ int batch_scratch(mfh_ctx *c, uint32_t nproofs, uint32_t whv /* w | h | v areas 
                   uint32_t nsmudge = 0 /* proofs whose smudging terms are staged */) {
   const uint32_t d = c->P.d, m = c->P.m, n = c->P.n;
   const size_t ctl = (size_t)(n + 1) * ((c->P.logq + 63) / 64);
-  const size_t nsg = ((size_t)nproofs + BSG - 1) / BSG;
+  const size_t nsg = ((size_t)nproofs + BSG_REGEN - 1) / BSG_REGEN;  // (the smaller super-group size: never fewer slots than a call uses)
   B.nslots = nsg * (1 + 2 * ((BSG + BG - 1) / BG));  // multi-vector launches of the call
   const size_t whv_b = (size_t)whv * 3 * BSG * d * 4;
   const size_t packed = ((size_t)BSG * ((m + 6) / 8) + 3) & ~(size_t)3;
@@ -502,15 +505,15 @@ int batch_scratch(mfh_ctx *c, uint32_t nproofs, uint32_t whv /* w | h | v areas 
 // witness bits (the m - 1 bits of a statement repacked densely) and the deltas, then the smudging terms u p of all five draws of every
 // proof (schoolbook by 32-bit words: src/lwe.c:65-76) and their signs.  B was sized with ncw = super-groups, nsmudge = nproofs.
 int batch_stage_host(mfh_ctx *c, const BatchScratch &B, uint32_t nproofs, const uint8_t *h_bits, size_t bits_stride, const uint32_t *h_delta,
-                     const uint8_t *h_mag, size_t maglen, const uint8_t *h_sign) {
-  const uint32_t m = c->P.m, nsg = (nproofs + BSG - 1) / BSG;
+                     const uint8_t *h_mag, size_t maglen, const uint8_t *h_sign, uint32_t SG) {
+  const uint32_t m = c->P.m, nsg = (nproofs + SG - 1) / SG;
   const uint32_t bstride = (m + 6) / 8, KW = 2 * (c->P.logq / 64);
   if (maglen + 4 > (size_t)KW * 4) { c->err = "smudge magnitude too wide"; return MFH_EINVAL; }
   const size_t total = (size_t)((uint8_t *)B.SMS - B.CW) + (size_t)nproofs * 5;
   uint8_t *st = (uint8_t *)pin_acquire(c, c->pin_cw, total);
   if (!st) return MFH_ENOMEM;
   for (uint32_t g = 0; g < nsg; g++) {
-    const uint32_t s0 = g * BSG, sg = std::min(BSG, nproofs - s0);
+    const uint32_t s0 = g * SG, sg = std::min(SG, nproofs - s0);
     uint8_t *a = st + (size_t)g * B.cw_stride;
     for (uint32_t b = 0; b < sg; b++) memcpy(a + (size_t)b * bstride, h_bits + (size_t)(s0 + b) * bits_stride, bstride);
     memcpy(a + B.cw_delta_off, h_delta + s0, (size_t)sg * 4);
@@ -852,7 +855,11 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
   // measured with 2, 3, 4, 8 areas: 88.2, 88.7, 89.4, 89.9 ms per 992 statements -- because every kernel of the call fills the CUs it
   // gets (one k_mmstream workgroup owns a CU's registers and LDS, k_expand_mm runs 8 waves per SIMD): concurrent streams time-share
   // the GPU and the work is conserved.  In turn keeps the streaming launches' durations clean.
-  const uint32_t nsg = (nproofs + BSG - 1) / BSG;
+  // super-group size: 255 statements when the row work streams an image (the caller's, or the call's transient one: groups of 63 / 64 coefficient vectors
+  // with a shared ones column), 248 = 8 x 31 when every group regenerates the keystream
+  const bool will_stream = c->mm_image || (c->batch_image && nproofs > BG && (((uint64_t)n * (c->P.logq / 8)) & 7) == 0);
+  const uint32_t SG = will_stream ? BSG : BSG_REGEN;
+  const uint32_t nsg = (nproofs + SG - 1) / SG;
   // Row slabs.  When the call would stream an image that does not fit HBM (363 GB at 2^20 constraints), the CRS rows are cut into
   // `nsl` slabs -- exactly the row shares of the multi-GPU prover, one after the other on this GPU: a slab's image is expanded once and
   // streamed for EVERY group of the call (results accumulated mod 2^(64K)), so the keystream is generated once per call instead of
@@ -871,8 +878,8 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
         const size_t area = (size_t)3 * BSG * d * 4, maxsg = std::max<size_t>(1, avail / 4 / area);
         if (nsg > maxsg) {  // the w | h | v areas of the whole call would not fit: sub-calls of maxsg super-groups
           const size_t ctl0 = (size_t)(n + 1) * ((c->P.logq + 63) / 64);
-          for (uint32_t s0 = 0; s0 < nproofs; s0 += (uint32_t)maxsg * BSG) {
-            const uint32_t cnt = std::min<uint32_t>((uint32_t)maxsg * BSG, nproofs - s0);
+          for (uint32_t s0 = 0; s0 < nproofs; s0 += (uint32_t)maxsg * SG) {
+            const uint32_t cnt = std::min<uint32_t>((uint32_t)maxsg * SG, nproofs - s0);
             int r = mfh_prove_batch(c, d_crs_c8, d_ssp, cnt, h_witness_bits + (size_t)s0 * bits_stride, bits_stride, h_delta + s0,
                                     h_smudge_mag + (size_t)s0 * 5 * maglen, maglen, h_smudge_sign + (size_t)s0 * 5, d_proofs + (size_t)s0 * 5 * ctl0);
             if (r) return r;
@@ -906,7 +913,7 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
     V = H + (size_t)BSG * d;
   };
   auto launch_chain = [&](uint32_t sgi) -> int {  // the chain stream has been told what to wait for
-    const uint32_t s0 = sgi * BSG, sg = std::min(BSG, nproofs - s0);
+    const uint32_t s0 = sgi * SG, sg = std::min(SG, nproofs - s0);
     uint32_t *WALL, *HALL, *VALL;
     whv_of(sgi, WALL, HALL, VALL);
     OnStream chain(c, chain_stream);
@@ -941,8 +948,8 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
       HIP_TRY(c, hipMemsetAsync(B.SCZ, 0, B.nslots * 2048, c->stream));
       slot = 0;
       const uint32_t loS = (uint32_t)((uint64_t)d * r / nsl);
-      for (uint32_t s0 = 0, sgi = 0; s0 < nproofs; s0 += BSG, sgi++) {
-        const uint32_t sg = std::min(BSG, nproofs - s0);
+      for (uint32_t s0 = 0, sgi = 0; s0 < nproofs; s0 += SG, sgi++) {
+        const uint32_t sg = std::min(SG, nproofs - s0);
         uint32_t *WALL, *HALL, *VALL;
         whv_of(sgi, WALL, HALL, VALL);
         const BatchCoef co = {WALL + loS, HALL + loS, VALL + loS, d};
@@ -951,8 +958,8 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
         if (rc) return rc;
       }
     }
-    for (uint32_t s0 = 0; s0 < nproofs; s0 += BSG) {
-      rc = batch_smudge(c, d_proofs + (size_t)s0 * 5 * ctl, std::min(BSG, nproofs - s0), h_smudge_mag + (size_t)s0 * 5 * maglen, maglen, h_smudge_sign + (size_t)s0 * 5);
+    for (uint32_t s0 = 0; s0 < nproofs; s0 += SG) {
+      rc = batch_smudge(c, d_proofs + (size_t)s0 * 5 * ctl, std::min(SG, nproofs - s0), h_smudge_mag + (size_t)s0 * 5 * maglen, maglen, h_smudge_sign + (size_t)s0 * 5);
       if (rc) return rc;
     }
     return MFH_OK;
@@ -961,7 +968,7 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
   rc = batch_transient_image(c, d_crs_c8, nproofs, 0, 1, transient);
   if (rc) return rc;
   // everything the host contributes, in one copy (no host-side wait between the super-groups), staged while the GPU expands the CRS
-  rc = batch_stage_host(c, B, nproofs, h_witness_bits, bits_stride, h_delta, h_smudge_mag, maglen, h_smudge_sign);
+  rc = batch_stage_host(c, B, nproofs, h_witness_bits, bits_stride, h_delta, h_smudge_mag, maglen, h_smudge_sign, SG);
   if (rc) return rc;
   rc = batch_ct_t(c, d_crs_c8, B);
   if (rc) return rc;
@@ -969,8 +976,8 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
   // BT+BV image -- could run in the background under the matrix-core bound S / AS launches.  Built and measured: on an unrestricted side
   // stream the call takes the same 81.5 ms, on a stream masked to 64 / 32 / 16 CUs 88.5 / 98.1 / 116.3 ms -- a k_mmstream workgroup pulls
   // ~18 GB/s whether 16 or 256 CUs stream, so fewer CUs only stretch the pass.  b_w stays in line.)
-  for (uint32_t s0 = 0, sgi = 0; s0 < nproofs; s0 += BSG, sgi++) {
-    const uint32_t sg = std::min(BSG, nproofs - s0);
+  for (uint32_t s0 = 0, sgi = 0; s0 < nproofs; s0 += SG, sgi++) {
+    const uint32_t sg = std::min(SG, nproofs - s0);
     uint64_t *sproofs = d_proofs + (size_t)s0 * 5 * ctl;
     uint32_t *WALL, *HALL, *VALL;
     whv_of(sgi, WALL, HALL, VALL);
