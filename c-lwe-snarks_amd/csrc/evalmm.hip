@@ -638,6 +638,11 @@ __device__ __forceinline__ void mmstream_body(const MmsImages &imgs, uint32_t mt
     __builtin_amdgcn_sched_barrier(0);
   }
   __syncthreads();
+#if defined(MMS_PRIO_YOUNG)  /* timing variants (MI355X_MICROARCH.md, two waves per SIMD, item 4): static priority for one half of the workgroup's waves */
+  if (wave >= SW / 2) __builtin_amdgcn_s_setprio(1);
+#elif defined(MMS_PRIO_OLD)
+  if (wave < SW / 2) __builtin_amdgcn_s_setprio(1);
+#endif
   uint32_t buf = 0;
   for (uint32_t u0 = r0; u0 < r1; u0 += RT2) {
     const uint32_t un1 = min(u0 + RT2, ulast), un2 = min(u0 + 2 * RT2, ulast);
