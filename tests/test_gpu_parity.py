@@ -385,8 +385,9 @@ def test_degenerate_inputs(ctx, mf):
 
 
 # ---------------------------------------------------------------- regev_decrypt as a batch on the matrix cores (encmm.hip)
+@pytest.mark.parametrize("count", [1, 16, 37, 300])  # one lane row; a whole wave tile; a ragged one; more than one 256-row workgroup
 @pytest.mark.parametrize("logq", [736, 1472])
-def test_decrypt_matrix_core_path_matches_oracle(gpu_ctx_factory, oracle, mf, logq):
+def test_decrypt_matrix_core_path_matches_oracle(gpu_ctx_factory, oracle, mf, logq, count):
     """mfh_decrypt with <a, sk> as a Toeplitz int8 GEMM (k_decrypt_mm) against the oracle's regev_decrypt (src/lwe.c:105-111) on ciphertexts with
     unreduced b (as after a raw ct_import), all-ones / zero values and a key with extreme balanced digits; counts that are multiples of neither
     the 32-row wave tile nor the 256-row workgroup; both paths against each other"""
@@ -397,11 +398,11 @@ def test_decrypt_matrix_core_path_matches_oracle(gpu_ctx_factory, oracle, mf, lo
     sk[0] = ol.int_to_limbs((1 << p.logq) - 1, p.L)      # digits 0xff ... : every balanced digit carries
     sk[1] = ol.int_to_limbs(int("80" * p.ctb, 16), p.L)  # digits 0x80: the most negative balanced digit
     sk[2] = 0
-    count = 37
     cts = _rand_ct(rng, p, count=count)
     cts[0, :p.n] = ol.int_to_limbs((1 << p.logq) - 1, p.L)
-    cts[1, :p.n] = 0
-    cts[2, 5] = ol.int_to_limbs((1 << (64 * p.L)) - 1, p.L)  # bits above logq set in memory (an unreduced value): only the low 64K bits may matter
+    if count > 2:
+        cts[1, :p.n] = 0
+        cts[2, 5] = ol.int_to_limbs((1 << (64 * p.L)) - 1, p.L)  # bits above logq set in memory (an unreduced value): only the low 64K bits may matter
     d_sk, d_ct = c.to_device(sk), c.to_device(cts)
     c.set_decrypt_path(2)
     try:
@@ -413,10 +414,10 @@ def test_decrypt_matrix_core_path_matches_oracle(gpu_ctx_factory, oracle, mf, lo
         valu = c.to_host(c.decrypt(d_sk, d_ct, count), np.uint32)
     finally:
         c.set_decrypt_path(0)
-    for i in range(count):
+    assert np.array_equal(got, valu), "the two kernels disagree"
+    for i in (range(count) if count <= 40 else list(range(8)) + [255, 256, 257, count - 1]):
         want = oracle.decrypt(p, sk, cts[i])
         assert int(got[i]) == want, f"ciphertext {i}: matrix-core path"
-        assert int(valu[i]) == want, f"ciphertext {i}: VALU path"
 
 
 def test_decrypt_paths_agree_on_a_batch_and_recover_the_messages(gpu_ctx_factory, mf):
