@@ -205,6 +205,7 @@ def main():
                          "single: a step = one prover() call, CRS rows sharded over the ranks + lane all-reduces")
     ap.add_argument("--batch", type=int, default=1020, help="statements per GPU per step in batch mode (4 super-groups of 255)")
     ap.add_argument("--no-overlap", action="store_true", help="run the prover on one stream (A/B check of the side-stream overlap)")
+    ap.add_argument("--groups-per-launch", type=int, default=8, help="batch mode: groups of 63 / 64 coefficient vectors per streaming launch and region (8 = a super-group's S and AS regions in one launch; 4 = rounds 1-3)")
     ap.add_argument("--no-merge", action="store_true", help="batch mode: S and AS groups of a round as two launches on two streams (A/B check)")
     ap.add_argument("--sharded-batch", type=int, default=None,
                     help="N > 1: statements per step of the row-sharded batch leg for the whole job (default: --batch at the default workload, 255 for config4/5)")
@@ -265,7 +266,7 @@ def main():
     if args.no_overlap:
         ctx.set_overlap(False)
     merge_regions = not args.no_merge
-    ctx.set_batch_launch(4, merge_regions)
+    ctx.set_batch_launch(args.groups_per_launch, merge_regions)
     seed = bytes((37 * i + 11) & 0xFF for i in range(40))
     ctx.set_seed(seed)
     if not big:

@@ -96,6 +96,11 @@ struct mfh_ctx {
   void *batch_img = nullptr;
   size_t batch_img_bytes = 0;
   int batch_image = 1;
+  // k_mmstream launches with several groups (mfh_set_mm_stream): slot -> (group, tile group) map, persistent grid, rendezvous of the sharers
+  int mm_map = 1;
+  bool mm_persist = true;
+  uint32_t mm_sync_mode = 0, mm_spin = 64;
+  uint32_t *mm_sync = nullptr;  // 8 x 32 counters of the persistent grid's rendezvous
   uint32_t mm_chunk_rows = 131071;  // rows per row chunk of the matrix-core launches (int32 accumulators: |A'C'| <= 2^14 per row)
   int expand_path = 0;     // mfh_crs_expand_mm*: 0 = k_expand_mm (lane = row, MFMA transposition, no LDS tile), 1 = k_evalmm16<MODE 1> (LDS tile + byte gathers)
   int enc_path = 0;        // mfh_encrypt_rows: 0 = pick by batch size, 1 = VALU kernel (k_encrypt), 2 = matrix-core kernel (k_encrypt_mm)
@@ -106,7 +111,7 @@ struct mfh_ctx {
   uint32_t witness_per = 0;  // batch chain: statements per witness GEMM pass, 0 = one pass per super-group (mfh_set_witness_per; A/B knob)
   uint32_t batch_slabs = 0;  // mfh_prove_batch: 0 = row slabs only when the image does not fit HBM (count picked from free memory), n = always n slabs
   int batch_merge = 1;     // the S and AS groups of a round in one streaming launch (0: two launches on two streams)
-  uint32_t batch_ngl = 4;  // groups of 31 proofs per streaming launch over the image (1..8)
+  uint32_t batch_ngl = 8;  // groups of 63 / 64 coefficient vectors per streaming launch and region (1..8; 8 = a super-group's S and AS regions in ONE launch)
   PinBuf pin_rows, pin_cw, pin_smudge;
   // generator-defined SSP (ssp_prg.hpp): used by every entry point that is handed d_ssp == NULL
   bool prg_on = false;

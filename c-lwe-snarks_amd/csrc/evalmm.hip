@@ -575,21 +575,36 @@ constexpr int CH = NQ2 / CG;      // column tiles per wave
 // same 16 row tiles for consecutive groups, so the second one's A fragments come out of that XCD's L2 (or the Infinity Cache) instead
 // of HBM: the image is read from HBM once per ng groups.  grid.x = 8 ng ceil(tile groups / 8).
 struct MmsImages { const v4i *image[16]; };  // the region image each group of a launch streams (S and AS groups share one launch)
+// Which (group, tile group) the slot-th workgroup of an XCD takes.  `ngt` groups in the launch, `ngr` of them per region (ngt / ngr regions).
+//   map 0: slot -> (slot % ngt, slot / ngt): the 32 workgroups an XCD runs at a time are 32 / ngt tile groups x all groups of BOTH regions -- an image's
+//          fragments are shared by ngr workgroups, a group's digit fragments by 32 / ngt of them;
+//   map 1: 32 consecutive slots are 32 / ngr tile groups x the ngr groups of ONE region (regions alternate per 32 slots): the fragments are shared by ngr
+//          workgroups as before, a group's digit fragments by 32 / ngr -- the digit fragments are as many bytes per workgroup as the image's, so with two
+//          regions this halves their share of the L2 misses.  Needs ngr | 32; the host picks map 0 otherwise.
+__device__ __forceinline__ void mms_item(uint32_t xcd, uint32_t slot, uint32_t ngt, uint32_t ngr, uint32_t map, uint32_t &grp, uint32_t &tg) {
+  if (map == 0) {
+    grp = slot % ngt;
+    tg = (slot / ngt) * 8 + xcd;
+  } else {
+    const uint32_t blk = slot >> 5, i = slot & 31, nreg = ngt / ngr, tpb = 32 / ngr;
+    grp = (blk % nreg) * ngr + i % ngr;
+    tg = ((blk / nreg) * tpb + i / ngr) * 8 + xcd;
+  }
+}
 __device__ __forceinline__ void mmstream_body(const MmsImages &imgs, uint32_t mtiles, uint32_t KS, uint32_t nrows, uint32_t rows_per_chunk,
-                                              const v4i *__restrict__ cdv, int *__restrict__ part, uint32_t ng, uint64_t cd_stride /* v4i */,
-                                              uint64_t part_stride /* int */) {
+                                              const v4i *__restrict__ cdv, int *__restrict__ part, uint32_t grp, uint32_t tg /* tile group = 16 row tiles */,
+                                              uint32_t chunk, uint64_t cd_stride /* v4i */, uint64_t part_stride /* int */) {
   __shared__ v4i bfrag[2][RT2 / 64][NQ2][64];  // 2 x 64 KiB
   const uint32_t tid = threadIdx.x, lane = tid & 63;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // uniform: the fragment addresses are a scalar base + the lane's 16 bytes
   const uint32_t c16 = lane & 15, g4 = lane >> 4;
   const uint32_t rq = wave % RG, ch = wave / RG;
-  const uint32_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, grp = slot % ng, tg = (slot / ng) * 8 + xcd;  // tile group = 16 row tiles
   if (tg * 16 >= mtiles) return;  // (uniform)
   const v4i *__restrict__ image = imgs.image[grp];
   cdv += grp * cd_stride;
   part += grp * part_stride;
   const uint32_t mt0 = (tg * RG + rq) * RQ;  // this wave's row tiles (with CG > 1 the waves rq and rq + RG read the same A fragments)
-  const uint32_t r0 = blockIdx.y * rows_per_chunk, r1 = min(nrows, r0 + rows_per_chunk);
+  const uint32_t r0 = chunk * rows_per_chunk, r1 = min(nrows, r0 + rows_per_chunk);
   v4i acc[RQ][CH];
 #pragma unroll
   for (int t = 0; t < RQ; t++)
@@ -686,7 +701,7 @@ __device__ __forceinline__ void mmstream_body(const MmsImages &imgs, uint32_t mt
 #pragma unroll
   for (int t = 0; t < RQ; t++) {
     if (mt0 + t >= mtiles) continue;
-    int *p = part + ((uint64_t)blockIdx.y * Mtot + (uint64_t)(mt0 + t) * 16) * N2;
+    int *p = part + ((uint64_t)chunk * Mtot + (uint64_t)(mt0 + t) * 16) * N2;
 #pragma unroll
     for (int q = 0; q < CH; q++)
 #pragma unroll
@@ -698,13 +713,43 @@ __device__ __forceinline__ void mmstream_body(const MmsImages &imgs, uint32_t mt
 // rounds of the batch prover: matrix-core bound, the kernel bench.py's roofline describes), k_mmstream1 = one group per launch (b_w's pass
 // over the BT+BV image, mfh_eval_rows_multi from a registered image: HBM-bound).
 __global__ __launch_bounds__(SW * 64) void k_mmstream(MmsImages imgs, uint32_t mtiles, uint32_t KS, uint32_t nrows, uint32_t rows_per_chunk,
-                                                      const v4i *__restrict__ cdv, int *__restrict__ part, uint32_t ng, uint64_t cd_stride,
-                                                      uint64_t part_stride) {
-  mmstream_body(imgs, mtiles, KS, nrows, rows_per_chunk, cdv, part, ng, cd_stride, part_stride);
+                                                      const v4i *__restrict__ cdv, int *__restrict__ part, uint32_t ngt, uint32_t ngr, uint32_t map,
+                                                      uint64_t cd_stride, uint64_t part_stride) {
+  uint32_t grp, tg;
+  mms_item(blockIdx.x & 7, blockIdx.x >> 3, ngt, ngr, map, grp, tg);
+  mmstream_body(imgs, mtiles, KS, nrows, rows_per_chunk, cdv, part, grp, tg, blockIdx.y, cd_stride, part_stride);
 }
 __global__ __launch_bounds__(SW * 64) void k_mmstream1(MmsImages imgs, uint32_t mtiles, uint32_t KS, uint32_t nrows, uint32_t rows_per_chunk,
                                                        const v4i *__restrict__ cdv, int *__restrict__ part) {
-  mmstream_body(imgs, mtiles, KS, nrows, rows_per_chunk, cdv, part, 1u, 0, 0);
+  mmstream_body(imgs, mtiles, KS, nrows, rows_per_chunk, cdv, part, 0u, blockIdx.x, blockIdx.y, 0, 0);
+}
+// The same launch as a PERSISTENT grid: one workgroup per CU (the 128 KiB of LDS allow no second one anyway), workgroup b = CU slot b >> 3 of the XCD
+// b & 7 (blocks are dealt round-robin over the XCDs), looping over the slots cu, cu + 32, cu + 64, ... of its XCD and over the row chunks.  The ngr
+// workgroups that stream the same fragments -- and, with sync_mode 2, all 32 workgroups of the XCD -- therefore stay on the same CUs for the whole launch
+// and begin every item together: before an item lane 0 adds to the set's counter and polls it (sc1 loads, s_sleep between polls) until every member has
+// arrived OR spin_max polls have passed.  The rendezvous is for speed only (the members then find each other's fragments in the XCD's L2): nothing is
+// handed over, a member that is not resident (fewer CUs than workgroups, another kernel on the GPU) only costs the others spin_max polls per item, and
+// every wave reaches the end of the grid whatever the counters hold.  sync: 8 x 32 counters zeroed before the launch.
+__global__ __launch_bounds__(SW * 64) void k_mmstream_p(MmsImages imgs, uint32_t mtiles, uint32_t KS, uint32_t nrows, uint32_t rows_per_chunk,
+                                                        const v4i *__restrict__ cdv, int *__restrict__ part, uint32_t ngt, uint32_t ngr, uint32_t map,
+                                                        uint64_t cd_stride, uint64_t part_stride, uint32_t nblk /* 32-slot blocks per XCD */, uint32_t nchunks,
+                                                        uint32_t *__restrict__ sync, uint32_t sync_mode, uint32_t spin_max) {
+  const uint32_t xcd = blockIdx.x & 7, cu = blockIdx.x >> 3;
+  const uint32_t members = sync_mode == 2 ? 32u : (map ? ngr : ngt);
+  uint32_t *ctr = sync + xcd * 32 + (sync_mode == 2 ? 0u : cu / members);
+  for (uint32_t k = 0; k < nblk * nchunks; k++) {
+    if (sync_mode && members > 1) {
+      if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t target = (k + 1) * members;
+        for (uint32_t spin = 0; spin < spin_max && __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; spin++) __builtin_amdgcn_s_sleep(8);
+      }
+      __syncthreads();
+    }
+    uint32_t grp, tg;
+    mms_item(xcd, (k % nblk) * 32 + cu, ngt, ngr, map, grp, tg);
+    mmstream_body(imgs, mtiles, KS, nrows, rows_per_chunk, cdv, part, grp, tg, k / nblk, cd_stride, part_stride);
+  }
 }
 
 // out_v[j] = sum_{u,w} G[(j,u)][(v,w)] 256^(u + w) mod 2^704 with G = G' + 128 SA[(j,u)] + 128 sc[(v,w)] + 16384 nrows, G' and
@@ -1455,10 +1500,22 @@ int mms_stream(mfh_ctx *c, const MmsPlan &P) {
   const uint32_t KS = (P.nrows + RT2 - 1) / RT2 * (RT2 / 64), tgs = (P.mtiles + TPW - 1) / TPW;
   MmsImages imgs{};
   for (uint32_t g = 0; g < P.ngt; g++) imgs.image[g] = (const v4i *)P.img[g / P.ng];
-  if (P.ngt > 1)
-    hipLaunchKernelGGL(k_mmstream, dim3((tgs + 7) / 8 * 8 * P.ngt, P.nchunks), dim3(SW * 64), 0, c->stream, imgs, P.mtiles, KS, P.nrows, P.rpc, (const v4i *)P.cd,
-                       P.part, P.ngt, (uint64_t)(P.cd_bytes / 16), (uint64_t)(P.part_bytes / 4));
-  else
+  if (P.ngt > 1) {
+    // slot -> (group, tile group) map and grid shape (mfh_set_mm_stream): see mms_item / k_mmstream_p
+    const uint32_t tgx = (tgs + 7) / 8;  // tile groups per XCD
+    const uint32_t map = c->mm_map && 32 % P.ng == 0 ? 1u : 0u;
+    const uint32_t slots = map ? (tgx + 32 / P.ng - 1) / (32 / P.ng) * (P.ngt / P.ng) * 32 : tgx * P.ngt;  // per XCD
+    const bool persistent = c->mm_persist && c->ncu == 256 && (map || 32 % P.ngt == 0);
+    if (persistent) {
+      if (!c->mm_sync) HIP_TRY(c, hipMalloc(&c->mm_sync, 8 * 32 * sizeof(uint32_t)));
+      HIP_TRY(c, hipMemsetAsync(c->mm_sync, 0, 8 * 32 * sizeof(uint32_t), c->stream));
+      hipLaunchKernelGGL(k_mmstream_p, dim3(256), dim3(SW * 64), 0, c->stream, imgs, P.mtiles, KS, P.nrows, P.rpc, (const v4i *)P.cd, P.part, P.ngt, P.ng, map,
+                         (uint64_t)(P.cd_bytes / 16), (uint64_t)(P.part_bytes / 4), (slots + 31) / 32, P.nchunks, c->mm_sync, c->mm_sync_mode, c->mm_spin);
+    } else {
+      hipLaunchKernelGGL(k_mmstream, dim3(slots * 8, P.nchunks), dim3(SW * 64), 0, c->stream, imgs, P.mtiles, KS, P.nrows, P.rpc, (const v4i *)P.cd, P.part, P.ngt, P.ng,
+                         map, (uint64_t)(P.cd_bytes / 16), (uint64_t)(P.part_bytes / 4));
+    }
+  } else
     hipLaunchKernelGGL(k_mmstream1, dim3((tgs + 7) / 8 * 8, P.nchunks), dim3(SW * 64), 0, c->stream, imgs, P.mtiles, KS, P.nrows, P.rpc, (const v4i *)P.cd, P.part);
   HIP_TRY(c, hipGetLastError());
   return MFH_OK;
@@ -1585,6 +1642,14 @@ int mfh_crs_expand_mm_share(mfh_ctx *c, const uint8_t *d_crs_c8, uint32_t rank, 
 int mfh_crs_expand_mm(mfh_ctx *c, const uint8_t *d_crs_c8, uint8_t *d_image) { return mfh_crs_expand_mm_share(c, d_crs_c8, 0, 1, d_image); }
 // rows per row chunk of the matrix-core launches: an int32 accumulator holds at most 131 071 rows (the default); smaller values split
 // a region into more chunks (tuning / tests).  0 restores the default.
+int mfh_set_mm_stream(mfh_ctx *c, int map, int persistent, int sync_mode, uint32_t spin_max) {
+  if (!c || map < 0 || map > 1 || sync_mode < 0 || sync_mode > 2) return MFH_EINVAL;
+  c->mm_map = map;
+  c->mm_persist = persistent != 0;
+  c->mm_sync_mode = (uint32_t)sync_mode;
+  c->mm_spin = spin_max;
+  return MFH_OK;
+}
 int mfh_set_mm_chunk_rows(mfh_ctx *c, uint32_t rows) {
   if (!c || rows > 131071) return MFH_EINVAL;
   c->mm_chunk_rows = rows ? rows : 131071;

@@ -1072,6 +1072,7 @@ void mfh_ctx_destroy(mfh_ctx *c) {
   if (c->wws) hipFree(c->wws);
   if (c->ws2) hipFree(c->ws2);
   if (c->ws3) hipFree(c->ws3);
+  if (c->mm_sync) hipFree(c->mm_sync);
   for (hipEvent_t e : c->ev_round) hipEventDestroy(e);
   for (hipEvent_t e : c->ev_cdone) hipEventDestroy(e);
   for (hipEvent_t e : c->ev_rdone) hipEventDestroy(e);

@@ -232,6 +232,12 @@ int mfh_set_witness_per(mfh_ctx *ctx, uint32_t statements);
  * over a region's image (1..8, default 4), and whether the S and AS groups of a round share ONE launch (default) or run as two
  * launches on two streams. */
 int mfh_set_batch_launch(mfh_ctx *ctx, uint32_t groups_per_launch, int merge_regions);
+/* how a streaming launch with several groups is laid out on the chip (tuning; results do not depend on it).  map: 0 = a tile group's workgroups for all
+ * groups of both regions are neighbours, 1 = the 32 workgroups an XCD runs at a time are 32 / g tile groups x the g groups of ONE region (a group's digit
+ * fragments are then shared by twice as many workgroups of the XCD).  persistent: one workgroup per CU looping over its XCD's items instead of one workgroup
+ * per item; sync_mode (persistent only): 0 = none, 1 = the workgroups that stream the same fragments begin every item together, 2 = all workgroups of an XCD
+ * do -- a speed-only rendezvous bounded by spin_max polls (a workgroup never waits longer, so the grid drains whatever is resident). */
+int mfh_set_mm_stream(mfh_ctx *ctx, int map, int persistent, int sync_mode, uint32_t spin_max);
 /* rows per row chunk of the matrix-core launches (mfh_eval_rows_multi, mfh_prove_batch): the int32 accumulators hold at most
  * 131071 rows (the default; 0 restores it); smaller values split every region into more chunks -- same results (tuning, tests). */
 int mfh_set_mm_chunk_rows(mfh_ctx *ctx, uint32_t rows);

@@ -179,7 +179,7 @@ def test_chunk_rows_knob_rejects_overflowing_values(gpu_ctx_factory):
     ctx.set_mm_chunk_rows(0)
 
 
-@pytest.mark.parametrize("ngl,merge", [(1, True), (2, True), (8, True), (4, False), (1, False)])
+@pytest.mark.parametrize("ngl,merge", [(1, True), (2, True), (4, True), (3, True), (4, False), (1, False)])
 def test_batch_launch_shapes_give_identical_proofs(gpu_ctx_factory, ngl, merge):
     """mfh_set_batch_launch: groups per streaming launch and S + AS in one launch or two change the launch geometry of k_mmstream (per-group
     image pointers, up to 16 groups in a grid), never the proofs.  250 statements = two super-groups, 9 groups: every shape has a ragged
@@ -202,15 +202,57 @@ def test_batch_launch_shapes_give_identical_proofs(gpu_ctx_factory, ngl, merge):
     rng = np.random.default_rng(5)
     nb = 250
     bits, deltas, mags, signs = _statements(rng, p, nb, valid_bits=inst["bits"])
-    want = ctx.prove_batch(d_crs, inst["d_ssp"], bits, deltas, mags, signs).clone()  # default shape: 4 groups, merged
+    want = ctx.prove_batch(d_crs, inst["d_ssp"], bits, deltas, mags, signs).clone()  # default shape: 8 groups per region, merged
     ctx.set_batch_launch(ngl, merge)
     try:
         got = ctx.prove_batch(d_crs, inst["d_ssp"], bits, deltas, mags, signs)
     finally:
-        ctx.set_batch_launch(4, True)
+        ctx.set_batch_launch(8, True)
     assert torch.equal(got, want)
     one = ctx.prove(d_crs, inst["d_ssp"], bits[249], deltas[249], mags[249], signs[249])
     assert torch.equal(want.view(nb, -1)[249], one)
+    ctx.close()
+
+
+@pytest.mark.parametrize("layout", [(0, False, 0), (1, False, 0), (0, True, 0), (0, True, 1), (1, True, 1), (1, True, 2)])
+@pytest.mark.parametrize("nb,ngl,chunk_rows", [(250, 8, 0), (250, 4, 512), (130, 8, 0), (96, 4, 256), (33, 8, 0), (255, 2, 0)])
+def test_streaming_launch_layouts_give_identical_proofs(gpu_ctx_factory, layout, nb, ngl, chunk_rows):
+    """mfh_set_mm_stream: which workgroup takes which (group, tile group) of a streaming launch (map 0 | 1), one workgroup per item or a persistent
+    one-workgroup-per-CU grid looping over its XCD's items, with or without the speed-only rendezvous of the sharers -- never the proofs.  Against the
+    round-3 layout (map 0, one workgroup per item).  Group counts per region that divide 32 (8, 4, 2: map 1 and the persistent grid apply) and that do
+    not (130 statements = 5 groups, 96 with 4 per launch = 3 + 1: the host falls back to map 0 / one workgroup per item); 2 - 5 row chunks per item
+    (the persistent grid walks chunk by chunk); 255 statements with 2 groups per region = 4 launches per super-group."""
+    import sys
+
+    import torch
+
+    import c_lwe_snarks_amd as mf
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    p = mf.Params(d=1152, m=1000)
+    ctx = gpu_ctx_factory(p)
+    ctx.set_seed(SEED)
+    inst = bench.build_instance(mf, ctx, torch, p, 99)
+    ctx.ssp_prepare(inst["d_ssp"])
+    d_crs = ctx.setup(inst["d_ssp"], inst["alpha"], inst["beta"], inst["s"], inst["sk"], inst["err"])
+    rng = np.random.default_rng(nb)
+    bits, deltas, mags, signs = _statements(rng, p, nb, valid_bits=inst["bits"])
+    ctx.set_batch_launch(ngl, True)
+    ctx.set_mm_chunk_rows(chunk_rows)
+    try:
+        ctx.set_mm_stream(0, False, 0, 0)
+        want = ctx.prove_batch(d_crs, inst["d_ssp"], bits, deltas, mags, signs).clone()
+        ctx.set_mm_stream(layout[0], layout[1], layout[2], 16)
+        got = ctx.prove_batch(d_crs, inst["d_ssp"], bits, deltas, mags, signs)
+    finally:
+        ctx.set_mm_stream(1, True, 0, 64)
+        ctx.set_batch_launch(8, True)
+        ctx.set_mm_chunk_rows(0)
+    assert torch.equal(got, want)
+    one = ctx.prove(d_crs, inst["d_ssp"], bits[nb - 1], deltas[nb - 1], mags[nb - 1], signs[nb - 1])
+    assert torch.equal(want.view(nb, -1)[nb - 1], one)
     ctx.close()
 
 

@@ -125,6 +125,16 @@ def test_streaming_gemm_waits_one_stage_behind(asm_evalmm):
     assert not any(x.startswith("scratch_") for x in loop)
 
 
+def test_persistent_streaming_gemm_keeps_the_same_waits(asm_evalmm):
+    """k_mmstream_p (the persistent one-workgroup-per-CU grid, round 4): the item loop around the stage loop must not change what the stage loop
+    waits for.  (The scheduler places the first two MFMAs of k-step 1 between the loads of k-step 0 here, so the same two waits read vmcnt(10) after
+    one load and vmcnt(11) after three instead of vmcnt(12) after three and four: the same loads of the previous stage are awaited.)"""
+    loop = _mfma_loop(_kernel(asm_evalmm, "_ZN12_GLOBAL__N_112k_mmstream_pE"), 128)
+    waits = [int(m.group(1)) for x in loop for m in [re.search(r"s_waitcnt vmcnt\((\d+)\)", x)] if m]
+    assert waits and min(waits) >= 10, waits
+    assert not any(x.startswith("scratch_") for x in loop)
+
+
 def test_expansion_kernel_has_no_scratch(tmp_path_factory):
     """k_expand_mm at 64 VGPRs (8 waves per SIMD): the lane offset of a piece's store is recomputed per piece; kept live it was spilled and
     reloaded before every store behind s_waitcnt vmcnt(0)"""
