@@ -161,9 +161,26 @@ __device__ __forceinline__ void aes_span_consts(const uint8_t *tab, const AesLan
   sc[4] = MF_T0AT(t3, 0) ^ rotl8_(MF_T0AT(t0, 1)) ^ MF_T2AT(t1, 2) ^ k.rk[11];                    // D3
 }
 
+// One of a middle round's 16 lookups through the vector-memory path instead of LDS (tools/aes7_ubench.hip: the LDS pipe is the limiter of every AES kernel and
+// the texture-addresser / L1 path is idle; one gather in sixteen lookups is what that path takes -- a dword gather costs ~23 CU-clk per wave-instruction against
+// 2.15 for ds_read_b32 -- : +4.9 % at 8 waves per SIMD, +2.3 % at 4; two in sixteen already lose).  gt3 = T3 = rotl24(T0), 256 words in global memory
+// (L1-resident after the first touch), addressed through a buffer resource so that the address is one VALU instruction.
+struct AesGl {
+  __amdgpu_buffer_rsrc_t rs;
+};
+__device__ __forceinline__ AesGl aes_gl(const uint32_t *gt3) {
+  return AesGl{__builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(gt3), 0, 1024, 0x00020000)};
+}
+__device__ __forceinline__ uint32_t aes_col_g(const uint8_t *tab, const AesLane &L, const AesGl &G, uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t rk) {
+  const uint32_t x3 = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(G.rs, (int)((d >> 22) & 0x3fcu), 0, 0);
+  const uint32_t x0 = MF_LD(MF_A(a, L.lo0, 0)), x1 = MF_LD(MF_A(b, L.lo0, 1)), x2 = MF_LD(MF_A(c, L.lo2, 2));
+  return MF_XOR3(x0 ^ rk, x2, __builtin_amdgcn_alignbit(x1, x1, 24)) ^ x3;
+}
+
 // the same block as aes256_ctr_block, entering at round 3 with the span constants of ctr >> 8
+template <bool GL = false>
 __device__ __forceinline__ void aes256_ctr_block_sc(const uint8_t *tab, const AesLane &L, const AesKey &k, uint64_t ctr, const uint32_t sc[5],
-                                                    uint32_t out[4]) {
+                                                    uint32_t out[4], const AesGl *G = nullptr) {
   const uint32_t s2 = (uint32_t)ctr ^ k.rk[2];
   const uint32_t t2 = MF_T0AT(s2, 0) ^ sc[0];
   uint32_t s0 = sc[1] ^ MF_T2AT(t2, 2);
@@ -172,7 +189,7 @@ __device__ __forceinline__ void aes256_ctr_block_sc(const uint8_t *tab, const Ae
   uint32_t s3 = sc[4] ^ rotl8_(MF_T2AT(t2, 3));
 #pragma unroll
   for (int r = 3; r < 14; r++) {
-    uint32_t u0 = aes_col(tab, L, s0, s1, sB, s3, k.rk[4 * r]);
+    uint32_t u0 = GL ? aes_col_g(tab, L, *G, s0, s1, sB, s3, k.rk[4 * r]) : aes_col(tab, L, s0, s1, sB, s3, k.rk[4 * r]);
     uint32_t u1 = aes_col(tab, L, s1, sB, s3, s0, k.rk[4 * r + 1]);
     uint32_t u2 = aes_col(tab, L, sB, s3, s0, s1, k.rk[4 * r + 2]);
     uint32_t u3 = aes_col(tab, L, s3, s0, s1, sB, k.rk[4 * r + 3]);

@@ -118,6 +118,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(LOGQ == 73
   uint64_t ctr = (rowstart >> 4) + 4ull * ks0 + g;
   uint64_t span_a = ctr >> 8;
   uint32_t sca[5], scb[5];
+#ifdef MF_AES_GL_ENC
+  const mf::AesGl GLT = mf::aes_gl(g_t0 + 256);
+#endif
   mf::aes_span_consts(tab, L, key, span_a, sca);
   mf::aes_span_consts(tab, L, key, span_a + 1, scb);
   for (uint32_t ks = ks0; ks < ks1; ks++, ctr += 4) {
@@ -140,7 +143,11 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(LOGQ == 73
 #pragma unroll
     for (int i = 0; i < 5; i++) sc[i] = crossed ? scb[i] : sca[i];
     uint32_t w[4];
+#ifdef MF_AES_GL_ENC
+    mf::aes256_ctr_block_sc<true>(tab, L, key, ctr, sc, w, &GLT);
+#else
     mf::aes256_ctr_block_sc(tab, L, key, ctr, sc, w);
+#endif
     const v4i a = {(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
 #pragma unroll
     for (int q = 0; q < NQ; q++) acc[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b[q], acc[q], 0, 0, 0);

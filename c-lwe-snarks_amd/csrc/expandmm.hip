@@ -150,6 +150,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
   // counter-mode shortcut: a chunk is at most 10 periods = 230 (+1) consecutive blocks per lane: they lie in the span of the first one or the next
   const uint64_t span_a = ctr >> 8;
   uint32_t sca[5], scb[5];
+#ifdef MF_AES_GL_EXPAND
+  const mf::AesGl GLT = mf::aes_gl(g_t0 + 256);
+#endif
   mf::aes_span_consts(tab, L, key, span_a, sca);
   mf::aes_span_consts(tab, L, key, span_a + 1, scb);
   auto block = [&](uint64_t c, uint32_t (&o)[4]) {
@@ -157,7 +160,11 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     uint32_t sc[5];
 #pragma unroll
     for (int i = 0; i < 5; i++) sc[i] = crossed ? scb[i] : sca[i];
+#ifdef MF_AES_GL_EXPAND
+    mf::aes256_ctr_block_sc<true>(tab, L, key, c, sc, o, &GLT);
+#else
     mf::aes256_ctr_block_sc(tab, L, key, c, sc, o);
+#endif
   };
   uint32_t x[4];
   block(ctr, x);

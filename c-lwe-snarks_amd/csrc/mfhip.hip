@@ -1049,8 +1049,9 @@ int mfh_ctx_create(mfh_ctx **out, int device, const mfh_params *P) {
     return MFH_EDEVICE;
   }
   c->stream = c->own_stream;
-  uint32_t t0[256];
+  uint32_t t0[512];  // T0, then T3 = rotl24(T0) for the one-lookup-in-sixteen that the AES of the 8-waves-per-SIMD kernels gathers from global memory (aes_dev.hpp)
   mf::make_t0_le(t0);
+  for (int a = 0; a < 256; a++) t0[256 + a] = (t0[a] << 24) | (t0[a] >> 8);
   if (hipMalloc(&c->d_t0, sizeof t0) != hipSuccess || hipMemcpy(c->d_t0, t0, sizeof t0, hipMemcpyHostToDevice) != hipSuccess) {
     mfh_ctx_destroy(c);
     return MFH_EDEVICE;
