@@ -174,7 +174,14 @@ def launch_ranks(n):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
     live = list(procs)
+    deadline = time.time() + float(os.environ.get("MFUOCO_BENCH_DEADLINE_S", "3000"))  # a hung rank must not hold the GPUs for ever
     while live:
+        if time.time() > deadline:
+            print(f"[bench] {len(live)} rank process(es) still running at the deadline: ending them", file=sys.stderr, flush=True)
+            for other in live:
+                other.terminate()
+            deadline = float("inf")
+            rc = rc or 124
         for pr in list(live):
             code = pr.poll()
             if code is None:
@@ -252,6 +259,13 @@ def main():
     else:
         dist = None
         torch.cuda.set_device(0)
+    # control-plane group on the host (gloo): ranks agree there on what to do after a failed collective -- a rank that is alone with its exception must not
+    # change mode while the others sit inside an RCCL call; it finds nobody in the agreement, times out and EXITS non-zero, which ends the job
+    ctl_group = None
+    if dist is not None:
+        import datetime
+
+        ctl_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=float(os.environ.get("MFUOCO_BENCH_AGREE_S", "90"))))
     if dist is not None and dist.get_world_size() != args.gpus:
         print(f"[bench] error: {dist.get_world_size()} ranks joined the process group, --gpus {args.gpus}", file=sys.stderr, flush=True)
         return 2
@@ -321,6 +335,17 @@ def main():
             torch.cuda.synchronize()
         except Exception as e:
             single_err = f"{type(e).__name__}: {e}"
+        # the outcome is agreed on the host group (MIN of an ok flag): only when EVERY rank arrives -- all of them out of the collective, by success or
+        # by exception -- does the job go on, all in the same mode; a rank that waits here alone (the others hang in the collective) times out and exits
+        try:
+            flag = torch.tensor([0 if single_err else 1], dtype=torch.int64)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=ctl_group)
+        except Exception as e:
+            print(f"[bench] rank {rank}: no agreement after the first row-sharded step ({single_err or 'this rank succeeded'}; {type(e).__name__}): exiting",
+                  file=sys.stderr, flush=True)
+            os._exit(3)
+        if int(flag.item()) == 0:
+            single_err = single_err or "another rank's first row-sharded step failed"
             by_rows = False
             eff_rank, eff_world = 0, 1
             bufs.clear()
@@ -637,7 +662,7 @@ def main():
         dist.all_reduce(ta, op=dist.ReduceOp.MIN)
         ok_s = bool(int(ta.item()))
         per_s = -(-nbt // world)
-        lps = 5 * (p.n + 1) * 2 * p.K
+        lps = 5 * (p.n + 1) * p.lanes
         share_img = int(ctx.lib.mfh_crs_mm_share_bytes(ctx._h, rank, world))
         sharded_b = {"value": nbt * sh_steps / el_s, "unit": "proofs/s", "scaling": "strong", "steps": sh_steps, "ms_per_step": el_s / sh_steps * 1e3,
                      "statements_per_step_whole_job": nbt, "ranks": world, "backend": backend + (" (RCCL)" if backend == "nccl" else " (host-staged rehearsal)"),
@@ -648,10 +673,10 @@ def main():
                                                     (p.d * r // world) % 128 == 0 for r in range(world + 1)) else []) + [
                          {"op": "all_to_all_single", "what": "rows [d r/N, d (r+1)/N) of w | h | v of every statement to rank r",
                           "bytes_sent_per_rank": per_s * 3 * 4 * (p.d - p.d // world)},
-                         {"op": "reduce_scatter_tensor(sum, int64 lanes)", "what": "one uint64 lane per surviving 32-bit word of the 5 partial ciphertexts of every statement",
+                         {"op": "reduce_scatter_tensor(sum, int64 lanes)", "what": "the 5 partial ciphertexts of every statement as uint64 lanes of 56 bits (13 per 704-bit value, 27 at logq 1472)",
                           "input_bytes_per_rank": per_s * world * lps * 8, "output_bytes_per_rank": per_s * lps * 8}],
                      "reduce_scatter_bytes_per_rank_per_step": {"in": per_s * world * lps * 8, "out": per_s * lps * 8},
-                     "note": ("the reduce-scatter carries 1.29 MB of uint64 lanes per statement into every rank whatever the instance size, while the row work per "
+                     "note": ("the reduce-scatter carries 0.76 MB of uint64 lanes per statement (1.29 MB in rounds 1 - 3: one lane per 32-bit word) into every rank whatever the instance size, while the row work per "
                               "rank shrinks with D / N: at the default instance (D = 2^15) this leg is collective-bound and REPLICAS (the headline `value`) are "
                               "the better use of N GPUs; row sharding is for CRS images that do not fit one GPU (config 4/5: 45 / 90 GB per GPU on 8)"),
                      "image_share_bytes_per_rank": share_img,
@@ -842,8 +867,8 @@ def main():
                              if world > 1 else "single GPU"),
                 "scaling": "strong" if (by_rows and world > 1) else ("weak" if world > 1 else None),
                 "collectives_per_proof": ([{"op": "all_reduce(sum, int64 lanes)", "what": "this rank's share of sum_bits v_i: the witness polynomial", "bytes": p.d * 8},
-                                           {"op": "all_reduce(sum, int64 lanes)", "what": "the five partial ciphertexts, one lane per surviving 32-bit word",
-                                            "bytes": 5 * (p.n + 1) * 2 * p.K * 8}] if (by_rows and world > 1) else []),
+                                           {"op": "all_reduce(sum, int64 lanes)", "what": "the five partial ciphertexts, 56 bits per uint64 lane",
+                                            "bytes": 5 * (p.n + 1) * p.lanes * 8}] if (by_rows and world > 1) else []),
                 "ranks": world, "backend": (backend + (" (RCCL)" if backend == "nccl" else " (host-staged rehearsal)")) if world > 1 else None,
                 "row_sharding_error": single_err,
                 "roofline": {"bound": "hbm", "kernel": f"k_eval<{p.logq},2> (fused AES-256-CTR expansion + 2x MAC, S and AS regions)",

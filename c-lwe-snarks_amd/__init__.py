@@ -42,6 +42,10 @@ class Params:
         return self.logq // 64
 
     @property
+    def lanes(self):  # uint64 lanes of 56 bits per value in the multi-GPU sums (mfh_lanes_per_value)
+        return (64 * self.K + 55) // 56
+
+    @property
     def ctb(self):  # CT_BYTES
         return self.logq // 8
 
@@ -86,7 +90,7 @@ EXPORTS = [
     "mfh_encrypt_rows", "mfh_decrypt", "mfh_ct_smudge", "mfh_ssp_upload", "mfh_witness_poly", "mfh_version",
     "mfh_workspace_bytes", "mfh_last_kernel_ms", "mfh_set_timing", "mfh_set_overlap", "mfh_eval_rows_multi", "mfh_prove_batch", "mfh_crs_mm_image_bytes", "mfh_crs_expand_mm", "mfh_crs_set_resident_mm", "mfh_witness_poly_multi", "mfh_witness_poly_mm", "mfh_poly_h_multi", "mfh_poly_mul", "mfh_poly_add", "mfh_poly_prepare_t",
     "mfh_ssp_prepare", "mfh_poly_h", "mfh_setup_messages", "mfh_setup", "mfh_prove",
-    "mfh_prove_partial", "mfh_prove_finish", "mfh_ct_to_lanes", "mfh_ct_from_lanes", "mfh_timing_drain", "mfh_timing_busy_ms", "mfh_timing_work_rows", "mfh_set_batch_image", "mfh_set_batch_slabs", "mfh_set_expand_path", "mfh_set_encrypt_path", "mfh_set_batch_launch", "mfh_set_mm_chunk_rows", "mfh_set_mm_stream", "mfh_add_dotp", "mfh_set_encrypt_chunks", "mfh_set_witness_per", "mfh_set_eval_path", "mfh_set_decrypt_path", "mfh_decrypt_rows",
+    "mfh_prove_partial", "mfh_prove_finish", "mfh_ct_to_lanes", "mfh_ct_from_lanes", "mfh_lanes_per_value", "mfh_digest128", "mfh_timing_drain", "mfh_timing_busy_ms", "mfh_timing_work_rows", "mfh_set_batch_image", "mfh_set_batch_slabs", "mfh_set_expand_path", "mfh_set_encrypt_path", "mfh_set_batch_launch", "mfh_set_mm_chunk_rows", "mfh_set_mm_stream", "mfh_add_dotp", "mfh_set_encrypt_chunks", "mfh_set_witness_per", "mfh_set_eval_path", "mfh_set_decrypt_path", "mfh_decrypt_rows",
     "mfh_crs_mm_share_bytes", "mfh_crs_expand_mm_share", "mfh_crs_set_resident_mm_share", "mfh_batch_chain", "mfh_batch_witness_cols", "mfh_batch_chain_from_w", "mfh_witness_poly_mm_cols", "mfh_prove_batch_partial", "mfh_prove_batch_finish",
     "mfh_resident_row_bytes", "mfh_crs_expand", "mfh_eval_rows_resident", "mfh_crs_set_resident",
     "mfh_witness_lanes", "mfh_witness_from_lanes", "mfh_prove_partial_w", "mfh_verify",
@@ -146,6 +150,8 @@ def load_library():
         "mfh_prove": (i32, [vp, vp, vp, ctypes.c_char_p, u32, ctypes.c_char_p, sz, ctypes.c_char_p, vp]),
         "mfh_prove_partial": (i32, [vp, vp, vp, ctypes.c_char_p, u32, u32, u32, vp]),
         "mfh_prove_finish": (i32, [vp, vp, ctypes.c_char_p, sz, ctypes.c_char_p]),
+        "mfh_lanes_per_value": (u32, [vp]),
+        "mfh_digest128": (i32, [vp, vp, sz, vp]),
         "mfh_ct_to_lanes": (i32, [vp, vp, sz, vp]),
         "mfh_ct_from_lanes": (i32, [vp, vp, sz, vp]),
         "mfh_add_dotp": (i32, [vp, vp, vp, vp, sz]),
@@ -581,9 +587,16 @@ class Context:
         self._chk(self.lib.mfh_prove_finish(self._h, _ptr(d_proof), bytes(smudge_mag), maglen, bytes(smudge_sign)))
         return d_proof
 
+    def digest128(self, d_buf, nbytes=None):
+        """128-bit digest of a device buffer (a cache key, not a cryptographic hash): (lo, hi)"""
+        h = (ctypes.c_uint64 * 2)()
+        n = d_buf.numel() * d_buf.element_size() if nbytes is None else int(nbytes)
+        self._chk(self.lib.mfh_digest128(self._h, _ptr(d_buf), n, ctypes.cast(h, ctypes.c_void_p)))
+        return int(h[0]), int(h[1])
+
     def ct_to_lanes(self, d_cts, count, out=None):
         p = self.params
-        out = self.torch.empty(count * (p.n + 1) * 2 * p.K, dtype=self.torch.int64, device=self.device) if out is None else out
+        out = self.torch.empty(count * (p.n + 1) * p.lanes, dtype=self.torch.int64, device=self.device) if out is None else out
         self._chk(self.lib.mfh_ct_to_lanes(self._h, _ptr(d_cts), count, _ptr(out)))
         return out
 

@@ -395,8 +395,19 @@ __global__ __launch_bounds__(256) void k_decrypt_finish_mm(const int *__restrict
 }
 
 // per-key operands shared by the three matrix-core forms: balanced digits, prefix sums, Toeplitz fragments for element stride `ctb` (heads 0 and, for
-// stream rows, 8).  Returns the scratch layout in w / sb / ps / bf / part; the caller zeroes [w, w + keyed) after its launches.
-struct KeyOps { uint8_t *w; int8_t *sb; int64_t *ps; v4i *bf; int *part; size_t keyed; };
+// stream rows, 8).  Returns the scratch layout in w / sb / ps / bf / part; the caller's KeyWipe zeroes [w, w + total) when the call ends.
+struct KeyOps { uint8_t *w; int8_t *sb; int64_t *ps; v4i *bf; int *part; size_t keyed, total; };
+// Everything in the shared scratch that is derived from the secret key is zeroed on EVERY way out of the call, early error returns included: the balanced
+// digits, prefix sums and Toeplitz fragments ([w, w + keyed)) and the partial products behind them -- those hold the exact digits of <a_i, sk> for every row,
+// which with the public a (about n rows) determine sk, and for an encryption also expose e p + m.
+struct KeyWipe {
+  mfh_ctx *c;
+  KeyOps &K;
+  KeyWipe(mfh_ctx *c_, KeyOps &K_) : c(c_), K(K_) { K.w = nullptr; K.total = 0; }
+  ~KeyWipe() {
+    if (K.w && K.total) (void)hipMemsetAsync(K.w, 0, K.total, c->stream);
+  }
+};
 template <int LOGQ>
 int key_operands(mfh_ctx *c, const uint64_t *sk, uint32_t ctb, uint32_t rowlen, uint32_t ksteps, int nheads, size_t part_b, KeyOps &K) {
   using G = EG<LOGQ>;
@@ -411,6 +422,7 @@ int key_operands(mfh_ctx *c, const uint64_t *sk, uint32_t ctb, uint32_t rowlen, 
   K.bf = (v4i *)(K.w + sb_b + ps_b);
   K.part = (int *)(K.w + sb_b + ps_b + bf_b);
   K.keyed = sb_b + ps_b + bf_b;
+  K.total = K.keyed + part_b;
   hipLaunchKernelGGL(k_sk_digits, dim3((n + 255) / 256), dim3(256), 0, c->stream, sk, n, (uint32_t)G::L, (uint32_t)G::SBY, K.sb);
   long long *col = (long long *)(K.ps + 256);
   HIP_TRY(c, hipMemsetAsync(col, 0, 256 * 8, c->stream));
@@ -442,6 +454,7 @@ int decrypt_mm_t(mfh_ctx *c, const uint64_t *sk, const uint64_t *cts, size_t cou
   kpc = (kpc + D::GK - 1) / D::GK * D::GK;
   kc = (ksteps + kpc - 1) / kpc;
   KeyOps K;
+  KeyWipe wipe(c, K);
   int rc = key_operands<LOGQ>(c, sk, (uint32_t)D::ELB, (uint32_t)klen, ksteps, 1, (size_t)count * kc * 16 * G::NQ * 4, K);
   if (rc) return rc;
   const uint64_t ct_stride = (uint64_t)(n + 1) * D::ELB;
@@ -454,7 +467,7 @@ int decrypt_mm_t(mfh_ctx *c, const uint64_t *sk, const uint64_t *cts, size_t cou
   hipLaunchKernelGGL((k_decrypt_finish_mm<LOGQ, 1>), dim3(((uint32_t)count + 3) / 4), dim3(256), 0, c->stream, K.part, kc, (uint32_t)count, K.ps,
                      reinterpret_cast<const uint8_t *>(cts) + (uint64_t)n * D::ELB, ct_stride, out);
   HIP_TRY(c, hipGetLastError());
-  HIP_TRY(c, hipMemsetAsync(K.w, 0, K.keyed, c->stream));  // nothing derived from the secret key outlives the call in the shared scratch
+  // (KeyWipe zeroes the key's digits, prefix sums, Toeplitz fragments and the partial products on every way out)
   return MFH_OK;
 }
 
@@ -502,6 +515,7 @@ int encrypt_rows_mm_t(mfh_ctx *c, uint64_t off, size_t nrows, const uint64_t *sk
   int rc = enc_plan<LOGQ>(c, nrows, P);
   if (rc) return rc;
   KeyOps K;
+  KeyWipe wipe(c, K);
   rc = key_operands<LOGQ>(c, sk, (uint32_t)G::CTB, P.rowlen, P.ksteps, 2, (size_t)nrows * P.kc * 16 * G::NQ * 4, K);
   if (rc) return rc;
   AesKey keyx = c->key;
@@ -513,8 +527,7 @@ int encrypt_rows_mm_t(mfh_ctx *c, uint64_t off, size_t nrows, const uint64_t *sk
   HIP_TRY(c, hipGetLastError());
   hipLaunchKernelGGL(k_encrypt_finish_mm<LOGQ>, dim3(((uint32_t)nrows + 3) / 4), dim3(256), 0, c->stream, K.part, P.kc, (uint32_t)nrows, K.ps, msg, err, c8);
   HIP_TRY(c, hipGetLastError());
-  // the balanced digits of the secret key, their prefix sums and Toeplitz fragments do not outlive the call in the shared scratch
-  HIP_TRY(c, hipMemsetAsync(K.w, 0, K.keyed, c->stream));
+  // (KeyWipe zeroes the key's digits, prefix sums, Toeplitz fragments and the partial products on every way out)
   return MFH_OK;
 }
 
@@ -526,6 +539,7 @@ int decrypt_rows_mm_t(mfh_ctx *c, uint64_t off, size_t nrows, const uint64_t *sk
   int rc = enc_plan<LOGQ>(c, nrows, P);
   if (rc) return rc;
   KeyOps K;
+  KeyWipe wipe(c, K);
   rc = key_operands<LOGQ>(c, sk, (uint32_t)G::CTB, P.rowlen, P.ksteps, 2, (size_t)nrows * P.kc * 16 * G::NQ * 4, K);
   if (rc) return rc;
   AesKey keyx = c->key;
@@ -537,7 +551,7 @@ int decrypt_rows_mm_t(mfh_ctx *c, uint64_t off, size_t nrows, const uint64_t *sk
   HIP_TRY(c, hipGetLastError());
   hipLaunchKernelGGL((k_decrypt_finish_mm<LOGQ, 0>), dim3(((uint32_t)nrows + 3) / 4), dim3(256), 0, c->stream, K.part, P.kc, (uint32_t)nrows, K.ps, c8, (uint64_t)G::CTB, out);
   HIP_TRY(c, hipGetLastError());
-  HIP_TRY(c, hipMemsetAsync(K.w, 0, K.keyed, c->stream));
+  // (KeyWipe zeroes the key's digits, prefix sums, Toeplitz fragments and the partial products on every way out)
   return MFH_OK;
 }
 

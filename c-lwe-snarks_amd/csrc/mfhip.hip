@@ -45,6 +45,36 @@ struct PS {
 // ------------------------------------------------------------------------------------------------------
 // keystream kernel: aesctr_prg / rng_seek (src/aes.c:104-144, src/entropy.c:46-56), stateless form
 // ------------------------------------------------------------------------------------------------------
+// 128-bit digest of a device buffer (mfh_digest128): sum over the 32-bit words of two different 64-bit mixes of (position, word).  The mix is a
+// bijection of the pair, so ANY change of one word changes both sums; changes of several words cancel with probability 2^-128.  A cache key
+// (has the caller rewritten this buffer since it was expanded?), not a cryptographic hash.
+__device__ __forceinline__ uint64_t digest_mix(uint64_t x, uint64_t m1, uint64_t m2) {
+  x = (x ^ (x >> 30)) * m1;
+  x = (x ^ (x >> 27)) * m2;
+  return x ^ (x >> 31);
+}
+__global__ __launch_bounds__(256) void k_digest128(const uint8_t *__restrict__ buf, uint64_t nbytes, unsigned long long *__restrict__ acc) {
+  const uint64_t nfull = nbytes / 4;
+  uint64_t h0 = 0, h1 = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i * 4 < nbytes; i += (uint64_t)gridDim.x * 256) {
+    uint32_t w = 0;
+    if (i < nfull) w = reinterpret_cast<const uint32_t *>(buf)[i];
+    else
+      for (uint64_t b = 4 * i; b < nbytes; b++) w |= (uint32_t)buf[b] << (8 * (b - 4 * i));
+    const uint64_t x = ((i + 1) << 32) ^ w ^ ((i + 1) >> 32 << 40);  // (position, word) -> one 64-bit value, injective below 2^56 words
+    h0 += digest_mix(x + 0x9e3779b97f4a7c15ull, 0xbf58476d1ce4e5b9ull, 0x94d049bb133111ebull);
+    h1 += digest_mix(x ^ 0xd6e8feb86659fd93ull, 0xff51afd7ed558ccdull, 0xc4ceb9fe1a85ec53ull);
+  }
+  for (int o = 32; o; o >>= 1) {
+    h0 += __shfl_xor((unsigned long long)h0, o);
+    h1 += __shfl_xor((unsigned long long)h1, o);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(acc, (unsigned long long)h0);
+    atomicAdd(acc + 1, (unsigned long long)h1);
+  }
+}
+
 __global__ __launch_bounds__(1024) void k_keystream(AesKey key, const uint32_t *__restrict__ g_t0, uint64_t off,
                                                     uint8_t *__restrict__ out, uint64_t nbytes) {
   __shared__ __attribute__((aligned(16))) uint32_t lt[mf::kTabBytes / 4];
@@ -1274,6 +1304,21 @@ int mfh_set_seed(mfh_ctx *c, const uint8_t seed[40]) {
       CALL1472;                             \
     }                                       \
   } while (0)
+
+int mfh_digest128(mfh_ctx *c, const void *d_buf, size_t nbytes, uint64_t h_digest[2]) {
+  if (!c || (!d_buf && nbytes) || !h_digest || (reinterpret_cast<uintptr_t>(d_buf) & 3)) return MFH_EINVAL;
+  HIP_TRY(c, hipSetDevice(c->device));
+  int rc = aux_reserve(c, 16);
+  if (rc) return rc;
+  HIP_TRY(c, hipMemsetAsync(c->aux, 0, 16, c->stream));
+  const uint64_t nwords = (nbytes + 3) / 4;
+  const uint32_t grid = (uint32_t)std::min<uint64_t>(2048, (nwords + 255) / 256);
+  if (grid) hipLaunchKernelGGL(k_digest128, dim3(grid), dim3(256), 0, c->stream, (const uint8_t *)d_buf, (uint64_t)nbytes, (unsigned long long *)c->aux);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(h_digest, c->aux, 16, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return MFH_OK;
+}
 
 int mfh_keystream(mfh_ctx *c, uint64_t off, void *d_out, size_t nbytes) {
   if (!c || (!d_out && nbytes)) return MFH_EINVAL;

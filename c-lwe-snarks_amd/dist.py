@@ -2,7 +2,7 @@
 
 SURVEY 8(e): every proof element is sum_i coeff_i * row_i over CRS rows and the AES-CTR stream is seekable, so
 each rank takes a contiguous share of the rows of every region and produces five partial ciphertexts.  The
-exchange steps are one all-reduce per proof of 5 x 1471 x 22 uint64 lanes (1.3 MB) and, so that the SSP pass shards
+exchange steps are one all-reduce per proof of 5 x 1471 x 13 uint64 lanes (0.76 MB) and, so that the SSP pass shards
 as well, one of D uint64 lanes for the witness polynomial (256 KB): each 32-bit limb travels in its own
 64-bit lane so RCCL's integer sum cannot overflow (2^32 ranks of headroom), carries are propagated once afterwards,
 and because sums mod 2^704 are order-independent the result is bit-identical to the single-GPU proof.
@@ -117,7 +117,7 @@ def prove_batch_sharded(ctx, d_crs, d_ssp, witness_bits_list, deltas, smudge_mag
     Every rank is given the same statement list.  Data path per call:
       chain (own statements)  ->  all-to-all of the w | h | v row slices (3 x 4 B x d x nb / world sent per rank)
       ->  row shares of all five ciphertexts of all statements on the matrix cores
-      ->  ONE reduce-scatter (sum) of uint64 lanes, nb x 5 x (n+1) x 2K lanes of 8 B  ->  carries, modq, delta ct_t, smudging (own statements).
+      ->  ONE reduce-scatter (sum) of uint64 lanes, nb x 5 x (n+1) x ceil(64 K / 56) lanes of 8 B  ->  carries, modq, delta ct_t, smudging (own statements).
     witness_by_cols (default: on for a generator-defined SSP, d_ssp = None, where the witness pass is the chain's cost): the chain is cut
     in two -- every rank computes its COEFFICIENT RANGE [d r / world, d (r+1) / world) of w of ALL statements (1 / world of the
     generation of the selected rows, no reduction), one more all-to-all (4 B x d x nb / world sent per rank) hands every statement's
@@ -167,8 +167,8 @@ def prove_batch_sharded(ctx, d_crs, d_ssp, witness_bits_list, deltas, smudge_mag
     if partial is not None and partial.numel() * partial.element_size() < nb * 5 * p.ct_limbs * 8:
         partial = None  # a buffer kept from a smaller call: mfh_prove_batch_partial writes nb x 5 ciphertexts
     partial = ctx.prove_batch_partial(d_crs, rank, world, witness_bits_list, recv, recv[cs:], recv[2 * cs:], 3 * cs, out=partial)
-    # 4. one uint64 lane per surviving 32-bit word, statements padded to world equal slabs; reduce-scatter: the rank receives its slab summed
-    lps = 5 * (p.n + 1) * 2 * p.K  # lanes per statement
+    # 4. the partial ciphertexts as uint64 lanes of 56 bits (13 per 704-bit value), statements padded to world equal slabs; reduce-scatter: the rank receives its slab summed
+    lps = 5 * (p.n + 1) * p.lanes  # lanes per statement
     lanes = bufs.get("blanes")
     if lanes is None or lanes.numel() != per * world * lps:
         lanes = torch.zeros(per * world * lps, dtype=torch.int64, device=send.device)
@@ -184,24 +184,41 @@ def prove_batch_sharded(ctx, d_crs, d_ssp, witness_bits_list, deltas, smudge_mag
     return first, count, proofs
 
 
+def lanes_per_value(K):
+    return (64 * K + 55) // 56
+
+
 def lanes_from_limbs_cpu(cts_u64, K):
-    """CPU/torch restatement of mfh_ct_to_lanes for the gloo tests: (..., L) uint64 limbs -> (..., 2K) int64 lanes."""
+    """CPU restatement of mfh_ct_to_lanes for the gloo tests: (..., L) uint64 limbs -> (..., ceil(64 K / 56)) int64 lanes, lane j = bits [56 j, 56 j + 56)."""
     import numpy as np
 
-    w = np.ascontiguousarray(cts_u64).view(np.uint32).reshape(*cts_u64.shape[:-1], -1)[..., : 2 * K]
-    return w.astype(np.int64)
+    x = np.ascontiguousarray(cts_u64).astype(np.uint64)
+    nl = lanes_per_value(K)
+    out = np.zeros(x.shape[:-1] + (nl,), dtype=np.uint64)
+    for j in range(nl):
+        l, sh = (56 * j) >> 6, (56 * j) & 63
+        r = x[..., l] >> np.uint64(sh)
+        if sh > 8 and l + 1 < K:
+            r = r | (x[..., l + 1] << np.uint64(64 - sh))
+        out[..., j] = r & np.uint64((1 << 56) - 1)
+    return out.astype(np.int64)
 
 
 def limbs_from_lanes_cpu(lanes, L, K):
-    """CPU restatement of mfh_ct_from_lanes: propagate carries over the 2K lanes, drop what exceeds 2^(64K) (modq)."""
+    """CPU restatement of mfh_ct_from_lanes: sum_j lane_j 2^(56 j) mod 2^(64 K) (carries propagated, modq) as (..., L) uint64 limbs."""
     import numpy as np
 
     lanes = np.asarray(lanes).astype(np.uint64)
-    out = np.zeros(lanes.shape[:-1] + (2 * L,), dtype=np.uint32)
-    carry = np.zeros(lanes.shape[:-1], dtype=np.uint64)
-    for w in range(2 * K):
-        x = lanes[..., w]
-        lo = (x & np.uint64(0xFFFFFFFF)) + (carry & np.uint64(0xFFFFFFFF))
-        out[..., w] = (lo & np.uint64(0xFFFFFFFF)).astype(np.uint32)
-        carry = (x >> np.uint64(32)) + (carry >> np.uint64(32)) + (lo >> np.uint64(32))
-    return out.view(np.uint64)
+    nl = lanes_per_value(K)
+    assert lanes.shape[-1] == nl
+    flat = lanes.reshape(-1, nl)
+    out = np.zeros((flat.shape[0], L), dtype=np.uint64)
+    mask = (1 << (64 * K)) - 1
+    for i in range(flat.shape[0]):
+        v = 0
+        for j in range(nl):
+            v += int(flat[i, j]) << (56 * j)
+        v &= mask
+        for l in range(K):
+            out[i, l] = (v >> (64 * l)) & 0xFFFFFFFFFFFFFFFF
+    return out.reshape(lanes.shape[:-1] + (L,))

@@ -6,11 +6,16 @@
  *
  * This is the DROP-IN path: every call crosses PCIe and converts mpz_t, so it measures the PCIe/host-inclusive cost of
  * using the GPU through the reference API, not the kernel throughput bench.py reports.
- *   usage: bench_snark [nproofs] [nenc]
+ *   usage: bench_snark [nproofs] [nenc] [nbatch] [eval]
+ *          nbatch statements through mfuoco_prover_batch, three calls (the first expands the CRS image, the others stream the image the shim kept:
+ *          `prover_batch` lines); eval != 0: what src/benchmark_eval.c:30-86 measures (D encryptions written to a coeffs file, the file mapped, ONE
+ *          eval_poly over its D rows timed: `eval` line).
  */
 #define _GNU_SOURCE
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
 #include <sys/random.h>
 #include <sys/time.h>
 
@@ -25,7 +30,7 @@ static double now(void)
 
 int main(int argc, char **argv)
 {
-  int nproofs = argc > 1 ? atoi(argv[1]) : 3, nenc = argc > 2 ? atoi(argv[2]) : 200;
+  int nproofs = argc > 1 ? atoi(argv[1]) : 3, nenc = argc > 2 ? atoi(argv[2]) : 200, nbatch = argc > 3 ? atoi(argv[3]) : 255, do_eval = argc > 4 ? atoi(argv[4]) : 1;
   ssp_t ssp = calloc(1, SSP_SIZE);
   mpz_t witness;
   mpz_init(witness);
@@ -51,6 +56,77 @@ int main(int argc, char **argv)
     bool out = verifier(ssp, vrs, pi);
     printf("verifier\t%lf\n", now() - t0);
     ok = ok && out;
+  }
+
+  /* many statements under one CRS through the reference's types: the first call expands the CRS (AES on the CU) and the shim keeps the image, keyed by
+   * the seed and a device-side digest of the compressed CRS; the following calls stream it (the materialised-CRS regime) */
+  if (nbatch > 0) {
+    proof_t *pb = malloc(nbatch * sizeof *pb);
+    mpz_t *wit = malloc(nbatch * sizeof *wit);
+    uint8_t *okb = malloc(nbatch);
+    for (int k = 0; k < nbatch; k++) { proof_init(pb[k]); mpz_init_set(wit[k], witness); }
+    for (int call = 0; call < 3; call++) {
+      t0 = now();
+      mfuoco_prover_batch(pb, crs, ssp, wit, nbatch);
+      double dt = now() - t0;
+      printf("prover_batch\t%lf\t(%d statements, %s: %.1f proofs/s incl. PCIe and mpz_t conversion)\n", dt, nbatch,
+             call == 0 ? "cold: the call expands the CRS image" : "warm: the image kept by the shim is streamed", nbatch / dt);
+    }
+    t0 = now();
+    mfuoco_verifier_batch(ssp, vrs, pb, nbatch, okb);
+    printf("verifier_batch\t%lf\t(%d proofs)\n", now() - t0, nbatch);
+    for (int k = 0; k < nbatch; k++) ok = ok && okb[k] == 1;
+    for (int k = 0; k < nbatch; k++) { proof_clear(pb[k]); mpz_clear(wit[k]); }
+    free(pb); free(wit); free(okb);
+  }
+
+  /* benchmark_eval (src/benchmark_eval.c:30-86): D encryptions exported to a coeffs file, the file mapped read-only, ONE eval_poly over its D rows timed.
+   * (Here the stream is rewound before the evaluation, so the result is also checked: it decrypts to sum_i coeff_i m_i mod p.) */
+  if (do_eval) {
+    char dir[] = "/tmp/mfuoco_eval_XXXXXX", path[64];
+    if (!mkdtemp(dir)) { perror("mkdtemp"); return 1; }
+    snprintf(path, sizeof path, "%s/coeffs", dir);
+    rng_t erng;
+    rng_init(erng, crs->seed);
+    ct_t ect, evaluated;
+    ct_init(ect);
+    ct_init(evaluated);
+    nmod_poly_t coeffs;
+    nmod_poly_init(coeffs, GAMMA_P);
+    uint8_t (*rows)[CT_BYTES] = malloc((size_t)GAMMA_D * CT_BYTES);
+    mpz_t em;
+    mpz_init(em);
+    unsigned __int128 expect = 0;
+    t0 = now();
+    for (size_t i = 0; i != GAMMA_D; i++) {
+      uint64_t r[2];
+      getrandom(r, 16, 0);
+      nmod_poly_set_coeff_ui(coeffs, i, r[0] % GAMMA_P);
+      mpz_set_ui(em, r[1] % GAMMA_P);
+      regev_encrypt(ect, erng, vrs->sk, em);
+      ct_export(rows[i], ect);
+      expect = (expect + (unsigned __int128)(r[0] % GAMMA_P) * (r[1] % GAMMA_P)) % GAMMA_P;
+    }
+    fprintf(stderr, "eval: %d encryptions, one at a time\t%lf\n", (int)GAMMA_D, now() - t0);
+    if (mfuoco_rows_save(path, rows, GAMMA_D)) { perror("coeffs"); return 1; }
+    free(rows);
+    size_t nrows = 0;
+    uint8_t (*c8)[CT_BYTES] = mfuoco_rows_map(path, &nrows);
+    if (!c8 || nrows != GAMMA_D) { perror("coeffs map"); return 1; }
+    rng_seek(erng, 0);
+    t0 = now();
+    eval_poly(evaluated, erng, c8, coeffs, GAMMA_D);
+    printf("eval\t%lf\n", now() - t0);
+    regev_decrypt(em, vrs->sk, evaluated);
+    ok = ok && !mpz_cmp_ui(em, (unsigned long)expect);
+    mfuoco_rows_unmap(c8, nrows);
+    unlink(path);
+    rmdir(dir);
+    mpz_clear(em);
+    nmod_poly_clear(coeffs);
+    ct_clear(ect);
+    ct_clear(evaluated);
+    rng_clear(erng);
   }
 
   /* benchmark_lwe's loop: one encryption and one decryption at a time */

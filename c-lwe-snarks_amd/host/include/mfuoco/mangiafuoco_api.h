@@ -104,9 +104,34 @@ void setup(crs_t crs, vrs_t vrs, ssp_t ssp);
 void prover(proof_t pi, crs_t crs, ssp_t ssp, mpz_t witness);
 bool verifier(ssp_t ssp, vrs_t vrs, proof_t pi);
 
+/* ---- the reference headers' inline helpers and macros: same names and meaning (src/lwe.h:57-67,76-104, src/entropy.h:40-72, src/snark.h:8-12,
+ * src/ssp.h:8-9, src/aes.h:33-34).  modq (src/lwe.h:107-118) works on GMP internals and is applied by the device kernels to every value they produce:
+ * a caller never needs it; CTR(x) / REM(x) read the stream state this header's struct aesctr keeps like the reference's. ---- */
+#include <strings.h>
+#include <sys/random.h>
+#define CTR(x) ((*(x))->ctr)
+#define REM(x) ((*(x))->rem)
+#define CTR_CT (CT_BYTES * GAMMA_N)
+#define CTR_S 0
+#define CTR_AS (CTR_CT * GAMMA_D)
+#define CTR_BT (2 * CTR_CT * GAMMA_D)
+#define CTR_BV (2 * CTR_CT * GAMMA_D + CTR_CT)
+#define ssp_t_offset 0
+#define ssp_v_offset(i) (GAMMA_D * 8 * ((i) + 1))
+#define RNG_INIT(rs) do { rseed_t rseed_; getrandom(&rseed_, sizeof(rseed_t), GRND_NONBLOCK); rng_init(rs, rseed_); bzero(&rseed_, sizeof(rseed_t)); } while (0)
+static inline void rng_gen(rng_t prg, void *out, size_t count) { aesctr_prg((aesctr_ptr)prg, out, count); }
+#define mpz2_urandommv(vs, rng, bits, len) do { for (size_t i_ = 0; i_ < (len); i_++) mpz2_urandomb((vs)[i_], rng, bits); } while (0)
+#define mpz2_urandombv2(vs, bits, len) do { for (size_t i_ = 0; i_ < (len); i_++) mpz2_urandomb2((vs)[i_], bits); } while (0)
+#define mpz_initv(vs, len) do { for (size_t i_ = 0; i_ < (len); i_++) mpz_init((vs)[i_]); } while (0)
+#define mpz_clearv(vs, len) do { for (size_t i_ = 0; i_ < (len); i_++) mpz_clear((vs)[i_]); } while (0)
+#define ct_clearv(vs, len) do { for (size_t i_ = 0; i_ < (len); i_++) ct_clear((vs)[i_]); } while (0)
+static inline void mpz_dotp(mpz_t rop, mpz_t a[], mpz_t b[], size_t len) { mpz_set_ui(rop, 0); mpz_add_dotp(rop, a, b, len); }
+static inline void regev_encrypt(ct_t c, rng_t rs, sk_t sk, mpz_t m) { regev_encrypt2(c, rs, sk, m, errdist_uniform); }
+static inline uint64_t rand_modp(void) { uint64_t rop_ = 0; while (getrandom(&rop_, sizeof rop_, 0) != (ssize_t)sizeof rop_) { } return rop_ % GAMMA_P; }
+
 /* ---- additions (not in the reference) ---- */
 /* The shim keeps the last SSP it uploaded (keyed by host pointer) resident in HBM; call this after changing the
- * bytes of an SSP buffer in place. */
+ * bytes of an SSP buffer in place.  (It also drops the expanded CRS images; a CRS changed in place is noticed without it.) */
 void mfuoco_gpu_invalidate(void);
 /* prover() for `count` statements under one CRS and SSP: rows expanded once per group of proofs, multiply-accumulate on the matrix
  * cores; every proof is what prover() would produce with the same randomness.  pis[k] initialised by proof_init. */
@@ -115,8 +140,15 @@ void mfuoco_prover_batch(proof_t *pis, crs_t crs, ssp_t ssp, mpz_t *witnesses, s
 void mfuoco_verifier_batch(ssp_t ssp, vrs_t vrs, proof_t *pis, size_t count, uint8_t *ok);
 /* regev_decrypt for `count` ciphertexts under one key (src/lwe.c:105-111 per ciphertext); ms[k] initialised by the caller */
 void mfuoco_decrypt_batch(mpz_t *ms, sk_t sk, ct_t *cts, size_t count);
-/* select the GPU (default 0, or $MFUOCO_GPU); must precede the first call */
-void mfuoco_gpu_set_device(int device);
+/* select the GPU (default 0, or $MFUOCO_GPU); must precede the first call: returns 0, or -1 (with a message) once the shim runs on another GPU.
+ * mfuoco_gpu_device: the GPU the shim runs on, -1 before its first call. */
+int mfuoco_gpu_set_device(int device);
+int mfuoco_gpu_device(void);
+/* The shim keeps the CRS it expanded across prover calls, keyed by the seed and a device-side digest of the compressed CRS (SURVEY 8(d)'s materialised-CRS
+ * regime behind the reference's types): mfuoco_prover_batch / _sharded stream the matrix-core image from the second call on (no AES in the call), prover()
+ * the single-proof image from its second call under one CRS on (that call expands it).  Default on; $MFUOCO_GPU_RESIDENT_CRS=0 or mfuoco_gpu_set_resident_crs(0) turn it off and
+ * free the images; mfuoco_gpu_invalidate() drops them (and the resident SSP). */
+void mfuoco_gpu_set_resident_crs(int on);
 
 
 /* ---- flat on-disk images (host only; host/mfuoco_files.c).  Sizes are the reference's: CRS_SIZE (src/snark.h:6),

@@ -19,21 +19,34 @@ typedef struct mfuoco_comm mfuoco_comm;
 
 #define MFUOCO_UNIQUE_ID_BYTES 128 /* = NCCL_UNIQUE_ID_BYTES */
 
-/* Communicator of `world` processes, this one being `rank`, on GPU `device` (which also becomes the shim's device: call before any other
- * shim function).  The 128-byte ncclUniqueId travels through the file `id_file`: rank 0 creates it (ncclGetUniqueId), writes it under a
- * temporary name and renames it into place; the other ranks wait for the file (at most 120 s).  Remove the file between jobs.
- * Returns 0, or -1 with a message on stderr. */
+/* Communicator of `world` processes, this one being `rank`, on GPU `device`, which must be the shim's GPU: call this before any other shim function, or
+ * after mfuoco_gpu_set_device(device); -1 if the shim already runs on another GPU.  The 128-byte ncclUniqueId travels through files named after
+ * `id_file` (a path in a directory only this user can write -- the caller's job directory, not a shared /tmp): rank 0 removes what an earlier job may
+ * have left, publishes the id with a fresh session nonce, collects an acknowledgement of THAT nonce from every rank and only then releases them, so that no
+ * rank enters ncclCommInitRank with a stale or foreign id (host/mfuoco_dist.c, "rendezvous through files").  Every file is created exclusively, mode 0600,
+ * and removed once the communicator exists.  Gives up after $MFUOCO_RENDEZVOUS_S seconds (default 120).  Returns 0, or -1 with a message on stderr: exit
+ * non-zero then, do not retry inside the process. */
 int mfuoco_comm_create(mfuoco_comm **comm, int rank, int world, int device, const char *id_file);
 /* the same with the id handed over by the caller's own launcher (MPI_Bcast, a socket, an environment variable ...) */
 void mfuoco_comm_unique_id(uint8_t id[MFUOCO_UNIQUE_ID_BYTES]);
 int mfuoco_comm_create_from_id(mfuoco_comm **comm, int rank, int world, int device, const uint8_t id[MFUOCO_UNIQUE_ID_BYTES]);
-/* REHEARSAL backend for boxes with fewer GPUs than ranks (tests): the same call sequence with every collective staged through a POSIX
- * shared-memory segment `/name` on the host (what gloo is to the Python driver); all ranks may share one GPU.  Never the product path. */
-int mfuoco_comm_create_rehearsal(mfuoco_comm **comm, int rank, int world, int device, const char *shm_name);
+/* A communicator over the caller's OWN collectives (an MPI build, a test harness) instead of RCCL: the four operations the sequences below need, on device
+ * buffers, ordered with the NULL stream (a transport that stages through the host synchronises the device itself).  Element counts, not bytes;
+ * reduce_scatter: d_recv[0 .. n) = sum over ranks q of q's d_send[rank * n .. (rank + 1) * n), wrap-around uint64 sums; destroy may be NULL. */
+typedef struct mfuoco_transport {
+  const char *name;
+  void (*alltoallv_u32)(void *impl, int rank, int world, const uint32_t *d_send, const size_t *scnt, const size_t *sdsp, uint32_t *d_recv, const size_t *rcnt,
+                        const size_t *rdsp);
+  void (*reduce_scatter_u64)(void *impl, int rank, int world, const uint64_t *d_send, uint64_t *d_recv, size_t n);
+  void (*allreduce_u64)(void *impl, int rank, int world, uint64_t *d_buf, size_t n);
+  void (*bcast_bytes)(void *impl, int rank, int world, uint8_t *d_buf, size_t n, int root);
+  void (*destroy)(void *impl);
+} mfuoco_transport;
+int mfuoco_comm_create_transport(mfuoco_comm **comm, int rank, int world, int device, const mfuoco_transport *transport, void *impl);
 void mfuoco_comm_destroy(mfuoco_comm *comm);
 int mfuoco_comm_rank(const mfuoco_comm *comm);
 int mfuoco_comm_world(const mfuoco_comm *comm);
-/* "rccl" or "rehearsal (host shared memory)" */
+/* the transport's name: "rccl" for the communicators this library creates itself */
 const char *mfuoco_comm_backend(const mfuoco_comm *comm);
 /* calls and bytes handed to the backend so far: index 0 all-to-all (send/recv groups), 1 reduce-scatter, 2 all-reduce, 3 broadcast */
 void mfuoco_comm_stats(const mfuoco_comm *comm, uint64_t calls[4], uint64_t bytes[4]);
@@ -51,7 +64,7 @@ void mfuoco_comm_stats(const mfuoco_comm *comm, uint64_t calls[4], uint64_t byte
 void mfuoco_prover_batch_sharded(proof_t *pis, crs_t crs, ssp_t ssp, mpz_t *witnesses, size_t count, mfuoco_comm *comm, size_t *own_first,
                                  size_t *own_count);
 /* ONE proof computed by all ranks together (every rank returns the complete proof): the rank's share of the witness polynomial ->
- * ncclAllReduce(sum, ncclUint64) over D lanes -> the rank's row shares of the five ciphertexts -> ncclAllReduce over 5 x 1471 x 22 lanes ->
+ * ncclAllReduce(sum, ncclUint64) over D lanes -> the rank's row shares of the five ciphertexts -> ncclAllReduce over 5 x 1471 x 13 lanes (56 bits per uint64 lane) ->
  * carries, modq, smudging.  Rank 0 draws the entropy and broadcasts it (ncclBroadcast, 413 bytes). */
 void mfuoco_prover_sharded(proof_t pi, crs_t crs, ssp_t ssp, mpz_t witness, mfuoco_comm *comm);
 

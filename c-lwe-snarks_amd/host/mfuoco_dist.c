@@ -12,12 +12,11 @@
 #define _GNU_SOURCE
 #include <errno.h>
 #include <fcntl.h>
-#include <stdatomic.h>
 #include <stdbool.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
-#include <sys/mman.h>
+#include <sys/random.h>
 #include <sys/stat.h>
 #include <time.h>
 #include <unistd.h>
@@ -30,6 +29,7 @@
 
 #include "mfhip.h"
 #include "mfuoco/mfuoco_dist.h"
+#include "mfuoco_rendezvous.h"
 
 /* shared with host/mfuoco_gpu.c (libmfuoco_gpu) */
 mfh_ctx *mfuoco_gpu_ctx(void);
@@ -39,33 +39,25 @@ size_t mfuoco_gpu_bits_stride(void);
 void mfuoco_gpu_witness_bits(uint8_t *bits, mpz_t witness);
 void mfuoco_gpu_prover_entropy(uint32_t *delta, uint8_t *mag, uint8_t *sign);
 void mfuoco_gpu_proofs_to_host(proof_t *pis, const uint64_t *d_proofs, size_t count);
+void mfuoco_gpu_image_resident_share(const uint8_t *d_crs, uint32_t rank, uint32_t world);
 
 #define L_LIMBS 12
 #define K_LIMBS 11
 #define CTL ((size_t)(GAMMA_N + 1) * L_LIMBS)
-#define LANES_PER_CT ((size_t)(GAMMA_N + 1) * 2 * K_LIMBS) /* one uint64 lane per surviving 32-bit word */
+#define LANES_PER_CT ((size_t)(GAMMA_N + 1) * ((64 * K_LIMBS + 55) / 56)) /* uint64 lanes of 56 bits: 13 per 704-bit value (mfh_lanes_per_value) */
 #define MAGLEN (GAMMA_LOG_SMUDGING / 8)
 #define MAXW 64
 
-enum { KIND_NONE = 0, KIND_RCCL = 1, KIND_SHM = 2 };
 enum { ST_A2A = 0, ST_RS = 1, ST_AR = 2, ST_BC = 3 };
 
-struct shm_hdr {
-  _Atomic uint32_t ready, arrived, generation, detached;
-  uint32_t world;
-  uint64_t slot_bytes;
-  uint64_t disp[MAXW][MAXW], cnt[MAXW][MAXW]; /* all-to-all: bytes rank r sends to q, and where they start in r's mailbox */
-};
-
+/* The communicator: rank / world / device, the transport that carries the four collectives (RCCL here; mfuoco_comm_create_transport for a caller's own),
+ * call statistics and device scratch.  The product library contains the RCCL transport only. */
 struct mfuoco_comm {
-  int kind, rank, world, device;
-  ncclComm_t nccl;
-  struct shm_hdr *shm;
-  size_t shm_total;
-  char shm_name[96];
+  int rank, world, device;
+  const mfuoco_transport *t; /* NULL: no backend (comm == NULL callers, world 1) */
+  void *impl;
   uint64_t calls[4], bytes[4];
-  /* device scratch, grown on demand */
-  void *buf[8];
+  void *buf[8]; /* device scratch, grown on demand */
   size_t cap[8];
 };
 
@@ -87,6 +79,12 @@ static void *scratch(mfuoco_comm *c, int slot, size_t bytes)
   }
   return c->buf[slot];
 }
+static void *xmalloc(size_t bytes)
+{
+  void *p = malloc(bytes ? bytes : 1);
+  if (!p) dist_die("out of host memory", NULL);
+  return p;
+}
 
 /* ---- split arithmetic (dist.py: row_shares, statement_shares) ------------------------------------------------------------ */
 static size_t row_lo(size_t total, int r, int world) { return total * (size_t)r / (size_t)world; }
@@ -97,25 +95,72 @@ static size_t stmt_lo(size_t nb, int r, int world)
   return lo < nb ? lo : nb;
 }
 
-/* ---- communicator ---------------------------------------------------------------------------------------------------------- */
-static mfuoco_comm *comm_new(int kind, int rank, int world, int device)
+/* ---- the RCCL transport ---------------------------------------------------------------------------------------------------- */
+static void rccl_alltoallv_u32(void *impl, int rank, int world, const uint32_t *d_send, const size_t *scnt, const size_t *sdsp, uint32_t *d_recv,
+                               const size_t *rcnt, const size_t *rdsp)
 {
-  if (world < 1 || world > MAXW || rank < 0 || rank >= world) {
-    fprintf(stderr, "libmfuoco_gpu_dist: bad rank %d / world %d (at most %d ranks)\n", rank, world, MAXW);
-    return NULL;
+  (void)rank;
+  ncclComm_t nc = impl;
+  NK(ncclGroupStart());
+  for (int q = 0; q < world; q++) {
+    if (scnt[q]) NK(ncclSend(d_send + sdsp[q], scnt[q], ncclUint32, q, nc, NULL));
+    if (rcnt[q]) NK(ncclRecv(d_recv + rdsp[q], rcnt[q], ncclUint32, q, nc, NULL));
   }
+  NK(ncclGroupEnd());
+}
+static void rccl_reduce_scatter_u64(void *impl, int rank, int world, const uint64_t *d_send, uint64_t *d_recv, size_t n)
+{
+  (void)rank; (void)world;
+  NK(ncclReduceScatter(d_send, d_recv, n, ncclUint64, ncclSum, (ncclComm_t)impl, NULL));
+}
+static void rccl_allreduce_u64(void *impl, int rank, int world, uint64_t *d_buf, size_t n)
+{
+  (void)rank; (void)world;
+  NK(ncclAllReduce(d_buf, d_buf, n, ncclUint64, ncclSum, (ncclComm_t)impl, NULL));
+}
+static void rccl_bcast_bytes(void *impl, int rank, int world, uint8_t *d_buf, size_t n, int root)
+{
+  (void)rank; (void)world;
+  NK(ncclBroadcast(d_buf, d_buf, n, ncclUint8, root, (ncclComm_t)impl, NULL));
+}
+static void rccl_destroy(void *impl) { ncclCommDestroy((ncclComm_t)impl); }
+static const mfuoco_transport rccl_transport = { "rccl", rccl_alltoallv_u32, rccl_reduce_scatter_u64, rccl_allreduce_u64, rccl_bcast_bytes, rccl_destroy };
+
+/* ---- communicator ---------------------------------------------------------------------------------------------------------- */
+/* The shim's GPU and the communicator's must be the same one: every mfh_* call switches the current device to the shim's, so scratch and collectives
+ * on another device would end in a wrong-device collective or a hang.  Checked here instead of trusted. */
+static int bind_device(int device)
+{
+  if (mfuoco_gpu_set_device(device)) return -1;
+  if (hipSetDevice(device) != hipSuccess) {
+    fprintf(stderr, "libmfuoco_gpu_dist: no HIP device %d\n", device);
+    return -1;
+  }
+  return 0;
+}
+int mfuoco_comm_create_transport(mfuoco_comm **out, int rank, int world, int device, const mfuoco_transport *t, void *impl)
+{
+  if (!out || world < 1 || world > MAXW || rank < 0 || rank >= world) {
+    fprintf(stderr, "libmfuoco_gpu_dist: bad rank %d / world %d (at most %d ranks)\n", rank, world, MAXW);
+    return -1;
+  }
+  if (t && (!t->alltoallv_u32 || !t->reduce_scatter_u64 || !t->allreduce_u64 || !t->bcast_bytes)) {
+    fprintf(stderr, "libmfuoco_gpu_dist: incomplete transport\n");
+    return -1;
+  }
+  if (bind_device(device)) return -1;
   mfuoco_comm *c = calloc(1, sizeof *c);
-  c->kind = kind;
+  if (!c) {
+    fprintf(stderr, "libmfuoco_gpu_dist: out of host memory\n");
+    return -1;
+  }
   c->rank = rank;
   c->world = world;
   c->device = device;
-  mfuoco_gpu_set_device(device);
-  if (hipSetDevice(device) != hipSuccess) {
-    fprintf(stderr, "libmfuoco_gpu_dist: no HIP device %d\n", device);
-    free(c);
-    return NULL;
-  }
-  return c;
+  c->t = t;
+  c->impl = impl;
+  *out = c;
+  return 0;
 }
 
 void mfuoco_comm_unique_id(uint8_t id[MFUOCO_UNIQUE_ID_BYTES])
@@ -127,132 +172,44 @@ void mfuoco_comm_unique_id(uint8_t id[MFUOCO_UNIQUE_ID_BYTES])
 
 int mfuoco_comm_create_from_id(mfuoco_comm **out, int rank, int world, int device, const uint8_t id[MFUOCO_UNIQUE_ID_BYTES])
 {
-  mfuoco_comm *c = comm_new(KIND_RCCL, rank, world, device);
-  if (!c) return -1;
-  ncclUniqueId u;
-  memcpy(u.internal, id, MFUOCO_UNIQUE_ID_BYTES);
-  ncclResult_t r = ncclCommInitRank(&c->nccl, world, u, rank);
-  if (r != ncclSuccess) {
-    fprintf(stderr, "libmfuoco_gpu_dist: ncclCommInitRank(rank %d of %d): %s\n", rank, world, ncclGetErrorString(r));
-    free(c);
+  if (world < 1 || world > MAXW || rank < 0 || rank >= world) {
+    fprintf(stderr, "libmfuoco_gpu_dist: bad rank %d / world %d (at most %d ranks)\n", rank, world, MAXW);
     return -1;
   }
-  *out = c;
+  if (bind_device(device)) return -1;
+  ncclUniqueId u;
+  memcpy(u.internal, id, MFUOCO_UNIQUE_ID_BYTES);
+  ncclComm_t nc;
+  ncclResult_t r = ncclCommInitRank(&nc, world, u, rank);
+  if (r != ncclSuccess) {
+    fprintf(stderr, "libmfuoco_gpu_dist: ncclCommInitRank(rank %d of %d): %s\n", rank, world, ncclGetErrorString(r));
+    return -1;
+  }
+  if (mfuoco_comm_create_transport(out, rank, world, device, &rccl_transport, nc)) {
+    ncclCommDestroy(nc);
+    return -1;
+  }
   return 0;
 }
 
 int mfuoco_comm_create(mfuoco_comm **out, int rank, int world, int device, const char *id_file)
 {
+  if (!out || !id_file || world < 1 || world > MAXW || rank < 0 || rank >= world) {
+    fprintf(stderr, "libmfuoco_gpu_dist: bad arguments (rank %d, world %d, at most %d ranks)\n", rank, world, MAXW);
+    return -1;
+  }
+  if (bind_device(device)) return -1;
   uint8_t id[MFUOCO_UNIQUE_ID_BYTES];
-  if (hipSetDevice(device) != hipSuccess) {
-    fprintf(stderr, "libmfuoco_gpu_dist: no HIP device %d\n", device);
-    return -1;
+  memset(id, 0, sizeof id);
+  if (rank == 0) mfuoco_comm_unique_id(id);
+  if (world > 1) {
+    const char *te = getenv("MFUOCO_RENDEZVOUS_S");
+    if (mfuoco_rendezvous_files(rank, world, id_file, id, te && atof(te) > 0 ? atof(te) : 120.0)) return -1;
   }
-  if (rank == 0) {
-    mfuoco_comm_unique_id(id);
-    char tmp[4096];
-    snprintf(tmp, sizeof tmp, "%s.tmp.%ld", id_file, (long)getpid());
-    FILE *f = fopen(tmp, "wb");
-    if (!f || fwrite(id, 1, sizeof id, f) != sizeof id || fclose(f) || rename(tmp, id_file)) {
-      fprintf(stderr, "libmfuoco_gpu_dist: cannot publish the communicator id in %s: %s\n", id_file, strerror(errno));
-      return -1;
-    }
-  } else {
-    size_t got = 0;
-    for (int tries = 0; tries < 2400 && got != sizeof id; tries++) { /* 120 s */
-      FILE *f = fopen(id_file, "rb");
-      if (f) {
-        got = fread(id, 1, sizeof id, f);
-        fclose(f);
-      }
-      if (got != sizeof id) usleep(50000);
-    }
-    if (got != sizeof id) {
-      fprintf(stderr, "libmfuoco_gpu_dist: rank %d: no communicator id in %s after 120 s\n", rank, id_file);
-      return -1;
-    }
-  }
-  return mfuoco_comm_create_from_id(out, rank, world, device, id);
-}
-
-static double now_s(void)
-{
-  struct timespec ts;
-  clock_gettime(CLOCK_MONOTONIC, &ts);
-  return ts.tv_sec + ts.tv_nsec * 1e-9;
-}
-
-static void shm_barrier(mfuoco_comm *c)
-{
-  struct shm_hdr *h = c->shm;
-  uint32_t gen = atomic_load(&h->generation);
-  if (atomic_fetch_add(&h->arrived, 1) + 1 == (uint32_t)c->world) {
-    atomic_store(&h->arrived, 0);
-    atomic_fetch_add(&h->generation, 1);
-    return;
-  }
-  double t0 = now_s();
-  while (atomic_load(&h->generation) == gen) {
-    usleep(20);
-    if (now_s() - t0 > 300.0) dist_die("rehearsal barrier", "a rank did not arrive within 300 s");
-  }
-}
-
-int mfuoco_comm_create_rehearsal(mfuoco_comm **out, int rank, int world, int device, const char *shm_name)
-{
-  mfuoco_comm *c = comm_new(KIND_SHM, rank, world, device);
-  if (!c) return -1;
-  snprintf(c->shm_name, sizeof c->shm_name, "/%s", shm_name[0] == '/' ? shm_name + 1 : shm_name);
-  const char *mb = getenv("MFUOCO_REHEARSAL_SLOT_MB");
-  size_t slot = (size_t)(mb ? atol(mb) : 256) << 20;
-  c->shm_total = sizeof(struct shm_hdr) + (size_t)world * slot;
-  int fd = -1;
-  if (rank == 0) {
-    shm_unlink(c->shm_name);
-    fd = shm_open(c->shm_name, O_CREAT | O_EXCL | O_RDWR, 0600);
-    if (fd < 0 || ftruncate(fd, (off_t)c->shm_total)) {
-      fprintf(stderr, "libmfuoco_gpu_dist: shm_open(%s): %s\n", c->shm_name, strerror(errno));
-      free(c);
-      return -1;
-    }
-  } else {
-    struct stat st;
-    for (int tries = 0; tries < 2400; tries++) {
-      fd = shm_open(c->shm_name, O_RDWR, 0600);
-      if (fd >= 0 && !fstat(fd, &st) && (size_t)st.st_size == c->shm_total) break;
-      if (fd >= 0) close(fd);
-      fd = -1;
-      usleep(50000);
-    }
-    if (fd < 0) {
-      fprintf(stderr, "libmfuoco_gpu_dist: rank %d: segment %s did not appear\n", rank, c->shm_name);
-      free(c);
-      return -1;
-    }
-  }
-  c->shm = mmap(NULL, c->shm_total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-  close(fd);
-  if (c->shm == MAP_FAILED) {
-    fprintf(stderr, "libmfuoco_gpu_dist: mmap(%s): %s\n", c->shm_name, strerror(errno));
-    free(c);
-    return -1;
-  }
-  if (rank == 0) {
-    c->shm->world = (uint32_t)world;
-    c->shm->slot_bytes = slot;
-    atomic_store(&c->shm->ready, 1);
-  } else {
-    double t0 = now_s();
-    while (!atomic_load(&c->shm->ready)) {
-      usleep(100);
-      if (now_s() - t0 > 120.0) dist_die("rehearsal segment", "rank 0 never initialised it");
-    }
-    if (c->shm->world != (uint32_t)world) dist_die("rehearsal segment", "world size differs from rank 0's");
-  }
-  shm_barrier(c);
-  if (rank == 0) shm_unlink(c->shm_name); /* every rank has mapped it: the name can go now, so that a rank that dies later leaks nothing in /dev/shm */
-  *out = c;
-  return 0;
+  int rc = mfuoco_comm_create_from_id(out, rank, world, device, id);
+  /* every rank is through ncclCommInitRank now (it returns when all have joined): the files have done their work */
+  if (world > 1) mfuoco_rendezvous_cleanup(rank, id_file);
+  return rc;
 }
 
 void mfuoco_comm_destroy(mfuoco_comm *c)
@@ -261,33 +218,19 @@ void mfuoco_comm_destroy(mfuoco_comm *c)
   hipDeviceSynchronize();
   for (int i = 0; i < 8; i++)
     if (c->buf[i]) hipFree(c->buf[i]);
-  if (c->kind == KIND_RCCL) ncclCommDestroy(c->nccl);
-  if (c->kind == KIND_SHM) {
-    shm_barrier(c);
-    munmap(c->shm, c->shm_total);
-  }
+  if (c->t && c->t->destroy) c->t->destroy(c->impl);
   free(c);
 }
 
 int mfuoco_comm_rank(const mfuoco_comm *c) { return c ? c->rank : 0; }
 int mfuoco_comm_world(const mfuoco_comm *c) { return c ? c->world : 1; }
-const char *mfuoco_comm_backend(const mfuoco_comm *c)
-{
-  return !c ? "none" : c->kind == KIND_RCCL ? "rccl" : "rehearsal (host shared memory)";
-}
+const char *mfuoco_comm_backend(const mfuoco_comm *c) { return c && c->t ? c->t->name : "none"; }
 void mfuoco_comm_stats(const mfuoco_comm *c, uint64_t calls[4], uint64_t bytes[4])
 {
   for (int i = 0; i < 4; i++) {
     calls[i] = c ? c->calls[i] : 0;
     bytes[i] = c ? c->bytes[i] : 0;
   }
-}
-
-static uint8_t *mailbox(mfuoco_comm *c, int r) { return (uint8_t *)c->shm + sizeof(struct shm_hdr) + (size_t)r * c->shm->slot_bytes; }
-static void mailbox_put(mfuoco_comm *c, const void *d_src, size_t bytes)
-{
-  if (bytes > c->shm->slot_bytes) dist_die("rehearsal mailbox too small", "raise MFUOCO_REHEARSAL_SLOT_MB");
-  if (bytes) HK(hipMemcpy(mailbox(c, c->rank), d_src, bytes, hipMemcpyDeviceToHost));
 }
 
 /* ---- collectives (device buffers; counts in elements) ---------------------------------------------------------------------- */
@@ -299,90 +242,33 @@ static void comm_alltoallv_u32(mfuoco_comm *c, const uint32_t *d_send, const siz
   for (int q = 0; q < c->world; q++) total += scnt[q];
   c->calls[ST_A2A]++;
   c->bytes[ST_A2A] += total * 4;
-  if (c->kind == KIND_RCCL) {
-    NK(ncclGroupStart());
-    for (int q = 0; q < c->world; q++) {
-      if (scnt[q]) NK(ncclSend(d_send + sdsp[q], scnt[q], ncclUint32, q, c->nccl, NULL));
-      if (rcnt[q]) NK(ncclRecv(d_recv + rdsp[q], rcnt[q], ncclUint32, q, c->nccl, NULL));
-    }
-    NK(ncclGroupEnd());
-    return;
-  }
-  size_t end = 0;
-  for (int q = 0; q < c->world; q++) {
-    c->shm->disp[c->rank][q] = sdsp[q] * 4;
-    c->shm->cnt[c->rank][q] = scnt[q] * 4;
-    if (sdsp[q] + scnt[q] > end) end = sdsp[q] + scnt[q];
-  }
-  mailbox_put(c, d_send, end * 4);
-  shm_barrier(c);
-  for (int q = 0; q < c->world; q++) {
-    if (c->shm->cnt[q][c->rank] != rcnt[q] * 4) dist_die("rehearsal all-to-all", "send and receive counts disagree");
-    if (rcnt[q]) HK(hipMemcpy(d_recv + rdsp[q], mailbox(c, q) + c->shm->disp[q][c->rank], rcnt[q] * 4, hipMemcpyHostToDevice));
-  }
-  shm_barrier(c);
+  c->t->alltoallv_u32(c->impl, c->rank, c->world, d_send, scnt, sdsp, d_recv, rcnt, rdsp);
 }
-
 /* d_recv[0 .. n) = sum over ranks of their d_send[rank * n .. (rank + 1) * n)   (uint64 lanes, wrap-around sum) */
 static void comm_reduce_scatter_u64(mfuoco_comm *c, const uint64_t *d_send, uint64_t *d_recv, size_t n)
 {
   c->calls[ST_RS]++;
   c->bytes[ST_RS] += n * c->world * 8;
-  if (c->kind == KIND_RCCL) {
-    NK(ncclReduceScatter(d_send, d_recv, n, ncclUint64, ncclSum, c->nccl, NULL));
-    return;
-  }
-  mailbox_put(c, d_send, n * c->world * 8);
-  shm_barrier(c);
-  uint64_t *acc = calloc(n ? n : 1, 8);
-  for (int q = 0; q < c->world; q++) {
-    const uint64_t *src = (const uint64_t *)mailbox(c, q) + (size_t)c->rank * n;
-    for (size_t i = 0; i < n; i++) acc[i] += src[i];
-  }
-  if (n) HK(hipMemcpy(d_recv, acc, n * 8, hipMemcpyHostToDevice));
-  free(acc);
-  shm_barrier(c);
+  c->t->reduce_scatter_u64(c->impl, c->rank, c->world, d_send, d_recv, n);
 }
-
 static void comm_allreduce_u64(mfuoco_comm *c, uint64_t *d_buf, size_t n)
 {
   c->calls[ST_AR]++;
   c->bytes[ST_AR] += n * 8;
-  if (c->kind == KIND_RCCL) {
-    NK(ncclAllReduce(d_buf, d_buf, n, ncclUint64, ncclSum, c->nccl, NULL));
-    return;
-  }
-  mailbox_put(c, d_buf, n * 8);
-  shm_barrier(c);
-  uint64_t *acc = calloc(n ? n : 1, 8);
-  for (int q = 0; q < c->world; q++) {
-    const uint64_t *src = (const uint64_t *)mailbox(c, q);
-    for (size_t i = 0; i < n; i++) acc[i] += src[i];
-  }
-  if (n) HK(hipMemcpy(d_buf, acc, n * 8, hipMemcpyHostToDevice));
-  free(acc);
-  shm_barrier(c);
+  c->t->allreduce_u64(c->impl, c->rank, c->world, d_buf, n);
 }
-
 static void comm_bcast_bytes(mfuoco_comm *c, uint8_t *d_buf, size_t n, int root)
 {
   c->calls[ST_BC]++;
   c->bytes[ST_BC] += n;
-  if (c->kind == KIND_RCCL) {
-    NK(ncclBroadcast(d_buf, d_buf, n, ncclUint8, root, c->nccl, NULL));
-    return;
-  }
-  if (c->rank == root) mailbox_put(c, d_buf, n);
-  shm_barrier(c);
-  if (c->rank != root) HK(hipMemcpy(d_buf, mailbox(c, root), n, hipMemcpyHostToDevice));
-  shm_barrier(c);
+  c->t->bcast_bytes(c->impl, c->rank, c->world, d_buf, n, root);
 }
 
 /* ---- the row-sharded batch prover ------------------------------------------------------------------------------------------- */
 void mfuoco_prover_batch_sharded(proof_t *pis, crs_t crs, ssp_t ssp, mpz_t *witnesses, size_t count, mfuoco_comm *comm, size_t *own_first,
                                  size_t *own_count)
 {
-  mfuoco_comm local = { .kind = KIND_NONE, .rank = 0, .world = 1 };
+  mfuoco_comm local = { .rank = 0, .world = 1 };
   mfuoco_comm *c = comm ? comm : &local;
   const int rank = c->rank, world = c->world;
   const size_t nb = count, d = GAMMA_D;
@@ -397,8 +283,10 @@ void mfuoco_prover_batch_sharded(proof_t *pis, crs_t crs, ssp_t ssp, mpz_t *witn
   const size_t lo = row_lo(d, rank, world), cs = row_lo(d, rank + 1, world) - lo;
 
   /* host inputs: the bit strings of ALL statements (they select the rank's BT+BV rows), entropy of the OWN statements */
-  uint8_t *bits = calloc(nb, stride), *mag = malloc((nown ? nown : 1) * 5 * MAGLEN), *sign = malloc((nown ? nown : 1) * 5);
-  uint32_t *delta = malloc((nown ? nown : 1) * 4);
+  if (world > 1 && !c->t) dist_die("mfuoco_prover_batch_sharded", "more than one rank needs a communicator with a transport");
+  uint8_t *bits = xmalloc(nb * stride), *mag = xmalloc((nown ? nown : 1) * 5 * MAGLEN), *sign = xmalloc((nown ? nown : 1) * 5);
+  uint32_t *delta = xmalloc((nown ? nown : 1) * 4);
+  memset(bits, 0, nb * stride);
   for (size_t k = 0; k < nb; k++) mfuoco_gpu_witness_bits(bits + k * stride, witnesses[k]);
   for (size_t k = 0; k < nown; k++) mfuoco_gpu_prover_entropy(delta + k, mag + k * 5 * MAGLEN, sign + k * 5);
 
@@ -423,19 +311,20 @@ void mfuoco_prover_batch_sharded(proof_t *pis, crs_t crs, ssp_t ssp, mpz_t *witn
     rdsp[q] = fq * 3 * cs;
     rcnt[q] = nq * 3 * cs;
   }
-  if (world > 1 || c->kind != KIND_NONE) comm_alltoallv_u32(c, send, scnt, sdsp, recv, rcnt, rdsp);
+  if (c->t) comm_alltoallv_u32(c, send, scnt, sdsp, recv, rcnt, rdsp);
   else HK(hipMemcpyAsync(recv, send, scnt[0] * 4, hipMemcpyDeviceToDevice, NULL));
 
   /* 3. the rank's row shares of the five ciphertexts of every statement (matrix cores; no delta ct_t term, un-smudged) */
   uint64_t *partial = scratch(c, 3, nb * 5 * CTL * 8);
+  if (nb > 31) mfuoco_gpu_image_resident_share(d_crs, (uint32_t)rank, (uint32_t)world); /* the rank's share of the image, kept across calls while the CRS is the same */
   CK(mfh_prove_batch_partial(ctx, d_crs, (uint32_t)rank, (uint32_t)world, (uint32_t)nb, bits, stride, recv, recv + cs, recv + 2 * cs, 3 * cs, partial));
 
-  /* 4. one uint64 lane per surviving 32-bit word, statements padded to `world` equal slabs; ONE reduce-scatter: the own slab, summed */
+  /* 4. the partial ciphertexts as uint64 lanes of 56 bits, statements padded to `world` equal slabs; ONE reduce-scatter: the own slab, summed */
   const size_t lps = 5 * LANES_PER_CT;
   uint64_t *lanes = scratch(c, 4, per * world * lps * 8), *own = scratch(c, 5, per * lps * 8);
   if (per * world > nb) HK(hipMemsetAsync(lanes + nb * lps, 0, (per * world - nb) * lps * 8, NULL));
   CK(mfh_ct_to_lanes(ctx, partial, nb * 5, lanes));
-  if (world > 1 || c->kind != KIND_NONE) comm_reduce_scatter_u64(c, lanes, own, per * lps);
+  if (c->t) comm_reduce_scatter_u64(c, lanes, own, per * lps);
   else HK(hipMemcpyAsync(own, lanes, per * lps * 8, hipMemcpyDeviceToDevice, NULL));
 
   /* 5. carries + modq, then b_w += delta ct_t and the smudging of the own statements (src/snark.c:143-145,185-189) */
@@ -449,13 +338,16 @@ void mfuoco_prover_batch_sharded(proof_t *pis, crs_t crs, ssp_t ssp, mpz_t *witn
   if (c == &local)
     for (int i = 0; i < 8; i++)
       if (local.buf[i]) hipFree(local.buf[i]);
+  explicit_bzero(mag, (nown ? nown : 1) * 5 * MAGLEN); /* smudging terms and deltas are the proofs' zero-knowledge: not left on the heap */
+  explicit_bzero(sign, (nown ? nown : 1) * 5);
+  explicit_bzero(delta, (nown ? nown : 1) * 4);
   free(bits); free(mag); free(sign); free(delta);
 }
 
 /* ---- one proof, rows sharded (dist.py: prove_sharded) ------------------------------------------------------------------------ */
 void mfuoco_prover_sharded(proof_t pi, crs_t crs, ssp_t ssp, mpz_t witness, mfuoco_comm *comm)
 {
-  mfuoco_comm local = { .kind = KIND_NONE, .rank = 0, .world = 1 };
+  mfuoco_comm local = { .rank = 0, .world = 1 };
   mfuoco_comm *c = comm ? comm : &local;
   mfh_ctx *ctx = mfuoco_gpu_ctx();
   const uint8_t *d_crs = mfuoco_gpu_stage_crs(crs);
@@ -466,7 +358,7 @@ void mfuoco_prover_sharded(proof_t pi, crs_t crs, ssp_t ssp, mpz_t witness, mfuo
   struct { uint32_t delta; uint8_t mag[5 * MAGLEN], sign[5]; } ent;
   memset(&ent, 0, sizeof ent);
   if (c->rank == 0) mfuoco_gpu_prover_entropy(&ent.delta, ent.mag, ent.sign);
-  if (c->kind != KIND_NONE) {
+  if (c->t) {
     uint8_t *d_ent = scratch(c, 0, sizeof ent);
     HK(hipMemcpy(d_ent, &ent, sizeof ent, hipMemcpyHostToDevice));
     comm_bcast_bytes(c, d_ent, sizeof ent, 0);
@@ -475,12 +367,13 @@ void mfuoco_prover_sharded(proof_t pi, crs_t crs, ssp_t ssp, mpz_t witness, mfuo
   uint64_t *wl = scratch(c, 1, (size_t)GAMMA_D * 8), *partial = scratch(c, 2, 5 * CTL * 8), *lanes = scratch(c, 3, 5 * LANES_PER_CT * 8),
            *proof = scratch(c, 4, 5 * CTL * 8);
   CK(mfh_witness_lanes(ctx, d_ssp, bits, (uint32_t)c->rank, (uint32_t)c->world, wl));
-  if (c->kind != KIND_NONE) comm_allreduce_u64(c, wl, GAMMA_D);
+  if (c->t) comm_allreduce_u64(c, wl, GAMMA_D);
   CK(mfh_prove_partial_w(ctx, d_crs, d_ssp, bits, ent.delta, (uint32_t)c->rank, (uint32_t)c->world, wl, partial));
   CK(mfh_ct_to_lanes(ctx, partial, 5, lanes));
-  if (c->kind != KIND_NONE) comm_allreduce_u64(c, lanes, 5 * LANES_PER_CT);
+  if (c->t) comm_allreduce_u64(c, lanes, 5 * LANES_PER_CT);
   CK(mfh_ct_from_lanes(ctx, lanes, 5, proof));
   CK(mfh_prove_finish(ctx, proof, ent.mag, MAGLEN, ent.sign));
+  explicit_bzero(&ent, sizeof ent);
   proof_t *one = (proof_t *)pi;
   mfuoco_gpu_proofs_to_host(one, proof, 1);
   if (c == &local)

@@ -11,6 +11,7 @@
  * reference does.
  */
 #define _GNU_SOURCE
+#include <errno.h>
 #include <stdbool.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -29,10 +30,7 @@
 #define L_LIMBS 12
 #define K_LIMBS 11
 #define CTL ((size_t)(GAMMA_N + 1) * L_LIMBS)
-#define CTR_CT ((uint64_t)CT_BYTES * GAMMA_N)
-#define CTR_S 0ULL
-#define CTR_AS (CTR_CT * GAMMA_D)
-#define CTR_BT (2 * CTR_CT * GAMMA_D)
+/* (CTR_CT, CTR_S, CTR_AS, CTR_BT come from the header, as in src/snark.h:8-12: CT_BYTES is 92UL, so they are 64-bit values) */
 
 static struct {
   mfh_ctx *ctx;
@@ -49,7 +47,24 @@ static struct {
   const void *ssp_host; /* host pointer the resident SSP was uploaded from */
   uint8_t *d_crs;     /* (2D+M) * CT_BYTES */
   uint64_t *d_err;
-} G = { .device = -1 };
+  /* the expanded CRS kept across prover calls (mfuoco_gpu_set_resident_crs): the matrix-core image of (seed, compressed CRS) */
+  int resident_crs;     /* -1 = not decided yet ($MFUOCO_GPU_RESIDENT_CRS, default on), 0 / 1 */
+  uint8_t *d_img;
+  size_t img_bytes;
+  bool img_valid, img_registered;
+  uint32_t img_rank, img_world;
+  uint8_t img_seed[40];
+  uint64_t img_digest[2];
+  /* ... and the single-proof form (mfh_crs_expand: limb planes, streamed by k_mac_resident), kept from the second prover() under one CRS on */
+  void *d_rows;
+  size_t rows_bytes;
+  bool rows_valid;
+  uint8_t rows_seed[40], seen_seed[40];
+  uint64_t rows_digest[2], seen_digest[2];
+  bool seen;
+  uint64_t staged_digest[2]; /* of the compressed CRS as last staged (mfuoco_gpu_stage_crs) */
+  bool staged_digest_valid;
+} G = { .device = -1, .resident_crs = -1 };
 
 static void die(const char *what)
 {
@@ -59,8 +74,72 @@ static void die(const char *what)
 #define CK(call) do { if ((call) != MFH_OK) die(#call); } while (0)
 #define HK(call) do { if ((call) != hipSuccess) die(#call); } while (0)
 
-void mfuoco_gpu_set_device(int device) { G.device = device; }
-void mfuoco_gpu_invalidate(void) { G.ssp_host = NULL; }
+static void *xmalloc(size_t bytes)
+{
+  void *p = malloc(bytes ? bytes : 1);
+  if (!p) die("out of host memory");
+  return p;
+}
+static void *xcalloc(size_t n, size_t size)
+{
+  void *p = calloc(n ? n : 1, size ? size : 1);
+  if (!p) die("out of host memory");
+  return p;
+}
+/* OS entropy where the reference calls getrandom(2) (src/entropy.h, src/snark.c:40,62-65,140,185-189): EINTR and short reads are retried, the pool not
+ * being initialised yet is waited for, and any other failure ends the process -- a buffer left undrawn would silently cost zero-knowledge */
+static void shim_random(void *buf, size_t bytes)
+{
+  uint8_t *p = buf;
+  while (bytes) {
+    ssize_t got = getrandom(p, bytes, 0);
+    if (got < 0) {
+      if (errno == EINTR || errno == EAGAIN) continue;
+      perror("getrandom");
+      die("no OS entropy");
+    }
+    p += got;
+    bytes -= (size_t)got;
+  }
+}
+
+int mfuoco_gpu_set_device(int device)
+{
+  if (G.ctx && G.device != device) {
+    fprintf(stderr, "libmfuoco_gpu: the shim already runs on GPU %d; mfuoco_gpu_set_device(%d) must precede the first call\n", G.device, device);
+    return -1;
+  }
+  G.device = device;
+  return 0;
+}
+int mfuoco_gpu_device(void) { return G.ctx ? G.device : -1; }
+static void drop_image(void)
+{
+  if (G.ctx && G.img_registered) {
+    mfh_crs_set_resident_mm(G.ctx, NULL);
+    G.img_registered = false;
+  }
+  G.img_valid = false;
+  G.rows_valid = false;
+  G.seen = false;
+}
+void mfuoco_gpu_invalidate(void)
+{
+  G.ssp_host = NULL;
+  drop_image();
+}
+void mfuoco_gpu_set_resident_crs(int on)
+{
+  G.resident_crs = on ? 1 : 0;
+  if (!on) {
+    drop_image();
+    if (G.d_img) hipFree(G.d_img);
+    if (G.d_rows) hipFree(G.d_rows);
+    G.d_img = NULL;
+    G.d_rows = NULL;
+    G.img_bytes = G.rows_bytes = 0;
+  }
+}
 
 static mfh_ctx *gpu(void)
 {
@@ -195,7 +274,7 @@ void mpz2_urandomb2(mpz_ptr rop, size_t nbits)
 {
   size_t limbs = (nbits + 63) / 64, bytes = nbits / 8;
   uint64_t *buf = calloc(limbs ? limbs : 1, 8);
-  if (getrandom(buf, bytes, GRND_NONBLOCK) < 0) perror("getrandom");
+  shim_random(buf, bytes);
   if (limbs) buf[limbs - 1] &= ~0ULL >> (limbs * 64 - nbits);
   mpz_import(rop, limbs, -1, 8, 0, 0, buf);
   free(buf);
@@ -248,7 +327,7 @@ void regev_encrypt2(ct_t c, rng_t rs, sk_t sk, mpz_t m, void (*chi)(mpz_t))
   mpz_init(e);
   (*chi)(e);
   uint8_t sign;
-  if (getrandom(&sign, 1, GRND_NONBLOCK) < 0) perror("getrandom"); /* the reference burns one byte here (src/lwe.c:87) */
+  shim_random(&sign, 1); /* the reference burns one byte here (src/lwe.c:87) */
   uint64_t eh[L_LIMBS];
   to_limbs(eh, e);
   mpz_clear(e);
@@ -302,7 +381,8 @@ void ct_smudge(ct_t ct)
 {
   gpu();
   uint8_t mag[GAMMA_LOG_SMUDGING / 8], sign;
-  if (getrandom(mag, sizeof mag, GRND_NONBLOCK) < 0 || getrandom(&sign, 1, GRND_NONBLOCK) < 0) perror("getrandom");
+  shim_random(mag, sizeof mag);
+  shim_random(&sign, 1);
   ct_to_dev(G.d_ct[0], ct, GAMMA_N + 1);
   CK(mfh_ct_smudge(G.ctx, G.d_ct[0], 1, mag, sizeof mag, &sign));
   ct_from_dev(ct + GAMMA_N, G.d_ct[0] + (size_t)GAMMA_N * L_LIMBS, 1);
@@ -373,7 +453,7 @@ void random_ssp(mpz_t input, uint8_t *circuit)
   uint64_t *t = calloc(GAMMA_D, 8), *out;
   mpz2_urandomb2(input, GAMMA_M);
   for (size_t i = 0; i < GAMMA_M; i++) {
-    if (getrandom(buf, buflen, GRND_NONBLOCK) < 0) perror("getrandom");
+    shim_random(buf, buflen);
     out = (uint64_t *)(circuit + 8 * GAMMA_D * (i + 1));
     int take = i == 0 || mpz_tstbit(input, i - 1);
     for (size_t k = 0; k < GAMMA_D; k++) {
@@ -393,7 +473,7 @@ void proof_init(proof_t pi) { ct_init(pi->h); ct_init(pi->hat_h); ct_init(pi->ha
 void proof_clear(proof_t pi) { ct_clear(pi->h); ct_clear(pi->hat_h); ct_clear(pi->hat_v); ct_clear(pi->v_w); ct_clear(pi->b_w); }
 void crs_init(crs_t crs)
 {
-  if (getrandom(crs->seed, sizeof(rseed_t), GRND_NONBLOCK) < 0) perror("getrandom");
+  shim_random(crs->seed, sizeof(rseed_t));
   crs->s = malloc(CT_BYTES * GAMMA_D);
   crs->as = malloc(CT_BYTES * GAMMA_D);
   crs->v = malloc(CT_BYTES * GAMMA_M);
@@ -405,7 +485,7 @@ void crs_clear(crs_t crs) { free(crs->s); free(crs->as); free(crs->v); free(crs-
 static uint64_t rand_modp_(void)
 {
   uint64_t r;
-  if (getrandom(&r, 8, GRND_NONBLOCK) < 0) perror("getrandom");
+  shim_random(&r, 8);
   return r % GAMMA_P;
 }
 
@@ -431,7 +511,8 @@ void setup(crs_t crs, vrs_t vrs, ssp_t ssp)
   uint64_t *err = calloc(rows * L_LIMBS, 8);
   for (size_t i = 0; i < rows; i++) {
     uint8_t sign;
-    if (getrandom(err + i * L_LIMBS, (GAMMA_LOG_SIGMA + 3) / 8, GRND_NONBLOCK) < 0 || getrandom(&sign, 1, GRND_NONBLOCK) < 0) perror("getrandom");
+    shim_random(err + i * L_LIMBS, (GAMMA_LOG_SIGMA + 3) / 8);
+    shim_random(&sign, 1);
   }
   if (!G.d_err) HK(hipMalloc((void **)&G.d_err, rows * L_LIMBS * 8));
   HK(hipMemcpy(G.d_err, err, rows * L_LIMBS * 8, hipMemcpyHostToDevice));
@@ -439,6 +520,8 @@ void setup(crs_t crs, vrs_t vrs, ssp_t ssp)
   ct_to_dev(G.d_sk, vrs->sk, GAMMA_N);
   G.ssp_host = NULL;
   ssp_resident(ssp);
+  drop_image(); /* G.d_crs is about to be rewritten */
+  G.staged_digest_valid = false;
   CK(mfh_setup(G.ctx, G.d_ssp, (uint32_t)vrs->alpha, (uint32_t)vrs->beta, (uint32_t)vrs->s, G.d_sk, G.d_err, G.d_crs));
   HK(hipMemcpy(crs->s, G.d_crs, CT_BYTES * GAMMA_D, hipMemcpyDeviceToHost));
   HK(hipMemcpy(crs->as, G.d_crs + CT_BYTES * GAMMA_D, CT_BYTES * GAMMA_D, hipMemcpyDeviceToHost));
@@ -458,6 +541,17 @@ const uint8_t *mfuoco_gpu_stage_crs(crs_t crs)
   HK(hipMemcpy(G.d_crs + CT_BYTES * GAMMA_D, crs->as, CT_BYTES * GAMMA_D, hipMemcpyHostToDevice));
   HK(hipMemcpy(G.d_crs + 2 * CT_BYTES * GAMMA_D, crs->t, CT_BYTES, hipMemcpyHostToDevice));
   HK(hipMemcpy(G.d_crs + (2 * GAMMA_D + 1) * CT_BYTES, crs->v, CT_BYTES * (GAMMA_M - 1), hipMemcpyHostToDevice));
+  /* an image kept from an earlier call serves this CRS only if seed and bytes are the same: checked on EVERY staging, whatever the caller does next */
+  G.staged_digest_valid = false;
+  if (G.resident_crs != 0) {
+    CK(mfh_digest128(G.ctx, G.d_crs, (2 * (size_t)GAMMA_D + GAMMA_M) * CT_BYTES, G.staged_digest));
+    G.staged_digest_valid = true;
+    if (G.img_valid && (memcmp(G.img_seed, G.seed, 40) || G.staged_digest[0] != G.img_digest[0] || G.staged_digest[1] != G.img_digest[1])) {
+      if (G.img_registered) CK(mfh_crs_set_resident_mm(G.ctx, NULL));
+      G.img_registered = G.img_valid = false;
+    }
+    if (G.rows_valid && (memcmp(G.rows_seed, G.seed, 40) || G.staged_digest[0] != G.rows_digest[0] || G.staged_digest[1] != G.rows_digest[1])) G.rows_valid = false;
+  }
   return G.d_crs;
 }
 
@@ -482,8 +576,10 @@ void mfuoco_gpu_prover_entropy(uint32_t *delta, uint8_t *mag, uint8_t *sign)
 {
   const size_t maglen = GAMMA_LOG_SMUDGING / 8;
   *delta = (uint32_t)rand_modp_();
-  for (int q = 0; q < 5; q++)
-    if (getrandom(mag + q * maglen, maglen, GRND_NONBLOCK) < 0 || getrandom(sign + q, 1, GRND_NONBLOCK) < 0) perror("getrandom");
+  for (int q = 0; q < 5; q++) {
+    shim_random(mag + q * maglen, maglen);
+    shim_random(sign + q, 1);
+  }
 }
 
 /* count proofs (5 ciphertexts each, struct proof order) from device limbs into initialised proof_t's */
@@ -495,6 +591,101 @@ void mfuoco_gpu_proofs_to_host(proof_t *pis, const uint64_t *d_proofs, size_t co
   }
 }
 
+/* ---- the expanded CRS kept across prover calls (the materialised-CRS regime behind the reference's types) -------------------------------
+ * The reference's prover() regenerates every a-vector from the seed on every call (ct_import, src/lwe.c:122-126); a caller that proves many statements
+ * under one CRS (src/benchmark_snark.c:70-74 in a loop) would pay the AES expansion each time.  The shim therefore keeps what it expanded, keyed by the
+ * 40-byte seed and a 128-bit digest of the staged compressed CRS taken ON the device (mfh_digest128: 8 MB read at HBM speed, so a caller that rewrites
+ * crs->s/as/t/v in place is noticed without an extra API call; mfuoco_gpu_invalidate() drops everything explicitly).  Off: $MFUOCO_GPU_RESIDENT_CRS=0 or
+ * mfuoco_gpu_set_resident_crs(0).  An image that does not fit the free device memory is simply not kept. */
+static bool resident_on(void)
+{
+  if (G.resident_crs < 0) {
+    const char *e = getenv("MFUOCO_GPU_RESIDENT_CRS");
+    G.resident_crs = e && *e ? atoi(e) != 0 : 1;
+  }
+  return G.resident_crs == 1;
+}
+static bool fits_device(size_t need, size_t have)
+{
+  size_t fr = 0, tot = 0;
+  if (hipMemGetInfo(&fr, &tot) != hipSuccess) return false;
+  return need <= have || need - have + ((size_t)24 << 30) <= fr; /* leave room for the call's own scratch (w | h | v, partial products, the SSP's second image) */
+}
+/* matrix-core image (mfh_prove_batch / mfh_prove_batch_partial): rank's shares of `world`, the whole regions when world == 1 */
+static void image_resident_mm(const uint8_t *d_crs, uint32_t rank, uint32_t world)
+{
+  if (!resident_on() || d_crs != G.d_crs) return;
+  uint64_t dg[2];
+  if (!G.staged_digest_valid) {
+    CK(mfh_digest128(G.ctx, d_crs, (2 * (size_t)GAMMA_D + GAMMA_M) * CT_BYTES, G.staged_digest));
+    G.staged_digest_valid = true;
+  }
+  dg[0] = G.staged_digest[0];
+  dg[1] = G.staged_digest[1];
+  if (G.img_valid && G.img_rank == rank && G.img_world == world && !memcmp(G.img_seed, G.seed, 40) && dg[0] == G.img_digest[0] && dg[1] == G.img_digest[1]) {
+    if (!G.img_registered) {
+      CK(world == 1 ? mfh_crs_set_resident_mm(G.ctx, G.d_img) : mfh_crs_set_resident_mm_share(G.ctx, G.d_img, rank, world));
+      G.img_registered = true;
+    }
+    return;
+  }
+  if (G.img_registered) CK(mfh_crs_set_resident_mm(G.ctx, NULL));
+  G.img_registered = G.img_valid = false;
+  const size_t need = world == 1 ? mfh_crs_mm_image_bytes(G.ctx) : mfh_crs_mm_share_bytes(G.ctx, rank, world);
+  if (!fits_device(need, G.img_bytes)) return;
+  if (need > G.img_bytes) {
+    if (G.d_img) HK(hipFree(G.d_img));
+    G.d_img = NULL;
+    G.img_bytes = 0;
+    if (hipMalloc((void **)&G.d_img, need) != hipSuccess) { (void)hipGetLastError(); G.d_img = NULL; return; }
+    G.img_bytes = need;
+  }
+  CK(world == 1 ? mfh_crs_expand_mm(G.ctx, d_crs, G.d_img) : mfh_crs_expand_mm_share(G.ctx, d_crs, rank, world, G.d_img));
+  CK(world == 1 ? mfh_crs_set_resident_mm(G.ctx, G.d_img) : mfh_crs_set_resident_mm_share(G.ctx, G.d_img, rank, world));
+  G.img_valid = G.img_registered = true;
+  G.img_rank = rank;
+  G.img_world = world;
+  memcpy(G.img_seed, G.seed, 40);
+  G.img_digest[0] = dg[0];
+  G.img_digest[1] = dg[1];
+}
+void mfuoco_gpu_image_resident_share(const uint8_t *d_crs, uint32_t rank, uint32_t world) { image_resident_mm(d_crs, rank, world); }
+/* single-proof image (mfh_prove): expanded when prover() meets the same (seed, CRS) a second time; returns the image to register, or NULL */
+static const void *image_resident_rows(const uint8_t *d_crs)
+{
+  if (!resident_on() || d_crs != G.d_crs) return NULL;
+  uint64_t dg[2];
+  if (!G.staged_digest_valid) {
+    CK(mfh_digest128(G.ctx, d_crs, (2 * (size_t)GAMMA_D + GAMMA_M) * CT_BYTES, G.staged_digest));
+    G.staged_digest_valid = true;
+  }
+  dg[0] = G.staged_digest[0];
+  dg[1] = G.staged_digest[1];
+  if (G.rows_valid && !memcmp(G.rows_seed, G.seed, 40) && dg[0] == G.rows_digest[0] && dg[1] == G.rows_digest[1]) return G.d_rows;
+  G.rows_valid = false;
+  const bool again = G.seen && !memcmp(G.seen_seed, G.seed, 40) && dg[0] == G.seen_digest[0] && dg[1] == G.seen_digest[1];
+  G.seen = true;
+  memcpy(G.seen_seed, G.seed, 40);
+  G.seen_digest[0] = dg[0];
+  G.seen_digest[1] = dg[1];
+  if (!again) return NULL; /* first proof under this CRS: regenerate, as the reference does */
+  const size_t rows = 2 * (size_t)GAMMA_D + GAMMA_M, need = rows * mfh_resident_row_bytes(G.ctx);
+  if (!fits_device(need, G.rows_bytes)) return NULL;
+  if (need > G.rows_bytes) {
+    if (G.d_rows) HK(hipFree(G.d_rows));
+    G.d_rows = NULL;
+    G.rows_bytes = 0;
+    if (hipMalloc(&G.d_rows, need) != hipSuccess) { (void)hipGetLastError(); G.d_rows = NULL; return NULL; }
+    G.rows_bytes = need;
+  }
+  CK(mfh_crs_expand(G.ctx, 0, rows, d_crs, G.d_rows));
+  G.rows_valid = true;
+  memcpy(G.rows_seed, G.seed, 40);
+  G.rows_digest[0] = dg[0];
+  G.rows_digest[1] = dg[1];
+  return G.d_rows;
+}
+
 void prover(proof_t pi, crs_t crs, ssp_t ssp, mpz_t witness)
 {
   const uint8_t *d_crs = mfuoco_gpu_stage_crs(crs);
@@ -504,7 +695,13 @@ void prover(proof_t pi, crs_t crs, ssp_t ssp, mpz_t witness)
   uint32_t delta;
   uint8_t mag[5 * (GAMMA_LOG_SMUDGING / 8)], sign[5];
   mfuoco_gpu_prover_entropy(&delta, mag, sign);
-  CK(mfh_prove(G.ctx, d_crs, d_ssp, bits, delta, mag, GAMMA_LOG_SMUDGING / 8, sign, G.d_proof));
+  const void *rows = image_resident_rows(d_crs);
+  if (rows) CK(mfh_crs_set_resident(G.ctx, rows));
+  int rc = mfh_prove(G.ctx, d_crs, d_ssp, bits, delta, mag, GAMMA_LOG_SMUDGING / 8, sign, G.d_proof);
+  if (rows) CK(mfh_crs_set_resident(G.ctx, NULL)); /* (mfh_prove_batch must not find the single-proof image) */
+  explicit_bzero(mag, sizeof mag);
+  explicit_bzero(&delta, sizeof delta);
+  if (rc != MFH_OK) die("mfh_prove");
   proof_t *one = (proof_t *)pi; /* proof_t is struct proof[1]: pi is the address of the one element */
   mfuoco_gpu_proofs_to_host(one, G.d_proof, 1);
 }
@@ -518,18 +715,23 @@ void mfuoco_prover_batch(proof_t *pis, crs_t crs, ssp_t ssp, mpz_t *witnesses, s
   const uint8_t *d_crs = mfuoco_gpu_stage_crs(crs);
   const uint32_t *d_ssp = mfuoco_gpu_stage_ssp(ssp);
   const size_t stride = mfuoco_gpu_bits_stride(), maglen = GAMMA_LOG_SMUDGING / 8;
-  uint8_t *bits = calloc(count, stride), *mag = malloc(count * 5 * maglen), *sign = malloc(count * 5);
-  uint32_t *delta = malloc(count * 4);
+  uint8_t *bits = xcalloc(count, stride), *mag = xmalloc(count * 5 * maglen), *sign = xmalloc(count * 5);
+  uint32_t *delta = xmalloc(count * 4);
   uint64_t *d_out = NULL;
   HK(hipMalloc((void **)&d_out, count * 5 * CTL * 8));
   for (size_t k = 0; k < count; k++) {
     mfuoco_gpu_witness_bits(bits + k * stride, witnesses[k]);
     mfuoco_gpu_prover_entropy(delta + k, mag + k * 5 * maglen, sign + k * 5);
   }
-  CK(mfh_prove_batch(G.ctx, d_crs, d_ssp, (uint32_t)count, bits, stride, delta, mag, maglen, sign, d_out));
+  if (count > 31) image_resident_mm(d_crs, 0, 1); /* (smaller calls do not expand an image at all) */
+  int rc = mfh_prove_batch(G.ctx, d_crs, d_ssp, (uint32_t)count, bits, stride, delta, mag, maglen, sign, d_out);
+  explicit_bzero(mag, count * 5 * maglen); /* the smudging terms and deltas are the proofs' zero-knowledge: not left on the heap */
+  explicit_bzero(sign, count * 5);
+  explicit_bzero(delta, count * 4);
+  free(bits); free(mag); free(sign); free(delta);
+  if (rc != MFH_OK) die("mfh_prove_batch");
   mfuoco_gpu_proofs_to_host(pis, d_out, count);
   HK(hipFree(d_out));
-  free(bits); free(mag); free(sign); free(delta);
 }
 
 static uint64_t horner_modp(const uint8_t *slot, uint64_t x)
@@ -575,7 +777,7 @@ void mfuoco_verifier_batch(ssp_t ssp, vrs_t vrs, proof_t *pis, size_t count, uin
   gpu();
   ssp_resident(ssp);
   ct_to_dev(G.d_sk, vrs->sk, GAMMA_N);
-  uint64_t *d_proofs = NULL, *h = malloc(count * 5 * CTL * 8);
+  uint64_t *d_proofs = NULL, *h = xmalloc(count * 5 * CTL * 8);
   uint8_t *d_ok = NULL;
   HK(hipMalloc((void **)&d_proofs, count * 5 * CTL * 8));
   HK(hipMalloc((void **)&d_ok, count));
@@ -599,8 +801,8 @@ void mfuoco_decrypt_batch(mpz_t *ms, sk_t sk, ct_t *cts, size_t count)
   if (!count) return;
   gpu();
   ct_to_dev(G.d_sk, sk, GAMMA_N);
-  uint64_t *d_cts = NULL, *h = malloc(count * CTL * 8);
-  uint32_t *d_m = NULL, *hm = malloc(count * 4);
+  uint64_t *d_cts = NULL, *h = xmalloc(count * CTL * 8);
+  uint32_t *d_m = NULL, *hm = xmalloc(count * 4);
   HK(hipMalloc((void **)&d_cts, count * CTL * 8));
   HK(hipMalloc((void **)&d_m, count * 4));
   for (size_t k = 0; k < count; k++)

@@ -4,7 +4,8 @@
  * host/bench_snark_sharded (NDEBUG parameters: the measurement src/benchmark_snark.c:70-74 makes, for N GPUs, `label\tseconds` lines).
  *
  *   RANK, WORLD_SIZE, LOCAL_RANK       as a launcher (mpirun, torchrun, a shell loop) sets them; default 0 / 1 / 0
- *   MFUOCO_COMM_ID_FILE                file through which rank 0 publishes the ncclUniqueId (default /tmp/mfuoco_comm_id.$MASTER_PORT)
+ *   MFUOCO_COMM_ID_FILE                file through which rank 0 publishes the ncclUniqueId: REQUIRED with more than one rank on RCCL -- a path in the job's
+ *                                      own directory (mode 0700), never a shared /tmp (mfuoco_dist.h: mfuoco_comm_create)
  *   MFUOCO_REHEARSAL_SHM=name          rehearsal backend instead of RCCL (host shared memory; with MFUOCO_SHARE_GPU=1 all ranks use GPU 0)
  *   usage: test_sharded [statements]        bench_snark_sharded [statements] [calls]
  *
@@ -21,6 +22,7 @@
 #include <sys/types.h>
 
 #include "mfuoco/mfuoco_dist.h"
+#include "mfuoco_dist_rehearsal.h" /* test scaffolding compiled into this driver, not into libmfuoco_gpu_dist.so */
 
 /* ---- the tape: byte i = byte (i % 8) of mix(seed + i / 8) -------------------------------------------------------------------- */
 static uint64_t tape_pos;
@@ -83,12 +85,13 @@ int main(int argc, char **argv)
   int calls = argc > 2 ? atoi(argv[2]) : 3;
   mfuoco_comm *comm = NULL;
   const char *shm = getenv("MFUOCO_REHEARSAL_SHM");
-  char idfile[512];
-  if (getenv("MFUOCO_COMM_ID_FILE")) snprintf(idfile, sizeof idfile, "%s", getenv("MFUOCO_COMM_ID_FILE"));
-  else snprintf(idfile, sizeof idfile, "/tmp/mfuoco_comm_id.%d", env_int("MASTER_PORT", 0));
-  int rc = shm && *shm ? mfuoco_comm_create_rehearsal(&comm, rank, world, device, shm) : mfuoco_comm_create(&comm, rank, world, device, idfile);
-  if (rc) return 2;
-  if (rank == 0 && !(shm && *shm)) remove(idfile); /* every rank has read it once the communicator exists */
+  const char *idfile = getenv("MFUOCO_COMM_ID_FILE");
+  if (!(shm && *shm) && world > 1 && !(idfile && *idfile)) {
+    fprintf(stderr, "rank %d: set MFUOCO_COMM_ID_FILE to a path in a directory of this job's own (the ranks meet there)\n", rank);
+    return 2;
+  }
+  int rc = shm && *shm ? mfuoco_comm_create_rehearsal(&comm, rank, world, device, shm) : mfuoco_comm_create(&comm, rank, world, device, idfile ? idfile : "");
+  if (rc) return 2; /* (non-zero exit: a launcher then ends the other ranks; no retry in-process) */
 
   /* the same instance on every rank */
   tape_seek(0);

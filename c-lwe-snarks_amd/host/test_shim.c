@@ -15,8 +15,8 @@
 #include "mfuoco/mangiafuoco_api.h"
 
 #define CHECK(cond) do { if (!(cond)) { fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); exit(1); } } while (0)
-#define CTR_CT ((size_t)CT_BYTES * GAMMA_N)
-#define CTR_AS (CTR_CT * GAMMA_D)
+
+
 
 static uint64_t rnd_modp(void) { uint64_t r; getrandom(&r, 8, 0); return r % GAMMA_P; }
 
@@ -196,6 +196,35 @@ static void t_snark(void)
       mpz_clear(one);
     }
     for (int k = 0; k < 3; k++) { proof_clear(pb[k]); mpz_clear(wit[k]); }
+  }
+  { /* the expanded CRS kept across calls (mangiafuoco_api.h: mfuoco_gpu_set_resident_crs): 40 statements per call so that the call streams an image.
+     * Call 1 expands it, call 2 finds it (seed and device-side digest of the compressed CRS unchanged); then ONE BYTE of crs->s changes in place: the
+     * image no longer serves that CRS, call 3 must notice without being told -- its proofs are computed from the corrupted row and are REJECTED (from
+     * the stale image they would be accepted) --, and with the byte restored call 4 is accepted again.  The same for prover()'s single-proof image
+     * (regenerates, expands, streams, notices). */
+    enum { NB = 40 };
+    proof_t pb[NB];
+    mpz_t wit[NB];
+    for (int k = 0; k < NB; k++) { proof_init(pb[k]); mpz_init_set(wit[k], witness); }
+    for (int call = 1; call <= 4; call++) {
+      if (call == 3) crs->s[5][40] ^= 0x10;
+      if (call == 4) crs->s[5][40] ^= 0x10;
+      mfuoco_prover_batch(pb, crs, ssp, wit, NB);
+      uint8_t okb[NB];
+      mfuoco_verifier_batch(ssp, vrs, pb, NB, okb);
+      for (int k = 0; k < NB; k++) CHECK(okb[k] == (call == 3 ? 0 : 1));
+    }
+    for (int call = 1; call <= 5; call++) {
+      if (call == 4) crs->as[7][12] ^= 0x01;
+      if (call == 5) crs->as[7][12] ^= 0x01;
+      prover(pi, crs, ssp, witness);
+      CHECK(verifier(ssp, vrs, pi) == (call != 4));
+    }
+    mfuoco_gpu_set_resident_crs(0); /* off: images freed, every call regenerates as before */
+    mfuoco_prover_batch(pb, crs, ssp, wit, NB);
+    CHECK(verifier(ssp, vrs, pb[0]) && verifier(ssp, vrs, pb[NB - 1]));
+    mfuoco_gpu_set_resident_crs(1);
+    for (int k = 0; k < NB; k++) { proof_clear(pb[k]); mpz_clear(wit[k]); }
   }
   proof_clear(pi);
   crs_clear(crs);

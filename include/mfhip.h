@@ -310,12 +310,17 @@ int mfh_witness_lanes(mfh_ctx *ctx, const uint32_t *d_ssp, const uint8_t *h_witn
 int mfh_witness_from_lanes(mfh_ctx *ctx, const uint32_t *d_ssp, const uint64_t *d_lanes, uint32_t delta, uint32_t *d_w);
 int mfh_prove_partial_w(mfh_ctx *ctx, const uint8_t *d_crs_c8, const uint32_t *d_ssp, const uint8_t *h_witness_bits, uint32_t delta,
                         uint32_t rank, uint32_t world, const uint64_t *d_wlanes, uint64_t *d_partial);
-/* count ciphertexts <-> count*(n+1)*2K uint64 lanes (one per surviving 32-bit word) */
+/* count ciphertexts <-> count * (n+1) * mfh_lanes_per_value uint64 lanes: lane j of a value = its bits [56 j, 56 j + 56) (13 lanes per 704-bit value, 27 at
+ * logq 1472): sums of up to 256 ranks' lanes fit 64 bits; mfh_ct_from_lanes propagates the carries and applies modq (src/lwe.h:107-118). */
+uint32_t mfh_lanes_per_value(const mfh_ctx *ctx);
 int mfh_ct_to_lanes(mfh_ctx *ctx, const uint64_t *d_cts, size_t count, uint64_t *d_lanes);
 int mfh_ct_from_lanes(mfh_ctx *ctx, const uint64_t *d_lanes, size_t count, uint64_t *d_cts);
 
 /* ---- library info -------------------------------------------------------------------------------- */
 const char *mfh_version(void);
+/* 128-bit digest of nbytes at d_buf (4-byte aligned), copied to the host: a cache key for "has this device buffer changed" (the host shim keeps the expanded
+ * CRS image across prover calls while the compressed CRS it was made from is unchanged), not a cryptographic hash.  Synchronises the context's stream. */
+int mfh_digest128(mfh_ctx *ctx, const void *d_buf, size_t nbytes, uint64_t h_digest[2]);
 /* size in bytes the context's scratch currently occupies on the device */
 size_t mfh_workspace_bytes(const mfh_ctx *ctx);
 /* eval_poly (src/lwe.c:160-178) for MANY coefficient vectors over the same nrows CRS rows -- the S / AS / BV regions of a batch of

@@ -67,3 +67,8 @@ def test_dist_header_symbols_are_exported():
         for name in ("ncclReduceScatter", "ncclSend", "ncclRecv", "ncclGroupStart", "ncclAllReduce", "ncclCommInitRank", "mfh_prove_batch_partial"):
             assert name in und, f"{so} does not call {name}"
         assert "librccl" in subprocess.run(["ldd", path], capture_output=True, text=True).stdout
+        # the product library carries the RCCL transport only: the host-shared-memory rehearsal transport of the tests (host/mfuoco_dist_rehearsal.c) is
+        # compiled into the test drivers, so no rehearsal symbol, no shm_open / mmap and no spin-wait scaffolding is in the .so
+        allsyms = subprocess.run(["nm", "-D", path], capture_output=True, text=True).stdout
+        assert "rehearsal" not in allsyms and "shm_open" not in allsyms and "mmap" not in allsyms
+        assert "rehearsal" not in subprocess.run(["strings", path], capture_output=True, text=True).stdout.lower()

@@ -66,17 +66,25 @@ def test_sharded_eval_allreduce_gloo(tmp_path):
         assert open(tmp_path / f"rank{r}.txt").read() == "ok"
 
 
-def test_lane_roundtrip_and_carries():
+@pytest.mark.parametrize("L,K", [(12, 11), (23, 23)])
+def test_lane_roundtrip_and_carries(L, K):
+    """56-bit lanes (13 per 704-bit value, 27 per 1472-bit value): lane-wise uint64 sums of up to 256 maximal values do not overflow, and the carry
+    propagation + modq of the restatement gives the big-integer sum mod 2^(64 K)"""
     from c_lwe_snarks_amd import dist as mfdist
 
-    L, K = 12, 11
+    bits = 64 * K
+    assert mfdist.lanes_per_value(K) == {11: 13, 23: 27}[K]
     rng = np.random.default_rng(0)
-    vals = [int.from_bytes(rng.bytes(88), "little") for _ in range(7)] + [(1 << 704) - 1] * 3
-    limbs = np.array([list(int(v).to_bytes(96, "little")) for v in vals], dtype=np.uint8).view(np.uint64)
+    vals = [int.from_bytes(rng.bytes(bits // 8), "little") for _ in range(7)] + [(1 << bits) - 1] * 249
+    limbs = np.array([list(int(v).to_bytes(8 * L, "little")) for v in vals], dtype=np.uint8).view(np.uint64)
     lanes = mfdist.lanes_from_limbs_cpu(limbs, K)
-    total = lanes.sum(axis=0, keepdims=True)
+    assert lanes.shape == (256, mfdist.lanes_per_value(K)) and int(lanes.max()) < 1 << 56
+    back = mfdist.limbs_from_lanes_cpu(lanes, L, K)
+    assert np.array_equal(back, limbs)
+    total = lanes.astype(np.uint64).sum(axis=0, keepdims=True, dtype=np.uint64)  # what ncclSum on ncclUint64 computes
+    assert sum(int(x) for x in lanes[:, 0]) == int(total[0, 0])                  # no wrap-around at 256 summands
     got = mfdist.limbs_from_lanes_cpu(total, L, K)
-    assert int.from_bytes(got.tobytes(), "little") == sum(vals) % (1 << 704)
+    assert int.from_bytes(got.tobytes(), "little") == sum(vals) % (1 << bits)
 
 
 class _FakeCtx:
@@ -116,7 +124,7 @@ class _LinearCtx:
     reduce-scatter, which statements a rank finishes."""
 
     class _P:
-        d, m, n, K, L = 13, 9, 1, 1, 1
+        d, m, n, K, L, lanes = 13, 9, 1, 1, 1, 2  # (one 64-bit limb per value: two 56-bit lanes)
 
     def __init__(self):
         import torch
@@ -175,7 +183,7 @@ class _LinearCtx:
 
         p = self.params
         n = count * (p.n + 1)
-        return self.torch.from_numpy(mfdist.limbs_from_lanes_cpu(lanes[: n * 2 * p.K].numpy().reshape(n, 2 * p.K), p.L, p.K).astype(np.int64)).reshape(-1)
+        return self.torch.from_numpy(mfdist.limbs_from_lanes_cpu(lanes[: n * p.lanes].numpy().reshape(n, p.lanes), p.L, p.K).astype(np.int64)).reshape(-1)
 
     def prove_batch_finish(self, d_crs, deltas, mags, signs, proofs, maglen=80):
         p = self.params

@@ -65,7 +65,7 @@ def test_sharded_batch_emulation_equals_prove_batch(gpu_ctx_factory, d, m, nb, w
     shares = mfdist.row_shares(p.d, world)
     # step 1 on every "rank": the chain of its own statements
     whv = [ctx.batch_chain(inst["d_ssp"], bits[a:b], deltas[a:b]).clone() for a, b in owned]
-    lps = 5 * (p.n + 1) * 2 * p.K
+    lps = 5 * (p.n + 1) * p.lanes
     total = torch.zeros(per * world * lps, dtype=torch.int64, device=ctx.device)
     try:
         for r in range(world):

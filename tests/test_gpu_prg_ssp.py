@@ -179,7 +179,7 @@ def test_config4_row_sharded_batch_emulated_on_one_gpu(gpu_ctx_factory, mf):
     del w_all
     one = ctx.batch_chain(None, stmts[:2], deltas[:2])
     assert torch.equal(one, whv[0][:, :2])  # (the per-owner chain gives the same polynomials)
-    lps = 5 * (p.n + 1) * 2 * p.K
+    lps = 5 * (p.n + 1) * p.lanes
     total = torch.zeros(per * world * lps, dtype=torch.int64, device=ctx.device)
     image = ctx.empty(max(int(ctx.lib.mfh_crs_mm_share_bytes(ctx._h, r, world)) for r in range(world)))
     t_exp = t_rows = 0.0

@@ -212,7 +212,7 @@ def test_sharded_prover_equals_single(ctx, oracle, instance, mf):
     part = ctx.prove_partial(d_crs, I["d_ssp"], I["bits"], delta, 1, world)
     limbs = ctx.to_host(part, np.uint64).reshape(5, p.n + 1, p.L)
     assert np.array_equal(mfdist.lanes_from_limbs_cpu(limbs, p.K).reshape(-1), ctx.to_host(ctx.ct_to_lanes(part, 5), np.int64))
-    assert np.array_equal(mfdist.limbs_from_lanes_cpu(ctx.to_host(lanes, np.int64).reshape(5, p.n + 1, 2 * p.K), p.L, p.K).reshape(-1),
+    assert np.array_equal(mfdist.limbs_from_lanes_cpu(ctx.to_host(lanes, np.int64).reshape(5, p.n + 1, p.lanes), p.L, p.K).reshape(-1),
                           ctx.to_host(ctx.ct_from_lanes(lanes, 5), np.uint64))
 
 

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.skipif(not os.path.isdir(REF) or not os.path.exists("/o
                                 reason="reference sources or gmp.h not present")
 
 
-@pytest.mark.parametrize("prog,ndebug", [("benchmark_snark", True), ("benchmark_lwe", True), ("test_snark", False), ("test_lwe", False),
+@pytest.mark.parametrize("prog,ndebug", [("benchmark_snark", True), ("benchmark_lwe", True), ("benchmark_eval", True), ("test_snark", False), ("test_lwe", False),
                                          ("test_entropy", False), ("test_ssp", False), ("test_aes", False)])
 def test_reference_driver_links_unchanged(tmp_path, prog, ndebug):
     lib = "mfuoco_gpu" if ndebug else "mfuoco_gpu_debug"
@@ -31,3 +31,5 @@ def test_reference_driver_links_unchanged(tmp_path, prog, ndebug):
     # every reference-library symbol the driver needs is provided by the shim (none by the reference's .c files)
     nm = subprocess.run(["nm", "-u", str(out)], capture_output=True, text=True).stdout
     assert shutil.which("nm") and ("prover" in nm or "regev_encrypt2" in nm or "aesctr_prg" in nm or "random_ssp" in nm or "aesctr_init" in nm)
+    if prog == "benchmark_eval":  # src/benchmark_eval.c:30-86: D encryptions, then ONE eval_poly over the mapped ./coeffs -- all three from the shim
+        assert "eval_poly" in nm and "regev_encrypt2" in nm and "ct_export" in nm
