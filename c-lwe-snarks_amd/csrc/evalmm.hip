@@ -1041,14 +1041,15 @@ __global__ __launch_bounds__(256) void k_witness_mm_prg(const uint32_t *__restri
         part[(((uint64_t)blockIdx.y * 4 + w) * (32 * MT) + stmt) * d + k] = acc[t][w][e];
       }
 }
-// 256 statements per generation with TWO waves per SIMD: a coefficient tile's four byte planes go to four waves (8 statement tiles x 1
-// plane = 128 accumulator registers each), which SHARE the hashes four ways -- wave j hashes rows 4 j .. 4 j + 3 of a lane's 16 and
-// publishes dword j of all four planes' fragments through LDS (a three-slot ring: the hashes of step K + 2 are issued between the MFMAs
-// of step K, the fragment of step K + 1 is read during step K; the row keys are loaded four steps ahead), wave w
-// reads plane w's fragment with one 16-byte load.  4 hashes and 8 MFMAs per wave and step, and with two waves per SIMD one wave's
-// hashes run under the other's MFMAs (a first version on wave pairs, one wave per SIMD with 256 accumulators and the
-// hashes shared two ways, took 0.89 s per 248 statements at 2^20 constraints against 0.83: nothing overlaps the matrix pipe there).
-// Chunk partials only (k_witness_mm_finish).  grid = (d / 64, row chunks), block = 8 waves = 2 coefficient tiles x 4 planes.
+// 256 statements per generation with TWO waves per SIMD.  The 8 statement tiles x 4 byte planes of a 32-coefficient tile (512 accumulator registers) go to
+// four waves, 4 statement tiles x 2 planes each (128 registers; round 4 -- rounds 2-3 gave a wave all 8 statement tiles of ONE plane: 8 KiB of bit fragments
+// + 1 KiB of coefficient bytes read from LDS per wave and 32-row step, 72 KiB per CU = 576 clk of the LDS pipe against 512 clk of MFMAs per SIMD: the pass was
+// LDS-bound, a build without the MFMAs ran no faster; 4 + 2 KiB per wave are 384 clk).  The four waves SHARE the hashes four ways -- wave j hashes rows
+// 4 j .. 4 j + 3 of a lane's 16 and publishes dword j of all four planes' fragments through LDS (a three-slot ring: the hashes of step K + 2 are issued between
+// the MFMAs of step K, the fragments of step K + 1 are read during step K; the row keys are loaded four steps ahead), wave (sh, pp) reads the fragments of
+// planes 2 pp and 2 pp + 1 with two 16-byte loads and the bit fragments of statement tiles 4 sh .. 4 sh + 3.  4 hashes and 8 MFMAs per wave and step, and
+// with two waves per SIMD one wave's hashes run under the other's MFMAs.
+// Chunk partials only (k_witness_mm_finish).  grid = (d / 64, row chunks), block = 8 waves = 2 coefficient tiles x (2 statement halves x 2 plane pairs).
 __global__ __launch_bounds__(512) void k_witness_mm8q_prg(const uint32_t *__restrict__ rowkeys, const v4i *__restrict__ bitfrag, uint32_t nrowsel /* m - 1 */,
                                                           uint32_t ksteps_per_chunk, uint32_t d, int *__restrict__ part, WCols wc) {
   constexpr int MT = 8, RING = 4;
@@ -1057,19 +1058,29 @@ __global__ __launch_bounds__(512) void k_witness_mm8q_prg(const uint32_t *__rest
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t r32 = lane & 31, h = lane >> 5;
   const uint32_t tile = wave >> 2, pl = wave & 3;
+  const uint32_t sh = pl >> 1, pp = pl & 1;        // the wave's statement half (tiles 4 sh ..) and plane pair (planes 2 pp, 2 pp + 1)
+  // which 4 of a lane's 16 rows this wave hashes = which dword of the lane's fragments it publishes: rotated by the lane's 16-lane group, so that the 64
+  // lanes of a ds_write_b32 into the [lane][4 dwords] slots hit 64 different banks (with pos = pl for every lane the addresses are 16 bytes apart: 16
+  // distinct banks, every publish a 4-way conflict -- PMC: SQ_LDS_BANK_CONFLICT was 37 % of the LDS cycles of the pass)
+  const uint32_t pos = (pl + (lane >> 4)) & 3;
   const uint32_t ktl = blockIdx.x * 2 + tile, kt = wc.kt0 + ktl;
   const uint32_t kc = kt * 32 + r32 + 0x632BE5ABu;
   const uint32_t K0 = blockIdx.y * ksteps_per_chunk, K1 = min((nrowsel + 31) / 32, K0 + ksteps_per_chunk);
-  v16i acc[MT];
+  v16i acc[4][2];
 #pragma unroll
-  for (int t = 0; t < MT; t++)
+  for (int t = 0; t < 4; t++)
 #pragma unroll
-    for (int e = 0; e < 16; e++) acc[t][e] = 0;
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[t][q][e] = 0;
   if (K0 >= K1) return;  // (uniform)
   auto bits_load = [&](uint32_t K) -> v4i { return bitfrag[(uint64_t)min(K, K1 - 1) * MT * 64 + tid]; };  // 512 elements per step: one per thread
   auto bits_store = [&](uint32_t K, v4i st) { (&bits[K % RING][0][0])[tid] = st; };
-  auto rk_load = [&](uint32_t K) -> uint4 { return *reinterpret_cast<const uint4 *>(rowkeys + 32 * (uint64_t)min(K, K1 - 1) + 16 * h + 4 * pl); };
+  auto rk_load = [&](uint32_t K) -> uint4 { return *reinterpret_cast<const uint4 *>(rowkeys + 32 * (uint64_t)min(K, K1 - 1) + 16 * h + 4 * pos); };
   auto hash1 = [&](uint32_t rowkey) -> uint32_t {  // mf::ssp_prg_raw(rowkey, k)
+#ifdef WPRG_NOHASH  // timing-only build (wrong results): what the kernel costs without the generator's arithmetic
+    return kc ^ rowkey;
+#endif
     uint32_t y = kc * rowkey;
     y ^= y >> 16;
     y *= 0x7FEB352Du;
@@ -1078,15 +1089,15 @@ __global__ __launch_bounds__(512) void k_witness_mm8q_prg(const uint32_t *__rest
     y ^= y >> 16;
     return y;
   };
-  auto publish = [&](uint32_t K, const uint32_t (&x)[4]) {  // dword `pl` of the four planes' fragments of step K
+  auto publish = [&](uint32_t K, const uint32_t (&x)[4]) {  // dword `pos` of the four planes' fragments of step K
 #pragma unroll
     for (int w = 0; w < 4; w++) {
       const uint32_t lo = __builtin_amdgcn_perm(x[1], x[0], 0x0c0c0400u + 0x00000101u * w);  // {x0.bw, x1.bw, 0, 0}
       const uint32_t hi = __builtin_amdgcn_perm(x[3], x[2], 0x04000c0cu + 0x01010000u * w);  // {0, 0, x2.bw, x3.bw}
-      xch[K % 3][tile][w][lane][pl] = (lo | hi) ^ 0x80808080u;
+      xch[K % 3][tile][w][lane][pos] = (lo | hi) ^ 0x80808080u;
     }
   };
-  auto fragment = [&](uint32_t K) -> v4i { return *reinterpret_cast<const v4i *>(&xch[K % 3][tile][pl][lane][0]); };
+  auto fragment = [&](uint32_t K, uint32_t q) -> v4i { return *reinterpret_cast<const v4i *>(&xch[K % 3][tile][2 * pp + q][lane][0]); };
   uint4 rkr[4];  // the row keys of steps K + 2 .. K + 5
   v4i sta, stb;  // the bit fragments of steps K + 1 / K + 2 on their way to the ring
   sta = bits_load(K0);
@@ -1103,25 +1114,35 @@ __global__ __launch_bounds__(512) void k_witness_mm8q_prg(const uint32_t *__rest
 #pragma unroll
   for (int i = 2; i <= 5; i++) rkr[i & 3] = rk_load(K0 + i);
   __syncthreads();
-  v4i bq = fragment(K0);
+  v4i bq0 = fragment(K0, 0), bq1 = fragment(K0, 1);
   uint32_t K = K0;
   auto step = [&](int slot, v4i &st) {  // st: the bit fragment of step K + 1 (loaded two steps ago); refilled with that of step K + 3
-    const v4i bnext = fragment(K + 1);  // (published a step ago, before the barrier)
+    const v4i bn0 = fragment(K + 1, 0), bn1 = fragment(K + 1, 1);  // (published a step ago, before the barrier)
     const uint4 rk = rkr[(slot + 2) & 3];  // step K + 2
     const uint32_t hr[4] = {rk.x, rk.y, rk.z, rk.w};
     uint32_t hx[4];
     bits_store(K + 1, st);
-    const v4i *aq = &bits[K % RING][0][lane];
+    const v4i *aq = &bits[K % RING][4 * sh][lane];
 #pragma unroll
-    for (int t = 0; t < MT; t++) {
-      acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(aq[t * 64], bq, acc[t], 0, 0, 0);
-      if (t & 1) hx[t >> 1] = hash1(hr[t >> 1]);
+    for (int t = 0; t < 4; t++) {
+      const v4i a = aq[t * 64];
+#ifdef WPRG_NOMFMA  // timing-only build (wrong results): the generation, its LDS exchange and the barriers without the matrix cores
+      acc[t][0][0] += a[0] ^ bq0[t];
+      acc[t][1][0] += a[1] ^ bq1[t];
+#else
+      acc[t][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq0, acc[t][0], 0, 0, 0);
+      acc[t][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq1, acc[t][1], 0, 0, 0);
+#endif
+      hx[t] = hash1(hr[t]);
     }
     publish(K + 2, hx);  // (slot last read during step K - 2, two barriers ago)
     rkr[(slot + 2) & 3] = rk_load(K + 6);
-    bq = bnext;
+    bq0 = bn0;
+    bq1 = bn1;
     st = bits_load(K + 3);
+#ifndef WPRG_NOSYNC  // (timing-only build without it: wrong results -- what the step barrier costs)
     __syncthreads();
+#endif
     K++;
   };
   for (; K + 4 <= K1;) {
@@ -1135,12 +1156,15 @@ __global__ __launch_bounds__(512) void k_witness_mm8q_prg(const uint32_t *__rest
   if (K < K1) step(2, sta);
   uint32_t dd = d;
   asm volatile("" : "+s"(dd));  // (keeps the store addresses from being computed ahead of the loop)
-  int *dst = part + ((uint64_t)blockIdx.y * 4 + pl) * (32 * MT) * dd + ktl * 32 + r32 + (uint64_t)(4 * h) * dd;
 #pragma unroll
-  for (int t = 0; t < MT; t++) {
+  for (int q = 0; q < 2; q++) {
+    int *dst = part + (((uint64_t)blockIdx.y * 4 + 2 * pp + q) * (32 * MT) + 128 * sh) * dd + ktl * 32 + r32 + (uint64_t)(4 * h) * dd;
 #pragma unroll
-    for (int e = 0; e < 16; e++) dst[(uint64_t)((e & 3) + 8 * (e >> 2)) * dd] = acc[t][e];
-    dst += (uint64_t)32 * dd;
+    for (int t = 0; t < 4; t++) {
+#pragma unroll
+      for (int e = 0; e < 16; e++) dst[(uint64_t)((e & 3) + 8 * (e >> 2)) * dd] = acc[t][q][e];
+      dst += (uint64_t)32 * dd;
+    }
   }
 }
 // 256 statements (a whole super-group of 248) in ONE read of the dense SSP.  8 statement tiles x 4 byte planes are 512 accumulator
