@@ -448,6 +448,24 @@ def main():
         except Exception:
             return None
 
+    def clock_note():
+        """effective clock under k_mmstream from the committed PMC summary (GRBM_GUI_ACTIVE / 8 XCDs / the kernel's duration in the same profile), not a constant"""
+        try:
+            tag = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_by_kernel.json"))[-1]
+            pm = json.load(open(os.path.join(ROOT, "profiles", tag)))["kernels"]
+            kk = [k for k in pm if "k_mmstream_p(" in k or "k_mmstream(" in k]
+            stats = os.path.join(ROOT, "profiles", tag.replace("_pmc_by_kernel.json", "_kernel_stats.csv"))
+            avg_ns = None
+            for line in open(stats):
+                if ("k_mmstream_p(" in line or "k_mmstream(" in line) and not line.startswith("#"):
+                    avg_ns = float(line.rsplit('"', 1)[1].split(",")[3])
+                    break
+            ghz = pm[kk[0]]["GRBM_GUI_ACTIVE"]["mean_of_large_launches"] / 8 / avg_ns
+            return (f"the chip holds {ghz:.2f} GHz under this kernel (GRBM_GUI_ACTIVE / 8 / average launch duration, profiles/{tag} and its kernel_stats: 2.4 nominal); "
+                    "a bare register-only loop of this MFMA sustains ~4050 TOPS (tools/mfma_i8_rate.hip)")
+        except Exception:
+            return "effective clock not available (no PMC summary under profiles/); a bare register-only loop of this MFMA sustains ~4050 TOPS (tools/mfma_i8_rate.hip)"
+
     def mmstream_roofline(ktd, step_ms, steps_=None):
         """roofline of k_mmstream from the launches that serve several groups (the S / AS rounds: the dominant shape); the single-group
         launches of the same kernel (b_w over the BT+BV rows: HBM-bound) are listed beside it and counted in whole_step"""
@@ -467,9 +485,10 @@ def main():
         ops_other = 2.0 * mtile_rows * 256 * other[4]               # (all single-group launches together)
         step_tops = (ops * n_ + ops_other) / (steps_ or args.steps) / (step_ms * 1e-3) / 1e12  # the kernel's operations of a step over the WHOLE step time
         gbs = regions * rows * tile_bytes_per_row / (avg * 1e-3) / 1e9  # one pass over each region's image
-        return {"bound": "mfma", "kernel": "k_mmstream (A fragments of the expanded CRS streamed once per launch and region for 4 groups of 63 + 64 + 64 + 64 coefficient vectors (127.5 proofs) -- "
-                                           "HBM for the first workgroup of a row-tile set, that XCD's L2 for the other three --, digit fragments "
-                                           "through LDS, i8 MFMA 16x16x64; the S and the AS groups of a round share one launch)",
+        return {"bound": "mfma", "kernel": "k_mmstream_p (persistent grid, one workgroup per CU: A fragments of the expanded CRS streamed once per launch and region for the "
+                                           f"{groups / regions:.0f} groups of 63 / 64 coefficient vectors of a super-group (255 proofs) -- HBM for the first workgroup of a "
+                                           "row-tile set, that XCD's L2 for the others, 8 tile groups x 4 groups of ONE region on an XCD at a time --, digit fragments "
+                                           "through LDS, i8 MFMA 16x16x64; the S and the AS region of a super-group share one launch)",
                 "achieved": tops, "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s (int8; multiply and add counted separately)", "frac": tops / MFMA_I8_PEAK_TOPS,
                 "traffic": traffic_of("traffic_mmstream.json"),
                 "traffic_source": "static file profiles/traffic_mmstream.json (a separate rocprofv3 --pmc pass of this command, not this run)",
@@ -484,8 +503,7 @@ def main():
                 "note": CONC_NOTE.replace("algorithmic bytes", "int8 operations"),
                 "hbm": {"bytes_read_per_row": tile_bytes_per_row, "achieved_gbs": gbs, "peak_gbs": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS,
                         "fragment_gbs_consumed_incl_l2": gbs * groups / regions},
-                "clock_note": "the chip holds ~1.5 GHz under this load (GRBM_GUI_ACTIVE / 8 / duration, DESIGN.md 4.2c); a bare register-only loop "
-                              "of this MFMA sustains ~4050 TOPS (tools/mfma_i8_rate.hip)"}
+                "clock_note": clock_note()}
 
     def evalmm16_roofline(kt):
         n_, ms_, rows_, busy_, _ = kt

@@ -24,7 +24,7 @@ if f:
     rows = list(csv.DictReader(open(f)))
     with open(os.path.join(out_dir, f"{tag}_kernel_stats.csv"), "w") as o:
         commit_ = sys.argv[2] if len(sys.argv) > 2 else os.popen("git -C %s rev-parse --short HEAD" % ROOT).read().strip()
-        o.write(f"# commit {commit_}: rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline   (MI355X, 1 GPU; default batch mode: the single-proof path (regenerated and resident), then the headline run, then the regenerate-per-group and resident-image variants of the same batch, then the LWE encryption and decryption batches).  k_mmstream = the 8-group S / AS rounds (bench.py's roofline kernel), k_mmstream1 = single-group launches (b_w)\n")
+        o.write(f"# commit {commit_}: rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline   (MI355X, 1 GPU; default batch mode: the single-proof path (regenerated and resident), then the headline run, then the regenerate-per-group and resident-image variants of the same batch, then the LWE encryption and decryption batches).  k_mmstream_p = the persistent 16-group S + AS launches, one per super-group of 255 proofs (bench.py's roofline kernel), k_mmstream1 = single-group launches (b_w)\n")
         o.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
         for r in rows:
             o.write(",".join(['"' + r["Name"][:110].replace('"', "'") + '"', r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]]) + "\n")
@@ -38,7 +38,7 @@ if f:
 # round 1/2 layout: one directory per counter group)
 commit = sys.argv[2] if len(sys.argv) > 2 else os.popen("git -C %s rev-parse --short HEAD" % ROOT).read().strip()
 res = {}
-for name in ("fetch", "write", "sq"):
+for name in ("fetch", "write", "tcc", "sq"):
     files = glob.glob(os.path.join(RAW, f"{tag}_pmc_{name}*/*/*_counter_collection.csv"))
     for f in files:
         agg = defaultdict(lambda: defaultdict(list))
@@ -54,15 +54,18 @@ json.dump({"commit": commit, "kernels": res}, open(os.path.join(out_dir, f"{tag}
 # HBM traffic per launch (MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE in KiB; on gfx950 FETCH_SIZE reports half the bytes of a wide coalesced read stream:
 # doubled -- an upper bound where the reads are not wide streams)
 TRAFFIC = [
-    ("k_mmstream(", "traffic_mmstream.json", "k_mmstream", "launches over the whole S and AS regions for 4 + 4 groups of 31 proofs.  Algorithmic: 2 x 4.24 GB of A fragments once + 8 x 8 MB of "
-     "digits read, 8 x 133 MB of int32 partial products written; the workgroups consume 8 x 4.24 GB of fragments, the rest of which L2 / Infinity Cache serve"),
+    ("k_mmstream_p(", "traffic_mmstream.json", "k_mmstream_p", "persistent launches over the whole S and AS regions for 8 + 8 groups of 63 / 64 coefficient vectors (a super-group of 255 proofs).  Algorithmic: "
+     "2 x 4.24 GB of A fragments once + 16 x 8 MB of digits read, 16 x 133 MB of int32 partial products written.  The workgroups consume 16 x 4.24 GB of fragments and 8096 x 8 MB of digit "
+     "fragments out of the L2s; what an XCD's 32 concurrent workgroups (4 tile groups x 8 groups of one region) can share bounds the L2 misses at 4048 x (8.39 / 8 + 8 / 4) MB = 12.3 GB per 8 groups "
+     "(24.7 GB per launch): DESIGN.md 4.2c"),
+    ("k_mmstream(", "traffic_mmstream_nonpersistent.json", "k_mmstream", "one workgroup per item (the layout of rounds 1-3, mfh_set_mm_stream(ctx, 0, 0, 0, 0)); only present when a profiled program selects it"),
     ("k_mmstream1(", "traffic_mmstream1.json", "k_mmstream1", "one group per launch: b_w's pass over the BT+BV image (2.83 GB of fragments), HBM-bound"),
     ("k_expand_mm", "traffic_expandmm.json", "k_expand_mm", "the barrier-free CRS expansion: reads the compressed CRS region (92 B per row), writes the image region (129 536 B per row)"),
     ("k_encrypt_mm", "traffic_encryptmm.json", "k_encrypt_mm", "reads the Toeplitz(sk) fragments (12.7 MB per head value, from L2 after the first workgroups), writes 384 B of int32 partial sums per row and column chunk"),
     ("k_decrypt_mm", "traffic_decryptmm.json", "k_decrypt_mm", "65 536 full ciphertexts of 141 216 B streamed once (9.25 GB), Toeplitz(sk) fragments through LDS (13.2 MB, L2), 384 B of int32 partial sums "
      "written per row and column chunk"),
     ("k_witness_mm8q(", "traffic_witnessmm.json", "k_witness_mm8q", "one read of the SSP image in fragment order (2.86 GB) per 248 statements, 248 x 128 KB of w written"),
-    ("k_evalmm_finish_groups", "traffic_evalmm_finish.json", "k_evalmm_finish_groups", "reads the int32 partial products of a round's 8 groups (8 x 133 MB), writes their ciphertexts"),
+    ("k_evalmm_finish_groups", "traffic_evalmm_finish.json", "k_evalmm_finish_groups", "reads the int32 partial products of a launch's 16 groups (16 x 133 MB), writes their ciphertexts"),
     ("k_ntt_lds_mul8", "traffic_ntt_lds.json", "k_ntt_lds_mul8", "2048-point blocks of 248 x 3 transforms: forward low stages, pointwise product, inverse low stages"),
     ("void k_eval<736, 2>", "traffic_eval2.json", "k_eval<736,2>", "the single-proof kernel: ~0 HBM bytes by construction (CRS b's, coefficients, partials)"),
     ("void k_mac_resident<736, 2>", "traffic_mac2.json", "k_mac_resident<736,2>", "the resident single-proof regime: one read of the expanded region"),
