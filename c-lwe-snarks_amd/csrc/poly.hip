@@ -267,7 +267,11 @@ __global__ __launch_bounds__(256) void k_ntt_lds_mul(uint32_t *__restrict__ a, c
 // (b_is_hat); two fresh operands keep the generic kernel above.
 __device__ __forceinline__ uint32_t lpad(uint32_t i) { return i + (i >> 5); }
 // K DIF stages (block lengths len, len/2, ...) on v[0 .. 2^K): element m sits at position j + m * qd of its block, qd = len >> K
-template <int K>
+// PAD: the twiddle table lies in LDS at lpad() indices -- the stages read it with power-of-two strides (8, 16, ... entries between neighbouring lanes: 4 - 8 of
+// the 64 banks, PMC round 3: SQ_LDS_BANK_CONFLICT was a quarter of k_ntt_lds_mul8's cycles); one skipped word per 32 spreads every such stride over the banks.
+// (Measured, round 4: the chain of 255 statements takes the same 1.80 ms with and without the padding -- the kernel is bound by its Montgomery multiplies and
+// its six barriers, not by these gathers; kept because it costs nothing.)
+template <int K, bool PAD = false>
 __device__ __forceinline__ void dif_regs(uint32_t *v, uint32_t j, uint32_t qd, uint32_t len, const uint32_t *__restrict__ t, uint32_t half_max,
                                          const NttPrime q) {
   constexpr int R = 1 << K;
@@ -278,7 +282,8 @@ __device__ __forceinline__ void dif_regs(uint32_t *v, uint32_t j, uint32_t qd, u
 #pragma unroll
     for (int m = 0; m < R; m++) {
       if ((m & h) == 0) {
-        const uint32_t w = t[(size_t)(j + (uint32_t)(m & (h - 1)) * qd) * tstep];
+        const uint32_t ti_ = (j + (uint32_t)(m & (h - 1)) * qd) * tstep;
+        const uint32_t w = PAD ? t[ti_ + (ti_ >> 5)] : t[(size_t)ti_];
         const uint32_t u = v[m], z = v[m + h];
         v[m] = add_mod(u, z, q.p);
         v[m + h] = mont_mul(sub_mod(u, z, q.p), w, q.p, q.ninv);
@@ -287,7 +292,7 @@ __device__ __forceinline__ void dif_regs(uint32_t *v, uint32_t j, uint32_t qd, u
   }
 }
 // K DIT stages (block lengths len, 2 len, ...; inverse twiddles): element m at position j + m * qd, qd = len / 2
-template <int K>
+template <int K, bool PAD = false>
 __device__ __forceinline__ void dit_regs(uint32_t *v, uint32_t j, uint32_t qd, uint32_t len, const uint32_t *__restrict__ t, uint32_t half_max,
                                          const NttPrime q) {
   constexpr int R = 1 << K;
@@ -298,7 +303,8 @@ __device__ __forceinline__ void dit_regs(uint32_t *v, uint32_t j, uint32_t qd, u
 #pragma unroll
     for (int m = 0; m < R; m++) {
       if ((m & h) == 0) {
-        const uint32_t w = t[(size_t)(j + (uint32_t)(m & (h - 1)) * qd) * tstep];
+        const uint32_t ti_ = (j + (uint32_t)(m & (h - 1)) * qd) * tstep;
+        const uint32_t w = PAD ? t[ti_ + (ti_ >> 5)] : t[(size_t)ti_];
         const uint32_t u = v[m], z = mont_mul(v[m + h], w, q.p, q.ninv);
         v[m] = add_mod(u, z, q.p);
         v[m + h] = sub_mod(u, z, q.p);
@@ -311,7 +317,7 @@ __global__ __launch_bounds__(256) void k_ntt_lds_mul8(uint32_t *__restrict__ a, 
   __shared__ uint32_t sm[2048 + 64];
   // the block's stages use every (half_max / 1024)-th entry of the twiddle tables: 2 x 1024 words, staged in LDS once per workgroup -- the
   // 88 twiddle reads per thread are then LDS gathers instead of global ones (64 different cache lines per wave-load)
-  __shared__ uint32_t tws[2][1024];
+  __shared__ uint32_t tws[2][1024 + 32];  // entry i at lpad(i)
   const NttPrime q = P.q[blockIdx.y % 3];
   const uint32_t tid = threadIdx.x;
   const size_t base = (size_t)blockIdx.y * N + (size_t)blockIdx.x * 2048;
@@ -320,8 +326,8 @@ __global__ __launch_bounds__(256) void k_ntt_lds_mul8(uint32_t *__restrict__ a, 
     const uint32_t sc = half_max >> 10;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      tws[0][tid + 256 * i] = tg[(size_t)(tid + 256 * i) * sc];
-      tws[1][tid + 256 * i] = tig[(size_t)(tid + 256 * i) * sc];
+      tws[0][lpad(tid + 256 * i)] = tg[(size_t)(tid + 256 * i) * sc];
+      tws[1][lpad(tid + 256 * i)] = tig[(size_t)(tid + 256 * i) * sc];
     }
   }
   const uint32_t *t = tws[0], *ti = tws[1];
@@ -333,26 +339,26 @@ __global__ __launch_bounds__(256) void k_ntt_lds_mul8(uint32_t *__restrict__ a, 
 #pragma unroll
   for (int m = 0; m < 8; m++) v[m] = a[base + i1 + 256 * m];
   __syncthreads();  // the staged twiddles
-  dif_regs<3>(v, tid, 256, 2048, t, half_max, q);
+  dif_regs<3, true>(v, tid, 256, 2048, t, half_max, q);
 #pragma unroll
   for (int m = 0; m < 8; m++) sm[lpad(i1 + 256 * m)] = v[m];
   __syncthreads();
 #pragma unroll
   for (int m = 0; m < 8; m++) v[m] = sm[lpad(i2 + 32 * m)];
-  dif_regs<3>(v, j2, 32, 256, t, half_max, q);
+  dif_regs<3, true>(v, j2, 32, 256, t, half_max, q);
 #pragma unroll
   for (int m = 0; m < 8; m++) sm[lpad(i2 + 32 * m)] = v[m];
   __syncthreads();
 #pragma unroll
   for (int m = 0; m < 8; m++) v[m] = sm[lpad(i3 + 4 * m)];
-  dif_regs<3>(v, j3, 4, 32, t, half_max, q);
+  dif_regs<3, true>(v, j3, 4, 32, t, half_max, q);
 #pragma unroll
   for (int m = 0; m < 8; m++) sm[lpad(i3 + 4 * m)] = v[m];
   __syncthreads();
 #pragma unroll
   for (int m = 0; m < 8; m++) v[m] = sm[lpad(8 * tid + m)];
-  dif_regs<2>(v, 0, 1, 4, t, half_max, q);
-  dif_regs<2>(v + 4, 0, 1, 4, t, half_max, q);
+  dif_regs<2, true>(v, 0, 1, 4, t, half_max, q);
+  dif_regs<2, true>(v + 4, 0, 1, 4, t, half_max, q);
   // ---- pointwise product with the right-hand side's transform (itself when squaring)
   if (bhat) {
     const uint4 *bp = reinterpret_cast<const uint4 *>(bhat + (size_t)(blockIdx.y % 3) * N + (size_t)blockIdx.x * 2048 + 8 * tid);
@@ -365,26 +371,26 @@ __global__ __launch_bounds__(256) void k_ntt_lds_mul8(uint32_t *__restrict__ a, 
     for (int m = 0; m < 8; m++) v[m] = mont_mul(v[m], v[m], q.p, q.ninv);
   }
   // ---- inverse: block lengths 2 .. 2048
-  dit_regs<2>(v, 0, 1, 2, ti, half_max, q);
-  dit_regs<2>(v + 4, 0, 1, 2, ti, half_max, q);
+  dit_regs<2, true>(v, 0, 1, 2, ti, half_max, q);
+  dit_regs<2, true>(v + 4, 0, 1, 2, ti, half_max, q);
 #pragma unroll
   for (int m = 0; m < 8; m++) sm[lpad(8 * tid + m)] = v[m];
   __syncthreads();
 #pragma unroll
   for (int m = 0; m < 8; m++) v[m] = sm[lpad(i3 + 4 * m)];
-  dit_regs<3>(v, j3, 4, 8, ti, half_max, q);
+  dit_regs<3, true>(v, j3, 4, 8, ti, half_max, q);
 #pragma unroll
   for (int m = 0; m < 8; m++) sm[lpad(i3 + 4 * m)] = v[m];
   __syncthreads();
 #pragma unroll
   for (int m = 0; m < 8; m++) v[m] = sm[lpad(i2 + 32 * m)];
-  dit_regs<3>(v, j2, 32, 64, ti, half_max, q);
+  dit_regs<3, true>(v, j2, 32, 64, ti, half_max, q);
 #pragma unroll
   for (int m = 0; m < 8; m++) sm[lpad(i2 + 32 * m)] = v[m];
   __syncthreads();
 #pragma unroll
   for (int m = 0; m < 8; m++) v[m] = sm[lpad(i1 + 256 * m)];
-  dit_regs<3>(v, tid, 256, 512, ti, half_max, q);
+  dit_regs<3, true>(v, tid, 256, 512, ti, half_max, q);
 #pragma unroll
   for (int m = 0; m < 8; m++) a[base + i1 + 256 * m] = v[m];
 }
