@@ -25,6 +25,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -266,6 +267,15 @@ def main():
         import datetime
 
         ctl_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=float(os.environ.get("MFUOCO_BENCH_AGREE_S", "90"))))
+
+    def ctl_reduce(value, op):
+        """MAX / MIN of a scalar over the ranks on the host group: timing and acceptance flags never depend on the data-path backend"""
+        if dist is None:
+            return value
+        t = torch.tensor([float(value)], dtype=torch.float64)
+        dist.all_reduce(t, op=op, group=ctl_group)
+        return float(t.item())
+
     if dist is not None and dist.get_world_size() != args.gpus:
         print(f"[bench] error: {dist.get_world_size()} ranks joined the process group, --gpus {args.gpus}", file=sys.stderr, flush=True)
         return 2
@@ -297,7 +307,7 @@ def main():
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
-            dist.barrier()
+            dist.barrier(group=ctl_group)
         torch.cuda.synchronize()
 
     # ---- setup(): 2D+M encryptions -> compressed CRS (also the "LWE encryptions/s" figure at scale)
@@ -316,6 +326,11 @@ def main():
     bufs = {}
 
     by_rows = args.sharding == "rows"
+    # batch mode on N > 1 ranks (what the driver's scaling runs are): the headline needs no collective, so every leg that does -- the row-sharded single
+    # proof and the row-sharded batch prover -- runs LAST, under a watchdog (collective_legs below): a backend that hangs costs those legs, not the line
+    defer_rows = by_rows and world > 1 and mode == "batch" and not big
+    if defer_rows:
+        by_rows = False
     eff_rank, eff_world = (rank, world) if by_rows else (0, 1)
 
     def step():
@@ -364,9 +379,7 @@ def main():
         n2, ms2, rows2 = ctx.timing_drain("eval2")
         n1, ms1, rows1 = ctx.timing_drain("eval1")
         if dist is not None:
-            tt = torch.tensor([elapsed], dtype=torch.float64, device=ctx.device)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            elapsed = float(tt.item())
+            elapsed = ctl_reduce(elapsed, dist.ReduceOp.MAX)
 
         if rank != 0:
             accepted = True
@@ -412,9 +425,7 @@ def main():
         m2n, m2ms, m2rows = ctx.timing_drain("mac2")
         m1n, m1ms, m1rows = ctx.timing_drain("mac1")
         if dist is not None:
-            tt = torch.tensor([el_r], dtype=torch.float64, device=ctx.device)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            el_r = float(tt.item())
+            el_r = ctl_reduce(el_r, dist.ReduceOp.MAX)
         same = bool(torch.equal(proof_r, proof))
         ctx.set_resident_share(None, 0, 1)
         rb = ctx.resident_row_bytes()
@@ -566,9 +577,7 @@ def main():
                 n_, ms_, rows_ = ctx.timing_drain(k)
                 kt[k] = (n_, ms_, rows_, ctx.timing_busy_ms(), ctx.timing_work_rows())  # launches on two streams overlap: busy = union of their spans
             if dist is not None:
-                tt = torch.tensor([el], dtype=torch.float64, device=ctx.device)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                el = float(tt.item())
+                el = ctl_reduce(el, dist.ReduceOp.MAX)
             return out, el, kt
 
         # headline: the CRS expanded once per call (= per step) into a transient image, streamed for every super-group of 255 proofs
@@ -586,9 +595,7 @@ def main():
             same_b = same_b and bool(torch.equal(out_b.view(nb, -1)[i], one))
         all_ok = [bool(int(x)) for x in ok_b] == b_valid and same_b
         if dist is not None:
-            ta = torch.tensor([1 if all_ok else 0], dtype=torch.int64, device=ctx.device)
-            dist.all_reduce(ta, op=dist.ReduceOp.MIN)
-            all_ok = bool(int(ta.item()))
+            all_ok = bool(int(ctl_reduce(1 if all_ok else 0, dist.ReduceOp.MIN)))
         image_bytes = int(ctx.lib.mfh_crs_mm_image_bytes(ctx._h))
         # the memory-light variant: no transient image, every group of 31 proofs regenerates the keystream on the CU (k_evalmm16)
         regen = None
@@ -624,85 +631,6 @@ def main():
                    "regenerate_per_group": regen, "device_verifier_proofs_per_s": verify_per_s,
                    "transient_image_bytes_per_rank": image_bytes if used_image else 0, "crs_expansion": expand_info(kt_b["expandmm"]),
                    "roofline": mmstream_roofline(kt_b, el_b / args.steps * 1e3) if used_image else evalmm16_roofline(kt_b["evalmm"])}
-
-    # ---- N > 1: the row-sharded BATCH prover (BASELINE configs 3/4): one statement list for the whole job, CRS rows sharded over the ranks,
-    # all-to-all of the coefficient row slices + ONE reduce-scatter of uint64 lanes per step (dist.prove_batch_sharded)
-    sharded_b = None
-    if mode == "batch" and world > 1:
-        nbt = args.sharded_batch or (args.batch if not big else 255)
-        srng = np.random.default_rng(4000)  # the same statements on every rank
-        s_delta = [int(x) for x in srng.integers(0, mf.P, size=nbt, dtype=np.uint64)]
-        s_mags = [srng.integers(0, 256, size=5 * 80, dtype=np.uint8).tobytes() for _ in range(nbt)]
-        s_signs = [bytes(srng.integers(0, 2, size=5, dtype=np.uint8).tolist()) for _ in range(nbt)]
-        s_valid = [i % 2 == 0 for i in range(nbt)]
-        s_bits = [inst["bits"] if s_valid[i] else srng.bytes(len(inst["bits"])) for i in range(nbt)]
-        sbufs = {}
-        sh_steps = min(args.steps, 10 if not big else 3)
-
-        def sharded_step():
-            return mfdist.prove_batch_sharded(ctx, d_crs, inst["d_ssp"], s_bits, s_delta, s_mags, s_signs, rank, world, bufs=sbufs)
-
-        try:
-            for _ in range(max(args.warmup, 1) if not big else 1):
-                s_first, s_count, s_pr = sharded_step()
-            sharded_err = None
-        except Exception as e:  # (a collective the backend refuses fails on every rank alike: report it, keep the other legs)
-            sharded_err = f"{type(e).__name__}: {e}"
-    if mode == "batch" and world > 1 and sharded_err is not None:
-        sharded_b = {"error": sharded_err, "value": None, "unit": "proofs/s", "scaling": "strong", "ranks": world, "roofline": None,
-                     "own_proofs_accepted_rejected_as_expected_and_identical_to_prover": False, "ms_per_step": None,
-                     "statements_per_step_whole_job": nbt}
-    elif mode == "batch" and world > 1:
-        ctx.set_timing(True)
-        for k in ("evalmm", "mmstream_rounds", "evalmm_resident", "expandmm"):
-            ctx.timing_drain(k)
-        barrier()
-        ts = time.perf_counter()
-        for _ in range(sh_steps):
-            s_first, s_count, s_pr = sharded_step()
-        barrier()
-        el_s = time.perf_counter() - ts
-        ctx.set_timing(False)
-        kt_s = {}
-        for k in ("evalmm", "mmstream_rounds", "evalmm_resident", "expandmm"):
-            n_, ms_, rows_ = ctx.timing_drain(k)
-            kt_s[k] = (n_, ms_, rows_, ctx.timing_busy_ms(), ctx.timing_work_rows())
-        tt = torch.tensor([el_s], dtype=torch.float64, device=ctx.device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        el_s = float(tt.item())
-        ok_s = True
-        if s_count:  # the rank's own proofs: accepted / rejected as the witnesses demand, and the first one bit for bit against prover()
-            okv = ctx.to_host(ctx.verify(inst["d_ssp"], inst["alpha"], inst["beta"], inst["s"], inst["sk"], s_pr, s_count))
-            ok_s = [bool(int(x)) for x in okv] == s_valid[s_first:s_first + s_count]
-            one = ctx.prove(d_crs, inst["d_ssp"], s_bits[s_first], s_delta[s_first], s_mags[s_first], s_signs[s_first])
-            ok_s = ok_s and bool(torch.equal(s_pr.view(s_count, -1)[0], one))
-        ta = torch.tensor([1 if ok_s else 0], dtype=torch.int64, device=ctx.device)
-        dist.all_reduce(ta, op=dist.ReduceOp.MIN)
-        ok_s = bool(int(ta.item()))
-        per_s = -(-nbt // world)
-        lps = 5 * (p.n + 1) * p.lanes
-        share_img = int(ctx.lib.mfh_crs_mm_share_bytes(ctx._h, rank, world))
-        sharded_b = {"value": nbt * sh_steps / el_s, "unit": "proofs/s", "scaling": "strong", "steps": sh_steps, "ms_per_step": el_s / sh_steps * 1e3,
-                     "statements_per_step_whole_job": nbt, "ranks": world, "backend": backend + (" (RCCL)" if backend == "nccl" else " (host-staged rehearsal)"),
-                     "own_proofs_accepted_rejected_as_expected_and_identical_to_prover": ok_s,
-                     "collectives_per_step": ([{"op": "all_to_all_single", "what": "generator-defined SSP: the rank's coefficient range of w of every statement to the statement's owner "
-                                                                                    "(the witness pass sharded by coefficient range: 1/N of the generation per rank)",
-                                                "bytes_sent_per_rank": nbt * 4 * (p.d // world) * (world - 1) // world}] if inst["d_ssp"] is None and all(
-                                                    (p.d * r // world) % 128 == 0 for r in range(world + 1)) else []) + [
-                         {"op": "all_to_all_single", "what": "rows [d r/N, d (r+1)/N) of w | h | v of every statement to rank r",
-                          "bytes_sent_per_rank": per_s * 3 * 4 * (p.d - p.d // world)},
-                         {"op": "reduce_scatter_tensor(sum, int64 lanes)", "what": "the 5 partial ciphertexts of every statement as uint64 lanes of 56 bits (13 per 704-bit value, 27 at logq 1472)",
-                          "input_bytes_per_rank": per_s * world * lps * 8, "output_bytes_per_rank": per_s * lps * 8}],
-                     "reduce_scatter_bytes_per_rank_per_step": {"in": per_s * world * lps * 8, "out": per_s * lps * 8},
-                     "note": ("the reduce-scatter carries 0.76 MB of uint64 lanes per statement (1.29 MB in rounds 1 - 3: one lane per 32-bit word) into every rank whatever the instance size, while the row work per "
-                              "rank shrinks with D / N: at the default instance (D = 2^15) this leg is collective-bound and REPLICAS (the headline `value`) are "
-                              "the better use of N GPUs; row sharding is for CRS images that do not fit one GPU (config 4/5: 45 / 90 GB per GPU on 8)"),
-                     "image_share_bytes_per_rank": share_img,
-                     "image": "transient: every call expands the rank's row shares (AES on the CU) inside the timed region" if kt_s["expandmm"][0] else
-                              ("regenerated per group" if kt_s["evalmm"][0] else "resident"),
-                     "roofline": mmstream_roofline(kt_s, el_s / sh_steps * 1e3, sh_steps) if (kt_s["evalmm_resident"][0] + kt_s["mmstream_rounds"][0]) else None,
-                     "crs_expansion": expand_info(kt_s["expandmm"], sh_steps)}
-        del sbufs, s_pr
 
     # ---- LWE batch (BASELINE config 1/2: one batch of 65 536 encryptions, rows at stream offset k*135240)
     enc_per_s = None
@@ -862,7 +790,8 @@ def main():
             cpu["note"] = ("the oracle's table AES is faster than the reference's OpenSSL AES_encrypt path; reference_* fields time the real "
                            "reference aes.c/entropy.c (92-byte reads, as ct_import does) on this host")
 
-    if rank == 0:
+    def emit(sharded_b, single_rows):
+        """rank 0: assemble and print THE json line (called once: at the end, or by the watchdog of the collective legs); returns the overall acceptance"""
         launch_rows = rows2 / max(n2, 1)
         avg_ms = ms2 / max(n2, 1)
         row_bytes = (p.n + 1) * p.ctb
@@ -970,6 +899,7 @@ def main():
             "resident_crs_batch": batched["resident_crs"] if batched else None,
             "device_verifier_proofs_per_s": batched["device_verifier_proofs_per_s"] if batched else None,
             "row_sharded_batch": sharded_b,
+            "single_proof_row_sharded": single_rows,
             "lwe": lwe,
             "lwe_dec_per_s": dec["value"] if dec else None,
             "lwe_decrypt": dec,
@@ -980,10 +910,156 @@ def main():
         }
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
-        accepted = ok_all
+        return ok_all
+    # ---- the legs that need the data-path backend (RCCL), last and under a watchdog ---------------------------------------------------------------------
+    sharded_b, single_rows = None, None
+    emitted = threading.Event()
+
+    def on_timeout(limit):
+        # a collective has not completed: the main thread sits inside it and cannot be recovered.  Rank 0 prints the line with what has been measured (the
+        # headline needs no collective) and the legs marked, then every rank leaves; exit code 0 -- the measurement is valid, the marked legs are not
+        if emitted.is_set():
+            return
+        emitted.set()
+        msg = f"timed out after {limit:.0f} s: a collective of this leg did not complete on the {backend} backend"
+        print(f"[bench] rank {rank}: {msg}", file=sys.stderr, flush=True)
+        if rank == 0:
+            sb = sharded_b if isinstance(sharded_b, dict) else {"error": msg, "value": None, "unit": "proofs/s", "scaling": "strong", "ranks": world, "roofline": None,
+                                                                  "own_proofs_accepted_rejected_as_expected_and_identical_to_prover": False, "ms_per_step": None}
+            sr = single_rows if isinstance(single_rows, dict) else {"error": msg, "value": None}
+            try:
+                emit(sb, sr)
+            except BaseException as e:  # (never silent: without the line the run is lost)
+                print(f"[bench] rank 0: could not print the line from the watchdog: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+                os._exit(5)
+            os._exit(0)
+        os._exit(0)
+
+    watchdog = None
+    if world > 1 and (mode == "batch" or defer_rows):
+        limit = float(os.environ.get("MFUOCO_BENCH_COLLECTIVE_S", "300"))
+        watchdog = threading.Timer(limit, on_timeout, args=(limit,))
+        watchdog.daemon = True
+        watchdog.start()
+    if world > 1 and os.environ.get("MFUOCO_BENCH_TEST_HANG") == str(rank):  # (rehearsal of the watchdog: this rank never joins the collectives)
+        time.sleep(10 ** 6)
+    if defer_rows:
+        # one proof computed by all ranks together: CRS rows sharded, two lane all-reduces per proof (dist.prove_sharded)
+        try:
+            rb = {}
+            pr = None
+            for _ in range(max(args.warmup, 1)):
+                pr = mfdist.prove_sharded(ctx, d_crs, inst["d_ssp"], inst["bits"], delta, mags, signs, rank, world, bufs=rb)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(single_steps):
+                pr = mfdist.prove_sharded(ctx, d_crs, inst["d_ssp"], inst["bits"], delta, mags, signs, rank, world, bufs=rb)
+            barrier()
+            el_sr = ctl_reduce(time.perf_counter() - t0, dist.ReduceOp.MAX)
+            same_sr = bool(int(ctl_reduce(1 if torch.equal(pr, proof) else 0, dist.ReduceOp.MIN)))
+            single_rows = {"value": single_steps / el_sr, "unit": "proofs/s", "steps": single_steps, "ms_per_step": el_sr / single_steps * 1e3, "scaling": "strong",
+                           "sharding": f"CRS rows over {world} rank(s), 2 lane all-reduces per proof", "proof_identical_to_the_single_gpu_proof_on_every_rank": same_sr,
+                           "collectives_per_proof": [{"op": "all_reduce(sum, int64 lanes)", "what": "this rank's share of sum_bits v_i: the witness polynomial", "bytes": p.d * 8},
+                                                     {"op": "all_reduce(sum, int64 lanes)", "what": "the five partial ciphertexts, 56 bits per uint64 lane",
+                                                      "bytes": 5 * (p.n + 1) * p.lanes * 8}],
+                           "backend": backend + (" (RCCL)" if backend == "nccl" else " (host-staged rehearsal)")}
+            del rb, pr
+        except Exception as e:
+            single_rows = {"error": f"{type(e).__name__}: {e}", "value": None}
+            # the other ranks may sit in the collective this rank left: agree on the host group or leave (see the first-collectives block above)
+            try:
+                ctl_reduce(0, dist.ReduceOp.MIN)
+            except Exception:
+                os._exit(3)
+    # ---- N > 1: the row-sharded BATCH prover (BASELINE configs 3/4): one statement list for the whole job, CRS rows sharded over the ranks,
+    # all-to-all of the coefficient row slices + ONE reduce-scatter of uint64 lanes per step (dist.prove_batch_sharded)
+    sharded_b = None
+    if mode == "batch" and world > 1:
+        nbt = args.sharded_batch or (args.batch if not big else 255)
+        srng = np.random.default_rng(4000)  # the same statements on every rank
+        s_delta = [int(x) for x in srng.integers(0, mf.P, size=nbt, dtype=np.uint64)]
+        s_mags = [srng.integers(0, 256, size=5 * 80, dtype=np.uint8).tobytes() for _ in range(nbt)]
+        s_signs = [bytes(srng.integers(0, 2, size=5, dtype=np.uint8).tolist()) for _ in range(nbt)]
+        s_valid = [i % 2 == 0 for i in range(nbt)]
+        s_bits = [inst["bits"] if s_valid[i] else srng.bytes(len(inst["bits"])) for i in range(nbt)]
+        sbufs = {}
+        sh_steps = min(args.steps, 10 if not big else 3)
+
+        def sharded_step():
+            return mfdist.prove_batch_sharded(ctx, d_crs, inst["d_ssp"], s_bits, s_delta, s_mags, s_signs, rank, world, bufs=sbufs)
+
+        try:
+            for _ in range(max(args.warmup, 1) if not big else 1):
+                s_first, s_count, s_pr = sharded_step()
+            sharded_err = None
+        except Exception as e:  # (a collective the backend refuses fails on every rank alike: report it, keep the other legs)
+            sharded_err = f"{type(e).__name__}: {e}"
+    if mode == "batch" and world > 1 and sharded_err is not None:
+        sharded_b = {"error": sharded_err, "value": None, "unit": "proofs/s", "scaling": "strong", "ranks": world, "roofline": None,
+                     "own_proofs_accepted_rejected_as_expected_and_identical_to_prover": False, "ms_per_step": None,
+                     "statements_per_step_whole_job": nbt}
+    elif mode == "batch" and world > 1:
+        ctx.set_timing(True)
+        for k in ("evalmm", "mmstream_rounds", "evalmm_resident", "expandmm"):
+            ctx.timing_drain(k)
+        barrier()
+        ts = time.perf_counter()
+        for _ in range(sh_steps):
+            s_first, s_count, s_pr = sharded_step()
+        barrier()
+        el_s = time.perf_counter() - ts
+        ctx.set_timing(False)
+        kt_s = {}
+        for k in ("evalmm", "mmstream_rounds", "evalmm_resident", "expandmm"):
+            n_, ms_, rows_ = ctx.timing_drain(k)
+            kt_s[k] = (n_, ms_, rows_, ctx.timing_busy_ms(), ctx.timing_work_rows())
+        el_s = ctl_reduce(el_s, dist.ReduceOp.MAX)
+        ok_s = True
+        if s_count:  # the rank's own proofs: accepted / rejected as the witnesses demand, and the first one bit for bit against prover()
+            okv = ctx.to_host(ctx.verify(inst["d_ssp"], inst["alpha"], inst["beta"], inst["s"], inst["sk"], s_pr, s_count))
+            ok_s = [bool(int(x)) for x in okv] == s_valid[s_first:s_first + s_count]
+            one = ctx.prove(d_crs, inst["d_ssp"], s_bits[s_first], s_delta[s_first], s_mags[s_first], s_signs[s_first])
+            ok_s = ok_s and bool(torch.equal(s_pr.view(s_count, -1)[0], one))
+        ok_s = bool(int(ctl_reduce(1 if ok_s else 0, dist.ReduceOp.MIN)))
+        per_s = -(-nbt // world)
+        lps = 5 * (p.n + 1) * p.lanes
+        share_img = int(ctx.lib.mfh_crs_mm_share_bytes(ctx._h, rank, world))
+        sharded_b = {"value": nbt * sh_steps / el_s, "unit": "proofs/s", "scaling": "strong", "steps": sh_steps, "ms_per_step": el_s / sh_steps * 1e3,
+                     "statements_per_step_whole_job": nbt, "ranks": world, "backend": backend + (" (RCCL)" if backend == "nccl" else " (host-staged rehearsal)"),
+                     "own_proofs_accepted_rejected_as_expected_and_identical_to_prover": ok_s,
+                     "collectives_per_step": ([{"op": "all_to_all_single", "what": "generator-defined SSP: the rank's coefficient range of w of every statement to the statement's owner "
+                                                                                    "(the witness pass sharded by coefficient range: 1/N of the generation per rank)",
+                                                "bytes_sent_per_rank": nbt * 4 * (p.d // world) * (world - 1) // world}] if inst["d_ssp"] is None and all(
+                                                    (p.d * r // world) % 128 == 0 for r in range(world + 1)) else []) + [
+                         {"op": "all_to_all_single", "what": "rows [d r/N, d (r+1)/N) of w | h | v of every statement to rank r",
+                          "bytes_sent_per_rank": per_s * 3 * 4 * (p.d - p.d // world)},
+                         {"op": "reduce_scatter_tensor(sum, int64 lanes)", "what": "the 5 partial ciphertexts of every statement as uint64 lanes of 56 bits (13 per 704-bit value, 27 at logq 1472)",
+                          "input_bytes_per_rank": per_s * world * lps * 8, "output_bytes_per_rank": per_s * lps * 8}],
+                     "reduce_scatter_bytes_per_rank_per_step": {"in": per_s * world * lps * 8, "out": per_s * lps * 8},
+                     "note": ("the reduce-scatter carries 0.76 MB of uint64 lanes per statement (1.29 MB in rounds 1 - 3: one lane per 32-bit word) into every rank whatever the instance size, while the row work per "
+                              "rank shrinks with D / N: at the default instance (D = 2^15) this leg is collective-bound and REPLICAS (the headline `value`) are "
+                              "the better use of N GPUs; row sharding is for CRS images that do not fit one GPU (config 4/5: 45 / 90 GB per GPU on 8)"),
+                     "image_share_bytes_per_rank": share_img,
+                     "image": "transient: every call expands the rank's row shares (AES on the CU) inside the timed region" if kt_s["expandmm"][0] else
+                              ("regenerated per group" if kt_s["evalmm"][0] else "resident"),
+                     "roofline": mmstream_roofline(kt_s, el_s / sh_steps * 1e3, sh_steps) if (kt_s["evalmm_resident"][0] + kt_s["mmstream_rounds"][0]) else None,
+                     "crs_expansion": expand_info(kt_s["expandmm"], sh_steps)}
+        del sbufs, s_pr
+
+    if watchdog is not None:
+        watchdog.cancel()
+    if emitted.is_set():  # (the watchdog fired while the last collective was returning: it prints and exits)
+        time.sleep(3600)
+
+    if rank == 0:
+        emitted.set()
+        accepted = emit(sharded_b, single_rows)
     if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        try:
+            dist.barrier(group=ctl_group)
+            dist.destroy_process_group()
+        except Exception as e:  # (a rank that left through its watchdog is not coming: the line is out, nothing to wait for)
+            print(f"[bench] rank {rank}: closing barrier failed ({type(e).__name__})", file=sys.stderr, flush=True)
     return 0 if accepted else 1
 
 
