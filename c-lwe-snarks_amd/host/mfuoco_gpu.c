@@ -12,12 +12,14 @@
  */
 #define _GNU_SOURCE
 #include <errno.h>
+#include <pthread.h>
 #include <stdbool.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <strings.h>
 #include <sys/random.h>
+#include <unistd.h>
 
 #include <gmp.h>
 
@@ -86,6 +88,45 @@ static void *xcalloc(size_t n, size_t size)
   if (!p) die("out of host memory");
   return p;
 }
+/* mpz_t <-> limb conversions of a batch on a few host threads (distinct mpz_t: GMP is re-entrant).  Plain pthreads, created and joined per call: no runtime that
+ * keeps spinning worker threads around a process whose other threads feed a GPU (an OpenMP team did exactly that on the 16-core share of a many-core box and made every
+ * call 10 x slower).  $MFUOCO_HOST_THREADS (default 8, at most 64; 1 = the calling thread only). */
+struct par_job { void (*fn)(size_t lo, size_t hi, void *arg); void *arg; size_t lo, hi; };
+static void *par_worker(void *p)
+{
+  struct par_job *j = p;
+  j->fn(j->lo, j->hi, j->arg);
+  return NULL;
+}
+static void parallel_for(size_t n, void (*fn)(size_t lo, size_t hi, void *arg), void *arg)
+{
+  static int nthreads;
+  if (!nthreads) {
+    const char *e = getenv("MFUOCO_HOST_THREADS");
+    long want = e && *e ? atol(e) : 8, have = sysconf(_SC_NPROCESSORS_ONLN);
+    nthreads = (int)(want < 1 ? 1 : want > 64 ? 64 : want);
+    if (have > 0 && nthreads > have) nthreads = (int)have;
+  }
+  int nt = nthreads;
+  if (n < 65536 || nt < 2) { /* (a single proof is 7 355 values: not worth a thread) */
+    fn(0, n, arg);
+    return;
+  }
+  pthread_t th[64];
+  struct par_job job[64];
+  int started = 0;
+  for (int t = 0; t < nt; t++) {
+    job[t] = (struct par_job){ fn, arg, n * (size_t)t / nt, n * (size_t)(t + 1) / nt };
+    if (t == nt - 1 || pthread_create(&th[t], NULL, par_worker, &job[t])) { /* the last slice (and any slice whose thread cannot be had) runs here */
+      job[t].hi = n;
+      fn(job[t].lo, n, arg);
+      break;
+    }
+    started++;
+  }
+  for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
+}
+
 /* OS entropy where the reference calls getrandom(2) (src/entropy.h, src/snark.c:40,62-65,140,185-189): EINTR and short reads are retried, the pool not
  * being initialised yet is waited for, and any other failure ends the process -- a buffer left undrawn would silently cost zero-knowledge */
 static void shim_random(void *buf, size_t bytes)
@@ -582,13 +623,40 @@ void mfuoco_gpu_prover_entropy(uint32_t *delta, uint8_t *mag, uint8_t *sign)
   }
 }
 
+struct conv_arg { proof_t *pis; ct_t *cts; uint64_t *h; };
+static mpz_t *proof_ct(struct proof *pk, size_t q) { return q == 0 ? pk->h : q == 1 ? pk->hat_h : q == 2 ? pk->hat_v : q == 3 ? pk->v_w : pk->b_w; }
+static void proofs_from_limbs(size_t lo, size_t hi, void *arg)
+{
+  struct conv_arg *a = arg;
+  const size_t per = 5 * (size_t)(GAMMA_N + 1);
+  for (size_t i = lo; i < hi; i++) from_limbs(proof_ct(a->pis[i / per], (i % per) / (GAMMA_N + 1))[i % (GAMMA_N + 1)], a->h + i * L_LIMBS);
+}
+static void proofs_to_limbs(size_t lo, size_t hi, void *arg)
+{
+  struct conv_arg *a = arg;
+  const size_t per = 5 * (size_t)(GAMMA_N + 1);
+  for (size_t i = lo; i < hi; i++) to_limbs(a->h + i * L_LIMBS, proof_ct(a->pis[i / per], (i % per) / (GAMMA_N + 1))[i % (GAMMA_N + 1)]);
+}
+static void cts_to_limbs(size_t lo, size_t hi, void *arg)
+{
+  struct conv_arg *a = arg;
+  for (size_t i = lo; i < hi; i++) to_limbs(a->h + i * L_LIMBS, a->cts[i / (GAMMA_N + 1)][i % (GAMMA_N + 1)]);
+}
+
 /* count proofs (5 ciphertexts each, struct proof order) from device limbs into initialised proof_t's */
 void mfuoco_gpu_proofs_to_host(proof_t *pis, const uint64_t *d_proofs, size_t count)
 {
-  for (size_t k = 0; k < count; k++) {
-    mpz_t *cts[5] = { pis[k]->h, pis[k]->hat_h, pis[k]->hat_v, pis[k]->v_w, pis[k]->b_w };
-    for (int q = 0; q < 5; q++) ct_from_dev(cts[q], d_proofs + (k * 5 + q) * CTL, GAMMA_N + 1);
+  /* slabs of up to 128 proofs: ONE device-to-host copy per slab (90 MB) instead of one per ciphertext, then the 5 x 1471 mpz_import per proof on all the cores
+   * a few host threads (parallel_for) -- at 255 statements per call the conversion was 2/3 of mfuoco_prover_batch's wall time */
+  const size_t slab = 128;
+  uint64_t *h = xmalloc((count < slab ? count : slab) * 5 * CTL * 8);
+  for (size_t k0 = 0; k0 < count; k0 += slab) {
+    const size_t nk = count - k0 < slab ? count - k0 : slab;
+    HK(hipMemcpy(h, d_proofs + k0 * 5 * CTL, nk * 5 * CTL * 8, hipMemcpyDeviceToHost));
+    struct conv_arg a = { pis + k0, NULL, h };
+    parallel_for(nk * 5 * (size_t)(GAMMA_N + 1), proofs_from_limbs, &a);
   }
+  free(h);
 }
 
 /* ---- the expanded CRS kept across prover calls (the materialised-CRS regime behind the reference's types) -------------------------------
@@ -781,11 +849,8 @@ void mfuoco_verifier_batch(ssp_t ssp, vrs_t vrs, proof_t *pis, size_t count, uin
   uint8_t *d_ok = NULL;
   HK(hipMalloc((void **)&d_proofs, count * 5 * CTL * 8));
   HK(hipMalloc((void **)&d_ok, count));
-  for (size_t k = 0; k < count; k++) {
-    mpz_t *cts[5] = { pis[k]->h, pis[k]->hat_h, pis[k]->hat_v, pis[k]->v_w, pis[k]->b_w };
-    for (int q = 0; q < 5; q++)
-      for (size_t j = 0; j <= GAMMA_N; j++) to_limbs(h + ((k * 5 + q) * (GAMMA_N + 1) + j) * L_LIMBS, cts[q][j]);
-  }
+  struct conv_arg ca = { pis, NULL, h };
+  parallel_for(count * 5 * (size_t)(GAMMA_N + 1), proofs_to_limbs, &ca);
   HK(hipMemcpy(d_proofs, h, count * 5 * CTL * 8, hipMemcpyHostToDevice));
   free(h);
   CK(mfh_verify(G.ctx, G.d_ssp, (uint32_t)vrs->alpha, (uint32_t)vrs->beta, (uint32_t)vrs->s, G.d_sk, d_proofs, count, d_ok));
@@ -805,8 +870,8 @@ void mfuoco_decrypt_batch(mpz_t *ms, sk_t sk, ct_t *cts, size_t count)
   uint32_t *d_m = NULL, *hm = xmalloc(count * 4);
   HK(hipMalloc((void **)&d_cts, count * CTL * 8));
   HK(hipMalloc((void **)&d_m, count * 4));
-  for (size_t k = 0; k < count; k++)
-    for (size_t j = 0; j <= GAMMA_N; j++) to_limbs(h + (k * (GAMMA_N + 1) + j) * L_LIMBS, cts[k][j]);
+  struct conv_arg ca = { NULL, cts, h };
+  parallel_for(count * (size_t)(GAMMA_N + 1), cts_to_limbs, &ca);
   HK(hipMemcpy(d_cts, h, count * CTL * 8, hipMemcpyHostToDevice));
   free(h);
   CK(mfh_decrypt(G.ctx, G.d_sk, d_cts, count, d_m));

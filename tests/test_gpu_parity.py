@@ -453,3 +453,30 @@ def test_decrypt_paths_agree_on_a_batch_and_recover_the_messages(gpu_ctx_factory
     assert torch.equal(auto, want) and torch.equal(valu, want) and torch.equal(rows, want)
     with pytest.raises(mf.MfhError):
         c.decrypt_rows(off + 4, B, d_sk, c8)  # rows must start at byte 0 or 8 of an AES block
+
+
+def test_digest128_is_a_function_of_every_byte(gpu_ctx_factory):
+    """mfh_digest128 (the cache key under which the host shim keeps an expanded CRS): equal buffers give equal digests, any single changed byte -- in the body,
+    in the last word, in a tail of 1 - 3 bytes -- changes both halves, and so does moving a word"""
+    import torch
+
+    import c_lwe_snarks_amd as mf
+
+    ctx = gpu_ctx_factory(mf.DEBUG)
+    g = torch.Generator(device="cuda").manual_seed(7)
+    for nbytes in (8039052, 4096, 92, 7, 5, 4, 1):
+        buf = torch.randint(0, 256, (nbytes + 8,), dtype=torch.uint8, device="cuda", generator=g)[:nbytes]
+        d0 = ctx.digest128(buf)
+        assert d0 == ctx.digest128(buf.clone()) and d0 != (0, 0)
+        for pos in {0, nbytes // 2, nbytes - 1}:
+            b2 = buf.clone()
+            b2[pos] ^= 0x40
+            d1 = ctx.digest128(b2)
+            assert d1[0] != d0[0] and d1[1] != d0[1], (nbytes, pos)
+        if nbytes >= 4096:
+            b3 = buf.clone()
+            b3[0:4], b3[8:12] = buf[8:12].clone(), buf[0:4].clone()  # two words swapped: a position-independent sum would not notice
+            assert ctx.digest128(b3) != d0
+    assert ctx.digest128(torch.zeros(16, dtype=torch.uint8, device="cuda"), 0) == (0, 0)
+    with pytest.raises(mf.MfhError):
+        ctx.digest128(torch.zeros(16, dtype=torch.uint8, device="cuda")[1:], 8)  # not 4-byte aligned
