@@ -943,12 +943,21 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
       rc = launch_chain(k);
       if (rc) return rc;
     }
-    size_t ib = 0;
-    for (uint32_t r = 0; r < nsl; r++) ib = std::max(ib, mfh_crs_mm_share_bytes(c, r, nsl));
-    if (c->batch_img_bytes < ib) {
+    // The slab count was sized from the free memory BEFORE this call's own scratch (w | h | v areas of every super-group, digit and partial-product areas) was
+    // reserved; when the slab image then does not fit, halve the slabs (twice as many, up to 256) instead of giving up: the result does not depend on the count.
+    for (;;) {
+      size_t ib = 0;
+      for (uint32_t r = 0; r < nsl; r++) ib = std::max(ib, mfh_crs_mm_share_bytes(c, r, nsl));
+      if (c->batch_img_bytes >= ib) break;
       if (c->batch_img) { hipDeviceSynchronize(); hipFree(c->batch_img); c->batch_img = nullptr; c->batch_img_bytes = 0; }
-      if (hipMalloc(&c->batch_img, ib) != hipSuccess) { c->batch_img = nullptr; (void)hipGetLastError(); c->err = "mfh_prove_batch: no room for a row slab of the CRS image"; return MFH_ENOMEM; }
-      c->batch_img_bytes = ib;
+      size_t mem_free = 0, mem_total = 0;
+      const bool fits = hipMemGetInfo(&mem_free, &mem_total) != hipSuccess || ib + ((size_t)8 << 30) <= mem_free;  // (leave room for the launches' workspaces)
+      if (fits && hipMalloc(&c->batch_img, ib) == hipSuccess) { c->batch_img_bytes = ib; break; }
+      c->batch_img = nullptr;
+      (void)hipGetLastError();
+      const uint32_t cap = std::min<uint32_t>(256u, std::max(1u, std::min(d, m)));
+      if (nsl >= cap || c->batch_slabs) { c->err = "mfh_prove_batch: no room for a row slab of the CRS image"; return MFH_ENOMEM; }
+      nsl = std::min(cap, nsl * 2);
     }
     rc = batch_ct_t(c, d_crs_c8, B);
     if (rc) return rc;
