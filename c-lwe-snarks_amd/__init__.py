@@ -308,7 +308,7 @@ class Context:
 
     def set_mm_stream(self, map=0, persistent=False, sync_mode=0, spin_max=64):
         """layout of a streaming launch with several groups: slot map (0 | 1), persistent one-workgroup-per-CU grid, rendezvous of the sharers (0 | 1 | 2)"""
-        self._chk(self.lib.mfh_set_mm_stream(self._h, int(map), 1 if persistent else 0, int(sync_mode), int(spin_max)))
+        self._chk(self.lib.mfh_set_mm_stream(self._h, int(map), int(persistent), int(sync_mode), int(spin_max)))
 
     def set_mm_chunk_rows(self, rows=0):
         """rows per row chunk of the matrix-core launches (<= 131071; 0 = default): smaller values force several chunks"""

@@ -99,6 +99,7 @@ struct mfh_ctx {
   // k_mmstream launches with several groups (mfh_set_mm_stream): slot -> (group, tile group) map, persistent grid, rendezvous of the sharers
   int mm_map = 1;
   bool mm_persist = true;
+  bool mm_wave1 = false;  // persistent grid with one wave per SIMD and 256 accumulators in AccVGPRs (k_mmstream_w)
   uint32_t mm_sync_mode = 0, mm_spin = 64;
   uint32_t *mm_sync = nullptr;  // 8 x 32 counters of the persistent grid's rendezvous
   uint32_t mm_chunk_rows = 131071;  // rows per row chunk of the matrix-core launches (int32 accumulators: |A'C'| <= 2^14 per row)

@@ -679,7 +679,13 @@ __device__ __forceinline__ void mmstream_body(const MmsImages &imgs, uint32_t mt
         const v4i b = ring[it % DEPTH];
         if (it + DEPTH < KSN * CH) ring[it % DEPTH] = bcur[(((it + DEPTH) / CH) * NQ2 + (it + DEPTH) % CH) * 64];
 #pragma unroll
-        for (int t = 0; t < RQ; t++) acc[t][q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[t][ks], b, acc[t][q], 0, 0, 0);
+        for (int t = 0; t < RQ; t++) {
+#ifdef MMS_ACC_ASM  // accumulators pinned to AccVGPRs (one wave per SIMD, 256 of them: MMS_SW=4 MMS_RQ=4): the compiler's own placement shuttles them through arch VGPRs and spills
+          asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+a"(acc[t][q]) : "v"(a[t][ks]), "v"(b));
+#else
+          acc[t][q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[t][ks], b, acc[t][q], 0, 0, 0);
+#endif
+        }
         __builtin_amdgcn_sched_barrier(0);  // keep [refill one ring slot, RQ MFMAs] as written: the reads stay DEPTH fragments ahead
       }
 #endif
@@ -698,6 +704,9 @@ __device__ __forceinline__ void mmstream_body(const MmsImages &imgs, uint32_t mt
     buf ^= 1;
   }
   const uint64_t Mtot = (uint64_t)mtiles * 16;
+#ifdef MMS_ACC_ASM
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // (the hazard recogniser does not see inside the asm MFMAs: their last results must have landed before they are read)
+#endif
 #pragma unroll
   for (int t = 0; t < RQ; t++) {
     if (mt0 + t >= mtiles) continue;
@@ -749,6 +758,141 @@ __global__ __launch_bounds__(SW * 64) void k_mmstream_p(MmsImages imgs, uint32_t
     uint32_t grp, tg;
     mms_item(xcd, (k % nblk) * 32 + cu, ngt, ngr, map, grp, tg);
     mmstream_body(imgs, mtiles, KS, nrows, rows_per_chunk, cdv, part, grp, tg, k / nblk, cd_stride, part_stride);
+  }
+}
+
+// ---- k_mmstream_w: the same GEMM with ONE wave per SIMD (round 4) -----------------------------------------------------------------------------------
+// k_mmstream is power-limited: what raises its clock is fewer bytes moved per MFMA.  Here a workgroup is 4 waves and a wave owns FOUR row tiles
+// (64 byte positions x 256 digit columns = 256 accumulator registers, all in AccVGPRs: the MFMAs are inline asm with "+a" operands -- left to itself the compiler
+// spreads 256 accumulators over both register files, shuttles them with v_accvgpr moves and spills), so every digit fragment read from LDS feeds 4 MFMAs instead
+// of 2: 256 KiB of LDS fragment reads per stage and CU instead of 512, the same L2 traffic.  With one wave per SIMD nothing hides a wave's own waits, so:
+//   * the digit fragments come from LDS in groups of four, two groups ahead (a ring of 16 fragments), one ds_read per fragment in use, and a group's LAST fragment
+//     is used first: LDS returns in order, so one s_waitcnt covers the group (the same trick for the four staging words of a k-step's ds_writes);
+//   * NOTHING is issued in a burst: the 4 ds_writes, 8 global loads and 16 ds_reads of a k-step are dealt one per fragment (4 MFMAs);
+//   * the ring runs across the stage boundary, so the stage's ONE barrier sits at the end of group 9 (its position and why one suffices: at the barrier), and
+//     it waits for the wave's ds_writes only (s_waitcnt lgkmcnt(4): the four fragment reads issued after them stay in flight).
+// Same operands, same partial products, same epilogues as k_mmstream; persistent grid only (mfh_set_mm_stream).
+constexpr int WSW = 4, WRQ = 4;
+__device__ __forceinline__ void mfma_acc(v4i &acc, const v4i &a, const v4i &b) {
+  asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mmstream_body_w(const MmsImages &imgs, uint32_t mtiles, uint32_t KS, uint32_t nrows, uint32_t rows_per_chunk,
+                                                const v4i *__restrict__ cdv, int *__restrict__ part, uint32_t grp, uint32_t tg, uint32_t chunk, uint64_t cd_stride,
+                                                uint64_t part_stride) {
+  __shared__ v4i bfrag[2][RT2 / 64][NQ2][64];  // 2 x 64 KiB
+  const uint32_t tid = threadIdx.x, lane = tid & 63;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t c16 = lane & 15, g4 = lane >> 4;
+  if (tg * 16 >= mtiles) return;  // (uniform)
+  const v4i *__restrict__ image = imgs.image[grp];
+  cdv += grp * cd_stride;
+  part += grp * part_stride;
+  const uint32_t mt0 = tg * 16 + wave * WRQ;
+  const uint32_t r0 = chunk * rows_per_chunk, r1 = min(nrows, r0 + rows_per_chunk);
+  if (r0 >= r1) return;  // (uniform)
+  constexpr int KSN = RT2 / 64;               // 4 k-steps per stage
+  constexpr int BPK = NQ2 * 64 / (WSW * 64);  // 4 staging words per thread and k-step
+  v4i acc[WRQ][NQ2];
+#pragma unroll
+  for (int t = 0; t < WRQ; t++)
+#pragma unroll
+    for (int q = 0; q < NQ2; q++) acc[t][q] = v4i{0, 0, 0, 0};
+  auto a_load = [&](int t, uint32_t u0, int ks) -> v4i {
+    const v4i *ap = image + ((uint64_t)min(mt0 + t, mtiles - 1) * KS + (u0 >> 6) + ks) * 64;  // scalar (clamped: the load is unconditional, see k_mmstream)
+    return ap[lane];
+  };
+  auto b_load = [&](uint32_t u0, int ks, int i) -> v4i {
+    const v4i *bp = cdv + (uint64_t)(u0 >> 6) * NQ2 * 64 + (uint64_t)ks * NQ2 * 64 + WSW * 64 * i;  // scalar
+    return bp[tid];
+  };
+  const uint32_t ulast = r0 + (r1 - r0 - 1) / RT2 * RT2;
+  v4i a[WRQ][KSN], bnr[KSN][BPK];
+#pragma unroll
+  for (int i = 0; i < KSN * BPK; i++) (&bfrag[0][0][0][0])[tid + WSW * 64 * i] = cdv[(uint64_t)(r0 >> 6) * NQ2 * 64 + tid + WSW * 64 * i];
+  __builtin_amdgcn_sched_barrier(0);
+  // The prologue issues its loads in the order they are outstanding at the head of a steady-state stage (vector-memory operations complete in issue order and
+  // s_waitcnt vmcnt(n) is a static count over all paths into the loop): B[0], then (B[ks], A[ks - 1]) for ks = 1 .. 3; A[3] is loaded by the stage's k-step 0.
+  const uint32_t ub1 = min(r0 + RT2, ulast);
+#pragma unroll
+  for (int i = 0; i < BPK; i++) bnr[0][i] = b_load(ub1, 0, i);
+#pragma unroll
+  for (int ks = 1; ks < KSN; ks++) {
+#pragma unroll
+    for (int i = 0; i < BPK; i++) bnr[ks][i] = b_load(ub1, ks, i);
+#pragma unroll
+    for (int t = 0; t < WRQ; t++) a[t][ks - 1] = a_load(t, r0, ks - 1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __syncthreads();
+  // The ring: 4 slots of 4 fragments; group G of a stage (16 per stage: 4 per k-step) lives in rg[G & 3] and is fetched two groups ahead, ONE ds_read per
+  // fragment of the group in use -- nothing of the loop is issued in a burst: with one wave per SIMD every instruction that is not an MFMA has to fit the gap
+  // the previous MFMA leaves (a burst of 8 loads + 4 ds_writes at the end of every k-step was a fifth of the stage).
+  v4i rg[4][4];
+  uint32_t buf = 0;
+  auto frag = [&](uint32_t b, int f) -> v4i { return bfrag[b][f >> 4][f & 15][lane]; };  // fragment f = 16 ks + q of buffer b
+#pragma unroll
+  for (int G = 0; G < 2; G++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) rg[G][j] = frag(0, 4 * G + j);
+  for (uint32_t u0 = r0; u0 < r1; u0 += RT2) {
+    const uint32_t un1 = min(u0 + RT2, ulast), un2 = min(u0 + 2 * RT2, ulast);
+    v4i *bnext = &bfrag[buf ^ 1][0][0][0];
+#pragma unroll
+    for (int ks = 0; ks < KSN; ks++) {
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int G = ks * 4 + g, Gn = G + 2;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int j = 3 - u;  // the group's last fragment first: LDS returns in order, one wait covers the group
+#pragma unroll
+          for (int t = WRQ - 1; t >= 0; t--) mfma_acc(acc[t][4 * g + j], a[t][ks], rg[G & 3][j]);
+          // one fragment of the group two ahead (groups 14, 15 reach into the next stage's buffer: its k-step 0, written before this stage's barrier)
+          rg[Gn & 3][u] = Gn < 16 ? frag(buf, 4 * Gn + u) : frag(buf ^ 1, 4 * (Gn - 16) + u);
+          // one memory operation of the k-step's twelve
+          if (g == 0) {  // this k-step's share of the next stage's digit fragments (loaded a stage ago) -> the other buffer; youngest staging word first
+            bnext[ks * NQ2 * 64 + tid + WSW * 64 * (BPK - 1 - u)] = bnr[ks][BPK - 1 - u];
+          } else if (g == 1) {  // ... and the staging words of the stage after
+            bnr[ks][u] = b_load(un2, ks, u);
+          } else if (g == 2) {  // the A fragments the previous k-step has finished with: k-step 3's take THIS stage's rows (they are used in its own k-step 3)
+            if (ks == 0) a[u][KSN - 1] = a_load(u, u0, KSN - 1);
+            else a[u][ks - 1] = a_load(u, un1, ks - 1);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (G == 9) {
+          // The stage's ONE barrier.  Buffer X[ks] is written in group 4 ks of stage s (for stage s + 1), fetched for stage s + 1 in groups 4 ks - 2 .. 4 ks + 1
+          // (k-step 0: from group 14 of stage s) and was last fetched for stage s - 1 two groups before its use: every write / first-fetch and last-fetch /
+          // write pair has the end of group 9 of one of the stages between them.  Only the ds_writes have to have landed: the four fragment reads issued after
+          // the last of them (group 9's) may still be in flight.
+          asm volatile("s_waitcnt lgkmcnt(4)\n\ts_barrier" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    buf ^= 1;
+  }
+  __syncthreads();  // (every wave is out of the item's last stage before the next item's prologue rewrites buffer 0)
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the hazard recogniser does not see inside the asm MFMAs: their last results must have landed
+  const uint64_t Mtot = (uint64_t)mtiles * 16;
+#pragma unroll
+  for (int t = 0; t < WRQ; t++) {
+    if (mt0 + t >= mtiles) continue;
+    int *p = part + ((uint64_t)chunk * Mtot + (uint64_t)(mt0 + t) * 16) * N2;
+#pragma unroll
+    for (int q = 0; q < NQ2; q++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) p[(uint64_t)(4 * g4 + e) * N2 + 16 * q + c16] = acc[t][q][e];
+  }
+}
+__global__ __launch_bounds__(WSW * 64) void k_mmstream_w(MmsImages imgs, uint32_t mtiles, uint32_t KS, uint32_t nrows, uint32_t rows_per_chunk,
+                                                         const v4i *__restrict__ cdv, int *__restrict__ part, uint32_t ngt, uint32_t ngr, uint32_t map,
+                                                         uint64_t cd_stride, uint64_t part_stride, uint32_t nblk, uint32_t nchunks) {
+  const uint32_t xcd = blockIdx.x & 7, cu = blockIdx.x >> 3;
+  for (uint32_t k = 0; k < nblk * nchunks; k++) {
+    uint32_t grp, tg;
+    mms_item(xcd, (k % nblk) * 32 + cu, ngt, ngr, map, grp, tg);
+    mmstream_body_w(imgs, mtiles, KS, nrows, rows_per_chunk, cdv, part, grp, tg, k / nblk, cd_stride, part_stride);
   }
 }
 
@@ -1530,7 +1674,10 @@ int mms_stream(mfh_ctx *c, const MmsPlan &P) {
     const uint32_t map = c->mm_map && 32 % P.ng == 0 ? 1u : 0u;
     const uint32_t slots = map ? (tgx + 32 / P.ng - 1) / (32 / P.ng) * (P.ngt / P.ng) * 32 : tgx * P.ngt;  // per XCD
     const bool persistent = c->mm_persist && c->ncu == 256 && (map || 32 % P.ngt == 0);
-    if (persistent) {
+    if (persistent && c->mm_wave1) {
+      hipLaunchKernelGGL(k_mmstream_w, dim3(256), dim3(WSW * 64), 0, c->stream, imgs, P.mtiles, KS, P.nrows, P.rpc, (const v4i *)P.cd, P.part, P.ngt, P.ng, map,
+                         (uint64_t)(P.cd_bytes / 16), (uint64_t)(P.part_bytes / 4), (slots + 31) / 32, P.nchunks);
+    } else if (persistent) {
       if (!c->mm_sync) HIP_TRY(c, hipMalloc(&c->mm_sync, 8 * 32 * sizeof(uint32_t)));
       HIP_TRY(c, hipMemsetAsync(c->mm_sync, 0, 8 * 32 * sizeof(uint32_t), c->stream));
       hipLaunchKernelGGL(k_mmstream_p, dim3(256), dim3(SW * 64), 0, c->stream, imgs, P.mtiles, KS, P.nrows, P.rpc, (const v4i *)P.cd, P.part, P.ngt, P.ng, map,
@@ -1667,9 +1814,10 @@ int mfh_crs_expand_mm(mfh_ctx *c, const uint8_t *d_crs_c8, uint8_t *d_image) { r
 // rows per row chunk of the matrix-core launches: an int32 accumulator holds at most 131 071 rows (the default); smaller values split
 // a region into more chunks (tuning / tests).  0 restores the default.
 int mfh_set_mm_stream(mfh_ctx *c, int map, int persistent, int sync_mode, uint32_t spin_max) {
-  if (!c || map < 0 || map > 1 || sync_mode < 0 || sync_mode > 2) return MFH_EINVAL;
+  if (!c || map < 0 || map > 1 || sync_mode < 0 || sync_mode > 2 || persistent < 0 || persistent > 2) return MFH_EINVAL;
   c->mm_map = map;
   c->mm_persist = persistent != 0;
+  c->mm_wave1 = persistent == 2;  // the one-wave-per-SIMD body (k_mmstream_w)
   c->mm_sync_mode = (uint32_t)sync_mode;
   c->mm_spin = spin_max;
   return MFH_OK;

@@ -234,8 +234,8 @@ int mfh_set_witness_per(mfh_ctx *ctx, uint32_t statements);
 int mfh_set_batch_launch(mfh_ctx *ctx, uint32_t groups_per_launch, int merge_regions);
 /* how a streaming launch with several groups is laid out on the chip (tuning; results do not depend on it).  map: 0 = a tile group's workgroups for all
  * groups of both regions are neighbours, 1 = the 32 workgroups an XCD runs at a time are 32 / g tile groups x the g groups of ONE region (a group's digit
- * fragments are then shared by twice as many workgroups of the XCD).  persistent: one workgroup per CU looping over its XCD's items instead of one workgroup
- * per item; sync_mode (persistent only): 0 = none, 1 = the workgroups that stream the same fragments begin every item together, 2 = all workgroups of an XCD
+ * fragments are then shared by twice as many workgroups of the XCD).  persistent: 1 = one workgroup per CU looping over its XCD's items instead of one workgroup
+ * per item (default), 2 = the same grid with the one-wave-per-SIMD body (k_mmstream_w: 256 accumulators per wave in AccVGPRs, half the LDS reads; measured the same time); sync_mode (persistent only): 0 = none, 1 = the workgroups that stream the same fragments begin every item together, 2 = all workgroups of an XCD
  * do -- a speed-only rendezvous bounded by spin_max polls (a workgroup never waits longer, so the grid drains whatever is resident). */
 int mfh_set_mm_stream(mfh_ctx *ctx, int map, int persistent, int sync_mode, uint32_t spin_max);
 /* rows per row chunk of the matrix-core launches (mfh_eval_rows_multi, mfh_prove_batch): the int32 accumulators hold at most

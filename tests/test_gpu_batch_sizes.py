@@ -214,7 +214,7 @@ def test_batch_launch_shapes_give_identical_proofs(gpu_ctx_factory, ngl, merge):
     ctx.close()
 
 
-@pytest.mark.parametrize("layout", [(0, False, 0), (1, False, 0), (0, True, 0), (0, True, 1), (1, True, 1), (1, True, 2)])
+@pytest.mark.parametrize("layout", [(0, False, 0), (1, False, 0), (0, True, 0), (0, True, 1), (1, True, 1), (1, True, 2), (1, 2, 0), (0, 2, 0)])
 @pytest.mark.parametrize("nb,ngl,chunk_rows", [(250, 8, 0), (250, 4, 512), (130, 8, 0), (96, 4, 256), (33, 8, 0), (255, 2, 0)])
 def test_streaming_launch_layouts_give_identical_proofs(gpu_ctx_factory, layout, nb, ngl, chunk_rows):
     """mfh_set_mm_stream: which workgroup takes which (group, tile group) of a streaming launch (map 0 | 1), one workgroup per item or a persistent

@@ -15,6 +15,8 @@ d_crs = ctx.setup(inst["d_ssp"], inst["alpha"], inst["beta"], inst["s"], inst["s
 rng = np.random.default_rng(5)
 nb = 992
 ctx.set_batch_launch(8, bool(int(sys.argv[1])) if len(sys.argv) > 1 else True)
+if os.environ.get("MFUOCO_MM_WAVE1") == "1":
+    ctx.set_mm_stream(1, 2, 0, 0)
 deltas = [int(x) for x in rng.integers(0, mf.P, size=nb, dtype=np.uint64)]
 mags = [rng.integers(0, 256, size=400, dtype=np.uint8).tobytes() for _ in range(nb)]
 signs = [bytes(5)] * nb

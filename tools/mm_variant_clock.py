@@ -5,8 +5,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ["TMPDIR"] = "/tmp"
 out = {}
 for lib in sys.argv[1:]:
-    name = os.path.basename(lib)
-    env = dict(os.environ, MFHIP_LIB=os.path.abspath(lib))
+    lib, _, wave1 = lib.partition("@")  # lib.so@w: run with the one-wave-per-SIMD body (MFUOCO_MM_WAVE1=1, read by tools/batch_prof.py)
+    name = os.path.basename(lib) + ("@" + wave1 if wave1 else "")
+    env = dict(os.environ, MFHIP_LIB=os.path.abspath(lib), MFUOCO_MM_WAVE1="1" if wave1 else "0")
     vals = {}
     for gi, g in enumerate(["GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES", "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"]):
         d = f"/tmp/mvc_{name}_{gi}"
@@ -18,7 +19,7 @@ for lib in sys.argv[1:]:
             continue
         for f in glob.glob(d + "/*/*_counter_collection.csv"):
             for row in csv.DictReader(open(f)):
-                if "k_mmstream_p(" in row["Kernel_Name"]:
+                if "k_mmstream_p(" in row["Kernel_Name"] or "k_mmstream_w(" in row["Kernel_Name"]:
                     vals.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
     d = f"/tmp/mvc_{name}_st"
     subprocess.run(["rm", "-rf", d])
@@ -27,7 +28,7 @@ for lib in sys.argv[1:]:
     avg_ns = None
     for f in glob.glob(d + "/*/*_kernel_stats.csv"):
         for row in csv.DictReader(open(f)):
-            if "k_mmstream_p(" in row["Name"]:
+            if "k_mmstream_p(" in row["Name"] or "k_mmstream_w(" in row["Name"]:
                 avg_ns = float(row["AverageNs"])
     m = {c: sum(v) / len(v) for c, v in vals.items()}
     res = {"avg_launch_ms": avg_ns / 1e6 if avg_ns else None}
