@@ -135,6 +135,22 @@ def test_persistent_streaming_gemm_keeps_the_same_waits(asm_evalmm):
     assert not any(x.startswith("scratch_") for x in loop)
 
 
+def test_one_wave_per_simd_gemm_keeps_its_accumulators_in_accvgprs(asm_evalmm):
+    """k_mmstream_w: 256 accumulators pinned in AccVGPRs by inline-asm MFMAs -- no v_accvgpr move and no scratch in the stage loop (the compiler's own placement
+    made 600 moves per stage and spilled); memory operations dealt one per fragment (no two global loads back to back); ONE s_barrier per stage, behind a wait for
+    the wave's ds_writes only (lgkmcnt(4): the four fragment reads issued after them stay in flight); s_waitcnt merged per group (19, was 91)"""
+    body = _kernel(asm_evalmm, "_ZN12_GLOBAL__N_112k_mmstream_wE")
+    loop = _mfma_loop(body, 256)
+    assert sum("v_mfma_i32_16x16x64_i8 a[" in x for x in loop) == 256  # destination in AccVGPRs
+    assert not any(x.startswith(("v_accvgpr", "scratch_")) for x in loop)
+    assert sum(x.startswith("s_barrier") for x in loop) == 1
+    k = next(i for i, x in enumerate(loop) if x.startswith("s_barrier"))
+    assert re.search(r"s_waitcnt lgkmcnt\(4\)", loop[k - 1]), loop[k - 3:k + 1]
+    assert sum(x.startswith("s_waitcnt") for x in loop) <= 24
+    mem = [x.split()[0] for x in loop if x.startswith(("global_load", "ds_write", "ds_read", "v_mfma"))]
+    assert not any(a.startswith("global_load") and b.startswith("global_load") for a, b in zip(mem, mem[1:]))
+
+
 def test_expansion_kernel_has_no_scratch(tmp_path_factory):
     """k_expand_mm at 64 VGPRs (8 waves per SIMD): the lane offset of a piece's store is recomputed per piece; kept live it was spilled and
     reloaded before every store behind s_waitcnt vmcnt(0)"""
