@@ -481,6 +481,7 @@ def main():
         """roofline of k_mmstream from the launches that serve several groups (the S / AS rounds: the dominant shape); the single-group
         launches of the same kernel (b_w over the BT+BV rows: HBM-bound) are listed beside it and counted in whole_step"""
         kt, other = ktd["mmstream_rounds"], ktd["evalmm_resident"]
+        bwk = ktd.get("mmstream_bw", (0, 0.0, 0, 0.0, 0))
         if not kt[0]:
             kt, other = other, (0, 0.0, 0, 0.0, 0)
         n_, ms_, rows_, busy_, work_ = kt
@@ -493,7 +494,7 @@ def main():
         ops = 2.0 * mtile_rows * 256 * work                      # int8 multiply-adds x 2 per launch (M x N = 256 x K = rows x groups)
         tops = ops / (avg * 1e-3) / 1e12                         # per average launch duration: what rocprofv3 --stats reproduces
         tops_busy = ops / (eff * 1e-3) / 1e12                    # per union of launch spans (= tops when launches do not overlap)
-        ops_other = 2.0 * mtile_rows * 256 * other[4]               # (all single-group launches together)
+        ops_other = 2.0 * mtile_rows * 256 * (other[4] + bwk[4])    # (all single-group and b_w launches together)
         step_tops = (ops * n_ + ops_other) / (steps_ or args.steps) / (step_ms * 1e-3) / 1e12  # the kernel's operations of a step over the WHOLE step time
         gbs = regions * rows * tile_bytes_per_row / (avg * 1e-3) / 1e9  # one pass over each region's image
         return {"bound": "mfma", "kernel": "k_mmstream_p (persistent grid, one workgroup per CU: A fragments of the expanded CRS streamed once per launch and region for the "
@@ -508,6 +509,9 @@ def main():
                 "single_group_launches": ({"launches": other[0], "avg_launch_ms": other[1] / other[0], "rows_per_launch": other[2] / other[0],
                                            "what": "b_w: one byte column per proof over the BT+BV rows, one pass over that region's image per 255 proofs (HBM-bound)",
                                            "image_gbs": other[2] / other[0] * tile_bytes_per_row / (other[1] / other[0] * 1e-3) / 1e9} if other[0] else None),
+                "bw_launches": ({"kernel": "k_mmstream_pb: b_w of up to 8 super-groups (one byte column per proof, 255 per group) in one pass over the BT+BV image",
+                                 "launches": bwk[0], "avg_launch_ms": bwk[1] / bwk[0], "rows_per_launch": bwk[2] / bwk[0], "groups_per_launch": bwk[4] / bwk[2],
+                                 "int8_tops": 2.0 * mtile_rows * 256 * bwk[4] / bwk[0] / (bwk[1] / bwk[0] * 1e-3) / 1e12} if bwk[0] else None),
                 "achieved_by_busy_time": tops_busy, "frac_by_busy_time": tops_busy / MFMA_I8_PEAK_TOPS,
                 "whole_step": {"achieved": step_tops, "frac": step_tops / MFMA_I8_PEAK_TOPS,
                                "note": "this kernel's int8 operations of a step / ms_per_step: the matrix-core fraction of the whole job"},
@@ -563,7 +567,7 @@ def main():
             for _ in range(max(args.warmup - 1, 0)):
                 ctx.prove_batch(d_crs, d_ssp_b, b_bits, b_delta, b_mags, b_signs, out=out)
             ctx.set_timing(True)
-            for k in ("evalmm", "mmstream_rounds", "evalmm_resident", "expandmm"):
+            for k in ("evalmm", "mmstream_rounds", "mmstream_bw", "evalmm_resident", "expandmm"):
                 ctx.timing_drain(k)
             barrier()
             t_ = time.perf_counter()
@@ -573,7 +577,7 @@ def main():
             el = time.perf_counter() - t_
             ctx.set_timing(False)
             kt = {}
-            for k in ("evalmm", "mmstream_rounds", "evalmm_resident", "expandmm"):  # (rounds first: "evalmm_resident" then holds the single-group launches, b_w's)
+            for k in ("evalmm", "mmstream_rounds", "mmstream_bw", "evalmm_resident", "expandmm"):  # (rounds first: "evalmm_resident" then holds the single-group launches, b_w's)
                 n_, ms_, rows_ = ctx.timing_drain(k)
                 kt[k] = (n_, ms_, rows_, ctx.timing_busy_ms(), ctx.timing_work_rows())  # launches on two streams overlap: busy = union of their spans
             if dist is not None:
@@ -1000,7 +1004,7 @@ def main():
                      "statements_per_step_whole_job": nbt}
     elif mode == "batch" and world > 1:
         ctx.set_timing(True)
-        for k in ("evalmm", "mmstream_rounds", "evalmm_resident", "expandmm"):
+        for k in ("evalmm", "mmstream_rounds", "mmstream_bw", "evalmm_resident", "expandmm"):
             ctx.timing_drain(k)
         barrier()
         ts = time.perf_counter()
@@ -1010,7 +1014,7 @@ def main():
         el_s = time.perf_counter() - ts
         ctx.set_timing(False)
         kt_s = {}
-        for k in ("evalmm", "mmstream_rounds", "evalmm_resident", "expandmm"):
+        for k in ("evalmm", "mmstream_rounds", "mmstream_bw", "evalmm_resident", "expandmm"):
             n_, ms_, rows_ = ctx.timing_drain(k)
             kt_s[k] = (n_, ms_, rows_, ctx.timing_busy_ms(), ctx.timing_work_rows())
         el_s = ctl_reduce(el_s, dist.ReduceOp.MAX)

@@ -90,7 +90,7 @@ EXPORTS = [
     "mfh_encrypt_rows", "mfh_decrypt", "mfh_ct_smudge", "mfh_ssp_upload", "mfh_witness_poly", "mfh_version",
     "mfh_workspace_bytes", "mfh_last_kernel_ms", "mfh_set_timing", "mfh_set_overlap", "mfh_eval_rows_multi", "mfh_prove_batch", "mfh_crs_mm_image_bytes", "mfh_crs_expand_mm", "mfh_crs_set_resident_mm", "mfh_witness_poly_multi", "mfh_witness_poly_mm", "mfh_poly_h_multi", "mfh_poly_mul", "mfh_poly_add", "mfh_poly_prepare_t",
     "mfh_ssp_prepare", "mfh_poly_h", "mfh_setup_messages", "mfh_setup", "mfh_prove",
-    "mfh_prove_partial", "mfh_prove_finish", "mfh_ct_to_lanes", "mfh_ct_from_lanes", "mfh_lanes_per_value", "mfh_digest128", "mfh_timing_drain", "mfh_timing_busy_ms", "mfh_timing_work_rows", "mfh_set_batch_image", "mfh_set_batch_slabs", "mfh_set_expand_path", "mfh_set_encrypt_path", "mfh_set_batch_launch", "mfh_set_mm_chunk_rows", "mfh_set_mm_stream", "mfh_add_dotp", "mfh_set_encrypt_chunks", "mfh_set_witness_per", "mfh_set_eval_path", "mfh_set_decrypt_path", "mfh_decrypt_rows",
+    "mfh_prove_partial", "mfh_prove_finish", "mfh_ct_to_lanes", "mfh_ct_from_lanes", "mfh_lanes_per_value", "mfh_digest128", "mfh_timing_drain", "mfh_timing_busy_ms", "mfh_timing_work_rows", "mfh_set_batch_image", "mfh_set_batch_slabs", "mfh_set_expand_path", "mfh_set_encrypt_path", "mfh_set_batch_launch", "mfh_set_batch_bw", "mfh_set_mm_chunk_rows", "mfh_set_mm_stream", "mfh_add_dotp", "mfh_set_encrypt_chunks", "mfh_set_witness_per", "mfh_set_eval_path", "mfh_set_decrypt_path", "mfh_decrypt_rows",
     "mfh_crs_mm_share_bytes", "mfh_crs_expand_mm_share", "mfh_crs_set_resident_mm_share", "mfh_batch_chain", "mfh_batch_witness_cols", "mfh_batch_chain_from_w", "mfh_witness_poly_mm_cols", "mfh_prove_batch_partial", "mfh_prove_batch_finish",
     "mfh_resident_row_bytes", "mfh_crs_expand", "mfh_eval_rows_resident", "mfh_crs_set_resident",
     "mfh_witness_lanes", "mfh_witness_from_lanes", "mfh_prove_partial_w", "mfh_verify",
@@ -178,6 +178,7 @@ def load_library():
         "mfh_set_mm_chunk_rows": (i32, [vp, u32]),
         "mfh_set_mm_stream": (i32, [vp, i32, i32, i32, u32]),
         "mfh_set_batch_launch": (i32, [vp, u32, i32]),
+        "mfh_set_batch_bw": (i32, [vp, i32]),
         "mfh_set_encrypt_path": (i32, [vp, i32]),
         "mfh_set_expand_path": (i32, [vp, i32]),
         "mfh_set_batch_slabs": (i32, [vp, u32]),
@@ -305,6 +306,10 @@ class Context:
     def set_batch_launch(self, groups_per_launch=4, merge_regions=True):
         """streaming regime of prove_batch: groups of 31 proofs per pass over a region's image; S and AS groups in one launch or two"""
         self._chk(self.lib.mfh_set_batch_launch(self._h, int(groups_per_launch), 1 if merge_regions else 0))
+
+    def set_batch_bw(self, merged=True):
+        """b_w of all super-groups of a call in one streaming launch per 8 of them (default) or one launch per super-group"""
+        self._chk(self.lib.mfh_set_batch_bw(self._h, 1 if merged else 0))
 
     def set_mm_stream(self, map=0, persistent=False, sync_mode=0, spin_max=64):
         """layout of a streaming launch with several groups: slot map (0 | 1), persistent one-workgroup-per-CU grid, rendezvous of the sharers (0 | 1 | 2)"""

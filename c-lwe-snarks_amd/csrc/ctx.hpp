@@ -111,6 +111,7 @@ struct mfh_ctx {
   uint32_t enc_chunks = 0;   // k_encrypt_mm: 0 = column chunks per row picked from the batch size, n = forced (mfh_set_encrypt_chunks; tuning)
   uint32_t witness_per = 0;  // batch chain: statements per witness GEMM pass, 0 = one pass per super-group (mfh_set_witness_per; A/B knob)
   uint32_t batch_slabs = 0;  // mfh_prove_batch: 0 = row slabs only when the image does not fit HBM (count picked from free memory), n = always n slabs
+  int batch_bw_merged = 1;  // b_w of all super-groups of a call in one streaming launch per 8 of them (mfh_set_batch_bw)
   int batch_merge = 1;     // the S and AS groups of a round in one streaming launch (0: two launches on two streams)
   uint32_t batch_ngl = 8;  // groups of 63 / 64 coefficient vectors per streaming launch and region (1..8; 8 = a super-group's S and AS regions in ONE launch)
   PinBuf pin_rows, pin_cw, pin_smudge;

@@ -760,6 +760,29 @@ __global__ __launch_bounds__(SW * 64) void k_mmstream_p(MmsImages imgs, uint32_t
     mmstream_body(imgs, mtiles, KS, nrows, rows_per_chunk, cdv, part, grp, tg, k / nblk, cd_stride, part_stride);
   }
 }
+// the same grid under another name for the launch that serves b_w of several super-groups (one-byte coefficient columns over the BT+BV image): profiles then show
+// the two launch shapes -- 16 groups x 32768 rows, matrix-core bound; up to 8 groups x 21845 rows -- as two rows
+__global__ __launch_bounds__(SW * 64) void k_mmstream_pb(MmsImages imgs, uint32_t mtiles, uint32_t KS, uint32_t nrows, uint32_t rows_per_chunk,
+                                                        const v4i *__restrict__ cdv, int *__restrict__ part, uint32_t ngt, uint32_t ngr, uint32_t map,
+                                                        uint64_t cd_stride, uint64_t part_stride, uint32_t nblk /* 32-slot blocks per XCD */, uint32_t nchunks,
+                                                        uint32_t *__restrict__ sync, uint32_t sync_mode, uint32_t spin_max) {
+  const uint32_t xcd = blockIdx.x & 7, cu = blockIdx.x >> 3;
+  const uint32_t members = sync_mode == 2 ? 32u : (map ? ngr : ngt);
+  uint32_t *ctr = sync + xcd * 32 + (sync_mode == 2 ? 0u : cu / members);
+  for (uint32_t k = 0; k < nblk * nchunks; k++) {
+    if (sync_mode && members > 1) {
+      if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t target = (k + 1) * members;
+        for (uint32_t spin = 0; spin < spin_max && __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; spin++) __builtin_amdgcn_s_sleep(8);
+      }
+      __syncthreads();
+    }
+    uint32_t grp, tg;
+    mms_item(xcd, (k % nblk) * 32 + cu, ngt, ngr, map, grp, tg);
+    mmstream_body(imgs, mtiles, KS, nrows, rows_per_chunk, cdv, part, grp, tg, k / nblk, cd_stride, part_stride);
+  }
+}
 
 // ---- k_mmstream_w: the same GEMM with ONE wave per SIMD (round 4) -----------------------------------------------------------------------------------
 // k_mmstream is power-limited: what raises its clock is fewer bytes moved per MFMA.  Here a workgroup is 4 waves and a wave owns FOUR row tiles
@@ -1664,7 +1687,7 @@ int mms_digits(mfh_ctx *c, const MmsPlan &P, const MmIo *ios, const uint32_t *nv
   return MFH_OK;
 }
 int mms_stream(mfh_ctx *c, const MmsPlan &P) {
-  Timer t(c, P.ngt > 1 ? 10 : 8, P.nrows, (uint64_t)P.nrows * P.ngt);  // kind 10 ("mmstream_rounds"): several groups per launch
+  Timer t(c, P.ngt > 1 ? (P.ND == 1 ? 14 : 10) : 8, P.nrows, (uint64_t)P.nrows * P.ngt);  // kind 10 ("mmstream_rounds"): several groups per launch; 14 ("mmstream_bw"): b_w of several super-groups
   const uint32_t KS = (P.nrows + RT2 - 1) / RT2 * (RT2 / 64), tgs = (P.mtiles + TPW - 1) / TPW;
   MmsImages imgs{};
   for (uint32_t g = 0; g < P.ngt; g++) imgs.image[g] = (const v4i *)P.img[g / P.ng];
@@ -1680,7 +1703,7 @@ int mms_stream(mfh_ctx *c, const MmsPlan &P) {
     } else if (persistent) {
       if (!c->mm_sync) HIP_TRY(c, hipMalloc(&c->mm_sync, 8 * 32 * sizeof(uint32_t)));
       HIP_TRY(c, hipMemsetAsync(c->mm_sync, 0, 8 * 32 * sizeof(uint32_t), c->stream));
-      hipLaunchKernelGGL(k_mmstream_p, dim3(256), dim3(SW * 64), 0, c->stream, imgs, P.mtiles, KS, P.nrows, P.rpc, (const v4i *)P.cd, P.part, P.ngt, P.ng, map,
+      hipLaunchKernelGGL(P.ND == 1 ? k_mmstream_pb : k_mmstream_p, dim3(256), dim3(SW * 64), 0, c->stream, imgs, P.mtiles, KS, P.nrows, P.rpc, (const v4i *)P.cd, P.part, P.ngt, P.ng, map,
                          (uint64_t)(P.cd_bytes / 16), (uint64_t)(P.part_bytes / 4), (slots + 31) / 32, P.nchunks, c->mm_sync, c->mm_sync_mode, c->mm_spin);
     } else {
       hipLaunchKernelGGL(k_mmstream, dim3(slots * 8, P.nchunks), dim3(SW * 64), 0, c->stream, imgs, P.mtiles, KS, P.nrows, P.rpc, (const v4i *)P.cd, P.part, P.ngt, P.ng,

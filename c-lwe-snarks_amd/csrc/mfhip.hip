@@ -1189,6 +1189,12 @@ int mfh_set_batch_launch(mfh_ctx *c, uint32_t groups_per_launch, int merge_regio
   return MFH_OK;
 }
 
+int mfh_set_batch_bw(mfh_ctx *c, int merged) {
+  if (!c) return MFH_EINVAL;
+  c->batch_bw_merged = merged != 0;
+  return MFH_OK;
+}
+
 int mfh_set_batch_image(mfh_ctx *c, int en) {
   if (!c) return MFH_EINVAL;
   c->batch_image = en != 0;
@@ -1220,6 +1226,7 @@ static int timing_kind(const char *which) {
   if (!strcmp(which, "expandmm")) return 9;
   if (!strcmp(which, "decrypt")) return 11;       // k_decrypt_mm (full ciphertexts from HBM)
   if (!strcmp(which, "decrypt_rows")) return 13;  // k_encrypt_mm run for mfh_decrypt_rows (seed-compressed ciphertexts)
+  if (!strcmp(which, "mmstream_bw")) return 14;      // the streaming launch that serves b_w of several super-groups (mfh_set_batch_bw)
   if (!strcmp(which, "mmstream_rounds")) return 10;  // the streaming launches that serve several groups (a subset of "evalmm_resident")
   return -1;
 }
@@ -1237,7 +1244,7 @@ int mfh_timing_drain(mfh_ctx *c, const char *which, uint64_t *count, double *tot
   std::vector<std::pair<float, float>> spans;  // [start, end) of every matching launch, relative to the first one's start event
   hipEvent_t base = nullptr;
   for (auto &t : c->timed) {
-    const bool match = t.kind == kind || (kind == 12 && (t.kind == 1 || t.kind == 2)) || (kind == 8 && t.kind == 10);
+    const bool match = t.kind == kind || (kind == 12 && (t.kind == 1 || t.kind == 2)) || (kind == 8 && (t.kind == 10 || t.kind == 14));
     if (!match) { keep.push_back(t); continue; }
     float ms = 0;
     if (hipEventElapsedTime(&ms, t.e0, t.e1) == hipSuccess) {
@@ -1259,7 +1266,7 @@ int mfh_timing_drain(mfh_ctx *c, const char *which, uint64_t *count, double *tot
   c->last_busy_ms = busy;
   c->last_work_rows = work;
   for (auto &t : c->timed) {
-    const bool match = t.kind == kind || (kind == 12 && (t.kind == 1 || t.kind == 2)) || (kind == 8 && t.kind == 10);
+    const bool match = t.kind == kind || (kind == 12 && (t.kind == 1 || t.kind == 2)) || (kind == 8 && (t.kind == 10 || t.kind == 14));
     if (!match) continue;
     c->ev_pool.push_back(t.e0);
     c->ev_pool.push_back(t.e1);

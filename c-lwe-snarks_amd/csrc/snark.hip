@@ -488,7 +488,7 @@ int batch_scratch(mfh_ctx *c, uint32_t nproofs, uint32_t whv /* w | h | v areas 
   const uint32_t d = c->P.d, m = c->P.m, n = c->P.n;
   const size_t ctl = (size_t)(n + 1) * ((c->P.logq + 63) / 64);
   const size_t nsg = ((size_t)nproofs + BSG_REGEN - 1) / BSG_REGEN;  // (the smaller super-group size: never fewer slots than a call uses)
-  B.nslots = nsg * (1 + 2 * ((BSG + BG - 1) / BG));  // multi-vector launches of the call
+  B.nslots = nsg * (2 + 2 * ((BSG + BG - 1) / BG));  // multi-vector launches of the call
   const size_t whv_b = (size_t)whv * 3 * BSG * d * 4;
   const size_t packed = ((size_t)BSG * ((m + 6) / 8) + 3) & ~(size_t)3;
   const size_t cw_b = packed + (size_t)BSG * 4;
@@ -660,7 +660,7 @@ int batch_bw(mfh_ctx *c, const uint8_t *d_crs_c8, uint32_t rank, uint32_t world,
 // d_cw: the super-group's staged area (batch_stage_host), or nullptr: staged here from h_bits / h_delta.
 int batch_rows_supergroup(mfh_ctx *c, const uint8_t *d_crs_c8, uint32_t rank, uint32_t world, uint32_t sg, const uint8_t *h_bits,
                           size_t bits_stride, const BatchCoef &co, uint64_t *sproofs, const BatchScratch &B, size_t &slot,
-                          const uint32_t *h_delta, hipEvent_t wait_ev, int accumulate = 0, const uint8_t *d_cw = nullptr) {
+                          const uint32_t *h_delta, hipEvent_t wait_ev, int accumulate = 0, const uint8_t *d_cw = nullptr, bool bw_done = false) {
   const uint32_t d = c->P.d, m = c->P.m, n = c->P.n;
   const uint32_t ctb = c->P.logq / 8;
   const size_t ctl = (size_t)(n + 1) * ((c->P.logq + 63) / 64);
@@ -669,7 +669,7 @@ int batch_rows_supergroup(mfh_ctx *c, const uint8_t *d_crs_c8, uint32_t rank, ui
   hipStream_t const main_stream = c->stream, side_stream = c->side;
   const uint32_t loS = (uint32_t)((uint64_t)d * rank / world), cS = (uint32_t)((uint64_t)d * (rank + 1) / world) - loS;
   int rc = MFH_OK;
-  {
+  if (!bw_done) {
     if (!d_cw) {
       // ---- b_w: the packed bits travel as they are (2.7 KB per statement at the default size; the digit kernel unpacks them), the deltas
       // behind them, through one pinned staging buffer and one copy
@@ -997,6 +997,31 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
   // BT+BV image -- could run in the background under the matrix-core bound S / AS launches.  Built and measured: on an unrestricted side
   // stream the call takes the same 81.5 ms, on a stream masked to 64 / 32 / 16 CUs 88.5 / 98.1 / 116.3 ms -- a k_mmstream workgroup pulls
   // ~18 GB/s whether 16 or 256 CUs stream, so fewer CUs only stretch the pass.  b_w stays in line.)
+  // b_w of ALL super-groups of the call in one streaming launch per (up to) 8 of them: b_w needs the witness bits only (staged above), so it does not have to wait
+  // for its super-group's turn, and 4 - 8 groups over the BT+BV image share its fragments in the XCDs' L2s like the S / AS groups of a super-group do (one group
+  // per launch is HBM-bound at 3.4 TB/s: 0.9 ms per super-group).  mfh_set_batch_bw(ctx, 0) restores one launch per super-group.
+  bool bw_done = false;
+  if (c->batch_bw_merged && nsg > 1 && mm_image_covers(c, (uint64_t)ctb0 * n * 2 * d, m)) {
+    const uint64_t ctr_ct = (uint64_t)ctb0 * n, pstride = 5 * ctl;
+    const uint32_t bstride = (m + 6) / 8;
+    const MmRegion reg = {ctr_ct * 2 * d, d_crs_c8 + (size_t)2 * d * ctb0};
+    for (uint32_t g0 = 0; g0 < nsg; g0 += 8) {
+      MmIo ios[8];
+      uint32_t nvs[8];
+      const uint32_t ng = std::min(8u, nsg - g0);
+      for (uint32_t k = 0; k < ng; k++) {
+        const uint32_t sgi = g0 + k, s0 = sgi * SG, sg = std::min(SG, nproofs - s0);
+        const uint8_t *d_cw = B.CW + (size_t)sgi * B.cw_stride;
+        ios[k] = MmIo{{nullptr, nullptr}, sg, {d_proofs + (size_t)s0 * 5 * ctl + 4 * ctl, nullptr}, sg, pstride, d_cw, bstride, B.SCZ + 256 * slot++};
+        ios[k].add_ct = B.CT_T;  // + delta_b ct_t (src/snark.c:143-145) in the epilogue
+        ios[k].add_scale = (const uint32_t *)(d_cw + B.cw_delta_off);
+        nvs[k] = sg;
+      }
+      rc = ng > 1 ? eval_rows_multi_io_regions(c, &reg, 1, m, ios, nvs, ng, 1, 0) : eval_rows_multi_io(c, reg.off, m, reg.c8, ios[0], nvs[0], 1, 0);
+      if (rc) return rc;
+    }
+    bw_done = true;
+  }
   for (uint32_t s0 = 0, sgi = 0; s0 < nproofs; s0 += SG, sgi++) {
     const uint32_t sg = std::min(SG, nproofs - s0);
     uint64_t *sproofs = d_proofs + (size_t)s0 * 5 * ctl;
@@ -1008,7 +1033,7 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
     HIP_TRY(c, hipStreamWaitEvent(main_stream, c->ev_wdone[sgi % nbuf], 0));
     // the multi-vector launches read their coefficient vectors where the polynomial step left them and write the proof structs in place (MmIo)
     rc = batch_rows_supergroup(c, d_crs_c8, 0, 1, sg, h_witness_bits + (size_t)s0 * bits_stride, bits_stride, co, sproofs, B, slot, h_delta + s0,
-                               c->ev_cdone[sgi % nbuf], 0, B.CW + (size_t)sgi * B.cw_stride);
+                               c->ev_cdone[sgi % nbuf], 0, B.CW + (size_t)sgi * B.cw_stride, bw_done);
     if (rc) return rc;
     if (sgi + 1 < nsg) {  // the next super-group's chain, into the other area (last read by super-group sgi - 1)
       HIP_TRY(c, hipEventRecord(c->ev_rdone[sgi % nbuf], main_stream));

@@ -232,6 +232,9 @@ int mfh_set_witness_per(mfh_ctx *ctx, uint32_t statements);
  * over a region's image (1..8, default 4), and whether the S and AS groups of a round share ONE launch (default) or run as two
  * launches on two streams. */
 int mfh_set_batch_launch(mfh_ctx *ctx, uint32_t groups_per_launch, int merge_regions);
+/* b_w (src/snark.c:143-155) of all super-groups of a streaming mfh_prove_batch call in ONE launch per up to 8 super-groups over the BT+BV image (default), or one
+ * launch per super-group (0; rounds 1 - 3).  Tuning; results do not depend on it. */
+int mfh_set_batch_bw(mfh_ctx *ctx, int merged);
 /* how a streaming launch with several groups is laid out on the chip (tuning; results do not depend on it).  map: 0 = a tile group's workgroups for all
  * groups of both regions are neighbours, 1 = the 32 workgroups an XCD runs at a time are 32 / g tile groups x the g groups of ONE region (a group's digit
  * fragments are then shared by twice as many workgroups of the XCD).  persistent: 1 = one workgroup per CU looping over its XCD's items instead of one workgroup

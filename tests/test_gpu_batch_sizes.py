@@ -257,6 +257,44 @@ def test_streaming_launch_layouts_give_identical_proofs(gpu_ctx_factory, layout,
     ctx.close()
 
 
+@pytest.mark.parametrize("nb,persistent", [(600, 1), (600, 0), (2300, 1), (300, 2)])
+def test_bw_of_all_super_groups_in_one_launch_gives_identical_proofs(gpu_ctx_factory, nb, persistent):
+    """mfh_set_batch_bw: b_w (src/snark.c:143-155) of all super-groups of a call in ONE streaming launch per up to 8 of them over the BT+BV image (default) against one
+    launch per super-group (rounds 1 - 3): 600 statements = 3 super-groups (a group count that does not divide 32: the non-persistent fallback), 2300 = 10 super-groups =
+    a launch of 8 and one of 2, 300 = 2 with the one-wave-per-SIMD body; delta ct_t lands in every statement's b_w either way"""
+    import sys
+
+    import torch
+
+    import c_lwe_snarks_amd as mf
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    p = mf.Params(d=512, m=300)
+    ctx = gpu_ctx_factory(p)
+    ctx.set_seed(SEED)
+    inst = bench.build_instance(mf, ctx, torch, p, 41)
+    ctx.ssp_prepare(inst["d_ssp"])
+    d_crs = ctx.setup(inst["d_ssp"], inst["alpha"], inst["beta"], inst["s"], inst["sk"], inst["err"])
+    rng = np.random.default_rng(nb)
+    bits, deltas, mags, signs = _statements(rng, p, nb, valid_bits=inst["bits"])
+    try:
+        ctx.set_mm_stream(1, persistent, 0, 0)
+        ctx.set_batch_bw(False)
+        want = ctx.prove_batch(d_crs, inst["d_ssp"], bits, deltas, mags, signs).clone()
+        ctx.set_batch_bw(True)
+        got = ctx.prove_batch(d_crs, inst["d_ssp"], bits, deltas, mags, signs)
+    finally:
+        ctx.set_mm_stream(1, 1, 0, 64)
+        ctx.set_batch_bw(True)
+    assert torch.equal(got, want)
+    for b in (0, 255, nb - 1):
+        one = ctx.prove(d_crs, inst["d_ssp"], bits[b], deltas[b], mags[b], signs[b])
+        assert torch.equal(got.view(nb, -1)[b], one)
+    ctx.close()
+
+
 @pytest.mark.parametrize("d,m,nb,nslabs,chunk_rows", [(256, 64, 40, 3, 0), (1152, 1000, 270, 5, 0), (1152, 1000, 64, 2, 256), (256, 10, 33, 12, 0)])
 def test_row_slabs_give_identical_proofs(gpu_ctx_factory, d, m, nb, nslabs, chunk_rows):
     """mfh_set_batch_slabs: the out-of-core form of mfh_prove_batch (what a 2^20-constraint CRS needs on one GPU) -- the CRS rows cut into

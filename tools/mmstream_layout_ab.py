@@ -1,7 +1,7 @@
 """Same-process, same-box A/B of k_mmstream's launch layouts (mfh_set_mm_stream / mfh_set_batch_launch) on the headline call:
 mfh_prove_batch, 1020 statements, default instance, CRS expanded inside the call.  Configurations are run round-robin REPS times so that
 clock / box drift hits all of them alike; every configuration's proofs are compared bit for bit with the first one's.  dev tool.
-usage: python tools/mmstream_layout_ab.py [--nb=1020] [--reps=3] [cfg ...]     cfg = name:map,persistent,sync,spin[,ngl]"""
+usage: python tools/mmstream_layout_ab.py [--nb=1020] [--reps=3] [cfg ...]     cfg = name:map,persistent,sync,spin[,ngl[,bw_merged]]"""
 import os, sys, time, json
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,10 +16,11 @@ for a in sys.argv[1:]:
     else:
         name, v = a.split(":")
         v = [int(x) for x in v.split(",")]
-        cfgs.append((name, v + [4] * (5 - len(v))))
+        v = v + [4] * (5 - len(v)) if len(v) < 5 else v
+        cfgs.append((name, v + [1] * (6 - len(v))))
 if not cfgs:
-    cfgs = [("base", [0, 0, 0, 0, 4]), ("map1", [1, 0, 0, 0, 4]), ("pers_map1_nosync", [1, 1, 0, 0, 4]), ("pers_map1_sync1", [1, 1, 1, 64, 4]),
-            ("pers_map1_sync2", [1, 1, 2, 64, 4]), ("pers_map0_sync1", [0, 1, 1, 64, 4])]
+    cfgs = [("base", [0, 0, 0, 0, 4, 0]), ("map1", [1, 0, 0, 0, 4, 0]), ("pers_map1_nosync", [1, 1, 0, 0, 4, 0]), ("pers_map1_sync1", [1, 1, 1, 64, 4, 0]),
+            ("pers_map1_sync2", [1, 1, 2, 64, 4, 0]), ("pers_map0_sync1", [0, 1, 1, 64, 4, 0])]
 p = mf.DEFAULT
 ctx = mf.Context(p, 0)
 ctx.set_seed(bytes((37 * i + 11) & 0xFF for i in range(40)))
@@ -35,9 +36,10 @@ out = ctx.prove_batch(d_crs, inst["d_ssp"], bits, deltas, mags, signs)
 ref = None
 res = {name: {"ms_call": [], "ms_launch": []} for name, _ in cfgs}
 for r in range(reps + 1):  # round 0 = warm-up + bit-identity
-    for name, (mp, pers, sync, spin, ngl) in cfgs:
+    for name, (mp, pers, sync, spin, ngl, bwm) in cfgs:
         ctx.set_batch_launch(ngl, True)
-        ctx.set_mm_stream(mp, bool(pers), sync, spin)
+        ctx.set_batch_bw(bool(bwm))
+        ctx.set_mm_stream(mp, int(pers), sync, spin)
         ctx.prove_batch(d_crs, inst["d_ssp"], bits, deltas, mags, signs, out=out)
         if r == 0:
             torch.cuda.synchronize()

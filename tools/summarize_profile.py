@@ -58,6 +58,7 @@ TRAFFIC = [
      "2 x 4.24 GB of A fragments once + 16 x 8 MB of digits read, 16 x 133 MB of int32 partial products written.  The workgroups consume 16 x 4.24 GB of fragments and 8096 x 8 MB of digit "
      "fragments out of the L2s; what an XCD's 32 concurrent workgroups (4 tile groups x 8 groups of one region) can share bounds the L2 misses at 4048 x (8.39 / 8 + 8 / 4) MB = 12.3 GB per 8 groups "
      "(24.7 GB per launch): DESIGN.md 4.2c"),
+    ("k_mmstream_pb(", "traffic_mmstream_bw.json", "k_mmstream_pb", "b_w of the call's super-groups (4 groups of 255 one-byte columns) in one persistent launch over the BT+BV image (2.83 GB of fragments)"),
     ("k_mmstream(", "traffic_mmstream_nonpersistent.json", "k_mmstream", "one workgroup per item (the layout of rounds 1-3, mfh_set_mm_stream(ctx, 0, 0, 0, 0)); only present when a profiled program selects it"),
     ("k_mmstream1(", "traffic_mmstream1.json", "k_mmstream1", "one group per launch: b_w's pass over the BT+BV image (2.83 GB of fragments), HBM-bound"),
     ("k_expand_mm", "traffic_expandmm.json", "k_expand_mm", "the barrier-free CRS expansion: reads the compressed CRS region (92 B per row), writes the image region (129 536 B per row)"),
