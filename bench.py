@@ -851,7 +851,7 @@ def main():
                     "proof_accepted": batched["valid_accepted_invalid_rejected_and_identical_to_single_proof_path"],
                     "config": {"workload": base_workload + f"; a step = {args.batch} statements per GPU (same circuit and CRS; half with the satisfying witness, half with random ones; own randomness) through "
                                            "mfh_prove_batch: every call expands the compressed CRS once (AES on the CU) into a transient image in HBM and streams it for every "
-                                           "super-group of 255 proofs (two launches of 4 + 4 groups of 63 / 64 coefficient vectors over the S / AS images, one over BT+BV), "
+                                           "super-group of 255 proofs (one persistent launch of 8 + 8 groups of 63 / 64 coefficient vectors over the S / AS images per super-group, one launch over BT+BV for b_w of all super-groups), "
                                            "the groups' multiply-accumulate on the matrix cores; every proof is bit-identical to "
                                            "the single-proof prover()'s",
                                "rows_per_proof": rows_crs, "statements_per_gpu_per_step": args.batch,
