@@ -39,7 +39,7 @@ size_t mfuoco_gpu_bits_stride(void);
 void mfuoco_gpu_witness_bits(uint8_t *bits, mpz_t witness);
 void mfuoco_gpu_prover_entropy(uint32_t *delta, uint8_t *mag, uint8_t *sign);
 void mfuoco_gpu_proofs_to_host(proof_t *pis, const uint64_t *d_proofs, size_t count);
-void mfuoco_gpu_image_resident_share(const uint8_t *d_crs, uint32_t rank, uint32_t world);
+void mfuoco_gpu_image_resident_share(const uint8_t *d_crs, uint32_t rank, uint32_t world, int expand);
 
 #define L_LIMBS 12
 #define K_LIMBS 11
@@ -316,7 +316,7 @@ void mfuoco_prover_batch_sharded(proof_t *pis, crs_t crs, ssp_t ssp, mpz_t *witn
 
   /* 3. the rank's row shares of the five ciphertexts of every statement (matrix cores; no delta ct_t term, un-smudged) */
   uint64_t *partial = scratch(c, 3, nb * 5 * CTL * 8);
-  if (nb > 31) mfuoco_gpu_image_resident_share(d_crs, (uint32_t)rank, (uint32_t)world); /* the rank's share of the image, kept across calls while the CRS is the same */
+  mfuoco_gpu_image_resident_share(d_crs, (uint32_t)rank, (uint32_t)world, nb > 31); /* the rank's share of the image, kept across calls while the CRS is the same */
   CK(mfh_prove_batch_partial(ctx, d_crs, (uint32_t)rank, (uint32_t)world, (uint32_t)nb, bits, stride, recv, recv + cs, recv + 2 * cs, 3 * cs, partial));
 
   /* 4. the partial ciphertexts as uint64 lanes of 56 bits, statements padded to `world` equal slabs; ONE reduce-scatter: the own slab, summed */

@@ -680,9 +680,15 @@ static bool fits_device(size_t need, size_t have)
   return need <= have || need - have + ((size_t)24 << 30) <= fr; /* leave room for the call's own scratch (w | h | v, partial products, the SSP's second image) */
 }
 /* matrix-core image (mfh_prove_batch / mfh_prove_batch_partial): rank's shares of `world`, the whole regions when world == 1 */
-static void image_resident_mm(const uint8_t *d_crs, uint32_t rank, uint32_t world)
+static void image_resident_mm(const uint8_t *d_crs, uint32_t rank, uint32_t world, bool expand)
 {
-  if (!resident_on() || d_crs != G.d_crs) return;
+  /* whatever this call does, an image registered for OTHER row shares must not meet it (mfh_prove_batch refuses a share image, mfh_prove_batch_partial one of
+   * another rank or world) */
+  if (G.img_registered && (G.img_rank != rank || G.img_world != world)) {
+    CK(mfh_crs_set_resident_mm(G.ctx, NULL));
+    G.img_registered = false;
+  }
+  if (!expand || !resident_on() || d_crs != G.d_crs) return;
   uint64_t dg[2];
   if (!G.staged_digest_valid) {
     CK(mfh_digest128(G.ctx, d_crs, (2 * (size_t)GAMMA_D + GAMMA_M) * CT_BYTES, G.staged_digest));
@@ -717,7 +723,7 @@ static void image_resident_mm(const uint8_t *d_crs, uint32_t rank, uint32_t worl
   G.img_digest[0] = dg[0];
   G.img_digest[1] = dg[1];
 }
-void mfuoco_gpu_image_resident_share(const uint8_t *d_crs, uint32_t rank, uint32_t world) { image_resident_mm(d_crs, rank, world); }
+void mfuoco_gpu_image_resident_share(const uint8_t *d_crs, uint32_t rank, uint32_t world, int expand) { image_resident_mm(d_crs, rank, world, expand != 0); }
 /* single-proof image (mfh_prove): expanded when prover() meets the same (seed, CRS) a second time; returns the image to register, or NULL */
 static const void *image_resident_rows(const uint8_t *d_crs)
 {
@@ -791,7 +797,7 @@ void mfuoco_prover_batch(proof_t *pis, crs_t crs, ssp_t ssp, mpz_t *witnesses, s
     mfuoco_gpu_witness_bits(bits + k * stride, witnesses[k]);
     mfuoco_gpu_prover_entropy(delta + k, mag + k * 5 * maglen, sign + k * 5);
   }
-  if (count > 31) image_resident_mm(d_crs, 0, 1); /* (smaller calls do not expand an image at all) */
+  image_resident_mm(d_crs, 0, 1, count > 31); /* (smaller calls do not expand an image at all; one kept from an earlier call is used if it still serves this CRS) */
   int rc = mfh_prove_batch(G.ctx, d_crs, d_ssp, (uint32_t)count, bits, stride, delta, mag, maglen, sign, d_out);
   explicit_bzero(mag, count * 5 * maglen); /* the smudging terms and deltas are the proofs' zero-knowledge: not left on the heap */
   explicit_bzero(sign, count * 5);
