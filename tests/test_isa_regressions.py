@@ -147,6 +147,10 @@ def test_one_wave_per_simd_gemm_keeps_its_accumulators_in_accvgprs(asm_evalmm):
     k = next(i for i, x in enumerate(loop) if x.startswith("s_barrier"))
     assert re.search(r"s_waitcnt lgkmcnt\(4\)", loop[k - 1]), loop[k - 3:k + 1]
     assert sum(x.startswith("s_waitcnt") for x in loop) <= 24
+    assert not any(x.startswith(("s_load", "s_buffer_load")) for x in loop)  # (scalar loads share lgkmcnt and return out of order: the hand-written lgkmcnt(4) assumes none)
+    # between the k-step's last ds_write and the barrier exactly the four fragment reads of group 9 are issued
+    w = max(i for i, x in enumerate(loop[:k]) if x.startswith("ds_write"))
+    assert sum(x.startswith("ds_read") for x in loop[w:k]) == 4 and not any(x.startswith("ds_write") for x in loop[w + 1:k])
     mem = [x.split()[0] for x in loop if x.startswith(("global_load", "ds_write", "ds_read", "v_mfma"))]
     assert not any(a.startswith("global_load") and b.startswith("global_load") for a, b in zip(mem, mem[1:]))
 
