@@ -1702,7 +1702,7 @@ int mms_stream(mfh_ctx *c, const MmsPlan &P) {
                          (uint64_t)(P.cd_bytes / 16), (uint64_t)(P.part_bytes / 4), (slots + 31) / 32, P.nchunks);
     } else if (persistent) {
       if (!c->mm_sync) HIP_TRY(c, hipMalloc(&c->mm_sync, 8 * 32 * sizeof(uint32_t)));
-      HIP_TRY(c, hipMemsetAsync(c->mm_sync, 0, 8 * 32 * sizeof(uint32_t), c->stream));
+      if (c->mm_sync_mode) HIP_TRY(c, hipMemsetAsync(c->mm_sync, 0, 8 * 32 * sizeof(uint32_t), c->stream));  // (the rendezvous counters; unused by default)
       hipLaunchKernelGGL(P.ND == 1 ? k_mmstream_pb : k_mmstream_p, dim3(256), dim3(SW * 64), 0, c->stream, imgs, P.mtiles, KS, P.nrows, P.rpc, (const v4i *)P.cd, P.part, P.ngt, P.ng, map,
                          (uint64_t)(P.cd_bytes / 16), (uint64_t)(P.part_bytes / 4), (slots + 31) / 32, P.nchunks, c->mm_sync, c->mm_sync_mode, c->mm_spin);
     } else {
