@@ -73,6 +73,13 @@ static void die(const char *what)
   fprintf(stderr, "libmfuoco_gpu: %s%s%s\n", what, G.ctx ? ": " : "", G.ctx ? mfh_last_error(G.ctx) : "");
   abort();
 }
+/* errno is the CALLER's: the reference's drivers test it after their own system calls (src/benchmark_eval.c:22-27 exits when errno > 0 after open / write / mmap), and
+ * the HIP runtime leaves ENOENT and friends behind on success (a missing amdgpu.ids on first use is enough).  Every exported function hands errno back as it found it. */
+static inline void errno_restore_(int *saved) { errno = *saved; }
+/* ... and the process starts with errno == 0, as it does with the reference's objects: the initialisers of the ROCm libraries this one pulls in probe files that need not
+ * exist (they run before this constructor: dependencies are initialised first) */
+__attribute__((constructor)) static void shim_clean_errno(void) { errno = 0; }
+#define KEEP_ERRNO int errno_keep_ __attribute__((cleanup(errno_restore_), unused)) = errno
 #define CK(call) do { if ((call) != MFH_OK) die(#call); } while (0)
 #define HK(call) do { if ((call) != hipSuccess) die(#call); } while (0)
 
@@ -146,6 +153,7 @@ static void shim_random(void *buf, size_t bytes)
 
 int mfuoco_gpu_set_device(int device)
 {
+  KEEP_ERRNO;
   if (G.ctx && G.device != device) {
     fprintf(stderr, "libmfuoco_gpu: the shim already runs on GPU %d; mfuoco_gpu_set_device(%d) must precede the first call\n", G.device, device);
     return -1;
@@ -166,11 +174,13 @@ static void drop_image(void)
 }
 void mfuoco_gpu_invalidate(void)
 {
+  KEEP_ERRNO;
   G.ssp_host = NULL;
   drop_image();
 }
 void mfuoco_gpu_set_resident_crs(int on)
 {
+  KEEP_ERRNO;
   G.resident_crs = on ? 1 : 0;
   if (!on) {
     drop_image();
@@ -245,6 +255,7 @@ typedef struct { uint8_t seed[40]; } shim_key;
 
 void aesctr_init(aesctr_ptr s, const uint8_t *key, const uint64_t nonce)
 {
+  KEEP_ERRNO;
   s->rem = 0;
   s->ctr = 0;
   shim_key *k = malloc(sizeof *k);
@@ -257,6 +268,7 @@ void aesctr_init(aesctr_ptr s, const uint8_t *key, const uint64_t nonce)
 
 void aesctr_clear(aesctr_ptr s)
 {
+  KEEP_ERRNO;
   if (!s) return;
   if (s->key) { memset(s->key, 0, sizeof(shim_key)); free(s->key); }
   memset(s, 0, sizeof(struct aesctr));
@@ -282,6 +294,7 @@ static void stream_set_pos(struct aesctr *s, uint64_t pos)
 
 void aesctr_prg(aesctr_ptr s, void *out, size_t bytes)
 {
+  KEEP_ERRNO;
   if (!bytes) return;
   use_seed(((shim_key *)s->key)->seed);
   uint64_t pos = stream_pos(s);
@@ -295,6 +308,7 @@ void aesctr_prg(aesctr_ptr s, void *out, size_t bytes)
 
 void rng_init(rng_t rs, uint8_t *rseed)
 {
+  KEEP_ERRNO;
   uint64_t nonce;
   memcpy(&nonce, rseed, 8);
   aesctr_init((aesctr_ptr)rs, rseed + 8, nonce);
@@ -304,6 +318,7 @@ void rng_seek(rng_t rs, size_t count) { stream_set_pos((aesctr_ptr)rs, count); }
 
 void mpz2_urandomb(mpz_ptr rop, rng_t rs, size_t nbits)
 {
+  KEEP_ERRNO;
   size_t limbs = (nbits + 63) / 64, bytes = nbits / 8;
   uint64_t *buf = calloc(limbs ? limbs : 1, 8);
   aesctr_prg((aesctr_ptr)rs, buf, bytes);
@@ -313,6 +328,7 @@ void mpz2_urandomb(mpz_ptr rop, rng_t rs, size_t nbits)
 }
 void mpz2_urandomb2(mpz_ptr rop, size_t nbits)
 {
+  KEEP_ERRNO;
   size_t limbs = (nbits + 63) / 64, bytes = nbits / 8;
   uint64_t *buf = calloc(limbs ? limbs : 1, 8);
   shim_random(buf, bytes);
@@ -333,6 +349,7 @@ void ct_zero(ct_t rop) { for (size_t i = 0; i <= GAMMA_N; i++) mpz_set_ui(rop[i]
 
 void ct_export(uint8_t *buf, ct_t ct)
 {
+  KEEP_ERRNO;
   bzero(buf, CT_BYTES);
   if (mpz_sizeinbase(ct[GAMMA_N], 2) > 8 * CT_BYTES) die("ct_export: b does not fit CT_BYTES");
   mpz_export(buf, NULL, -1, 1, -1, 0, ct[GAMMA_N]);
@@ -351,17 +368,20 @@ static void sample_a(ct_t ct, rng_t rng)
 
 void ct_import(ct_t ct, rng_t rng, uint8_t *buf)
 {
+  KEEP_ERRNO;
   sample_a(ct, rng);
   mpz_import(ct[GAMMA_N], LOGQ_BYTES, -1, 1, -1, 0, buf);
 }
 void decompress_encryption(ct_t c, rng_t rng, mpz_t b)
 {
+  KEEP_ERRNO;
   sample_a(c, rng);
   mpz_set(c[GAMMA_N], b);
 }
 
 void regev_encrypt2(ct_t c, rng_t rs, sk_t sk, mpz_t m, void (*chi)(mpz_t))
 {
+  KEEP_ERRNO;
   if (mpz_sgn(m) < 0 || mpz_cmp_ui(m, GAMMA_P) >= 0) die("regev_encrypt2: message must be < p (src/lwe.c:80)");
   struct aesctr *s = (struct aesctr *)rs;
   mpz_t e;
@@ -387,6 +407,7 @@ void regev_encrypt2(ct_t c, rng_t rs, sk_t sk, mpz_t m, void (*chi)(mpz_t))
 
 void regev_decrypt(mpz_t m, sk_t sk, ct_t ct)
 {
+  KEEP_ERRNO;
   gpu();
   uint32_t out;
   ct_to_dev(G.d_sk, sk, GAMMA_N);
@@ -398,6 +419,7 @@ void regev_decrypt(mpz_t m, sk_t sk, ct_t ct)
 
 void mpz_add_dotp(mpz_t rop, mpz_t a[], mpz_t b[], size_t len)
 {
+  KEEP_ERRNO;
   gpu();
   uint64_t r[L_LIMBS], *da, *db, *dr;
   /* rop may be an unreduced accumulator in the reference; only its value mod 2^704 survives the final modq */
@@ -420,6 +442,7 @@ void mpz_add_dotp(mpz_t rop, mpz_t a[], mpz_t b[], size_t len)
 
 void ct_smudge(ct_t ct)
 {
+  KEEP_ERRNO;
   gpu();
   uint8_t mag[GAMMA_LOG_SMUDGING / 8], sign;
   shim_random(mag, sizeof mag);
@@ -431,6 +454,7 @@ void ct_smudge(ct_t ct)
 
 void ct_add(ct_t rop, ct_t a, ct_t b)
 {
+  KEEP_ERRNO;
   gpu();
   ct_to_dev(G.d_ct[0], a, GAMMA_N + 1);
   ct_to_dev(G.d_ct[1], b, GAMMA_N + 1);
@@ -439,6 +463,7 @@ void ct_add(ct_t rop, ct_t a, ct_t b)
 }
 void ct_mul_ui(ct_t rop, ct_t a, uint64_t b)
 {
+  KEEP_ERRNO;
   gpu();
   if (b >= GAMMA_P) die("ct_mul_ui: scalar must be < p (src/lwe.c:133)");
   ct_to_dev(G.d_ct[0], a, GAMMA_N + 1);
@@ -447,6 +472,7 @@ void ct_mul_ui(ct_t rop, ct_t a, uint64_t b)
 }
 void ct_addmul_ui(ct_t rop, ct_t a, uint64_t b)
 {
+  KEEP_ERRNO;
   gpu();
   if (b >= GAMMA_P) die("ct_addmul_ui: scalar must be < p (src/lwe.c:143)");
   ct_to_dev(G.d_ct[0], a, GAMMA_N + 1);
@@ -457,6 +483,7 @@ void ct_addmul_ui(ct_t rop, ct_t a, uint64_t b)
 
 void eval_poly(ct_t rop, rng_t rng, uint8_t (*c8)[CT_BYTES], nmod_poly_t p, size_t d)
 {
+  KEEP_ERRNO;
   struct aesctr *s = (struct aesctr *)rng;
   use_seed(((shim_key *)s->key)->seed);
   if (d > 2 * (size_t)GAMMA_D + GAMMA_M) die("eval_poly: more rows than a CRS holds");
@@ -479,16 +506,19 @@ void eval_poly(ct_t rop, rng_t rng, uint8_t (*c8)[CT_BYTES], nmod_poly_t p, size
 /* ---- L3: SSP (host harness, src/ssp.c) --------------------------------------------------------------------- */
 void nmod_poly_export(void *buf_, nmod_poly_t *pp, size_t degree)
 {
+  KEEP_ERRNO;
   uint64_t *buf = buf_;
   for (size_t i = 0; i < degree; i++) buf[i] = nmod_poly_get_coeff_ui(*pp, i);
 }
 void nmod_poly_import(nmod_poly_t *pp, void *buf_, size_t degree)
 {
+  KEEP_ERRNO;
   uint64_t *buf = buf_;
   for (size_t i = 0; i < degree; i++) nmod_poly_set_coeff_ui(*pp, i, buf[i]);
 }
 void random_ssp(mpz_t input, uint8_t *circuit)
 {
+  KEEP_ERRNO;
   const size_t buflen = 8 * GAMMA_D;
   uint8_t *buf = malloc(buflen);
   uint64_t *t = calloc(GAMMA_D, 8), *out;
@@ -514,6 +544,7 @@ void proof_init(proof_t pi) { ct_init(pi->h); ct_init(pi->hat_h); ct_init(pi->ha
 void proof_clear(proof_t pi) { ct_clear(pi->h); ct_clear(pi->hat_h); ct_clear(pi->hat_v); ct_clear(pi->v_w); ct_clear(pi->b_w); }
 void crs_init(crs_t crs)
 {
+  KEEP_ERRNO;
   shim_random(crs->seed, sizeof(rseed_t));
   crs->s = malloc(CT_BYTES * GAMMA_D);
   crs->as = malloc(CT_BYTES * GAMMA_D);
@@ -541,6 +572,7 @@ static void ssp_resident(ssp_t ssp)
 
 void setup(crs_t crs, vrs_t vrs, ssp_t ssp)
 {
+  KEEP_ERRNO;
   gpu();
   use_seed(crs->seed);
   vrs->alpha = rand_modp_();
@@ -576,6 +608,7 @@ mfh_ctx *mfuoco_gpu_ctx(void) { return gpu(); }
 /* the CRS in keystream order s | as | t | v on the device (the order setup() encrypts in, src/snark.c:75-110) */
 const uint8_t *mfuoco_gpu_stage_crs(crs_t crs)
 {
+  KEEP_ERRNO;
   gpu();
   use_seed(crs->seed);
   HK(hipMemcpy(G.d_crs, crs->s, CT_BYTES * GAMMA_D, hipMemcpyHostToDevice));
@@ -598,6 +631,7 @@ const uint8_t *mfuoco_gpu_stage_crs(crs_t crs)
 
 const uint32_t *mfuoco_gpu_stage_ssp(ssp_t ssp)
 {
+  KEEP_ERRNO;
   gpu();
   ssp_resident(ssp);
   return G.d_ssp;
@@ -608,6 +642,7 @@ size_t mfuoco_gpu_bits_stride(void) { return (GAMMA_M + 7) / 8 + 8; }
 /* the witness as the little-endian bit string mfh_prove* take (bit i-1 selects v_i, src/snark.c:150) */
 void mfuoco_gpu_witness_bits(uint8_t *bits, mpz_t witness)
 {
+  KEEP_ERRNO;
   if (mpz_sizeinbase(witness, 2) > GAMMA_M + 8) die("prover: witness wider than M bits");
   mpz_export(bits, NULL, -1, 1, -1, 0, witness);
 }
@@ -615,6 +650,7 @@ void mfuoco_gpu_witness_bits(uint8_t *bits, mpz_t witness)
 /* entropy of one prover() call in the reference's order: delta (8 B), then 5 x [80 B magnitude, 1 B sign] (src/snark.c:140,185-189) */
 void mfuoco_gpu_prover_entropy(uint32_t *delta, uint8_t *mag, uint8_t *sign)
 {
+  KEEP_ERRNO;
   const size_t maglen = GAMMA_LOG_SMUDGING / 8;
   *delta = (uint32_t)rand_modp_();
   for (int q = 0; q < 5; q++) {
@@ -646,6 +682,7 @@ static void cts_to_limbs(size_t lo, size_t hi, void *arg)
 /* count proofs (5 ciphertexts each, struct proof order) from device limbs into initialised proof_t's */
 void mfuoco_gpu_proofs_to_host(proof_t *pis, const uint64_t *d_proofs, size_t count)
 {
+  KEEP_ERRNO;
   /* slabs of up to 128 proofs: ONE device-to-host copy per slab (90 MB) instead of one per ciphertext, then the 5 x 1471 mpz_import per proof on all the cores
    * a few host threads (parallel_for) -- at 255 statements per call the conversion was 2/3 of mfuoco_prover_batch's wall time */
   const size_t slab = 128;
@@ -762,6 +799,7 @@ static const void *image_resident_rows(const uint8_t *d_crs)
 
 void prover(proof_t pi, crs_t crs, ssp_t ssp, mpz_t witness)
 {
+  KEEP_ERRNO;
   const uint8_t *d_crs = mfuoco_gpu_stage_crs(crs);
   const uint32_t *d_ssp = mfuoco_gpu_stage_ssp(ssp);
   uint8_t bits[(GAMMA_M + 7) / 8 + 8] = { 0 };
@@ -785,6 +823,7 @@ void prover(proof_t pi, crs_t crs, ssp_t ssp, mpz_t witness)
  * [80-byte magnitude, sign byte].  pis[k] must be initialised (proof_init). */
 void mfuoco_prover_batch(proof_t *pis, crs_t crs, ssp_t ssp, mpz_t *witnesses, size_t count)
 {
+  KEEP_ERRNO;
   if (!count) return;
   const uint8_t *d_crs = mfuoco_gpu_stage_crs(crs);
   const uint32_t *d_ssp = mfuoco_gpu_stage_ssp(ssp);
@@ -821,6 +860,7 @@ static uint64_t horner_modp(const uint8_t *slot, uint64_t x)
 
 bool verifier(ssp_t ssp, vrs_t vrs, proof_t pi)
 {
+  KEEP_ERRNO;
   gpu();
   uint32_t dec[5];
   ct_to_dev(G.d_sk, vrs->sk, GAMMA_N);
@@ -847,6 +887,7 @@ bool verifier(ssp_t ssp, vrs_t vrs, proof_t pi)
  * 5 x count decryptions on the matrix cores from 820 proofs on, the four equations): ok[k] = 1 iff proof k is accepted.  Not in the reference. */
 void mfuoco_verifier_batch(ssp_t ssp, vrs_t vrs, proof_t *pis, size_t count, uint8_t *ok)
 {
+  KEEP_ERRNO;
   if (!count) return;
   gpu();
   ssp_resident(ssp);
@@ -869,6 +910,7 @@ void mfuoco_verifier_batch(ssp_t ssp, vrs_t vrs, proof_t *pis, size_t count, uin
  * as a Toeplitz int8 GEMM on the matrix cores (mfh_decrypt).  Not in the reference (src/benchmark_lwe.c:35-38 decrypts one at a time). */
 void mfuoco_decrypt_batch(mpz_t *ms, sk_t sk, ct_t *cts, size_t count)
 {
+  KEEP_ERRNO;
   if (!count) return;
   gpu();
   ct_to_dev(G.d_sk, sk, GAMMA_N);

@@ -1,0 +1,43 @@
+"""GPU: the reference's OWN programs -- src/test_snark.c, test_lwe.c, test_entropy.c, test_ssp.c, test_aes.c (debug size, their asserts live) and
+src/benchmark_snark.c, benchmark_lwe.c, benchmark_eval.c (NDEBUG size) -- compiled unmodified, with the reference's own headers, where they lie
+(oracle/Makefile `drivers`, in the build container) and LINKED AGAINST THE SHIM instead of the reference's objects: the drop-in of INTEGRATION.md section A,
+executed.  The binaries travel to the GPU box under oracle/_ref/drivers/ (git-ignored, like every built file); the reference's sources do not.  Every assertion
+these programs make is the reference authors' own (stream determinism / seek / chunking, encrypt-decrypt and the homomorphic identities, CRS relations, proof
+relations and acceptance); the benchmarks must run to completion and print the reference's `label\\tseconds` lines.  Test infrastructure: a checker of the
+boundary, not an oracle (their <flint/nmod_poly.h> is the shim's layout-compatible header, since FLINT is not in the image)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DRV = os.path.join(ROOT, "oracle", "_ref", "drivers")
+
+
+def _run(prog, timeout, cwd):
+    exe = os.path.join(DRV, prog)
+    if not os.path.exists(exe):
+        pytest.skip(f"oracle/_ref/drivers/{prog} was not built (the reference sources exist in the build container only: make -C oracle drivers)")
+    return subprocess.run([exe], capture_output=True, text=True, timeout=timeout, cwd=cwd)
+
+
+@pytest.mark.parametrize("prog", ["test_aes", "test_entropy", "test_ssp", "test_lwe", "test_snark"])
+def test_reference_test_program_passes_against_the_shim(prog, tmp_path):
+    """assert() is live in these builds (src/tests.h refuses NDEBUG): exit code 0 = every assertion of the reference's test held on the GPU library"""
+    r = _run(prog, 600, tmp_path)
+    assert r.returncode == 0, (prog, r.stdout[-2000:], r.stderr[-2000:])
+    assert "Assertion" not in r.stderr
+
+
+@pytest.mark.parametrize("prog,labels", [("benchmark_lwe", ("encryption", "decryption")), ("benchmark_eval", ()), ("benchmark_snark", ("setup", "prover", "verifier"))])
+def test_reference_benchmark_program_runs_against_the_shim(prog, labels, tmp_path):
+    """the reference's benchmark drivers at the NDEBUG default size (D = 2^15, M = 21845): they run to completion (benchmark_snark asserts nothing under NDEBUG
+    but computes setup, prover and verifier through the reference's types; benchmark_eval writes and maps ./coeffs in its working directory) and print timings"""
+    r = _run(prog, 900, tmp_path)
+    assert r.returncode == 0, (prog, r.stdout[-2000:], r.stderr[-2000:])
+    out = r.stdout + r.stderr
+    for lab in labels:
+        assert re.search(rf"{lab}\s+[0-9.]+", out), (prog, lab, out[-1500:])
+    assert re.search(r"[0-9]+\.[0-9]+", out), out[-500:]
