@@ -251,14 +251,46 @@ static void ct_from_dev(mpz_t *ct, const uint64_t *d, size_t count)
 }
 
 /* ---- L0/L1: stream -------------------------------------------------------------------------------------- */
-typedef struct { uint8_t seed[40]; } shim_key;
+/* what struct aesctr's opaque `key` points to: the 40-byte seed and a host window of the stream.  The reference's callers draw the stream in small pieces (92 bytes per
+ * mpz2_urandomb, 16-byte tails for remb): served one GPU round trip each, src/test_entropy.c took 68 s; the window fetches 64 KiB at a time. */
+#define WIN_BYTES ((size_t)1 << 16)
+typedef struct { uint8_t seed[40]; uint64_t win_pos; size_t win_len; uint8_t *win; } shim_key;
+static uint8_t *d_win; /* device staging of the window and of large reads, grown on demand */
+static size_t d_win_bytes;
+static void stream_fetch(shim_key *k, uint64_t pos, void *out, size_t bytes)
+{
+  use_seed(k->seed);
+  if (bytes > d_win_bytes) {
+    if (d_win) HK(hipFree(d_win));
+    d_win = NULL;
+    HK(hipMalloc((void **)&d_win, bytes < WIN_BYTES ? WIN_BYTES : bytes));
+    d_win_bytes = bytes < WIN_BYTES ? WIN_BYTES : bytes;
+  }
+  CK(mfh_keystream(G.ctx, pos, d_win, bytes));
+  HK(hipMemcpy(out, d_win, bytes, hipMemcpyDeviceToHost));
+}
+/* stream bytes [pos, pos + bytes) into out */
+static void stream_read(shim_key *k, uint64_t pos, void *out, size_t bytes)
+{
+  if (bytes > WIN_BYTES / 2) { /* bulk reads go straight through */
+    stream_fetch(k, pos, out, bytes);
+    return;
+  }
+  if (!k->win || pos < k->win_pos || pos + bytes > k->win_pos + k->win_len) {
+    if (!k->win) k->win = xmalloc(WIN_BYTES);
+    k->win_pos = pos & ~(uint64_t)15;
+    k->win_len = WIN_BYTES;
+    stream_fetch(k, k->win_pos, k->win, WIN_BYTES);
+  }
+  memcpy(out, k->win + (pos - k->win_pos), bytes);
+}
 
 void aesctr_init(aesctr_ptr s, const uint8_t *key, const uint64_t nonce)
 {
   KEEP_ERRNO;
   s->rem = 0;
   s->ctr = 0;
-  shim_key *k = malloc(sizeof *k);
+  shim_key *k = calloc(1, sizeof *k);
   if (!k) { perror("Failed malloc"); return; }
   memcpy(k->seed, &nonce, 8);
   memcpy(k->seed + 8, key, 32);
@@ -270,7 +302,12 @@ void aesctr_clear(aesctr_ptr s)
 {
   KEEP_ERRNO;
   if (!s) return;
-  if (s->key) { memset(s->key, 0, sizeof(shim_key)); free(s->key); }
+  if (s->key) {
+    shim_key *k = s->key;
+    if (k->win) { explicit_bzero(k->win, WIN_BYTES); free(k->win); }
+    memset(k, 0, sizeof(shim_key));
+    free(k);
+  }
   memset(s, 0, sizeof(struct aesctr));
 }
 
@@ -282,12 +319,8 @@ static void stream_set_pos(struct aesctr *s, uint64_t pos)
   s->rem = (size_t)(s->ctr * 16 - pos);
   /* remb mirrors the reference: the unread tail of the last generated block (src/aes.c:135-142) */
   if (s->rem) {
-    uint8_t blk[16], *d;
-    use_seed(((shim_key *)s->key)->seed);
-    HK(hipMalloc((void **)&d, 16));
-    CK(mfh_keystream(G.ctx, (s->ctr - 1) * 16, d, 16));
-    HK(hipMemcpy(blk, d, 16, hipMemcpyDeviceToHost));
-    HK(hipFree(d));
+    uint8_t blk[16];
+    stream_read((shim_key *)s->key, (s->ctr - 1) * 16, blk, 16);
     memcpy(s->remb, blk + 16 - s->rem, s->rem);
   }
 }
@@ -296,13 +329,9 @@ void aesctr_prg(aesctr_ptr s, void *out, size_t bytes)
 {
   KEEP_ERRNO;
   if (!bytes) return;
-  use_seed(((shim_key *)s->key)->seed);
+  gpu();
   uint64_t pos = stream_pos(s);
-  uint8_t *d;
-  HK(hipMalloc((void **)&d, bytes));
-  CK(mfh_keystream(G.ctx, pos, d, bytes));
-  HK(hipMemcpy(out, d, bytes, hipMemcpyDeviceToHost));
-  HK(hipFree(d));
+  stream_read((shim_key *)s->key, pos, out, bytes);
   stream_set_pos(s, pos + bytes);
 }
 

@@ -26,9 +26,9 @@ def _run(prog, timeout, cwd):
 @pytest.mark.parametrize("prog", ["test_aes", "test_entropy", "test_ssp", "test_lwe", "test_snark"])
 def test_reference_test_program_passes_against_the_shim(prog, tmp_path):
     """assert() is live in these builds (src/tests.h refuses NDEBUG): exit code 0 = every assertion of the reference's test held on the GPU library"""
-    # fresh OS entropy every run: four random instances of the LWE and SNARK tests (1 - 2 s each); test_entropy makes ~10^5 small stream reads, each a PCIe
-    # round trip through the shim (68 s): once
-    for attempt in range(4 if prog in ("test_lwe", "test_snark", "test_aes") else 1):
+    # fresh OS entropy every run: four random instances per program (test_entropy's ~10^5 small stream reads took 68 s when each was a GPU round trip; the shim now
+    # serves them from a 64 KiB host window of the stream: under 2 s)
+    for attempt in range(4 if prog != "test_ssp" else 1):
         r = _run(prog, 600, tmp_path)
         assert r.returncode == 0, (prog, attempt, r.stdout[-2000:], r.stderr[-2000:])
         assert "Assertion" not in r.stderr
