@@ -44,3 +44,14 @@ def test_reference_benchmark_program_runs_against_the_shim(prog, labels, tmp_pat
     for lab in labels:
         assert re.search(rf"{lab}\s+[0-9.]+", out), (prog, lab, out[-1500:])
     assert re.search(r"[0-9]+\.[0-9]+", out), out[-500:]
+    if prog == "benchmark_eval":
+        # the one file the reference itself writes (src/benchmark_eval.c:44-66: D rows of ct_export bytes, `./coeffs`): written here by the reference's own code
+        # through the shim's regev_encrypt / ct_export, and it is the image the repo's readers take (files.py / mfuoco_rows_map: SURVEY 8 f3)
+        import c_lwe_snarks_amd as mf
+        from c_lwe_snarks_amd import files as mffiles
+
+        path = os.path.join(str(tmp_path), "coeffs")
+        p = mf.DEFAULT
+        assert os.path.getsize(path) == p.d * p.ctb
+        rows = mffiles.rows_map(path, p)
+        assert rows.shape == (p.d, p.ctb) and rows.any()
