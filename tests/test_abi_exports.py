@@ -72,3 +72,26 @@ def test_dist_header_symbols_are_exported():
         allsyms = subprocess.run(["nm", "-D", path], capture_output=True, text=True).stdout
         assert "rehearsal" not in allsyms and "shm_open" not in allsyms and "mmap" not in allsyms
         assert "rehearsal" not in subprocess.run(["strings", path], capture_output=True, text=True).stdout.lower()
+
+
+def test_shim_header_symbols_are_exported():
+    """libmfuoco_gpu.so / libmfuoco_gpu_debug.so export every FUNCTION host/include/mfuoco/mangiafuoco_api.h declares: the reference's names (src/aes.h, src/entropy.h,
+    src/lwe.h, src/ssp.h, src/snark.h) and the additions (batch prover / verifier / decryption, files, device and resident-CRS controls); static inline helpers of the
+    header (regev_encrypt, mpz_dotp, rng_gen, rand_modp) are not symbols"""
+    import subprocess
+
+    hdr = open(os.path.join(ROOT, "c-lwe-snarks_amd", "host", "include", "mfuoco", "mangiafuoco_api.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    hdr = re.sub(r"^\s*#.*?$", "", hdr, flags=re.M)          # macros
+    hdr = re.sub(r"static inline[^{;]*\{[^}]*\}", "", hdr)  # inline helpers
+    declared = sorted(set(re.findall(r"\b([a-z][a-z0-9_]+)\s*\([^;{]*\)\s*;", hdr)) | set(re.findall(r"\(\*([a-z][a-z0-9_]+)\([^;{]*\)\)\[", hdr)))  # (also `T (*f(args))[N];`)
+    for must in ("prover", "verifier", "setup", "eval_poly", "regev_encrypt2", "regev_decrypt", "aesctr_prg", "rng_seek", "mpz2_urandomb", "ct_smudge", "random_ssp",
+                 "mfuoco_prover_batch", "mfuoco_gpu_set_resident_crs", "mfuoco_gpu_device", "mfuoco_crs_map", "mfuoco_rows_map"):
+        assert must in declared, must
+    for so in ("libmfuoco_gpu.so", "libmfuoco_gpu_debug.so"):
+        path = os.path.join(ROOT, "c-lwe-snarks_amd", so)
+        if not os.path.exists(path):
+            pytest.fail(f"{so} has not been built (make -C c-lwe-snarks_amd shim)")
+        syms = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True).stdout
+        missing = [n for n in declared if not re.search(rf"\bT {n}\b", syms)]
+        assert not missing, (so, missing)
