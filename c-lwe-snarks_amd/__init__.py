@@ -96,6 +96,7 @@ EXPORTS = [
     "mfh_witness_lanes", "mfh_witness_from_lanes", "mfh_prove_partial_w", "mfh_verify",
     "mfh_ssp_set_prg", "mfh_ssp_prg_make_t", "mfh_ssp_prg_fill",
     "mfh_resident_share_rows", "mfh_crs_expand_share", "mfh_crs_set_resident_share", "mfh_crs_set_resident_prefix",
+    "mfh_prove_batch_supergroup", "mfh_prove_batch_stream_wait",
 ]
 
 
@@ -140,6 +141,8 @@ def load_library():
         "mfh_crs_expand_mm": (i32, [vp, vp, vp]),
         "mfh_crs_set_resident_mm": (i32, [vp, vp]),
         "mfh_prove_batch": (i32, [vp, vp, vp, u32, ctypes.c_char_p, sz, vp, ctypes.c_char_p, sz, ctypes.c_char_p, vp]),
+        "mfh_prove_batch_supergroup": (u32, [vp]),
+        "mfh_prove_batch_stream_wait": (i32, [vp, u32, vp]),
         "mfh_poly_mul": (i32, [vp, vp, sz, vp, sz, vp]),
         "mfh_poly_add": (i32, [vp, vp, vp, sz, vp]),
         "mfh_poly_prepare_t": (i32, [vp, vp]),
@@ -510,6 +513,14 @@ class Context:
         self._chk(self.lib.mfh_prove_batch(self._h, _ptr(d_crs), _ptr(d_ssp), nb, bits, stride, ctypes.cast(dl, ctypes.c_void_p), mags, maglen,
                                            signs, _ptr(out)))
         return out
+
+    def prove_batch_supergroup(self):
+        """statements per super-group of the last prove_batch call (255 streaming, 248 regenerating; 0 before the first call)"""
+        return int(self.lib.mfh_prove_batch_supergroup(self._h))
+
+    def prove_batch_stream_wait(self, upto, stream):
+        """make the torch stream `stream` wait until statements [0, upto) of the last prove_batch call are final in its output"""
+        self._chk(self.lib.mfh_prove_batch_stream_wait(self._h, int(upto), ctypes.c_void_p(stream.cuda_stream)))
 
     # -- row-sharded batch prover (one process per GPU; dist.prove_batch_sharded drives the sequence) ----------------
     def _pack_bits(self, witness_bits_list):

@@ -47,6 +47,8 @@ struct mfh_ctx {
   size_t ws3_bytes = 0;
   std::vector<hipEvent_t> ev_cdone, ev_rdone, ev_wdone;  // mfh_prove_batch: chain of super-group k done / its w | h | v area read / its witness pass done (per area)
   std::vector<hipEvent_t> ev_round;  // one per round: its streaming launch has finished
+  std::vector<hipEvent_t> ev_sgdone;  // mfh_prove_batch: super-group k's proofs are final in d_proofs (mfh_prove_batch_stream_wait)
+  uint32_t last_batch_sg = 0, last_batch_n = 0;  // super-group size and statement count of the last mfh_prove_batch call
   void *wws = nullptr;       // scratch of the witness pass (its own buffer: the pass may run beside an eval launch that owns `ws`)
   size_t wws_bytes = 0;
   // lazy-carry image (one u64 per accumulator word and coordinate) + active-row counter of the eval launches.  Invariant: all
@@ -69,6 +71,7 @@ struct mfh_ctx {
     int kind;        // 0 keystream, 1/2 eval (1/2 coeff vectors), 3 encrypt, 4 expand, 5/6 resident MAC (1/2 vectors)
     uint64_t rows;   // rows handed to the launch
     uint64_t work;   // rows x evaluations the launch serves (k_mmstream with several groups; = rows elsewhere)
+    int sub;         // 1: the launch ran the persistent one-workgroup-per-CU grid (k_mmstream_p / _pb / _w); 0 otherwise
   };
   std::vector<Timed> timed;
   double last_busy_ms = 0;  // union of the spans of the launches the last mfh_timing_drain matched
@@ -129,7 +132,7 @@ struct Timer {  // brackets one launch with events when timing is on; never sync
   mfh_ctx *c;
   mfh_ctx::Timed t{};
   bool on;
-  Timer(mfh_ctx *c_, int kind, uint64_t rows, uint64_t work = 0) : c(c_), on(c_->timing) {
+  Timer(mfh_ctx *c_, int kind, uint64_t rows, uint64_t work = 0, int sub = 0) : c(c_), on(c_->timing) {
     if (!on) return;
     auto get = [&]() {
       hipEvent_t e;
@@ -137,7 +140,7 @@ struct Timer {  // brackets one launch with events when timing is on; never sync
       else hipEventCreate(&e);
       return e;
     };
-    t.e0 = get(); t.e1 = get(); t.kind = kind; t.rows = rows; t.work = work ? work : rows;
+    t.e0 = get(); t.e1 = get(); t.kind = kind; t.rows = rows; t.work = work ? work : rows; t.sub = sub;
     hipEventRecord(t.e0, c->stream);
   }
   ~Timer() {

@@ -1687,8 +1687,9 @@ int mms_digits(mfh_ctx *c, const MmsPlan &P, const MmIo *ios, const uint32_t *nv
   return MFH_OK;
 }
 int mms_stream(mfh_ctx *c, const MmsPlan &P) {
-  Timer t(c, P.ngt > 1 ? (P.ND == 1 ? 14 : 10) : 8, P.nrows, (uint64_t)P.nrows * P.ngt);  // kind 10 ("mmstream_rounds"): several groups per launch; 14 ("mmstream_bw"): b_w of several super-groups
   const uint32_t KS = (P.nrows + RT2 - 1) / RT2 * (RT2 / 64), tgs = (P.mtiles + TPW - 1) / TPW;
+  const bool will_persist = P.ngt > 1 && c->mm_persist && c->ncu == 256 && ((c->mm_map && 32 % P.ng == 0) || 32 % P.ngt == 0);  // (the choice made below)
+  Timer t(c, P.ngt > 1 ? (P.ND == 1 ? 14 : 10) : 8, P.nrows, (uint64_t)P.nrows * P.ngt, will_persist ? 1 : 0);  // kind 10 ("mmstream_rounds"): several groups per launch; 14 ("mmstream_bw"): b_w of several super-groups
   MmsImages imgs{};
   for (uint32_t g = 0; g < P.ngt; g++) imgs.image[g] = (const v4i *)P.img[g / P.ng];
   if (P.ngt > 1) {
@@ -1696,7 +1697,7 @@ int mms_stream(mfh_ctx *c, const MmsPlan &P) {
     const uint32_t tgx = (tgs + 7) / 8;  // tile groups per XCD
     const uint32_t map = c->mm_map && 32 % P.ng == 0 ? 1u : 0u;
     const uint32_t slots = map ? (tgx + 32 / P.ng - 1) / (32 / P.ng) * (P.ngt / P.ng) * 32 : tgx * P.ngt;  // per XCD
-    const bool persistent = c->mm_persist && c->ncu == 256 && (map || 32 % P.ngt == 0);
+    const bool persistent = will_persist;
     if (persistent && c->mm_wave1) {
       hipLaunchKernelGGL(k_mmstream_w, dim3(256), dim3(WSW * 64), 0, c->stream, imgs, P.mtiles, KS, P.nrows, P.rpc, (const v4i *)P.cd, P.part, P.ngt, P.ng, map,
                          (uint64_t)(P.cd_bytes / 16), (uint64_t)(P.part_bytes / 4), (slots + 31) / 32, P.nchunks);

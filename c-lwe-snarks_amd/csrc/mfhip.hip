@@ -1105,6 +1105,7 @@ void mfh_ctx_destroy(mfh_ctx *c) {
   if (c->ws3) hipFree(c->ws3);
   if (c->mm_sync) hipFree(c->mm_sync);
   for (hipEvent_t e : c->ev_round) hipEventDestroy(e);
+  for (hipEvent_t e : c->ev_sgdone) hipEventDestroy(e);
   for (hipEvent_t e : c->ev_cdone) hipEventDestroy(e);
   for (hipEvent_t e : c->ev_rdone) hipEventDestroy(e);
   for (hipEvent_t e : c->ev_wdone) hipEventDestroy(e);
@@ -1228,6 +1229,8 @@ static int timing_kind(const char *which) {
   if (!strcmp(which, "decrypt_rows")) return 13;  // k_encrypt_mm run for mfh_decrypt_rows (seed-compressed ciphertexts)
   if (!strcmp(which, "mmstream_bw")) return 14;      // the streaming launch that serves b_w of several super-groups (mfh_set_batch_bw)
   if (!strcmp(which, "mmstream_rounds")) return 10;  // the streaming launches that serve several groups (a subset of "evalmm_resident")
+  if (!strcmp(which, "mmstream_rounds_persistent")) return 110;  // ... those of them that ran the persistent one-workgroup-per-CU grid (k_mmstream_p / k_mmstream_w)
+  if (!strcmp(which, "mmstream_bw_persistent")) return 114;      // ... and of "mmstream_bw" (k_mmstream_pb)
   return -1;
 }
 
@@ -1244,7 +1247,7 @@ int mfh_timing_drain(mfh_ctx *c, const char *which, uint64_t *count, double *tot
   std::vector<std::pair<float, float>> spans;  // [start, end) of every matching launch, relative to the first one's start event
   hipEvent_t base = nullptr;
   for (auto &t : c->timed) {
-    const bool match = t.kind == kind || (kind == 12 && (t.kind == 1 || t.kind == 2)) || (kind == 8 && (t.kind == 10 || t.kind == 14));
+    const bool match = t.kind == kind || (kind == 12 && (t.kind == 1 || t.kind == 2)) || (kind == 8 && (t.kind == 10 || t.kind == 14)) || (kind >= 100 && t.kind == kind - 100 && t.sub == 1);
     if (!match) { keep.push_back(t); continue; }
     float ms = 0;
     if (hipEventElapsedTime(&ms, t.e0, t.e1) == hipSuccess) {
@@ -1266,7 +1269,7 @@ int mfh_timing_drain(mfh_ctx *c, const char *which, uint64_t *count, double *tot
   c->last_busy_ms = busy;
   c->last_work_rows = work;
   for (auto &t : c->timed) {
-    const bool match = t.kind == kind || (kind == 12 && (t.kind == 1 || t.kind == 2)) || (kind == 8 && (t.kind == 10 || t.kind == 14));
+    const bool match = t.kind == kind || (kind == 12 && (t.kind == 1 || t.kind == 2)) || (kind == 8 && (t.kind == 10 || t.kind == 14)) || (kind >= 100 && t.kind == kind - 100 && t.sub == 1);
     if (!match) continue;
     c->ev_pool.push_back(t.e0);
     c->ev_pool.push_back(t.e1);

@@ -902,6 +902,13 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
     }
   }
   const uint32_t nbuf = nsl > 1 ? nsg : 2;
+  // one completion event per super-group (mfh_prove_batch_stream_wait: a caller's copy stream drains super-group k while k + 1 runs)
+  while (c->ev_sgdone.size() < nsg) {
+    hipEvent_t e;
+    HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    c->ev_sgdone.push_back(e);
+  }
+  c->last_batch_sg = 0;  // (set when the whole call has been queued)
   BatchScratch B;
   int rc = batch_scratch(c, nproofs, nbuf, B, nsl > 1 ? 1 : nsg, nsl > 1 ? 0 : nproofs);
   if (rc) return rc;
@@ -982,7 +989,10 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
     for (uint32_t s0 = 0; s0 < nproofs; s0 += SG) {
       rc = batch_smudge(c, d_proofs + (size_t)s0 * 5 * ctl, std::min(SG, nproofs - s0), h_smudge_mag + (size_t)s0 * 5 * maglen, maglen, h_smudge_sign + (size_t)s0 * 5);
       if (rc) return rc;
+      HIP_TRY(c, hipEventRecord(c->ev_sgdone[s0 / SG], c->stream));  // (every slab touches every proof: all super-groups complete together, at the end)
     }
+    c->last_batch_sg = SG;
+    c->last_batch_n = nproofs;
     return MFH_OK;
   }
   ImageGuard transient{c, false};
@@ -1043,7 +1053,19 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
     }
     rc = batch_smudge_staged(c, B, sproofs, s0, sg);
     if (rc) return rc;
+    HIP_TRY(c, hipEventRecord(c->ev_sgdone[sgi], main_stream));  // this super-group's proofs are final (b_w was written before the loop or by batch_rows_supergroup)
   }
+  c->last_batch_sg = SG;
+  c->last_batch_n = nproofs;
+  return MFH_OK;
+}
+
+uint32_t mfh_prove_batch_supergroup(const mfh_ctx *c) { return c ? c->last_batch_sg : 0; }
+
+int mfh_prove_batch_stream_wait(mfh_ctx *c, uint32_t upto, void *hip_stream) {
+  if (!c) return MFH_EINVAL;
+  if (!c->last_batch_sg || !upto || upto > c->last_batch_n) { c->err = "mfh_prove_batch_stream_wait: no such statements in the last mfh_prove_batch call"; return MFH_EINVAL; }
+  HIP_TRY(c, hipStreamWaitEvent((hipStream_t)hip_stream, c->ev_sgdone[(upto - 1) / c->last_batch_sg], 0));
   return MFH_OK;
 }
 

@@ -6,10 +6,11 @@
  *
  * This is the DROP-IN path: every call crosses PCIe and converts mpz_t, so it measures the PCIe/host-inclusive cost of
  * using the GPU through the reference API, not the kernel throughput bench.py reports.
- *   usage: bench_snark [nproofs] [nenc] [nbatch] [eval]
+ *   usage: bench_snark [nproofs] [nenc] [nbatch] [eval] [nencbatch]
  *          nbatch statements through mfuoco_prover_batch, three calls (the first expands the CRS image, the others stream the image the shim kept:
  *          `prover_batch` lines); eval != 0: what src/benchmark_eval.c:30-86 measures (D encryptions written to a coeffs file, the file mapped, ONE
- *          eval_poly over its D rows timed: `eval` line).
+ *          eval_poly over its D rows timed: `eval` line); nencbatch messages
+ *          through mfuoco_encrypt_batch (three calls) and back through mfuoco_decrypt_rows_batch (`encryption_batch` / `decryption_rows_batch` lines).
  */
 #define _GNU_SOURCE
 #include <stdio.h>
@@ -31,6 +32,7 @@ static double now(void)
 int main(int argc, char **argv)
 {
   int nproofs = argc > 1 ? atoi(argv[1]) : 3, nenc = argc > 2 ? atoi(argv[2]) : 200, nbatch = argc > 3 ? atoi(argv[3]) : 255, do_eval = argc > 4 ? atoi(argv[4]) : 1;
+  int nencb = argc > 5 ? atoi(argv[5]) : 65536;
   ssp_t ssp = calloc(1, SSP_SIZE);
   mpz_t witness;
   mpz_init(witness);
@@ -150,6 +152,33 @@ int main(int argc, char **argv)
     ok = ok && !mpz_cmp(m, m2);
   }
   if (nenc) printf("encryption\t%lf\ndecryption\t%lf\n", te / nenc, td / nenc);
+
+  /* the same loop as ONE call per direction: nencb messages under one key (errors drawn from the OS in bulk, rows at consecutive stream positions), then the
+   * seed-compressed rows decrypted again; three calls, the first one allocates the staging */
+  if (nencb > 0) {
+    mpz_t *bm = malloc((size_t)nencb * sizeof *bm), *bd = malloc((size_t)nencb * sizeof *bd);
+    uint8_t (*bc)[CT_BYTES] = malloc((size_t)nencb * CT_BYTES);
+    for (int i = 0; i < nencb; i++) {
+      uint64_t r;
+      getrandom(&r, 8, 0);
+      mpz_init_set_ui(bm[i], r % GAMMA_P);
+      mpz_init(bd[i]);
+    }
+    for (int call = 0; call < 3; call++) {
+      rng_seek(rng, 0);
+      t0 = now();
+      mfuoco_encrypt_batch(bc, rng, vrs->sk, bm, nencb);
+      double dt = now() - t0;
+      printf("encryption_batch\t%lf\t(%d messages, %s: %.0f enc/s incl. OS entropy, PCIe and the export)\n", dt, nencb, call ? "warm" : "first call", nencb / dt);
+    }
+    rng_seek(rng, 0);
+    t0 = now();
+    mfuoco_decrypt_rows_batch(bd, rng, vrs->sk, bc, nencb);
+    double dt = now() - t0;
+    printf("decryption_rows_batch\t%lf\t(%d seed-compressed ciphertexts: %.0f dec/s incl. PCIe)\n", dt, nencb, nencb / dt);
+    for (int i = 0; i < nencb; i++) { ok = ok && !mpz_cmp(bm[i], bd[i]); mpz_clear(bm[i]); mpz_clear(bd[i]); }
+    free(bm); free(bd); free(bc);
+  }
   fprintf(stderr, "%s\n", ok ? "all proofs verified, all decryptions correct" : "FAILURE");
   return ok ? 0 : 1;
 }

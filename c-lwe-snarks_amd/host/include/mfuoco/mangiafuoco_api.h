@@ -140,6 +140,14 @@ void mfuoco_prover_batch(proof_t *pis, crs_t crs, ssp_t ssp, mpz_t *witnesses, s
 void mfuoco_verifier_batch(ssp_t ssp, vrs_t vrs, proof_t *pis, size_t count, uint8_t *ok);
 /* regev_decrypt for `count` ciphertexts under one key (src/lwe.c:105-111 per ciphertext); ms[k] initialised by the caller */
 void mfuoco_decrypt_batch(mpz_t *ms, sk_t sk, ct_t *cts, size_t count);
+/* regev_encrypt + ct_export (src/lwe.c:78-97,115-119; the loops of src/benchmark_lwe.c:28-33 and src/snark.c:75-110) for `count` messages under one key: row k is
+ * encrypted with the stream at rs + k * CTR_CT and its own error draw, c8[k] receives the exported b (ct_import at that stream position restores the ciphertext),
+ * rs ends count rows further.  mfuoco_encrypt_batch2 takes the error distribution like regev_encrypt2 (NULL = errdist_uniform, drawn in bulk). */
+void mfuoco_encrypt_batch(uint8_t (*c8)[CT_BYTES], rng_t rs, sk_t sk, mpz_t *ms, size_t count);
+void mfuoco_encrypt_batch2(uint8_t (*c8)[CT_BYTES], rng_t rs, sk_t sk, mpz_t *ms, size_t count, void (*chi)(mpz_t));
+/* regev_decrypt of `count` seed-compressed ciphertexts (c8[k] = exported b of the row at rs + k * CTR_CT; the a part is regenerated on the device as ct_import
+ * does, src/lwe.c:122-126): ms[k] initialised by the caller, rs ends count rows further */
+void mfuoco_decrypt_rows_batch(mpz_t *ms, rng_t rs, sk_t sk, uint8_t (*c8)[CT_BYTES], size_t count);
 /* select the GPU (default 0, or $MFUOCO_GPU); must precede the first call: returns 0, or -1 (with a message) once the shim runs on another GPU.
  * mfuoco_gpu_device: the GPU the shim runs on, -1 before its first call. */
 int mfuoco_gpu_set_device(int device);

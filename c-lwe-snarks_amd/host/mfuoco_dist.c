@@ -38,6 +38,7 @@ const uint32_t *mfuoco_gpu_stage_ssp(ssp_t ssp);
 size_t mfuoco_gpu_bits_stride(void);
 void mfuoco_gpu_witness_bits(uint8_t *bits, mpz_t witness);
 void mfuoco_gpu_prover_entropy(uint32_t *delta, uint8_t *mag, uint8_t *sign);
+void mfuoco_gpu_prover_entropy_batch(uint32_t *delta, uint8_t *mag, uint8_t *sign, size_t count);
 void mfuoco_gpu_proofs_to_host(proof_t *pis, const uint64_t *d_proofs, size_t count);
 void mfuoco_gpu_image_resident_share(const uint8_t *d_crs, uint32_t rank, uint32_t world, int expand);
 
@@ -288,7 +289,7 @@ void mfuoco_prover_batch_sharded(proof_t *pis, crs_t crs, ssp_t ssp, mpz_t *witn
   uint32_t *delta = xmalloc((nown ? nown : 1) * 4);
   memset(bits, 0, nb * stride);
   for (size_t k = 0; k < nb; k++) mfuoco_gpu_witness_bits(bits + k * stride, witnesses[k]);
-  for (size_t k = 0; k < nown; k++) mfuoco_gpu_prover_entropy(delta + k, mag + k * 5 * MAGLEN, sign + k * 5);
+  if (nown) mfuoco_gpu_prover_entropy_batch(delta, mag, sign, nown); /* (one draw, cut up in the order of nown prover() calls) */
 
   /* 1. the chain of the own statements (src/snark.c:141-169): w | h | v, nown x d coefficients each */
   uint32_t *whv = scratch(c, 0, 3 * nown * d * 4);

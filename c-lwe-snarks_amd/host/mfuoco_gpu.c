@@ -32,6 +32,9 @@
 #define L_LIMBS 12
 #define K_LIMBS 11
 #define CTL ((size_t)(GAMMA_N + 1) * L_LIMBS)
+#define PIN_BYTES ((size_t)1 << 20)
+#define ENC_CHUNK ((size_t)16384)
+#define ENC_UP ((size_t)L_LIMBS * 8 + 4) /* per row: the error's limbs, then the message */
 /* (CTR_CT, CTR_S, CTR_AS, CTR_BT come from the header, as in src/snark.h:8-12: CT_BYTES is 92UL, so they are 64-bit values) */
 
 static struct {
@@ -49,6 +52,15 @@ static struct {
   const void *ssp_host; /* host pointer the resident SSP was uploaded from */
   uint8_t *d_crs;     /* (2D+M) * CT_BYTES */
   uint64_t *d_err;
+  uint64_t *d_out;    /* mfuoco_prover_batch: out_cap proofs */
+  size_t out_cap;
+  /* the secret key last uploaded: host copy of its limbs (exact comparison, no digest) so that a caller encrypting / decrypting in a loop under one key uploads it once */
+  uint64_t *h_sk, *pin_sk;
+  bool sk_valid;
+  uint8_t *pin;       /* PIN_BYTES of pinned host memory: staging of the single-ciphertext calls */
+  /* mfuoco_encrypt_batch: two chunks of ENC_CHUNK rows in flight (error limbs and messages up, exported b's down) */
+  uint8_t *enc_pin[2], *d_enc[2];
+  hipEvent_t enc_ev[2];
   /* the expanded CRS kept across prover calls (mfuoco_gpu_set_resident_crs): the matrix-core image of (seed, compressed CRS) */
   int resident_crs;     /* -1 = not decided yet ($MFUOCO_GPU_RESIDENT_CRS, default on), 0 / 1 */
   uint8_t *d_img;
@@ -83,6 +95,20 @@ __attribute__((constructor)) static void shim_clean_errno(void) { errno = 0; }
 #define CK(call) do { if ((call) != MFH_OK) die(#call); } while (0)
 #define HK(call) do { if ((call) != hipSuccess) die(#call); } while (0)
 
+/* $MFUOCO_TRACE=1: wall-clock phases of the batch entry points on stderr (where a call's time goes: staging, queueing, draining) */
+#include <time.h>
+static double tnow(void)
+{
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+static bool tracing(void)
+{
+  static int on = -1;
+  if (on < 0) { const char *e = getenv("MFUOCO_TRACE"); on = e && *e && atoi(e) != 0; }
+  return on == 1;
+}
 static void *xmalloc(size_t bytes)
 {
   void *p = malloc(bytes ? bytes : 1);
@@ -105,7 +131,7 @@ static void *par_worker(void *p)
   j->fn(j->lo, j->hi, j->arg);
   return NULL;
 }
-static void parallel_for(size_t n, void (*fn)(size_t lo, size_t hi, void *arg), void *arg)
+static void parallel_for_grain(size_t n, size_t serial_below, void (*fn)(size_t lo, size_t hi, void *arg), void *arg)
 {
   static int nthreads;
   if (!nthreads) {
@@ -115,7 +141,7 @@ static void parallel_for(size_t n, void (*fn)(size_t lo, size_t hi, void *arg), 
     if (have > 0 && nthreads > have) nthreads = (int)have;
   }
   int nt = nthreads;
-  if (n < 65536 || nt < 2) { /* (a single proof is 7 355 values: not worth a thread) */
+  if (n < serial_below || nt < 2) {
     fn(0, n, arg);
     return;
   }
@@ -133,6 +159,8 @@ static void parallel_for(size_t n, void (*fn)(size_t lo, size_t hi, void *arg), 
   }
   for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
 }
+/* (a single proof is 7 355 values: not worth a thread) */
+static void parallel_for(size_t n, void (*fn)(size_t lo, size_t hi, void *arg), void *arg) { parallel_for_grain(n, 65536, fn, arg); }
 
 /* OS entropy where the reference calls getrandom(2) (src/entropy.h, src/snark.c:40,62-65,140,185-189): EINTR and short reads are retried, the pool not
  * being initialised yet is waited for, and any other failure ends the process -- a buffer left undrawn would silently cost zero-knowledge */
@@ -177,6 +205,12 @@ void mfuoco_gpu_invalidate(void)
   KEEP_ERRNO;
   G.ssp_host = NULL;
   drop_image();
+  if (G.h_sk) { /* ... and forget the cached key */
+    explicit_bzero(G.h_sk, (size_t)GAMMA_N * L_LIMBS * 8);
+    explicit_bzero(G.pin_sk, (size_t)GAMMA_N * L_LIMBS * 8);
+    (void)hipMemset(G.d_sk, 0, (size_t)GAMMA_N * L_LIMBS * 8);
+    G.sk_valid = false;
+  }
 }
 void mfuoco_gpu_set_resident_crs(int on)
 {
@@ -206,12 +240,15 @@ static mfh_ctx *gpu(void)
   }
   CK(mfh_set_stream(G.ctx, NULL)); /* default stream: hipMemcpy below is ordered with the kernels */
   size_t rows = 2 * (size_t)GAMMA_D + GAMMA_M;
-  for (int i = 0; i < 3; i++) HK(hipMalloc((void **)&G.d_ct[i], CTL * 8));
+  for (int i = 0; i < 3; i++) HK(hipMalloc((void **)&G.d_ct[i], CTL * 8 + 256)); /* (+ room for a keystream block behind a ciphertext: regev_encrypt2) */
   HK(hipMalloc((void **)&G.d_sk, (size_t)GAMMA_N * L_LIMBS * 8));
   HK(hipMalloc((void **)&G.d_c8, rows * CT_BYTES));
   HK(hipMalloc((void **)&G.d_co, rows * 4));
   HK(hipMalloc((void **)&G.d_proof, 5 * CTL * 8));
   HK(hipMalloc((void **)&G.d_crs, rows * CT_BYTES));
+  HK(hipHostMalloc((void **)&G.pin, PIN_BYTES, hipHostMallocDefault));
+  HK(hipHostMalloc((void **)&G.pin_sk, (size_t)GAMMA_N * L_LIMBS * 8, hipHostMallocDefault));
+  G.h_sk = xcalloc((size_t)GAMMA_N * L_LIMBS, 8);
   return G.ctx;
 }
 
@@ -226,14 +263,24 @@ static void use_seed(const uint8_t seed[40])
 }
 
 /* ---- mpz <-> limbs -------------------------------------------------------------------------------------- */
-static void to_limbs(uint64_t *out, const mpz_t z)
+static inline void to_limbs(uint64_t *out, const mpz_t z)
 {
   if (mpz_sgn(z) < 0) die("negative value (the reference asserts SIZ >= 0, src/lwe.h:109)");
-  if (mpz_sizeinbase(z, 2) > 64 * L_LIMBS) die("value wider than 768 bits");
-  memset(out, 0, L_LIMBS * 8);
-  mpz_export(out, NULL, -1, 8, 0, 0, z);
+  const size_t n = mpz_size(z);
+  if (n > L_LIMBS) die("value wider than 768 bits");
+  memcpy(out, mpz_limbs_read(z), n * 8); /* (whole native limbs, least significant first: what mpz_export(out, NULL, -1, 8, 0, 0, z) writes) */
+  memset(out + n, 0, (L_LIMBS - n) * 8);
 }
-static void from_limbs(mpz_t z, const uint64_t *in) { mpz_import(z, L_LIMBS, -1, 8, 0, 0, in); }
+/* (what mpz_import(z, L_LIMBS, -1, 8, 0, 0, in) does for whole native limbs -- normalise, make room, copy -- without its per-call word-order / nails dispatch:
+ * a batch of 1020 proofs is 7.5 M values) */
+static inline void from_limbs(mpz_t z, const uint64_t *in)
+{
+  _Static_assert(sizeof(mp_limb_t) == 8 && GMP_NAIL_BITS == 0, "64-bit limbs without nails");
+  mp_size_t n = L_LIMBS;
+  while (n > 0 && !in[n - 1]) n--;
+  if (n) memcpy(mpz_limbs_write(z, n), in, (size_t)n * 8);
+  mpz_limbs_finish(z, n);
+}
 
 static void ct_to_dev(uint64_t *d, mpz_t *ct, size_t count)
 {
@@ -248,6 +295,20 @@ static void ct_from_dev(mpz_t *ct, const uint64_t *d, size_t count)
   HK(hipMemcpy(h, d, count * L_LIMBS * 8, hipMemcpyDeviceToHost));
   for (size_t j = 0; j < count; j++) from_limbs(ct[j], h + j * L_LIMBS);
   free(h);
+}
+
+/* the key on the device (G.d_sk), uploaded only when its limbs differ from the ones uploaded last (src/benchmark_lwe.c:28-38 and the encryption loops of
+ * src/snark.c:75-110 pass the same sk to every call) */
+static const uint64_t *sk_resident(mpz_t *sk)
+{
+  gpu();
+  const size_t bytes = (size_t)GAMMA_N * L_LIMBS * 8;
+  for (size_t j = 0; j < GAMMA_N; j++) to_limbs(G.pin_sk + j * L_LIMBS, sk[j]);
+  if (G.sk_valid && !memcmp(G.pin_sk, G.h_sk, bytes)) return G.d_sk;
+  HK(hipMemcpy(G.d_sk, G.pin_sk, bytes, hipMemcpyHostToDevice));
+  memcpy(G.h_sk, G.pin_sk, bytes);
+  G.sk_valid = true;
+  return G.d_sk;
 }
 
 /* ---- L0/L1: stream -------------------------------------------------------------------------------------- */
@@ -313,17 +374,22 @@ void aesctr_clear(aesctr_ptr s)
 
 /* absolute stream position of the next byte */
 static uint64_t stream_pos(const struct aesctr *s) { return s->ctr * 16 - s->rem; }
-static void stream_set_pos(struct aesctr *s, uint64_t pos)
+/* blk: the 16 stream bytes at ((pos + 15) / 16 - 1) * 16 when the caller already has them (NULL: fetched through the window if pos is not block-aligned) */
+static void stream_set_pos_blk(struct aesctr *s, uint64_t pos, const uint8_t *blk)
 {
   s->ctr = (pos + 15) / 16;
   s->rem = (size_t)(s->ctr * 16 - pos);
   /* remb mirrors the reference: the unread tail of the last generated block (src/aes.c:135-142) */
   if (s->rem) {
-    uint8_t blk[16];
-    stream_read((shim_key *)s->key, (s->ctr - 1) * 16, blk, 16);
+    uint8_t fetched[16];
+    if (!blk) {
+      stream_read((shim_key *)s->key, (s->ctr - 1) * 16, fetched, 16);
+      blk = fetched;
+    }
     memcpy(s->remb, blk + 16 - s->rem, s->rem);
   }
 }
+static void stream_set_pos(struct aesctr *s, uint64_t pos) { stream_set_pos_blk(s, pos, NULL); }
 
 void aesctr_prg(aesctr_ptr s, void *out, size_t bytes)
 {
@@ -418,32 +484,155 @@ void regev_encrypt2(ct_t c, rng_t rs, sk_t sk, mpz_t m, void (*chi)(mpz_t))
   (*chi)(e);
   uint8_t sign;
   shim_random(&sign, 1); /* the reference burns one byte here (src/lwe.c:87) */
-  uint64_t eh[L_LIMBS];
-  to_limbs(eh, e);
+  const uint64_t *d_sk = sk_resident(sk);
+  /* one small upload ([error limbs | message] from pinned memory), the two launches (the row's a part -- the caller receives it too -- and its b, exported into the
+   * slot behind the a's), ONE download of the whole ciphertext */
+  uint64_t *up = (uint64_t *)G.pin, *down = (uint64_t *)(G.pin + 4096);
+  to_limbs(up, e);
   mpz_clear(e);
+  const uint32_t mh = (uint32_t)mpz_get_ui(m);
+  memcpy(up + L_LIMBS, &mh, 4);
   use_seed(((shim_key *)s->key)->seed);
-  uint64_t pos = stream_pos(s);
-  uint32_t mh = (uint32_t)mpz_get_ui(m);
-  uint8_t c8[CT_BYTES];
-  ct_to_dev(G.d_sk, sk, GAMMA_N);
-  HK(hipMemcpy(G.d_co, &mh, 4, hipMemcpyHostToDevice));
-  HK(hipMemcpy(G.d_ct[1], eh, sizeof eh, hipMemcpyHostToDevice));
-  CK(mfh_encrypt_rows(G.ctx, pos, 1, G.d_sk, G.d_co, G.d_ct[1], G.d_c8));
-  HK(hipMemcpy(c8, G.d_c8, CT_BYTES, hipMemcpyDeviceToHost));
-  sample_a(c, rs); /* the caller receives the a's too; advances the stream */
-  mpz_import(c[GAMMA_N], LOGQ_BYTES, -1, 1, -1, 0, c8);
+  const uint64_t pos = stream_pos(s);
+  uint8_t *d_b = (uint8_t *)(G.d_ct[0] + (size_t)GAMMA_N * L_LIMBS);
+  HK(hipMemcpyAsync(G.d_ct[1], up, ENC_UP, hipMemcpyHostToDevice, NULL));
+  CK(mfh_sample_rows(G.ctx, pos, 1, G.d_ct[0]));
+  CK(mfh_encrypt_rows(G.ctx, pos, 1, d_sk, (const uint32_t *)(G.d_ct[1] + L_LIMBS), G.d_ct[1], d_b));
+  /* ... and the stream block the row ends in (its unread tail is the caller's remb: CTR_CT = 16 * 8452 + 8, every other row ends mid-block) in the same download,
+   * instead of a round trip of its own through the stream window */
+  const uint64_t end = pos + CTR_CT, endblk = ((end + 15) / 16 - 1) * 16;
+  CK(mfh_keystream(G.ctx, endblk, (uint8_t *)G.d_ct[0] + CTL * 8, 16));
+  HK(hipMemcpyAsync(down, G.d_ct[0], CTL * 8 + 16, hipMemcpyDeviceToHost, NULL));
+  HK(hipStreamSynchronize(NULL));
+  explicit_bzero(up, ENC_UP);
+  for (size_t j = 0; j < GAMMA_N; j++) from_limbs(c[j], down + j * L_LIMBS);
+  mpz_import(c[GAMMA_N], LOGQ_BYTES, -1, 1, -1, 0, down + (size_t)GAMMA_N * L_LIMBS);
+  stream_set_pos_blk(s, end, (const uint8_t *)down + CTL * 8);
+}
+
+/* regev_encrypt2 + ct_export (src/lwe.c:78-97,115-119) for `count` messages under one key: row k is what regev_encrypt2 produces with the stream at rs + k CTR_CT
+ * and the k-th error draw; c8[k] receives its exported b (the a part is public: ct_import regenerates it from the stream position), and rs ends count rows further.
+ * chi == NULL or errdist_uniform: the errors are drawn in bulk (per row the GAMMA_LOG_SIGMA + 3 bits of errdist_uniform, then the sign byte the reference burns,
+ * src/lwe.c:60-63,85-87) on a few host threads; any other chi is called once per row, in order.  Chunks of ENC_CHUNK rows: the host draws chunk k + 1 while the GPU
+ * encrypts chunk k.  Not in the reference, whose loops (src/benchmark_lwe.c:28-33, src/snark.c:75-110) encrypt one message at a time. */
+struct enc_fill { uint8_t *up; mpz_t *ms; size_t base; };
+static void enc_fill_uniform(size_t lo, size_t hi, void *arg)
+{
+  struct enc_fill *f = arg;
+  enum { EB = (GAMMA_LOG_SIGMA + 3) / 8, DRAW = EB + 1, RUN = 512 };
+  uint8_t tmp[RUN * DRAW];
+  for (size_t r0 = lo; r0 < hi; r0 += RUN) {
+    const size_t nr = hi - r0 < RUN ? hi - r0 : RUN;
+    shim_random(tmp, nr * DRAW);
+    for (size_t r = 0; r < nr; r++) {
+      uint8_t *row = f->up + (r0 + r) * (L_LIMBS * 8);
+      memcpy(row, tmp + r * DRAW, EB); /* (mpz2_urandomb2(e, 559) draws 559 / 8 = 69 whole bytes: the value has 552 random bits) */
+      memset(row + EB, 0, L_LIMBS * 8 - EB);
+      mpz_srcptr m = f->ms[f->base + r0 + r];
+      if (mpz_sgn(m) < 0 || mpz_cmp_ui(m, GAMMA_P) >= 0) die("mfuoco_encrypt_batch: message must be < p (src/lwe.c:80)");
+      const uint32_t mh = (uint32_t)mpz_get_ui(m);
+      memcpy(f->up + ENC_CHUNK * L_LIMBS * 8 + (r0 + r) * 4, &mh, 4);
+    }
+  }
+  explicit_bzero(tmp, sizeof tmp);
+}
+void mfuoco_encrypt_batch2(uint8_t (*c8)[CT_BYTES], rng_t rs, sk_t sk, mpz_t *ms, size_t count, void (*chi)(mpz_t))
+{
+  KEEP_ERRNO;
+  if (!count) return;
+  struct aesctr *s = (struct aesctr *)rs;
+  const uint64_t *d_sk = sk_resident(sk);
+  use_seed(((shim_key *)s->key)->seed);
+  if (!G.d_enc[0])
+    for (int i = 0; i < 2; i++) {
+      HK(hipMalloc((void **)&G.d_enc[i], ENC_CHUNK * (ENC_UP + CT_BYTES)));
+      HK(hipHostMalloc((void **)&G.enc_pin[i], ENC_CHUNK * (ENC_UP + CT_BYTES), hipHostMallocDefault));
+      HK(hipEventCreateWithFlags(&G.enc_ev[i], hipEventDisableTiming));
+    }
+  const uint64_t pos = stream_pos(s);
+  const bool bulk = !chi || chi == errdist_uniform;
+  size_t done[2] = { 0, 0 }, at[2] = { 0, 0 };
+  int slot = 0;
+  for (size_t k0 = 0; k0 < count || done[0] || done[1]; k0 += ENC_CHUNK, slot ^= 1) {
+    if (done[slot]) { /* the chunk that used this slot two rounds ago: its b's are down */
+      HK(hipEventSynchronize(G.enc_ev[slot]));
+      memcpy(c8[at[slot]], G.enc_pin[slot] + ENC_CHUNK * ENC_UP, done[slot] * CT_BYTES);
+      done[slot] = 0;
+    }
+    if (k0 >= count) continue;
+    const size_t nk = count - k0 < ENC_CHUNK ? count - k0 : ENC_CHUNK;
+    uint8_t *up = G.enc_pin[slot];
+    if (bulk) {
+      struct enc_fill f = { up, ms, k0 };
+      parallel_for_grain(nk, 2048, enc_fill_uniform, &f);
+    } else {
+      mpz_t e;
+      mpz_init(e);
+      for (size_t r = 0; r < nk; r++) {
+        if (mpz_sgn(ms[k0 + r]) < 0 || mpz_cmp_ui(ms[k0 + r], GAMMA_P) >= 0) die("mfuoco_encrypt_batch: message must be < p (src/lwe.c:80)");
+        (*chi)(e);
+        uint8_t sign;
+        shim_random(&sign, 1);
+        uint64_t eh[L_LIMBS];
+        to_limbs(eh, e);
+        memcpy(up + r * sizeof eh, eh, sizeof eh);
+        const uint32_t mh = (uint32_t)mpz_get_ui(ms[k0 + r]);
+        memcpy(up + ENC_CHUNK * sizeof eh + r * 4, &mh, 4);
+      }
+      mpz_clear(e);
+    }
+    /* slot layout, host and device alike: [ENC_CHUNK x L limbs of error | ENC_CHUNK x uint32 message | ENC_CHUNK x CT_BYTES of b] */
+    uint8_t *d = G.d_enc[slot];
+    HK(hipMemcpyAsync(d, up, nk * L_LIMBS * 8, hipMemcpyHostToDevice, NULL));
+    HK(hipMemcpyAsync(d + ENC_CHUNK * L_LIMBS * 8, up + ENC_CHUNK * L_LIMBS * 8, nk * 4, hipMemcpyHostToDevice, NULL));
+    CK(mfh_encrypt_rows(G.ctx, pos + k0 * CTR_CT, nk, d_sk, (const uint32_t *)(d + ENC_CHUNK * L_LIMBS * 8), (const uint64_t *)d, d + ENC_CHUNK * ENC_UP));
+    HK(hipMemcpyAsync(G.enc_pin[slot] + ENC_CHUNK * ENC_UP, d + ENC_CHUNK * ENC_UP, nk * CT_BYTES, hipMemcpyDeviceToHost, NULL));
+    HK(hipEventRecord(G.enc_ev[slot], NULL));
+    done[slot] = nk;
+    at[slot] = k0;
+  }
+  for (int i = 0; i < 2; i++) explicit_bzero(G.enc_pin[i], ENC_CHUNK * ENC_UP); /* the errors are secret */
+  stream_set_pos(s, pos + count * CTR_CT);
+}
+void mfuoco_encrypt_batch(uint8_t (*c8)[CT_BYTES], rng_t rs, sk_t sk, mpz_t *ms, size_t count) { mfuoco_encrypt_batch2(c8, rs, sk, ms, count, NULL); }
+
+/* regev_decrypt (src/lwe.c:105-111) of `count` SEED-COMPRESSED ciphertexts -- the form mfuoco_encrypt_batch / ct_export produce and a CRS holds: row k's a part is
+ * regenerated on the device from the stream at rs + k CTR_CT (what ct_import does, src/lwe.c:122-126), c8[k] is its b.  ms[k] initialised by the caller; rs ends count
+ * rows further. */
+void mfuoco_decrypt_rows_batch(mpz_t *ms, rng_t rs, sk_t sk, uint8_t (*c8)[CT_BYTES], size_t count)
+{
+  KEEP_ERRNO;
+  if (!count) return;
+  struct aesctr *s = (struct aesctr *)rs;
+  const uint64_t *d_sk = sk_resident(sk);
+  use_seed(((shim_key *)s->key)->seed);
+  const uint64_t pos = stream_pos(s);
+  uint8_t *d_c8 = NULL;
+  uint32_t *d_m = NULL, *hm = xmalloc(count * 4);
+  HK(hipMalloc((void **)&d_c8, count * CT_BYTES));
+  HK(hipMalloc((void **)&d_m, count * 4));
+  HK(hipMemcpy(d_c8, c8, count * CT_BYTES, hipMemcpyHostToDevice));
+  CK(mfh_decrypt_rows(G.ctx, pos, count, d_sk, d_c8, d_m));
+  HK(hipMemcpy(hm, d_m, count * 4, hipMemcpyDeviceToHost));
+  for (size_t k = 0; k < count; k++) mpz_set_ui(ms[k], hm[k]);
+  free(hm);
+  HK(hipFree(d_c8));
+  HK(hipFree(d_m));
+  stream_set_pos(s, pos + count * CTR_CT);
 }
 
 void regev_decrypt(mpz_t m, sk_t sk, ct_t ct)
 {
   KEEP_ERRNO;
-  gpu();
-  uint32_t out;
-  ct_to_dev(G.d_sk, sk, GAMMA_N);
-  ct_to_dev(G.d_ct[0], ct, GAMMA_N + 1);
-  CK(mfh_decrypt(G.ctx, G.d_sk, G.d_ct[0], 1, G.d_co));
-  HK(hipMemcpy(&out, G.d_co, 4, hipMemcpyDeviceToHost));
-  mpz_set_ui(m, out);
+  const uint64_t *d_sk = sk_resident(sk);
+  uint64_t *up = (uint64_t *)G.pin;
+  for (size_t j = 0; j <= GAMMA_N; j++) to_limbs(up + j * L_LIMBS, ct[j]);
+  HK(hipMemcpyAsync(G.d_ct[0], up, CTL * 8, hipMemcpyHostToDevice, NULL));
+  CK(mfh_decrypt(G.ctx, d_sk, G.d_ct[0], 1, G.d_co));
+  uint32_t *out = (uint32_t *)(G.pin + CTL * 8);
+  HK(hipMemcpyAsync(out, G.d_co, 4, hipMemcpyDeviceToHost, NULL));
+  HK(hipStreamSynchronize(NULL));
+  mpz_set_ui(m, *out);
 }
 
 void mpz_add_dotp(mpz_t rop, mpz_t a[], mpz_t b[], size_t len)
@@ -599,6 +788,19 @@ static void ssp_resident(ssp_t ssp)
   G.ssp_host = ssp;
 }
 
+/* Everything a first prover() would otherwise pay for besides the proof itself -- the context's scratch (hipMalloc), the code objects of the prover's kernels (loaded
+ * on first launch), the NTT tables of the polynomial step -- is paid here, by ONE proof of the all-zero witness with zero randomness over the CRS and SSP setup() has
+ * just put on the device, its result discarded: public inputs only.  src/benchmark_snark.c:70-74 times the first prover() after setup(); without this it measured
+ * 22 ms for 9.9 ms of GPU work.  $MFUOCO_GPU_WARM=0 skips it. */
+static void shim_warm_prover(void)
+{
+  const char *e = getenv("MFUOCO_GPU_WARM");
+  if (e && *e && !atoi(e)) return;
+  static const uint8_t zero_bits[(GAMMA_M + 7) / 8 + 8], zero_mag[5 * (GAMMA_LOG_SMUDGING / 8)], zero_sign[5];
+  CK(mfh_prove(G.ctx, G.d_crs, G.d_ssp, zero_bits, 0, zero_mag, GAMMA_LOG_SMUDGING / 8, zero_sign, G.d_proof));
+  CK(mfh_sync(G.ctx));
+}
+
 void setup(crs_t crs, vrs_t vrs, ssp_t ssp)
 {
   KEEP_ERRNO;
@@ -619,7 +821,7 @@ void setup(crs_t crs, vrs_t vrs, ssp_t ssp)
   if (!G.d_err) HK(hipMalloc((void **)&G.d_err, rows * L_LIMBS * 8));
   HK(hipMemcpy(G.d_err, err, rows * L_LIMBS * 8, hipMemcpyHostToDevice));
   free(err);
-  ct_to_dev(G.d_sk, vrs->sk, GAMMA_N);
+  sk_resident(vrs->sk);
   G.ssp_host = NULL;
   ssp_resident(ssp);
   drop_image(); /* G.d_crs is about to be rewritten */
@@ -629,6 +831,7 @@ void setup(crs_t crs, vrs_t vrs, ssp_t ssp)
   HK(hipMemcpy(crs->as, G.d_crs + CT_BYTES * GAMMA_D, CT_BYTES * GAMMA_D, hipMemcpyDeviceToHost));
   HK(hipMemcpy(crs->t, G.d_crs + 2 * CT_BYTES * GAMMA_D, CT_BYTES, hipMemcpyDeviceToHost));
   HK(hipMemcpy(crs->v, G.d_crs + (2 * GAMMA_D + 1) * CT_BYTES, CT_BYTES * (GAMMA_M - 1), hipMemcpyDeviceToHost));
+  shim_warm_prover();
 }
 
 /* ---- pieces shared with the multi-GPU entry points (host/mfuoco_dist.c, libmfuoco_gpu_dist): not part of the reference interface ---- */
@@ -688,6 +891,28 @@ void mfuoco_gpu_prover_entropy(uint32_t *delta, uint8_t *mag, uint8_t *sign)
   }
 }
 
+/* the same for `count` calls, drawn from the OS in one piece and cut up in the reference's order (per call: 8 bytes of delta, then 5 x [80 + 1]): one system call
+ * instead of eleven per proof (5 ms per 1020 proofs) */
+void mfuoco_gpu_prover_entropy_batch(uint32_t *delta, uint8_t *mag, uint8_t *sign, size_t count)
+{
+  KEEP_ERRNO;
+  const size_t maglen = GAMMA_LOG_SMUDGING / 8, per = 8 + 5 * (maglen + 1);
+  uint8_t *tape = xmalloc(count * per);
+  shim_random(tape, count * per);
+  for (size_t k = 0; k < count; k++) {
+    const uint8_t *t = tape + k * per;
+    uint64_t r;
+    memcpy(&r, t, 8);
+    delta[k] = (uint32_t)(r % GAMMA_P);
+    for (int q = 0; q < 5; q++) {
+      memcpy(mag + (k * 5 + q) * maglen, t + 8 + q * (maglen + 1), maglen);
+      sign[k * 5 + q] = t[8 + q * (maglen + 1) + maglen];
+    }
+  }
+  explicit_bzero(tape, count * per);
+  free(tape);
+}
+
 struct conv_arg { proof_t *pis; ct_t *cts; uint64_t *h; };
 static mpz_t *proof_ct(struct proof *pk, size_t q) { return q == 0 ? pk->h : q == 1 ? pk->hat_h : q == 2 ? pk->hat_v : q == 3 ? pk->v_w : pk->b_w; }
 static void proofs_from_limbs(size_t lo, size_t hi, void *arg)
@@ -708,21 +933,71 @@ static void cts_to_limbs(size_t lo, size_t hi, void *arg)
   for (size_t i = lo; i < hi; i++) to_limbs(a->h + i * L_LIMBS, a->cts[i / (GAMMA_N + 1)][i % (GAMMA_N + 1)]);
 }
 
-/* count proofs (5 ciphertexts each, struct proof order) from device limbs into initialised proof_t's */
+/* Device-to-host drain of proofs: slabs of DRAIN_SLAB proofs copied on a stream of the shim's own (non-blocking: independent of the kernels' stream) into two pinned
+ * host buffers, slab j + 1 in flight while the host threads turn slab j into mpz_t's.  Nothing is allocated per call: the pinned pair (2 x 45 MB) and the stream are made once. */
+#define DRAIN_SLAB ((size_t)64)
+static struct {
+  hipStream_t stream;
+  hipEvent_t ev[2], ev_src;
+  uint64_t *pin[2];
+} DR;
+static void drain_init(void)
+{
+  if (DR.stream) return;
+  HK(hipStreamCreateWithFlags(&DR.stream, hipStreamNonBlocking));
+  HK(hipEventCreateWithFlags(&DR.ev_src, hipEventDisableTiming));
+  for (int i = 0; i < 2; i++) {
+    HK(hipEventCreateWithFlags(&DR.ev[i], hipEventDisableTiming));
+    HK(hipHostMalloc((void **)&DR.pin[i], DRAIN_SLAB * 5 * CTL * 8, hipHostMallocDefault));
+  }
+}
+/* count proofs (5 ciphertexts each, struct proof order) from device limbs into initialised proof_t's.  batch != 0: d_proofs is being written by the mfh_prove_batch call
+ * just queued, super-group by super-group; a slab's copy waits (on the device, mfh_prove_batch_stream_wait) for its super-group only, so super-group k crosses PCIe and
+ * becomes mpz_t's under the kernels of k + 1.  batch == 0: d_proofs is final once the work queued on the shim's (default) stream so far has run. */
+static void proofs_drain(proof_t *pis, const uint64_t *d_proofs, size_t count, int batch)
+{
+  if (count * 5 * CTL * 8 <= PIN_BYTES) { /* one proof (706 KB): the small pinned scratch, no pipeline (and none of its 90 MB of page-locking on a first prover() call) */
+    if (batch) CK(mfh_sync(G.ctx));
+    HK(hipMemcpyAsync(G.pin, d_proofs, count * 5 * CTL * 8, hipMemcpyDeviceToHost, NULL));
+    HK(hipStreamSynchronize(NULL));
+    struct conv_arg a = { pis, NULL, (uint64_t *)G.pin };
+    proofs_from_limbs(0, count * 5 * (size_t)(GAMMA_N + 1), &a);
+    return;
+  }
+  drain_init();
+  const size_t sg = batch ? mfh_prove_batch_supergroup(G.ctx) : 0;
+  if (!batch) { /* order the copies after what the default stream holds */
+    HK(hipEventRecord(DR.ev_src, NULL));
+    HK(hipStreamWaitEvent(DR.stream, DR.ev_src, 0));
+  }
+  /* slabs never straddle a super-group (a straddling copy would wait for the later one) */
+  size_t lo[2] = { 0, 0 }, n[2] = { 0, 0 }, next = 0;
+  int slot = 0;
+#define DRAIN_ISSUE(sl)                                                                                                        \
+  do {                                                                                                                         \
+    size_t nk_ = count - next < DRAIN_SLAB ? count - next : DRAIN_SLAB;                                                        \
+    if (sg && next / sg != (next + nk_ - 1) / sg) nk_ = (next / sg + 1) * sg - next;                                           \
+    if (sg) CK(mfh_prove_batch_stream_wait(G.ctx, (uint32_t)(next + nk_), DR.stream));                                         \
+    HK(hipMemcpyAsync(DR.pin[sl], d_proofs + next * 5 * CTL, nk_ * 5 * CTL * 8, hipMemcpyDeviceToHost, DR.stream));            \
+    HK(hipEventRecord(DR.ev[sl], DR.stream));                                                                                  \
+    lo[sl] = next;                                                                                                             \
+    n[sl] = nk_;                                                                                                               \
+    next += nk_;                                                                                                               \
+  } while (0)
+  DRAIN_ISSUE(0);
+  while (n[slot]) {
+    if (next < count) DRAIN_ISSUE(slot ^ 1); else n[slot ^ 1] = 0;
+    HK(hipEventSynchronize(DR.ev[slot]));
+    struct conv_arg a = { pis + lo[slot], NULL, DR.pin[slot] };
+    parallel_for(n[slot] * 5 * (size_t)(GAMMA_N + 1), proofs_from_limbs, &a);
+    slot ^= 1;
+  }
+#undef DRAIN_ISSUE
+}
 void mfuoco_gpu_proofs_to_host(proof_t *pis, const uint64_t *d_proofs, size_t count)
 {
   KEEP_ERRNO;
-  /* slabs of up to 128 proofs: ONE device-to-host copy per slab (90 MB) instead of one per ciphertext, then the 5 x 1471 mpz_import per proof on all the cores
-   * a few host threads (parallel_for) -- at 255 statements per call the conversion was 2/3 of mfuoco_prover_batch's wall time */
-  const size_t slab = 128;
-  uint64_t *h = xmalloc((count < slab ? count : slab) * 5 * CTL * 8);
-  for (size_t k0 = 0; k0 < count; k0 += slab) {
-    const size_t nk = count - k0 < slab ? count - k0 : slab;
-    HK(hipMemcpy(h, d_proofs + k0 * 5 * CTL, nk * 5 * CTL * 8, hipMemcpyDeviceToHost));
-    struct conv_arg a = { pis + k0, NULL, h };
-    parallel_for(nk * 5 * (size_t)(GAMMA_N + 1), proofs_from_limbs, &a);
-  }
-  free(h);
+  proofs_drain(pis, d_proofs, count, 0);
 }
 
 /* ---- the expanded CRS kept across prover calls (the materialised-CRS regime behind the reference's types) -------------------------------
@@ -829,8 +1104,10 @@ static const void *image_resident_rows(const uint8_t *d_crs)
 void prover(proof_t pi, crs_t crs, ssp_t ssp, mpz_t witness)
 {
   KEEP_ERRNO;
+  const double t_in = tnow();
   const uint8_t *d_crs = mfuoco_gpu_stage_crs(crs);
   const uint32_t *d_ssp = mfuoco_gpu_stage_ssp(ssp);
+  const double t_staged = tnow();
   uint8_t bits[(GAMMA_M + 7) / 8 + 8] = { 0 };
   mfuoco_gpu_witness_bits(bits, witness);
   uint32_t delta;
@@ -843,8 +1120,14 @@ void prover(proof_t pi, crs_t crs, ssp_t ssp, mpz_t witness)
   explicit_bzero(mag, sizeof mag);
   explicit_bzero(&delta, sizeof delta);
   if (rc != MFH_OK) die("mfh_prove");
+  const double t_queued = tnow();
+  if (tracing()) CK(mfh_sync(G.ctx));
+  const double t_done = tnow();
   proof_t *one = (proof_t *)pi; /* proof_t is struct proof[1]: pi is the address of the one element */
   mfuoco_gpu_proofs_to_host(one, G.d_proof, 1);
+  if (tracing())
+    fprintf(stderr, "prover(): stage CRS+SSP %.2f ms, image + queue %.2f, GPU %.2f, copy + mpz_t %.2f (%s)\n", t_staged - t_in, t_queued - t_staged, t_done - t_queued, tnow() - t_done,
+            rows ? "resident rows" : "regenerated");
 }
 
 /* prover() for `count` statements under one CRS and SSP (not in the reference): the CRS rows are expanded once per group of proofs
@@ -854,17 +1137,24 @@ void mfuoco_prover_batch(proof_t *pis, crs_t crs, ssp_t ssp, mpz_t *witnesses, s
 {
   KEEP_ERRNO;
   if (!count) return;
+  const double t_in = tnow();
   const uint8_t *d_crs = mfuoco_gpu_stage_crs(crs);
   const uint32_t *d_ssp = mfuoco_gpu_stage_ssp(ssp);
+  const double t_staged = tnow();
   const size_t stride = mfuoco_gpu_bits_stride(), maglen = GAMMA_LOG_SMUDGING / 8;
   uint8_t *bits = xcalloc(count, stride), *mag = xmalloc(count * 5 * maglen), *sign = xmalloc(count * 5);
   uint32_t *delta = xmalloc(count * 4);
-  uint64_t *d_out = NULL;
-  HK(hipMalloc((void **)&d_out, count * 5 * CTL * 8));
-  for (size_t k = 0; k < count; k++) {
-    mfuoco_gpu_witness_bits(bits + k * stride, witnesses[k]);
-    mfuoco_gpu_prover_entropy(delta + k, mag + k * 5 * maglen, sign + k * 5);
+  if (count > G.out_cap) { /* the call's device output: kept, grown when a call is larger than every one before */
+    if (G.d_out) HK(hipFree(G.d_out));
+    G.d_out = NULL;
+    G.out_cap = 0;
+    HK(hipMalloc((void **)&G.d_out, count * 5 * CTL * 8));
+    G.out_cap = count;
   }
+  uint64_t *d_out = G.d_out;
+  for (size_t k = 0; k < count; k++) mfuoco_gpu_witness_bits(bits + k * stride, witnesses[k]);
+  mfuoco_gpu_prover_entropy_batch(delta, mag, sign, count);
+  const double t_host = tnow();
   image_resident_mm(d_crs, 0, 1, count > 31); /* (smaller calls do not expand an image at all; one kept from an earlier call is used if it still serves this CRS) */
   int rc = mfh_prove_batch(G.ctx, d_crs, d_ssp, (uint32_t)count, bits, stride, delta, mag, maglen, sign, d_out);
   explicit_bzero(mag, count * 5 * maglen); /* the smudging terms and deltas are the proofs' zero-knowledge: not left on the heap */
@@ -872,8 +1162,12 @@ void mfuoco_prover_batch(proof_t *pis, crs_t crs, ssp_t ssp, mpz_t *witnesses, s
   explicit_bzero(delta, count * 4);
   free(bits); free(mag); free(sign); free(delta);
   if (rc != MFH_OK) die("mfh_prove_batch");
-  mfuoco_gpu_proofs_to_host(pis, d_out, count);
-  HK(hipFree(d_out));
+  /* the call above only QUEUED the work: super-group k is copied and converted while the GPU runs k + 1 */
+  const double t_queued = tnow();
+  proofs_drain(pis, d_out, count, 1);
+  if (tracing())
+    fprintf(stderr, "mfuoco_prover_batch(%zu): stage CRS+SSP %.2f ms, witness bits + entropy %.2f, image + queue %.2f, drain (copy + mpz_t under the GPU work) %.2f\n", count,
+            t_staged - t_in, t_host - t_staged, t_queued - t_host, tnow() - t_queued);
 }
 
 static uint64_t horner_modp(const uint8_t *slot, uint64_t x)
@@ -892,7 +1186,7 @@ bool verifier(ssp_t ssp, vrs_t vrs, proof_t pi)
   KEEP_ERRNO;
   gpu();
   uint32_t dec[5];
-  ct_to_dev(G.d_sk, vrs->sk, GAMMA_N);
+  sk_resident(vrs->sk);
   ct_to_dev(G.d_proof, pi->h, GAMMA_N + 1);
   ct_to_dev(G.d_proof + CTL, pi->hat_h, GAMMA_N + 1);
   ct_to_dev(G.d_proof + 2 * CTL, pi->hat_v, GAMMA_N + 1);
@@ -920,7 +1214,7 @@ void mfuoco_verifier_batch(ssp_t ssp, vrs_t vrs, proof_t *pis, size_t count, uin
   if (!count) return;
   gpu();
   ssp_resident(ssp);
-  ct_to_dev(G.d_sk, vrs->sk, GAMMA_N);
+  sk_resident(vrs->sk);
   uint64_t *d_proofs = NULL, *h = xmalloc(count * 5 * CTL * 8);
   uint8_t *d_ok = NULL;
   HK(hipMalloc((void **)&d_proofs, count * 5 * CTL * 8));
@@ -941,8 +1235,7 @@ void mfuoco_decrypt_batch(mpz_t *ms, sk_t sk, ct_t *cts, size_t count)
 {
   KEEP_ERRNO;
   if (!count) return;
-  gpu();
-  ct_to_dev(G.d_sk, sk, GAMMA_N);
+  sk_resident(sk);
   uint64_t *d_cts = NULL, *h = xmalloc(count * CTL * 8);
   uint32_t *d_m = NULL, *hm = xmalloc(count * 4);
   HK(hipMalloc((void **)&d_cts, count * CTL * 8));

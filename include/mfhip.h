@@ -247,6 +247,13 @@ int mfh_set_mm_chunk_rows(mfh_ctx *ctx, uint32_t rows);
 int mfh_prove_batch(mfh_ctx *ctx, const uint8_t *d_crs_c8, const uint32_t *d_ssp, uint32_t nproofs, const uint8_t *h_witness_bits,
                     size_t bits_stride, const uint32_t *h_delta, const uint8_t *h_smudge_mag, size_t maglen, const uint8_t *h_smudge_sign,
                     uint64_t *d_proofs);
+/* Draining a call while it runs.  mfh_prove_batch queues its work super-group by super-group (mfh_prove_batch_supergroup() statements each: 255 when the
+ * call streams an image, 248 when every group regenerates the keystream; 0 before the first call) and statement k's five ciphertexts are final in d_proofs
+ * once super-group k / size has been smudged.  mfh_prove_batch_stream_wait makes `hip_stream` (a stream of the caller's, not the context's) wait until statements
+ * [0, upto) of the LAST mfh_prove_batch call are final: a device-to-host copy queued on it afterwards runs under the following super-groups' kernels (the host shim's
+ * mfuoco_prover_batch converts super-group k to mpz_t while the GPU works on k + 1).  Row-slab calls complete all statements together. */
+uint32_t mfh_prove_batch_supergroup(const mfh_ctx *ctx);
+int mfh_prove_batch_stream_wait(mfh_ctx *ctx, uint32_t upto, void *hip_stream);
 /* ---- multi-GPU: row-sharded BATCH prover (BASELINE configs 3/4: "ciphertexts sharded across 8 x MI355X + RCCL reduce") ------
  * The loops that shard are src/snark.c:147-155 (b_w over the BT+BV rows) and :157-174 (the four eval_poly passes over the S / AS rows):
  * rank r of `world` owns rows [R r / world, R (r+1) / world) of each region (R = d, d, m) and, for the steps that do not touch the CRS,
@@ -339,7 +346,7 @@ int mfh_eval_rows_multi(mfh_ctx *ctx, uint64_t off, size_t nrows, const uint8_t 
 /* Kernel timing for the roofline leg of bench.py.  With timing enabled every launch of a hot kernel is bracketed by
  * HIP events on the context's stream (no synchronisation is added).  mfh_timing_drain waits for the stream, then
  * reports and forgets the launches of kind `which`: "eval2" / "eval1" (k_eval with 2 / 1 coefficient vectors),
- * "eval" (both), "encrypt", "keystream", "expand", "mac2" / "mac1" (resident MAC), "evalmm" / "evalmm_resident" (mfh_eval_rows_multi from the seed / from the image), "mmstream_rounds" (those of "evalmm_resident" that serve several groups of a batch: the S / AS rounds of mfh_prove_batch; drain it first), "expandmm" (mfh_crs_expand_mm, one launch per region).  total_rows = rows handed to those launches (AES blocks for "keystream"). */
+ * "eval" (both), "encrypt", "keystream", "expand", "mac2" / "mac1" (resident MAC), "evalmm" / "evalmm_resident" (mfh_eval_rows_multi from the seed / from the image), "mmstream_rounds" (those of "evalmm_resident" that serve several groups of a batch: the S / AS rounds of mfh_prove_batch; drain it first), "mmstream_bw" (b_w of several super-groups in one launch), "mmstream_rounds_persistent" / "mmstream_bw_persistent" (those of the two that ran the persistent one-workgroup-per-CU grid; drain them before their supersets), "expandmm" (mfh_crs_expand_mm, one launch per region).  total_rows = rows handed to those launches (AES blocks for "keystream"). */
 int mfh_set_timing(mfh_ctx *ctx, int enabled);
 /* prover scheduling: mfh_prove* run the witness pass + polynomial step on an internal stream beside the evaluation of
  * b_w's rows and join before the S / AS regions; results are identical in every mode.  0 = one stream, 1 (default) = two

@@ -56,10 +56,11 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_sharded_eval_allreduce_gloo(tmp_path):
+@pytest.mark.parametrize("world", [2, 8])
+def test_sharded_eval_allreduce_gloo(tmp_path, world):
+    """the lazy-carry all-reduce of 56-bit lanes against the oracle's eval_poly over all rows; world = 8: the machine's rank count (11 rows: shares of 1 or 2)"""
     import torch.multiprocessing as mp
 
-    world = 2
     port = _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
@@ -224,10 +225,13 @@ def _batch_worker(rank, world, port, out_dir, nb, by_cols=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,nb,by_cols", [(2, 5, False), (2, 4, False), (3, 2, False), (2, 5, True), (3, 2, True), (3, 7, True)])
+@pytest.mark.parametrize("world,nb,by_cols", [(2, 5, False), (2, 4, False), (3, 2, False), (2, 5, True), (3, 2, True), (3, 7, True), (8, 20, False), (8, 5, True),
+                                              (8, 5, False), (8, 20, True)])
 def test_prove_batch_sharded_sequencing_gloo(tmp_path, world, nb, by_cols):
     """uneven statement slabs (5 over 2), even ones, and a rank that owns no statement (2 over 3; d = 13 and m = 9 never divide);
-    by_cols: the chain cut in two -- coefficient ranges of w of all statements per rank, a first all-to-all to the statement owners"""
+    by_cols: the chain cut in two -- coefficient ranges of w of all statements per rank, a first all-to-all to the statement owners.
+    world = 8 is the machine's real rank count (one process per GPU of an 8 x MI355X node): 20 statements = slabs of 3, 3, 3, 3, 3, 3, 2, 0 (the last rank owns
+    none), 5 statements = three ranks without any; row shares of 13 and 9 rows over 8 ranks are 1 or 2 rows each"""
     import torch.multiprocessing as mp
 
     port = _free_port()

@@ -97,6 +97,71 @@ def test_default_size_batch_proof0_matches_oracle_hashes(gpu_ctx_factory, golden
     ctx.close()
 
 
+@pytest.mark.parametrize("mode", ["transient", "resident", "one_wave_per_simd"])
+def test_default_size_shipped_launch_shape_matches_oracle_hashes(gpu_ctx_factory, golden, mode):
+    """The launch shape bench.py's headline runs, under the golden at the NDEBUG default size: 510 statements = two full super-groups of 255, each
+    served by ONE persistent k_mmstream_p launch over the S and AS images (8 + 8 groups of 63 / 64 coefficient vectors, 128 stages of 256 rows,
+    506 tile groups) and b_w of both super-groups by ONE k_mmstream_pb launch over the BT+BV image (the loops of src/snark.c:147-174).  Statement 0
+    is the golden instance (tests/golden/default_size_proof.json: the oracle's complete prover, 111 s of CPU) and must reproduce its five SHA-256s;
+    statements at the super-group boundary and the last one equal the single-proof path (pinned to the same golden in test_gpu_fullsize.py).
+    transient: the call's own image; resident: the caller's; one_wave_per_simd: the k_mmstream_w body (mfh_set_mm_stream(1, 2, 0, 0)).  The timing
+    records say which grid ran: every streaming launch of the call must have been the persistent one."""
+    import torch
+
+    import c_lwe_snarks_amd as mf
+
+    gold, mk = golden
+    p = mf.DEFAULT
+    I = mk.instance(p)
+    ctx = gpu_ctx_factory(p)
+    ctx.set_seed(I["seed"])
+    d_t = ctx.ssp_prg_make_t(gold["prg_seed"], I["bits"])
+    d_ssp = torch.cat([d_t, ctx.ssp_prg_fill(gold["prg_seed"], 1, p.m + 2)])
+    ctx.ssp_prepare(d_ssp)
+    d_crs = ctx.to_device(I["c8"])
+    nb = 510
+    rng = np.random.default_rng(510)
+    bits, deltas, mags, signs = _statements(rng, p, nb)
+    bits[0], deltas[0], mags[0], signs[0] = I["bits"], I["delta"], I["mags"], I["signs"]
+    image = None
+    if mode == "resident":
+        image = ctx.crs_expand_mm(d_crs)
+        ctx.set_resident_mm(image)
+    if mode == "one_wave_per_simd":
+        ctx.set_mm_stream(1, 2, 0, 0)
+    for k in ("mmstream_rounds_persistent", "mmstream_bw_persistent", "mmstream_rounds", "mmstream_bw", "evalmm_resident", "evalmm"):
+        ctx.timing_drain(k)
+    ctx.set_timing(True)
+    try:
+        out = ctx.prove_batch(d_crs, d_ssp, bits, deltas, mags, signs)
+        ctx.sync()
+    finally:
+        ctx.set_timing(False)
+        ctx.set_mm_stream(1, True, 0, 64)
+        if image is not None:
+            ctx.set_resident_mm(None)
+    # what ran: 2 persistent S + AS launches of 16 groups over 32768 rows, 1 persistent b_w launch of 2 groups over 21845 rows, nothing else streamed or regenerated
+    n_rounds, _, rows_rounds = ctx.timing_drain("mmstream_rounds_persistent")
+    work_rounds = ctx.timing_work_rows()
+    n_bw, _, rows_bw = ctx.timing_drain("mmstream_bw_persistent")
+    work_bw = ctx.timing_work_rows()
+    assert (n_rounds, rows_rounds, work_rounds) == (2, 2 * p.d, 2 * 16 * p.d)
+    assert (n_bw, rows_bw, work_bw) == (1, p.m, 2 * p.m)
+    assert ctx.timing_drain("mmstream_rounds")[0] == 0 and ctx.timing_drain("mmstream_bw")[0] == 0  # no launch of the non-persistent grid
+    assert ctx.timing_drain("evalmm_resident")[0] == 0 and ctx.timing_drain("evalmm")[0] == 0        # no single-group launch, no per-group AES
+    nbytes = p.ct_limbs * 8
+    proofs = out.view(nb, 5 * nbytes)
+    sha = lambda t: hashlib.sha256(ctx.to_host(t).tobytes()).hexdigest()
+    for k, nme in enumerate(NAMES):
+        assert sha(proofs[0][k * nbytes:(k + 1) * nbytes]) == gold["proof_sha256"][nme], nme
+    assert sha(proofs[0]) == gold["proof_all_sha256"]
+    for b in (254, 255, nb - 1):
+        one = ctx.prove(d_crs, d_ssp, bits[b], deltas[b], mags[b], signs[b])
+        assert torch.equal(proofs[b], one), f"statement {b}"
+    del image, out
+    ctx.close()
+
+
 def _instance(mf, ctx, oracle, p, seed_int):
     """valid SSP (oracle's random_ssp restatement), GPU setup -> CRS; returns what the oracle's prover / verifier need"""
     rng = np.random.default_rng(seed_int)

@@ -1,5 +1,6 @@
-"""GPU: the reference-signature C shim (libmfuoco_gpu_debug.so) driven by a C program that restates the assertions of
-the reference's own test programs (c-lwe-snarks_amd/host/test_shim.c): same function names and call sequences."""
+"""GPU: the reference-signature C shim (libmfuoco_gpu_debug.so) driven by a C program that exercises what the shim adds to the reference's interface --
+batch encryption / decryption / prover / verifier, the images kept across calls, the on-disk formats (c-lwe-snarks_amd/host/test_shim.c) -- and the C entry
+points for N GPUs.  (The reference's own test programs run against the shim in test_gpu_reference_drivers.py.)"""
 import os
 import subprocess
 
@@ -15,7 +16,7 @@ def test_c_shim_properties():
         pytest.fail("host/test_shim has not been built (make -C c-lwe-snarks_amd shim); the shim needs gmp.h at build time")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "snark ok" in r.stdout
+    assert "encrypt batch ok" in r.stdout and "snark ok" in r.stdout and "files ok" in r.stdout
 
 
 def _sharded_exe():
@@ -40,10 +41,12 @@ def test_c_sharded_prover_one_rank_rccl(tmp_path):
     assert "backend=rccl" in r.stdout and "sharded ok" in r.stdout
 
 
-@pytest.mark.parametrize("world,count", [(2, 9), (3, 40)])
+@pytest.mark.parametrize("world,count", [(2, 9), (3, 40), (6, 41)])
 def test_c_sharded_prover_rehearsal_ranks_share_the_gpu(world, count):
     """the same C sequence with `world` PROCESSES on the one GPU, collectives staged through host shared memory (rehearsal backend): uneven
-    statement slabs and row shares (256 rows over 3 ranks), a second call in which the last rank owns no statement"""
+    statement slabs and row shares (256 rows over 3 ranks), a second call in which the last rank owns no statement.  6 ranks is the most the GPU box lets one
+    command put on its card at once (its process guard), so the machine's real rank count, 8, is rehearsed on the CPU only: the host sequence over gloo in
+    tests/test_dist_cpu.py, the rendezvous in tests/test_rendezvous_cpu.py."""
     name = "mfuoco_test_%d_%d" % (os.getpid(), world)
     procs = [subprocess.Popen([_sharded_exe(), str(count)], env=_rank_env(rk, world, MFUOCO_REHEARSAL_SHM=name, MFUOCO_SHARE_GPU="1"),
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for rk in range(world)]

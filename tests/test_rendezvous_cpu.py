@@ -37,7 +37,7 @@ def _plant_stale(idf, world, nonce=0x1111222233334444, tag=b"S"):
             f.write(struct.pack("<QQQ", MAGIC, nonce, 0xAAAA + k))
 
 
-@pytest.mark.parametrize("world", [2, 3, 5])
+@pytest.mark.parametrize("world", [2, 3, 5, 8])
 def test_ranks_agree_on_the_fresh_id(tmp_path, world):
     _need()
     idf = str(tmp_path / "comm_id")
@@ -48,16 +48,16 @@ def test_ranks_agree_on_the_fresh_id(tmp_path, world):
         assert so.strip() == f"rank {rk} id " + "41" * 8
 
 
-@pytest.mark.parametrize("late_rank0", [False, True])
-def test_stale_files_of_a_killed_job_are_not_believed(tmp_path, late_rank0):
+@pytest.mark.parametrize("world,late_rank0", [(3, False), (3, True), (8, False), (8, True)])
+def test_stale_files_of_a_killed_job_are_not_believed(tmp_path, world, late_rank0):
     """id, go and ack files of an earlier session lie at the path; with late_rank0 the other ranks start FIRST and read the stale id before rank 0 has
-    replaced it (they acknowledge the old nonce; rank 0 deletes those acks; they read again).  Every rank must end up with the NEW id."""
+    replaced it (they acknowledge the old nonce; rank 0 deletes those acks; they read again).  Every rank must end up with the NEW id.  world = 8: the rank count of the
+    8 x MI355X node the C entry points are written for."""
     _need()
-    world = 3
     idf = str(tmp_path / "comm_id")
     _plant_stale(idf, world)
     if late_rank0:
-        procs = {rk: subprocess.Popen([EXE, str(rk), str(world), idf, "30", "N"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for rk in (1, 2)}
+        procs = {rk: subprocess.Popen([EXE, str(rk), str(world), idf, "30", "N"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for rk in range(1, world)}
         time.sleep(0.5)
         procs[0] = subprocess.Popen([EXE, "0", str(world), idf, "30", "N"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         res = {rk: (p.communicate(timeout=120), p.returncode) for rk, p in procs.items()}
