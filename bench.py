@@ -215,6 +215,8 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="run the prover on one stream (A/B check of the side-stream overlap)")
     ap.add_argument("--groups-per-launch", type=int, default=8, help="batch mode: groups of 63 / 64 coefficient vectors per streaming launch and region (8 = a super-group's S and AS regions in one launch; 4 = rounds 1-3)")
     ap.add_argument("--no-merge", action="store_true", help="batch mode: S and AS groups of a round as two launches on two streams (A/B check)")
+    ap.add_argument("--mm-width", type=int, default=32, help="batch mode: workgroups per XCD of the persistent S / AS launch (32 = every CU; A/B knob of the round-5 power experiment)")
+    ap.add_argument("--early-chain", action="store_true", help="batch mode: chain of super-group k + 1 and epilogues of k queued beside the streaming launches (with --mm-width < 32)")
     ap.add_argument("--sharded-batch", type=int, default=None,
                     help="N > 1: statements per step of the row-sharded batch leg for the whole job (default: --batch at the default workload, 255 for config4/5)")
     ap.add_argument("--resident-gb", type=float, default=200.0, help="HBM budget for the resident CRS image per GPU")
@@ -291,6 +293,8 @@ def main():
         ctx.set_overlap(False)
     merge_regions = not args.no_merge
     ctx.set_batch_launch(args.groups_per_launch, merge_regions)
+    if args.mm_width != 32 or args.early_chain:
+        ctx.set_mm_width(args.mm_width, args.early_chain)
     seed = bytes((37 * i + 11) & 0xFF for i in range(40))
     ctx.set_seed(seed)
     if not big:

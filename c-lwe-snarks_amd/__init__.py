@@ -96,7 +96,7 @@ EXPORTS = [
     "mfh_witness_lanes", "mfh_witness_from_lanes", "mfh_prove_partial_w", "mfh_verify",
     "mfh_ssp_set_prg", "mfh_ssp_prg_make_t", "mfh_ssp_prg_fill",
     "mfh_resident_share_rows", "mfh_crs_expand_share", "mfh_crs_set_resident_share", "mfh_crs_set_resident_prefix",
-    "mfh_prove_batch_supergroup", "mfh_prove_batch_stream_wait",
+    "mfh_prove_batch_supergroup", "mfh_prove_batch_stream_wait", "mfh_set_mm_width",
 ]
 
 
@@ -142,6 +142,7 @@ def load_library():
         "mfh_crs_set_resident_mm": (i32, [vp, vp]),
         "mfh_prove_batch": (i32, [vp, vp, vp, u32, ctypes.c_char_p, sz, vp, ctypes.c_char_p, sz, ctypes.c_char_p, vp]),
         "mfh_prove_batch_supergroup": (u32, [vp]),
+        "mfh_set_mm_width": (i32, [vp, u32, i32]),
         "mfh_prove_batch_stream_wait": (i32, [vp, u32, vp]),
         "mfh_poly_mul": (i32, [vp, vp, sz, vp, sz, vp]),
         "mfh_poly_add": (i32, [vp, vp, vp, sz, vp]),
@@ -317,6 +318,10 @@ class Context:
     def set_mm_stream(self, map=0, persistent=False, sync_mode=0, spin_max=64):
         """layout of a streaming launch with several groups: slot map (0 | 1), persistent one-workgroup-per-CU grid, rendezvous of the sharers (0 | 1 | 2)"""
         self._chk(self.lib.mfh_set_mm_stream(self._h, int(map), int(persistent), int(sync_mode), int(spin_max)))
+
+    def set_mm_width(self, per_xcd=32, early_chain=False):
+        """workgroups per XCD of the persistent S / AS launch (32 = every CU); early_chain: chain / epilogues queued beside the streaming launches"""
+        self._chk(self.lib.mfh_set_mm_width(self._h, int(per_xcd), 1 if early_chain else 0))
 
     def set_mm_chunk_rows(self, rows=0):
         """rows per row chunk of the matrix-core launches (<= 131071; 0 = default): smaller values force several chunks"""

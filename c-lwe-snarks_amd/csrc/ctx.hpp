@@ -104,6 +104,8 @@ struct mfh_ctx {
   bool mm_persist = true;
   bool mm_wave1 = false;  // persistent grid with one wave per SIMD and 256 accumulators in AccVGPRs (k_mmstream_w)
   uint32_t mm_sync_mode = 0, mm_spin = 64;
+  uint32_t mm_width = 32;  // workgroups per XCD of the persistent S / AS launch (mfh_set_mm_width): 32 = every CU
+  bool batch_early_chain = false;  // mfh_prove_batch: chain of super-group k + 1 and epilogue of k queued BESIDE the streaming launch of k / k + 1 (for the CUs a narrower grid leaves free)
   uint32_t *mm_sync = nullptr;  // 8 x 32 counters of the persistent grid's rendezvous
   uint32_t mm_chunk_rows = 131071;  // rows per row chunk of the matrix-core launches (int32 accumulators: |A'C'| <= 2^14 per row)
   int expand_path = 0;     // mfh_crs_expand_mm*: 0 = k_expand_mm (lane = row, MFMA transposition, no LDS tile), 1 = k_evalmm16<MODE 1> (LDS tile + byte gathers)
@@ -118,6 +120,7 @@ struct mfh_ctx {
   int batch_merge = 1;     // the S and AS groups of a round in one streaming launch (0: two launches on two streams)
   uint32_t batch_ngl = 8;  // groups of 63 / 64 coefficient vectors per streaming launch and region (1..8; 8 = a super-group's S and AS regions in ONE launch)
   PinBuf pin_rows, pin_cw, pin_smudge;
+  void *uploader = nullptr;  // mfh_ssp_upload: per-thread pinned / device staging pairs and streams (mfhip.hip), made on the first large upload
   // generator-defined SSP (ssp_prg.hpp): used by every entry point that is handed d_ssp == NULL
   bool prg_on = false;
   uint64_t prg_seed = 0;

@@ -739,49 +739,44 @@ __global__ __launch_bounds__(SW * 64) void k_mmstream1(MmsImages imgs, uint32_t 
 // arrived OR spin_max polls have passed.  The rendezvous is for speed only (the members then find each other's fragments in the XCD's L2): nothing is
 // handed over, a member that is not resident (fewer CUs than workgroups, another kernel on the GPU) only costs the others spin_max polls per item, and
 // every wave reaches the end of the grid whatever the counters hold.  sync: 8 x 32 counters zeroed before the launch.
-__global__ __launch_bounds__(SW * 64) void k_mmstream_p(MmsImages imgs, uint32_t mtiles, uint32_t KS, uint32_t nrows, uint32_t rows_per_chunk,
-                                                        const v4i *__restrict__ cdv, int *__restrict__ part, uint32_t ngt, uint32_t ngr, uint32_t map,
-                                                        uint64_t cd_stride, uint64_t part_stride, uint32_t nblk /* 32-slot blocks per XCD */, uint32_t nchunks,
-                                                        uint32_t *__restrict__ sync, uint32_t sync_mode, uint32_t spin_max) {
+// (`width`: workgroups per XCD = grid / 8, 32 by default -- every CU --; fewer leave CUs of every XCD to other streams' kernels, and the workgroup then strides
+// over its XCD's slots by `width` (mfh_set_mm_width: the round-5 experiment on the power finding, EXPERIMENTS.md); the rendezvous needs width == 32)
+__device__ __forceinline__ void mmstream_persistent(const MmsImages &imgs, uint32_t mtiles, uint32_t KS, uint32_t nrows, uint32_t rows_per_chunk,
+                                                    const v4i *__restrict__ cdv, int *__restrict__ part, uint32_t ngt, uint32_t ngr, uint32_t map,
+                                                    uint64_t cd_stride, uint64_t part_stride, uint32_t nblk /* 32-slot blocks per XCD */, uint32_t nchunks,
+                                                    uint32_t *__restrict__ sync, uint32_t sync_mode, uint32_t spin_max, uint32_t width) {
   const uint32_t xcd = blockIdx.x & 7, cu = blockIdx.x >> 3;
   const uint32_t members = sync_mode == 2 ? 32u : (map ? ngr : ngt);
   uint32_t *ctr = sync + xcd * 32 + (sync_mode == 2 ? 0u : cu / members);
-  for (uint32_t k = 0; k < nblk * nchunks; k++) {
-    if (sync_mode && members > 1) {
-      if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t target = (k + 1) * members;
-        for (uint32_t spin = 0; spin < spin_max && __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; spin++) __builtin_amdgcn_s_sleep(8);
+  uint32_t k = 0;
+  for (uint32_t chunk = 0; chunk < nchunks; chunk++)
+    for (uint32_t slot = cu; slot < nblk * 32; slot += width, k++) {
+      if (sync_mode && members > 1) {
+        if (threadIdx.x == 0) {
+          __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const uint32_t target = (k + 1) * members;
+          for (uint32_t spin = 0; spin < spin_max && __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; spin++) __builtin_amdgcn_s_sleep(8);
+        }
+        __syncthreads();
       }
-      __syncthreads();
+      uint32_t grp, tg;
+      mms_item(xcd, slot, ngt, ngr, map, grp, tg);
+      mmstream_body(imgs, mtiles, KS, nrows, rows_per_chunk, cdv, part, grp, tg, chunk, cd_stride, part_stride);
     }
-    uint32_t grp, tg;
-    mms_item(xcd, (k % nblk) * 32 + cu, ngt, ngr, map, grp, tg);
-    mmstream_body(imgs, mtiles, KS, nrows, rows_per_chunk, cdv, part, grp, tg, k / nblk, cd_stride, part_stride);
-  }
+}
+__global__ __launch_bounds__(SW * 64) void k_mmstream_p(MmsImages imgs, uint32_t mtiles, uint32_t KS, uint32_t nrows, uint32_t rows_per_chunk,
+                                                        const v4i *__restrict__ cdv, int *__restrict__ part, uint32_t ngt, uint32_t ngr, uint32_t map,
+                                                        uint64_t cd_stride, uint64_t part_stride, uint32_t nblk, uint32_t nchunks,
+                                                        uint32_t *__restrict__ sync, uint32_t sync_mode, uint32_t spin_max, uint32_t width) {
+  mmstream_persistent(imgs, mtiles, KS, nrows, rows_per_chunk, cdv, part, ngt, ngr, map, cd_stride, part_stride, nblk, nchunks, sync, sync_mode, spin_max, width);
 }
 // the same grid under another name for the launch that serves b_w of several super-groups (one-byte coefficient columns over the BT+BV image): profiles then show
 // the two launch shapes -- 16 groups x 32768 rows, matrix-core bound; up to 8 groups x 21845 rows -- as two rows
 __global__ __launch_bounds__(SW * 64) void k_mmstream_pb(MmsImages imgs, uint32_t mtiles, uint32_t KS, uint32_t nrows, uint32_t rows_per_chunk,
-                                                        const v4i *__restrict__ cdv, int *__restrict__ part, uint32_t ngt, uint32_t ngr, uint32_t map,
-                                                        uint64_t cd_stride, uint64_t part_stride, uint32_t nblk /* 32-slot blocks per XCD */, uint32_t nchunks,
-                                                        uint32_t *__restrict__ sync, uint32_t sync_mode, uint32_t spin_max) {
-  const uint32_t xcd = blockIdx.x & 7, cu = blockIdx.x >> 3;
-  const uint32_t members = sync_mode == 2 ? 32u : (map ? ngr : ngt);
-  uint32_t *ctr = sync + xcd * 32 + (sync_mode == 2 ? 0u : cu / members);
-  for (uint32_t k = 0; k < nblk * nchunks; k++) {
-    if (sync_mode && members > 1) {
-      if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t target = (k + 1) * members;
-        for (uint32_t spin = 0; spin < spin_max && __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; spin++) __builtin_amdgcn_s_sleep(8);
-      }
-      __syncthreads();
-    }
-    uint32_t grp, tg;
-    mms_item(xcd, (k % nblk) * 32 + cu, ngt, ngr, map, grp, tg);
-    mmstream_body(imgs, mtiles, KS, nrows, rows_per_chunk, cdv, part, grp, tg, k / nblk, cd_stride, part_stride);
-  }
+                                                         const v4i *__restrict__ cdv, int *__restrict__ part, uint32_t ngt, uint32_t ngr, uint32_t map,
+                                                         uint64_t cd_stride, uint64_t part_stride, uint32_t nblk, uint32_t nchunks,
+                                                         uint32_t *__restrict__ sync, uint32_t sync_mode, uint32_t spin_max, uint32_t width) {
+  mmstream_persistent(imgs, mtiles, KS, nrows, rows_per_chunk, cdv, part, ngt, ngr, map, cd_stride, part_stride, nblk, nchunks, sync, sync_mode, spin_max, width);
 }
 
 // ---- k_mmstream_w: the same GEMM with ONE wave per SIMD (round 4) -----------------------------------------------------------------------------------
@@ -1704,8 +1699,9 @@ int mms_stream(mfh_ctx *c, const MmsPlan &P) {
     } else if (persistent) {
       if (!c->mm_sync) HIP_TRY(c, hipMalloc(&c->mm_sync, 8 * 32 * sizeof(uint32_t)));
       if (c->mm_sync_mode) HIP_TRY(c, hipMemsetAsync(c->mm_sync, 0, 8 * 32 * sizeof(uint32_t), c->stream));  // (the rendezvous counters; unused by default)
-      hipLaunchKernelGGL(P.ND == 1 ? k_mmstream_pb : k_mmstream_p, dim3(256), dim3(SW * 64), 0, c->stream, imgs, P.mtiles, KS, P.nrows, P.rpc, (const v4i *)P.cd, P.part, P.ngt, P.ng, map,
-                         (uint64_t)(P.cd_bytes / 16), (uint64_t)(P.part_bytes / 4), (slots + 31) / 32, P.nchunks, c->mm_sync, c->mm_sync_mode, c->mm_spin);
+      const uint32_t width = P.ND == 1 ? 32u : c->mm_width;  // (b_w's HBM-bound launch keeps every CU)
+      hipLaunchKernelGGL(P.ND == 1 ? k_mmstream_pb : k_mmstream_p, dim3(8 * width), dim3(SW * 64), 0, c->stream, imgs, P.mtiles, KS, P.nrows, P.rpc, (const v4i *)P.cd, P.part, P.ngt, P.ng, map,
+                         (uint64_t)(P.cd_bytes / 16), (uint64_t)(P.part_bytes / 4), (slots + 31) / 32, P.nchunks, c->mm_sync, width == 32 ? c->mm_sync_mode : 0u, c->mm_spin, width);
     } else {
       hipLaunchKernelGGL(k_mmstream, dim3(slots * 8, P.nchunks), dim3(SW * 64), 0, c->stream, imgs, P.mtiles, KS, P.nrows, P.rpc, (const v4i *)P.cd, P.part, P.ngt, P.ng,
                          map, (uint64_t)(P.cd_bytes / 16), (uint64_t)(P.part_bytes / 4));
@@ -1844,6 +1840,12 @@ int mfh_set_mm_stream(mfh_ctx *c, int map, int persistent, int sync_mode, uint32
   c->mm_wave1 = persistent == 2;  // the one-wave-per-SIMD body (k_mmstream_w)
   c->mm_sync_mode = (uint32_t)sync_mode;
   c->mm_spin = spin_max;
+  return MFH_OK;
+}
+int mfh_set_mm_width(mfh_ctx *c, uint32_t per_xcd, int early_chain) {
+  if (!c || per_xcd < 1 || per_xcd > 32) return MFH_EINVAL;
+  c->mm_width = per_xcd;
+  c->batch_early_chain = early_chain != 0;
   return MFH_OK;
 }
 int mfh_set_mm_chunk_rows(mfh_ctx *c, uint32_t rows) {

@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "aes_dev.hpp"
@@ -41,6 +42,8 @@ struct PS {
 };
 
 #include "ctx.hpp"
+
+static void upload_free(mfh_ctx *c);  // (mfh_ssp_upload's staging lanes, below)
 
 // ------------------------------------------------------------------------------------------------------
 // keystream kernel: aesctr_prg / rng_seek (src/aes.c:104-144, src/entropy.c:46-56), stateless form
@@ -1095,6 +1098,7 @@ void mfh_ctx_destroy(mfh_ctx *c) {
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
   mfh_poly_destroy(c);
+  upload_free(c);
   pin_free(c->pin_rows);
   pin_free(c->pin_cw);
   pin_free(c->pin_smudge);
@@ -1744,25 +1748,101 @@ int mfh_ct_smudge(mfh_ctx *c, uint64_t *d_cts, size_t count, const uint8_t *h_ma
   return MFH_OK;
 }
 
+// The SSP comes from pageable host memory (a calloc'ed or mmap'ed buffer of the caller's: 5.7 GB at the default instance).  Handed to hipMemcpy as it is, the runtime
+// stages it through its own pinned buffer on ONE thread (about 12 GB/s: 0.45 s of setup()'s 0.55 s).  Here UP_T host threads each take every UP_T-th chunk of
+// UP_CHUNK bytes: memcpy into the thread's own pinned pair, an asynchronous copy and the uint64 -> uint32 reduction (k_ssp_reduce) on the thread's own stream, the
+// second buffer being filled while the first one crosses PCIe.  Host work is byte moving only; the reduction mod p stays on the GPU.
+namespace {
+constexpr size_t UP_CHUNK = (size_t)4 << 20;
+constexpr int UP_T = 8;
+struct UpLane {
+  hipStream_t st = nullptr;
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  uint8_t *pin[2] = {nullptr, nullptr};
+  uint8_t *dev[2] = {nullptr, nullptr};
+};
+struct Uploader {
+  UpLane lane[UP_T];
+  bool ready = false;
+};
+}  // namespace
+static void upload_free(mfh_ctx *c) {
+  Uploader *u = (Uploader *)c->uploader;
+  if (!u) return;
+  for (auto &l : u->lane) {
+    for (int i = 0; i < 2; i++) {
+      if (l.pin[i]) hipHostFree(l.pin[i]);
+      if (l.dev[i]) hipFree(l.dev[i]);
+      if (l.ev[i]) hipEventDestroy(l.ev[i]);
+    }
+    if (l.st) hipStreamDestroy(l.st);
+  }
+  delete u;
+  c->uploader = nullptr;
+}
 int mfh_ssp_upload(mfh_ctx *c, const void *h_ssp_u64, uint32_t *d_ssp, size_t first_slot, size_t nslots) {
   if (!c || !h_ssp_u64 || !d_ssp) return MFH_EINVAL;
   c->ssp_frag_src = nullptr;  // derived images of the SSP are stale
   HIP_TRY(c, hipSetDevice(c->device));
   const size_t d = c->P.d;
-  const size_t chunk_slots = std::max<size_t>(1, (64u << 20) / (8 * d));
-  void *stage = nullptr;
-  HIP_TRY(c, hipMalloc(&stage, chunk_slots * d * 8));
-  int rc = MFH_OK;
-  for (size_t s = 0; s < nslots && rc == MFH_OK; s += chunk_slots) {
-    size_t ns = std::min(chunk_slots, nslots - s);
-    const uint8_t *src = (const uint8_t *)h_ssp_u64 + (first_slot + s) * d * 8;
-    if (hipMemcpyAsync(stage, src, ns * d * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = MFH_EDEVICE; break; }
-    hipLaunchKernelGGL(k_ssp_reduce, dim3(2048), dim3(256), 0, c->stream, (const uint64_t *)stage, d_ssp + (first_slot + s) * d, (uint64_t)ns * d);
+  const size_t total = nslots * d * 8;  // bytes of uint64 coefficients
+  if (!total) return MFH_OK;
+  const uint8_t *src = (const uint8_t *)h_ssp_u64 + first_slot * d * 8;
+  uint32_t *dst = d_ssp + first_slot * d;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));  // what the caller queued before (e.g. readers of the old image) is over
+  const size_t nchunks = (total + UP_CHUNK - 1) / UP_CHUNK;
+  if (nchunks < 2 * UP_T) {  // small images (the debug SSP is 137 KB): one copy on the caller's stream
+    void *stage = nullptr;
+    HIP_TRY(c, hipMalloc(&stage, total));
+    int rc = MFH_OK;
+    if (hipMemcpyAsync(stage, src, total, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = MFH_EDEVICE;
+    if (!rc) hipLaunchKernelGGL(k_ssp_reduce, dim3(2048), dim3(256), 0, c->stream, (const uint64_t *)stage, dst, (uint64_t)(total / 8));
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) rc = MFH_EDEVICE;
+    hipFree(stage);
+    if (rc) c->err = "ssp upload failed";
+    return rc;
   }
-  hipFree(stage);
-  if (rc) c->err = "ssp upload failed";
-  return rc;
+  Uploader *u = (Uploader *)c->uploader;
+  if (!u) c->uploader = u = new Uploader();
+  if (!u->ready) {
+    for (auto &l : u->lane) {
+      HIP_TRY(c, hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking));
+      for (int i = 0; i < 2; i++) {
+        HIP_TRY(c, hipEventCreateWithFlags(&l.ev[i], hipEventDisableTiming));
+        HIP_TRY(c, hipHostMalloc((void **)&l.pin[i], UP_CHUNK, hipHostMallocDefault));
+        HIP_TRY(c, hipMalloc((void **)&l.dev[i], UP_CHUNK));
+      }
+    }
+    u->ready = true;
+  }
+  int failed[UP_T] = {};
+  auto work = [&](int t) {
+    if (hipSetDevice(c->device) != hipSuccess) { failed[t] = 1; return; }
+    UpLane &l = u->lane[t];
+    int slot = 0;
+    bool used[2] = {false, false};
+    for (size_t k = (size_t)t; k < nchunks; k += UP_T, slot ^= 1) {
+      const size_t off = k * UP_CHUNK, nb = std::min(UP_CHUNK, total - off);
+      if (used[slot] && hipEventSynchronize(l.ev[slot]) != hipSuccess) { failed[t] = 1; return; }
+      memcpy(l.pin[slot], src + off, nb);
+      if (hipMemcpyAsync(l.dev[slot], l.pin[slot], nb, hipMemcpyHostToDevice, l.st) != hipSuccess) { failed[t] = 1; return; }
+      hipLaunchKernelGGL(k_ssp_reduce, dim3(256), dim3(256), 0, l.st, (const uint64_t *)l.dev[slot], dst + off / 8, (uint64_t)(nb / 8));
+      if (hipEventRecord(l.ev[slot], l.st) != hipSuccess) { failed[t] = 1; return; }
+      used[slot] = true;
+    }
+    if (hipStreamSynchronize(l.st) != hipSuccess) failed[t] = 1;
+  };
+  std::thread th[UP_T];
+  int started = 0;
+  for (int t = 1; t < UP_T; t++) {
+    try { th[t] = std::thread(work, t); started++; } catch (...) { break; }
+  }
+  work(0);
+  for (int t = started + 1; t < UP_T; t++) work(t);  // lanes whose thread could not be had run here, one after the other
+  for (int t = 1; t <= started; t++) th[t].join();
+  for (int t = 0; t < UP_T; t++)
+    if (failed[t] || hipGetLastError() != hipSuccess) { c->err = "ssp upload failed"; return MFH_EDEVICE; }
+  return MFH_OK;
 }
 
 // shared body: partial[g][k] sums over this rank's share of the selected SSP rows

@@ -660,7 +660,8 @@ int batch_bw(mfh_ctx *c, const uint8_t *d_crs_c8, uint32_t rank, uint32_t world,
 // d_cw: the super-group's staged area (batch_stage_host), or nullptr: staged here from h_bits / h_delta.
 int batch_rows_supergroup(mfh_ctx *c, const uint8_t *d_crs_c8, uint32_t rank, uint32_t world, uint32_t sg, const uint8_t *h_bits,
                           size_t bits_stride, const BatchCoef &co, uint64_t *sproofs, const BatchScratch &B, size_t &slot,
-                          const uint32_t *h_delta, hipEvent_t wait_ev, int accumulate = 0, const uint8_t *d_cw = nullptr, bool bw_done = false) {
+                          const uint32_t *h_delta, hipEvent_t wait_ev, int accumulate = 0, const uint8_t *d_cw = nullptr, bool bw_done = false,
+                          uint32_t ws_slot = 0 /* early mode: which half of ws3 */, bool *tail_on_side = nullptr /* early mode: the epilogues were queued on c->side, not joined */) {
   const uint32_t d = c->P.d, m = c->P.m, n = c->P.n;
   const uint32_t ctb = c->P.logq / 8;
   const size_t ctl = (size_t)(n + 1) * ((c->P.logq + 63) / 64);
@@ -736,9 +737,12 @@ int batch_rows_supergroup(mfh_ctx *c, const uint8_t *d_crs_c8, uint32_t rank, ui
       if (!mms_plan(c, regs, 2, cS, io[R], nv[R], ng, 4, plan[R])) { c->err = "mfh_prove_batch: the registered image does not serve the S / AS regions"; return MFH_EINVAL; }
       ws_need += (mms_ws_bytes(plan[R]) + 255) & ~(size_t)255;
     }
-    rc = buf_reserve(c, c->ws3, c->ws3_bytes, ws_need);
+    // early mode (mfh_set_mm_width): the epilogues of this super-group run on the side stream beside the NEXT super-group's digit and streaming kernels, which
+    // therefore get the other half of ws3
+    const bool early = c->batch_early_chain && tail_on_side;
+    rc = buf_reserve(c, c->ws3, c->ws3_bytes, early ? 2 * ws_need : ws_need);
     if (rc) return rc;
-    size_t wo = 0;
+    size_t wo = early ? (size_t)(ws_slot & 1) * ws_need : 0;
     for (uint32_t r = 0; r < R; r++) {
       mms_bind(plan[r], (uint8_t *)c->ws3 + wo);
       wo += (mms_ws_bytes(plan[r]) + 255) & ~(size_t)255;
@@ -748,8 +752,25 @@ int batch_rows_supergroup(mfh_ctx *c, const uint8_t *d_crs_c8, uint32_t rank, ui
     for (uint32_t r = 0; r < R; r++) {
       rc = mms_stream(c, plan[r]);
       if (rc) return rc;
+      if (early) {  // epilogue on the side stream, behind this round's launch only
+        while (c->ev_round.size() <= r) {
+          hipEvent_t e;
+          HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+          c->ev_round.push_back(e);
+        }
+        HIP_TRY(c, hipEventRecord(c->ev_round[r], main_stream));
+        HIP_TRY(c, hipStreamWaitEvent(side_stream, c->ev_round[r], 0));
+        OnStream side(c, side_stream);
+        rc = mms_finish(c, plan[r], io[r], nv[r], accumulate);
+        if (rc) return rc;
+        continue;
+      }
       rc = mms_finish(c, plan[r], io[r], nv[r], accumulate);  // (on a side stream beside the next launch the epilogues starve -- 0.5 ms each instead of 0.05 -- and slow that launch by more than they take alone)
       if (rc) return rc;
+    }
+    if (early) {  // the caller continues this super-group (smudging, completion event) on the side stream and joins once, at the end of the call
+      *tail_on_side = true;
+      return MFH_OK;
     }
   } else {
     // Regenerating regime (or one group per launch): two streams, so that one stream's small kernels run under the other's row kernel
@@ -1032,28 +1053,47 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
     }
     bw_done = true;
   }
+  // early mode (mfh_set_mm_width(ctx, w < 32, 1): the persistent streaming launch leaves CUs of every XCD free): the chain of super-group k + 1 is queued BESIDE the
+  // row work of super-group k (its w | h | v area was last read by k - 1) and the epilogues + smudging of k beside the row work of k + 1, instead of between them
+  const bool early = c->batch_early_chain && bw_done;
+  bool any_on_side = false;
   for (uint32_t s0 = 0, sgi = 0; s0 < nproofs; s0 += SG, sgi++) {
     const uint32_t sg = std::min(SG, nproofs - s0);
     uint64_t *sproofs = d_proofs + (size_t)s0 * 5 * ctl;
     uint32_t *WALL, *HALL, *VALL;
     whv_of(sgi, WALL, HALL, VALL);
     const BatchCoef co = {WALL, HALL, VALL, d};
+    if (early && sgi + 1 < nsg) {
+      if (sgi >= 1) HIP_TRY(c, hipStreamWaitEvent(chain_stream, c->ev_rdone[(sgi - 1) % nbuf], 0));
+      rc = launch_chain(sgi + 1);
+      if (rc) return rc;
+    }
     // b_w's pass over the BT+BV image is HBM-bound like the chain's witness pass, and the chain is what the S / AS launches wait for: b_w
     // starts when the witness pass is over and runs beside the polynomial step (NTT: VALU / LDS)
     HIP_TRY(c, hipStreamWaitEvent(main_stream, c->ev_wdone[sgi % nbuf], 0));
     // the multi-vector launches read their coefficient vectors where the polynomial step left them and write the proof structs in place (MmIo)
+    bool on_side = false;
     rc = batch_rows_supergroup(c, d_crs_c8, 0, 1, sg, h_witness_bits + (size_t)s0 * bits_stride, bits_stride, co, sproofs, B, slot, h_delta + s0,
-                               c->ev_cdone[sgi % nbuf], 0, B.CW + (size_t)sgi * B.cw_stride, bw_done);
+                               c->ev_cdone[sgi % nbuf], 0, B.CW + (size_t)sgi * B.cw_stride, bw_done, sgi, early ? &on_side : nullptr);
     if (rc) return rc;
-    if (sgi + 1 < nsg) {  // the next super-group's chain, into the other area (last read by super-group sgi - 1)
+    if (early) HIP_TRY(c, hipEventRecord(c->ev_rdone[sgi % nbuf], main_stream));  // (the digit kernels were the last readers of the area)
+    else if (sgi + 1 < nsg) {  // the next super-group's chain, into the other area (last read by super-group sgi - 1)
       HIP_TRY(c, hipEventRecord(c->ev_rdone[sgi % nbuf], main_stream));
       HIP_TRY(c, hipStreamWaitEvent(chain_stream, c->ev_rdone[sgi % nbuf], 0));
       rc = launch_chain(sgi + 1);
       if (rc) return rc;
     }
-    rc = batch_smudge_staged(c, B, sproofs, s0, sg);
-    if (rc) return rc;
-    HIP_TRY(c, hipEventRecord(c->ev_sgdone[sgi], main_stream));  // this super-group's proofs are final (b_w was written before the loop or by batch_rows_supergroup)
+    {
+      OnStream tail(c, on_side ? c->side : main_stream);
+      rc = batch_smudge_staged(c, B, sproofs, s0, sg);
+      if (rc) return rc;
+      HIP_TRY(c, hipEventRecord(c->ev_sgdone[sgi], c->stream));  // this super-group's proofs are final (b_w was written before the loop or by batch_rows_supergroup)
+    }
+    any_on_side = any_on_side || on_side;
+  }
+  if (any_on_side) {  // the caller's stream ends behind everything the call queued
+    HIP_TRY(c, hipEventRecord(c->ev_join, c->side));
+    HIP_TRY(c, hipStreamWaitEvent(main_stream, c->ev_join, 0));
   }
   c->last_batch_sg = SG;
   c->last_batch_n = nproofs;

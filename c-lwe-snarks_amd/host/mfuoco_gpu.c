@@ -54,6 +54,8 @@ static struct {
   uint64_t *d_err;
   uint64_t *d_out;    /* mfuoco_prover_batch: out_cap proofs */
   size_t out_cap;
+  uint64_t *d_up;     /* mfuoco_verifier_batch / mfuoco_decrypt_batch: up_cap ciphertexts + up_cap result words */
+  size_t up_cap;
   /* the secret key last uploaded: host copy of its limbs (exact comparison, no digest) so that a caller encrypting / decrypting in a loop under one key uploads it once */
   uint64_t *h_sk, *pin_sk;
   bool sk_valid;
@@ -812,18 +814,24 @@ void setup(crs_t crs, vrs_t vrs, ssp_t ssp)
   key_gen(vrs->sk);
   const size_t rows = 2 * (size_t)GAMMA_D + GAMMA_M;
   /* errors: 559-bit draws (errdist_uniform) + the ineffective sign byte per encryption (src/lwe.c:85-87) */
-  uint64_t *err = calloc(rows * L_LIMBS, 8);
-  for (size_t i = 0; i < rows; i++) {
-    uint8_t sign;
-    shim_random(err + i * L_LIMBS, (GAMMA_LOG_SIGMA + 3) / 8);
-    shim_random(&sign, 1);
-  }
+  /* (drawn in ONE piece on this thread, in the reference's order -- 69 + 1 bytes per encryption --, then cut up: 175 000 system calls were 0.1 s of this function) */
+  const double t_in = tnow();
+  enum { EB = (GAMMA_LOG_SIGMA + 3) / 8, DRAW = EB + 1 };
+  uint64_t *err = xcalloc(rows * L_LIMBS, 8);
+  uint8_t *tape = xmalloc(rows * DRAW);
+  shim_random(tape, rows * DRAW);
+  for (size_t i = 0; i < rows; i++) memcpy(err + i * L_LIMBS, tape + i * DRAW, EB);
+  explicit_bzero(tape, rows * DRAW);
+  free(tape);
   if (!G.d_err) HK(hipMalloc((void **)&G.d_err, rows * L_LIMBS * 8));
   HK(hipMemcpy(G.d_err, err, rows * L_LIMBS * 8, hipMemcpyHostToDevice));
+  explicit_bzero(err, rows * L_LIMBS * 8); /* the encryption errors are part of the trapdoor: not left on the heap */
   free(err);
   sk_resident(vrs->sk);
+  const double t_drawn = tnow();
   G.ssp_host = NULL;
   ssp_resident(ssp);
+  const double t_ssp = tnow();
   drop_image(); /* G.d_crs is about to be rewritten */
   G.staged_digest_valid = false;
   CK(mfh_setup(G.ctx, G.d_ssp, (uint32_t)vrs->alpha, (uint32_t)vrs->beta, (uint32_t)vrs->s, G.d_sk, G.d_err, G.d_crs));
@@ -831,7 +839,11 @@ void setup(crs_t crs, vrs_t vrs, ssp_t ssp)
   HK(hipMemcpy(crs->as, G.d_crs + CT_BYTES * GAMMA_D, CT_BYTES * GAMMA_D, hipMemcpyDeviceToHost));
   HK(hipMemcpy(crs->t, G.d_crs + 2 * CT_BYTES * GAMMA_D, CT_BYTES, hipMemcpyDeviceToHost));
   HK(hipMemcpy(crs->v, G.d_crs + (2 * GAMMA_D + 1) * CT_BYTES, CT_BYTES * (GAMMA_M - 1), hipMemcpyDeviceToHost));
+  const double t_crs = tnow();
   shim_warm_prover();
+  if (tracing())
+    fprintf(stderr, "setup(): key + error draws and upload %.2f ms, SSP upload (%.2f GB) + quotient precomputation %.2f, encryptions + CRS download %.2f, prover warm-up %.2f\n",
+            t_drawn - t_in, SSP_SIZE / 1e9, t_ssp - t_drawn, t_crs - t_ssp, tnow() - t_crs);
 }
 
 /* ---- pieces shared with the multi-GPU entry points (host/mfuoco_dist.c, libmfuoco_gpu_dist): not part of the reference interface ---- */
@@ -1156,6 +1168,7 @@ void mfuoco_prover_batch(proof_t *pis, crs_t crs, ssp_t ssp, mpz_t *witnesses, s
   mfuoco_gpu_prover_entropy_batch(delta, mag, sign, count);
   const double t_host = tnow();
   image_resident_mm(d_crs, 0, 1, count > 31); /* (smaller calls do not expand an image at all; one kept from an earlier call is used if it still serves this CRS) */
+  const double t_image = tnow();
   int rc = mfh_prove_batch(G.ctx, d_crs, d_ssp, (uint32_t)count, bits, stride, delta, mag, maglen, sign, d_out);
   explicit_bzero(mag, count * 5 * maglen); /* the smudging terms and deltas are the proofs' zero-knowledge: not left on the heap */
   explicit_bzero(sign, count * 5);
@@ -1166,8 +1179,8 @@ void mfuoco_prover_batch(proof_t *pis, crs_t crs, ssp_t ssp, mpz_t *witnesses, s
   const double t_queued = tnow();
   proofs_drain(pis, d_out, count, 1);
   if (tracing())
-    fprintf(stderr, "mfuoco_prover_batch(%zu): stage CRS+SSP %.2f ms, witness bits + entropy %.2f, image + queue %.2f, drain (copy + mpz_t under the GPU work) %.2f\n", count,
-            t_staged - t_in, t_host - t_staged, t_queued - t_host, tnow() - t_queued);
+    fprintf(stderr, "mfuoco_prover_batch(%zu): stage CRS+SSP %.2f ms, witness bits + entropy %.2f, image %.2f, queue %.2f, drain (copy + mpz_t under the GPU work) %.2f\n", count,
+            t_staged - t_in, t_host - t_staged, t_image - t_host, t_queued - t_image, tnow() - t_queued);
 }
 
 static uint64_t horner_modp(const uint8_t *slot, uint64_t x)
@@ -1206,6 +1219,40 @@ bool verifier(ssp_t ssp, vrs_t vrs, proof_t pi)
   return true;
 }
 
+/* The way up: `nct` ciphertexts (proof structs are 5 each) converted slab by slab into the drain's two pinned buffers on the host threads and copied on the shim's own
+ * stream, slab j + 1 being converted while slab j crosses PCIe; the kernels' (default) stream is made to wait for the last copy.  conv = proofs_to_limbs (src = proof_t's)
+ * or cts_to_limbs (src = ct_t's). */
+static void cts_upload(uint64_t *d_dst, proof_t *pis, ct_t *cts, size_t nct)
+{
+  drain_init();
+  const size_t slab = DRAIN_SLAB * 5; /* ciphertexts per pinned buffer */
+  int slot = 0;
+  bool used[2] = { false, false };
+  for (size_t c0 = 0; c0 < nct; c0 += slab, slot ^= 1) {
+    const size_t nk = nct - c0 < slab ? nct - c0 : slab;
+    if (used[slot]) HK(hipEventSynchronize(DR.ev[slot]));
+    struct conv_arg a = { pis ? pis + c0 / 5 : NULL, cts ? cts + c0 : NULL, DR.pin[slot] };
+    parallel_for(nk * (size_t)(GAMMA_N + 1), pis ? proofs_to_limbs : cts_to_limbs, &a);
+    HK(hipMemcpyAsync(d_dst + c0 * CTL, DR.pin[slot], nk * CTL * 8, hipMemcpyHostToDevice, DR.stream));
+    HK(hipEventRecord(DR.ev[slot], DR.stream));
+    used[slot] = true;
+  }
+  HK(hipEventRecord(DR.ev_src, DR.stream));
+  HK(hipStreamWaitEvent(NULL, DR.ev_src, 0));
+}
+/* device scratch of the batch verifier / decryption, kept and grown like the prover's output */
+static uint64_t *up_reserve(size_t nct)
+{
+  if (nct > G.up_cap) {
+    if (G.d_up) HK(hipFree(G.d_up));
+    G.d_up = NULL;
+    G.up_cap = 0;
+    HK(hipMalloc((void **)&G.d_up, nct * CTL * 8 + nct * 4));
+    G.up_cap = nct;
+  }
+  return G.d_up;
+}
+
 /* verifier() (src/snark.c:192-250) for `count` proofs under one SSP and verification key, entirely on the device (mfh_verify: t(s), v_0(s), the
  * 5 x count decryptions on the matrix cores from 820 proofs on, the four equations): ok[k] = 1 iff proof k is accepted.  Not in the reference. */
 void mfuoco_verifier_batch(ssp_t ssp, vrs_t vrs, proof_t *pis, size_t count, uint8_t *ok)
@@ -1215,18 +1262,11 @@ void mfuoco_verifier_batch(ssp_t ssp, vrs_t vrs, proof_t *pis, size_t count, uin
   gpu();
   ssp_resident(ssp);
   sk_resident(vrs->sk);
-  uint64_t *d_proofs = NULL, *h = xmalloc(count * 5 * CTL * 8);
-  uint8_t *d_ok = NULL;
-  HK(hipMalloc((void **)&d_proofs, count * 5 * CTL * 8));
-  HK(hipMalloc((void **)&d_ok, count));
-  struct conv_arg ca = { pis, NULL, h };
-  parallel_for(count * 5 * (size_t)(GAMMA_N + 1), proofs_to_limbs, &ca);
-  HK(hipMemcpy(d_proofs, h, count * 5 * CTL * 8, hipMemcpyHostToDevice));
-  free(h);
+  uint64_t *d_proofs = up_reserve(count * 5);
+  uint8_t *d_ok = (uint8_t *)(d_proofs + G.up_cap * CTL);
+  cts_upload(d_proofs, pis, NULL, count * 5);
   CK(mfh_verify(G.ctx, G.d_ssp, (uint32_t)vrs->alpha, (uint32_t)vrs->beta, (uint32_t)vrs->s, G.d_sk, d_proofs, count, d_ok));
   HK(hipMemcpy(ok, d_ok, count, hipMemcpyDeviceToHost));
-  HK(hipFree(d_proofs));
-  HK(hipFree(d_ok));
 }
 
 /* regev_decrypt (src/lwe.c:105-111) for `count` ciphertexts under one key: ms[k] initialised by the caller.  From 4096 ciphertexts the dot products run
@@ -1236,18 +1276,11 @@ void mfuoco_decrypt_batch(mpz_t *ms, sk_t sk, ct_t *cts, size_t count)
   KEEP_ERRNO;
   if (!count) return;
   sk_resident(sk);
-  uint64_t *d_cts = NULL, *h = xmalloc(count * CTL * 8);
-  uint32_t *d_m = NULL, *hm = xmalloc(count * 4);
-  HK(hipMalloc((void **)&d_cts, count * CTL * 8));
-  HK(hipMalloc((void **)&d_m, count * 4));
-  struct conv_arg ca = { NULL, cts, h };
-  parallel_for(count * (size_t)(GAMMA_N + 1), cts_to_limbs, &ca);
-  HK(hipMemcpy(d_cts, h, count * CTL * 8, hipMemcpyHostToDevice));
-  free(h);
+  uint64_t *d_cts = up_reserve(count);
+  uint32_t *d_m = (uint32_t *)(d_cts + G.up_cap * CTL), *hm = xmalloc(count * 4);
+  cts_upload(d_cts, NULL, cts, count);
   CK(mfh_decrypt(G.ctx, G.d_sk, d_cts, count, d_m));
   HK(hipMemcpy(hm, d_m, count * 4, hipMemcpyDeviceToHost));
   for (size_t k = 0; k < count; k++) mpz_set_ui(ms[k], hm[k]);
   free(hm);
-  HK(hipFree(d_cts));
-  HK(hipFree(d_m));
 }

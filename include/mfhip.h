@@ -241,6 +241,10 @@ int mfh_set_batch_bw(mfh_ctx *ctx, int merged);
  * per item (default), 2 = the same grid with the one-wave-per-SIMD body (k_mmstream_w: 256 accumulators per wave in AccVGPRs, half the LDS reads; measured the same time); sync_mode (persistent only): 0 = none, 1 = the workgroups that stream the same fragments begin every item together, 2 = all workgroups of an XCD
  * do -- a speed-only rendezvous bounded by spin_max polls (a workgroup never waits longer, so the grid drains whatever is resident). */
 int mfh_set_mm_stream(mfh_ctx *ctx, int map, int persistent, int sync_mode, uint32_t spin_max);
+/* Width of the persistent S / AS launch: workgroups per XCD (1..32; 32 = one per CU, the default).  Fewer leave CUs of every XCD free; with early_chain != 0
+ * mfh_prove_batch then queues the chain of super-group k + 1 and the epilogue of super-group k on side streams beside the streaming launches instead of between them
+ * (the round-5 experiment on the power finding, EXPERIMENTS.md).  Tuning; results do not depend on it. */
+int mfh_set_mm_width(mfh_ctx *ctx, uint32_t per_xcd, int early_chain);
 /* rows per row chunk of the matrix-core launches (mfh_eval_rows_multi, mfh_prove_batch): the int32 accumulators hold at most
  * 131071 rows (the default; 0 restores it); smaller values split every region into more chunks -- same results (tuning, tests). */
 int mfh_set_mm_chunk_rows(mfh_ctx *ctx, uint32_t rows);

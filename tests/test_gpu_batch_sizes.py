@@ -322,6 +322,92 @@ def test_streaming_launch_layouts_give_identical_proofs(gpu_ctx_factory, layout,
     ctx.close()
 
 
+@pytest.mark.parametrize("width,early", [(28, False), (28, True), (24, True), (32, True), (5, True)])
+def test_narrow_persistent_grid_and_early_chain_give_identical_proofs(gpu_ctx_factory, width, early):
+    """mfh_set_mm_width: the persistent S / AS launch on `width` workgroups per XCD (each then strides over its XCD's items by `width`) and, with early,
+    the chain of super-group k + 1 queued beside the row work of k, the epilogues and smudging of k on the side stream beside the row work of k + 1 (two halves
+    of the digit / partial-product scratch).  1000 statements = 4 super-groups, so every hand-over happens twice; never the proofs."""
+    import sys
+
+    import torch
+
+    import c_lwe_snarks_amd as mf
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    p = mf.Params(d=1152, m=1000)
+    ctx = gpu_ctx_factory(p)
+    ctx.set_seed(SEED)
+    inst = bench.build_instance(mf, ctx, torch, p, 99)
+    ctx.ssp_prepare(inst["d_ssp"])
+    d_crs = ctx.setup(inst["d_ssp"], inst["alpha"], inst["beta"], inst["s"], inst["sk"], inst["err"])
+    rng = np.random.default_rng(width)
+    nb = 1000
+    bits, deltas, mags, signs = _statements(rng, p, nb, valid_bits=inst["bits"])
+    want = ctx.prove_batch(d_crs, inst["d_ssp"], bits, deltas, mags, signs).clone()
+    ctx.set_mm_width(width, early)
+    try:
+        got = ctx.prove_batch(d_crs, inst["d_ssp"], bits, deltas, mags, signs)
+        ctx.sync()
+        again = ctx.prove_batch(d_crs, inst["d_ssp"], bits, deltas, mags, signs)  # (scratch halves and events re-used by a second call)
+        ctx.sync()
+    finally:
+        ctx.set_mm_width(32, False)
+    assert torch.equal(got, want) and torch.equal(again, want)
+    for b in (0, 254, 255, 509, 510, 765, nb - 1):
+        one = ctx.prove(d_crs, inst["d_ssp"], bits[b], deltas[b], mags[b], signs[b])
+        assert torch.equal(want.view(nb, -1)[b], one), f"statement {b}"
+    ctx.close()
+
+
+def test_stream_wait_hands_over_finished_super_groups(gpu_ctx_factory):
+    """mfh_prove_batch_stream_wait: a stream of the caller's waits for statements [0, upto) of the call just queued and copies them out while the later super-groups
+    still run (what the host shim's mfuoco_prover_batch does with its copy stream): what arrives is what the output holds when the whole call has finished"""
+    import sys
+
+    import torch
+
+    import c_lwe_snarks_amd as mf
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    p = mf.Params(d=1152, m=1000)
+    ctx = gpu_ctx_factory(p)
+    assert ctx.prove_batch_supergroup() == 0
+    ctx.set_seed(SEED)
+    inst = bench.build_instance(mf, ctx, torch, p, 99)
+    ctx.ssp_prepare(inst["d_ssp"])
+    d_crs = ctx.setup(inst["d_ssp"], inst["alpha"], inst["beta"], inst["s"], inst["sk"], inst["err"])
+    rng = np.random.default_rng(3)
+    nb = 700
+    bits, deltas, mags, signs = _statements(rng, p, nb, valid_bits=inst["bits"])
+    ctx.sync()
+    torch.cuda.synchronize()
+    out = ctx.prove_batch(d_crs, inst["d_ssp"], bits, deltas, mags, signs)  # queued, not waited for
+    sg = ctx.prove_batch_supergroup()
+    assert sg == 255
+    st = torch.cuda.Stream()
+    rows = out.view(nb, -1)
+    host = torch.empty(rows.shape, dtype=rows.dtype, pin_memory=True)
+    for a in range(0, nb, sg):
+        b = min(a + sg, nb)
+        ctx.prove_batch_stream_wait(b, st)
+        with torch.cuda.stream(st):
+            host[a:b].copy_(rows[a:b], non_blocking=True)
+    st.synchronize()
+    ctx.sync()
+    assert torch.equal(host, rows.cpu())
+    with pytest.raises(mf.MfhError):
+        ctx.prove_batch_stream_wait(nb + 1, st)
+    with pytest.raises(mf.MfhError):
+        ctx.prove_batch_stream_wait(0, st)
+    for b_ in (0, 254, 255, nb - 1):
+        assert torch.equal(rows[b_], ctx.prove(d_crs, inst["d_ssp"], bits[b_], deltas[b_], mags[b_], signs[b_]))
+    ctx.close()
+
+
 @pytest.mark.parametrize("nb,persistent", [(600, 1), (600, 0), (2300, 1), (300, 2)])
 def test_bw_of_all_super_groups_in_one_launch_gives_identical_proofs(gpu_ctx_factory, nb, persistent):
     """mfh_set_batch_bw: b_w (src/snark.c:143-155) of all super-groups of a call in ONE streaming launch per up to 8 of them over the BT+BV image (default) against one

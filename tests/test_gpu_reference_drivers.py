@@ -33,10 +33,17 @@ def test_reference_test_program_passes_against_the_shim(prog, tmp_path):
     """assert() is live in these builds (src/tests.h refuses NDEBUG): exit code 0 = every assertion of the reference's test held on the GPU library"""
     # fresh OS entropy every run: four random instances per program (test_entropy's ~10^5 small stream reads took 68 s when each was a GPU round trip; the shim now
     # serves them from a 64 KiB host window of the stream: under 2 s)
+    chance = 0
     for attempt in range(4 if prog != "test_ssp" else 1):
         r = _run(prog, 600, tmp_path)
+        if prog == "test_aes" and r.returncode != 0 and re.search(r"test_aes\.c:(20|24): main: Assertion", r.stderr):
+            # src/test_aes.c:20,24 assert `buf[0] != 0` and `buf[0] != buf2[0]` on the first bytes of two keystream blocks under a RANDOM key: each fails with
+            # probability 2^-8 against any correct AES, the reference's own included (seen once in round 5).  One such miss in four runs is chance, two are not.
+            chance += 1
+            continue
         assert r.returncode == 0, (prog, attempt, r.stdout[-2000:], r.stderr[-2000:])
         assert "Assertion" not in r.stderr
+    assert chance <= 1, "src/test_aes.c's one-in-256 assertions failed more than once in four runs"
 
 
 @pytest.mark.parametrize("prog,labels", [("benchmark_lwe", ("encryption", "decryption")), ("benchmark_eval", ()), ("benchmark_snark", ("setup", "prover", "verifier"))])
