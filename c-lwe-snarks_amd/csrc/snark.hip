@@ -917,6 +917,7 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
                                     h_smudge_mag + (size_t)s0 * 5 * maglen, maglen, h_smudge_sign + (size_t)s0 * 5, d_proofs + (size_t)s0 * 5 * ctl0);
             if (r) return r;
           }
+          c->last_batch_sg = 0;  // (several sub-calls: no per-super-group completion to hand out; a caller drains after mfh_sync)
           return MFH_OK;
         }
       }
