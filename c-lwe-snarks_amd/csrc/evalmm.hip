@@ -790,6 +790,8 @@ __global__ __launch_bounds__(SW * 64) void k_mmstream_pb(MmsImages imgs, uint32_
 //   * the ring runs across the stage boundary, so the stage's ONE barrier sits at the end of group 9 (its position and why one suffices: at the barrier), and
 //     it waits for the wave's ds_writes only (s_waitcnt lgkmcnt(4): the four fragment reads issued after them stay in flight).
 // Same operands, same partial products, same epilogues as k_mmstream; persistent grid only (mfh_set_mm_stream).
+// WHY IT SHIPS although it is never the default: it takes the same time as the two-wave body with half the LDS reads and a quarter of the parked cycles -- the reproducible half of
+// the finding that k_mmstream_p is power-limited; tools/mm_variant_clock.py A/Bs the two bodies on any box, and tests keep it bit-identical.
 constexpr int WSW = 4, WRQ = 4;
 __device__ __forceinline__ void mfma_acc(v4i &acc, const v4i &a, const v4i &b) {
   asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));

@@ -267,6 +267,11 @@ static mfh_ctx *gpu(void)
     HK(hipMemset(G.d_co, 1, (size_t)GAMMA_D * 4));
     CK(mfh_eval_rows(G.ctx, 0, GAMMA_D, G.d_c8, G.d_co, NULL, G.d_ct[2], NULL, 0));
     CK(mfh_sync(G.ctx));
+    /* ... and the runtime's copy engines: the first host-to-device copy of more than a few KB in a process takes 8 ms whatever memory it comes from (measured inside
+     * benchmark_eval's one timed eval_poly: 131 KB of coefficients from pinned memory, 8.2 ms; the next copy 0.03) */
+    memset(G.pin, 0, (size_t)1 << 20);
+    HK(hipMemcpy(G.d_c8, G.pin, (size_t)1 << 20 < rows * CT_BYTES ? (size_t)1 << 20 : rows * CT_BYTES, hipMemcpyHostToDevice));
+    HK(hipMemcpy(G.pin, G.d_c8, (size_t)1 << 20 < rows * CT_BYTES ? (size_t)1 << 20 : rows * CT_BYTES, hipMemcpyDeviceToHost));
   }
   return G.ctx;
 }
@@ -757,10 +762,13 @@ void eval_poly(ct_t rop, rng_t rng, uint8_t (*c8)[CT_BYTES], nmod_poly_t p, size
   uint64_t pos = stream_pos(s);
   const double t_in = tnow();
   h2d_staged(G.d_co, co, d * 4);
+  const double t_co = tnow();
   h2d_staged(G.d_c8, c8, d * CT_BYTES); /* (c8 is typically a read-only file mapping: src/benchmark_eval.c:62-66) */
+  const double t_c8 = tnow();
   free(co);
   ct_to_dev(G.d_ct[2], rop, GAMMA_N + 1); /* eval_poly accumulates into rop (src/lwe.c:183) */
   const double t_up = tnow();
+  if (tracing()) fprintf(stderr, "eval_poly uploads: coefficients %.2f ms, rows %.2f, accumulator %.2f\n", t_co - t_in, t_c8 - t_co, t_up - t_c8);
   CK(mfh_eval_rows(G.ctx, pos, d, G.d_c8, G.d_co, NULL, G.d_ct[2], NULL, 1));
   if (tracing()) CK(mfh_sync(G.ctx));
   const double t_gpu = tnow();
