@@ -550,10 +550,11 @@ void regev_encrypt2(ct_t c, rng_t rs, sk_t sk, mpz_t m, void (*chi)(mpz_t))
   HK(hipMemcpyAsync(G.d_ct[1], up, ENC_UP, hipMemcpyHostToDevice, NULL));
   CK(mfh_encrypt_rows(G.ctx, pos, 1, d_sk, (const uint32_t *)(G.d_ct[1] + L_LIMBS), G.d_ct[1], (uint8_t *)d_b));
   HK(hipMemcpyAsync(down + (size_t)GAMMA_N * L_LIMBS, d_b, L_LIMBS * 8, hipMemcpyDeviceToHost, NULL));
+  HK(hipMemsetAsync(G.d_ct[1], 0, ENC_UP, NULL)); /* the error leaves neither the device scratch ... */
   HK(hipEventSynchronize(G.ev_small));
   for (size_t j = 0; j < GAMMA_N; j++) from_limbs(c[j], down + j * L_LIMBS);
   HK(hipStreamSynchronize(NULL));
-  explicit_bzero(up, ENC_UP);
+  explicit_bzero(up, ENC_UP); /* ... nor the pinned one behind */
   mpz_import(c[GAMMA_N], LOGQ_BYTES, -1, 1, -1, 0, down + (size_t)GAMMA_N * L_LIMBS);
   stream_set_pos_blk(s, end, (const uint8_t *)(down + CTL));
 }
@@ -639,7 +640,10 @@ void mfuoco_encrypt_batch2(uint8_t (*c8)[CT_BYTES], rng_t rs, sk_t sk, mpz_t *ms
     done[slot] = nk;
     at[slot] = k0;
   }
-  for (int i = 0; i < 2; i++) explicit_bzero(G.enc_pin[i], ENC_CHUNK * ENC_UP); /* the errors are secret */
+  for (int i = 0; i < 2; i++) { /* the errors are secret (with the public a and b an error gives <sk, a> away): neither the pinned nor the device staging keeps them */
+    explicit_bzero(G.enc_pin[i], ENC_CHUNK * ENC_UP);
+    HK(hipMemsetAsync(G.d_enc[i], 0, ENC_CHUNK * ENC_UP, NULL));
+  }
   stream_set_pos(s, pos + count * CTR_CT);
 }
 void mfuoco_encrypt_batch(uint8_t (*c8)[CT_BYTES], rng_t rs, sk_t sk, mpz_t *ms, size_t count) { mfuoco_encrypt_batch2(c8, rs, sk, ms, count, NULL); }
@@ -888,6 +892,7 @@ void setup(crs_t crs, vrs_t vrs, ssp_t ssp)
   drop_image(); /* G.d_crs is about to be rewritten */
   G.staged_digest_valid = false;
   CK(mfh_setup(G.ctx, G.d_ssp, (uint32_t)vrs->alpha, (uint32_t)vrs->beta, (uint32_t)vrs->s, G.d_sk, G.d_err, G.d_crs));
+  HK(hipMemsetAsync(G.d_err, 0, rows * L_LIMBS * 8, NULL)); /* (the errors are not kept on the device either) */
   HK(hipMemcpy(crs->s, G.d_crs, CT_BYTES * GAMMA_D, hipMemcpyDeviceToHost));
   HK(hipMemcpy(crs->as, G.d_crs + CT_BYTES * GAMMA_D, CT_BYTES * GAMMA_D, hipMemcpyDeviceToHost));
   HK(hipMemcpy(crs->t, G.d_crs + 2 * CT_BYTES * GAMMA_D, CT_BYTES, hipMemcpyDeviceToHost));
