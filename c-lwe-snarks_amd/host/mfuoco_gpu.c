@@ -656,9 +656,19 @@ void mfuoco_decrypt_rows_batch(mpz_t *ms, rng_t rs, sk_t sk, uint8_t (*c8)[CT_BY
   KEEP_ERRNO;
   if (!count) return;
   struct aesctr *s = (struct aesctr *)rs;
+  const uint64_t pos = stream_pos(s);
+  if (pos & 7) { /* the batched kernel wants every row to start at byte 0 or 8 of an AES block (any position a row-wise caller reaches); anything else: one row at a time */
+    ct_t ct;
+    ct_init(ct);
+    for (size_t k = 0; k < count; k++) {
+      ct_import(ct, rs, c8[k]);
+      regev_decrypt(ms[k], sk, ct);
+    }
+    ct_clear(ct);
+    return;
+  }
   const uint64_t *d_sk = sk_resident(sk);
   use_seed(((shim_key *)s->key)->seed);
-  const uint64_t pos = stream_pos(s);
   uint8_t *d_c8 = NULL;
   uint32_t *d_m = NULL, *hm = xmalloc(count * 4);
   HK(hipMalloc((void **)&d_c8, count * CT_BYTES));
@@ -1026,7 +1036,7 @@ static void drain_init(void)
  * becomes mpz_t's under the kernels of k + 1.  batch == 0: d_proofs is final once the work queued on the shim's (default) stream so far has run. */
 static void proofs_drain(proof_t *pis, const uint64_t *d_proofs, size_t count, int batch)
 {
-  if (count * 5 * CTL * 8 <= PIN_BYTES) { /* one proof (706 KB): the small pinned scratch, no pipeline (and none of its 90 MB of page-locking on a first prover() call) */
+  if (count * 5 * CTL * 8 <= PIN_BYTES) { /* up to five proofs (706 KB each): the small pinned scratch, no pipeline (and none of its 90 MB of page-locking on a first prover() call) */
     if (batch) CK(mfh_sync(G.ctx));
     HK(hipMemcpyAsync(G.pin, d_proofs, count * 5 * CTL * 8, hipMemcpyDeviceToHost, NULL));
     HK(hipStreamSynchronize(NULL));

@@ -98,6 +98,18 @@ static void t_encrypt_batch(void)
       mpz_clear(out[i]);
     }
   }
+  { /* a stream position that is no multiple of 8 (a caller that drew 5 bytes first): both batch calls still serve it (the encryption on the VALU kernel, the decryption row by row) */
+    enum { NU = 9 };
+    rng_seek(rs, 5);
+    mfuoco_encrypt_batch(c8, rs, sk, ms, NU);
+    rng_seek(twin, 5);
+    mfuoco_decrypt_rows_batch(back, twin, sk, c8, NU);
+    for (size_t k = 0; k < NU; k++) CHECK(!mpz_cmp(ms[k], back[k]));
+    rng_seek(twin, 5 + (uint64_t)NU * CTR_CT);
+    aesctr_prg((aesctr_ptr)rs, &got, 8);
+    aesctr_prg((aesctr_ptr)twin, &want, 8);
+    CHECK(got == want);
+  }
   /* another key is noticed by the key cache: rows under sk2 decrypt under sk2 and (overwhelmingly) not under sk; one-row batch */
   rng_seek(rs, 0);
   mfuoco_encrypt_batch(c8, rs, sk2, ms, 1);

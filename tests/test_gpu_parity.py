@@ -300,6 +300,33 @@ def test_witness_poly(ctx, oracle, mf):
     assert np.array_equal(got.astype(np.uint64), np.array(w, dtype=np.uint64))
 
 
+def test_ssp_upload_staged_on_host_threads(gpu_ctx_factory, mf):
+    """mfh_ssp_upload of an image large enough for its threaded path (from 16 chunks of 4 MB: eight host threads stage every eighth chunk through their own pinned pair and
+    stream, the reduction mod p in the same stream): 210 MB of arbitrary uint64 values -- nmod_poly_import reduces them (src/ssp.c:28-34) -- a slot range that starts and ends
+    inside chunks, then the whole image again; checked against numpy's `% p`, untouched slots must stay untouched"""
+    import torch
+
+    p = mf.Params(d=1 << 15, m=800)
+    ctx = gpu_ctx_factory(p)
+    rng = np.random.default_rng(99)
+    slots = p.m + 3
+    ssp = rng.integers(0, 1 << 63, size=slots * p.d, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=slots * p.d, dtype=np.uint64)  # all 64 bits
+    red = (ssp % np.uint64(ol.P)).astype(np.uint32).reshape(slots, p.d)
+    d_ssp = torch.full((slots * p.d * 4,), 0xA5, dtype=torch.uint8, device=ctx.device)
+    first, n = 37, 613  # 160 MB: starts and ends mid-chunk
+    ctx.ssp_upload(ssp, d_ssp, first, n)
+    got = ctx.to_host(d_ssp, np.uint32).reshape(slots, p.d)
+    assert np.array_equal(got[first:first + n], red[first:first + n])
+    assert (got[:first] == 0xA5A5A5A5).all() and (got[first + n:] == 0xA5A5A5A5).all()
+    ctx.ssp_upload(ssp, d_ssp)
+    assert np.array_equal(ctx.to_host(d_ssp, np.uint32).reshape(slots, p.d), red)
+    # ... and a small range (one copy on the caller's stream)
+    d_ssp[: 3 * p.d * 4] = 0
+    ctx.ssp_upload(ssp, d_ssp, 0, 3)
+    assert np.array_equal(ctx.to_host(d_ssp, np.uint32).reshape(slots, p.d), red)
+    ctx.close()
+
+
 # ---------------------------------------------------------------- BASELINE configs 4/5: stream offsets of a 2^20-constraint CRS
 @pytest.mark.parametrize("logq", [736, 1472])
 def test_rows_at_2pow20_scale_offsets(gpu_ctx_factory, oracle, mf, logq):
