@@ -1749,12 +1749,12 @@ int mfh_ct_smudge(mfh_ctx *c, uint64_t *d_cts, size_t count, const uint8_t *h_ma
 }
 
 // The SSP comes from pageable host memory (a calloc'ed or mmap'ed buffer of the caller's: 5.7 GB at the default instance).  Handed to hipMemcpy as it is, the runtime
-// stages it through its own pinned buffer on ONE thread (about 12 GB/s: 0.45 s of setup()'s 0.55 s).  Here UP_T host threads each take every UP_T-th chunk of
+// stages it through its own pinned buffer on ONE thread (about 12 GB/s: 0.45 s of setup()'s 0.55 s).  Here NT host threads (8, $MFH_UPLOAD_THREADS) each take every NT-th chunk of
 // UP_CHUNK bytes: memcpy into the thread's own pinned pair, an asynchronous copy and the uint64 -> uint32 reduction (k_ssp_reduce) on the thread's own stream, the
 // second buffer being filled while the first one crosses PCIe.  Host work is byte moving only; the reduction mod p stays on the GPU.
 namespace {
 constexpr size_t UP_CHUNK = (size_t)4 << 20;
-constexpr int UP_T = 8;
+constexpr int UP_T = 16;  // lanes that exist; a call uses min(UP_T, $MFH_UPLOAD_THREADS or 8) of them
 struct UpLane {
   hipStream_t st = nullptr;
   hipEvent_t ev[2] = {nullptr, nullptr};
@@ -1763,7 +1763,6 @@ struct UpLane {
 };
 struct Uploader {
   UpLane lane[UP_T];
-  bool ready = false;
 };
 }  // namespace
 static void upload_free(mfh_ctx *c) {
@@ -1791,7 +1790,7 @@ int mfh_ssp_upload(mfh_ctx *c, const void *h_ssp_u64, uint32_t *d_ssp, size_t fi
   uint32_t *dst = d_ssp + first_slot * d;
   HIP_TRY(c, hipStreamSynchronize(c->stream));  // what the caller queued before (e.g. readers of the old image) is over
   const size_t nchunks = (total + UP_CHUNK - 1) / UP_CHUNK;
-  if (nchunks < 2 * UP_T) {  // small images (the debug SSP is 137 KB): one copy on the caller's stream
+  if (nchunks < 16) {  // small images (the debug SSP is 137 KB): one copy on the caller's stream
     void *stage = nullptr;
     HIP_TRY(c, hipMalloc(&stage, total));
     int rc = MFH_OK;
@@ -1802,18 +1801,24 @@ int mfh_ssp_upload(mfh_ctx *c, const void *h_ssp_u64, uint32_t *d_ssp, size_t fi
     if (rc) c->err = "ssp upload failed";
     return rc;
   }
+  static int nthreads = 0;
+  if (!nthreads) {
+    const char *e = getenv("MFH_UPLOAD_THREADS");
+    const long want = e && *e ? atol(e) : 8;
+    nthreads = (int)(want < 1 ? 1 : want > UP_T ? UP_T : want);
+  }
+  const int NT = nthreads;
   Uploader *u = (Uploader *)c->uploader;
   if (!u) c->uploader = u = new Uploader();
-  if (!u->ready) {
-    for (auto &l : u->lane) {
-      HIP_TRY(c, hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking));
-      for (int i = 0; i < 2; i++) {
-        HIP_TRY(c, hipEventCreateWithFlags(&l.ev[i], hipEventDisableTiming));
-        HIP_TRY(c, hipHostMalloc((void **)&l.pin[i], UP_CHUNK, hipHostMallocDefault));
-        HIP_TRY(c, hipMalloc((void **)&l.dev[i], UP_CHUNK));
-      }
+  for (int t = 0; t < NT; t++) {  // the lanes this call uses (made once, kept by the context)
+    UpLane &l = u->lane[t];
+    if (l.st) continue;
+    HIP_TRY(c, hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) {
+      HIP_TRY(c, hipEventCreateWithFlags(&l.ev[i], hipEventDisableTiming));
+      HIP_TRY(c, hipHostMalloc((void **)&l.pin[i], UP_CHUNK, hipHostMallocDefault));
+      HIP_TRY(c, hipMalloc((void **)&l.dev[i], UP_CHUNK));
     }
-    u->ready = true;
   }
   int failed[UP_T] = {};
   auto work = [&](int t) {
@@ -1821,7 +1826,7 @@ int mfh_ssp_upload(mfh_ctx *c, const void *h_ssp_u64, uint32_t *d_ssp, size_t fi
     UpLane &l = u->lane[t];
     int slot = 0;
     bool used[2] = {false, false};
-    for (size_t k = (size_t)t; k < nchunks; k += UP_T, slot ^= 1) {
+    for (size_t k = (size_t)t; k < nchunks; k += (size_t)NT, slot ^= 1) {
       const size_t off = k * UP_CHUNK, nb = std::min(UP_CHUNK, total - off);
       if (used[slot] && hipEventSynchronize(l.ev[slot]) != hipSuccess) { failed[t] = 1; return; }
       memcpy(l.pin[slot], src + off, nb);
@@ -1834,13 +1839,13 @@ int mfh_ssp_upload(mfh_ctx *c, const void *h_ssp_u64, uint32_t *d_ssp, size_t fi
   };
   std::thread th[UP_T];
   int started = 0;
-  for (int t = 1; t < UP_T; t++) {
+  for (int t = 1; t < NT; t++) {
     try { th[t] = std::thread(work, t); started++; } catch (...) { break; }
   }
   work(0);
-  for (int t = started + 1; t < UP_T; t++) work(t);  // lanes whose thread could not be had run here, one after the other
+  for (int t = started + 1; t < NT; t++) work(t);  // lanes whose thread could not be had run here, one after the other
   for (int t = 1; t <= started; t++) th[t].join();
-  for (int t = 0; t < UP_T; t++)
+  for (int t = 0; t < NT; t++)
     if (failed[t] || hipGetLastError() != hipSuccess) { c->err = "ssp upload failed"; return MFH_EDEVICE; }
   return MFH_OK;
 }
