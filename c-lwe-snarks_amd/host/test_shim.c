@@ -209,6 +209,44 @@ static void t_snark(void)
     mfuoco_gpu_set_resident_crs(1);
     for (int k = 0; k < NB; k++) { proof_clear(pb[k]); mpz_clear(wit[k]); }
   }
+  { /* more proofs than one pinned slab holds in either direction (64 proofs = 320 ciphertexts per slab): 150 statements down through the drain pipeline (two super-groups'
+     * worth of events would need 256; here one, three slabs), up again through the upload pipeline of the batch verifier and of the batch decryption; one proof is damaged
+     * on the host in between and must be the only one rejected */
+    enum { NP = 150 };
+    proof_t *pb = malloc(NP * sizeof *pb);
+    mpz_t *wit = malloc(NP * sizeof *wit);
+    uint8_t okb[NP];
+    for (int k = 0; k < NP; k++) { proof_init(pb[k]); mpz_init_set(wit[k], witness); }
+    mfuoco_prover_batch(pb, crs, ssp, wit, NP);
+    mpz_add_ui(pb[97]->hat_h[GAMMA_N], pb[97]->hat_h[GAMMA_N], 1);
+    mfuoco_verifier_batch(ssp, vrs, pb, NP, okb);
+    for (int k = 0; k < NP; k++) CHECK(okb[k] == (k != 97));
+    ct_t *cts = malloc(5 * NP * sizeof *cts);
+    mpz_t *dec = malloc(5 * NP * sizeof *dec);
+    mpz_t one;
+    mpz_init(one);
+    for (int k = 0; k < 5 * NP; k++) {
+      ct_init(cts[k]);
+      mpz_init(dec[k]);
+      struct proof *pk = pb[k / 5];
+      mpz_t *src = k % 5 == 0 ? pk->h : k % 5 == 1 ? pk->hat_h : k % 5 == 2 ? pk->hat_v : k % 5 == 3 ? pk->v_w : pk->b_w;
+      for (size_t j = 0; j <= GAMMA_N; j++) mpz_set(cts[k][j], src[j]);
+    }
+    mfuoco_decrypt_batch(dec, vrs->sk, cts, 5 * NP);
+    for (int k = 0; k < 5 * NP; k += 37) { /* against the one-at-a-time path */
+      regev_decrypt(one, vrs->sk, cts[k]);
+      CHECK(!mpz_cmp(one, dec[k]));
+    }
+    for (int k = 0; k < NP; k++) { /* eq-pke on the decrypted values: hat_h = alpha h (src/snark.c:213-216), except for the damaged proof */
+      mpz_mul_ui(one, dec[5 * k], vrs->alpha);
+      mpz_mod_ui(one, one, GAMMA_P);
+      CHECK((mpz_cmp(one, dec[5 * k + 1]) == 0) == (k != 97));
+    }
+    for (int k = 0; k < 5 * NP; k++) { ct_clear(cts[k]); mpz_clear(dec[k]); }
+    for (int k = 0; k < NP; k++) { proof_clear(pb[k]); mpz_clear(wit[k]); }
+    mpz_clear(one);
+    free(cts); free(dec); free(pb); free(wit);
+  }
   proof_clear(pi);
   crs_clear(crs);
   free(ssp);

@@ -361,7 +361,8 @@ def test_narrow_persistent_grid_and_early_chain_give_identical_proofs(gpu_ctx_fa
     ctx.close()
 
 
-def test_stream_wait_hands_over_finished_super_groups(gpu_ctx_factory):
+@pytest.mark.parametrize("nslabs", [0, 3])
+def test_stream_wait_hands_over_finished_super_groups(gpu_ctx_factory, nslabs):
     """mfh_prove_batch_stream_wait: a stream of the caller's waits for statements [0, upto) of the call just queued and copies them out while the later super-groups
     still run (what the host shim's mfuoco_prover_batch does with its copy stream): what arrives is what the output holds when the whole call has finished"""
     import sys
@@ -385,7 +386,11 @@ def test_stream_wait_hands_over_finished_super_groups(gpu_ctx_factory):
     bits, deltas, mags, signs = _statements(rng, p, nb, valid_bits=inst["bits"])
     ctx.sync()
     torch.cuda.synchronize()
-    out = ctx.prove_batch(d_crs, inst["d_ssp"], bits, deltas, mags, signs)  # queued, not waited for
+    ctx.set_batch_slabs(nslabs)  # (3: the out-of-core form -- every slab touches every proof, all super-groups complete together at the end of the call)
+    try:
+        out = ctx.prove_batch(d_crs, inst["d_ssp"], bits, deltas, mags, signs)  # queued, not waited for
+    finally:
+        ctx.set_batch_slabs(0)
     sg = ctx.prove_batch_supergroup()
     assert sg == 255
     st = torch.cuda.Stream()
