@@ -54,6 +54,8 @@ int main() {
   const char *n = "cheap-addr";
 #elif defined(SHIFT_ADDR)
   const char *n = "shift-addr";
+#elif defined(MF_AES_SDWA)
+  const char *n = "sdwa-addr";
 #else
   const char *n = "real";
 #endif
@@ -62,5 +64,12 @@ int main() {
   run<4, 94240>(n, key, d_t0, d_out, 1024, 1);
   run<4, 0>(n, key, d_t0, d_out, 512, 2);
   run<8, 0>(n, key, d_t0, d_out, 1024, 2);
+  {  // digest of the last launch's outputs: builds that compute the real keystream must agree (a timing-only build is recognisable)
+    static uint32_t h[256 * 2 * 1024];
+    hipMemcpy(h, d_out, sizeof h, hipMemcpyDeviceToHost);
+    uint64_t dg = 0;
+    for (size_t i = 0; i < sizeof h / 4; i++) dg = dg * 0x9E3779B97F4A7C15ull + h[i];
+    printf("%-10s digest %016llx\n", n, (unsigned long long)dg);
+  }
   return 0;
 }
