@@ -91,6 +91,19 @@ inline void expand_key(AesKey &k, const uint8_t seed[40]) {
 //   t_j = T0[b0(s_j)] ^ T2[b2(s_j+2)] ^ rotl8(T0[b1(s_j+1)] ^ T2[b3(s_j+3)]) ^ rk
 // Measured on MI355X (tools/rate*_ubench.hip): ds_read_b32 ~2.15 CU-clk per wave-instruction, v_xor/v_bitop3 ~2.5
 // and v_perm/v_alignbit ~4.3 SIMD-clk: 27 SIMD-clk of VALU per column against 34 of LDS: the round is LDS-bound.
+#ifdef MF_AES_T4
+// experiment (round 5): all four tables in LDS -- a second 64 KiB image [T1 | T3] behind the first -- so that a column needs no v_alignbit and two v_bitop3 xors
+// instead of xor, alignbit, xor, xor3 (20 instead of 27 SIMD-clk of VALU per column); 128 KiB of LDS: one 1024-thread workgroup per CU, 4 waves per SIMD
+constexpr int kTabBytes = 2 * 256 * 64 * 4;
+__device__ __forceinline__ void lds_fill_tab(uint32_t *lt, const uint32_t *__restrict__ g_t0) {
+  for (int i = threadIdx.x; i < 2 * 256 * 64; i += blockDim.x) {
+    uint32_t v = g_t0[(i >> 6) & 255];
+    if (i & 32) v = (v << 16) | (v >> 16);           // T2 half of an entry
+    if (i >= 256 * 64) v = (v << 8) | (v >> 24);     // second image: T1 = rotl8(T0), T3 = rotl8(T2)
+    lt[i] = v;
+  }
+}
+#else
 constexpr int kTabBytes = 256 * 64 * 4;
 
 __device__ __forceinline__ void lds_fill_tab(uint32_t *lt, const uint32_t *__restrict__ g_t0) {
@@ -99,10 +112,14 @@ __device__ __forceinline__ void lds_fill_tab(uint32_t *lt, const uint32_t *__res
     lt[i] = (i & 32) ? ((v << 16) | (v >> 16)) : v;
   }
 }
+#endif
 
 struct AesLane {
   uint32_t lo0, lo2;  // byte offsets of this lane's T0 / T2 replica inside a 256-byte entry
   uint32_t m1;        // 0x0000ff00, kept in a VGPR so v_bitop3 runs at full rate
+#ifdef MF_AES_T4
+  uint32_t lo1, lo3;  // the lane's T1 / T3 replica: lo0 / lo2 + 64 KiB
+#endif
 #ifdef MF_PERM_VSEL
   uint32_t sel0, sel2, sel3;  // experiment (round 5): the v_perm selectors in VGPRs instead of SGPRs (does v_perm then issue at the rate of v_bitop3 with VGPR operands?)
 #endif
@@ -118,6 +135,10 @@ __device__ __forceinline__ AesLane aes_lane() {
   l.lo2 = l.lo0 + 128;
   l.m1 = 0xff00u;
   asm volatile("" : "+v"(l.m1));  // keep it a VGPR
+#ifdef MF_AES_T4
+  l.lo1 = l.lo0 + 65536u;
+  l.lo3 = l.lo2 + 65536u;
+#endif
 #ifdef MF_PERM_VSEL
   l.sel0 = 0x0c0c0400u; l.sel2 = 0x0c0c0600u; l.sel3 = 0x0c0c0700u;
   asm volatile("" : "+v"(l.sel0), "+v"(l.sel2), "+v"(l.sel3));
@@ -142,7 +163,15 @@ __device__ __forceinline__ AesLane aes_lane() {
 #define MF_A(s, lo, k) ((k) == 1 ? MF_ANDOR((s), L.m1, (lo)) : __builtin_amdgcn_perm((s), (lo), 0x0c0c0400u + ((k) << 8)))
 #endif
 
-#ifdef MF_AES_SDWA
+#ifdef MF_AES_T4
+// address of entry byte_k(s) in the second image: the replica offset's byte 2 (the 64 KiB bit) travels through the v_perm too
+#define MF_A4(s, lo, k) ((k) == 1 ? MF_ANDOR((s), L.m1, (lo)) : __builtin_amdgcn_perm((s), (lo), 0x0c020400u + ((k) << 8)))
+__device__ __forceinline__ uint32_t aes_col(const uint8_t *tab, const AesLane &L, uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t rk) {
+  uint32_t x0 = MF_LD(MF_A(a, L.lo0, 0)), x1 = MF_LD(MF_A4(b, L.lo1, 1));
+  uint32_t x2 = MF_LD(MF_A(c, L.lo2, 2)), x3 = MF_LD(MF_A4(d, L.lo3, 3));
+  return MF_XOR3(MF_XOR3(x0, x1, x2), x3, rk);
+}
+#elif defined(MF_AES_SDWA)
 #define MF_SDWA_PUT(dst, src, sel) asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:" sel : "+v"(dst) : "v"(src))
 __device__ __forceinline__ uint32_t aes_col(const uint8_t *tab, const AesLane &L, uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t rk) {
   MF_SDWA_PUT(L.ar[0], a, "BYTE_0");

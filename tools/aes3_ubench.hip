@@ -19,8 +19,8 @@ using mf::AesKey;
 // cannot, and every lookup pays a v_add_u32 -- the condition the product kernels were in before their LDS was made one object).
 template <int MINW, int PAD>
 __global__ __launch_bounds__(1024, MINW) void k_bench(AesKey key, const uint32_t *g_t0, uint32_t nb, uint32_t *out) {
-  __shared__ __attribute__((aligned(16))) uint8_t smem[65536 + PAD];
-  if (PAD && nb == 0xffffffffu) smem[65536 + threadIdx.x % PAD] = 1;  // keep the pad allocated
+  __shared__ __attribute__((aligned(16))) uint8_t smem[mf::kTabBytes + PAD];
+  if (PAD && nb == 0xffffffffu) smem[mf::kTabBytes + threadIdx.x % PAD] = 1;  // keep the pad allocated
   mf::lds_fill_tab(reinterpret_cast<uint32_t *>(smem), g_t0);
   __syncthreads();
   const mf::AesLane L = mf::aes_lane();
@@ -56,14 +56,24 @@ int main() {
   const char *n = "shift-addr";
 #elif defined(MF_AES_SDWA)
   const char *n = "sdwa-addr";
+#elif defined(MF_AES_T4)
+  const char *n = "4-tables";
+#elif defined(MF_PERM_VSEL)
+  const char *n = "vgpr-sel";
 #else
   const char *n = "real";
 #endif
+#ifdef MF_AES_T4  // 128 KiB of tables: one workgroup per CU
+  run<1, 0>(n, key, d_t0, d_out, 256, 1);
+  run<2, 0>(n, key, d_t0, d_out, 512, 1);
+  run<4, 0>(n, key, d_t0, d_out, 1024, 1);
+#else
   run<1, 94240>(n, key, d_t0, d_out, 256, 1);
   run<2, 94240>(n, key, d_t0, d_out, 512, 1);
   run<4, 94240>(n, key, d_t0, d_out, 1024, 1);
   run<4, 0>(n, key, d_t0, d_out, 512, 2);
   run<8, 0>(n, key, d_t0, d_out, 1024, 2);
+#endif
   {  // digest of the last launch's outputs: builds that compute the real keystream must agree (a timing-only build is recognisable)
     static uint32_t h[256 * 2 * 1024];
     hipMemcpy(h, d_out, sizeof h, hipMemcpyDeviceToHost);
