@@ -131,7 +131,8 @@ static inline uint64_t rand_modp(void) { uint64_t rop_ = 0; while (getrandom(&ro
 
 /* ---- additions (not in the reference) ---- */
 /* The shim keeps the last SSP it uploaded (keyed by host pointer) resident in HBM; call this after changing the
- * bytes of an SSP buffer in place.  (It also drops the expanded CRS images; a CRS changed in place is noticed without it.) */
+ * bytes of an SSP buffer in place.  (It also drops the expanded CRS images -- a CRS changed in place is noticed without it --, forgets the cached secret key and
+ * frees the device scratch the batch calls keep between calls: 706 KB per proof of the largest batch so far.) */
 void mfuoco_gpu_invalidate(void);
 /* prover() for `count` statements under one CRS and SSP: rows expanded once per group of proofs, multiply-accumulate on the matrix
  * cores; every proof is what prover() would produce with the same randomness.  pis[k] initialised by proof_init. */

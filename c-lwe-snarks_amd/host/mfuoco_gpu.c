@@ -208,6 +208,9 @@ void mfuoco_gpu_invalidate(void)
   KEEP_ERRNO;
   G.ssp_host = NULL;
   drop_image();
+  /* ... and the batch calls' device scratch (720 MB per 1020 proofs), which otherwise stays for the next call */
+  if (G.d_out) { (void)hipFree(G.d_out); G.d_out = NULL; G.out_cap = 0; }
+  if (G.d_up) { (void)hipFree(G.d_up); G.d_up = NULL; G.up_cap = 0; }
   if (G.h_sk) { /* ... and forget the cached key */
     explicit_bzero(G.h_sk, (size_t)GAMMA_N * L_LIMBS * 8);
     explicit_bzero(G.pin_sk, (size_t)GAMMA_N * L_LIMBS * 8);
