@@ -537,8 +537,7 @@ void regev_encrypt2(ct_t c, rng_t rs, sk_t sk, mpz_t m, void (*chi)(mpz_t))
   uint64_t *d_b = G.d_ct[0] + (size_t)GAMMA_N * L_LIMBS;
   CK(mfh_sample_rows(G.ctx, pos, 1, G.d_ct[0]));
   CK(mfh_keystream(G.ctx, endblk, (uint8_t *)G.d_ct[0] + CTL * 8, 16));
-  HK(hipMemcpyAsync(down, G.d_ct[0], (size_t)GAMMA_N * L_LIMBS * 8, hipMemcpyDeviceToHost, NULL));
-  HK(hipMemcpyAsync(down + CTL, (uint8_t *)G.d_ct[0] + CTL * 8, 16, hipMemcpyDeviceToHost, NULL));
+  HK(hipMemcpyAsync(down, G.d_ct[0], CTL * 8 + 16, hipMemcpyDeviceToHost, NULL)); /* (one copy: the a part, the b slot as it stands -- overwritten below --, the tail block) */
   HK(hipEventRecord(G.ev_small, NULL));
   mpz_t e;
   mpz_init(e);
