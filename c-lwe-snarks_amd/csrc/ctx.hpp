@@ -120,6 +120,8 @@ struct mfh_ctx {
   int batch_merge = 1;     // the S and AS groups of a round in one streaming launch (0: two launches on two streams)
   uint32_t batch_ngl = 8;  // groups of 63 / 64 coefficient vectors per streaming launch and region (1..8; 8 = a super-group's S and AS regions in ONE launch)
   PinBuf pin_rows, pin_cw, pin_smudge;
+  void *sample_tmp = nullptr;  // mfh_sample_rows: the rows' raw stream bytes (small requests; kept so that the call neither allocates nor waits)
+  size_t sample_bytes = 0;
   void *uploader = nullptr;  // mfh_ssp_upload: per-thread pinned / device staging pairs and streams (mfhip.hip), made on the first large upload
   // generator-defined SSP (ssp_prg.hpp): used by every entry point that is handed d_ssp == NULL
   bool prg_on = false;

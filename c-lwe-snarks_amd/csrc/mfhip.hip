@@ -1099,6 +1099,7 @@ void mfh_ctx_destroy(mfh_ctx *c) {
   if (c->stream) hipStreamSynchronize(c->stream);
   mfh_poly_destroy(c);
   upload_free(c);
+  if (c->sample_tmp) hipFree(c->sample_tmp);
   pin_free(c->pin_rows);
   pin_free(c->pin_cw);
   pin_free(c->pin_smudge);
@@ -1356,8 +1357,20 @@ int mfh_sample_rows(mfh_ctx *c, uint64_t off, size_t nrows, uint64_t *d_out) {
   HIP_TRY(c, hipSetDevice(c->device));
   const uint64_t nelem = (uint64_t)nrows * c->P.n;
   const uint64_t bytes = nelem * (c->P.logq / 8);
+  // the raw stream bytes of the rows: up to 16 MiB (118 rows at logq = 736; the shim's ct_import / regev_encrypt2 ask for ONE row per call) in a buffer the context keeps --
+  // no allocation, no synchronisation, the call stays asynchronous like every other --; larger requests allocate and wait as before
+  const bool kept = bytes <= ((uint64_t)16 << 20);
   void *tmp = nullptr;
-  HIP_TRY(c, hipMalloc(&tmp, bytes));
+  if (kept) {
+    if (c->sample_bytes < bytes) {
+      if (c->sample_tmp) { hipDeviceSynchronize(); hipFree(c->sample_tmp); c->sample_tmp = nullptr; c->sample_bytes = 0; }
+      HIP_TRY(c, hipMalloc(&c->sample_tmp, bytes));
+      c->sample_bytes = bytes;
+    }
+    tmp = c->sample_tmp;
+  } else {
+    HIP_TRY(c, hipMalloc(&tmp, bytes));
+  }
   int rc = mfh_keystream(c, off, tmp, bytes);
   if (rc == MFH_OK) {
     const uint64_t total = nelem * 2 * ((c->P.logq + 63) / 64);
@@ -1366,8 +1379,10 @@ int mfh_sample_rows(mfh_ctx *c, uint64_t off, size_t nrows, uint64_t *d_out) {
                   hipLaunchKernelGGL(k_repack_values<1472>, grid, dim3(256), 0, c->stream, (const uint32_t *)tmp, (uint32_t *)d_out, nelem));
     if (hipGetLastError() != hipSuccess) rc = MFH_EDEVICE;
   }
-  hipStreamSynchronize(c->stream);
-  hipFree(tmp);
+  if (!kept) {
+    hipStreamSynchronize(c->stream);
+    hipFree(tmp);
+  }
   return rc;
 }
 

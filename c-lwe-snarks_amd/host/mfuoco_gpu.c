@@ -61,6 +61,7 @@ static struct {
   bool sk_valid;
   uint8_t *pin;       /* PIN_BYTES of pinned host memory: staging of the single-ciphertext calls */
   hipEvent_t ev_small; /* ... and an event for their split downloads */
+  hipStream_t s2;      /* ... and a second stream: the public half of a regev_encrypt2 beside its secret half */
   /* mfuoco_encrypt_batch: two chunks of ENC_CHUNK rows in flight (error limbs and messages up, exported b's down) */
   uint8_t *enc_pin[2], *d_enc[2];
   hipEvent_t enc_ev[2];
@@ -259,6 +260,7 @@ static mfh_ctx *gpu(void)
   HK(hipMalloc((void **)&G.d_crs, rows * CT_BYTES));
   HK(hipHostMalloc((void **)&G.pin, PIN_BYTES, hipHostMallocDefault));
   HK(hipEventCreateWithFlags(&G.ev_small, hipEventDisableTiming));
+  HK(hipStreamCreateWithFlags(&G.s2, hipStreamNonBlocking));
   HK(hipHostMalloc((void **)&G.pin_sk, (size_t)GAMMA_N * L_LIMBS * 8, hipHostMallocDefault));
   G.h_sk = xcalloc((size_t)GAMMA_N * L_LIMBS, 8);
   /* eval_poly's share of the context's scratch and code objects, paid here instead of by the first eval_poly a caller times (src/benchmark_eval.c:70-74 times exactly one,
@@ -528,17 +530,13 @@ void regev_encrypt2(ct_t c, rng_t rs, sk_t sk, mpz_t m, void (*chi)(mpz_t))
   gpu();
   use_seed(((shim_key *)s->key)->seed);
   const uint64_t pos = stream_pos(s);
-  /* The public half first, so that the host's share of the call runs beside it: the row's a part (the caller receives it too) and the stream block the row ends in
-   * (its unread tail is the caller's remb: CTR_CT = 16 * 8452 + 8, every other row ends mid-block) come down in ONE copy while the host draws the error, checks the
-   * cached key and packs [error limbs | message]; then one small upload, the encryption (b exported into the slot behind the a's) and 96 more bytes down, under which
-   * the host turns the a part into mpz_t's. */
-  uint64_t *up = (uint64_t *)G.pin, *down = (uint64_t *)(G.pin + 4096);
+  const double T0 = tnow();
+  /* The call is latency: seven runtime calls of 5 - 10 us each and two short kernels.  So the SECRET half goes first, on the default stream -- error draw, key check
+   * (uploaded only when it changed), ONE 100-byte upload of [error limbs | message], the encryption of the row, 96 bytes of b down -- and the PUBLIC half (the row's a
+   * part, which the caller receives too, and the stream block the row ends in: its unread tail is the caller's remb, CTR_CT = 16 * 8452 + 8, every other row ends
+   * mid-block) is queued behind it on a second stream and runs beside it on the GPU: one copy down, turned into mpz_t's while the encryption finishes. */
+  uint64_t *up = (uint64_t *)G.pin, *down = (uint64_t *)(G.pin + 4096), *down_b = (uint64_t *)(G.pin + 2048);
   const uint64_t end = pos + CTR_CT, endblk = ((end + 15) / 16 - 1) * 16;
-  uint64_t *d_b = G.d_ct[0] + (size_t)GAMMA_N * L_LIMBS;
-  CK(mfh_sample_rows(G.ctx, pos, 1, G.d_ct[0]));
-  CK(mfh_keystream(G.ctx, endblk, (uint8_t *)G.d_ct[0] + CTL * 8, 16));
-  HK(hipMemcpyAsync(down, G.d_ct[0], CTL * 8 + 16, hipMemcpyDeviceToHost, NULL)); /* (one copy: the a part, the b slot as it stands -- overwritten below --, the tail block) */
-  HK(hipEventRecord(G.ev_small, NULL));
   mpz_t e;
   mpz_init(e);
   (*chi)(e);
@@ -549,16 +547,40 @@ void regev_encrypt2(ct_t c, rng_t rs, sk_t sk, mpz_t m, void (*chi)(mpz_t))
   mpz_clear(e);
   const uint32_t mh = (uint32_t)mpz_get_ui(m);
   memcpy(up + L_LIMBS, &mh, 4);
+  const double T1 = tnow();
+  uint8_t *d_b = (uint8_t *)G.d_ct[1] + 128; /* (behind the 100 bytes of [error | message]) */
   HK(hipMemcpyAsync(G.d_ct[1], up, ENC_UP, hipMemcpyHostToDevice, NULL));
-  CK(mfh_encrypt_rows(G.ctx, pos, 1, d_sk, (const uint32_t *)(G.d_ct[1] + L_LIMBS), G.d_ct[1], (uint8_t *)d_b));
-  HK(hipMemcpyAsync(down + (size_t)GAMMA_N * L_LIMBS, d_b, L_LIMBS * 8, hipMemcpyDeviceToHost, NULL));
-  HK(hipMemsetAsync(G.d_ct[1], 0, ENC_UP, NULL)); /* the error leaves neither the device scratch ... */
-  HK(hipEventSynchronize(G.ev_small));
+  CK(mfh_encrypt_rows(G.ctx, pos, 1, d_sk, (const uint32_t *)(G.d_ct[1] + L_LIMBS), G.d_ct[1], d_b));
+  HK(hipMemcpyAsync(down_b, d_b, L_LIMBS * 8, hipMemcpyDeviceToHost, NULL));
+  HK(hipEventRecord(G.ev_small, NULL));           /* (what the call waits for: b is down) */
+  HK(hipMemsetAsync(G.d_ct[1], 0, ENC_UP, NULL)); /* the error leaves neither the device scratch (wiped behind the call's back, before anything else runs on this stream) ... */
+  const double T2 = tnow();
+  CK(mfh_set_stream(G.ctx, G.s2));
+  CK(mfh_sample_rows(G.ctx, pos, 1, G.d_ct[0]));
+  CK(mfh_keystream(G.ctx, endblk, (uint8_t *)G.d_ct[0] + (size_t)GAMMA_N * L_LIMBS * 8, 16));
+  CK(mfh_set_stream(G.ctx, NULL));
+  HK(hipMemcpyAsync(down, G.d_ct[0], (size_t)GAMMA_N * L_LIMBS * 8 + 16, hipMemcpyDeviceToHost, G.s2));
+  const double T3 = tnow();
+  HK(hipStreamSynchronize(G.s2));
+  const double T4 = tnow();
   for (size_t j = 0; j < GAMMA_N; j++) from_limbs(c[j], down + j * L_LIMBS);
-  HK(hipStreamSynchronize(NULL));
-  explicit_bzero(up, ENC_UP); /* ... nor the pinned one behind */
-  mpz_import(c[GAMMA_N], LOGQ_BYTES, -1, 1, -1, 0, down + (size_t)GAMMA_N * L_LIMBS);
-  stream_set_pos_blk(s, end, (const uint8_t *)(down + CTL));
+  const double T5 = tnow();
+  HK(hipEventSynchronize(G.ev_small));
+  const double T6 = tnow();
+  explicit_bzero(up, ENC_UP); /* ... nor the pinned one behind (the upload it fed is over: b came after it) */
+  mpz_import(c[GAMMA_N], LOGQ_BYTES, -1, 1, -1, 0, down_b);
+  stream_set_pos_blk(s, end, (const uint8_t *)(down + (size_t)GAMMA_N * L_LIMBS));
+  if (tracing()) {
+    static double acc[7];
+    static unsigned calls;
+    const double T7 = tnow(), t[8] = { T0, T1, T2, T3, T4, T5, T6, T7 };
+    for (int q = 0; q < 7; q++) acc[q] += t[q + 1] - t[q];
+    if (++calls % 256 == 0) {
+      fprintf(stderr, "regev_encrypt2 x256 (us per call): error + key check + pack %.1f, queue encryption %.1f, queue public half %.1f, wait public half %.1f, a -> mpz_t %.1f, wait b %.1f, b + stream state %.1f\n",
+              acc[0] * 1e3 / 256, acc[1] * 1e3 / 256, acc[2] * 1e3 / 256, acc[3] * 1e3 / 256, acc[4] * 1e3 / 256, acc[5] * 1e3 / 256, acc[6] * 1e3 / 256);
+      memset(acc, 0, sizeof acc);
+    }
+  }
 }
 
 /* regev_encrypt2 + ct_export (src/lwe.c:78-97,115-119) for `count` messages under one key: row k is what regev_encrypt2 produces with the stream at rs + k CTR_CT
