@@ -894,11 +894,22 @@ static void shim_warm_prover(void)
   CK(mfh_sync(G.ctx));
 }
 
+static void *setup_ssp_thread(void *ssp)
+{
+  HK(hipSetDevice(G.device)); /* (a new thread starts on device 0) */
+  ssp_resident((uint8_t *)ssp);
+  return NULL;
+}
 void setup(crs_t crs, vrs_t vrs, ssp_t ssp)
 {
   KEEP_ERRNO;
   gpu();
   use_seed(crs->seed);
+  /* the SSP (5.7 GB at the NDEBUG size) starts crossing PCIe at once, on a helper thread (mfh_ssp_upload has its own staging threads; this one only waits for them), while
+   * THIS thread draws the secrets from the OS -- the only thread that does, so the draws keep the reference's order.  Nothing below touches the GPU before the join. */
+  G.ssp_host = NULL;
+  pthread_t ssp_th;
+  const bool ssp_bg = pthread_create(&ssp_th, NULL, setup_ssp_thread, ssp) == 0;
   vrs->alpha = rand_modp_();
   vrs->beta = rand_modp_();
   vrs->s = rand_modp_();
@@ -914,15 +925,14 @@ void setup(crs_t crs, vrs_t vrs, ssp_t ssp)
   for (size_t i = 0; i < rows; i++) memcpy(err + i * L_LIMBS, tape + i * DRAW, EB);
   explicit_bzero(tape, rows * DRAW);
   free(tape);
+  const double t_drawn = tnow();
+  if (ssp_bg) pthread_join(ssp_th, NULL); else ssp_resident(ssp);
+  const double t_ssp = tnow();
   if (!G.d_err) HK(hipMalloc((void **)&G.d_err, rows * L_LIMBS * 8));
   HK(hipMemcpy(G.d_err, err, rows * L_LIMBS * 8, hipMemcpyHostToDevice));
   explicit_bzero(err, rows * L_LIMBS * 8); /* the encryption errors are part of the trapdoor: not left on the heap */
   free(err);
   sk_resident(vrs->sk);
-  const double t_drawn = tnow();
-  G.ssp_host = NULL;
-  ssp_resident(ssp);
-  const double t_ssp = tnow();
   drop_image(); /* G.d_crs is about to be rewritten */
   G.staged_digest_valid = false;
   CK(mfh_setup(G.ctx, G.d_ssp, (uint32_t)vrs->alpha, (uint32_t)vrs->beta, (uint32_t)vrs->s, G.d_sk, G.d_err, G.d_crs));
@@ -934,7 +944,7 @@ void setup(crs_t crs, vrs_t vrs, ssp_t ssp)
   const double t_crs = tnow();
   shim_warm_prover();
   if (tracing())
-    fprintf(stderr, "setup(): key + error draws and upload %.2f ms, SSP upload (%.2f GB) + quotient precomputation %.2f, encryptions + CRS download %.2f, prover warm-up %.2f\n",
+    fprintf(stderr, "setup(): key + error draws %.2f ms (the SSP upload runs beside them), rest of the SSP upload (%.2f GB) + quotient precomputation %.2f, uploads + encryptions + CRS download %.2f, prover warm-up %.2f\n",
             t_drawn - t_in, SSP_SIZE / 1e9, t_ssp - t_drawn, t_crs - t_ssp, tnow() - t_crs);
 }
 
