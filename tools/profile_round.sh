@@ -12,7 +12,7 @@ cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
 raw=/tmp/prof_$tag
 rm -rf $raw; mkdir -p $raw gpurun_out/${tag}_profiles
-rocprofv3 --kernel-trace --stats --output-format csv -d $raw/${tag}_stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > $raw/${tag}_stats.log 2> $raw/${tag}_stats.err || { tail -5 $raw/${tag}_stats.err; exit 1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d $raw/${tag}_stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-drop-in > $raw/${tag}_stats.log 2> $raw/${tag}_stats.err || { tail -5 $raw/${tag}_stats.err; exit 1; }
 echo "[profile] stats done: $(ls $raw/${tag}_stats/*/ | head -3 | tr '\n' ' ')"
 declare -A counters=( [fetch]="FETCH_SIZE" [write]="WRITE_SIZE" [tcc]="TCC_HIT_sum TCC_MISS_sum" [sq]="SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_INSTS_VALU GRBM_GUI_ACTIVE" )
 declare -A progs=( [batch]="tools/batch_prof.py" [enc]="tools/enc_prof.py" [dec]="tools/decrypt_time.py 65536" )
