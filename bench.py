@@ -53,7 +53,7 @@ def drop_in_leg():
         return {"error": "c-lwe-snarks_amd/host/bench_snark has not been built (make -C c-lwe-snarks_amd shim)"}
     nb, nenc = 1020, 65536
     try:
-        r = subprocess.run([exe, "1", "300", str(nb), "0", str(nenc)], capture_output=True, text=True, timeout=240)
+        r = subprocess.run([exe, "1", "300", str(nb), "0", str(nenc)], capture_output=True, text=True, timeout=120)
     except Exception as e:  # (timeout, exec failure)
         return {"error": f"{type(e).__name__}: {e}"}
     if r.returncode != 0:
