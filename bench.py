@@ -968,6 +968,9 @@ def main():
             "resident_crs": resident if mode == "single" else None,
             "cpu_baseline": cpu,
             "reference_typed_api": drop_in,
+            "aes_note": ("the lds_lookup_roofline objects price the AES kernels against the LDS pipe (201 lookups per block at 2.15 CU-clk per ds_read_b32: 91 Gblock/s); "
+                         "round 5 measured that this pipe is NOT what binds them -- a timing-only build whose lookup addresses are all one full-rate v_bitop3 runs 108-113 Gblock/s "
+                         "standalone against 67-77: the three v_perm_b32 per column that put a state byte at bits 8..15 of an address are (profiles/r05_aes_address_bound.txt)"),
         }
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
