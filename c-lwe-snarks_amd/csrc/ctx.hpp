@@ -120,6 +120,10 @@ struct mfh_ctx {
   int batch_merge = 1;     // the S and AS groups of a round in one streaming launch (0: two launches on two streams)
   uint32_t batch_ngl = 8;  // groups of 63 / 64 coefficient vectors per streaming launch and region (1..8; 8 = a super-group's S and AS regions in ONE launch)
   PinBuf pin_rows, pin_cw, pin_smudge;
+  // the batch chain's witness staging (one per super-group of a call, evalmm.hip): a ring, so that queueing super-group k + 1 does not wait on the host for
+  // super-group k's copy to have RUN (with one buffer mfh_prove_batch blocked its caller for half of the call's GPU time)
+  PinBuf pin_wring[8];
+  uint32_t pin_wnext = 0;
   void *sample_tmp = nullptr;  // mfh_sample_rows: the rows' raw stream bytes (small requests; kept so that the call neither allocates nor waits)
   size_t sample_bytes = 0;
   void *uploader = nullptr;  // mfh_ssp_upload: per-thread pinned / device staging pairs and streams (mfhip.hip), made on the first large upload

@@ -1920,7 +1920,8 @@ int mfh_witness_poly_mm_cols(mfh_ctx *c, const uint32_t *d_ssp, uint32_t nstmt, 
   int rc = wws_reserve(c, head_b + frag_b + part_b + rk_b);
   if (rc) return rc;
   // staged: packed bits, then (count of selected rows, delta) per statement
-  uint8_t *stage = (uint8_t *)pin_acquire(c, c->pin_rows, head_b);
+  PinBuf &wpin = c->pin_wring[c->pin_wnext++ % 8];
+  uint8_t *stage = (uint8_t *)pin_acquire(c, wpin, head_b);
   if (!stage) return MFH_ENOMEM;
   memcpy(stage, h_bits, packed);
   uint32_t *cd = (uint32_t *)(stage + packed + ((8 - packed % 8) % 8));
@@ -1934,7 +1935,7 @@ int mfh_witness_poly_mm_cols(mfh_ctx *c, const uint32_t *d_ssp, uint32_t nstmt, 
   }
   uint8_t *dev = (uint8_t *)c->wws;
   HIP_TRY(c, hipMemcpyAsync(dev, stage, head_b, hipMemcpyHostToDevice, c->stream));
-  pin_release(c, c->pin_rows);
+  pin_release(c, wpin);
   const uint32_t *d_cd = (const uint32_t *)(dev + packed + ((8 - packed % 8) % 8));
   int8_t *d_frag = (int8_t *)(dev + head_b);
   int *d_part = (int *)(dev + head_b + frag_b);

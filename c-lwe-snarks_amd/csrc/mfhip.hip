@@ -1101,6 +1101,7 @@ void mfh_ctx_destroy(mfh_ctx *c) {
   upload_free(c);
   if (c->sample_tmp) hipFree(c->sample_tmp);
   pin_free(c->pin_rows);
+  for (auto &b : c->pin_wring) pin_free(b);
   pin_free(c->pin_cw);
   pin_free(c->pin_smudge);
   if (c->side) hipStreamSynchronize(c->side);
