@@ -105,6 +105,7 @@ struct mfh_ctx {
   bool mm_wave1 = false;  // persistent grid with one wave per SIMD and 256 accumulators in AccVGPRs (k_mmstream_w)
   uint32_t mm_sync_mode = 0, mm_spin = 64;
   uint32_t mm_width = 32;  // workgroups per XCD of the persistent S / AS launch (mfh_set_mm_width): 32 = every CU
+  size_t early_ws_half = 0;        // early chain: distance of the two halves of ws3 = the scratch of the call's first (largest) super-group
   bool batch_early_chain = false;  // mfh_prove_batch: chain of super-group k + 1 and epilogue of k queued BESIDE the streaming launch of k / k + 1 (for the CUs a narrower grid leaves free)
   uint32_t *mm_sync = nullptr;  // 8 x 32 counters of the persistent grid's rendezvous
   uint32_t mm_chunk_rows = 131071;  // rows per row chunk of the matrix-core launches (int32 accumulators: |A'C'| <= 2^14 per row)

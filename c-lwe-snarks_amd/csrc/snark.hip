@@ -740,9 +740,15 @@ int batch_rows_supergroup(mfh_ctx *c, const uint8_t *d_crs_c8, uint32_t rank, ui
     // early mode (mfh_set_mm_width): the epilogues of this super-group run on the side stream beside the NEXT super-group's digit and streaming kernels, which
     // therefore get the other half of ws3
     const bool early = c->batch_early_chain && tail_on_side;
-    rc = buf_reserve(c, c->ws3, c->ws3_bytes, early ? 2 * ws_need : ws_need);
+    // The two halves are ONE stride apart for the whole call: the stride of the call's first super-group, which is its largest (a ragged last one has fewer
+    // groups and a smaller ws_need: placed at ITS ws_need, an odd-indexed short super-group would land inside the half its predecessor's epilogues still read).
+    if (early && (ws_slot == 0 || c->early_ws_half < ws_need)) {
+      if (ws_slot != 0) { c->err = "early chain: a later super-group needs more scratch than the call's first"; return MFH_EINVAL; }
+      c->early_ws_half = ws_need;
+    }
+    rc = buf_reserve(c, c->ws3, c->ws3_bytes, early ? 2 * c->early_ws_half : ws_need);
     if (rc) return rc;
-    size_t wo = early ? (size_t)(ws_slot & 1) * ws_need : 0;
+    size_t wo = early ? (size_t)(ws_slot & 1) * c->early_ws_half : 0;
     for (uint32_t r = 0; r < R; r++) {
       mms_bind(plan[r], (uint8_t *)c->ws3 + wo);
       wo += (mms_ws_bytes(plan[r]) + 255) & ~(size_t)255;
@@ -1069,6 +1075,9 @@ int mfh_prove_batch(mfh_ctx *c, const uint8_t *d_crs_c8, const uint32_t *d_ssp, 
       rc = launch_chain(sgi + 1);
       if (rc) return rc;
     }
+    // early mode: this super-group's digit kernels and streaming launches write the half of the scratch that super-group sgi - 2 used; its epilogues read that half
+    // on the side stream and its completion event is recorded behind them
+    if (early && sgi >= 2) HIP_TRY(c, hipStreamWaitEvent(main_stream, c->ev_sgdone[sgi - 2], 0));
     // b_w's pass over the BT+BV image is HBM-bound like the chain's witness pass, and the chain is what the S / AS launches wait for: b_w
     // starts when the witness pass is over and runs beside the polynomial step (NTT: VALU / LDS)
     HIP_TRY(c, hipStreamWaitEvent(main_stream, c->ev_wdone[sgi % nbuf], 0));

@@ -69,32 +69,45 @@ def _on_host_backend(t, group=None):
     return t.is_cuda and dist.get_backend(group) == "gloo"
 
 
-def all_to_all_rows(recv, send, out_splits, in_splits, group=None):
+class _Done:
+    """a finished collective (host-staged backends complete inside the call)"""
+
+    def wait(self):
+        return True
+
+
+def all_to_all_rows(recv, send, out_splits, in_splits, group=None, async_op=False):
+    """async_op (device tensors on RCCL only): the collective is queued on the backend's own stream behind what the current stream holds and a handle is returned;
+    handle.wait() makes the CURRENT STREAM wait for it (no host wait) -- kernels queued in between run beside the transfer"""
     import torch.distributed as dist
 
+    work = _Done()
     if _on_host_backend(send, group):
         r = recv.cpu()
         dist.all_to_all_single(r, send.cpu(), output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
         recv.copy_(r)
     else:
-        dist.all_to_all_single(recv, send, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+        w = dist.all_to_all_single(recv, send, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group, async_op=async_op)
+        work = w if async_op and w is not None else work
     _count("all_to_all_single", send.numel() * send.element_size())
-    return recv
+    return work if async_op else recv
 
 
-def reduce_scatter_lanes(own, lanes, group=None):
+def reduce_scatter_lanes(own, lanes, group=None, async_op=False):
     """own = this rank's equal slab of the element-wise sum of `lanes` over the ranks (int64 stands in for uint64: two's-complement sums
-    are the same bits, and 2^32 ranks of 32-bit words fit)"""
+    are the same bits, and 2^32 ranks of 32-bit words fit).  async_op: as in all_to_all_rows."""
     import torch.distributed as dist
 
+    work = _Done()
     if _on_host_backend(lanes, group):
         o = own.cpu()
         dist.reduce_scatter_tensor(o, lanes.cpu(), op=dist.ReduceOp.SUM, group=group)
         own.copy_(o)
     else:
-        dist.reduce_scatter_tensor(own, lanes, op=dist.ReduceOp.SUM, group=group)
+        w = dist.reduce_scatter_tensor(own, lanes, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+        work = w if async_op and w is not None else work
     _count("reduce_scatter_tensor", lanes.numel() * lanes.element_size())
-    return own
+    return work if async_op else own
 
 
 def row_shares(total, world):
@@ -109,17 +122,44 @@ def statement_shares(nb, world):
     return per, [(min(nb, r * per), min(nb, (r + 1) * per)) for r in range(world)]
 
 
+def stage_plan(nb, world, stage=None):
+    """How a row-sharded batch call is cut into pipeline stages (host/mfuoco_dist.c uses the same arithmetic): stage k holds, from every rank, the statements
+    [k sper, (k + 1) sper) of that rank's slab.  sper: the fewest equally long stages of at most 255 statements each (one super-group of the row work = one pass over
+    the rank's image share per stage; 1020 statements on 8 ranks: 5 stages of 26 per rank; 255 on 8: one stage); `stage` forces it (0 = one stage).
+    Returns (sper, number of stages)."""
+    per, _ = statement_shares(nb, world)
+    if per == 0:
+        return 0, 0
+    if stage is None:
+        nst = -(-nb // 255)
+        while True:
+            sper = -(-per // nst)
+            if sum(min(sper, max(0, min(nb, (q + 1) * per) - min(nb, q * per))) for q in range(world)) <= 255 or sper == 1:
+                break
+            nst += 1
+    else:
+        sper = int(stage)
+    if sper <= 0 or sper > per:
+        sper = per
+    return sper, -(-per // sper)
+
+
 def prove_batch_sharded(ctx, d_crs, d_ssp, witness_bits_list, deltas, smudge_mags, smudge_signs, rank, world, maglen=80, group=None, bufs=None,
-                        witness_by_cols=None, force_collectives=False):
+                        witness_by_cols=None, force_collectives=False, stage=None):
     """prover() (reference src/snark.c:117-190) for len(witness_bits_list) statements with the CRS ROWS sharded over `world` ranks
     (BASELINE configs 3/4: "ciphertexts sharded across 8 x MI355X + RCCL reduce"; include/mfhip.h, row-sharded batch prover).
 
-    Every rank is given the same statement list.  Data path per call:
+    Every rank is given the same statement list.  Data path:
       chain (own statements)  ->  all-to-all of the w | h | v row slices (3 x 4 B x d x nb / world sent per rank)
       ->  row shares of all five ciphertexts of all statements on the matrix cores
-      ->  ONE reduce-scatter (sum) of uint64 lanes, nb x 5 x (n+1) x ceil(64 K / 56) lanes of 8 B  ->  carries, modq, delta ct_t, smudging (own statements).
+      ->  reduce-scatter (sum) of uint64 lanes, nb x 5 x (n+1) x ceil(64 K / 56) lanes of 8 B  ->  carries, modq, delta ct_t, smudging (own statements),
+    PIPELINED in stages (stage_plan: world x sper <= 255 statements, sper from every rank's slab): with device tensors on RCCL the collectives are issued
+    async_op -- they run on the backend's stream -- in the order  C0 A0 | C1 A1 P0 L0 R0 | C2 A2 P1 L1 R1 F0 | ...  (C chain, A all-to-all, P row shares, L lanes,
+    R reduce-scatter, F finish), so stage k + 1's all-to-all runs under the row work of stage k and stage k's reduce-scatter under the chain and row work behind it.
+    Bytes handed to the backend are those of the one-shot sequence (stage=0); the call is one stage when no image share is registered with the context (the row
+    work would expand its transient image once per stage).
     witness_by_cols (default: on for a generator-defined SSP, d_ssp = None, where the witness pass is the chain's cost): the chain is cut
-    in two -- every rank computes its COEFFICIENT RANGE [d r / world, d (r+1) / world) of w of ALL statements (1 / world of the
+    in two -- every rank computes its COEFFICIENT RANGE [d r / world, d (r+1) / world) of w of the stage's statements (1 / world of the
     generation of the selected rows, no reduction), one more all-to-all (4 B x d x nb / world sent per rank) hands every statement's
     slices to its owner, who finishes the chain (v = w + v_0, h = (v^2 - 1) / t).  Needs the ranges to start at multiples of 128.
     Returns (first, count, proofs): the rank's own statements [first, first + count) and their finished proofs (count x 5 ciphertexts,
@@ -141,46 +181,80 @@ def prove_batch_sharded(ctx, d_crs, d_ssp, witness_bits_list, deltas, smudge_mag
     align = getattr(ctx, "witness_cols_align", 128)
     use_cols = (d_ssp is None) if witness_by_cols is None else bool(witness_by_cols)
     use_cols = use_cols and all(a % align == 0 and b % align == 0 for a, b in shares)
-    # 1. the chain of the rank's own statements: w | h | v, [3][count][d]
-    if use_cols:
-        # 1a. this rank's coefficient range of w of ALL statements; 1b. all-to-all by statement owner; 1c. the owner finishes the chain
-        wsl = ctx.batch_witness_cols(d_ssp, witness_bits_list, deltas, lo, cs)  # [nb][cs]
-        wrecv = torch.empty(count * p.d, dtype=wsl.dtype, device=wsl.device)
-        all_to_all_rows(wrecv, wsl.reshape(-1), [count * (b - a) for a, b in shares], [(b - a) * cs for a, b in owned], group)
-        whv = torch.empty((3, count, p.d), dtype=wsl.dtype, device=wsl.device)
-        off = 0
-        for a, b in shares:  # the block from rank q: [count][its range]
-            whv[0][:, a:b] = wrecv[off:off + count * (b - a)].view(count, b - a)
-            off += count * (b - a)
-        del wsl, wrecv
-        ctx.batch_chain_from_w(d_ssp, whv)
-    else:
-        whv = ctx.batch_chain(d_ssp, witness_bits_list[first:last], deltas[first:last])
-    # 2. all-to-all: rank r gets rows [d r / world, d (r+1) / world) of w | h | v of every statement, laid out [statement][w | h | v][rows]
-    send = torch.cat([whv[:, :, a:b].permute(1, 0, 2).reshape(-1) for a, b in shares]) if count else whv.reshape(-1)
-    in_splits = [count * 3 * (b - a) for a, b in shares]
-    out_splits = [(b - a) * 3 * cs for a, b in owned]
-    recv = torch.empty(nb * 3 * cs, dtype=send.dtype, device=send.device)
-    all_to_all_rows(recv, send, out_splits, in_splits, group)
-    # 3. the rank's row shares of every statement's five ciphertexts
-    partial = bufs.get("bpartial")
-    if partial is not None and partial.numel() * partial.element_size() < nb * 5 * p.ct_limbs * 8:
-        partial = None  # a buffer kept from a smaller call: mfh_prove_batch_partial writes nb x 5 ciphertexts
-    partial = ctx.prove_batch_partial(d_crs, rank, world, witness_bits_list, recv, recv[cs:], recv[2 * cs:], 3 * cs, out=partial)
-    # 4. the partial ciphertexts as uint64 lanes of 56 bits (13 per 704-bit value), statements padded to world equal slabs; reduce-scatter: the rank receives its slab summed
+    if stage is None and getattr(ctx, "_resident_mm", None) is None:
+        stage = 0  # no image share registered: one stage, one transient expansion
+    sper, nst = stage_plan(nb, world, stage)
     lps = 5 * (p.n + 1) * p.lanes  # lanes per statement
-    lanes = bufs.get("blanes")
-    if lanes is None or lanes.numel() != per * world * lps:
-        lanes = torch.zeros(per * world * lps, dtype=torch.int64, device=send.device)
-    ctx.ct_to_lanes(partial, nb * 5, out=lanes)
-    own = bufs.get("bown")
-    if own is None or own.numel() != per * lps:
-        own = torch.empty(per * lps, dtype=torch.int64, device=send.device)
-    reduce_scatter_lanes(own, lanes, group)
-    bufs.update(bpartial=partial, blanes=lanes, bown=own)
-    # 5. carries + modq, then delta ct_t and the smudging of the rank's own statements
-    proofs = ctx.ct_from_lanes(own, count * 5) if count else ctx.empty(0)
-    ctx.prove_batch_finish(d_crs, deltas[first:last], smudge_mags[first:last], smudge_signs[first:last], proofs, maglen)
+    dev = ctx.device
+    proofs = ctx.empty(count * 5 * p.ct_limbs * 8) if count else ctx.empty(0)
+    if nb == 0:
+        return first, count, proofs
+
+    def cnt(q, k):  # statements of rank q's slab in stage k
+        nq = owned[q][1] - owned[q][0]
+        return max(0, min(sper, nq - k * sper))
+
+    def stage_ids(k):  # the stage's statements in stage order: by rank, then by place in the rank's slab
+        return [owned[q][0] + k * sper + i for q in range(world) for i in range(cnt(q, k))]
+
+    st = [None] * nst  # per stage: what the later steps need
+    for it in range(nst + 2):
+        if it < nst:  # ---- C(it): the chain of the OWN statements of the stage, operands laid out for the all-to-all; A(it)
+            k = it
+            on = cnt(rank, k)
+            ids = stage_ids(k)
+            own_ids = [first + k * sper + i for i in range(on)]
+            cnts = [cnt(q, k) for q in range(world)]
+            if use_cols:
+                # this rank's coefficient range of w of the stage's statements; all-to-all by statement owner; the owner finishes the chain
+                wsl = ctx.batch_witness_cols(d_ssp, [witness_bits_list[i] for i in ids], [deltas[i] for i in ids], lo, cs)  # [stage statements][cs]
+                wrecv = torch.empty(on * p.d, dtype=wsl.dtype, device=dev)
+                all_to_all_rows(wrecv, wsl.reshape(-1), [on * (b - a) for a, b in shares], [c * cs for c in cnts], group)
+                whv = torch.empty((3, on, p.d), dtype=wsl.dtype, device=dev)
+                off = 0
+                for a, b in shares:  # the block from rank q: [on][its range]
+                    whv[0][:, a:b] = wrecv[off:off + on * (b - a)].view(on, b - a)
+                    off += on * (b - a)
+                del wsl, wrecv
+                ctx.batch_chain_from_w(d_ssp, whv)
+            else:
+                whv = ctx.batch_chain(d_ssp, [witness_bits_list[i] for i in own_ids], [deltas[i] for i in own_ids])
+            # rank r gets rows [d r / world, d (r+1) / world) of w | h | v of the own statements, laid out [statement][w | h | v][rows]
+            send = torch.cat([whv[:, :, a:b].permute(1, 0, 2).reshape(-1) for a, b in shares]) if on else whv.reshape(-1)
+            recv = torch.empty(len(ids) * 3 * cs, dtype=send.dtype, device=dev)
+            work = all_to_all_rows(recv, send, [c * 3 * cs for c in cnts], [on * 3 * (b - a) for a, b in shares], group, async_op=True)
+            st[k] = {"ids": ids, "on": on, "own_ids": own_ids, "recv": recv, "send": send, "a2a": work, "sl": cnts[0]}
+            del whv
+        if 1 <= it <= nst:  # ---- P(it - 1): the rank's row shares of the stage's statements; L: as uint64 lanes, padded to world equal slabs; R: the reduce-scatter
+            k = it - 1
+            s_ = st[k]
+            s_["a2a"].wait()
+            nk, sl = len(s_["ids"]), s_["sl"]
+            key = "bpartial%d" % (k & 1)
+            partial = bufs.get(key)
+            if partial is not None and partial.numel() * partial.element_size() < nk * 5 * p.ct_limbs * 8:
+                partial = None  # a buffer kept from a smaller call: mfh_prove_batch_partial writes nk x 5 ciphertexts
+            recv = s_["recv"]
+            partial = ctx.prove_batch_partial(d_crs, rank, world, [witness_bits_list[i] for i in s_["ids"]], recv, recv[cs:], recv[2 * cs:], 3 * cs, out=partial)
+            bufs[key] = partial
+            lanes = torch.zeros(sl * world * lps, dtype=torch.int64, device=dev) if sl * world > nk else torch.empty(sl * world * lps, dtype=torch.int64, device=dev)
+            ctx.ct_to_lanes(partial, nk * 5, out=lanes)
+            own = torch.empty(sl * lps, dtype=torch.int64, device=dev)
+            s_["rs"] = reduce_scatter_lanes(own, lanes, group, async_op=True)
+            s_["own"], s_["lanes"] = own, lanes
+            s_["recv"] = s_["send"] = None
+        if it >= 2:  # ---- F(it - 2): carries + modq, then delta ct_t and the smudging of the rank's own statements
+            k = it - 2
+            s_ = st[k]
+            s_["rs"].wait()
+            on = s_["on"]
+            if on:
+                o0 = (k * sper) * 5 * p.ct_limbs * 8
+                out = proofs[o0:o0 + on * 5 * p.ct_limbs * 8]
+                ctx.ct_from_lanes(s_["own"], on * 5, out=out)
+                oi = s_["own_ids"]
+                ctx.prove_batch_finish(d_crs, [deltas[i] for i in oi], [smudge_mags[i] for i in oi], [smudge_signs[i] for i in oi], out, maglen)
+            st[k] = None
     return first, count, proofs
 
 

@@ -154,10 +154,16 @@ void mfuoco_decrypt_rows_batch(mpz_t *ms, rng_t rs, sk_t sk, uint8_t (*c8)[CT_BY
 int mfuoco_gpu_set_device(int device);
 int mfuoco_gpu_device(void);
 /* The shim keeps the CRS it expanded across prover calls, keyed by the seed and a device-side digest of the compressed CRS (SURVEY 8(d)'s materialised-CRS
- * regime behind the reference's types): mfuoco_prover_batch / _sharded stream the matrix-core image from the second call on (no AES in the call), prover()
- * the single-proof image from its second call under one CRS on (that call expands it).  Default on; $MFUOCO_GPU_RESIDENT_CRS=0 or mfuoco_gpu_set_resident_crs(0) turn it off and
- * free the images; mfuoco_gpu_invalidate() drops them (and the resident SSP). */
+ * regime behind the reference's types): mfuoco_prover_batch / _sharded stream the matrix-core image from the second call on (no AES in the call).  prover() streams the
+ * single-proof row image from its FIRST call on when the CRS came out of setup() (which writes the rows as a by-product of its encryptions) or out of
+ * mfuoco_crs_map() (which queues the expansion, mfuoco_gpu_prefetch_crs); under a CRS the caller filled in by hand, from the second call on (that call expands it).
+ * Default on; $MFUOCO_GPU_RESIDENT_CRS=0 or mfuoco_gpu_set_resident_crs(0) turn it off and free the images; mfuoco_gpu_invalidate() drops them (and the resident SSP). */
 void mfuoco_gpu_set_resident_crs(int on);
+/* stage `crs` on the device and queue the expansion of its row image (returns after a few ms of host time, the GPU expands in the background): the first prover() under it
+ * then streams the rows instead of regenerating them.  mfuoco_crs_map() calls it for read-only mappings; $MFUOCO_GPU_PREFETCH=0 turns that off. */
+void mfuoco_gpu_prefetch_crs(crs_t crs);
+/* what the last prover() ran on: 0 = keystream regenerated (src/lwe.c:122-126 as the reference does), 1 = the resident row image */
+int mfuoco_gpu_last_prover_path(void);
 
 
 /* ---- flat on-disk images (host only; host/mfuoco_files.c).  Sizes are the reference's: CRS_SIZE (src/snark.h:6),

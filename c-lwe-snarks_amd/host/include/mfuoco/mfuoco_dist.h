@@ -31,15 +31,17 @@ int mfuoco_comm_create(mfuoco_comm **comm, int rank, int world, int device, cons
 void mfuoco_comm_unique_id(uint8_t id[MFUOCO_UNIQUE_ID_BYTES]);
 int mfuoco_comm_create_from_id(mfuoco_comm **comm, int rank, int world, int device, const uint8_t id[MFUOCO_UNIQUE_ID_BYTES]);
 /* A communicator over the caller's OWN collectives (an MPI build, a test harness) instead of RCCL: the four operations the sequences below need, on device
- * buffers, ordered with the NULL stream (a transport that stages through the host synchronises the device itself).  Element counts, not bytes;
+ * buffers, ordered ON `stream` (a hipStream_t; NULL = the NULL stream): the operation reads its inputs after the work queued on that stream before the call and
+ * work queued on it after the call sees the outputs -- RCCL takes the stream as it is; a transport that stages through the host synchronises that stream itself.
+ * The batch prover issues its collectives on a stream of the communicator's own, every rank in the same order.  Element counts, not bytes;
  * reduce_scatter: d_recv[0 .. n) = sum over ranks q of q's d_send[rank * n .. (rank + 1) * n), wrap-around uint64 sums; destroy may be NULL. */
 typedef struct mfuoco_transport {
   const char *name;
   void (*alltoallv_u32)(void *impl, int rank, int world, const uint32_t *d_send, const size_t *scnt, const size_t *sdsp, uint32_t *d_recv, const size_t *rcnt,
-                        const size_t *rdsp);
-  void (*reduce_scatter_u64)(void *impl, int rank, int world, const uint64_t *d_send, uint64_t *d_recv, size_t n);
-  void (*allreduce_u64)(void *impl, int rank, int world, uint64_t *d_buf, size_t n);
-  void (*bcast_bytes)(void *impl, int rank, int world, uint8_t *d_buf, size_t n, int root);
+                        const size_t *rdsp, void *stream);
+  void (*reduce_scatter_u64)(void *impl, int rank, int world, const uint64_t *d_send, uint64_t *d_recv, size_t n, void *stream);
+  void (*allreduce_u64)(void *impl, int rank, int world, uint64_t *d_buf, size_t n, void *stream);
+  void (*bcast_bytes)(void *impl, int rank, int world, uint8_t *d_buf, size_t n, int root, void *stream);
   void (*destroy)(void *impl);
 } mfuoco_transport;
 int mfuoco_comm_create_transport(mfuoco_comm **comm, int rank, int world, int device, const mfuoco_transport *transport, void *impl);
@@ -54,8 +56,11 @@ void mfuoco_comm_stats(const mfuoco_comm *comm, uint64_t calls[4], uint64_t byte
 /* prover() (src/snark.h:50, src/snark.c:117-190) for `count` statements under one CRS and SSP with the CRS ROWS sharded over the ranks
  * of `comm` -- what c-lwe-snarks_amd/dist.py:prove_batch_sharded does, in C:
  *   chain of the rank's own statement slab (mfh_batch_chain)  ->  all-to-all of the w | h | v row slices (ncclGroupStart + ncclSend / ncclRecv)
- *   ->  mfh_prove_batch_partial on the rank's row shares  ->  mfh_ct_to_lanes  ->  ONE ncclReduceScatter(sum, ncclUint64)
- *   ->  mfh_ct_from_lanes  ->  mfh_prove_batch_finish (delta ct_t, smudging) on the own slab.
+ *   ->  mfh_prove_batch_partial on the rank's row shares  ->  mfh_ct_to_lanes  ->  ncclReduceScatter(sum, ncclUint64)
+ *   ->  mfh_ct_from_lanes  ->  mfh_prove_batch_finish (delta ct_t, smudging) on the own slab,
+ * pipelined in stages of (255 / world) statements per rank (at most one super-group of the row work): the collectives run on the communicator's own stream,
+ * stage k + 1's all-to-all and stage k - 1's reduce-scatter, finish and device-to-host drain under the row work of stage k; the bytes handed to the backend are those
+ * of the one-shot sequence ($MFUOCO_DIST_STAGE=0 restores it; it is also what runs when the rank's image share is not resident).
  * Every rank passes the same crs, ssp, witnesses and count.  Statements are owned in slabs of ceil(count / world): on return
  * [*own_first, *own_first + *own_count) are this rank's statements and pis[k] (initialised by proof_init) holds their proofs; the other
  * pis[] are untouched.  Entropy (delta, the five smudging draws) is drawn by the owner, per statement in prover()'s order.  With the same

@@ -7,7 +7,9 @@
  * device; the loops split here are src/snark.c:147-155 and :157-174.  c-lwe-snarks_amd/dist.py is the same sequence over
  * torch.distributed and is what bench.py drives; the split arithmetic below is the same (row_shares, statement_shares).
  *
- * Everything runs on the NULL stream (the shim's stream), so kernels, copies and collectives are ordered without events.
+ * Streams: kernels and device copies run on the shim's stream (the NULL stream); the collectives of the batch prover run on the communicator's OWN non-blocking
+ * stream, ordered with the kernels by events -- stage k's all-to-all under the row work of stage k - 1, its reduce-scatter under the row work of stage k + 1
+ * (mfuoco_prover_batch_sharded below).  The single-proof sequence (two small all-reduces) stays on the NULL stream.
  */
 #define _GNU_SOURCE
 #include <errno.h>
@@ -40,7 +42,8 @@ void mfuoco_gpu_witness_bits(uint8_t *bits, mpz_t witness);
 void mfuoco_gpu_prover_entropy(uint32_t *delta, uint8_t *mag, uint8_t *sign);
 void mfuoco_gpu_prover_entropy_batch(uint32_t *delta, uint8_t *mag, uint8_t *sign, size_t count);
 void mfuoco_gpu_proofs_to_host(proof_t *pis, const uint64_t *d_proofs, size_t count);
-void mfuoco_gpu_image_resident_share(const uint8_t *d_crs, uint32_t rank, uint32_t world, int expand);
+void mfuoco_gpu_proofs_to_host_after(proof_t *pis, const uint64_t *d_proofs, size_t count, void *hip_event);
+int mfuoco_gpu_image_resident_share(const uint8_t *d_crs, uint32_t rank, uint32_t world, int expand);
 
 #define L_LIMBS 12
 #define K_LIMBS 11
@@ -48,6 +51,7 @@ void mfuoco_gpu_image_resident_share(const uint8_t *d_crs, uint32_t rank, uint32
 #define LANES_PER_CT ((size_t)(GAMMA_N + 1) * ((64 * K_LIMBS + 55) / 56)) /* uint64 lanes of 56 bits: 13 per 704-bit value (mfh_lanes_per_value) */
 #define MAGLEN (GAMMA_LOG_SMUDGING / 8)
 #define MAXW 64
+#define NBUF 16
 
 enum { ST_A2A = 0, ST_RS = 1, ST_AR = 2, ST_BC = 3 };
 
@@ -58,8 +62,13 @@ struct mfuoco_comm {
   const mfuoco_transport *t; /* NULL: no backend (comm == NULL callers, world 1) */
   void *impl;
   uint64_t calls[4], bytes[4];
-  void *buf[8]; /* device scratch, grown on demand */
-  size_t cap[8];
+  void *buf[NBUF]; /* device scratch, grown on demand */
+  size_t cap[NBUF];
+  /* the batch prover's pipeline: the collectives' stream and the events that order it with the shim's stream (made on first use) */
+  hipStream_t cstream;
+  hipEvent_t ev_sent[2], ev_recv[2], ev_lanes[2], ev_own[2]; /* by stage parity: operands packed / all-to-all done / lanes written / reduce-scatter done */
+  hipEvent_t *ev_done;                                        /* per stage: the stage's proofs are final */
+  size_t n_done;
 };
 
 static void dist_die(const char *what, const char *detail)
@@ -87,6 +96,42 @@ static void *xmalloc(size_t bytes)
   return p;
 }
 
+static void comm_release(mfuoco_comm *c)
+{
+  for (int i = 0; i < NBUF; i++) {
+    if (c->buf[i]) hipFree(c->buf[i]);
+    c->buf[i] = NULL;
+    c->cap[i] = 0;
+  }
+  if (c->cstream) {
+    for (int i = 0; i < 2; i++) { hipEventDestroy(c->ev_sent[i]); hipEventDestroy(c->ev_recv[i]); hipEventDestroy(c->ev_lanes[i]); hipEventDestroy(c->ev_own[i]); }
+    hipStreamDestroy(c->cstream);
+    c->cstream = NULL;
+  }
+  for (size_t i = 0; i < c->n_done; i++) hipEventDestroy(c->ev_done[i]);
+  free(c->ev_done);
+  c->ev_done = NULL;
+  c->n_done = 0;
+}
+static void comm_pipeline(mfuoco_comm *c, size_t stages)
+{
+  if (!c->cstream) {
+    HK(hipStreamCreateWithFlags(&c->cstream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) {
+      HK(hipEventCreateWithFlags(&c->ev_sent[i], hipEventDisableTiming));
+      HK(hipEventCreateWithFlags(&c->ev_recv[i], hipEventDisableTiming));
+      HK(hipEventCreateWithFlags(&c->ev_lanes[i], hipEventDisableTiming));
+      HK(hipEventCreateWithFlags(&c->ev_own[i], hipEventDisableTiming));
+    }
+  }
+  if (stages > c->n_done) {
+    c->ev_done = realloc(c->ev_done, stages * sizeof *c->ev_done);
+    if (!c->ev_done) dist_die("out of host memory", NULL);
+    for (size_t i = c->n_done; i < stages; i++) HK(hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming));
+    c->n_done = stages;
+  }
+}
+
 /* ---- split arithmetic (dist.py: row_shares, statement_shares) ------------------------------------------------------------ */
 static size_t row_lo(size_t total, int r, int world) { return total * (size_t)r / (size_t)world; }
 static size_t stmt_per(size_t nb, int world) { return nb ? (nb + world - 1) / world : 0; }
@@ -98,31 +143,31 @@ static size_t stmt_lo(size_t nb, int r, int world)
 
 /* ---- the RCCL transport ---------------------------------------------------------------------------------------------------- */
 static void rccl_alltoallv_u32(void *impl, int rank, int world, const uint32_t *d_send, const size_t *scnt, const size_t *sdsp, uint32_t *d_recv,
-                               const size_t *rcnt, const size_t *rdsp)
+                               const size_t *rcnt, const size_t *rdsp, void *stream)
 {
   (void)rank;
   ncclComm_t nc = impl;
   NK(ncclGroupStart());
   for (int q = 0; q < world; q++) {
-    if (scnt[q]) NK(ncclSend(d_send + sdsp[q], scnt[q], ncclUint32, q, nc, NULL));
-    if (rcnt[q]) NK(ncclRecv(d_recv + rdsp[q], rcnt[q], ncclUint32, q, nc, NULL));
+    if (scnt[q]) NK(ncclSend(d_send + sdsp[q], scnt[q], ncclUint32, q, nc, (hipStream_t)stream));
+    if (rcnt[q]) NK(ncclRecv(d_recv + rdsp[q], rcnt[q], ncclUint32, q, nc, (hipStream_t)stream));
   }
   NK(ncclGroupEnd());
 }
-static void rccl_reduce_scatter_u64(void *impl, int rank, int world, const uint64_t *d_send, uint64_t *d_recv, size_t n)
+static void rccl_reduce_scatter_u64(void *impl, int rank, int world, const uint64_t *d_send, uint64_t *d_recv, size_t n, void *stream)
 {
   (void)rank; (void)world;
-  NK(ncclReduceScatter(d_send, d_recv, n, ncclUint64, ncclSum, (ncclComm_t)impl, NULL));
+  NK(ncclReduceScatter(d_send, d_recv, n, ncclUint64, ncclSum, (ncclComm_t)impl, (hipStream_t)stream));
 }
-static void rccl_allreduce_u64(void *impl, int rank, int world, uint64_t *d_buf, size_t n)
+static void rccl_allreduce_u64(void *impl, int rank, int world, uint64_t *d_buf, size_t n, void *stream)
 {
   (void)rank; (void)world;
-  NK(ncclAllReduce(d_buf, d_buf, n, ncclUint64, ncclSum, (ncclComm_t)impl, NULL));
+  NK(ncclAllReduce(d_buf, d_buf, n, ncclUint64, ncclSum, (ncclComm_t)impl, (hipStream_t)stream));
 }
-static void rccl_bcast_bytes(void *impl, int rank, int world, uint8_t *d_buf, size_t n, int root)
+static void rccl_bcast_bytes(void *impl, int rank, int world, uint8_t *d_buf, size_t n, int root, void *stream)
 {
   (void)rank; (void)world;
-  NK(ncclBroadcast(d_buf, d_buf, n, ncclUint8, root, (ncclComm_t)impl, NULL));
+  NK(ncclBroadcast(d_buf, d_buf, n, ncclUint8, root, (ncclComm_t)impl, (hipStream_t)stream));
 }
 static void rccl_destroy(void *impl) { ncclCommDestroy((ncclComm_t)impl); }
 static const mfuoco_transport rccl_transport = { "rccl", rccl_alltoallv_u32, rccl_reduce_scatter_u64, rccl_allreduce_u64, rccl_bcast_bytes, rccl_destroy };
@@ -217,8 +262,7 @@ void mfuoco_comm_destroy(mfuoco_comm *c)
 {
   if (!c) return;
   hipDeviceSynchronize();
-  for (int i = 0; i < 8; i++)
-    if (c->buf[i]) hipFree(c->buf[i]);
+  comm_release(c);
   if (c->t && c->t->destroy) c->t->destroy(c->impl);
   free(c);
 }
@@ -237,35 +281,47 @@ void mfuoco_comm_stats(const mfuoco_comm *c, uint64_t calls[4], uint64_t bytes[4
 /* ---- collectives (device buffers; counts in elements) ---------------------------------------------------------------------- */
 /* all-to-all of uint32 words: scnt[q] words from d_send + sdsp[q] go to rank q; rcnt[q] words from rank q land at d_recv + rdsp[q] */
 static void comm_alltoallv_u32(mfuoco_comm *c, const uint32_t *d_send, const size_t *scnt, const size_t *sdsp, uint32_t *d_recv, const size_t *rcnt,
-                               const size_t *rdsp)
+                               const size_t *rdsp, hipStream_t stream)
 {
   size_t total = 0;
   for (int q = 0; q < c->world; q++) total += scnt[q];
   c->calls[ST_A2A]++;
   c->bytes[ST_A2A] += total * 4;
-  c->t->alltoallv_u32(c->impl, c->rank, c->world, d_send, scnt, sdsp, d_recv, rcnt, rdsp);
+  c->t->alltoallv_u32(c->impl, c->rank, c->world, d_send, scnt, sdsp, d_recv, rcnt, rdsp, stream);
 }
 /* d_recv[0 .. n) = sum over ranks of their d_send[rank * n .. (rank + 1) * n)   (uint64 lanes, wrap-around sum) */
-static void comm_reduce_scatter_u64(mfuoco_comm *c, const uint64_t *d_send, uint64_t *d_recv, size_t n)
+static void comm_reduce_scatter_u64(mfuoco_comm *c, const uint64_t *d_send, uint64_t *d_recv, size_t n, hipStream_t stream)
 {
   c->calls[ST_RS]++;
   c->bytes[ST_RS] += n * c->world * 8;
-  c->t->reduce_scatter_u64(c->impl, c->rank, c->world, d_send, d_recv, n);
+  c->t->reduce_scatter_u64(c->impl, c->rank, c->world, d_send, d_recv, n, stream);
 }
 static void comm_allreduce_u64(mfuoco_comm *c, uint64_t *d_buf, size_t n)
 {
   c->calls[ST_AR]++;
   c->bytes[ST_AR] += n * 8;
-  c->t->allreduce_u64(c->impl, c->rank, c->world, d_buf, n);
+  c->t->allreduce_u64(c->impl, c->rank, c->world, d_buf, n, NULL);
 }
 static void comm_bcast_bytes(mfuoco_comm *c, uint8_t *d_buf, size_t n, int root)
 {
   c->calls[ST_BC]++;
   c->bytes[ST_BC] += n;
-  c->t->bcast_bytes(c->impl, c->rank, c->world, d_buf, n, root);
+  c->t->bcast_bytes(c->impl, c->rank, c->world, d_buf, n, root, NULL);
 }
 
 /* ---- the row-sharded batch prover ------------------------------------------------------------------------------------------- */
+/* A call is cut into STAGES.  Stage k holds, from every rank, the statements k * sper .. (k + 1) * sper - 1 of that rank's slab (sper = 255 / world, so a stage is at most one
+ * super-group of mfh_prove_batch_partial: one pass over the rank's share of the image per stage), in rank order -- ownership and results are those of the one-shot sequence
+ * (sums mod 2^(64K) do not depend on the order, and a proof does not depend on which statements share its launches).  Per stage, the five steps of the header:
+ *     C  chain of the OWN statements of the stage, operands packed            shim stream
+ *     A  all-to-all of the w | h | v row slices                               communicator stream, after C
+ *     P  the rank's row shares of the stage's statements; L  lanes            shim stream, after A
+ *     R  reduce-scatter of the lanes                                          communicator stream, after L
+ *     F  carries, modq, delta ct_t, smudging of the own statements            shim stream, after R;  then the drain (own copy stream + host threads), after F
+ * queued as   C0 | C1 P0 L0 | C2 P1 L1 F0 | C3 P2 L2 F1 | ...   on the shim's stream and   A0 | A1 R0 | A2 R1 | ...   on the communicator's, so that A(k + 1) runs under
+ * P(k), R(k) under C(k + 2) and P(k + 1), and the host turns stage k into mpz_t's under the kernels of the stages behind it.  Everything is double-buffered by stage parity;
+ * the order above is what makes that safe (a buffer's next writer is queued behind an event its last reader precedes).  Without a resident image share
+ * ($MFUOCO_GPU_RESIDENT_CRS=0, or no room) the call is ONE stage: mfh_prove_batch_partial then expands its transient image once per call, not once per stage. */
 void mfuoco_prover_batch_sharded(proof_t *pis, crs_t crs, ssp_t ssp, mpz_t *witnesses, size_t count, mfuoco_comm *comm, size_t *own_first,
                                  size_t *own_count)
 {
@@ -282,67 +338,137 @@ void mfuoco_prover_batch_sharded(proof_t *pis, crs_t crs, ssp_t ssp, mpz_t *witn
   const uint32_t *d_ssp = mfuoco_gpu_stage_ssp(ssp);
   const size_t stride = mfuoco_gpu_bits_stride();
   const size_t lo = row_lo(d, rank, world), cs = row_lo(d, rank + 1, world) - lo;
-
-  /* host inputs: the bit strings of ALL statements (they select the rank's BT+BV rows), entropy of the OWN statements */
+  (void)lo;
   if (world > 1 && !c->t) dist_die("mfuoco_prover_batch_sharded", "more than one rank needs a communicator with a transport");
+
+  /* the rank's share of the image, kept across calls while the CRS is the same; stages only when the row work streams it */
+  const int streamed = mfuoco_gpu_image_resident_share(d_crs, (uint32_t)rank, (uint32_t)world, nb > 31);
+  const char *se = getenv("MFUOCO_DIST_STAGE"); /* statements per rank and stage (tests, tuning); 0 = one stage */
+  /* the fewest equally long stages of at most 255 statements (one super-group of the row work, one pass over the image share) each: 1020 statements on 8 ranks are 5 stages
+   * of 26 per rank, 255 on 8 ranks one stage (dist.py: stage_plan) */
+  size_t sper = per;
+  for (size_t ns = (nb + 254) / 255;; ns++) {
+    sper = (per + ns - 1) / ns;
+    size_t in_stage = 0;
+    for (int q = 0; q < world; q++) {
+      const size_t nq = stmt_lo(nb, q + 1, world) - stmt_lo(nb, q, world);
+      in_stage += nq < sper ? nq : sper;
+    }
+    if (in_stage <= 255 || sper == 1) break;
+  }
+  if (se && *se) sper = (size_t)atol(se);
+  if (!streamed || !sper || sper > per) sper = per;
+  const size_t nst = (per + sper - 1) / sper;
+  comm_pipeline(c, nst);
+  hipStream_t const cst = c->t ? c->cstream : NULL; /* (no backend: the stand-in copies run in line) */
+
+  /* host inputs: the bit strings of ALL statements in stage order (they select the rank's BT+BV rows), entropy of the OWN statements in the order of nown prover() calls */
   uint8_t *bits = xmalloc(nb * stride), *mag = xmalloc((nown ? nown : 1) * 5 * MAGLEN), *sign = xmalloc((nown ? nown : 1) * 5);
   uint32_t *delta = xmalloc((nown ? nown : 1) * 4);
   memset(bits, 0, nb * stride);
-  for (size_t k = 0; k < nb; k++) mfuoco_gpu_witness_bits(bits + k * stride, witnesses[k]);
-  if (nown) mfuoco_gpu_prover_entropy_batch(delta, mag, sign, nown); /* (one draw, cut up in the order of nown prover() calls) */
-
-  /* 1. the chain of the own statements (src/snark.c:141-169): w | h | v, nown x d coefficients each */
-  uint32_t *whv = scratch(c, 0, 3 * nown * d * 4);
-  uint32_t *W = whv, *H = whv + nown * d, *V = whv + 2 * nown * d;
-  if (nown) CK(mfh_batch_chain(ctx, d_ssp, (uint32_t)nown, bits + first * stride, stride, delta, W, H, V));
-
-  /* 2. all-to-all: rank q gets rows [d q / world, d (q+1) / world) of w | h | v of the own statements, laid out [statement][w | h | v][rows];
-   *    this rank receives its rows of ALL statements (the statements of rank q are contiguous: [first_q, last_q)) */
-  uint32_t *send = scratch(c, 1, 3 * nown * d * 4), *recv = scratch(c, 2, nb * 3 * cs * 4);
-  size_t scnt[MAXW], sdsp[MAXW], rcnt[MAXW], rdsp[MAXW], off = 0;
-  for (int q = 0; q < world; q++) {
-    const size_t a = row_lo(d, q, world), w = row_lo(d, q + 1, world) - a;
-    sdsp[q] = off;
-    scnt[q] = nown * 3 * w;
-    if (scnt[q])
-      for (int x = 0; x < 3; x++) /* a strided column slice per polynomial kind: one 2-D device copy */
-        HK(hipMemcpy2DAsync(send + off + (size_t)x * w, 3 * w * 4, whv + (size_t)x * nown * d + a, d * 4, w * 4, nown, hipMemcpyDeviceToDevice, NULL));
-    off += scnt[q];
-    const size_t fq = stmt_lo(nb, q, world), nq = stmt_lo(nb, q + 1, world) - fq;
-    rdsp[q] = fq * 3 * cs;
-    rcnt[q] = nq * 3 * cs;
+  size_t *soff = xmalloc((nst + 1) * sizeof *soff); /* first statement of stage k in stage order */
+  {
+    size_t pos = 0;
+    for (size_t k = 0; k < nst; k++) {
+      soff[k] = pos;
+      for (int q = 0; q < world; q++) {
+        const size_t fq = stmt_lo(nb, q, world), nq = stmt_lo(nb, q + 1, world) - fq;
+        for (size_t i = k * sper; i < (k + 1) * sper && i < nq; i++) mfuoco_gpu_witness_bits(bits + pos++ * stride, witnesses[fq + i]);
+      }
+    }
+    soff[nst] = pos;
   }
-  if (c->t) comm_alltoallv_u32(c, send, scnt, sdsp, recv, rcnt, rdsp);
-  else HK(hipMemcpyAsync(recv, send, scnt[0] * 4, hipMemcpyDeviceToDevice, NULL));
+  if (nown) mfuoco_gpu_prover_entropy_batch(delta, mag, sign, nown);
 
-  /* 3. the rank's row shares of the five ciphertexts of every statement (matrix cores; no delta ct_t term, un-smudged) */
-  uint64_t *partial = scratch(c, 3, nb * 5 * CTL * 8);
-  mfuoco_gpu_image_resident_share(d_crs, (uint32_t)rank, (uint32_t)world, nb > 31); /* the rank's share of the image, kept across calls while the CRS is the same */
-  CK(mfh_prove_batch_partial(ctx, d_crs, (uint32_t)rank, (uint32_t)world, (uint32_t)nb, bits, stride, recv, recv + cs, recv + 2 * cs, 3 * cs, partial));
-
-  /* 4. the partial ciphertexts as uint64 lanes of 56 bits, statements padded to `world` equal slabs; ONE reduce-scatter: the own slab, summed */
-  const size_t lps = 5 * LANES_PER_CT;
-  uint64_t *lanes = scratch(c, 4, per * world * lps * 8), *own = scratch(c, 5, per * lps * 8);
-  if (per * world > nb) HK(hipMemsetAsync(lanes + nb * lps, 0, (per * world - nb) * lps * 8, NULL));
-  CK(mfh_ct_to_lanes(ctx, partial, nb * 5, lanes));
-  if (c->t) comm_reduce_scatter_u64(c, lanes, own, per * lps);
-  else HK(hipMemcpyAsync(own, lanes, per * lps * 8, hipMemcpyDeviceToDevice, NULL));
-
-  /* 5. carries + modq, then b_w += delta ct_t and the smudging of the own statements (src/snark.c:143-145,185-189) */
-  if (nown) {
-    uint64_t *proofs = scratch(c, 6, nown * 5 * CTL * 8);
-    CK(mfh_ct_from_lanes(ctx, own, nown * 5, proofs));
-    CK(mfh_prove_batch_finish(ctx, d_crs, (uint32_t)nown, delta, mag, MAGLEN, sign, proofs));
-    mfuoco_gpu_proofs_to_host(pis + first, proofs, nown);
+  /* device buffers, all of them before anything is queued (growing one frees it, and hipFree waits for the device) */
+  const size_t lps = 5 * LANES_PER_CT, smax = sper * (size_t)world;
+  uint32_t *whv[2], *send[2], *recv[2];
+  uint64_t *partial[2], *lanes[2], *own[2];
+  for (int b = 0; b < 2; b++) {
+    whv[b] = scratch(c, 0 + b, 3 * sper * d * 4);
+    send[b] = scratch(c, 2 + b, 3 * sper * d * 4);
+    recv[b] = scratch(c, 4 + b, smax * 3 * cs * 4);
+    partial[b] = scratch(c, 6 + b, smax * 5 * CTL * 8);
+    lanes[b] = scratch(c, 8 + b, smax * lps * 8);
+    own[b] = scratch(c, 10 + b, sper * lps * 8);
   }
-  HK(hipDeviceSynchronize());
-  if (c == &local)
-    for (int i = 0; i < 8; i++)
-      if (local.buf[i]) hipFree(local.buf[i]);
+  uint64_t *proofs = scratch(c, 12, (nown ? nown : 1) * 5 * CTL * 8);
+
+  /* cnt(q, k): how many statements of rank q's slab stage k holds (own indices k * sper ...); rank 0's is the largest: the slab of the stage's reduce-scatter */
+#define STAGE_CNT(q, k) ({ const size_t nq_ = stmt_lo(nb, (q) + 1, world) - stmt_lo(nb, (q), world), lo_ = (k) * sper; nq_ > lo_ ? (nq_ - lo_ < sper ? nq_ - lo_ : sper) : (size_t)0; })
+  size_t scnt[MAXW], sdsp[MAXW], rcnt[MAXW], rdsp[MAXW];
+  for (size_t it = 0; it < nst + 2; it++) {
+    /* ---- C(it): chain of the own statements of stage `it` (src/snark.c:141-169), operands packed; A(it): the all-to-all */
+    if (it < nst) {
+      const size_t k = it, on = STAGE_CNT(rank, k), olo = k * sper;
+      const int b = (int)(k & 1);
+      size_t pre = 0; /* the own statements' place in stage order */
+      for (int q = 0; q < rank; q++) pre += STAGE_CNT(q, k);
+      if (on) CK(mfh_batch_chain(ctx, d_ssp, (uint32_t)on, bits + (soff[k] + pre) * stride, stride, delta + olo, whv[b], whv[b] + on * d, whv[b] + 2 * on * d));
+      /* rank q gets rows [d q / world, d (q+1) / world) of w | h | v of the own statements, laid out [statement][w | h | v][rows]; this rank receives its rows of the
+       * stage's statements of every rank, in stage order */
+      size_t off = 0, at = 0;
+      for (int q = 0; q < world; q++) {
+        const size_t a = row_lo(d, q, world), w = row_lo(d, q + 1, world) - a, nq = STAGE_CNT(q, k);
+        sdsp[q] = off;
+        scnt[q] = on * 3 * w;
+        if (scnt[q])
+          for (int x = 0; x < 3; x++) /* a strided column slice per polynomial kind: one 2-D device copy */
+            HK(hipMemcpy2DAsync(send[b] + off + (size_t)x * w, 3 * w * 4, whv[b] + (size_t)x * on * d + a, d * 4, w * 4, on, hipMemcpyDeviceToDevice, NULL));
+        off += scnt[q];
+        rdsp[q] = at * 3 * cs;
+        rcnt[q] = nq * 3 * cs;
+        at += nq;
+      }
+      if (c->t) {
+        HK(hipEventRecord(c->ev_sent[b], NULL));
+        HK(hipStreamWaitEvent(cst, c->ev_sent[b], 0));
+        comm_alltoallv_u32(c, send[b], scnt, sdsp, recv[b], rcnt, rdsp, cst);
+        HK(hipEventRecord(c->ev_recv[b], cst));
+      } else HK(hipMemcpyAsync(recv[b], send[b], scnt[0] * 4, hipMemcpyDeviceToDevice, NULL));
+    }
+    /* ---- P(it - 1), L(it - 1): the rank's row shares of the five ciphertexts of the stage's statements (matrix cores; no delta ct_t term, un-smudged), as uint64 lanes
+     * of 56 bits padded to `world` equal slabs; R(it - 1): the reduce-scatter -- the own slab, summed */
+    if (it >= 1 && it - 1 < nst) {
+      const size_t k = it - 1, nk = soff[k + 1] - soff[k], sl = STAGE_CNT(0, k);
+      const int b = (int)(k & 1);
+      if (c->t) HK(hipStreamWaitEvent(NULL, c->ev_recv[b], 0));
+      CK(mfh_prove_batch_partial(ctx, d_crs, (uint32_t)rank, (uint32_t)world, (uint32_t)nk, bits + soff[k] * stride, stride, recv[b], recv[b] + cs, recv[b] + 2 * cs, 3 * cs,
+                                 partial[b]));
+      if (sl * (size_t)world > nk) HK(hipMemsetAsync(lanes[b] + nk * lps, 0, (sl * (size_t)world - nk) * lps * 8, NULL));
+      CK(mfh_ct_to_lanes(ctx, partial[b], nk * 5, lanes[b]));
+      if (c->t) {
+        HK(hipEventRecord(c->ev_lanes[b], NULL));
+        HK(hipStreamWaitEvent(cst, c->ev_lanes[b], 0));
+        comm_reduce_scatter_u64(c, lanes[b], own[b], sl * lps, cst);
+        HK(hipEventRecord(c->ev_own[b], cst));
+      } else HK(hipMemcpyAsync(own[b], lanes[b], sl * lps * 8, hipMemcpyDeviceToDevice, NULL));
+    }
+    /* ---- F(it - 2): carries + modq, then b_w += delta ct_t and the smudging of the own statements (src/snark.c:143-145,185-189) */
+    if (it >= 2) {
+      const size_t k = it - 2, on = STAGE_CNT(rank, k), olo = k * sper;
+      const int b = (int)(k & 1);
+      if (c->t) HK(hipStreamWaitEvent(NULL, c->ev_own[b], 0));
+      if (on) {
+        CK(mfh_ct_from_lanes(ctx, own[b], on * 5, proofs + olo * 5 * CTL));
+        CK(mfh_prove_batch_finish(ctx, d_crs, (uint32_t)on, delta + olo, mag + olo * 5 * MAGLEN, MAGLEN, sign + olo * 5, proofs + olo * 5 * CTL));
+      }
+      HK(hipEventRecord(c->ev_done[k], NULL));
+    }
+  }
+  /* the drain: stage k crosses PCIe and becomes mpz_t's as soon as ITS proofs are final, under the kernels and collectives of the stages behind it */
+  for (size_t k = 0; k < nst; k++) {
+    const size_t on = STAGE_CNT(rank, k), olo = k * sper;
+    if (on) mfuoco_gpu_proofs_to_host_after(pis + first + olo, proofs + olo * 5 * CTL, on, c->ev_done[k]);
+  }
+#undef STAGE_CNT
+  HK(hipStreamSynchronize(NULL));
+  if (c->t) HK(hipStreamSynchronize(cst)); /* (a rank without own statements has waited for nothing so far) */
+  if (c == &local) comm_release(&local);
   explicit_bzero(mag, (nown ? nown : 1) * 5 * MAGLEN); /* smudging terms and deltas are the proofs' zero-knowledge: not left on the heap */
   explicit_bzero(sign, (nown ? nown : 1) * 5);
   explicit_bzero(delta, (nown ? nown : 1) * 4);
-  free(bits); free(mag); free(sign); free(delta);
+  free(bits); free(mag); free(sign); free(delta); free(soff);
 }
 
 /* ---- one proof, rows sharded (dist.py: prove_sharded) ------------------------------------------------------------------------ */
@@ -377,7 +503,5 @@ void mfuoco_prover_sharded(proof_t pi, crs_t crs, ssp_t ssp, mpz_t witness, mfuo
   explicit_bzero(&ent, sizeof ent);
   proof_t *one = (proof_t *)pi;
   mfuoco_gpu_proofs_to_host(one, proof, 1);
-  if (c == &local)
-    for (int i = 0; i < 8; i++)
-      if (local.buf[i]) hipFree(local.buf[i]);
+  if (c == &local) comm_release(&local);
 }

@@ -1,6 +1,7 @@
 /*
  * mfuoco_dist_rehearsal.c -- TEST SCAFFOLDING (see mfuoco_dist_rehearsal.h): the four collectives of mfuoco_transport staged through host shared memory.
- * Every operation: copy the rank's contribution into its mailbox, barrier, read the others' mailboxes, barrier.  Never linked into a product library.
+ * Every operation: wait for the stream it is ordered on, copy the rank's contribution into its mailbox, barrier, read the others' mailboxes (copies on that stream,
+ * waited for), barrier.  The host blocks in every call, so a pipelined caller is correct on it but overlaps nothing.  Never linked into a product library.
  */
 #define _GNU_SOURCE
 #include <errno.h>
@@ -62,34 +63,42 @@ static void barrier(struct rehearsal *r)
   }
 }
 static uint8_t *mailbox(struct rehearsal *r, int q) { return (uint8_t *)r->shm + sizeof(struct shm_hdr) + (size_t)q * r->shm->slot_bytes; }
-static void put(struct rehearsal *r, const void *d_src, size_t bytes)
+static void put(struct rehearsal *r, const void *d_src, size_t bytes, hipStream_t st)
 {
   if (bytes > r->shm->slot_bytes) die("mailbox too small", "raise MFUOCO_REHEARSAL_SLOT_MB");
-  if (bytes) HK(hipMemcpy(mailbox(r, r->rank), d_src, bytes, hipMemcpyDeviceToHost));
+  if (bytes) HK(hipMemcpyAsync(mailbox(r, r->rank), d_src, bytes, hipMemcpyDeviceToHost, st));
+  HK(hipStreamSynchronize(st)); /* (what the caller queued on the stream before the collective has run, and the mailbox is written) */
+}
+static void get(void *d_dst, const void *src, size_t bytes, hipStream_t st)
+{
+  HK(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, st));
+  HK(hipStreamSynchronize(st)); /* (pageable source: it may be reused or freed right after) */
 }
 
 static void reh_alltoallv_u32(void *impl, int rank, int world, const uint32_t *d_send, const size_t *scnt, const size_t *sdsp, uint32_t *d_recv,
-                              const size_t *rcnt, const size_t *rdsp)
+                              const size_t *rcnt, const size_t *rdsp, void *stream)
 {
   struct rehearsal *r = impl;
+  hipStream_t st = stream;
   size_t end = 0;
   for (int q = 0; q < world; q++) {
     r->shm->disp[rank][q] = sdsp[q] * 4;
     r->shm->cnt[rank][q] = scnt[q] * 4;
     if (sdsp[q] + scnt[q] > end) end = sdsp[q] + scnt[q];
   }
-  put(r, d_send, end * 4);
+  put(r, d_send, end * 4, st);
   barrier(r);
   for (int q = 0; q < world; q++) {
     if (r->shm->cnt[q][rank] != rcnt[q] * 4) die("all-to-all", "send and receive counts disagree");
-    if (rcnt[q]) HK(hipMemcpy(d_recv + rdsp[q], mailbox(r, q) + r->shm->disp[q][rank], rcnt[q] * 4, hipMemcpyHostToDevice));
+    if (rcnt[q]) get(d_recv + rdsp[q], mailbox(r, q) + r->shm->disp[q][rank], rcnt[q] * 4, st);
   }
   barrier(r);
 }
-static void reh_reduce_scatter_u64(void *impl, int rank, int world, const uint64_t *d_send, uint64_t *d_recv, size_t n)
+static void reh_reduce_scatter_u64(void *impl, int rank, int world, const uint64_t *d_send, uint64_t *d_recv, size_t n, void *stream)
 {
   struct rehearsal *r = impl;
-  put(r, d_send, n * world * 8);
+  hipStream_t st = stream;
+  put(r, d_send, n * world * 8, st);
   barrier(r);
   uint64_t *acc = calloc(n ? n : 1, 8);
   if (!acc) die("out of host memory", NULL);
@@ -97,15 +106,16 @@ static void reh_reduce_scatter_u64(void *impl, int rank, int world, const uint64
     const uint64_t *src = (const uint64_t *)mailbox(r, q) + (size_t)rank * n;
     for (size_t i = 0; i < n; i++) acc[i] += src[i];
   }
-  if (n) HK(hipMemcpy(d_recv, acc, n * 8, hipMemcpyHostToDevice));
+  if (n) get(d_recv, acc, n * 8, st);
   free(acc);
   barrier(r);
 }
-static void reh_allreduce_u64(void *impl, int rank, int world, uint64_t *d_buf, size_t n)
+static void reh_allreduce_u64(void *impl, int rank, int world, uint64_t *d_buf, size_t n, void *stream)
 {
   (void)rank;
   struct rehearsal *r = impl;
-  put(r, d_buf, n * 8);
+  hipStream_t st = stream;
+  put(r, d_buf, n * 8, st);
   barrier(r);
   uint64_t *acc = calloc(n ? n : 1, 8);
   if (!acc) die("out of host memory", NULL);
@@ -113,17 +123,18 @@ static void reh_allreduce_u64(void *impl, int rank, int world, uint64_t *d_buf, 
     const uint64_t *src = (const uint64_t *)mailbox(r, q);
     for (size_t i = 0; i < n; i++) acc[i] += src[i];
   }
-  if (n) HK(hipMemcpy(d_buf, acc, n * 8, hipMemcpyHostToDevice));
+  if (n) get(d_buf, acc, n * 8, st);
   free(acc);
   barrier(r);
 }
-static void reh_bcast_bytes(void *impl, int rank, int world, uint8_t *d_buf, size_t n, int root)
+static void reh_bcast_bytes(void *impl, int rank, int world, uint8_t *d_buf, size_t n, int root, void *stream)
 {
   (void)world;
   struct rehearsal *r = impl;
-  if (rank == root) put(r, d_buf, n);
+  hipStream_t st = stream;
+  if (rank == root) put(r, d_buf, n, st);
   barrier(r);
-  if (rank != root) HK(hipMemcpy(d_buf, mailbox(r, root), n, hipMemcpyHostToDevice));
+  if (rank != root) get(d_buf, mailbox(r, root), n, st);
   barrier(r);
 }
 static void reh_destroy(void *impl)

@@ -14,7 +14,8 @@
  *   row 2D+1 .. 2D+M    v[0..M)        (Enc(beta v_i(s)); the reference allocates M rows and uses M-1)
  *   row 2D+M+1, 2D+M+2  trailer: the 40-byte public seed (rseed_t), then zeros
  *
- * so a mapped image's first (2D+M) rows can be copied to the GPU in one piece.  Nothing here touches the GPU.
+ * so a mapped image's first (2D+M) rows can be copied to the GPU in one piece.  Nothing here touches the GPU, with one optional hook: when this file is part of
+ * libmfuoco_gpu (where mfuoco_gpu_prefetch_crs exists) a CRS mapped read-only is handed to it, so that its expansion is under way before the first prover().
  * All integers inside rows are the little-endian ct_export bytes (src/lwe.c:36-43); SSP slots are little-endian u64.
  */
 #define _GNU_SOURCE
@@ -28,6 +29,9 @@
 #include <unistd.h>
 
 #include "mangiafuoco_api.h"
+
+/* (weak: absent when this file is compiled on its own, e.g. by the CPU tests) */
+extern void mfuoco_gpu_prefetch_crs(crs_t crs) __attribute__((weak));
 
 #define ROW_T (2 * (size_t)GAMMA_D)
 #define ROW_V (ROW_T + 1)
@@ -100,6 +104,7 @@ int mfuoco_crs_map(struct crs *crs, const char *path, int writable)
   crs->as = (uint8_t(*)[CT_BYTES])(m + (size_t)GAMMA_D * CT_BYTES);
   crs->t = m + ROW_T * CT_BYTES;
   crs->v = (uint8_t(*)[CT_BYTES])(m + ROW_V * CT_BYTES);
+  if (!writable && mfuoco_gpu_prefetch_crs) mfuoco_gpu_prefetch_crs(crs); /* (a writable mapping is about to be filled by setup(), which writes the image itself) */
   return 0;
 }
 

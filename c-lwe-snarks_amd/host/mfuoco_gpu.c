@@ -73,7 +73,9 @@ static struct {
   uint32_t img_rank, img_world;
   uint8_t img_seed[40];
   uint64_t img_digest[2];
-  /* ... and the single-proof form (mfh_crs_expand: limb planes, streamed by k_mac_resident), kept from the second prover() under one CRS on */
+  /* ... and the single-proof form (mfh_crs_expand: limb planes, streamed by k_mac_resident): written by setup() as a by-product of its encryptions and by
+   * mfuoco_gpu_prefetch_crs() (what mfuoco_crs_map calls), so that the FIRST prover() under such a CRS streams it; for a CRS that reached the shim by neither way, kept
+   * from the second prover() under it on */
   void *d_rows;
   size_t rows_bytes;
   bool rows_valid;
@@ -82,6 +84,7 @@ static struct {
   bool seen;
   uint64_t staged_digest[2]; /* of the compressed CRS as last staged (mfuoco_gpu_stage_crs) */
   bool staged_digest_valid;
+  int last_prover_path;      /* what the last prover() ran on: 0 regenerated keystream, 1 the resident rows (mfuoco_gpu_last_prover_path) */
 } G = { .device = -1, .resident_crs = -1 };
 
 static void die(const char *what)
@@ -886,13 +889,19 @@ static void ssp_resident(ssp_t ssp)
  * on first launch), the NTT tables of the polynomial step -- is paid here, by ONE proof of the all-zero witness with zero randomness over the CRS and SSP setup() has
  * just put on the device, its result discarded: public inputs only.  src/benchmark_snark.c:70-74 times the first prover() after setup(); without this it measured
  * 22 ms for 9.9 ms of GPU work.  $MFUOCO_GPU_WARM=0 skips it. */
-static void shim_warm_prover(void)
+static void shim_warm_prover(const void *rows)
 {
   if (!shim_warm_on()) return;
   static const uint8_t zero_bits[(GAMMA_M + 7) / 8 + 8], zero_mag[5 * (GAMMA_LOG_SMUDGING / 8)], zero_sign[5];
-  CK(mfh_prove(G.ctx, G.d_crs, G.d_ssp, zero_bits, 0, zero_mag, GAMMA_LOG_SMUDGING / 8, zero_sign, G.d_proof));
+  /* (over the row image setup() has just written when there is one: the path the first prover() will take) */
+  if (rows) CK(mfh_crs_set_resident(G.ctx, rows));
+  int rc = mfh_prove(G.ctx, G.d_crs, G.d_ssp, zero_bits, 0, zero_mag, GAMMA_LOG_SMUDGING / 8, zero_sign, G.d_proof);
+  if (rows) CK(mfh_crs_set_resident(G.ctx, NULL));
+  if (rc != MFH_OK) die("mfh_prove (warm-up)");
   CK(mfh_sync(G.ctx));
 }
+static const void *rows_image_build(const uint8_t *d_crs, const uint64_t dg[2]);
+static bool resident_on(void);
 
 static void *setup_ssp_thread(void *ssp)
 {
@@ -942,10 +951,21 @@ void setup(crs_t crs, vrs_t vrs, ssp_t ssp)
   HK(hipMemcpy(crs->t, G.d_crs + 2 * CT_BYTES * GAMMA_D, CT_BYTES, hipMemcpyDeviceToHost));
   HK(hipMemcpy(crs->v, G.d_crs + (2 * GAMMA_D + 1) * CT_BYTES, CT_BYTES * (GAMMA_M - 1), hipMemcpyDeviceToHost));
   const double t_crs = tnow();
-  shim_warm_prover();
+  /* "... writing the expanded rows to HBM as a by-product, so the prover starts with a materialised CRS".  The encryptions above regenerated every
+   * a-vector of the CRS (src/snark.c:75-110); the same rows are written out here in the layout prover() streams (mfh_crs_expand: AES on the CU once more, 12 ms, in place
+   * of most of the warm-up proof's 10), registered under (seed, digest of the compressed CRS): the FIRST prover() under this CRS finds them.  Not when the image does
+   * not fit beside the call's scratch, nor with $MFUOCO_GPU_RESIDENT_CRS=0. */
+  const void *img = NULL;
+  if (resident_on()) {
+    CK(mfh_digest128(G.ctx, G.d_crs, rows * CT_BYTES, G.staged_digest));
+    G.staged_digest_valid = true;
+    img = rows_image_build(G.d_crs, G.staged_digest);
+  }
+  const double t_img = tnow();
+  shim_warm_prover(img);
   if (tracing())
-    fprintf(stderr, "setup(): key + error draws %.2f ms (the SSP upload runs beside them), rest of the SSP upload (%.2f GB) + quotient precomputation %.2f, uploads + encryptions + CRS download %.2f, prover warm-up %.2f\n",
-            t_drawn - t_in, SSP_SIZE / 1e9, t_ssp - t_drawn, t_crs - t_ssp, tnow() - t_crs);
+    fprintf(stderr, "setup(): key + error draws %.2f ms (the SSP upload runs beside them), rest of the SSP upload (%.2f GB) + quotient precomputation %.2f, uploads + encryptions + CRS download %.2f, row image for prover() %s (queued in %.2f), prover warm-up %.2f (with the image's expansion)\n",
+            t_drawn - t_in, SSP_SIZE / 1e9, t_ssp - t_drawn, t_crs - t_ssp, img ? "written" : "not kept", t_img - t_crs, tnow() - t_img);
 }
 
 /* ---- pieces shared with the multi-GPU entry points (host/mfuoco_dist.c, libmfuoco_gpu_dist): not part of the reference interface ---- */
@@ -1071,12 +1091,19 @@ static void drain_init(void)
 /* count proofs (5 ciphertexts each, struct proof order) from device limbs into initialised proof_t's.  batch != 0: d_proofs is being written by the mfh_prove_batch call
  * just queued, super-group by super-group; a slab's copy waits (on the device, mfh_prove_batch_stream_wait) for its super-group only, so super-group k crosses PCIe and
  * becomes mpz_t's under the kernels of k + 1.  batch == 0: d_proofs is final once the work queued on the shim's (default) stream so far has run. */
-static void proofs_drain(proof_t *pis, const uint64_t *d_proofs, size_t count, int batch)
+static void proofs_drain(proof_t *pis, const uint64_t *d_proofs, size_t count, int batch, hipEvent_t after)
 {
   if (count * 5 * CTL * 8 <= PIN_BYTES) { /* up to five proofs (706 KB each): the small pinned scratch, no pipeline (and none of its 90 MB of page-locking on a first prover() call) */
     if (batch) CK(mfh_sync(G.ctx));
-    HK(hipMemcpyAsync(G.pin, d_proofs, count * 5 * CTL * 8, hipMemcpyDeviceToHost, NULL));
-    HK(hipStreamSynchronize(NULL));
+    if (after) { /* d_proofs is final once `after` has happened (the caller queued more work behind it: not waited for) */
+      drain_init();
+      HK(hipStreamWaitEvent(DR.stream, after, 0));
+      HK(hipMemcpyAsync(G.pin, d_proofs, count * 5 * CTL * 8, hipMemcpyDeviceToHost, DR.stream));
+      HK(hipStreamSynchronize(DR.stream));
+    } else {
+      HK(hipMemcpyAsync(G.pin, d_proofs, count * 5 * CTL * 8, hipMemcpyDeviceToHost, NULL));
+      HK(hipStreamSynchronize(NULL));
+    }
     struct conv_arg a = { pis, NULL, (uint64_t *)G.pin };
     proofs_from_limbs(0, count * 5 * (size_t)(GAMMA_N + 1), &a);
     return;
@@ -1084,7 +1111,8 @@ static void proofs_drain(proof_t *pis, const uint64_t *d_proofs, size_t count, i
   drain_init();
   const size_t sg = batch ? mfh_prove_batch_supergroup(G.ctx) : 0;
   if (!sg) batch = 0; /* (a call that hands out no per-super-group completion is drained like any finished buffer) */
-  if (!batch) { /* order the copies after what the default stream holds */
+  if (!batch && after) HK(hipStreamWaitEvent(DR.stream, after, 0)); /* order the copies after the caller's event ... */
+  else if (!batch) {                                                /* ... or after what the default stream holds */
     HK(hipEventRecord(DR.ev_src, NULL));
     HK(hipStreamWaitEvent(DR.stream, DR.ev_src, 0));
   }
@@ -1115,7 +1143,13 @@ static void proofs_drain(proof_t *pis, const uint64_t *d_proofs, size_t count, i
 void mfuoco_gpu_proofs_to_host(proof_t *pis, const uint64_t *d_proofs, size_t count)
 {
   KEEP_ERRNO;
-  proofs_drain(pis, d_proofs, count, 0);
+  proofs_drain(pis, d_proofs, count, 0, NULL);
+}
+/* the same once `hip_event` (a hipEvent_t recorded by the caller behind the last writer of d_proofs) has happened: later work of the caller's streams is not waited for */
+void mfuoco_gpu_proofs_to_host_after(proof_t *pis, const uint64_t *d_proofs, size_t count, void *hip_event)
+{
+  KEEP_ERRNO;
+  proofs_drain(pis, d_proofs, count, 0, (hipEvent_t)hip_event);
 }
 
 /* ---- the expanded CRS kept across prover calls (the materialised-CRS regime behind the reference's types) -------------------------------
@@ -1182,8 +1216,35 @@ static void image_resident_mm(const uint8_t *d_crs, uint32_t rank, uint32_t worl
   G.img_digest[0] = dg[0];
   G.img_digest[1] = dg[1];
 }
-void mfuoco_gpu_image_resident_share(const uint8_t *d_crs, uint32_t rank, uint32_t world, int expand) { image_resident_mm(d_crs, rank, world, expand != 0); }
-/* single-proof image (mfh_prove): expanded when prover() meets the same (seed, CRS) a second time; returns the image to register, or NULL */
+/* returns 1 when an image of the rank's shares is registered with the context afterwards (the row work streams it), 0 when the row work will regenerate or expand per call */
+int mfuoco_gpu_image_resident_share(const uint8_t *d_crs, uint32_t rank, uint32_t world, int expand)
+{
+  image_resident_mm(d_crs, rank, world, expand != 0);
+  return G.img_registered ? 1 : 0;
+}
+/* single-proof image (mfh_prove): the rows of the CRS staged at d_crs (digest dg) in k_mac_resident's layout, registered under (seed, digest).  The expansion is
+ * QUEUED on the shim's stream, not waited for: whatever is queued next finds the rows written.  NULL when the image is not kept (does not fit). */
+static const void *rows_image_build(const uint8_t *d_crs, const uint64_t dg[2])
+{
+  G.rows_valid = false;
+  const size_t rows = 2 * (size_t)GAMMA_D + GAMMA_M, need = rows * mfh_resident_row_bytes(G.ctx);
+  if (!fits_device(need, G.rows_bytes)) return NULL;
+  if (need > G.rows_bytes) {
+    if (G.d_rows) HK(hipFree(G.d_rows));
+    G.d_rows = NULL;
+    G.rows_bytes = 0;
+    if (hipMalloc(&G.d_rows, need) != hipSuccess) { (void)hipGetLastError(); G.d_rows = NULL; return NULL; }
+    G.rows_bytes = need;
+  }
+  CK(mfh_crs_expand(G.ctx, 0, rows, d_crs, G.d_rows));
+  G.rows_valid = true;
+  memcpy(G.rows_seed, G.seed, 40);
+  G.rows_digest[0] = dg[0];
+  G.rows_digest[1] = dg[1];
+  return G.d_rows;
+}
+/* ... looked up by prover(): the image setup() / mfuoco_gpu_prefetch_crs() wrote for this (seed, CRS), else expanded when prover() meets the same (seed, CRS) a
+ * second time; returns the image to register, or NULL */
 static const void *image_resident_rows(const uint8_t *d_crs)
 {
   if (!resident_on() || d_crs != G.d_crs) return NULL;
@@ -1201,23 +1262,31 @@ static const void *image_resident_rows(const uint8_t *d_crs)
   memcpy(G.seen_seed, G.seed, 40);
   G.seen_digest[0] = dg[0];
   G.seen_digest[1] = dg[1];
-  if (!again) return NULL; /* first proof under this CRS: regenerate, as the reference does */
-  const size_t rows = 2 * (size_t)GAMMA_D + GAMMA_M, need = rows * mfh_resident_row_bytes(G.ctx);
-  if (!fits_device(need, G.rows_bytes)) return NULL;
-  if (need > G.rows_bytes) {
-    if (G.d_rows) HK(hipFree(G.d_rows));
-    G.d_rows = NULL;
-    G.rows_bytes = 0;
-    if (hipMalloc(&G.d_rows, need) != hipSuccess) { (void)hipGetLastError(); G.d_rows = NULL; return NULL; }
-    G.rows_bytes = need;
-  }
-  CK(mfh_crs_expand(G.ctx, 0, rows, d_crs, G.d_rows));
-  G.rows_valid = true;
-  memcpy(G.rows_seed, G.seed, 40);
-  G.rows_digest[0] = dg[0];
-  G.rows_digest[1] = dg[1];
-  return G.d_rows;
+  if (!again) return NULL; /* first proof under a CRS the caller filled in by hand: regenerate, as the reference does */
+  return rows_image_build(d_crs, dg);
 }
+
+/* A CRS that arrives from disk (mfuoco_crs_map calls this for a read-only mapping; a caller that fills a struct crs by other means may call it too): staged on the
+ * device and its row image queued at once, so that the GPU expands it while the caller maps its SSP and builds its witness, and the first prover() under it streams the
+ * rows.  Returns without waiting for the expansion.  Nothing happens with $MFUOCO_GPU_RESIDENT_CRS=0 / $MFUOCO_GPU_PREFETCH=0 or when the image does not fit. */
+void mfuoco_gpu_prefetch_crs(crs_t crs)
+{
+  KEEP_ERRNO;
+  const char *e = getenv("MFUOCO_GPU_PREFETCH");
+  if ((e && *e && !atoi(e)) || !crs->s || !crs->as || !crs->t || !crs->v) return;
+  if (!G.ctx) { /* a hint, not a compute call: on a host without a GPU (a tool that only inspects CRS files) mapping still works; prover() is what fails loudly there */
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); return; }
+  }
+  gpu();
+  if (!resident_on()) return;
+  const double t_in = tnow();
+  const uint8_t *d_crs = mfuoco_gpu_stage_crs(crs); /* (takes the digest: resident_on() made G.resident_crs 1) */
+  const bool had = G.rows_valid;
+  if (!had) rows_image_build(d_crs, G.staged_digest);
+  if (tracing()) fprintf(stderr, "mfuoco_gpu_prefetch_crs(): staged + %s in %.2f ms of host time\n", had ? "image already there" : G.rows_valid ? "row image queued" : "image not kept", tnow() - t_in);
+}
+int mfuoco_gpu_last_prover_path(void) { return G.last_prover_path; }
 
 void prover(proof_t pi, crs_t crs, ssp_t ssp, mpz_t witness)
 {
@@ -1238,6 +1307,7 @@ void prover(proof_t pi, crs_t crs, ssp_t ssp, mpz_t witness)
   explicit_bzero(mag, sizeof mag);
   explicit_bzero(&delta, sizeof delta);
   if (rc != MFH_OK) die("mfh_prove");
+  G.last_prover_path = rows ? 1 : 0;
   const double t_queued = tnow();
   if (tracing()) CK(mfh_sync(G.ctx));
   const double t_done = tnow();
@@ -1286,7 +1356,7 @@ void mfuoco_prover_batch(proof_t *pis, crs_t crs, ssp_t ssp, mpz_t *witnesses, s
   if (rc != MFH_OK) die("mfh_prove_batch");
   /* the call above only QUEUED the work: super-group k is copied and converted while the GPU runs k + 1 */
   const double t_queued = tnow();
-  proofs_drain(pis, d_out, count, 1);
+  proofs_drain(pis, d_out, count, 1, NULL);
   if (tracing())
     fprintf(stderr, "mfuoco_prover_batch(%zu): stage CRS+SSP %.2f ms, witness bits + entropy %.2f, image %.2f, queue %.2f, drain (copy + mpz_t under the GPU work) %.2f\n", count,
             t_staged - t_in, t_host - t_staged, t_image - t_host, t_queued - t_image, tnow() - t_queued);

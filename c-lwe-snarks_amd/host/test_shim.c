@@ -16,6 +16,33 @@
 
 #define CHECK(cond) do { if (!(cond)) { fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); exit(1); } } while (0)
 
+/* An entropy tape (SURVEY Appendix A's determinism recipe): this program's getrandom() comes before libc's in the lookup order of every object of the process, the shim
+ * included.  Off (the default) it is the system call; between tape_start(seed) and tape_stop() it serves a splitmix64 stream, so that two prover() calls can be given the
+ * same delta and smudging terms. */
+#include <sys/syscall.h>
+static int tape_on;
+static uint64_t tape_state;
+static void tape_start(uint64_t seed) { tape_on = 1; tape_state = seed; }
+static void tape_stop(void) { tape_on = 0; }
+ssize_t getrandom(void *buf, size_t len, unsigned int flags)
+{
+  if (!tape_on) return syscall(SYS_getrandom, buf, len, flags);
+  uint8_t *p = buf;
+  for (size_t i = 0; i < len; i += 8) {
+    uint64_t z = (tape_state += 0x9e3779b97f4a7c15UL);
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9UL;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebUL;
+    z ^= z >> 31;
+    memcpy(p + i, &z, len - i < 8 ? len - i : 8);
+  }
+  return (ssize_t)len;
+}
+static int proofs_equal(proof_t a, proof_t b)
+{
+  for (size_t j = 0; j <= GAMMA_N; j++)
+    if (mpz_cmp(a->h[j], b->h[j]) || mpz_cmp(a->hat_h[j], b->hat_h[j]) || mpz_cmp(a->hat_v[j], b->hat_v[j]) || mpz_cmp(a->v_w[j], b->v_w[j]) || mpz_cmp(a->b_w[j], b->b_w[j])) return 0;
+  return 1;
+}
 
 
 static uint64_t rnd_modp(void) { uint64_t r; getrandom(&r, 8, 0); return r % GAMMA_P; }
@@ -150,6 +177,28 @@ static void t_snark(void)
   setup(crs, vrs, ssp);
   proof_t pi;
   proof_init(pi);
+  { /* setup() leaves the expanded rows behind, so the FIRST prover() under its CRS streams them -- and what it computes is, on one entropy tape, bit for
+     * bit the proof the regenerating path (the reference's ct_import, src/lwe.c:122-126) computes */
+    proof_t pr;
+    proof_init(pr);
+    tape_start(0x5eed0001);
+    prover(pi, crs, ssp, witness);
+    tape_stop();
+    CHECK(mfuoco_gpu_last_prover_path() == 1);
+    CHECK(verifier(ssp, vrs, pi));
+    mfuoco_gpu_set_resident_crs(0); /* images freed: the next call regenerates */
+    tape_start(0x5eed0001);
+    prover(pr, crs, ssp, witness);
+    tape_stop();
+    CHECK(mfuoco_gpu_last_prover_path() == 0);
+    CHECK(proofs_equal(pi, pr));
+    tape_start(0x5eed0002); /* (and the tape matters: other smudging terms, another proof) */
+    prover(pr, crs, ssp, witness);
+    tape_stop();
+    CHECK(!proofs_equal(pi, pr) && verifier(ssp, vrs, pr));
+    mfuoco_gpu_set_resident_crs(1);
+    proof_clear(pr);
+  }
   { /* three statements in one batch: the witness twice (accepted) and a corrupted witness (rejected) */
     proof_t pb[3];
     mpz_t wit[3];
@@ -286,6 +335,7 @@ static void t_files(void)
   CHECK(stat(path[1], &st) == 0 && (size_t)st.st_size == SSP_SIZE);
 
   crs_t crs2;
+  mfuoco_gpu_invalidate(); /* (forget what setup() left on the device: the mapping below must bring its own row image) */
   CHECK(mfuoco_crs_map(crs2, path[0], 0) == 0);
   CHECK(!memcmp(crs2->seed, seed, sizeof seed));
   CHECK((uint8_t *)crs2->as == (uint8_t *)crs2->s + CT_BYTES * GAMMA_D && crs2->t == (uint8_t *)crs2->s + 2 * CT_BYTES * GAMMA_D &&
@@ -293,7 +343,16 @@ static void t_files(void)
   proof_t pi, pj;
   proof_init(pi);
   proof_init(pj);
-  prover(pi, crs2, ssp, witness);
+  tape_start(0x5eed0003);
+  prover(pi, crs2, ssp, witness); /* the first prover() under a mapped CRS streams the rows mfuoco_crs_map() had expanded in the background ... */
+  tape_stop();
+  CHECK(mfuoco_gpu_last_prover_path() == 1);
+  mfuoco_gpu_set_resident_crs(0);
+  tape_start(0x5eed0003);
+  prover(pj, crs2, ssp, witness); /* ... and computes what the regenerating path computes */
+  tape_stop();
+  CHECK(mfuoco_gpu_last_prover_path() == 0 && proofs_equal(pi, pj));
+  mfuoco_gpu_set_resident_crs(1);
   CHECK(mfuoco_proof_save(path[2], pi) == 0);
   CHECK(mfuoco_proof_load(pj, path[2]) == 0);
   for (size_t j = 0; j <= GAMMA_N; j++) CHECK(!mpz_cmp(pi->h[j], pj->h[j]) && !mpz_cmp(pi->b_w[j], pj->b_w[j]));

@@ -7,16 +7,16 @@ relations and acceptance); the benchmarks must run to completion and print the r
 boundary, not an oracle (their <flint/nmod_poly.h> is the shim's layout-compatible header, since FLINT is not in the image)."""
 import os
 import re
+import struct
 import subprocess
 
 import pytest
 
-pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DRV = os.path.join(ROOT, "oracle", "_ref", "drivers")
 
 
-def _run(prog, timeout, cwd):
+def _run(prog, timeout, cwd, env=None):
     exe = os.path.join(DRV, prog)
     if not os.path.exists(exe):
         # with the shim built, a driver that did not travel is a hole in the boundary evidence, not a reason to pass quietly: fail.  (Only a tree without the shim --
@@ -25,27 +25,64 @@ def _run(prog, timeout, cwd):
             pytest.fail(f"oracle/_ref/drivers/{prog} is missing although libmfuoco_gpu.so was built: run `make -C oracle drivers` in the build container (it has the "
                         "reference sources) before sending the tree to the GPU box")
         pytest.skip(f"oracle/_ref/drivers/{prog} was not built and neither was the shim (no gmp.h at build time)")
-    return subprocess.run([exe], capture_output=True, text=True, timeout=timeout, cwd=cwd)
+    return subprocess.run([exe], capture_output=True, text=True, timeout=timeout, cwd=cwd, env=env)
 
 
+# Determinism (SURVEY Appendix A's recipe): the reference's test programs draw every key, seed, message and error from getrandom(2); tests/getrandom_tape.c, preloaded
+# into the CHILD only, serves the splitmix64 stream of $MF_TAPE_SEED instead, so a run is a function of its seed.  The seeds are a fixed list.
+TAPE_SEEDS = (1, 2, 3, 4)
+_M64 = (1 << 64) - 1
+
+
+def tape_bytes(seed, n):
+    """the first n bytes tests/getrandom_tape.c serves for $MF_TAPE_SEED = seed when they are drawn in ONE call"""
+    out, st = b"", seed
+    while len(out) < n:
+        st = (st + 0x9E3779B97F4A7C15) & _M64
+        z = st
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+        z ^= z >> 31
+        out += struct.pack("<Q", z)
+    return out[:n]
+
+
+@pytest.fixture(scope="module")
+def tape_lib(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("tape") / "libgetrandom_tape.so")
+    subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-o", out, os.path.join(ROOT, "tests", "getrandom_tape.c")])
+    return out
+
+
+def test_tape_seeds_satisfy_the_one_in_256_assertions_of_test_aes(oracle):
+    """src/test_aes.c:15-24 draws a 32-byte key, then asserts `buf[0] != 0` and `buf[0] != buf2[0]` on the first bytes of keystream blocks 0 and 1 under nonce
+    0xfffffffffffff: each holds with probability 255/256 under ANY correct AES.  For the fixed seeds the checker says beforehand that both hold (161/156, 46/114, 178/141,
+    122/211), so a failing test_aes under one of them is a defect of the library's first keystream bytes, never chance."""
+    for seed in TAPE_SEEDS:
+        ks = oracle.keystream(struct.pack("<Q", 0xFFFFFFFFFFFFF) + tape_bytes(seed, 32), 0, 32)
+        assert ks[0] != 0 and ks[0] != ks[16], seed
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("prog", ["test_aes", "test_entropy", "test_ssp", "test_lwe", "test_snark"])
-def test_reference_test_program_passes_against_the_shim(prog, tmp_path):
-    """assert() is live in these builds (src/tests.h refuses NDEBUG): exit code 0 = every assertion of the reference's test held on the GPU library"""
-    # fresh OS entropy every run: four random instances per program (test_entropy's ~10^5 small stream reads took 68 s when each was a GPU round trip; the shim now
-    # serves them from a 64 KiB host window of the stream: under 2 s)
-    chance = 0
-    for attempt in range(4 if prog != "test_ssp" else 1):
-        r = _run(prog, 600, tmp_path)
-        if prog == "test_aes" and r.returncode != 0 and re.search(r"test_aes\.c:(20|24): main: Assertion", r.stderr):
-            # src/test_aes.c:20,24 assert `buf[0] != 0` and `buf[0] != buf2[0]` on the first bytes of two keystream blocks under a RANDOM key: each fails with
-            # probability 2^-8 against any correct AES, the reference's own included (seen once in round 5).  One such miss in four runs is chance, two are not.
-            chance += 1
-            continue
-        assert r.returncode == 0, (prog, attempt, r.stdout[-2000:], r.stderr[-2000:])
+def test_reference_test_program_passes_against_the_shim(prog, tmp_path, tape_lib):
+    """assert() is live in these builds (src/tests.h refuses NDEBUG): exit code 0 = every assertion of the reference's test held on the GPU library.  Four runs on the
+    fixed entropy tapes -- identical from run to run by construction, no tolerance --, then ONE run on the OS's entropy."""
+    for seed in TAPE_SEEDS if prog != "test_ssp" else TAPE_SEEDS[:1]:
+        env = dict(os.environ, LD_PRELOAD=tape_lib, MF_TAPE_SEED=str(seed))
+        r = _run(prog, 600, tmp_path, env)
+        assert r.returncode == 0, (prog, seed, r.stdout[-2000:], r.stderr[-2000:])
         assert "Assertion" not in r.stderr
-    assert chance <= 1, "src/test_aes.c's one-in-256 assertions failed more than once in four runs"
+    # fresh OS entropy (test_entropy's ~10^5 small stream reads took 68 s when each was a GPU round trip; the shim serves them from a 64 KiB host window of the stream:
+    # under 2 s).  The only failure let through is the reference's own 2^-8 event of src/test_aes.c:20,24 under a random key -- the tapes above cover those two lines
+    # deterministically.
+    r = _run(prog, 600, tmp_path)
+    if not (prog == "test_aes" and r.returncode != 0 and re.search(r"test_aes\.c:(20|24): main: Assertion", r.stderr)):
+        assert r.returncode == 0, (prog, "os entropy", r.stdout[-2000:], r.stderr[-2000:])
+        assert "Assertion" not in r.stderr
 
 
+@pytest.mark.gpu
 @pytest.mark.parametrize("prog,labels", [("benchmark_lwe", ("encryption", "decryption")), ("benchmark_eval", ()), ("benchmark_snark", ("setup", "prover", "verifier"))])
 def test_reference_benchmark_program_runs_against_the_shim(prog, labels, tmp_path):
     """the reference's benchmark drivers at the NDEBUG default size (D = 2^15, M = 21845): they run to completion (benchmark_snark asserts nothing under NDEBUG
@@ -57,10 +94,10 @@ def test_reference_benchmark_program_runs_against_the_shim(prog, labels, tmp_pat
         assert re.search(rf"{lab}\s+[0-9.]+", out), (prog, lab, out[-1500:])
     assert re.search(r"[0-9]+\.[0-9]+", out), out[-500:]
     if prog == "benchmark_snark":
-        # what src/benchmark_snark.c:70-74 times: the FIRST prover() after setup().  9.9 ms of GPU work plus staging and the mpz_t conversion; every allocation, code-object
-        # load and table the prover needs is paid by setup() (the shim's warm-up proof), so nothing else belongs in this number (it was 22 ms before)
+        # what src/benchmark_snark.c:70-74 times: the FIRST prover() after setup().  setup() leaves the expanded rows of the CRS in HBM (a by-product of its
+        # encryptions), so this call streams them: 2 ms of GPU work plus staging the compressed CRS and the mpz_t conversion (round 5, regenerating: 11.1 ms; round 4: 22)
         prover_s = float(re.search(r"prover\s+([0-9.]+)", out).group(1))
-        assert prover_s < 0.02, out[-1500:]
+        assert prover_s < 0.006, out[-1500:]
     if prog == "benchmark_eval":
         # the one file the reference itself writes (src/benchmark_eval.c:44-66: D rows of ct_export bytes, `./coeffs`): written here by the reference's own code
         # through the shim's regev_encrypt / ct_export, and it is the image the repo's readers take (files.py / mfuoco_rows_map: SURVEY 8 f3)
