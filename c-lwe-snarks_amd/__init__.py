@@ -85,12 +85,12 @@ class _CParams(ctypes.Structure):
 _lib = None
 
 EXPORTS = [
-    "mfh_ctx_create", "mfh_ctx_destroy", "mfh_set_stream", "mfh_sync", "mfh_last_error", "mfh_set_seed",
+    "mfh_ctx_create", "mfh_ctx_destroy", "mfh_set_stream", "mfh_sync", "mfh_scrub_staging", "mfh_last_error", "mfh_set_seed",
     "mfh_keystream", "mfh_sample_rows", "mfh_ct_add", "mfh_ct_mul_ui", "mfh_ct_addmul_ui", "mfh_eval_rows",
     "mfh_encrypt_rows", "mfh_decrypt", "mfh_ct_smudge", "mfh_ssp_upload", "mfh_witness_poly", "mfh_version",
     "mfh_workspace_bytes", "mfh_last_kernel_ms", "mfh_set_timing", "mfh_set_overlap", "mfh_eval_rows_multi", "mfh_prove_batch", "mfh_crs_mm_image_bytes", "mfh_crs_expand_mm", "mfh_crs_set_resident_mm", "mfh_witness_poly_multi", "mfh_witness_poly_mm", "mfh_poly_h_multi", "mfh_poly_mul", "mfh_poly_add", "mfh_poly_prepare_t",
     "mfh_ssp_prepare", "mfh_poly_h", "mfh_setup_messages", "mfh_setup", "mfh_prove",
-    "mfh_prove_partial", "mfh_prove_finish", "mfh_ct_to_lanes", "mfh_ct_from_lanes", "mfh_lanes_per_value", "mfh_digest128", "mfh_timing_drain", "mfh_timing_busy_ms", "mfh_timing_work_rows", "mfh_set_batch_image", "mfh_set_batch_slabs", "mfh_set_expand_path", "mfh_set_encrypt_path", "mfh_set_batch_launch", "mfh_set_batch_bw", "mfh_set_mm_chunk_rows", "mfh_set_mm_stream", "mfh_add_dotp", "mfh_set_encrypt_chunks", "mfh_set_witness_per", "mfh_set_eval_path", "mfh_set_decrypt_path", "mfh_decrypt_rows",
+    "mfh_prove_partial", "mfh_prove_finish", "mfh_ct_to_lanes", "mfh_ct_from_lanes", "mfh_lanes_per_value", "mfh_digest128", "mfh_timing_drain", "mfh_timing_busy_ms", "mfh_timing_work_rows", "mfh_set_batch_image", "mfh_set_batch_slabs", "mfh_set_expand_path", "mfh_set_encrypt_path", "mfh_set_batch_launch", "mfh_set_batch_bw", "mfh_set_mm_chunk_rows", "mfh_set_mm_pack", "mfh_set_mm_stream", "mfh_add_dotp", "mfh_set_encrypt_chunks", "mfh_set_witness_per", "mfh_set_eval_path", "mfh_set_decrypt_path", "mfh_decrypt_rows",
     "mfh_crs_mm_share_bytes", "mfh_crs_expand_mm_share", "mfh_crs_set_resident_mm_share", "mfh_batch_chain", "mfh_batch_witness_cols", "mfh_batch_chain_from_w", "mfh_witness_poly_mm_cols", "mfh_prove_batch_partial", "mfh_prove_batch_finish",
     "mfh_resident_row_bytes", "mfh_crs_expand", "mfh_eval_rows_resident", "mfh_crs_set_resident",
     "mfh_witness_lanes", "mfh_witness_from_lanes", "mfh_prove_partial_w", "mfh_verify",
@@ -115,6 +115,7 @@ def load_library():
         "mfh_ctx_destroy": (None, [vp]),
         "mfh_set_stream": (i32, [vp, vp]),
         "mfh_sync": (i32, [vp]),
+        "mfh_scrub_staging": (i32, [vp]),
         "mfh_last_error": (ctypes.c_char_p, [vp]),
         "mfh_set_seed": (i32, [vp, ctypes.c_char_p]),
         "mfh_keystream": (i32, [vp, u64, vp, sz]),
@@ -180,6 +181,7 @@ def load_library():
         "mfh_timing_work_rows": (u64, [vp]),
         "mfh_set_batch_image": (i32, [vp, i32]),
         "mfh_set_mm_chunk_rows": (i32, [vp, u32]),
+        "mfh_set_mm_pack": (i32, [vp, i32]),
         "mfh_set_mm_stream": (i32, [vp, i32, i32, i32, u32]),
         "mfh_set_batch_launch": (i32, [vp, u32, i32]),
         "mfh_set_batch_bw": (i32, [vp, i32]),
@@ -322,6 +324,10 @@ class Context:
     def set_mm_width(self, per_xcd=32, early_chain=False):
         """workgroups per XCD of the persistent S / AS launch (32 = every CU); early_chain: chain / epilogues queued beside the streaming launches"""
         self._chk(self.lib.mfh_set_mm_width(self._h, int(per_xcd), 1 if early_chain else 0))
+
+    def set_mm_pack(self, on=True):
+        """streaming kernels hand their partial products to the epilogue recombined (default) or as int32 (rounds 1 - 5): same results"""
+        self._chk(self.lib.mfh_set_mm_pack(self._h, 1 if on else 0))
 
     def set_mm_chunk_rows(self, rows=0):
         """rows per row chunk of the matrix-core launches (<= 131071; 0 = default): smaller values force several chunks"""

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <stdint.h>
+#include <string.h>
 
 #include <string>
 #include <vector>
@@ -28,6 +29,7 @@ struct PinBuf {
   size_t cap = 0;
   hipEvent_t ev = nullptr;
   bool pending = false;
+  size_t used = 0;  // bytes the last user asked for: what pin_scrub zeroes
 };
 
 struct mfh_ctx {
@@ -108,6 +110,7 @@ struct mfh_ctx {
   size_t early_ws_half = 0;        // early chain: distance of the two halves of ws3 = the scratch of the call's first (largest) super-group
   bool batch_early_chain = false;  // mfh_prove_batch: chain of super-group k + 1 and epilogue of k queued BESIDE the streaming launch of k / k + 1 (for the CUs a narrower grid leaves free)
   uint32_t *mm_sync = nullptr;  // 8 x 32 counters of the persistent grid's rendezvous
+  bool mm_pack = true;  // the streaming kernels hand their partial products to the epilogue recombined (evalmm.hip: mms_store_packed); mfh_set_mm_pack
   uint32_t mm_chunk_rows = 131071;  // rows per row chunk of the matrix-core launches (int32 accumulators: |A'C'| <= 2^14 per row)
   int expand_path = 0;     // mfh_crs_expand_mm*: 0 = k_expand_mm (lane = row, MFMA transposition, no LDS tile), 1 = k_evalmm16<MODE 1> (LDS tile + byte gathers)
   int enc_path = 0;        // mfh_encrypt_rows: 0 = pick by batch size, 1 = VALU kernel (k_encrypt), 2 = matrix-core kernel (k_encrypt_mm)
@@ -125,6 +128,7 @@ struct mfh_ctx {
   // super-group k's copy to have RUN (with one buffer mfh_prove_batch blocked its caller for half of the call's GPU time)
   PinBuf pin_wring[8];
   uint32_t pin_wnext = 0;
+  hipEvent_t ev_sample = nullptr;  // ... recorded behind the last reader of sample_tmp: the next call (on whatever stream) waits for it before it overwrites the buffer
   void *sample_tmp = nullptr;  // mfh_sample_rows: the rows' raw stream bytes (small requests; kept so that the call neither allocates nor waits)
   size_t sample_bytes = 0;
   void *uploader = nullptr;  // mfh_ssp_upload: per-thread pinned / device staging pairs and streams (mfhip.hip), made on the first large upload
@@ -168,11 +172,22 @@ inline void *pin_acquire(mfh_ctx *c, PinBuf &b, size_t bytes) {
     if (hipHostMalloc(&b.p, b.cap, hipHostMallocDefault) != hipSuccess) { b.p = nullptr; b.cap = 0; c->err = "hipHostMalloc failed"; return nullptr; }
   }
   if (!b.ev) hipEventCreateWithFlags(&b.ev, hipEventDisableTiming);
+  b.used = bytes;
   return b.p;
 }
 inline void pin_release(mfh_ctx *c, PinBuf &b) {
   hipEventRecord(b.ev, c->stream);
   b.pending = true;
+}
+// zero what the last user staged, once its copy has run (mfh_scrub_staging: witness bits, deltas and smudging terms do not outlive their call in pinned memory)
+inline void pin_scrub(PinBuf &b) {
+  if (b.pending) { hipEventSynchronize(b.ev); b.pending = false; }
+  if (b.p && b.used) {
+    volatile unsigned char *q = (volatile unsigned char *)b.p;  // (volatile: not elided as a dead store)
+    memset((void *)q, 0, b.used);
+    __asm__ __volatile__("" : : "r"(b.p) : "memory");
+  }
+  b.used = 0;
 }
 inline void pin_free(PinBuf &b) {
   if (b.pending) hipEventSynchronize(b.ev);

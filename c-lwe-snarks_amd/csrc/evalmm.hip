@@ -591,9 +591,41 @@ __device__ __forceinline__ void mms_item(uint32_t xcd, uint32_t slot, uint32_t n
     tg = ((blk / nreg) * tpb + i / ngr) * 8 + xcd;
   }
 }
+// ---- packed partial products (round 6) ------------------------------------------------------------------------------------------------------------------
+// A lane of the streaming kernels ends an item with, per row tile and column tile, the int32 sums of FOUR consecutive byte positions (rows 4 g4 + e of the tile) of ONE
+// digit column (16 q + c16).  Written as they are that is 1 KiB per byte position and group -- 2.1 GB per super-group launch, written by the kernel and read back by the
+// epilogue.  The epilogue only ever needs them recombined, so the kernel recombines what it holds (exact integer arithmetic, the corrections stay in the epilogue):
+//   pk = 1 (one-byte coefficient columns: b_w)   T = sum_e acc[e] 2^(8e), |T| < 2^56, one int64 per (byte-position quad, column): half the bytes;
+//   pk = 4 (four-byte coefficient vectors)       additionally over the vector's four digit columns w = c16 & 3, which are the four lanes of a DPP quad:
+//                                                U = sum_w T_w 2^(8w), |U| < 2^80, one 16-byte record {lo, mid, hi, 0} (two's complement, 96 bits) per
+//                                                (byte-position quad, vector), written by the quad's lane 0: a quarter of the bytes.
+// The ones column (sum_i A'[i][m], column 4 nvec) is the w = 0 lane of a quad whose other three columns are zero digits (k_mm_digits*: "every other column is zero"), so
+// its record is T_0 itself.  pk = 0: the int32 layout of the regenerating kernels (k_evalmm16<0>).  mfh_set_mm_pack(ctx, 0) keeps pk = 0 everywhere (A/B, tests).
+__device__ __forceinline__ long long mms_pack_e(const v4i &a) {
+  return (long long)a[0] + ((long long)a[1] << 8) + ((long long)a[2] << 16) + ((long long)a[3] << 24);
+}
+template <int CTRL>
+__device__ __forceinline__ long long mms_quad_bcast(long long t) {  // lane CTRL & 3 of every quad, to the whole quad
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned int)(unsigned long long)t, CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)((unsigned long long)t >> 32), CTRL, 0xf, 0xf, false);
+  return (long long)(((unsigned long long)(unsigned int)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ void mms_store_packed(int *__restrict__ part, uint32_t pk, uint64_t m4 /* byte-position quad, chunks included */, uint32_t ctile, uint32_t c16,
+                                                 const v4i &acc) {
+  const long long T = mms_pack_e(acc);
+  if (pk == 1) {
+    reinterpret_cast<long long *>(part)[m4 * N2 + 16 * ctile + c16] = T;
+    return;
+  }
+  const long long T1 = mms_quad_bcast<0x55>(T), T2 = mms_quad_bcast<0xAA>(T), T3 = mms_quad_bcast<0xFF>(T);
+  if (c16 & 3) return;
+  const __int128 U = (__int128)T + (__int128)T1 * 256 + (__int128)T2 * 65536 + (__int128)T3 * 16777216;
+  const unsigned __int128 u = (unsigned __int128)U;
+  reinterpret_cast<uint4 *>(part)[m4 * (N2 / 4) + 4 * ctile + (c16 >> 2)] = uint4{(uint32_t)u, (uint32_t)(u >> 32), (uint32_t)(u >> 64), 0u};
+}
 __device__ __forceinline__ void mmstream_body(const MmsImages &imgs, uint32_t mtiles, uint32_t KS, uint32_t nrows, uint32_t rows_per_chunk,
                                               const v4i *__restrict__ cdv, int *__restrict__ part, uint32_t grp, uint32_t tg /* tile group = 16 row tiles */,
-                                              uint32_t chunk, uint64_t cd_stride /* v4i */, uint64_t part_stride /* int */) {
+                                              uint32_t chunk, uint64_t cd_stride /* v4i */, uint64_t part_stride /* int */, uint32_t pk /* packed partial products */) {
   __shared__ v4i bfrag[2][RT2 / 64][NQ2][64];  // 2 x 64 KiB
   const uint32_t tid = threadIdx.x, lane = tid & 63;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // uniform: the fragment addresses are a scalar base + the lane's 16 bytes
@@ -707,6 +739,16 @@ __device__ __forceinline__ void mmstream_body(const MmsImages &imgs, uint32_t mt
 #ifdef MMS_ACC_ASM
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // (the hazard recogniser does not see inside the asm MFMAs: their last results must have landed before they are read)
 #endif
+  if (pk) {  // (uniform)
+#pragma unroll
+    for (int t = 0; t < RQ; t++) {
+      if (mt0 + t >= mtiles) continue;
+      const uint64_t m4 = (uint64_t)chunk * (Mtot / 4) + (uint64_t)(mt0 + t) * 4 + g4;
+#pragma unroll
+      for (int q = 0; q < CH; q++) mms_store_packed(part, pk, m4, ch * CH + q, c16, acc[t][q]);
+    }
+    return;
+  }
 #pragma unroll
   for (int t = 0; t < RQ; t++) {
     if (mt0 + t >= mtiles) continue;
@@ -723,14 +765,14 @@ __device__ __forceinline__ void mmstream_body(const MmsImages &imgs, uint32_t mt
 // over the BT+BV image, mfh_eval_rows_multi from a registered image: HBM-bound).
 __global__ __launch_bounds__(SW * 64) void k_mmstream(MmsImages imgs, uint32_t mtiles, uint32_t KS, uint32_t nrows, uint32_t rows_per_chunk,
                                                       const v4i *__restrict__ cdv, int *__restrict__ part, uint32_t ngt, uint32_t ngr, uint32_t map,
-                                                      uint64_t cd_stride, uint64_t part_stride) {
+                                                      uint64_t cd_stride, uint64_t part_stride, uint32_t pk) {
   uint32_t grp, tg;
   mms_item(blockIdx.x & 7, blockIdx.x >> 3, ngt, ngr, map, grp, tg);
-  mmstream_body(imgs, mtiles, KS, nrows, rows_per_chunk, cdv, part, grp, tg, blockIdx.y, cd_stride, part_stride);
+  mmstream_body(imgs, mtiles, KS, nrows, rows_per_chunk, cdv, part, grp, tg, blockIdx.y, cd_stride, part_stride, pk);
 }
 __global__ __launch_bounds__(SW * 64) void k_mmstream1(MmsImages imgs, uint32_t mtiles, uint32_t KS, uint32_t nrows, uint32_t rows_per_chunk,
-                                                       const v4i *__restrict__ cdv, int *__restrict__ part) {
-  mmstream_body(imgs, mtiles, KS, nrows, rows_per_chunk, cdv, part, 0u, blockIdx.x, blockIdx.y, 0, 0);
+                                                       const v4i *__restrict__ cdv, int *__restrict__ part, uint32_t pk) {
+  mmstream_body(imgs, mtiles, KS, nrows, rows_per_chunk, cdv, part, 0u, blockIdx.x, blockIdx.y, 0, 0, pk);
 }
 // The same launch as a PERSISTENT grid: one workgroup per CU (the 128 KiB of LDS allow no second one anyway), workgroup b = CU slot b >> 3 of the XCD
 // b & 7 (blocks are dealt round-robin over the XCDs), looping over the slots cu, cu + 32, cu + 64, ... of its XCD and over the row chunks.  The ngr
@@ -744,7 +786,7 @@ __global__ __launch_bounds__(SW * 64) void k_mmstream1(MmsImages imgs, uint32_t 
 __device__ __forceinline__ void mmstream_persistent(const MmsImages &imgs, uint32_t mtiles, uint32_t KS, uint32_t nrows, uint32_t rows_per_chunk,
                                                     const v4i *__restrict__ cdv, int *__restrict__ part, uint32_t ngt, uint32_t ngr, uint32_t map,
                                                     uint64_t cd_stride, uint64_t part_stride, uint32_t nblk /* 32-slot blocks per XCD */, uint32_t nchunks,
-                                                    uint32_t *__restrict__ sync, uint32_t sync_mode, uint32_t spin_max, uint32_t width) {
+                                                    uint32_t *__restrict__ sync, uint32_t sync_mode, uint32_t spin_max, uint32_t width, uint32_t pk) {
   const uint32_t xcd = blockIdx.x & 7, cu = blockIdx.x >> 3;
   const uint32_t members = sync_mode == 2 ? 32u : (map ? ngr : ngt);
   uint32_t *ctr = sync + xcd * 32 + (sync_mode == 2 ? 0u : cu / members);
@@ -761,22 +803,22 @@ __device__ __forceinline__ void mmstream_persistent(const MmsImages &imgs, uint3
       }
       uint32_t grp, tg;
       mms_item(xcd, slot, ngt, ngr, map, grp, tg);
-      mmstream_body(imgs, mtiles, KS, nrows, rows_per_chunk, cdv, part, grp, tg, chunk, cd_stride, part_stride);
+      mmstream_body(imgs, mtiles, KS, nrows, rows_per_chunk, cdv, part, grp, tg, chunk, cd_stride, part_stride, pk);
     }
 }
 __global__ __launch_bounds__(SW * 64) void k_mmstream_p(MmsImages imgs, uint32_t mtiles, uint32_t KS, uint32_t nrows, uint32_t rows_per_chunk,
                                                         const v4i *__restrict__ cdv, int *__restrict__ part, uint32_t ngt, uint32_t ngr, uint32_t map,
                                                         uint64_t cd_stride, uint64_t part_stride, uint32_t nblk, uint32_t nchunks,
-                                                        uint32_t *__restrict__ sync, uint32_t sync_mode, uint32_t spin_max, uint32_t width) {
-  mmstream_persistent(imgs, mtiles, KS, nrows, rows_per_chunk, cdv, part, ngt, ngr, map, cd_stride, part_stride, nblk, nchunks, sync, sync_mode, spin_max, width);
+                                                        uint32_t *__restrict__ sync, uint32_t sync_mode, uint32_t spin_max, uint32_t width, uint32_t pk) {
+  mmstream_persistent(imgs, mtiles, KS, nrows, rows_per_chunk, cdv, part, ngt, ngr, map, cd_stride, part_stride, nblk, nchunks, sync, sync_mode, spin_max, width, pk);
 }
 // the same grid under another name for the launch that serves b_w of several super-groups (one-byte coefficient columns over the BT+BV image): profiles then show
 // the two launch shapes -- 16 groups x 32768 rows, matrix-core bound; up to 8 groups x 21845 rows -- as two rows
 __global__ __launch_bounds__(SW * 64) void k_mmstream_pb(MmsImages imgs, uint32_t mtiles, uint32_t KS, uint32_t nrows, uint32_t rows_per_chunk,
                                                          const v4i *__restrict__ cdv, int *__restrict__ part, uint32_t ngt, uint32_t ngr, uint32_t map,
                                                          uint64_t cd_stride, uint64_t part_stride, uint32_t nblk, uint32_t nchunks,
-                                                         uint32_t *__restrict__ sync, uint32_t sync_mode, uint32_t spin_max, uint32_t width) {
-  mmstream_persistent(imgs, mtiles, KS, nrows, rows_per_chunk, cdv, part, ngt, ngr, map, cd_stride, part_stride, nblk, nchunks, sync, sync_mode, spin_max, width);
+                                                         uint32_t *__restrict__ sync, uint32_t sync_mode, uint32_t spin_max, uint32_t width, uint32_t pk) {
+  mmstream_persistent(imgs, mtiles, KS, nrows, rows_per_chunk, cdv, part, ngt, ngr, map, cd_stride, part_stride, nblk, nchunks, sync, sync_mode, spin_max, width, pk);
 }
 
 // ---- k_mmstream_w: the same GEMM with ONE wave per SIMD (round 4) -----------------------------------------------------------------------------------
@@ -895,6 +937,7 @@ __device__ __forceinline__ void mmstream_body_w(const MmsImages &imgs, uint32_t 
   __syncthreads();  // (every wave is out of the item's last stage before the next item's prologue rewrites buffer 0)
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the hazard recogniser does not see inside the asm MFMAs: their last results must have landed
   const uint64_t Mtot = (uint64_t)mtiles * 16;
+  // (int32 partial products only: the 256 accumulators live in AccVGPRs, and recombining them in the kernel -- mms_store_packed -- pulls them through the arch VGPRs all at once)
 #pragma unroll
   for (int t = 0; t < WRQ; t++) {
     if (mt0 + t >= mtiles) continue;
@@ -922,7 +965,8 @@ __global__ __launch_bounds__(WSW * 64) void k_mmstream_w(MmsImages imgs, uint32_
 // in LDS; the lq = 0 threads then add, per output word, the pieces of val_l, val_(l-1), val_(l-2) with the running carry (22 | 46 adds
 // on LDS data) and write the element in 16-byte (LL even: 96-byte elements) or 8-byte pieces: the elements of neighbouring threads lie a
 // ciphertext apart, so every store is its own memory transaction.
-template <int ND, int KWM /* 32-bit words of a value that survive modq, at most: sizes the LDS exchange (22 at logq 736, 46 at 1472) */>
+template <int ND, int KWM /* 32-bit words of a value that survive modq, at most: sizes the LDS exchange (22 at logq 736, 46 at 1472) */,
+          bool PK /* packed partial products (the streaming kernels): instantiated apart, so that the int32 form keeps its registers and occupancy */>
 __device__ __forceinline__ void evalmm_finish_body(const int *__restrict__ part, const int64_t *__restrict__ sc, uint32_t nchunks, uint32_t ntiles, uint32_t N,
                                                    uint32_t nvec, uint32_t n, uint32_t nrows, uint32_t ct, uint32_t MBv, uint32_t sby, uint32_t LL,
                                                    const MmIo &io, int accumulate, const int *__restrict__ sa_part, uint32_t sa_col) {
@@ -935,6 +979,35 @@ __device__ __forceinline__ void evalmm_finish_body(const int *__restrict__ part,
     int64_t corr[ND];
 #pragma unroll
     for (int w = 0; w < ND; w++) corr[w] = 128 * sc[ND * v + w] + 16384ll * nrows;
+    // packed partial products (the streaming kernels, mms_store_packed): word l of the value is byte-position quad (tile MBv + jj sby) / 4 + l -- one record per
+    // (quad, vector) [ND = 4: 96-bit U = sum_{k,w} G'[4 l + k][w] 2^(8 (k + w))] or per (quad, column) [ND = 1: T = sum_k G'[4 l + k] 2^(8 k)], and the same of the
+    // ones column; the corrections 128 SA + 128 sc + 16384 rows are linear, so they are applied to the recombined sums
+    if (PK) {
+      const uint64_t M4 = (uint64_t)ntiles * MBv / 4;
+      unsigned __int128 corrsum = 0;
+#pragma unroll
+      for (int w = 0; w < ND; w++) corrsum += (unsigned __int128)((uint64_t)corr[w] * 0x01010101ull) << (8 * w);  // (corr >= 0: sc >= -128 rows)
+      for (uint32_t l = lq; l < KWv; l += 4) {
+        const uint64_t m4 = ((uint64_t)tile * MBv + jj * sby) / 4 + l;
+        __int128 U = 0, SA = 0;
+        for (uint32_t ch = 0; ch < nchunks; ch++) {
+          const uint64_t at = (uint64_t)ch * M4 + m4;
+          if (ND == 4) {
+            const uint4 r = reinterpret_cast<const uint4 *>(part)[at * (N / 4) + v], q = reinterpret_cast<const uint4 *>(sa_part)[at * (N / 4) + sa_col / 4];
+            U += (__int128)(((unsigned __int128)(uint64_t)(int64_t)(int32_t)r.z << 64) | ((uint64_t)r.y << 32) | r.x);
+            SA += (__int128)(((unsigned __int128)(uint64_t)(int64_t)(int32_t)q.z << 64) | ((uint64_t)q.y << 32) | q.x);
+          } else {
+            U += reinterpret_cast<const long long *>(part)[at * N + v];
+            SA += reinterpret_cast<const long long *>(sa_part)[at * N + sa_col];
+          }
+        }
+        // 128 SA[4 l + k] is added once per digit column w of the vector: sum_w 2^(8 w) times the recombined ones-column sum
+        const unsigned __int128 val = (unsigned __int128)(U + SA * (__int128)(ND == 4 ? 128ll * 0x01010101ll : 128ll)) + corrsum;
+        sv[l][0][vl] = (uint32_t)val;
+        sv[l][1][vl] = (uint32_t)(val >> 32);
+        sv[l][2][vl] = (uint32_t)(val >> 64);
+      }
+    } else
     for (uint32_t l = lq; l < KWv; l += 4) {
       unsigned __int128 val = 0;
       // the first chunk's partial products of the word's four byte positions are loaded TOGETHER (eight loads in flight per thread; read
@@ -1006,20 +1079,20 @@ __device__ __forceinline__ void evalmm_finish_body(const int *__restrict__ part,
   }
 }
 
-template <int ND, int KWM>
+template <int ND, int KWM, bool PK>
 __global__ __launch_bounds__(256) void k_evalmm_finish(const int *__restrict__ part, const int64_t *__restrict__ sc, uint32_t nchunks, uint32_t ntiles,
                                                         uint32_t N, uint32_t nvec, uint32_t n, uint32_t nrows, uint32_t ct, uint32_t MBv, uint32_t sby,
                                                         uint32_t LL, MmIo io, int accumulate) {
-  evalmm_finish_body<ND, KWM>(part, sc, nchunks, ntiles, N, nvec, n, nrows, ct, MBv, sby, LL, io, accumulate, part, ND * nvec);
+  evalmm_finish_body<ND, KWM, PK>(part, sc, nchunks, ntiles, N, nvec, n, nrows, ct, MBv, sby, LL, io, accumulate, part, ND * nvec);
 }
 // all groups of a round in one launch: blockIdx.z = group, its partial products at part + group * part_stride
-template <int ND, int KWM>
+template <int ND, int KWM, bool PK>
 __global__ __launch_bounds__(256) void k_evalmm_finish_groups(const int *__restrict__ part, uint64_t part_stride, uint32_t nchunks, uint32_t ntiles, uint32_t N,
                                                                uint32_t n, uint32_t nrows, uint32_t ct, uint32_t MBv, uint32_t sby, uint32_t LL, MmGroupArgs A,
                                                                int accumulate) {
   const uint32_t g = blockIdx.z, lender = A.io[g].sa_from1 ? A.io[g].sa_from1 - 1 : g;
-  evalmm_finish_body<ND, KWM>(part + g * part_stride, A.io[g].sc_zeroed, nchunks, ntiles, N, A.nvec[g], n, nrows, ct, MBv, sby, LL, A.io[g], accumulate,
-                              part + lender * part_stride, ND * A.nvec[lender]);
+  evalmm_finish_body<ND, KWM, PK>(part + g * part_stride, A.io[g].sc_zeroed, nchunks, ntiles, N, A.nvec[g], n, nrows, ct, MBv, sby, LL, A.io[g], accumulate,
+                                  part + lender * part_stride, ND * A.nvec[lender]);
 }
 
 // ---- the witness pass of up to 32 statements as a GEMM over the SSP rows (one read of the SSP) ---------------------------------------
@@ -1498,10 +1571,12 @@ static WideGeom wide_geom(const mfh_ctx *c) {
 }
 
 // the epilogue kernels are instantiated per modulus: the LDS exchange holds 22 (logq 736) or 46 (1472) words per value
-#define FINISH_LAUNCH(kern, ND_, grid, ...)                                                                         \
-  do {                                                                                                              \
-    if (wg.sby / 4 <= 22) hipLaunchKernelGGL((kern<ND_, 22>), grid, dim3(256), 0, c->stream, __VA_ARGS__);          \
-    else hipLaunchKernelGGL((kern<ND_, 46>), grid, dim3(256), 0, c->stream, __VA_ARGS__);                           \
+#define FINISH_LAUNCH(kern, ND_, PK_, grid, ...)                                                                         \
+  do {                                                                                                                   \
+    if ((PK_) && wg.sby / 4 <= 22) hipLaunchKernelGGL((kern<ND_, 22, true>), grid, dim3(256), 0, c->stream, __VA_ARGS__);  \
+    else if (PK_) hipLaunchKernelGGL((kern<ND_, 46, true>), grid, dim3(256), 0, c->stream, __VA_ARGS__);                 \
+    else if (wg.sby / 4 <= 22) hipLaunchKernelGGL((kern<ND_, 22, false>), grid, dim3(256), 0, c->stream, __VA_ARGS__);   \
+    else hipLaunchKernelGGL((kern<ND_, 46, false>), grid, dim3(256), 0, c->stream, __VA_ARGS__);                         \
   } while (0)
 
 int mfh_eval_rows_multi(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d_c8, const uint32_t *d_coeffs, uint32_t nvec, uint32_t coeff_bytes,
@@ -1575,6 +1650,7 @@ int eval_rows_multi_io(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d_
     hipLaunchKernelGGL(k_mm_digits, dim3((rpad / 16 + DG_RG - 1) / DG_RG), dim3(N), 0, c->stream, io, nvec, ND, (uint32_t)nrows, rpad, NT, wide ? 1 : 0, cd, sc);
   AesKey keyx = c->key;
   for (int i = 56; i < 60; i++) keyx.rk[i] ^= 0x80808080u;  // the kernel's keystream bytes come out as A - 128
+  const uint32_t pk = img_region && c->mm_pack ? ND : 0u;  // the streaming kernel hands its partial products over recombined (mms_store_packed)
   {
     Timer t(c, img_region ? 8 : 7, nrows);
     if (img_region) {
@@ -1582,7 +1658,7 @@ int eval_rows_multi_io(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d_
       MmsImages imgs{};
       imgs.image[0] = (const v4i *)img_region;
       hipLaunchKernelGGL(k_mmstream1, dim3(((mtiles + TPW - 1) / TPW + 7) / 8 * 8, nchunks), dim3(SW * 64), 0, c->stream, imgs,
-                         mtiles, KS, (uint32_t)nrows, rpc, (const v4i *)cd, part);
+                         mtiles, KS, (uint32_t)nrows, rpc, (const v4i *)cd, part, pk);
     } else if (wide && q736)
       hipLaunchKernelGGL((k_evalmm16<0, 736>), dim3(ntiles, nchunks), dim3(1024), 0, c->stream, keyx, c->d_t0, off, n, (uint32_t)nrows, rpc, d_c8, cd, part,
                          (uint8_t *)nullptr);
@@ -1600,9 +1676,9 @@ int eval_rows_multi_io(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d_
   const uint32_t sby = wide ? wg.sby : SB;
   const dim3 fgrid(n + 1, (nvec + 63) / 64);
   if (ND == 4)
-    FINISH_LAUNCH(k_evalmm_finish, 4, fgrid, part, sc, nchunks, ntiles, N, nvec, n, (uint32_t)nrows, ct, mb, sby, wg.LL, io, accumulate);
+    FINISH_LAUNCH(k_evalmm_finish, 4, pk, fgrid, part, sc, nchunks, ntiles, N, nvec, n, (uint32_t)nrows, ct, mb, sby, wg.LL, io, accumulate);
   else
-    FINISH_LAUNCH(k_evalmm_finish, 1, fgrid, part, sc, nchunks, ntiles, N, nvec, n, (uint32_t)nrows, ct, mb, sby, wg.LL, io, accumulate);
+    FINISH_LAUNCH(k_evalmm_finish, 1, pk, fgrid, part, sc, nchunks, ntiles, N, nvec, n, (uint32_t)nrows, ct, mb, sby, wg.LL, io, accumulate);
   HIP_TRY(c, hipGetLastError());
   return MFH_OK;
 }
@@ -1683,12 +1759,21 @@ int mms_digits(mfh_ctx *c, const MmsPlan &P, const MmIo *ios, const uint32_t *nv
   HIP_TRY(c, hipGetLastError());
   return MFH_OK;
 }
+// persistent grid or one workgroup per item (mfh_set_mm_stream), and in which form the launch hands its partial products to mms_finish
+static bool mms_persistent(const mfh_ctx *c, const MmsPlan &P) {
+  return P.ngt > 1 && c->mm_persist && c->ncu == 256 && ((c->mm_map && 32 % P.ng == 0) || 32 % P.ngt == 0);
+}
+static uint32_t mms_pk(const mfh_ctx *c, const MmsPlan &P) {
+  if (!c->mm_pack || (mms_persistent(c, P) && c->mm_wave1)) return 0;  // (k_mmstream_w writes int32 only)
+  return P.ND;
+}
 int mms_stream(mfh_ctx *c, const MmsPlan &P) {
   const uint32_t KS = (P.nrows + RT2 - 1) / RT2 * (RT2 / 64), tgs = (P.mtiles + TPW - 1) / TPW;
-  const bool will_persist = P.ngt > 1 && c->mm_persist && c->ncu == 256 && ((c->mm_map && 32 % P.ng == 0) || 32 % P.ngt == 0);  // (the choice made below)
+  const bool will_persist = mms_persistent(c, P);  // (the choice made below)
   Timer t(c, P.ngt > 1 ? (P.ND == 1 ? 14 : 10) : 8, P.nrows, (uint64_t)P.nrows * P.ngt, will_persist ? 1 : 0);  // kind 10 ("mmstream_rounds"): several groups per launch; 14 ("mmstream_bw"): b_w of several super-groups
   MmsImages imgs{};
   for (uint32_t g = 0; g < P.ngt; g++) imgs.image[g] = (const v4i *)P.img[g / P.ng];
+  const uint32_t pk = mms_pk(c, P);  // (mms_finish reads what this launch writes: the same choice)
   if (P.ngt > 1) {
     // slot -> (group, tile group) map and grid shape (mfh_set_mm_stream): see mms_item / k_mmstream_p
     const uint32_t tgx = (tgs + 7) / 8;  // tile groups per XCD
@@ -1703,24 +1788,25 @@ int mms_stream(mfh_ctx *c, const MmsPlan &P) {
       if (c->mm_sync_mode) HIP_TRY(c, hipMemsetAsync(c->mm_sync, 0, 8 * 32 * sizeof(uint32_t), c->stream));  // (the rendezvous counters; unused by default)
       const uint32_t width = P.ND == 1 ? 32u : c->mm_width;  // (b_w's HBM-bound launch keeps every CU)
       hipLaunchKernelGGL(P.ND == 1 ? k_mmstream_pb : k_mmstream_p, dim3(8 * width), dim3(SW * 64), 0, c->stream, imgs, P.mtiles, KS, P.nrows, P.rpc, (const v4i *)P.cd, P.part, P.ngt, P.ng, map,
-                         (uint64_t)(P.cd_bytes / 16), (uint64_t)(P.part_bytes / 4), (slots + 31) / 32, P.nchunks, c->mm_sync, width == 32 ? c->mm_sync_mode : 0u, c->mm_spin, width);
+                         (uint64_t)(P.cd_bytes / 16), (uint64_t)(P.part_bytes / 4), (slots + 31) / 32, P.nchunks, c->mm_sync, width == 32 ? c->mm_sync_mode : 0u, c->mm_spin, width, pk);
     } else {
       hipLaunchKernelGGL(k_mmstream, dim3(slots * 8, P.nchunks), dim3(SW * 64), 0, c->stream, imgs, P.mtiles, KS, P.nrows, P.rpc, (const v4i *)P.cd, P.part, P.ngt, P.ng,
-                         map, (uint64_t)(P.cd_bytes / 16), (uint64_t)(P.part_bytes / 4));
+                         map, (uint64_t)(P.cd_bytes / 16), (uint64_t)(P.part_bytes / 4), pk);
     }
   } else
-    hipLaunchKernelGGL(k_mmstream1, dim3((tgs + 7) / 8 * 8, P.nchunks), dim3(SW * 64), 0, c->stream, imgs, P.mtiles, KS, P.nrows, P.rpc, (const v4i *)P.cd, P.part);
+    hipLaunchKernelGGL(k_mmstream1, dim3((tgs + 7) / 8 * 8, P.nchunks), dim3(SW * 64), 0, c->stream, imgs, P.mtiles, KS, P.nrows, P.rpc, (const v4i *)P.cd, P.part, pk);
   HIP_TRY(c, hipGetLastError());
   return MFH_OK;
 }
 int mms_finish(mfh_ctx *c, const MmsPlan &P, const MmIo *ios, const uint32_t *nvecs, int accumulate) {
   const WideGeom wg = wide_geom(c);
   const uint32_t n = c->P.n;
+  const uint32_t pk = mms_pk(c, P);
   MmGroupArgs A;
   if (mms_group_args(P, ios, nvecs, A)) {
     uint32_t nvmax = 0;
     for (uint32_t g = 0; g < P.ngt; g++) nvmax = std::max(nvmax, nvecs[g]);
-    FINISH_LAUNCH(k_evalmm_finish_groups, 4, dim3(n + 1, (nvmax + 63) / 64, P.ngt), P.part, (uint64_t)(P.part_bytes / 4), P.nchunks, P.ntiles, (uint32_t)N2, n, P.nrows,
+    FINISH_LAUNCH(k_evalmm_finish_groups, 4, pk, dim3(n + 1, (nvmax + 63) / 64, P.ngt), P.part, (uint64_t)(P.part_bytes / 4), P.nchunks, P.ntiles, (uint32_t)N2, n, P.nrows,
                   wg.ct, wg.mbp, wg.sby, wg.LL, A, accumulate);
     HIP_TRY(c, hipGetLastError());
     return MFH_OK;
@@ -1729,10 +1815,10 @@ int mms_finish(mfh_ctx *c, const MmsPlan &P, const MmIo *ios, const uint32_t *nv
     const dim3 fgrid(n + 1, (nvecs[g] + 63) / 64);
     int *pg = P.part + g * (P.part_bytes / 4);
     if (P.ND == 4)
-      FINISH_LAUNCH(k_evalmm_finish, 4, fgrid, pg, ios[g].sc_zeroed, P.nchunks, P.ntiles, (uint32_t)N2, nvecs[g], n, P.nrows, wg.ct, wg.mbp, wg.sby, wg.LL, ios[g],
+      FINISH_LAUNCH(k_evalmm_finish, 4, pk, fgrid, pg, ios[g].sc_zeroed, P.nchunks, P.ntiles, (uint32_t)N2, nvecs[g], n, P.nrows, wg.ct, wg.mbp, wg.sby, wg.LL, ios[g],
                     accumulate);
     else
-      FINISH_LAUNCH(k_evalmm_finish, 1, fgrid, pg, ios[g].sc_zeroed, P.nchunks, P.ntiles, (uint32_t)N2, nvecs[g], n, P.nrows, wg.ct, wg.mbp, wg.sby, wg.LL, ios[g],
+      FINISH_LAUNCH(k_evalmm_finish, 1, pk, fgrid, pg, ios[g].sc_zeroed, P.nchunks, P.ntiles, (uint32_t)N2, nvecs[g], n, P.nrows, wg.ct, wg.mbp, wg.sby, wg.LL, ios[g],
                     accumulate);
   }
   HIP_TRY(c, hipGetLastError());
@@ -1848,6 +1934,11 @@ int mfh_set_mm_width(mfh_ctx *c, uint32_t per_xcd, int early_chain) {
   if (!c || per_xcd < 1 || per_xcd > 32) return MFH_EINVAL;
   c->mm_width = per_xcd;
   c->batch_early_chain = early_chain != 0;
+  return MFH_OK;
+}
+int mfh_set_mm_pack(mfh_ctx *c, int on) {
+  if (!c) return MFH_EINVAL;
+  c->mm_pack = on != 0;
   return MFH_OK;
 }
 int mfh_set_mm_chunk_rows(mfh_ctx *c, uint32_t rows) {

@@ -1100,6 +1100,7 @@ void mfh_ctx_destroy(mfh_ctx *c) {
   mfh_poly_destroy(c);
   upload_free(c);
   if (c->sample_tmp) hipFree(c->sample_tmp);
+  if (c->ev_sample) hipEventDestroy(c->ev_sample);
   pin_free(c->pin_rows);
   for (auto &b : c->pin_wring) pin_free(b);
   pin_free(c->pin_cw);
@@ -1144,6 +1145,15 @@ int mfh_set_stream(mfh_ctx *c, void *s) {
 int mfh_sync(mfh_ctx *c) {
   if (!c) return MFH_EINVAL;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return MFH_OK;
+}
+
+int mfh_scrub_staging(mfh_ctx *c) {
+  if (!c) return MFH_EINVAL;
+  pin_scrub(c->pin_rows);
+  pin_scrub(c->pin_cw);
+  pin_scrub(c->pin_smudge);
+  for (auto &b : c->pin_wring) pin_scrub(b);
   return MFH_OK;
 }
 
@@ -1369,6 +1379,9 @@ int mfh_sample_rows(mfh_ctx *c, uint64_t off, size_t nrows, uint64_t *d_out) {
       c->sample_bytes = bytes;
     }
     tmp = c->sample_tmp;
+    // the buffer is the context's, the stream is whatever the caller set for THIS call: a previous call on another stream may still be repacking out of it
+    if (!c->ev_sample) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_sample, hipEventDisableTiming));
+    else HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_sample, 0));
   } else {
     HIP_TRY(c, hipMalloc(&tmp, bytes));
   }
@@ -1380,7 +1393,9 @@ int mfh_sample_rows(mfh_ctx *c, uint64_t off, size_t nrows, uint64_t *d_out) {
                   hipLaunchKernelGGL(k_repack_values<1472>, grid, dim3(256), 0, c->stream, (const uint32_t *)tmp, (uint32_t *)d_out, nelem));
     if (hipGetLastError() != hipSuccess) rc = MFH_EDEVICE;
   }
-  if (!kept) {
+  if (kept) {
+    if (hipEventRecord(c->ev_sample, c->stream) != hipSuccess && rc == MFH_OK) rc = MFH_EDEVICE;  // (the last reader of the kept buffer)
+  } else {
     hipStreamSynchronize(c->stream);
     hipFree(tmp);
   }
@@ -1828,12 +1843,16 @@ int mfh_ssp_upload(mfh_ctx *c, const void *h_ssp_u64, uint32_t *d_ssp, size_t fi
   if (!u) c->uploader = u = new Uploader();
   for (int t = 0; t < NT; t++) {  // the lanes this call uses (made once, kept by the context)
     UpLane &l = u->lane[t];
-    if (l.st) continue;
-    HIP_TRY(c, hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking));
-    for (int i = 0; i < 2; i++) {
-      HIP_TRY(c, hipEventCreateWithFlags(&l.ev[i], hipEventDisableTiming));
-      HIP_TRY(c, hipHostMalloc((void **)&l.pin[i], UP_CHUNK, hipHostMallocDefault));
-      HIP_TRY(c, hipMalloc((void **)&l.dev[i], UP_CHUNK));
+    if (l.st) continue;  // (a lane with a stream is complete: a lane that fails half-way takes the whole uploader down with it, below)
+    bool ok = hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; ok && i < 2; i++)
+      ok = hipEventCreateWithFlags(&l.ev[i], hipEventDisableTiming) == hipSuccess && hipHostMalloc((void **)&l.pin[i], UP_CHUNK, hipHostMallocDefault) == hipSuccess &&
+           hipMalloc((void **)&l.dev[i], UP_CHUNK) == hipSuccess;
+    if (!ok) {  // no half-built lane is left for the next call to find (it would skip it at `if (l.st)` and copy into a null staging buffer)
+      (void)hipGetLastError();
+      upload_free(c);
+      c->err = "ssp upload: no memory for the staging lanes";
+      return MFH_ENOMEM;
     }
   }
   int failed[UP_T] = {};

@@ -317,9 +317,10 @@ static void comm_bcast_bytes(mfuoco_comm *c, uint8_t *d_buf, size_t n, int root)
  *     A  all-to-all of the w | h | v row slices                               communicator stream, after C
  *     P  the rank's row shares of the stage's statements; L  lanes            shim stream, after A
  *     R  reduce-scatter of the lanes                                          communicator stream, after L
- *     F  carries, modq, delta ct_t, smudging of the own statements            shim stream, after R;  then the drain (own copy stream + host threads), after F
- * queued as   C0 | C1 P0 L0 | C2 P1 L1 F0 | C3 P2 L2 F1 | ...   on the shim's stream and   A0 | A1 R0 | A2 R1 | ...   on the communicator's, so that A(k + 1) runs under
- * P(k), R(k) under C(k + 2) and P(k + 1), and the host turns stage k into mpz_t's under the kernels of the stages behind it.  Everything is double-buffered by stage parity;
+ *     F  carries, modq, delta ct_t, smudging of the own statements            shim stream, after R
+ *     D  the drain: device to host on the shim's copy stream, mpz_t's on host threads   after F, an iteration later (the call blocks in it, with work queued behind)
+ * queued as   C0 | C1 P0 L0 | C2 P1 L1 F0 | C3 P2 L2 F1 [D0] | ...   on the shim's stream and   A0 | A1 R0 | A2 R1 | ...   on the communicator's, so that A(k + 1) runs under
+ * P(k), R(k) under C(k + 2) and P(k + 1), and the host turns stage k into mpz_t's under the kernels of the stages behind it.  (One rank: F(k) directly behind R(k).)  Everything is double-buffered by stage parity;
  * the order above is what makes that safe (a buffer's next writer is queued behind an event its last reader precedes).  Without a resident image share
  * ($MFUOCO_GPU_RESIDENT_CRS=0, or no room) the call is ONE stage: mfh_prove_batch_partial then expands its transient image once per call, not once per stage. */
 void mfuoco_prover_batch_sharded(proof_t *pis, crs_t crs, ssp_t ssp, mpz_t *witnesses, size_t count, mfuoco_comm *comm, size_t *own_first,
@@ -397,7 +398,12 @@ void mfuoco_prover_batch_sharded(proof_t *pis, crs_t crs, ssp_t ssp, mpz_t *witn
   /* cnt(q, k): how many statements of rank q's slab stage k holds (own indices k * sper ...); rank 0's is the largest: the slab of the stage's reduce-scatter */
 #define STAGE_CNT(q, k) ({ const size_t nq_ = stmt_lo(nb, (q) + 1, world) - stmt_lo(nb, (q), world), lo_ = (k) * sper; nq_ > lo_ ? (nq_ - lo_ < sper ? nq_ - lo_ : sper) : (size_t)0; })
   size_t scnt[MAXW], sdsp[MAXW], rcnt[MAXW], rdsp[MAXW];
-  for (size_t it = 0; it < nst + 2; it++) {
+  /* F(k) is queued f_lag iterations after C(k): with several ranks behind the row work of stage k + 1, so that the reduce-scatter of stage k has that long to complete
+   * before the shim's stream waits for it; with ONE rank the "reduce-scatter" is a device copy and nothing is gained by waiting -- F(k) follows it at once, and the
+   * stage's proofs leave for the host a whole stage earlier (one rank drains every proof of the call: 706 KB each) */
+  const size_t f_lag = world > 1 ? 2 : 1;
+  size_t next_drain = 0;
+  for (size_t it = 0; it < nst + f_lag; it++) {
     /* ---- C(it): chain of the own statements of stage `it` (src/snark.c:141-169), operands packed; A(it): the all-to-all */
     if (it < nst) {
       const size_t k = it, on = STAGE_CNT(rank, k), olo = k * sper;
@@ -444,9 +450,9 @@ void mfuoco_prover_batch_sharded(proof_t *pis, crs_t crs, ssp_t ssp, mpz_t *witn
         HK(hipEventRecord(c->ev_own[b], cst));
       } else HK(hipMemcpyAsync(own[b], lanes[b], sl * lps * 8, hipMemcpyDeviceToDevice, NULL));
     }
-    /* ---- F(it - 2): carries + modq, then b_w += delta ct_t and the smudging of the own statements (src/snark.c:143-145,185-189) */
-    if (it >= 2) {
-      const size_t k = it - 2, on = STAGE_CNT(rank, k), olo = k * sper;
+    /* ---- F(it - f_lag): carries + modq, then b_w += delta ct_t and the smudging of the own statements (src/snark.c:143-145,185-189) */
+    if (it >= f_lag) {
+      const size_t k = it - f_lag, on = STAGE_CNT(rank, k), olo = k * sper;
       const int b = (int)(k & 1);
       if (c->t) HK(hipStreamWaitEvent(NULL, c->ev_own[b], 0));
       if (on) {
@@ -455,10 +461,16 @@ void mfuoco_prover_batch_sharded(proof_t *pis, crs_t crs, ssp_t ssp, mpz_t *witn
       }
       HK(hipEventRecord(c->ev_done[k], NULL));
     }
+    /* ---- D(it - f_lag - 1), the drain: the stage crosses PCIe (the shim's own copy stream, behind its ev_done only) and becomes mpz_t's on the host threads while
+     * the GPU runs what this iteration has just queued.  One stage further back than F: the call blocks here for the copy, and a drain of the stage whose F was queued
+     * a moment ago would wait with nothing behind it for the GPU to go on with. */
+    if (it >= f_lag + 1) {
+      const size_t k = next_drain++, on = STAGE_CNT(rank, k), olo = k * sper;
+      if (on) mfuoco_gpu_proofs_to_host_after(pis + first + olo, proofs + olo * 5 * CTL, on, c->ev_done[k]);
+    }
   }
-  /* the drain: stage k crosses PCIe and becomes mpz_t's as soon as ITS proofs are final, under the kernels and collectives of the stages behind it */
-  for (size_t k = 0; k < nst; k++) {
-    const size_t on = STAGE_CNT(rank, k), olo = k * sper;
+  while (next_drain < nst) { /* ... and the last stage, which nothing is left to hide behind */
+    const size_t k = next_drain++, on = STAGE_CNT(rank, k), olo = k * sper;
     if (on) mfuoco_gpu_proofs_to_host_after(pis + first + olo, proofs + olo * 5 * CTL, on, c->ev_done[k]);
   }
 #undef STAGE_CNT

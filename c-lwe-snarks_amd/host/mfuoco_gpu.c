@@ -197,6 +197,7 @@ int mfuoco_gpu_set_device(int device)
   return 0;
 }
 int mfuoco_gpu_device(void) { return G.ctx ? G.device : -1; }
+static void sk_forget(void);
 static void drop_image(void)
 {
   if (G.ctx && G.img_registered) {
@@ -215,12 +216,7 @@ void mfuoco_gpu_invalidate(void)
   /* ... and the batch calls' device scratch (720 MB per 1020 proofs), which otherwise stays for the next call */
   if (G.d_out) { (void)hipFree(G.d_out); G.d_out = NULL; G.out_cap = 0; }
   if (G.d_up) { (void)hipFree(G.d_up); G.d_up = NULL; G.up_cap = 0; }
-  if (G.h_sk) { /* ... and forget the cached key */
-    explicit_bzero(G.h_sk, (size_t)GAMMA_N * L_LIMBS * 8);
-    explicit_bzero(G.pin_sk, (size_t)GAMMA_N * L_LIMBS * 8);
-    (void)hipMemset(G.d_sk, 0, (size_t)GAMMA_N * L_LIMBS * 8);
-    G.sk_valid = false;
-  }
+  sk_forget(); /* ... and forget the cached key */
 }
 void mfuoco_gpu_set_resident_crs(int on)
 {
@@ -481,7 +477,22 @@ void mpz2_urandomb2(mpz_ptr rop, size_t nbits)
 static void initv(mpz_t *v, size_t n) { for (size_t i = 0; i < n; i++) mpz_init2(v[i], GAMMA_LOGQ); }
 static void clearv(mpz_t *v, size_t n) { for (size_t i = 0; i < n; i++) mpz_clear(v[i]); }
 void key_gen(sk_t sk) { initv(sk, GAMMA_N); for (size_t i = 0; i < GAMMA_N; i++) mpz2_urandomb2(sk[i], GAMMA_LOGQ); }
-void key_clear(sk_t sk) { clearv(sk, GAMMA_N); }
+/* (the reference frees the limbs as they are, src/lwe.c:36-43.  The shim holds copies of the key last used -- pageable, pinned and on the device, sk_resident() -- and they
+ * go with it: a caller that is done with its key leaves none behind in this library.  The next call under another key uploads that one, as after any key change.) */
+static void sk_forget(void)
+{
+  if (!G.h_sk) return;
+  explicit_bzero(G.h_sk, (size_t)GAMMA_N * L_LIMBS * 8);
+  explicit_bzero(G.pin_sk, (size_t)GAMMA_N * L_LIMBS * 8);
+  if (G.ctx) { (void)hipDeviceSynchronize(); (void)hipMemset(G.d_sk, 0, (size_t)GAMMA_N * L_LIMBS * 8); }
+  G.sk_valid = false;
+}
+void key_clear(sk_t sk)
+{
+  KEEP_ERRNO;
+  sk_forget();
+  clearv(sk, GAMMA_N);
+}
 void ct_init(ct_t ct) { initv(ct, GAMMA_N + 1); }
 void ct_clear(ct_t ct) { clearv(ct, GAMMA_N + 1); }
 void errdist_uniform(mpz_t e) { mpz2_urandomb2(e, GAMMA_LOG_SIGMA + 3); }
@@ -1313,6 +1324,7 @@ void prover(proof_t pi, crs_t crs, ssp_t ssp, mpz_t witness)
   const double t_done = tnow();
   proof_t *one = (proof_t *)pi; /* proof_t is struct proof[1]: pi is the address of the one element */
   mfuoco_gpu_proofs_to_host(one, G.d_proof, 1);
+  CK(mfh_scrub_staging(G.ctx)); /* the proof is out, so every copy of the call has run: witness bits, delta and the smudging terms leave the pinned staging too */
   if (tracing())
     fprintf(stderr, "prover(): stage CRS+SSP %.2f ms, image + queue %.2f, GPU %.2f, copy + mpz_t %.2f (%s)\n", t_staged - t_in, t_queued - t_staged, t_done - t_queued, tnow() - t_done,
             rows ? "resident rows" : "regenerated");
@@ -1357,6 +1369,7 @@ void mfuoco_prover_batch(proof_t *pis, crs_t crs, ssp_t ssp, mpz_t *witnesses, s
   /* the call above only QUEUED the work: super-group k is copied and converted while the GPU runs k + 1 */
   const double t_queued = tnow();
   proofs_drain(pis, d_out, count, 1, NULL);
+  CK(mfh_scrub_staging(G.ctx)); /* (as in prover(): nothing secret of the call stays in the context's pinned staging) */
   if (tracing())
     fprintf(stderr, "mfuoco_prover_batch(%zu): stage CRS+SSP %.2f ms, witness bits + entropy %.2f, image %.2f, queue %.2f, drain (copy + mpz_t under the GPU work) %.2f\n", count,
             t_staged - t_in, t_host - t_staged, t_image - t_host, t_queued - t_image, tnow() - t_queued);

@@ -60,6 +60,10 @@ void mfh_ctx_destroy(mfh_ctx *ctx);
  * NOT the context's own stream (a fresh context runs on its own non-blocking stream until this is called). */
 int mfh_set_stream(mfh_ctx *ctx, void *hip_stream);
 int mfh_sync(mfh_ctx *ctx);
+/* The prover entry points stage what the host contributes -- witness bits, deltas (src/snark.c:140) and the smudging terms u p (src/lwe.c:65-76) -- in pinned host
+ * buffers the context keeps.  This waits for their copies and zeroes them: a caller whose proofs must stay zero-knowledge against a later reader of its memory calls
+ * it when the proofs are out (the shim's prover() / mfuoco_prover_batch() do; the reference, single-threaded on the CPU, leaves delta and u in freed mpz limbs). */
+int mfh_scrub_staging(mfh_ctx *ctx);
 const char *mfh_last_error(const mfh_ctx *ctx);
 /* rng_init (src/entropy.c:58-61) + aesctr_init (src/aes.c:49-95): expand the AES-256 key of `seed`
  * and make it the context's current public stream. */
@@ -249,6 +253,11 @@ int mfh_set_mm_width(mfh_ctx *ctx, uint32_t per_xcd, int early_chain);
 /* rows per row chunk of the matrix-core launches (mfh_eval_rows_multi, mfh_prove_batch): the int32 accumulators hold at most
  * 131071 rows (the default; 0 restores it); smaller values split every region into more chunks -- same results (tuning, tests). */
 int mfh_set_mm_chunk_rows(mfh_ctx *ctx, uint32_t rows);
+/* How the streaming kernels (k_mmstream*) hand the partial products sum_i A'[i][m] C'[i][n] to the epilogue: on (default) recombined in the kernel -- the four byte
+ * positions a lane holds and, for four-byte coefficient vectors, the vector's four digit columns: a 16-byte record per (byte-position quad, vector) instead of sixteen
+ * int32, a quarter of the bytes written and read back (2.1 GB per super-group launch otherwise) --; off: the int32 layout of rounds 1 - 5.  Exact integer arithmetic either
+ * way: same results (tuning, tests). */
+int mfh_set_mm_pack(mfh_ctx *ctx, int on);
 int mfh_prove_batch(mfh_ctx *ctx, const uint8_t *d_crs_c8, const uint32_t *d_ssp, uint32_t nproofs, const uint8_t *h_witness_bits,
                     size_t bits_stride, const uint32_t *h_delta, const uint8_t *h_smudge_mag, size_t maglen, const uint8_t *h_smudge_sign,
                     uint64_t *d_proofs);

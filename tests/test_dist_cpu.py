@@ -127,12 +127,16 @@ class _LinearCtx:
     class _P:
         d, m, n, K, L, lanes = 13, 9, 1, 1, 1, 2  # (one 64-bit limb per value: two 56-bit lanes)
 
-    def __init__(self):
+    def __init__(self, resident=True):
         import torch
 
         self.torch = torch
         self.params = self._P()
-        self.finished = None
+        self.params.ct_limbs = (self.params.n + 1) * self.params.L
+        self.finished = []
+        self.device = torch.device("cpu")
+        self.partial_calls = 0
+        self._resident_mm = "image share" if resident else None  # (without one prove_batch_sharded runs the call as ONE stage)
 
     def empty(self, nbytes):
         return self.torch.empty(int(nbytes), dtype=self.torch.uint8)
@@ -164,6 +168,7 @@ class _LinearCtx:
         lo, hi = p.d * rank // world, p.d * (rank + 1) // world
         wts = t.arange(lo + 1, hi + 1, dtype=t.int64)
         nb = len(bits_list)
+        self.partial_calls += 1
         part = t.zeros((nb, 5, p.n + 1, p.L), dtype=t.int64)
         for b in range(nb):
             for k, src in enumerate((d_w, d_h, d_v)):
@@ -179,23 +184,28 @@ class _LinearCtx:
         out[: lanes.numel()] = lanes
         return out
 
-    def ct_from_lanes(self, lanes, count):
+    def ct_from_lanes(self, lanes, count, out=None):
         from c_lwe_snarks_amd import dist as mfdist
 
         p = self.params
         n = count * (p.n + 1)
-        return self.torch.from_numpy(mfdist.limbs_from_lanes_cpu(lanes[: n * p.lanes].numpy().reshape(n, p.lanes), p.L, p.K).astype(np.int64)).reshape(-1)
+        res = self.torch.from_numpy(mfdist.limbs_from_lanes_cpu(lanes[: n * p.lanes].numpy().reshape(n, p.lanes), p.L, p.K).astype(np.int64)).reshape(-1)
+        if out is None:
+            return res
+        out.view(self.torch.int64)[: res.numel()] = res
+        return out
 
     def prove_batch_finish(self, d_crs, deltas, mags, signs, proofs, maglen=80):
         p = self.params
-        v = proofs.view(len(deltas), 5, p.n + 1, p.L) if len(deltas) else proofs
+        v = proofs.view(self.torch.int64).view(len(deltas), 5, p.n + 1, p.L) if len(deltas) else proofs
         for b, idb in enumerate(deltas):
             v[b, 4, 0, 0] += 7 * idb
-        self.finished = list(deltas)
+        self.finished += list(deltas)
         return proofs
 
 
-def _batch_worker(rank, world, port, out_dir, nb, by_cols=False):
+def _batch_worker(rank, world, port, out_dir, nb, by_cols=False, stage=None):
+    import torch
     import torch.distributed as dist
 
     from c_lwe_snarks_amd import dist as mfdist
@@ -203,14 +213,24 @@ def _batch_worker(rank, world, port, out_dir, nb, by_cols=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    ctx = _LinearCtx()
+    ctx = _LinearCtx(resident=stage != "no image")
     p = ctx.params
     ids = [3 + 2 * b for b in range(nb)]
     bits = [bytes([(37 * b + 1) & 0xFF, (11 * b) & 0xFF]) for b in range(nb)]
-    first, count, proofs = mfdist.prove_batch_sharded(ctx, None, None, bits, ids, [b""] * nb, [b""] * nb, rank, world, witness_by_cols=by_cols)
+    mfdist.collectives_snapshot(reset=True)
+    first, count, proofs = mfdist.prove_batch_sharded(ctx, None, None, bits, ids, [b""] * nb, [b""] * nb, rank, world, witness_by_cols=by_cols,
+                                                      stage=None if stage == "no image" else stage)
     per = -(-nb // world)
     ok = first == min(nb, rank * per) and count == min(nb, first + per) - first and ctx.finished == ids[first:first + count]
-    got = proofs.view(count, 5, p.n + 1, p.L) if count else None
+    # stages: as planned (one when no image share is registered), one row-work call each; the bytes handed to the backend do not depend on the cut
+    sper, nst = mfdist.stage_plan(nb, world, 0 if stage == "no image" else stage)
+    ok = ok and ctx.partial_calls == nst
+    snap = mfdist.collectives_snapshot()
+    lps = 5 * (p.n + 1) * p.lanes
+    ok = ok and snap["reduce_scatter_tensor"] == {"calls": nst, "bytes": per * world * lps * 8}
+    a2a_bytes = count * 3 * p.d * 4 + (nb * (p.d * (rank + 1) // world - p.d * rank // world) * 4 if by_cols else 0)
+    ok = ok and snap["all_to_all_single"] == {"calls": nst * (2 if by_cols else 1), "bytes": a2a_bytes}
+    got = proofs.view(torch.int64).view(count, 5, p.n + 1, p.L) if count else None
     wsum = sum(i * (i + 1) for i in range(p.d))   # sum_i i (i + 1)
     w1 = sum(i + 1 for i in range(p.d))
     for b in range(count):
@@ -225,16 +245,20 @@ def _batch_worker(rank, world, port, out_dir, nb, by_cols=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,nb,by_cols", [(2, 5, False), (2, 4, False), (3, 2, False), (2, 5, True), (3, 2, True), (3, 7, True), (8, 20, False), (8, 5, True),
-                                              (8, 5, False), (8, 20, True)])
-def test_prove_batch_sharded_sequencing_gloo(tmp_path, world, nb, by_cols):
+@pytest.mark.parametrize("world,nb,by_cols,stage", [(2, 5, False, None), (2, 4, False, 1), (3, 2, False, None), (2, 5, True, 2), (3, 2, True, None), (3, 7, True, 1),
+                                                    (8, 20, False, None), (8, 5, True, None), (8, 5, False, None), (8, 20, True, 2), (8, 20, False, 1), (2, 9, False, 2),
+                                                    (2, 9, True, "no image"), (8, 20, False, 0)])
+def test_prove_batch_sharded_sequencing_gloo(tmp_path, world, nb, by_cols, stage):
     """uneven statement slabs (5 over 2), even ones, and a rank that owns no statement (2 over 3; d = 13 and m = 9 never divide);
     by_cols: the chain cut in two -- coefficient ranges of w of all statements per rank, a first all-to-all to the statement owners.
     world = 8 is the machine's real rank count (one process per GPU of an 8 x MI355X node): 20 statements = slabs of 3, 3, 3, 3, 3, 3, 2, 0 (the last rank owns
-    none), 5 statements = three ranks without any; row shares of 13 and 9 rows over 8 ranks are 1 or 2 rows each"""
+    none), 5 statements = three ranks without any; row shares of 13 and 9 rows over 8 ranks are 1 or 2 rows each.
+    stage: statements per rank and pipeline stage (None = the plan of a real call -- one stage at these sizes --, 1 / 2 = several stages, the last one ragged and
+    some ranks empty in it: 20 statements over 8 ranks in stages of 2 are 16 + 4 with ranks 0 .. 5 holding one more and rank 6 done; 0 = the one-shot sequence;
+    "no image" = no image share registered: one stage whatever the plan says)"""
     import torch.multiprocessing as mp
 
     port = _free_port()
-    mp.spawn(_batch_worker, args=(world, port, str(tmp_path), nb, by_cols), nprocs=world, join=True)
+    mp.spawn(_batch_worker, args=(world, port, str(tmp_path), nb, by_cols, stage), nprocs=world, join=True)
     for r in range(world):
         assert open(tmp_path / f"brank{r}.txt").read() == "ok"

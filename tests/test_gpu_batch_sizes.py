@@ -322,11 +322,16 @@ def test_streaming_launch_layouts_give_identical_proofs(gpu_ctx_factory, layout,
     ctx.close()
 
 
-@pytest.mark.parametrize("width,early", [(28, False), (28, True), (24, True), (32, True), (5, True)])
-def test_narrow_persistent_grid_and_early_chain_give_identical_proofs(gpu_ctx_factory, width, early):
+@pytest.mark.parametrize("width,early,nb,ngl", [(28, False, 1000, 8), (28, True, 1000, 8), (24, True, 1000, 8), (32, True, 1000, 8), (5, True, 1000, 8),
+                                                 (32, True, 300, 8), (28, True, 810, 8), (32, True, 810, 2), (28, True, 300, 2)])
+def test_narrow_persistent_grid_and_early_chain_give_identical_proofs(gpu_ctx_factory, width, early, nb, ngl):
     """mfh_set_mm_width: the persistent S / AS launch on `width` workgroups per XCD (each then strides over its XCD's items by `width`) and, with early,
     the chain of super-group k + 1 queued beside the row work of k, the epilogues and smudging of k on the side stream beside the row work of k + 1 (two halves
-    of the digit / partial-product scratch).  1000 statements = 4 super-groups, so every hand-over happens twice; never the proofs."""
+    of the digit / partial-product scratch).  1000 statements = 4 super-groups, so every hand-over happens twice; never the proofs.
+    300 = 255 + 45 and 810 = 3 x 255 + 45 statements: the last super-group is SHORT and has an odd index, so its scratch is smaller than its predecessor's -- the two
+    halves must still be one full super-group apart (round 5 placed the short one at ITS size, inside the half its predecessor's epilogues were reading), and the
+    caller's stream must wait for super-group k - 2's epilogues before it reuses their half; with 2 groups per launch (4 launches per super-group) a super-group's
+    scratch is cut differently again."""
     import sys
 
     import torch
@@ -343,10 +348,10 @@ def test_narrow_persistent_grid_and_early_chain_give_identical_proofs(gpu_ctx_fa
     ctx.ssp_prepare(inst["d_ssp"])
     d_crs = ctx.setup(inst["d_ssp"], inst["alpha"], inst["beta"], inst["s"], inst["sk"], inst["err"])
     rng = np.random.default_rng(width)
-    nb = 1000
     bits, deltas, mags, signs = _statements(rng, p, nb, valid_bits=inst["bits"])
     want = ctx.prove_batch(d_crs, inst["d_ssp"], bits, deltas, mags, signs).clone()
     ctx.set_mm_width(width, early)
+    ctx.set_batch_launch(ngl, True)
     try:
         got = ctx.prove_batch(d_crs, inst["d_ssp"], bits, deltas, mags, signs)
         ctx.sync()
@@ -354,10 +359,75 @@ def test_narrow_persistent_grid_and_early_chain_give_identical_proofs(gpu_ctx_fa
         ctx.sync()
     finally:
         ctx.set_mm_width(32, False)
+        ctx.set_batch_launch(8, True)
     assert torch.equal(got, want) and torch.equal(again, want)
-    for b in (0, 254, 255, 509, 510, 765, nb - 1):
+    for b in [x for x in (0, 254, 255, 299, 509, 510, 765, nb - 1) if x < nb]:
         one = ctx.prove(d_crs, inst["d_ssp"], bits[b], deltas[b], mags[b], signs[b])
         assert torch.equal(want.view(nb, -1)[b], one), f"statement {b}"
+    ctx.close()
+
+
+@pytest.mark.parametrize("logq,nb,ngl,chunk_rows,persistent,bw", [(736, 300, 8, 0, True, True), (736, 300, 4, 512, True, False), (736, 130, 8, 256, False, True), (1472, 130, 8, 0, True, True),
+                                                                    (1472, 40, 2, 512, False, False), (736, 600, 8, 0, 2, True)])
+def test_packed_partial_products_give_identical_proofs(gpu_ctx_factory, logq, nb, ngl, chunk_rows, persistent, bw):
+    """mfh_set_mm_pack: the streaming kernels recombine the partial products they hold before writing them (four byte positions per lane; for four-byte coefficient
+    vectors also the vector's four digit columns, a DPP quad) and the epilogue applies the signedness corrections to the recombined sums -- against the int32 layout of
+    rounds 1 - 5, and against mfh_prove (k_eval: no matrix core, no digits).  Several row chunks (records of several chunks summed in the epilogue), both moduli (22 / 46
+    words per value, 11 / 12 row tiles per column tile), the persistent grid and one workgroup per item, b_w merged (several one-byte groups per launch) and per super-group
+    (k_mmstream1, with the delta ct_t term in its epilogue), borrowed ones columns (8 groups per region: the lender's record).  persistent = 2: the one-wave-per-SIMD body
+    writes int32 whatever the switch says, and its epilogue must follow."""
+    import sys
+
+    import torch
+
+    import c_lwe_snarks_amd as mf
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    p = mf.Params(d=1152, m=1000, logq=logq)
+    ctx = gpu_ctx_factory(p)
+    ctx.set_seed(SEED)
+    inst = bench.build_instance(mf, ctx, torch, p, 99)
+    ctx.ssp_prepare(inst["d_ssp"])
+    d_crs = ctx.setup(inst["d_ssp"], inst["alpha"], inst["beta"], inst["s"], inst["sk"], inst["err"])
+    rng = np.random.default_rng(nb + logq)
+    bits, deltas, mags, signs = _statements(rng, p, nb, valid_bits=inst["bits"])
+    ctx.set_batch_launch(ngl, True)
+    ctx.set_mm_chunk_rows(chunk_rows)
+    ctx.set_mm_stream(1, persistent, 0, 64)
+    ctx.set_batch_bw(bw)
+    try:
+        ctx.set_mm_pack(False)
+        want = ctx.prove_batch(d_crs, inst["d_ssp"], bits, deltas, mags, signs).clone()
+        ctx.set_mm_pack(True)
+        got = ctx.prove_batch(d_crs, inst["d_ssp"], bits, deltas, mags, signs)
+        # ... and one evaluation from a registered image (k_mmstream1, four-byte vectors and one-byte columns)
+        image = ctx.crs_expand_mm(d_crs)
+        ctx.set_resident_mm(image)
+        co = rng.integers(0, mf.P, size=(5, p.d), dtype=np.uint64).astype(np.uint32)
+        cb = rng.integers(0, 256, size=(7, p.d), dtype=np.uint32)
+        d_co, d_cb = ctx.to_device(co), ctx.to_device(cb)
+        c8 = d_crs[: p.d * p.ctb]
+        ev = {}
+        for pack in (False, True):
+            ctx.set_mm_pack(pack)
+            ev[pack] = (ctx.eval_rows_multi(p.ctr_s, p.d, c8, d_co, 5).clone(), ctx.eval_rows_multi(p.ctr_s, p.d, c8, d_cb, 7, coeff_bytes=1).clone())
+        ctx.set_resident_mm(None)
+    finally:
+        ctx.set_mm_pack(True)
+        ctx.set_mm_stream(1, True, 0, 64)
+        ctx.set_batch_launch(8, True)
+        ctx.set_mm_chunk_rows(0)
+        ctx.set_batch_bw(True)
+    assert torch.equal(got, want)
+    assert torch.equal(ev[True][0], ev[False][0]) and torch.equal(ev[True][1], ev[False][1])
+    for which, vec, k in ((0, co, 3), (1, cb, 6)):
+        one = ctx.eval_rows(p.ctr_s, p.d, c8, ctx.to_device(vec[k]))[0]
+        assert torch.equal(ev[True][which].view(vec.shape[0], -1)[k], one.reshape(-1)), (which, k)
+    for b in (0, nb // 2, nb - 1):
+        single = ctx.prove(d_crs, inst["d_ssp"], bits[b], deltas[b], mags[b], signs[b])
+        assert torch.equal(got.view(nb, -1)[b], single), f"statement {b}"
     ctx.close()
 
 

@@ -32,23 +32,32 @@ def _rank_env(rank, world, **extra):
     return env
 
 
-def test_c_sharded_prover_one_rank_rccl(tmp_path):
+@pytest.mark.parametrize("stage", [None, "7", "0"])
+def test_c_sharded_prover_one_rank_rccl(tmp_path, stage):
     """mfuoco_prover_batch_sharded / mfuoco_prover_sharded (host/mfuoco_dist.c) through librccl called from C: a one-rank communicator still
     sends the all-to-all (ncclSend/ncclRecv to itself), the ncclReduceScatter, both ncclAllReduce and the ncclBroadcast; proofs must equal
-    mfuoco_prover_batch's / prover()'s bit for bit on the same entropy tape and verify"""
-    r = subprocess.run([_sharded_exe(), "40"], env=_rank_env(0, 1, MFUOCO_COMM_ID_FILE=str(tmp_path / "id")), capture_output=True, text=True, timeout=600)
+    mfuoco_prover_batch's / prover()'s bit for bit on the same entropy tape and verify.  stage ($MFUOCO_DIST_STAGE): statements per rank and pipeline stage --
+    None: the plan of a real call (40 statements: one stage); 7: six stages (7, 7, 7, 7, 7, 5), the collectives of stage k + 1 / k - 1 on the communicator's stream
+    beside the row work of stage k, every buffer re-used by parity three times; 0: the one-shot sequence"""
+    extra = {"MFUOCO_DIST_STAGE": stage} if stage is not None else {}
+    r = subprocess.run([_sharded_exe(), "40"], env=_rank_env(0, 1, MFUOCO_COMM_ID_FILE=str(tmp_path / "id"), **extra), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "backend=rccl" in r.stdout and "sharded ok" in r.stdout
+    nst = {None: 1, "7": 6, "0": 1}[stage]
+    assert f"all_to_all={nst + 1} reduce_scatter={nst + 1}" in r.stdout, r.stdout  # (+ the second, one-statement call)
 
 
-@pytest.mark.parametrize("world,count", [(2, 9), (3, 40), (4, 41)])
-def test_c_sharded_prover_rehearsal_ranks_share_the_gpu(world, count):
+@pytest.mark.parametrize("world,count,stage", [(2, 9, None), (3, 40, None), (4, 41, None), (3, 40, "5"), (4, 41, "4")])
+def test_c_sharded_prover_rehearsal_ranks_share_the_gpu(world, count, stage):
     """the same C sequence with `world` PROCESSES on the one GPU, collectives staged through host shared memory (rehearsal backend): uneven
     statement slabs and row shares (256 rows over 3 ranks), a second call in which the last rank owns no statement.  4 ranks beside this test runner (which holds the GPU itself) stay clear of what the GPU box lets one
     command put on its card at once (its process guard: 6 processes; 6 ranks + the runner were killed by it in round 5), so the machine's real rank count, 8, is rehearsed on the CPU only: the host sequence over gloo in
-    tests/test_dist_cpu.py, the rendezvous in tests/test_rendezvous_cpu.py."""
+    tests/test_dist_cpu.py, the rendezvous in tests/test_rendezvous_cpu.py.
+    stage ($MFUOCO_DIST_STAGE): several pipeline stages per call -- 40 statements over 3 ranks in stages of 5 per rank: slabs of 14, 14, 12 = stages of 15, 15, 10 (rank 2
+    contributes 2 to the last); 41 over 4 ranks in stages of 4: slabs of 11, 11, 11, 8 = stages of 16, 16, 9 (rank 3 owns none of the last)."""
     name = "mfuoco_test_%d_%d" % (os.getpid(), world)
-    procs = [subprocess.Popen([_sharded_exe(), str(count)], env=_rank_env(rk, world, MFUOCO_REHEARSAL_SHM=name, MFUOCO_SHARE_GPU="1"),
+    extra = {"MFUOCO_DIST_STAGE": stage} if stage is not None else {}
+    procs = [subprocess.Popen([_sharded_exe(), str(count)], env=_rank_env(rk, world, MFUOCO_REHEARSAL_SHM=name, MFUOCO_SHARE_GPU="1", **extra),
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for rk in range(world)]
     outs = []
     try:

@@ -1,5 +1,5 @@
-"""three mfh_prove_batch steps of 992 statements at the default instance, for rocprofv3 --kernel-trace (tools/step_breakdown.py). dev tool.
-usage: python tools/batch_prof.py [merge 0|1]"""
+"""four mfh_prove_batch steps of $BATCH_PROF_NB (default 1020) statements at the default instance, for rocprofv3 --kernel-trace (tools/step_breakdown.py). dev tool.
+usage: python tools/batch_prof.py [merge 0|1]      $MFUOCO_MM_PACK=0: int32 partial products (the round-5 epilogue)"""
 import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,7 +13,9 @@ inst = bench.build_instance(mf, ctx, torch, p, 20260101)
 ctx.ssp_prepare(inst["d_ssp"])
 d_crs = ctx.setup(inst["d_ssp"], inst["alpha"], inst["beta"], inst["s"], inst["sk"], inst["err"])
 rng = np.random.default_rng(5)
-nb = 992
+nb = int(os.environ.get("BATCH_PROF_NB", "1020"))
+if os.environ.get("MFUOCO_MM_PACK") == "0":
+    ctx.set_mm_pack(False)
 ctx.set_batch_launch(8, bool(int(sys.argv[1])) if len(sys.argv) > 1 else True)
 if os.environ.get("MFUOCO_MM_WAVE1") == "1":
     ctx.set_mm_stream(1, 2, 0, 0)
