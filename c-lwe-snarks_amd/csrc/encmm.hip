@@ -236,7 +236,7 @@ template <int LOGQ>
 struct DG {
   static constexpr int ELB = EG<LOGQ>::L * 8;          // bytes of a value in memory (96 | 184)
   static constexpr int RT = LOGQ == 736 ? DEC_RT : 1;  // row tiles (16 rows) per wave
-  static constexpr int WAVES = DEC_WAVES, ROWS = WAVES * RT * 16, GK = DEC_GK;  // k-steps per group
+  static constexpr int WAVES = DEC_WAVES, ROWS = WAVES * RT * 16, GK = LOGQ == 736 || DEC_GK <= 4 ? DEC_GK : 4;  // k-steps per group (logq 1472: twice the fragments per k-step, 4 at most fit the LDS)
 };
 
 template <int LOGQ>

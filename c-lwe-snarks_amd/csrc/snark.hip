@@ -1224,29 +1224,54 @@ int mfh_prove_batch_finish(mfh_ctx *c, const uint8_t *d_crs_c8, uint32_t nstmt, 
   for (uint32_t b = 0; b < nstmt; b++)
     if (h_delta[b] >= P32) { c->err = "delta must be < p"; return MFH_EINVAL; }
   if (maglen + 4 > (size_t)(c->P.logq / 64) * 8) { c->err = "smudge magnitude too wide"; return MFH_EINVAL; }  // before delta ct_t is added
-  const uint32_t n = c->P.n;
+  const uint32_t n = c->P.n, KW = 2 * (c->P.logq / 64);
   const size_t ctl = (size_t)(n + 1) * ((c->P.logq + 63) / 64);
   HIP_TRY(c, hipSetDevice(c->device));
+  const uint32_t cap = std::min(nstmt, BSG);
   BatchScratch B;
-  int rc = batch_scratch(c, std::min(nstmt, BSG), 0, B);
+  int rc = batch_scratch(c, cap, 0, B, 1, cap);
   if (rc) return rc;
   rc = batch_ct_t(c, d_crs_c8, B);
   if (rc) return rc;
+  // Everything the host contributes to the call -- per chunk of up to BSG statements the deltas, the smudging terms u p of all five draws (schoolbook by 32-bit words,
+  // src/lwe.c:65-76) and their signs -- is staged in ONE pinned buffer taken once, so the call queues its copies and kernels and returns: the host does not wait for
+  // the GPU to reach this call between two smudging passes (it did until round 6, which held a pipelined caller -- mfuoco_prover_batch_sharded -- to the GPU's pace).
+  // (pin_smudge, not the pin_cw the row work stages its witness bits in: a caller that queues finish(k) behind rows(k + 1) would otherwise wait in rows(k + 2) for finish(k)'s copy)
+  const size_t per = 4 + (size_t)5 * KW * 4 + 5, total = (size_t)nstmt * per + 4 * (((size_t)nstmt + BSG - 1) / BSG);
+  uint8_t *st = (uint8_t *)pin_acquire(c, c->pin_smudge, total);
+  if (!st) return MFH_ENOMEM;
+  size_t at = 0;
   for (uint32_t s0 = 0; s0 < nstmt; s0 += BSG) {
     const uint32_t sg = std::min(BSG, nstmt - s0);
     uint64_t *sproofs = d_proofs + (size_t)s0 * 5 * ctl;
-    uint32_t *h_dl = (uint32_t *)pin_acquire(c, c->pin_cw, (size_t)sg * 4);
-    if (!h_dl) return MFH_ENOMEM;
+    uint32_t *h_dl = (uint32_t *)(st + at), *up = h_dl + sg;
+    uint8_t *sn = (uint8_t *)(up + (size_t)sg * 5 * KW);
     memcpy(h_dl, h_delta + s0, (size_t)sg * 4);
+    for (size_t i = 0; i < (size_t)sg * 5; i++) {
+      const uint8_t *mag = h_smudge_mag + ((size_t)s0 * 5 + i) * maglen;
+      uint64_t carry = 0;
+      for (uint32_t l = 0; l < KW; l++) {
+        uint32_t w = 0;
+        const size_t o = (size_t)l * 4;
+        if (o < maglen) memcpy(&w, mag + o, std::min<size_t>(4, maglen - o));
+        const uint64_t t = (uint64_t)w * P32 + carry;
+        up[i * KW + l] = (uint32_t)t;
+        carry = t >> 32;
+      }
+    }
+    memcpy(sn, h_smudge_sign + (size_t)s0 * 5, (size_t)sg * 5);
+    at += ((size_t)sg * per + 3) & ~(size_t)3;
     HIP_TRY(c, hipMemcpyAsync(B.CW, h_dl, (size_t)sg * 4, hipMemcpyHostToDevice, c->stream));
-    pin_release(c, c->pin_cw);
+    HIP_TRY(c, hipMemcpyAsync(B.SMU, up, (size_t)sg * 5 * KW * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(B.SMS, sn, (size_t)sg * 5, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_bw_add_delta_ct, dim3((n + 1 + 255) / 256, sg), dim3(256), 0, c->stream, sproofs, B.CT_T, (const uint32_t *)B.CW, n + 1,
                        (c->P.logq + 63) / 64, 2 * (c->P.logq / 64));
     HIP_TRY(c, hipGetLastError());
-    rc = batch_smudge(c, sproofs, sg, h_smudge_mag + (size_t)s0 * 5 * maglen, maglen, h_smudge_sign + (size_t)s0 * 5);
-    if (rc) return rc;
+    rc = batch_smudge_staged(c, B, sproofs, 0, sg);
+    if (rc) break;
   }
-  return MFH_OK;
+  pin_release(c, c->pin_smudge);
+  return rc;
 }
 
 }  // extern "C"
