@@ -156,8 +156,8 @@ def prove_batch_sharded(ctx, d_crs, d_ssp, witness_bits_list, deltas, smudge_mag
     PIPELINED in stages (stage_plan: world x sper <= 255 statements, sper from every rank's slab): with device tensors on RCCL the collectives are issued
     async_op -- they run on the backend's stream -- in the order  C0 A0 | C1 A1 P0 L0 R0 | C2 A2 P1 L1 R1 F0 | ...  (C chain, A all-to-all, P row shares, L lanes,
     R reduce-scatter, F finish), so stage k + 1's all-to-all runs under the row work of stage k and stage k's reduce-scatter under the chain and row work behind it.
-    Bytes handed to the backend are those of the one-shot sequence (stage=0); the call is one stage when no image share is registered with the context (the row
-    work would expand its transient image once per stage).
+    Bytes handed to the backend are those of the one-shot sequence (stage=0).  When no image share is registered with the context a call of several stages expands
+    the rank's shares itself, once (the row work would otherwise expand its transient image once per stage).
     witness_by_cols (default: on for a generator-defined SSP, d_ssp = None, where the witness pass is the chain's cost): the chain is cut
     in two -- every rank computes its COEFFICIENT RANGE [d r / world, d (r+1) / world) of w of the stage's statements (1 / world of the
     generation of the selected rows, no reduction), one more all-to-all (4 B x d x nb / world sent per rank) hands every statement's
@@ -181,9 +181,18 @@ def prove_batch_sharded(ctx, d_crs, d_ssp, witness_bits_list, deltas, smudge_mag
     align = getattr(ctx, "witness_cols_align", 128)
     use_cols = (d_ssp is None) if witness_by_cols is None else bool(witness_by_cols)
     use_cols = use_cols and all(a % align == 0 and b % align == 0 for a, b in shares)
-    if stage is None and getattr(ctx, "_resident_mm", None) is None:
-        stage = 0  # no image share registered: one stage, one transient expansion
     sper, nst = stage_plan(nb, world, stage)
+    # No image share registered with the context: every mfh_prove_batch_partial call would expand its own transient image -- once per STAGE.  A call of several stages
+    # therefore expands the rank's shares itself, once, streams them for all its stages and drops the registration at the end ("from the compressed CRS", like
+    # mfh_prove_batch's transient image; the buffer is kept in `bufs`).
+    own_image = None
+    if nst > 1 and getattr(ctx, "_resident_mm", None) is None:
+        if (p.n * p.ctb) % 8 == 0:
+            own_image = ctx.crs_expand_mm_share(d_crs, rank, world, out=bufs.get("bimage"))
+            ctx.set_resident_mm_share(own_image, rank, world)
+            bufs["bimage"] = own_image
+        else:
+            sper, nst = stage_plan(nb, world, 0)  # (rows the matrix-core image cannot hold: the groups regenerate the keystream; one stage)
     lps = 5 * (p.n + 1) * p.lanes  # lanes per statement
     dev = ctx.device
     proofs = ctx.empty(count * 5 * p.ct_limbs * 8) if count else ctx.empty(0)
@@ -255,6 +264,8 @@ def prove_batch_sharded(ctx, d_crs, d_ssp, witness_bits_list, deltas, smudge_mag
                 oi = s_["own_ids"]
                 ctx.prove_batch_finish(d_crs, [deltas[i] for i in oi], [smudge_mags[i] for i in oi], [smudge_signs[i] for i in oi], out, maglen)
             st[k] = None
+    if own_image is not None:
+        ctx.set_resident_mm_share(None, rank, world)
     return first, count, proofs
 
 

@@ -43,6 +43,21 @@ def main(out_path, port):
     first, count, proofs = mfdist.prove_batch_sharded(ctx, d_crs, inst["d_ssp"], bits, deltas, mags, signs, 0, 1, bufs=bufs, force_collectives=True)
     if not (first == 0 and count == nb and torch.equal(proofs, want)):
         fails.append("prove_batch_sharded != prove_batch (reused, grown buffers)")
+    # the pipelined form (round 6): stages of 7 statements -- 6 of them, the collectives issued async_op on RCCL's own stream and waited for by the compute stream only
+    # where their result is used --, first with the call's own transient image share (none is registered: expanded once for the six stages), then with a registered one
+    for registered in (False, True):
+        if registered:
+            ctx.set_resident_mm_share(ctx.crs_expand_mm_share(d_crs, 0, 1), 0, 1)
+        before = mfdist.collectives_snapshot().get("reduce_scatter_tensor", {}).get("calls", 0)
+        fs, cs_, prs = mfdist.prove_batch_sharded(ctx, d_crs, inst["d_ssp"], bits, deltas, mags, signs, 0, 1, bufs=bufs, force_collectives=True, stage=7)
+        torch.cuda.synchronize()
+        if not (fs == 0 and cs_ == nb and torch.equal(prs, want)):
+            fails.append(f"prove_batch_sharded(stage=7, image share {'registered' if registered else 'transient'}) != prove_batch")
+        if mfdist.collectives_snapshot()["reduce_scatter_tensor"]["calls"] - before != 6:
+            fails.append("stage=7 over 37 statements should issue 6 reduce-scatters")
+        if not registered and getattr(ctx, "_resident_mm", None) is not None:
+            fails.append("the call's transient image share stayed registered")
+    ctx.set_resident_mm_share(None, 0, 1)
     one = mfdist.prove_sharded(ctx, d_crs, inst["d_ssp"], bits[0], deltas[0], mags[0], signs[0], 0, 1, force_collectives=True)
     if not torch.equal(one, ctx.prove(d_crs, inst["d_ssp"], bits[0], deltas[0], mags[0], signs[0])):
         fails.append("prove_sharded != prove")

@@ -136,7 +136,16 @@ class _LinearCtx:
         self.finished = []
         self.device = torch.device("cpu")
         self.partial_calls = 0
-        self._resident_mm = "image share" if resident else None  # (without one prove_batch_sharded runs the call as ONE stage)
+        self._resident_mm = "image share" if resident else None  # (without one a call of several stages expands the rank's shares itself, once)
+        self.expansions = 0
+        self.params.ctb = 8
+
+    def crs_expand_mm_share(self, d_crs, rank, world, out=None):
+        self.expansions += 1
+        return "transient share"
+
+    def set_resident_mm_share(self, image, rank, world):
+        self._resident_mm = image
 
     def empty(self, nbytes):
         return self.torch.empty(int(nbytes), dtype=self.torch.uint8)
@@ -219,12 +228,14 @@ def _batch_worker(rank, world, port, out_dir, nb, by_cols=False, stage=None):
     bits = [bytes([(37 * b + 1) & 0xFF, (11 * b) & 0xFF]) for b in range(nb)]
     mfdist.collectives_snapshot(reset=True)
     first, count, proofs = mfdist.prove_batch_sharded(ctx, None, None, bits, ids, [b""] * nb, [b""] * nb, rank, world, witness_by_cols=by_cols,
-                                                      stage=None if stage == "no image" else stage)
+                                                      stage=2 if stage == "no image" else stage)
     per = -(-nb // world)
     ok = first == min(nb, rank * per) and count == min(nb, first + per) - first and ctx.finished == ids[first:first + count]
     # stages: as planned (one when no image share is registered), one row-work call each; the bytes handed to the backend do not depend on the cut
-    sper, nst = mfdist.stage_plan(nb, world, 0 if stage == "no image" else stage)
+    sper, nst = mfdist.stage_plan(nb, world, 2 if stage == "no image" else stage)
     ok = ok and ctx.partial_calls == nst
+    # no image share registered: a call of several stages expands the rank's shares once, streams them for every stage and leaves nothing registered
+    ok = ok and ctx.expansions == (1 if stage == "no image" and nst > 1 else 0) and (stage != "no image" or ctx._resident_mm is None)
     snap = mfdist.collectives_snapshot()
     lps = 5 * (p.n + 1) * p.lanes
     ok = ok and snap["reduce_scatter_tensor"] == {"calls": nst, "bytes": per * world * lps * 8}
@@ -255,7 +266,7 @@ def test_prove_batch_sharded_sequencing_gloo(tmp_path, world, nb, by_cols, stage
     none), 5 statements = three ranks without any; row shares of 13 and 9 rows over 8 ranks are 1 or 2 rows each.
     stage: statements per rank and pipeline stage (None = the plan of a real call -- one stage at these sizes --, 1 / 2 = several stages, the last one ragged and
     some ranks empty in it: 20 statements over 8 ranks in stages of 2 are 16 + 4 with ranks 0 .. 5 holding one more and rank 6 done; 0 = the one-shot sequence;
-    "no image" = no image share registered: one stage whatever the plan says)"""
+    "no image" = no image share registered with the context: the call (stages of 2) expands the rank's shares itself, once, and unregisters them at the end)"""
     import torch.multiprocessing as mp
 
     port = _free_port()
