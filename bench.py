@@ -610,6 +610,8 @@ def main():
         return {"kernel": "k_expand_mm (AES-256-CTR expansion of a CRS region or row slab, written in MFMA A-fragment order: lane = row, transposition on the matrix cores)", "launches": n_,
                 "avg_launch_ms": avg, "rows_per_launch": rows, "ms_per_step": ms_ / (steps_ or args.steps), "aes_gblocks_per_s": gblk_,
                 "aes_ceiling": aes_ceiling("k_expand_mm", gblk_),
+                "note": ("inside mfh_prove_batch the first super-group's chain (witness GEMM + polynomial step, 1.8 ms alone) runs beside these launches and shares their CUs; "
+                         "alone the three launches take 10.1 ms = 73 Gblock/s (profiles/r06_step_breakdown.txt)"),
                 "write_gbs": rows * tile_bytes_per_row / (avg * 1e-3) / 1e9}
 
     # ---- batch mode: --batch statements per GPU per step through mfh_prove_batch (disjoint statements per rank, no collective)
@@ -694,10 +696,28 @@ def main():
             resident_b = {"value": world * nb * args.steps / el_rb, "unit": "proofs/s", "ms_per_step": el_rb / args.steps * 1e3,
                           "proofs_identical_to_headline": same_rb, "crs_expand_s": expand_mm_s, "image_bytes_per_rank": img_bytes,
                           "roofline": mmstream_roofline(kt_r, el_rb / args.steps * 1e3)}
+        # the same call with twice the statements (8 super-groups): the per-call CRS expansion is shared by twice the proofs.  Reported beside the headline, never as it:
+        # the headline stays the 1020-statement call of rounds 3 - 5.
+        larger = None
+        if not big and not args.no_resident and world == 1:
+            nl = 2 * nb
+            lb, ld, lm, lsg = b_bits * 2, b_delta * 2, b_mags * 2, b_signs * 2
+            out_l = ctx.prove_batch(d_crs, d_ssp_b, lb, ld, lm, lsg)
+            torch.cuda.synchronize()
+            lsteps = max(2, args.steps // 4)
+            tl = time.perf_counter()
+            for _ in range(lsteps):
+                ctx.prove_batch(d_crs, d_ssp_b, lb, ld, lm, lsg, out=out_l)
+            torch.cuda.synchronize()
+            el_l = time.perf_counter() - tl
+            larger = {"statements_per_call": nl, "value": nl * lsteps / el_l, "unit": "proofs/s", "ms_per_call": el_l / lsteps * 1e3, "calls": lsteps,
+                      "second_half_identical_to_the_headline_call": bool(torch.equal(out_l.view(2, -1)[1], out_b.view(-1))),
+                      "note": "one mfh_prove_batch call of twice the headline's statements: same kernels, the 10 - 12 ms CRS expansion paid once per call"}
+            del out_l, lb, ld, lm, lsg
         used_image = kt_b["evalmm_resident"][0] + kt_b["mmstream_rounds"][0] > 0
         batched = {"value": world * nb * args.steps / el_b, "unit": "proofs/s", "ms_per_step": el_b / args.steps * 1e3, "statements_per_gpu_per_step": nb,
                    "valid_accepted_invalid_rejected_and_identical_to_single_proof_path": all_ok, "resident_crs": resident_b,
-                   "regenerate_per_group": regen, "device_verifier_proofs_per_s": verify_per_s,
+                   "regenerate_per_group": regen, "call_of_twice_the_statements": larger, "device_verifier_proofs_per_s": verify_per_s,
                    "transient_image_bytes_per_rank": image_bytes if used_image else 0, "crs_expansion": expand_info(kt_b["expandmm"]),
                    "roofline": mmstream_roofline(kt_b, el_b / args.steps * 1e3) if used_image else evalmm16_roofline(kt_b["evalmm"])}
 
@@ -971,6 +991,7 @@ def main():
             "transient_image_bytes_per_rank": batched["transient_image_bytes_per_rank"] if batched else None,
             "regenerate_per_group_batch": batched["regenerate_per_group"] if batched else None,
             "resident_crs_batch": batched["resident_crs"] if batched else None,
+            "call_of_twice_the_statements": batched["call_of_twice_the_statements"] if batched else None,
             "device_verifier_proofs_per_s": batched["device_verifier_proofs_per_s"] if batched else None,
             "row_sharded_batch": sharded_b,
             "single_proof_row_sharded": single_rows,
