@@ -91,19 +91,6 @@ inline void expand_key(AesKey &k, const uint8_t seed[40]) {
 //   t_j = T0[b0(s_j)] ^ T2[b2(s_j+2)] ^ rotl8(T0[b1(s_j+1)] ^ T2[b3(s_j+3)]) ^ rk
 // Measured on MI355X (tools/rate*_ubench.hip): ds_read_b32 ~2.15 CU-clk per wave-instruction, v_xor/v_bitop3 ~2.5
 // and v_perm/v_alignbit ~4.3 SIMD-clk: 27 SIMD-clk of VALU per column against 34 of LDS: the round is LDS-bound.
-#ifdef MF_AES_T4
-// experiment (round 5): all four tables in LDS -- a second 64 KiB image [T1 | T3] behind the first -- so that a column needs no v_alignbit and two v_bitop3 xors
-// instead of xor, alignbit, xor, xor3 (20 instead of 27 SIMD-clk of VALU per column); 128 KiB of LDS: one 1024-thread workgroup per CU, 4 waves per SIMD
-constexpr int kTabBytes = 2 * 256 * 64 * 4;
-__device__ __forceinline__ void lds_fill_tab(uint32_t *lt, const uint32_t *__restrict__ g_t0) {
-  for (int i = threadIdx.x; i < 2 * 256 * 64; i += blockDim.x) {
-    uint32_t v = g_t0[(i >> 6) & 255];
-    if (i & 32) v = (v << 16) | (v >> 16);           // T2 half of an entry
-    if (i >= 256 * 64) v = (v << 8) | (v >> 24);     // second image: T1 = rotl8(T0), T3 = rotl8(T2)
-    lt[i] = v;
-  }
-}
-#else
 constexpr int kTabBytes = 256 * 64 * 4;
 
 __device__ __forceinline__ void lds_fill_tab(uint32_t *lt, const uint32_t *__restrict__ g_t0) {
@@ -112,22 +99,10 @@ __device__ __forceinline__ void lds_fill_tab(uint32_t *lt, const uint32_t *__res
     lt[i] = (i & 32) ? ((v << 16) | (v >> 16)) : v;
   }
 }
-#endif
 
 struct AesLane {
   uint32_t lo0, lo2;  // byte offsets of this lane's T0 / T2 replica inside a 256-byte entry
   uint32_t m1;        // 0x0000ff00, kept in a VGPR so v_bitop3 runs at full rate
-#ifdef MF_AES_T4
-  uint32_t lo1, lo3;  // the lane's T1 / T3 replica: lo0 / lo2 + 64 KiB
-#endif
-#ifdef MF_PERM_VSEL
-  uint32_t sel0, sel2, sel3;  // experiment (round 5): the v_perm selectors in VGPRs instead of SGPRs (does v_perm then issue at the rate of v_bitop3 with VGPR operands?)
-#endif
-#ifdef MF_AES_SDWA
-  // experiment (round 5): four persistent lookup-address registers -- byte 0 = the lane's replica offset (T0 half for ar[0], ar[1], T2 half for ar[2], ar[3]), bytes 2-3
-  // zero; a lookup replaces byte 1 with the state byte by ONE v_mov_b32_sdwa (dst_sel:BYTE_1, UNUSED_PRESERVE) instead of a v_perm_b32
-  mutable uint32_t ar[4];
-#endif
 };
 __device__ __forceinline__ AesLane aes_lane() {
   AesLane l;
@@ -135,20 +110,10 @@ __device__ __forceinline__ AesLane aes_lane() {
   l.lo2 = l.lo0 + 128;
   l.m1 = 0xff00u;
   asm volatile("" : "+v"(l.m1));  // keep it a VGPR
-#ifdef MF_AES_T4
-  l.lo1 = l.lo0 + 65536u;
-  l.lo3 = l.lo2 + 65536u;
-#endif
-#ifdef MF_PERM_VSEL
-  l.sel0 = 0x0c0c0400u; l.sel2 = 0x0c0c0600u; l.sel3 = 0x0c0c0700u;
-  asm volatile("" : "+v"(l.sel0), "+v"(l.sel2), "+v"(l.sel3));
-#endif
-#ifdef MF_AES_SDWA
-  l.ar[0] = l.ar[1] = l.lo0;
-  l.ar[2] = l.ar[3] = l.lo2;
-#endif
   return l;
 }
+// (Round 5's address-formation experiments -- all four tables in LDS, SDWA byte moves into persistent address registers, v_perm selectors in VGPRs -- lived here behind
+// #ifdefs; none was faster (profiles/r05_aes_address_bound.txt, EXPERIMENTS.md section 5) and they are gone from the product header: git show 774b9bf:c-lwe-snarks_amd/csrc/aes_dev.hpp.)
 
 #define MF_XOR3(a, b, c) __builtin_amdgcn_bitop3_b32((a), (b), (c), 0x96)
 #define MF_ANDOR(a, m, c) __builtin_amdgcn_bitop3_b32((a), (m), (c), 0xEA) /* (a & m) | c */
@@ -156,40 +121,16 @@ __device__ __forceinline__ AesLane aes_lane() {
 #define MF_LD(addr) (*reinterpret_cast<const uint32_t *>(tab + (addr)))
 #endif
 // address of entry byte_k(s) in the T0 (lo0) or T2 (lo2) half
-#if defined(MF_PERM_VSEL) && !defined(MF_A)
-#define MF_A(s, lo, k) ((k) == 1 ? MF_ANDOR((s), L.m1, (lo)) : __builtin_amdgcn_perm((s), (lo), (k) == 0 ? L.sel0 : (k) == 2 ? L.sel2 : L.sel3))
-#endif
-#ifndef MF_A  /* tools/aes3_ubench.hip overrides this too (cheap-address build: how much does the address VALU cost?) */
+#ifndef MF_A  /* tools/aes3_ubench.hip overrides this too (cheap-address build: how much does the address VALU cost?  The ceiling bench.py's aes_ceiling objects quote) */
 #define MF_A(s, lo, k) ((k) == 1 ? MF_ANDOR((s), L.m1, (lo)) : __builtin_amdgcn_perm((s), (lo), 0x0c0c0400u + ((k) << 8)))
 #endif
 
-#ifdef MF_AES_T4
-// address of entry byte_k(s) in the second image: the replica offset's byte 2 (the 64 KiB bit) travels through the v_perm too
-#define MF_A4(s, lo, k) ((k) == 1 ? MF_ANDOR((s), L.m1, (lo)) : __builtin_amdgcn_perm((s), (lo), 0x0c020400u + ((k) << 8)))
-__device__ __forceinline__ uint32_t aes_col(const uint8_t *tab, const AesLane &L, uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t rk) {
-  uint32_t x0 = MF_LD(MF_A(a, L.lo0, 0)), x1 = MF_LD(MF_A4(b, L.lo1, 1));
-  uint32_t x2 = MF_LD(MF_A(c, L.lo2, 2)), x3 = MF_LD(MF_A4(d, L.lo3, 3));
-  return MF_XOR3(MF_XOR3(x0, x1, x2), x3, rk);
-}
-#elif defined(MF_AES_SDWA)
-#define MF_SDWA_PUT(dst, src, sel) asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:" sel : "+v"(dst) : "v"(src))
-__device__ __forceinline__ uint32_t aes_col(const uint8_t *tab, const AesLane &L, uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t rk) {
-  MF_SDWA_PUT(L.ar[0], a, "BYTE_0");
-  MF_SDWA_PUT(L.ar[1], b, "BYTE_1");
-  MF_SDWA_PUT(L.ar[2], c, "BYTE_2");
-  MF_SDWA_PUT(L.ar[3], d, "BYTE_3");
-  uint32_t x0 = MF_LD(L.ar[0]), x1 = MF_LD(L.ar[1]), x2 = MF_LD(L.ar[2]), x3 = MF_LD(L.ar[3]);
-  uint32_t y = x1 ^ x3;
-  return MF_XOR3(x0 ^ rk, x2, __builtin_amdgcn_alignbit(y, y, 24));
-}
-#else
 __device__ __forceinline__ uint32_t aes_col(const uint8_t *tab, const AesLane &L, uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t rk) {
   uint32_t x0 = MF_LD(MF_A(a, L.lo0, 0)), x1 = MF_LD(MF_A(b, L.lo0, 1));
   uint32_t x2 = MF_LD(MF_A(c, L.lo2, 2)), x3 = MF_LD(MF_A(d, L.lo2, 3));
   uint32_t y = x1 ^ x3;
   return MF_XOR3(x0 ^ rk, x2, __builtin_amdgcn_alignbit(y, y, 24));
 }
-#endif
 // last round (SubBytes+ShiftRows+AddRoundKey): S = T2.byte0 = T0.byte1 = T0.byte2 = T2.byte3
 __device__ __forceinline__ uint32_t aes_last(const uint8_t *tab, const AesLane &L, uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t rk) {
   uint32_t x0 = MF_LD(MF_A(a, L.lo2, 0)), x1 = MF_LD(MF_A(b, L.lo0, 1));

@@ -54,32 +54,25 @@ int main() {
   const char *n = "cheap-addr";
 #elif defined(SHIFT_ADDR)
   const char *n = "shift-addr";
-#elif defined(MF_AES_SDWA)
-  const char *n = "sdwa-addr";
-#elif defined(MF_AES_T4)
-  const char *n = "4-tables";
-#elif defined(MF_PERM_VSEL)
-  const char *n = "vgpr-sel";
 #else
   const char *n = "real";
 #endif
-#ifdef MF_AES_T4  // 128 KiB of tables: one workgroup per CU
-  run<1, 0>(n, key, d_t0, d_out, 256, 1);
-  run<2, 0>(n, key, d_t0, d_out, 512, 1);
-  run<4, 0>(n, key, d_t0, d_out, 1024, 1);
-#else
   run<1, 94240>(n, key, d_t0, d_out, 256, 1);
   run<2, 94240>(n, key, d_t0, d_out, 512, 1);
   run<4, 94240>(n, key, d_t0, d_out, 1024, 1);
   run<4, 0>(n, key, d_t0, d_out, 512, 2);
   run<8, 0>(n, key, d_t0, d_out, 1024, 2);
-#endif
-  {  // digest of the last launch's outputs: builds that compute the real keystream must agree (a timing-only build is recognisable)
-    static uint32_t h[256 * 2 * 1024];
+  {  // digest of ONE FIXED launch shape (256 workgroups of 256 threads, 256 blocks per lane), whatever shapes the variant timed above: builds that compute the real
+     // keystream agree on it, a timing-only build is recognisable.  (Round 5 digested "the last launch", whose shape differed between variants: its 4-table digest
+     // proved nothing either way -- VERDICT r5; the 4-table / SDWA / VGPR-selector variants are gone from csrc/aes_dev.hpp, their timings stand in
+     // profiles/r05_aes_address_bound.txt with that caveat.)
+    hipMemset(d_out, 0, 256 * 2 * 1024 * 4);
+    hipLaunchKernelGGL((k_bench<1, 0>), dim3(256), dim3(256), 0, 0, key, d_t0, 256u, d_out);
+    static uint32_t h[256 * 256];
     hipMemcpy(h, d_out, sizeof h, hipMemcpyDeviceToHost);
     uint64_t dg = 0;
     for (size_t i = 0; i < sizeof h / 4; i++) dg = dg * 0x9E3779B97F4A7C15ull + h[i];
-    printf("%-10s digest %016llx\n", n, (unsigned long long)dg);
+    printf("%-10s digest %016llx (fixed shape)\n", n, (unsigned long long)dg);
   }
   return 0;
 }
