@@ -55,7 +55,7 @@ json.dump({"commit": commit, "kernels": res}, open(os.path.join(out_dir, f"{tag}
 # doubled -- an upper bound where the reads are not wide streams)
 TRAFFIC = [
     ("k_mmstream_p(", "traffic_mmstream.json", "k_mmstream_p", "persistent launches over the whole S and AS regions for 8 + 8 groups of 63 / 64 coefficient vectors (a super-group of 255 proofs).  Algorithmic: "
-     "2 x 4.24 GB of A fragments once + 16 x 8 MB of digits read, 16 x 133 MB of int32 partial products written.  The workgroups consume 16 x 4.24 GB of fragments and 8096 x 8 MB of digit "
+     "2 x 4.24 GB of A fragments once + 16 x 8 MB of digits read, 16 x 33 MB of recombined partial products written (16-byte records per byte-position quad and vector: round 6; int32: 16 x 133 MB).  The workgroups consume 16 x 4.24 GB of fragments and 8096 x 8 MB of digit "
      "fragments out of the L2s; what an XCD's 32 concurrent workgroups (4 tile groups x 8 groups of one region) can share bounds the L2 misses at 4048 x (8.39 / 8 + 8 / 4) MB = 12.3 GB per 8 groups "
      "(24.7 GB per launch): DESIGN.md 4.2c"),
     ("k_mmstream_pb(", "traffic_mmstream_bw.json", "k_mmstream_pb", "b_w of the call's super-groups (4 groups of 255 one-byte columns) in one persistent launch over the BT+BV image (2.83 GB of fragments)"),
@@ -65,8 +65,8 @@ TRAFFIC = [
     ("k_encrypt_mm", "traffic_encryptmm.json", "k_encrypt_mm", "reads the Toeplitz(sk) fragments (12.7 MB per head value, from L2 after the first workgroups), writes 384 B of int32 partial sums per row and column chunk"),
     ("k_decrypt_mm", "traffic_decryptmm.json", "k_decrypt_mm", "65 536 full ciphertexts of 141 216 B streamed once (9.25 GB), Toeplitz(sk) fragments through LDS (13.2 MB, L2), 384 B of int32 partial sums "
      "written per row and column chunk"),
-    ("k_witness_mm8q(", "traffic_witnessmm.json", "k_witness_mm8q", "one read of the SSP image in fragment order (2.86 GB) per 248 statements, 248 x 128 KB of w written"),
-    ("k_evalmm_finish_groups", "traffic_evalmm_finish.json", "k_evalmm_finish_groups", "reads the int32 partial products of a launch's 16 groups (16 x 133 MB), writes their ciphertexts"),
+    ("k_witness_mm8q(", "traffic_witnessmm.json", "k_witness_mm8q", "one read of the SSP image in fragment order (2.86 GB) per 255 statements, 255 x 128 KB of w written"),
+    ("k_evalmm_finish_groups", "traffic_evalmm_finish.json", "k_evalmm_finish_groups", "reads the recombined partial products of a launch's 16 groups (16 x 33 MB of 16-byte records; 16 x 133 MB of int32 before round 6), writes their ciphertexts"),
     ("k_ntt_lds_mul8", "traffic_ntt_lds.json", "k_ntt_lds_mul8", "2048-point blocks of 248 x 3 transforms: forward low stages, pointwise product, inverse low stages"),
     ("void k_eval<736, 2>", "traffic_eval2.json", "k_eval<736,2>", "the single-proof kernel: ~0 HBM bytes by construction (CRS b's, coefficients, partials)"),
     ("void k_mac_resident<736, 2>", "traffic_mac2.json", "k_mac_resident<736,2>", "the resident single-proof regime: one read of the expanded region"),
