@@ -218,7 +218,8 @@ int mfh_set_expand_path(mfh_ctx *ctx, int path);
  * With more than 31 proofs and no image registered, the call first expands the CRS into a transient image of
  * mfh_crs_mm_image_bytes bytes (scratch kept by the context; expanded again by every call) and streams it for every group instead of
  * running AES once per group; if that scratch cannot be allocated, or after mfh_set_batch_image(ctx, 0) (which also frees it), every
- * group regenerates the keystream.  Same proofs either way.  The call only QUEUES its work (about 2.5 ms of host time per 1020 statements at the default instance): it returns
+ * group regenerates the keystream.  Same proofs either way.  The call only QUEUES its work (about 2.5 ms of host time per 1020 statements at the default instance, for calls of up to 8
+ * super-groups = 2040 statements: the witness pass stages through a ring of 8 pinned buffers, and a longer call waits for the copy of super-group k - 8 before it stages k): it returns
  * long before the proofs exist -- mfh_sync, or mfh_prove_batch_stream_wait below, before d_proofs is read. */
 int mfh_set_batch_image(mfh_ctx *ctx, int enabled);
 /* Row slabs of mfh_prove_batch.  A call whose matrix-core image does not fit the GPU's memory (363 GB at 2^20 constraints) cuts the CRS
