@@ -1382,7 +1382,7 @@ __global__ __launch_bounds__(512) void k_witness_mm8q_prg(const uint32_t *__rest
 #endif
     K++;
   };
-  for (; K + 4 <= K1;) {
+  while (K + 4 <= K1) {  // (K advances inside step)
     step(0, sta);
     step(1, stb);
     step(2, sta);
@@ -1474,7 +1474,7 @@ __global__ __launch_bounds__(512) void k_witness_mm8q(const v4i *__restrict__ ss
     __syncthreads();
     K++;
   };
-  for (; K + PF <= K1;) {
+  while (K + PF <= K1) {  // (K advances inside step)
 #pragma unroll
     for (int i = 0; i < PF; i++) step(i);
   }

@@ -106,7 +106,6 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
   // (kept as ONE fragment with the byte set in every lane row and masked per use: sixteen registers less than four fragments)
   const uint32_t one = 1u << (8 * (c16 & 3));
   const v4i selb = {(int)((c16 >> 2) == 0 ? one : 0u), (int)((c16 >> 2) == 1 ? one : 0u), (int)((c16 >> 2) == 2 ? one : 0u), (int)((c16 >> 2) == 3 ? one : 0u)};
-  const uint32_t lane16 = lane * 16;
   auto emit = [&](uint32_t P, uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3) {
     // P is wave-uniform: the fragment's address is a scalar base + the lane's 16 bytes.  (Opaque to the optimiser, or it hoists the 22
     // pieces' addresses of a period out of the block loop as 64-bit VGPR pairs and spills them.)

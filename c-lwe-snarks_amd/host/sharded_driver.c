@@ -127,6 +127,17 @@ int main(int argc, char **argv)
   tape_seek(BASE_BATCH + STMT_TAPE * first_expected);
   mfuoco_prover_batch_sharded(pis, crs, ssp, wit, count, comm, &first, &nown);
   ok = ok && first == first_expected;
+  { /* the bytes handed to the backend are those of the one-shot sequence however the call was cut into stages ($MFUOCO_DIST_STAGE): every own statement's w | h | v once
+     * through the all-to-all, ceil(count / world) x world statements of 5 x (N + 1) x 13 uint64 lanes into the reduce-scatter */
+    uint64_t c0[4], b0[4];
+    mfuoco_comm_stats(comm, c0, b0);
+    const uint64_t want_a2a = (uint64_t)nown * 3 * GAMMA_D * 4, want_rs = (uint64_t)per * world * 5 * (GAMMA_N + 1) * 13 * 8;
+    if (b0[0] != want_a2a || b0[1] != want_rs) {
+      fprintf(stderr, "rank %d: all-to-all %llu bytes (expected %llu), reduce-scatter %llu (expected %llu)\n", rank, (unsigned long long)b0[0],
+              (unsigned long long)want_a2a, (unsigned long long)b0[1], (unsigned long long)want_rs);
+      ok = 0;
+    }
+  }
   for (size_t k = first; k < first + nown; k++) {
     int same = proof_equal(pis[k], ref[k]);
     int acc = verifier(ssp, vrs, pis[k]);
