@@ -89,7 +89,7 @@ EXPORTS = [
     "mfh_keystream", "mfh_sample_rows", "mfh_ct_add", "mfh_ct_mul_ui", "mfh_ct_addmul_ui", "mfh_eval_rows",
     "mfh_encrypt_rows", "mfh_decrypt", "mfh_ct_smudge", "mfh_ssp_upload", "mfh_witness_poly", "mfh_version",
     "mfh_workspace_bytes", "mfh_last_kernel_ms", "mfh_set_timing", "mfh_set_overlap", "mfh_eval_rows_multi", "mfh_prove_batch", "mfh_crs_mm_image_bytes", "mfh_crs_expand_mm", "mfh_crs_set_resident_mm", "mfh_witness_poly_multi", "mfh_witness_poly_mm", "mfh_poly_h_multi", "mfh_poly_mul", "mfh_poly_add", "mfh_poly_prepare_t",
-    "mfh_ssp_prepare", "mfh_poly_h", "mfh_setup_messages", "mfh_setup", "mfh_prove",
+    "mfh_ssp_prepare", "mfh_poly_h", "mfh_setup_messages", "mfh_setup", "mfh_setup_image", "mfh_prove",
     "mfh_prove_partial", "mfh_prove_finish", "mfh_ct_to_lanes", "mfh_ct_from_lanes", "mfh_lanes_per_value", "mfh_digest128", "mfh_timing_drain", "mfh_timing_busy_ms", "mfh_timing_work_rows", "mfh_set_batch_image", "mfh_set_batch_slabs", "mfh_set_expand_path", "mfh_set_encrypt_path", "mfh_set_batch_launch", "mfh_set_batch_bw", "mfh_set_mm_chunk_rows", "mfh_set_mm_pack", "mfh_set_mm_stream", "mfh_add_dotp", "mfh_set_encrypt_chunks", "mfh_set_witness_per", "mfh_set_eval_path", "mfh_set_decrypt_path", "mfh_decrypt_rows",
     "mfh_crs_mm_share_bytes", "mfh_crs_expand_mm_share", "mfh_crs_set_resident_mm_share", "mfh_batch_chain", "mfh_batch_witness_cols", "mfh_batch_chain_from_w", "mfh_witness_poly_mm_cols", "mfh_prove_batch_partial", "mfh_prove_batch_finish",
     "mfh_resident_row_bytes", "mfh_crs_expand", "mfh_eval_rows_resident", "mfh_crs_set_resident",
@@ -152,6 +152,7 @@ def load_library():
         "mfh_poly_h": (i32, [vp, vp, vp]),
         "mfh_setup_messages": (i32, [vp, vp, u32, u32, u32, vp]),
         "mfh_setup": (i32, [vp, vp, u32, u32, u32, vp, vp, vp]),
+        "mfh_setup_image": (i32, [vp, vp, u32, u32, u32, vp, vp, vp, vp]),
         "mfh_prove": (i32, [vp, vp, vp, ctypes.c_char_p, u32, ctypes.c_char_p, sz, ctypes.c_char_p, vp]),
         "mfh_prove_partial": (i32, [vp, vp, vp, ctypes.c_char_p, u32, u32, u32, vp]),
         "mfh_prove_finish": (i32, [vp, vp, ctypes.c_char_p, sz, ctypes.c_char_p]),
@@ -478,6 +479,14 @@ class Context:
         out = self.empty((2 * p.d + p.m) * p.ctb) if out is None else out
         self._chk(self.lib.mfh_setup(self._h, _ptr(d_ssp), alpha, beta, s, _ptr(d_sk), _ptr(d_err), _ptr(out)))
         return out
+
+    def setup_image(self, d_ssp, alpha, beta, s, d_sk, d_err, out=None, rows=None):
+        """setup() leaving the expanded rows behind: returns (device CRS, row image for set_resident)"""
+        p = self.params
+        out = self.empty((2 * p.d + p.m) * p.ctb) if out is None else out
+        rows = self.empty((2 * p.d + p.m) * self.resident_row_bytes()) if rows is None else rows
+        self._chk(self.lib.mfh_setup_image(self._h, _ptr(d_ssp), alpha, beta, s, _ptr(d_sk), _ptr(d_err), _ptr(out), _ptr(rows)))
+        return out, rows
 
     def prove(self, d_crs, d_ssp, witness_bits: bytes, delta, smudge_mag: bytes, smudge_sign: bytes, maglen=80, out=None):
         """prover() (src/snark.c:117-190): returns 5 ciphertexts h | hat_h | hat_v | v_w | b_w."""

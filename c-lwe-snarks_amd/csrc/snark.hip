@@ -241,6 +241,13 @@ int mfh_setup(mfh_ctx *c, const uint32_t *d_ssp, uint32_t alpha, uint32_t beta, 
   return mfh_encrypt_rows(c, 0, rows, d_sk, c->d_msg, d_err, d_crs_c8);
 }
 
+int mfh_setup_image(mfh_ctx *c, const uint32_t *d_ssp, uint32_t alpha, uint32_t beta, uint32_t s, const uint64_t *d_sk, const uint64_t *d_err,
+                    uint8_t *d_crs_c8, void *d_rows_image) {
+  int rc = mfh_setup(c, d_ssp, alpha, beta, s, d_sk, d_err, d_crs_c8);
+  if (rc || !d_rows_image) return rc;
+  return mfh_crs_expand(c, 0, (size_t)2 * c->P.d + c->P.m, d_crs_c8, d_rows_image);  // (same stream: behind the encryptions that write d_crs_c8)
+}
+
 int mfh_verify(mfh_ctx *c, const uint32_t *d_ssp, uint32_t alpha, uint32_t beta, uint32_t s, const uint64_t *d_sk, const uint64_t *d_proofs,
                size_t count, uint8_t *d_ok) {
   if (!c || !d_sk || (count && (!d_proofs || !d_ok))) return MFH_EINVAL;

@@ -911,7 +911,8 @@ static void shim_warm_prover(const void *rows)
   if (rc != MFH_OK) die("mfh_prove (warm-up)");
   CK(mfh_sync(G.ctx));
 }
-static const void *rows_image_build(const uint8_t *d_crs, const uint64_t dg[2]);
+static void *rows_image_reserve(void);
+static void rows_image_register(const uint64_t dg[2]);
 static bool resident_on(void);
 
 static void *setup_ssp_thread(void *ssp)
@@ -955,28 +956,28 @@ void setup(crs_t crs, vrs_t vrs, ssp_t ssp)
   sk_resident(vrs->sk);
   drop_image(); /* G.d_crs is about to be rewritten */
   G.staged_digest_valid = false;
-  CK(mfh_setup(G.ctx, G.d_ssp, (uint32_t)vrs->alpha, (uint32_t)vrs->beta, (uint32_t)vrs->s, G.d_sk, G.d_err, G.d_crs));
+  /* "... writing the expanded rows to HBM as a by-product, so the prover starts with a materialised CRS".  The encryptions regenerate every a-vector of the
+   * CRS (src/snark.c:75-110); mfh_setup_image writes the same rows out in the layout prover() streams (12 ms of AES on the CU, in place of most of the warm-up proof's
+   * 10), and below they are registered under (seed, digest of the compressed CRS): the FIRST prover() under this CRS finds them.  Not when the image does not fit beside
+   * the calls' scratch, nor with $MFUOCO_GPU_RESIDENT_CRS=0. */
+  void *img = resident_on() ? rows_image_reserve() : NULL;
+  CK(mfh_setup_image(G.ctx, G.d_ssp, (uint32_t)vrs->alpha, (uint32_t)vrs->beta, (uint32_t)vrs->s, G.d_sk, G.d_err, G.d_crs, img));
   HK(hipMemsetAsync(G.d_err, 0, rows * L_LIMBS * 8, NULL)); /* (the errors are not kept on the device either) */
   HK(hipMemcpy(crs->s, G.d_crs, CT_BYTES * GAMMA_D, hipMemcpyDeviceToHost));
   HK(hipMemcpy(crs->as, G.d_crs + CT_BYTES * GAMMA_D, CT_BYTES * GAMMA_D, hipMemcpyDeviceToHost));
   HK(hipMemcpy(crs->t, G.d_crs + 2 * CT_BYTES * GAMMA_D, CT_BYTES, hipMemcpyDeviceToHost));
   HK(hipMemcpy(crs->v, G.d_crs + (2 * GAMMA_D + 1) * CT_BYTES, CT_BYTES * (GAMMA_M - 1), hipMemcpyDeviceToHost));
   const double t_crs = tnow();
-  /* "... writing the expanded rows to HBM as a by-product, so the prover starts with a materialised CRS".  The encryptions above regenerated every
-   * a-vector of the CRS (src/snark.c:75-110); the same rows are written out here in the layout prover() streams (mfh_crs_expand: AES on the CU once more, 12 ms, in place
-   * of most of the warm-up proof's 10), registered under (seed, digest of the compressed CRS): the FIRST prover() under this CRS finds them.  Not when the image does
-   * not fit beside the call's scratch, nor with $MFUOCO_GPU_RESIDENT_CRS=0. */
-  const void *img = NULL;
-  if (resident_on()) {
+  if (img) {
     CK(mfh_digest128(G.ctx, G.d_crs, rows * CT_BYTES, G.staged_digest));
     G.staged_digest_valid = true;
-    img = rows_image_build(G.d_crs, G.staged_digest);
+    rows_image_register(G.staged_digest);
   }
   const double t_img = tnow();
   shim_warm_prover(img);
   if (tracing())
-    fprintf(stderr, "setup(): key + error draws %.2f ms (the SSP upload runs beside them), rest of the SSP upload (%.2f GB) + quotient precomputation %.2f, uploads + encryptions + CRS download %.2f, row image for prover() %s (queued in %.2f), prover warm-up %.2f (with the image's expansion)\n",
-            t_drawn - t_in, SSP_SIZE / 1e9, t_ssp - t_drawn, t_crs - t_ssp, img ? "written" : "not kept", t_img - t_crs, tnow() - t_img);
+    fprintf(stderr, "setup(): key + error draws %.2f ms (the SSP upload runs beside them), rest of the SSP upload (%.2f GB) + quotient precomputation %.2f, uploads + encryptions (+ the row image for prover(): %s) + CRS download %.2f, digest %.2f, prover warm-up %.2f\n",
+            t_drawn - t_in, SSP_SIZE / 1e9, t_ssp - t_drawn, img ? "written" : "not kept", t_crs - t_ssp, t_img - t_crs, tnow() - t_img);
 }
 
 /* ---- pieces shared with the multi-GPU entry points (host/mfuoco_dist.c, libmfuoco_gpu_dist): not part of the reference interface ---- */
@@ -1235,7 +1236,8 @@ int mfuoco_gpu_image_resident_share(const uint8_t *d_crs, uint32_t rank, uint32_
 }
 /* single-proof image (mfh_prove): the rows of the CRS staged at d_crs (digest dg) in k_mac_resident's layout, registered under (seed, digest).  The expansion is
  * QUEUED on the shim's stream, not waited for: whatever is queued next finds the rows written.  NULL when the image is not kept (does not fit). */
-static const void *rows_image_build(const uint8_t *d_crs, const uint64_t dg[2])
+/* room for the row image (kept across calls; NULL when it does not fit beside the calls' scratch); whatever image was there is no longer valid */
+static void *rows_image_reserve(void)
 {
   G.rows_valid = false;
   const size_t rows = 2 * (size_t)GAMMA_D + GAMMA_M, need = rows * mfh_resident_row_bytes(G.ctx);
@@ -1247,12 +1249,23 @@ static const void *rows_image_build(const uint8_t *d_crs, const uint64_t dg[2])
     if (hipMalloc(&G.d_rows, need) != hipSuccess) { (void)hipGetLastError(); G.d_rows = NULL; return NULL; }
     G.rows_bytes = need;
   }
-  CK(mfh_crs_expand(G.ctx, 0, rows, d_crs, G.d_rows));
+  return G.d_rows;
+}
+/* G.d_rows holds (or is queued to hold) the rows of the CRS with digest dg under the current seed */
+static void rows_image_register(const uint64_t dg[2])
+{
   G.rows_valid = true;
   memcpy(G.rows_seed, G.seed, 40);
   G.rows_digest[0] = dg[0];
   G.rows_digest[1] = dg[1];
-  return G.d_rows;
+}
+static const void *rows_image_build(const uint8_t *d_crs, const uint64_t dg[2])
+{
+  void *img = rows_image_reserve();
+  if (!img) return NULL;
+  CK(mfh_crs_expand(G.ctx, 0, 2 * (size_t)GAMMA_D + GAMMA_M, d_crs, img));
+  rows_image_register(dg);
+  return img;
 }
 /* ... looked up by prover(): the image setup() / mfuoco_gpu_prefetch_crs() wrote for this (seed, CRS), else expanded when prover() meets the same (seed, CRS) a
  * second time; returns the image to register, or NULL */

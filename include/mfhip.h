@@ -186,6 +186,13 @@ int mfh_setup_messages(mfh_ctx *ctx, const uint32_t *d_ssp, uint32_t alpha, uint
  * s[0..d) | as[0..d) | t | v[0..m-1)  (struct crs, src/snark.h:27-33, keeps them in four arrays). */
 int mfh_setup(mfh_ctx *ctx, const uint32_t *d_ssp, uint32_t alpha, uint32_t beta, uint32_t s, const uint64_t *d_sk,
               const uint64_t *d_err, uint8_t *d_crs_c8);
+/* The same, leaving the expanded rows behind as a by-product ("writing the expanded rows to HBM as a by-product, so the prover starts with a materialised
+ * CRS"): d_rows_image (may be NULL: then this is mfh_setup) receives all 2d+m rows in the layout of mfh_crs_expand -- (2d+m) x mfh_resident_row_bytes() bytes, what
+ * mfh_crs_set_resident registers and mfh_prove streams -- so that the first proof under the new CRS does not regenerate a single a-vector.  The rows are written by a second
+ * pass over the stream (the expansion kernel of mfh_crs_expand, queued behind the encryptions); the encryption kernel itself keeps the keystream in its MFMA operand
+ * registers (csrc/encmm.hip) and would have to scatter it in 4-byte pieces to lay it out. */
+int mfh_setup_image(mfh_ctx *ctx, const uint32_t *d_ssp, uint32_t alpha, uint32_t beta, uint32_t s, const uint64_t *d_sk,
+                    const uint64_t *d_err, uint8_t *d_crs_c8, void *d_rows_image);
 /* prover() (src/snark.c:117-190) with caller-supplied entropy: delta (< p; the reference draws 8 bytes % p) and the
  * five smudging draws in call order h, hat_h, hat_v, v_w, v_w (sic: v_w twice, b_w never; src/snark.c:185-189):
  * h_smudge_mag = 5*maglen bytes, h_smudge_sign = 5 bytes.  Needs mfh_set_seed(crs seed) and mfh_ssp_prepare.

@@ -139,6 +139,29 @@ def test_setup_matches_oracle(ctx, instance):
     I["d_crs"] = d_crs
 
 
+def test_setup_image_leaves_the_rows_the_prover_streams(ctx, oracle, instance):
+    """mfh_setup_image (SURVEY 8(f)1's by-product clause): the CRS is the oracle's, the row image is what mfh_crs_expand writes for that CRS, and a proof over it
+    (k_mac_resident) is bit for bit the oracle's prover() -- no a-vector regenerated by the first proof under the new CRS"""
+    I = instance
+    p = I["p"]
+    d_crs, rows = ctx.setup_image(I["d_ssp"], I["alpha"], I["beta"], I["s"], ctx.to_device(I["sk"]), ctx.to_device(I["etape"]))
+    assert np.array_equal(ctx.to_host(d_crs), _crs_stream_order(p, I["crs"]))
+    assert np.array_equal(ctx.to_host(rows), ctx.to_host(ctx.crs_expand(0, 2 * p.d + p.m, d_crs)))
+    rng = np.random.default_rng(5)
+    delta = int(rng.integers(0, ol.P, dtype=np.uint64))
+    mags = rng.integers(0, 256, size=5 * 80, dtype=np.uint8).tobytes()
+    signs = bytes([0, 1, 1, 0, 1])
+    tape = b"".join(mags[80 * k: 80 * k + 80] + signs[k: k + 1] for k in range(5))
+    ctx.set_resident(rows)
+    try:
+        got = ctx.to_host(ctx.prove(d_crs, I["d_ssp"], I["bits"], delta, mags, signs), np.uint64).reshape(5, p.n + 1, p.L)
+    finally:
+        ctx.set_resident(None)
+    ref = oracle.prover(p, I["crs"], I["ssp"], I["bits"], delta, tape, 80, want_pre=False)
+    for k, name in enumerate(("h", "hat_h", "hat_v", "v_w", "b_w")):
+        assert np.array_equal(got[k], ref["proof"][k]), name
+
+
 def test_crs_structure_properties(ctx, instance):
     # src/test_snark.c:35-70: dec(s[0]) = 1, dec(as[0]) = alpha, alpha*dec(s[i]) = dec(as[i]) for i = 1, D-1
     I = instance
