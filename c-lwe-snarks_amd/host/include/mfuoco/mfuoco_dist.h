@@ -60,7 +60,8 @@ void mfuoco_comm_stats(const mfuoco_comm *comm, uint64_t calls[4], uint64_t byte
  *   ->  mfh_ct_from_lanes  ->  mfh_prove_batch_finish (delta ct_t, smudging) on the own slab,
  * pipelined in stages of (255 / world) statements per rank (at most one super-group of the row work): the collectives run on the communicator's own stream,
  * stage k + 1's all-to-all and stage k - 1's reduce-scatter, finish and device-to-host drain under the row work of stage k; the bytes handed to the backend are those
- * of the one-shot sequence ($MFUOCO_DIST_STAGE=0 restores it; it is also what runs when the rank's image share is not resident).
+ * of the one-shot sequence ($MFUOCO_DIST_STAGE=0 restores it).  The cut is a function of count, the number of ranks and the environment, so every rank issues the same
+ * collectives; a rank whose image share is not kept by the shim expands it once per call.
  * Every rank passes the same crs, ssp, witnesses and count.  Statements are owned in slabs of ceil(count / world): on return
  * [*own_first, *own_first + *own_count) are this rank's statements and pis[k] (initialised by proof_init) holds their proofs; the other
  * pis[] are untouched.  Entropy (delta, the five smudging draws) is drawn by the owner, per statement in prover()'s order.  With the same

@@ -321,8 +321,8 @@ static void comm_bcast_bytes(mfuoco_comm *c, uint8_t *d_buf, size_t n, int root)
  *     D  the drain: device to host on the shim's copy stream, mpz_t's on host threads   after F, an iteration later (the call blocks in it, with work queued behind)
  * queued as   C0 | C1 P0 L0 | C2 P1 L1 F0 | C3 P2 L2 F1 [D0] | ...   on the shim's stream and   A0 | A1 R0 | A2 R1 | ...   on the communicator's, so that A(k + 1) runs under
  * P(k), R(k) under C(k + 2) and P(k + 1), and the host turns stage k into mpz_t's under the kernels of the stages behind it.  (One rank: F(k) directly behind R(k).)  Everything is double-buffered by stage parity;
- * the order above is what makes that safe (a buffer's next writer is queued behind an event its last reader precedes).  Without a resident image share
- * ($MFUOCO_GPU_RESIDENT_CRS=0, or no room) the call is ONE stage: mfh_prove_batch_partial then expands its transient image once per call, not once per stage. */
+ * the order above is what makes that safe (a buffer's next writer is queued behind an event its last reader precedes).  The cut depends on count, world and the
+ * environment only, never on what a rank happens to have resident: every rank issues the same collectives. */
 void mfuoco_prover_batch_sharded(proof_t *pis, crs_t crs, ssp_t ssp, mpz_t *witnesses, size_t count, mfuoco_comm *comm, size_t *own_first,
                                  size_t *own_count)
 {
@@ -358,9 +358,23 @@ void mfuoco_prover_batch_sharded(proof_t *pis, crs_t crs, ssp_t ssp, mpz_t *witn
     if (in_stage <= 255 || sper == 1) break;
   }
   if (se && *se) sper = (size_t)atol(se);
-  if (!streamed || !sper || sper > per) sper = per;
-  const size_t nst = (per + sper - 1) / sper;
+  if (!sper || sper > per) sper = per;
+  const size_t nst = (per + sper - 1) / sper; /* (a function of count, world and the environment only: every rank cuts the call the same way) */
   comm_pipeline(c, nst);
+  /* No image share kept by the shim ($MFUOCO_GPU_RESIDENT_CRS=0, or no room beside the scratch): mfh_prove_batch_partial would expand its own transient image -- once per
+   * STAGE.  A call of several stages therefore expands the rank's shares itself, once, streams them for all its stages and drops the registration at the end.  (When even
+   * that does not fit, the row work expands or regenerates per stage: slower, same proofs, same collectives.) */
+  bool own_image = false;
+  if (!streamed && nst > 1 && nb > 31) {
+    const size_t ib = mfh_crs_mm_share_bytes(ctx, (uint32_t)rank, (uint32_t)world);
+    size_t fr = 0, tot = 0;
+    if (ib <= c->cap[13] || (hipMemGetInfo(&fr, &tot) == hipSuccess && ib + ((size_t)8 << 30) <= fr)) {
+      uint8_t *img = scratch(c, 13, ib);
+      CK(mfh_crs_expand_mm_share(ctx, d_crs, (uint32_t)rank, (uint32_t)world, img));
+      CK(mfh_crs_set_resident_mm_share(ctx, img, (uint32_t)rank, (uint32_t)world));
+      own_image = true;
+    }
+  }
   hipStream_t const cst = c->t ? c->cstream : NULL; /* (no backend: the stand-in copies run in line) */
 
   /* host inputs: the bit strings of ALL statements in stage order (they select the rank's BT+BV rows), entropy of the OWN statements in the order of nown prover() calls */
@@ -476,6 +490,7 @@ void mfuoco_prover_batch_sharded(proof_t *pis, crs_t crs, ssp_t ssp, mpz_t *witn
 #undef STAGE_CNT
   HK(hipStreamSynchronize(NULL));
   if (c->t) HK(hipStreamSynchronize(cst)); /* (a rank without own statements has waited for nothing so far) */
+  if (own_image) CK(mfh_crs_set_resident_mm_share(ctx, NULL, (uint32_t)rank, (uint32_t)world));
   if (c == &local) comm_release(&local);
   explicit_bzero(mag, (nown ? nown : 1) * 5 * MAGLEN); /* smudging terms and deltas are the proofs' zero-knowledge: not left on the heap */
   explicit_bzero(sign, (nown ? nown : 1) * 5);

@@ -32,14 +32,17 @@ def _rank_env(rank, world, **extra):
     return env
 
 
-@pytest.mark.parametrize("stage", [None, "7", "0"])
-def test_c_sharded_prover_one_rank_rccl(tmp_path, stage):
+@pytest.mark.parametrize("stage,resident", [(None, True), ("7", True), ("0", True), ("7", False)])
+def test_c_sharded_prover_one_rank_rccl(tmp_path, stage, resident):
     """mfuoco_prover_batch_sharded / mfuoco_prover_sharded (host/mfuoco_dist.c) through librccl called from C: a one-rank communicator still
     sends the all-to-all (ncclSend/ncclRecv to itself), the ncclReduceScatter, both ncclAllReduce and the ncclBroadcast; proofs must equal
     mfuoco_prover_batch's / prover()'s bit for bit on the same entropy tape and verify.  stage ($MFUOCO_DIST_STAGE): statements per rank and pipeline stage --
     None: the plan of a real call (40 statements: one stage); 7: six stages (7, 7, 7, 7, 7, 5), the collectives of stage k + 1 / k - 1 on the communicator's stream
-    beside the row work of stage k, every buffer re-used by parity three times; 0: the one-shot sequence"""
+    beside the row work of stage k, every buffer re-used by parity three times; 0: the one-shot sequence.  resident = False ($MFUOCO_GPU_RESIDENT_CRS=0): the shim
+    keeps no image share, the staged call expands its own once and drops it -- the cut of the call (hence the collectives every rank issues) must not depend on it"""
     extra = {"MFUOCO_DIST_STAGE": stage} if stage is not None else {}
+    if not resident:
+        extra["MFUOCO_GPU_RESIDENT_CRS"] = "0"
     r = subprocess.run([_sharded_exe(), "40"], env=_rank_env(0, 1, MFUOCO_COMM_ID_FILE=str(tmp_path / "id"), **extra), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "backend=rccl" in r.stdout and "sharded ok" in r.stdout
