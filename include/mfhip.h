@@ -310,7 +310,8 @@ int mfh_batch_chain_from_w(mfh_ctx *ctx, const uint32_t *d_ssp, uint32_t nstmt, 
 int mfh_prove_batch_partial(mfh_ctx *ctx, const uint8_t *d_crs_c8, uint32_t rank, uint32_t world, uint32_t nstmt, const uint8_t *h_witness_bits,
                             size_t bits_stride, const uint32_t *d_w, const uint32_t *d_h, const uint32_t *d_v, size_t coef_stride, uint64_t *d_partial);
 /* step 5: d_proofs = nstmt summed proofs (after mfh_ct_from_lanes): b_w += delta_b ct_t (src/snark.c:143-145), then the five smudging
- * draws per proof in the order of mfh_prove (src/snark.c:185-189) */
+ * draws per proof in the order of mfh_prove (src/snark.c:185-189).  Queue-only: the host's contribution (deltas, smudging terms, signs) is staged once in pinned memory and
+ * the call returns without waiting for the GPU to reach it (a pipelined caller queues it behind work that has not run yet: host/mfuoco_dist.c). */
 int mfh_prove_batch_finish(mfh_ctx *ctx, const uint8_t *d_crs_c8, uint32_t nstmt, const uint32_t *h_delta, const uint8_t *h_smudge_mag, size_t maglen,
                            const uint8_t *h_smudge_sign, uint64_t *d_proofs);
 
