@@ -89,7 +89,7 @@ EXPORTS = [
     "mfh_keystream", "mfh_sample_rows", "mfh_ct_add", "mfh_ct_mul_ui", "mfh_ct_addmul_ui", "mfh_eval_rows",
     "mfh_encrypt_rows", "mfh_decrypt", "mfh_ct_smudge", "mfh_ssp_upload", "mfh_witness_poly", "mfh_version",
     "mfh_workspace_bytes", "mfh_last_kernel_ms", "mfh_set_timing", "mfh_set_overlap", "mfh_eval_rows_multi", "mfh_prove_batch", "mfh_crs_mm_image_bytes", "mfh_crs_expand_mm", "mfh_crs_set_resident_mm", "mfh_witness_poly_multi", "mfh_witness_poly_mm", "mfh_poly_h_multi", "mfh_poly_mul", "mfh_poly_add", "mfh_poly_prepare_t",
-    "mfh_ssp_prepare", "mfh_poly_h", "mfh_setup_messages", "mfh_setup", "mfh_setup_image", "mfh_prove",
+    "mfh_ssp_prepare", "mfh_poly_h", "mfh_setup_messages", "mfh_setup", "mfh_setup_image", "mfh_crs_image_set_b", "mfh_prove",
     "mfh_prove_partial", "mfh_prove_finish", "mfh_ct_to_lanes", "mfh_ct_from_lanes", "mfh_lanes_per_value", "mfh_digest128", "mfh_timing_drain", "mfh_timing_busy_ms", "mfh_timing_work_rows", "mfh_set_batch_image", "mfh_set_batch_slabs", "mfh_set_expand_path", "mfh_set_encrypt_path", "mfh_set_batch_launch", "mfh_set_batch_bw", "mfh_set_mm_chunk_rows", "mfh_set_mm_pack", "mfh_set_mm_stream", "mfh_add_dotp", "mfh_set_encrypt_chunks", "mfh_set_witness_per", "mfh_set_eval_path", "mfh_set_decrypt_path", "mfh_decrypt_rows",
     "mfh_crs_mm_share_bytes", "mfh_crs_expand_mm_share", "mfh_crs_set_resident_mm_share", "mfh_batch_chain", "mfh_batch_witness_cols", "mfh_batch_chain_from_w", "mfh_witness_poly_mm_cols", "mfh_prove_batch_partial", "mfh_prove_batch_finish",
     "mfh_resident_row_bytes", "mfh_crs_expand", "mfh_eval_rows_resident", "mfh_crs_set_resident",
@@ -174,6 +174,7 @@ def load_library():
         "mfh_prove_partial_w": (i32, [vp, vp, vp, ctypes.c_char_p, u32, u32, u32, vp, vp]),
         "mfh_resident_row_bytes": (sz, [vp]),
         "mfh_crs_expand": (i32, [vp, u64, sz, vp, vp]),
+        "mfh_crs_image_set_b": (i32, [vp, sz, sz, vp, vp]),
         "mfh_eval_rows_resident": (i32, [vp, vp, sz, sz, vp, vp, vp, vp, i32]),
         "mfh_crs_set_resident": (i32, [vp, vp]),
         "mfh_timing_drain": (i32, [vp, ctypes.c_char_p, ctypes.POINTER(u64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(u64),
@@ -656,6 +657,11 @@ class Context:
         out = self.empty(nrows * self.resident_row_bytes()) if out is None else out
         self._chk(self.lib.mfh_crs_expand(self._h, off, nrows, _ptr(c8), _ptr(out)))
         return out
+
+    def crs_image_set_b(self, image, first_row, nrows, c8):
+        """coordinate n (the b's) of rows [first_row, first_row + nrows) of a row image expanded with c8 = None"""
+        self._chk(self.lib.mfh_crs_image_set_b(self._h, int(first_row), int(nrows), _ptr(c8), _ptr(image)))
+        return image
 
     def eval_rows_resident(self, rows, first_row, nrows, coeff0, coeff1=None, rop0=None, rop1=None, accumulate=False):
         p = self.params

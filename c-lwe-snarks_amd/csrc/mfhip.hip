@@ -489,7 +489,7 @@ __global__ __launch_bounds__(PS<LOGQ>::THREADS) void k_expand(AesKey key, const 
         const uint32_t *kw = reinterpret_cast<const uint32_t *>(ks + head) + t * S::EW;
 #pragma unroll
         for (int l = 0; l < S::KW; l++) a[l] = kw[l];
-      } else if (j == n) {
+      } else if (j == n && c8) {  // (c8 == nullptr: the a parts only -- they depend on the seed alone --, b left zero for k_rows_set_b)
         const uint32_t *bw = reinterpret_cast<const uint32_t *>(c8 + (uint64_t)cur_row * S::CTB);
 #pragma unroll
         for (int l = 0; l < S::KW; l++) a[l] = bw[l];
@@ -506,6 +506,22 @@ __global__ __launch_bounds__(PS<LOGQ>::THREADS) void k_expand(AesKey key, const 
     }
     __syncthreads();
   }
+}
+
+// coordinate n (the row's b) of rows [0, nrows) of an image from the compressed ciphertexts: what k_expand writes when it is given them
+template <int LOGQ>
+__global__ void k_rows_set_b(uint32_t n, uint32_t nrows, const uint8_t *__restrict__ c8, uint8_t *__restrict__ out) {
+  using S = PS<LOGQ>;
+  using R = RL<LOGQ>;
+  const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= nrows) return;
+  const uint32_t RS = R::rs(n);
+  const uint32_t *bw = reinterpret_cast<const uint32_t *>(c8 + (uint64_t)row * S::CTB);
+  uint8_t *rowp = out + (uint64_t)row * R::row_bytes(n);
+#pragma unroll
+  for (int k = 0; k < R::NP16; k++)
+    reinterpret_cast<uint4 *>(rowp + (uint64_t)k * RS * 16)[n] = make_uint4(bw[4 * k], bw[4 * k + 1], bw[4 * k + 2], bw[4 * k + 3]);
+  if (R::TAIL == 2) reinterpret_cast<uint2 *>(rowp + (uint64_t)R::NP16 * RS * 16)[n] = make_uint2(bw[4 * R::NP16], bw[4 * R::NP16 + 1]);
 }
 
 // streaming MAC over resident rows: grid = (RS/64 column groups x nchunks), 256 threads = 4 waves; each wave owns 64
@@ -1581,8 +1597,20 @@ size_t mfh_resident_row_bytes(const mfh_ctx *c) {
   return c->P.logq == 736 ? (size_t)RL<736>::row_bytes(c->P.n) : (size_t)RL<1472>::row_bytes(c->P.n);
 }
 
+int mfh_crs_image_set_b(mfh_ctx *c, size_t first_row, size_t nrows, const uint8_t *d_c8, void *d_rows) {
+  if (!c || (nrows && (!d_c8 || !d_rows)) || nrows > 0xffffffffu) return MFH_EINVAL;
+  if (!nrows) return MFH_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  uint8_t *out = (uint8_t *)d_rows + first_row * mfh_resident_row_bytes(c);
+  const dim3 grid((uint32_t)((nrows + 255) / 256));
+  DISPATCH_LOGQ(c, hipLaunchKernelGGL(k_rows_set_b<736>, grid, dim3(256), 0, c->stream, c->P.n, (uint32_t)nrows, d_c8, out),
+                hipLaunchKernelGGL(k_rows_set_b<1472>, grid, dim3(256), 0, c->stream, c->P.n, (uint32_t)nrows, d_c8, out));
+  HIP_TRY(c, hipGetLastError());
+  return MFH_OK;
+}
+
 int mfh_crs_expand(mfh_ctx *c, uint64_t off, size_t nrows, const uint8_t *d_c8, void *d_rows_out) {
-  if (!c || (nrows && (!d_c8 || !d_rows_out)) || nrows > 0xffffffffu) return MFH_EINVAL;
+  if (!c || (nrows && !d_rows_out) || nrows > 0xffffffffu) return MFH_EINVAL;
   NEED_SEED(c);
   if (!nrows) return MFH_OK;
   HIP_TRY(c, hipSetDevice(c->device));

@@ -61,6 +61,7 @@ static struct {
   bool sk_valid;
   uint8_t *pin;       /* PIN_BYTES of pinned host memory: staging of the single-ciphertext calls */
   hipEvent_t ev_small; /* ... and an event for their split downloads */
+  hipEvent_t ev_img;   /* setup(): the a parts of the row image have been written (queued on s2 beside the SSP upload) */
   hipStream_t s2;      /* ... and a second stream: the public half of a regev_encrypt2 beside its secret half */
   /* mfuoco_encrypt_batch: two chunks of ENC_CHUNK rows in flight (error limbs and messages up, exported b's down) */
   uint8_t *enc_pin[2], *d_enc[2];
@@ -259,6 +260,7 @@ static mfh_ctx *gpu(void)
   HK(hipMalloc((void **)&G.d_crs, rows * CT_BYTES));
   HK(hipHostMalloc((void **)&G.pin, PIN_BYTES, hipHostMallocDefault));
   HK(hipEventCreateWithFlags(&G.ev_small, hipEventDisableTiming));
+  HK(hipEventCreateWithFlags(&G.ev_img, hipEventDisableTiming));
   HK(hipStreamCreateWithFlags(&G.s2, hipStreamNonBlocking));
   HK(hipHostMalloc((void **)&G.pin_sk, (size_t)GAMMA_N * L_LIMBS * 8, hipHostMallocDefault));
   G.h_sk = xcalloc((size_t)GAMMA_N * L_LIMBS, 8);
@@ -929,6 +931,22 @@ void setup(crs_t crs, vrs_t vrs, ssp_t ssp)
   /* the SSP (5.7 GB at the NDEBUG size) starts crossing PCIe at once, on a helper thread (mfh_ssp_upload has its own staging threads; this one only waits for them), while
    * THIS thread draws the secrets from the OS -- the only thread that does, so the draws keep the reference's order.  Nothing below touches the GPU before the join. */
   G.ssp_host = NULL;
+  /* "... writing the expanded rows to HBM as a by-product, so the prover starts with a materialised CRS".  The a parts of the 2D + M rows depend on the
+   * public seed alone, so they are written out FIRST, in the layout prover() streams, on the shim's second stream: 12 ms of AES on the CU that run while the 5.7 GB of
+   * the SSP cross PCIe (in 16 row slices, so that the upload's small reduction kernels find CUs between them).  The b's are filled in below, once the encryptions
+   * exist, and the image is registered under (seed, digest of the compressed CRS): the FIRST prover() under this CRS streams it.  Not when the image does not fit beside
+   * the calls' scratch, nor with $MFUOCO_GPU_RESIDENT_CRS=0.  (Queued before the upload thread starts: one thread at a time talks to the context.) */
+  drop_image(); /* (the image buffer and G.d_crs are about to be rewritten) */
+  G.staged_digest_valid = false;
+  void *img = resident_on() ? rows_image_reserve() : NULL;
+  if (img) {
+    const size_t nrows_img = 2 * (size_t)GAMMA_D + GAMMA_M, rb = mfh_resident_row_bytes(G.ctx), slice = (nrows_img + 15) / 16;
+    CK(mfh_set_stream(G.ctx, G.s2));
+    for (size_t r0 = 0; r0 < nrows_img; r0 += slice)
+      CK(mfh_crs_expand(G.ctx, (uint64_t)r0 * CTR_CT, nrows_img - r0 < slice ? nrows_img - r0 : slice, NULL, (uint8_t *)img + r0 * rb));
+    HK(hipEventRecord(G.ev_img, G.s2));
+    CK(mfh_set_stream(G.ctx, NULL));
+  }
   pthread_t ssp_th;
   const bool ssp_bg = pthread_create(&ssp_th, NULL, setup_ssp_thread, ssp) == 0;
   vrs->alpha = rand_modp_();
@@ -954,14 +972,11 @@ void setup(crs_t crs, vrs_t vrs, ssp_t ssp)
   explicit_bzero(err, rows * L_LIMBS * 8); /* the encryption errors are part of the trapdoor: not left on the heap */
   free(err);
   sk_resident(vrs->sk);
-  drop_image(); /* G.d_crs is about to be rewritten */
-  G.staged_digest_valid = false;
-  /* "... writing the expanded rows to HBM as a by-product, so the prover starts with a materialised CRS".  The encryptions regenerate every a-vector of the
-   * CRS (src/snark.c:75-110); mfh_setup_image writes the same rows out in the layout prover() streams (12 ms of AES on the CU, in place of most of the warm-up proof's
-   * 10), and below they are registered under (seed, digest of the compressed CRS): the FIRST prover() under this CRS finds them.  Not when the image does not fit beside
-   * the calls' scratch, nor with $MFUOCO_GPU_RESIDENT_CRS=0. */
-  void *img = resident_on() ? rows_image_reserve() : NULL;
-  CK(mfh_setup_image(G.ctx, G.d_ssp, (uint32_t)vrs->alpha, (uint32_t)vrs->beta, (uint32_t)vrs->s, G.d_sk, G.d_err, G.d_crs, img));
+  CK(mfh_setup(G.ctx, G.d_ssp, (uint32_t)vrs->alpha, (uint32_t)vrs->beta, (uint32_t)vrs->s, G.d_sk, G.d_err, G.d_crs));
+  if (img) { /* the image's b column, behind the a parts (s2) and the encryptions (this stream) */
+    HK(hipStreamWaitEvent(NULL, G.ev_img, 0));
+    CK(mfh_crs_image_set_b(G.ctx, 0, rows, G.d_crs, img));
+  }
   HK(hipMemsetAsync(G.d_err, 0, rows * L_LIMBS * 8, NULL)); /* (the errors are not kept on the device either) */
   HK(hipMemcpy(crs->s, G.d_crs, CT_BYTES * GAMMA_D, hipMemcpyDeviceToHost));
   HK(hipMemcpy(crs->as, G.d_crs + CT_BYTES * GAMMA_D, CT_BYTES * GAMMA_D, hipMemcpyDeviceToHost));
@@ -976,8 +991,8 @@ void setup(crs_t crs, vrs_t vrs, ssp_t ssp)
   const double t_img = tnow();
   shim_warm_prover(img);
   if (tracing())
-    fprintf(stderr, "setup(): key + error draws %.2f ms (the SSP upload runs beside them), rest of the SSP upload (%.2f GB) + quotient precomputation %.2f, uploads + encryptions (+ the row image for prover(): %s) + CRS download %.2f, digest %.2f, prover warm-up %.2f\n",
-            t_drawn - t_in, SSP_SIZE / 1e9, t_ssp - t_drawn, img ? "written" : "not kept", t_crs - t_ssp, t_img - t_crs, tnow() - t_img);
+    fprintf(stderr, "setup(): key + error draws %.2f ms (the SSP upload runs beside them), rest of the SSP upload (%.2f GB) + quotient precomputation %.2f, uploads + encryptions + CRS download %.2f (row image for prover(): %s, its a parts expanded beside the SSP upload), digest %.2f, prover warm-up %.2f\n",
+            t_drawn - t_in, SSP_SIZE / 1e9, t_ssp - t_drawn, t_crs - t_ssp, img ? "written" : "not kept", t_img - t_crs, tnow() - t_img);
 }
 
 /* ---- pieces shared with the multi-GPU entry points (host/mfuoco_dist.c, libmfuoco_gpu_dist): not part of the reference interface ---- */

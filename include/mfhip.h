@@ -102,6 +102,10 @@ int mfh_eval_rows(mfh_ctx *ctx, uint64_t off, size_t nrows, const uint8_t *d_c8,
  * mfh_prove / mfh_prove_partial use the image (row index = position in stream order from CTR_S); NULL reverts. */
 size_t mfh_resident_row_bytes(const mfh_ctx *ctx);
 int mfh_crs_expand(mfh_ctx *ctx, uint64_t off, size_t nrows, const uint8_t *d_c8, void *d_rows_out);
+/* d_c8 may be NULL in mfh_crs_expand: the a parts only (they depend on the seed alone, not on the ciphertexts), coordinate n left zero -- so that the 12 ms of AES can run
+ * BEFORE the b's exist (the shim's setup() queues it beside the SSP upload); mfh_crs_image_set_b then fills coordinate n of rows [first_row, first_row + nrows)
+ * of the image from their compressed ciphertexts (d_c8[0] = row first_row).  Expanding with d_c8 gives the same bytes as expanding without and setting b afterwards. */
+int mfh_crs_image_set_b(mfh_ctx *ctx, size_t first_row, size_t nrows, const uint8_t *d_c8, void *d_rows);
 int mfh_eval_rows_resident(mfh_ctx *ctx, const void *d_rows, size_t first_row, size_t nrows, const uint32_t *d_coeff0,
                            const uint32_t *d_coeff1, uint64_t *d_rop0, uint64_t *d_rop1, int accumulate);
 int mfh_crs_set_resident(mfh_ctx *ctx, const void *d_rows);

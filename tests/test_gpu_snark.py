@@ -147,6 +147,16 @@ def test_setup_image_leaves_the_rows_the_prover_streams(ctx, oracle, instance):
     d_crs, rows = ctx.setup_image(I["d_ssp"], I["alpha"], I["beta"], I["s"], ctx.to_device(I["sk"]), ctx.to_device(I["etape"]))
     assert np.array_equal(ctx.to_host(d_crs), _crs_stream_order(p, I["crs"]))
     assert np.array_equal(ctx.to_host(rows), ctx.to_host(ctx.crs_expand(0, 2 * p.d + p.m, d_crs)))
+    # the a parts depend on the seed alone: expanded without the ciphertexts (in two row slices, as the shim's setup() does beside its SSP upload) and the b column
+    # filled in afterwards, the image is the same bytes
+    nrows_all, rb, cut = 2 * p.d + p.m, ctx.resident_row_bytes(), 301
+    img2 = ctx.zeros(nrows_all * rb)
+    ctx.crs_expand(0, cut, None, out=img2)
+    ctx.crs_expand(cut * p.ctr_ct, nrows_all - cut, None, out=img2[cut * rb:])
+    assert not np.array_equal(ctx.to_host(img2), ctx.to_host(rows))
+    ctx.crs_image_set_b(img2, 0, cut, d_crs)
+    ctx.crs_image_set_b(img2, cut, nrows_all - cut, d_crs[cut * p.ctb:])
+    assert np.array_equal(ctx.to_host(img2), ctx.to_host(rows))
     rng = np.random.default_rng(5)
     delta = int(rng.integers(0, ol.P, dtype=np.uint64))
     mags = rng.integers(0, 256, size=5 * 80, dtype=np.uint8).tobytes()
