@@ -207,6 +207,7 @@ def prove_batch_sharded(ctx, d_crs, d_ssp, witness_bits_list, deltas, smudge_mag
         return [owned[q][0] + k * sper + i for q in range(world) for i in range(cnt(q, k))]
 
     st = [None] * nst  # per stage: what the later steps need
+    chain_whv, chain_hi = None, 0  # w | h | v of all own statements, filled up to statement chain_hi by chain passes of 255
     for it in range(nst + 2):
         if it < nst:  # ---- C(it): the chain of the OWN statements of the stage, operands laid out for the all-to-all; A(it)
             k = it
@@ -227,7 +228,16 @@ def prove_batch_sharded(ctx, d_crs, d_ssp, witness_bits_list, deltas, smudge_mag
                 del wsl, wrecv
                 ctx.batch_chain_from_w(d_ssp, whv)
             else:
-                whv = ctx.batch_chain(d_ssp, [witness_bits_list[i] for i in own_ids], [deltas[i] for i in own_ids])
+                # the chain runs in passes of up to 255 OWN statements (one read of the SSP, one set of NTT launches per pass: a pass per stage would read the SSP once
+                # per 26 statements on 8 ranks), queued when the first stage that needs them comes up; a stage takes its slice of the pass
+                o0 = k * sper
+                if chain_whv is None:
+                    chain_whv = torch.empty((3, count, p.d), dtype=torch.int32, device=dev)
+                while chain_hi < min(count, o0 + on):  # (o0 may lie beyond a short slab: nothing to chain for this stage then)
+                    c0, c1 = chain_hi, min(count, chain_hi + 255)
+                    ctx.batch_chain(d_ssp, witness_bits_list[first + c0:first + c1], deltas[first + c0:first + c1], out=chain_whv[:, c0:c1, :])
+                    chain_hi = c1
+                whv = chain_whv[:, o0:o0 + on, :]
             # rank r gets rows [d r / world, d (r+1) / world) of w | h | v of the own statements, laid out [statement][w | h | v][rows]
             send = torch.cat([whv[:, :, a:b].permute(1, 0, 2).reshape(-1) for a, b in shares]) if on else whv.reshape(-1)
             recv = torch.empty(len(ids) * 3 * cs, dtype=send.dtype, device=dev)

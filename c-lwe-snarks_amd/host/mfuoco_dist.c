@@ -313,7 +313,7 @@ static void comm_bcast_bytes(mfuoco_comm *c, uint8_t *d_buf, size_t n, int root)
 /* A call is cut into STAGES.  Stage k holds, from every rank, the statements k * sper .. (k + 1) * sper - 1 of that rank's slab (sper = 255 / world, so a stage is at most one
  * super-group of mfh_prove_batch_partial: one pass over the rank's share of the image per stage), in rank order -- ownership and results are those of the one-shot sequence
  * (sums mod 2^(64K) do not depend on the order, and a proof does not depend on which statements share its launches).  Per stage, the five steps of the header:
- *     C  chain of the OWN statements of the stage, operands packed            shim stream
+ *     C  chain of the OWN statements (passes of 255, queued when a stage first needs them), the stage's operands packed            shim stream
  *     A  all-to-all of the w | h | v row slices                               communicator stream, after C
  *     P  the rank's row shares of the stage's statements; L  lanes            shim stream, after A
  *     R  reduce-scatter of the lanes                                          communicator stream, after L
@@ -394,13 +394,18 @@ void mfuoco_prover_batch_sharded(proof_t *pis, crs_t crs, ssp_t ssp, mpz_t *witn
     soff[nst] = pos;
   }
   if (nown) mfuoco_gpu_prover_entropy_batch(delta, mag, sign, nown);
+  /* ... and the own statements' bit strings once more in slab order: the chain runs in passes of up to 255 own statements (one read of the SSP each), whatever the stages */
+  uint8_t *obits = xmalloc((nown ? nown : 1) * stride);
+  memset(obits, 0, (nown ? nown : 1) * stride);
+  for (size_t i = 0; i < nown; i++) mfuoco_gpu_witness_bits(obits + i * stride, witnesses[first + i]);
+  size_t chained = 0; /* own statements whose chain has been queued */
 
   /* device buffers, all of them before anything is queued (growing one frees it, and hipFree waits for the device) */
   const size_t lps = 5 * LANES_PER_CT, smax = sper * (size_t)world;
-  uint32_t *whv[2], *send[2], *recv[2];
+  uint32_t *send[2], *recv[2];
   uint64_t *partial[2], *lanes[2], *own[2];
+  uint32_t *whv = scratch(c, 0, 3 * (nown ? nown : 1) * d * 4); /* w | h | v of ALL own statements: [kind][own statement][d] */
   for (int b = 0; b < 2; b++) {
-    whv[b] = scratch(c, 0 + b, 3 * sper * d * 4);
     send[b] = scratch(c, 2 + b, 3 * sper * d * 4);
     recv[b] = scratch(c, 4 + b, smax * 3 * cs * 4);
     partial[b] = scratch(c, 6 + b, smax * 5 * CTL * 8);
@@ -422,9 +427,14 @@ void mfuoco_prover_batch_sharded(proof_t *pis, crs_t crs, ssp_t ssp, mpz_t *witn
     if (it < nst) {
       const size_t k = it, on = STAGE_CNT(rank, k), olo = k * sper;
       const int b = (int)(k & 1);
-      size_t pre = 0; /* the own statements' place in stage order */
-      for (int q = 0; q < rank; q++) pre += STAGE_CNT(q, k);
-      if (on) CK(mfh_batch_chain(ctx, d_ssp, (uint32_t)on, bits + (soff[k] + pre) * stride, stride, delta + olo, whv[b], whv[b] + on * d, whv[b] + 2 * on * d));
+      /* the chain passes that cover this stage's own statements: 255 statements per pass (one read of the SSP, one set of NTT launches: a pass per STAGE would read
+       * the SSP once per 26 statements on 8 ranks), queued when the first stage that needs them comes up */
+      while (chained < nown && chained < olo + on) { /* (olo may lie beyond a short slab: nothing to chain for this stage then) */
+        const size_t np = nown - chained < 255 ? nown - chained : 255;
+        CK(mfh_batch_chain(ctx, d_ssp, (uint32_t)np, obits + chained * stride, stride, delta + chained, whv + chained * d, whv + (nown + chained) * d,
+                           whv + (2 * nown + chained) * d));
+        chained += np;
+      }
       /* rank q gets rows [d q / world, d (q+1) / world) of w | h | v of the own statements, laid out [statement][w | h | v][rows]; this rank receives its rows of the
        * stage's statements of every rank, in stage order */
       size_t off = 0, at = 0;
@@ -434,7 +444,7 @@ void mfuoco_prover_batch_sharded(proof_t *pis, crs_t crs, ssp_t ssp, mpz_t *witn
         scnt[q] = on * 3 * w;
         if (scnt[q])
           for (int x = 0; x < 3; x++) /* a strided column slice per polynomial kind: one 2-D device copy */
-            HK(hipMemcpy2DAsync(send[b] + off + (size_t)x * w, 3 * w * 4, whv[b] + (size_t)x * on * d + a, d * 4, w * 4, on, hipMemcpyDeviceToDevice, NULL));
+            HK(hipMemcpy2DAsync(send[b] + off + (size_t)x * w, 3 * w * 4, whv + ((size_t)x * nown + olo) * d + a, d * 4, w * 4, on, hipMemcpyDeviceToDevice, NULL));
         off += scnt[q];
         rdsp[q] = at * 3 * cs;
         rcnt[q] = nq * 3 * cs;
@@ -495,7 +505,7 @@ void mfuoco_prover_batch_sharded(proof_t *pis, crs_t crs, ssp_t ssp, mpz_t *witn
   explicit_bzero(mag, (nown ? nown : 1) * 5 * MAGLEN); /* smudging terms and deltas are the proofs' zero-knowledge: not left on the heap */
   explicit_bzero(sign, (nown ? nown : 1) * 5);
   explicit_bzero(delta, (nown ? nown : 1) * 4);
-  free(bits); free(mag); free(sign); free(delta); free(soff);
+  free(bits); free(obits); free(mag); free(sign); free(delta); free(soff);
 }
 
 /* ---- one proof, rows sharded (dist.py: prove_sharded) ------------------------------------------------------------------------ */

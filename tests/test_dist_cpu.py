@@ -136,6 +136,7 @@ class _LinearCtx:
         self.finished = []
         self.device = torch.device("cpu")
         self.partial_calls = 0
+        self.chain_passes = []  # own statements per chain pass: one pass of up to 255 covers every stage (not one pass per stage)
         self._resident_mm = "image share" if resident else None  # (without one a call of several stages expands the rank's shares itself, once)
         self.expansions = 0
         self.params.ctb = 8
@@ -150,12 +151,16 @@ class _LinearCtx:
     def empty(self, nbytes):
         return self.torch.empty(int(nbytes), dtype=self.torch.uint8)
 
-    def batch_chain(self, d_ssp, bits_list, deltas):
+    def batch_chain(self, d_ssp, bits_list, deltas, out=None):
         t, p = self.torch, self.params
-        out = t.zeros((3, len(deltas), p.d), dtype=t.int32)
+        self.chain_passes.append(len(deltas))
+        res = t.zeros((3, len(deltas), p.d), dtype=t.int32)
         for k in range(3):
             for b, idb in enumerate(deltas):
-                out[k, b] = 1000 * k + 10 * idb + t.arange(p.d, dtype=t.int32)
+                res[k, b] = 1000 * k + 10 * idb + t.arange(p.d, dtype=t.int32)
+        if out is None:
+            return res
+        out.copy_(res)
         return out
 
     witness_cols_align = 1  # (the C ABI wants coefficient ranges at multiples of 128; the stand-in takes any)
@@ -234,6 +239,7 @@ def _batch_worker(rank, world, port, out_dir, nb, by_cols=False, stage=None):
     # stages: as planned (one when no image share is registered), one row-work call each; the bytes handed to the backend do not depend on the cut
     sper, nst = mfdist.stage_plan(nb, world, 2 if stage == "no image" else stage)
     ok = ok and ctx.partial_calls == nst
+    ok = ok and (by_cols or ctx.chain_passes == ([count] if count else []))  # (fewer than 255 own statements here: ONE chain pass whatever the stages)
     # no image share registered: a call of several stages expands the rank's shares once, streams them for every stage and leaves nothing registered
     ok = ok and ctx.expansions == (1 if stage == "no image" and nst > 1 else 0) and (stage != "no image" or ctx._resident_mm is None)
     snap = mfdist.collectives_snapshot()
