@@ -50,14 +50,16 @@ def test_c_sharded_prover_one_rank_rccl(tmp_path, stage, resident):
     assert f"all_to_all={nst + 1} reduce_scatter={nst + 1}" in r.stdout, r.stdout  # (+ the second, one-statement call)
 
 
-@pytest.mark.parametrize("world,count,stage", [(2, 9, None), (3, 40, None), (4, 41, None), (3, 40, "5"), (4, 41, "4")])
+@pytest.mark.parametrize("world,count,stage", [(2, 9, None), (3, 40, None), (4, 41, None), (3, 40, "5"), (4, 41, "4"), (4, 9, "1")])
 def test_c_sharded_prover_rehearsal_ranks_share_the_gpu(world, count, stage):
     """the same C sequence with `world` PROCESSES on the one GPU, collectives staged through host shared memory (rehearsal backend): uneven
     statement slabs and row shares (256 rows over 3 ranks), a second call in which the last rank owns no statement.  4 ranks beside this test runner (which holds the GPU itself) stay clear of what the GPU box lets one
     command put on its card at once (its process guard: 6 processes; 6 ranks + the runner were killed by it in round 5), so the machine's real rank count, 8, is rehearsed on the CPU only: the host sequence over gloo in
     tests/test_dist_cpu.py, the rendezvous in tests/test_rendezvous_cpu.py.
     stage ($MFUOCO_DIST_STAGE): several pipeline stages per call -- 40 statements over 3 ranks in stages of 5 per rank: slabs of 14, 14, 12 = stages of 15, 15, 10 (rank 2
-    contributes 2 to the last); 41 over 4 ranks in stages of 4: slabs of 11, 11, 11, 8 = stages of 16, 16, 9 (rank 3 owns none of the last)."""
+    contributes 2 to the last); 41 over 4 ranks in stages of 4: slabs of 11, 11, 11, 8 = stages of 16, 16, 9 (rank 3 owns none of the last); 9 over 4 ranks in stages of 1: slabs of
+    3, 3, 3, 0 -- a rank with NO statement walks stages whose first own index lies beyond its slab (the chain-pass loop spun there forever in the Python mirror before it was
+    bounded by the slab: found by tests/test_dist_cpu.py at 8 ranks)."""
     name = "mfuoco_test_%d_%d" % (os.getpid(), world)
     extra = {"MFUOCO_DIST_STAGE": stage} if stage is not None else {}
     procs = [subprocess.Popen([_sharded_exe(), str(count)], env=_rank_env(rk, world, MFUOCO_REHEARSAL_SHM=name, MFUOCO_SHARE_GPU="1", **extra),
