@@ -502,6 +502,7 @@ void mfuoco_prover_batch_sharded(proof_t *pis, crs_t crs, ssp_t ssp, mpz_t *witn
   if (c->t) HK(hipStreamSynchronize(cst)); /* (a rank without own statements has waited for nothing so far) */
   if (own_image) CK(mfh_crs_set_resident_mm_share(ctx, NULL, (uint32_t)rank, (uint32_t)world));
   if (c == &local) comm_release(&local);
+  CK(mfh_scrub_staging(ctx)); /* (as in prover(): every copy of the call has run; witness bits, deltas and smudging terms leave the context's pinned staging) */
   explicit_bzero(mag, (nown ? nown : 1) * 5 * MAGLEN); /* smudging terms and deltas are the proofs' zero-knowledge: not left on the heap */
   explicit_bzero(sign, (nown ? nown : 1) * 5);
   explicit_bzero(delta, (nown ? nown : 1) * 4);
@@ -540,5 +541,6 @@ void mfuoco_prover_sharded(proof_t pi, crs_t crs, ssp_t ssp, mpz_t witness, mfuo
   explicit_bzero(&ent, sizeof ent);
   proof_t *one = (proof_t *)pi;
   mfuoco_gpu_proofs_to_host(one, proof, 1);
+  CK(mfh_scrub_staging(ctx)); /* (the proof is out: every copy of the call has run) */
   if (c == &local) comm_release(&local);
 }
