@@ -90,7 +90,7 @@ EXPORTS = [
     "mfh_encrypt_rows", "mfh_decrypt", "mfh_ct_smudge", "mfh_ssp_upload", "mfh_witness_poly", "mfh_version",
     "mfh_workspace_bytes", "mfh_last_kernel_ms", "mfh_set_timing", "mfh_set_overlap", "mfh_eval_rows_multi", "mfh_prove_batch", "mfh_crs_mm_image_bytes", "mfh_crs_expand_mm", "mfh_crs_set_resident_mm", "mfh_witness_poly_multi", "mfh_witness_poly_mm", "mfh_poly_h_multi", "mfh_poly_mul", "mfh_poly_add", "mfh_poly_prepare_t",
     "mfh_ssp_prepare", "mfh_poly_h", "mfh_setup_messages", "mfh_setup", "mfh_setup_image", "mfh_crs_image_set_b", "mfh_prove",
-    "mfh_prove_partial", "mfh_prove_finish", "mfh_ct_to_lanes", "mfh_ct_from_lanes", "mfh_lanes_per_value", "mfh_digest128", "mfh_timing_drain", "mfh_timing_busy_ms", "mfh_timing_work_rows", "mfh_set_batch_image", "mfh_set_batch_slabs", "mfh_set_expand_path", "mfh_set_encrypt_path", "mfh_set_batch_launch", "mfh_set_batch_bw", "mfh_set_mm_chunk_rows", "mfh_set_mm_pack", "mfh_set_mm_stream", "mfh_add_dotp", "mfh_set_encrypt_chunks", "mfh_set_witness_per", "mfh_set_eval_path", "mfh_set_decrypt_path", "mfh_decrypt_rows",
+    "mfh_prove_partial", "mfh_prove_finish", "mfh_ct_to_lanes", "mfh_ct_from_lanes", "mfh_lanes_per_value", "mfh_digest128", "mfh_timing_drain", "mfh_timing_busy_ms", "mfh_timing_work_rows", "mfh_set_batch_image", "mfh_set_batch_slabs", "mfh_set_expand_path", "mfh_set_encrypt_path", "mfh_set_batch_launch", "mfh_set_batch_bw", "mfh_set_mm_chunk_rows", "mfh_set_mm_pack", "mfh_set_poly_exact", "mfh_poly_exact_fallbacks", "mfh_set_mm_stream", "mfh_add_dotp", "mfh_set_encrypt_chunks", "mfh_set_witness_per", "mfh_set_eval_path", "mfh_set_decrypt_path", "mfh_decrypt_rows",
     "mfh_crs_mm_share_bytes", "mfh_crs_expand_mm_share", "mfh_crs_set_resident_mm_share", "mfh_batch_chain", "mfh_batch_witness_cols", "mfh_batch_chain_from_w", "mfh_witness_poly_mm_cols", "mfh_prove_batch_partial", "mfh_prove_batch_finish",
     "mfh_resident_row_bytes", "mfh_crs_expand", "mfh_eval_rows_resident", "mfh_crs_set_resident",
     "mfh_witness_lanes", "mfh_witness_from_lanes", "mfh_prove_partial_w", "mfh_verify",
@@ -184,6 +184,8 @@ def load_library():
         "mfh_set_batch_image": (i32, [vp, i32]),
         "mfh_set_mm_chunk_rows": (i32, [vp, u32]),
         "mfh_set_mm_pack": (i32, [vp, i32]),
+        "mfh_set_poly_exact": (i32, [vp, i32]),
+        "mfh_poly_exact_fallbacks": (ctypes.c_long, [vp]),
         "mfh_set_mm_stream": (i32, [vp, i32, i32, i32, u32]),
         "mfh_set_batch_launch": (i32, [vp, u32, i32]),
         "mfh_set_batch_bw": (i32, [vp, i32]),
@@ -331,6 +333,14 @@ class Context:
         """streaming kernels hand their partial products to the epilogue recombined (default) or as int32 (rounds 1 - 5): same results"""
         self._chk(self.lib.mfh_set_mm_pack(self._h, 1 if on else 0))
 
+    def set_poly_exact(self, on=True):
+        """batches of h = (v^2 - 1) / t try the exact-division path (two cyclic products of half the length, checked on the device) before Euclidean division: same results"""
+        self._chk(self.lib.mfh_set_poly_exact(self._h, 1 if on else 0))
+
+    def poly_exact_fallbacks(self):
+        """statements whose exact-division result failed the device check since the last call (they were recomputed by Euclidean division); -1: no exact path for this t"""
+        return int(self.lib.mfh_poly_exact_fallbacks(self._h))
+
     def set_mm_chunk_rows(self, rows=0):
         """rows per row chunk of the matrix-core launches (<= 131071; 0 = default): smaller values force several chunks"""
         self._chk(self.lib.mfh_set_mm_chunk_rows(self._h, int(rows)))
@@ -466,6 +476,12 @@ class Context:
     def poly_h(self, d_v):
         out = self.empty(self.params.d * 4)
         self._chk(self.lib.mfh_poly_h(self._h, _ptr(d_v), _ptr(out)))
+        return out
+
+    def poly_h_many(self, d_v, nb):
+        """h_k = floor((v_k^2 - 1) / t) for nb polynomials side by side (mfh_poly_h_multi): one set of launches for the batch"""
+        out = self.empty(nb * self.params.d * 4)
+        self._chk(self.lib.mfh_poly_h_multi(self._h, _ptr(d_v), _ptr(out), nb))
         return out
 
     def setup_messages(self, d_ssp, alpha, beta, s):

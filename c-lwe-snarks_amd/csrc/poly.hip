@@ -7,6 +7,15 @@
 // result is the canonical representative in [0, p), it is bit-identical to FLINT's whatever algorithm FLINT picks.
 // Division is a multiplication by the power-series inverse of rev(t), computed once per SSP by Newton iteration
 // (mfh_poly_prepare_t): q = rev( rev(A)[:n] * rev(t)^-1 mod x^n ), n = deg A - deg t + 1.
+//
+// Round 6, the exact-division path of a BATCH of statements: a prover with a valid witness divides exactly (t | v^2 - 1, src/ssp.c:37-77), and an exact quotient
+// of d coefficients is determined by the identity h t = v^2 - 1 taken modulo x^N - 1, N = the power of two >= d: h = (v^2 - 1 mod x^N - 1) * T' mod x^N - 1 with
+// T' = t^-1 in F_p[x] / (x^N - 1) -- two CYCLIC products of length N instead of two linear ones of length 2N: half the transform work (2^15 points instead of 2^16 at the
+// default size) and no reversals.  T' is computed once per SSP by the norm recursion a^-1 = a(-x) [a(x) a(-x)]^-1, the bracket being a polynomial in x^2, i.e. an
+// element of the ring of half the length (log N levels down to a scalar).  Whether the division WAS exact is not assumed: the batch's results are checked on the device
+// (h(r) t(r) = v(r)^2 - 1 at four points r: a wrong h of ANY origin survives with probability <= (2d / p)^4 < 2^-64), and when one statement fails the Euclidean path above
+// recomputes the statements that failed -- its kernels are queued behind the check, sized for the whole batch, and each workgroup returns at once unless the list
+// of failed statements reaches it: nothing waits for the host, and a batch with k such statements pays the Euclidean path for k.
 #include <algorithm>
 
 #include "ctx.hpp"
@@ -14,6 +23,12 @@
 namespace {
 
 constexpr uint32_t P32 = 0xfffffffbu;
+
+// kernels of the Euclidean path take `need`: nullptr = every polynomial of the launch; else only the first *need ones -- the statements whose exact-division result
+// failed the check, compacted: polynomial vs of the launch is statement need[2 + vs] of the batch (k_exact_check), which matters where a launch reads the
+// batch's input or writes its output (`map` = need + 2 there); the transform and scratch buffers in between hold the compacted polynomials.  Nothing failed: every
+// workgroup returns at once.
+#define MF_NEEDED(need, vs) do { if ((need) && (vs) >= *(need)) return; } while (0)
 
 struct NttPrime {
   uint32_t p, ninv, r2;  // modulus, -p^-1 mod 2^32, 2^64 mod p
@@ -58,11 +73,13 @@ uint64_t h_powmod(uint64_t a, uint64_t e, uint64_t p) {
 // load `len` coefficients (mod p32) into [3][N] Montgomery residues, zero padded
 // grid.y = 3 * batch everywhere below: blockIdx.y % 3 is the prime, blockIdx.y / 3 the polynomial of the batch; transform buffers are
 // [batch][3][N], so blockIdx.y * N addresses them as before
-__global__ void k_ntt_load(const uint32_t *__restrict__ in, uint32_t len, uint32_t N, Primes3 P, uint32_t *__restrict__ out, size_t in_stride) {
+__global__ void k_ntt_load(const uint32_t *__restrict__ in, uint32_t len, uint32_t N, Primes3 P, uint32_t *__restrict__ out, size_t in_stride,
+                           const uint32_t *__restrict__ need = nullptr, const uint32_t *__restrict__ map = nullptr) {
+  MF_NEEDED(need, blockIdx.y / 3);
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   const NttPrime q = P.q[blockIdx.y % 3];
-  uint32_t x = i < len ? in[(size_t)(blockIdx.y / 3) * in_stride + i] : 0u;
+  uint32_t x = i < len ? in[(size_t)(map ? map[blockIdx.y / 3] : blockIdx.y / 3) * in_stride + i] : 0u;
   out[(size_t)blockIdx.y * N + i] = mont_mul(x, q.r2, q.p, q.ninv);  // x * R mod p (x < 2^32, r2 < p: product < p * 2^32)
 }
 
@@ -102,7 +119,9 @@ __global__ void k_ntt_dit(uint32_t *__restrict__ a, uint32_t N, uint32_t len, co
 template <int K>
 __global__ __launch_bounds__(256) void k_ntt_dif_multi(uint32_t *__restrict__ a, uint32_t N, uint32_t len, const uint32_t *__restrict__ tw,
                                                        uint32_t half_max, Primes3 P, const uint32_t *__restrict__ in = nullptr, uint32_t in_len = 0,
-                                                       size_t in_stride = 0) {
+                                                       size_t in_stride = 0, const uint32_t *__restrict__ need = nullptr,
+                                                       const uint32_t *__restrict__ map = nullptr) {
+  MF_NEEDED(need, blockIdx.y / 3);
   constexpr int R = 1 << K;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (N >> K)) return;
@@ -114,7 +133,7 @@ __global__ __launch_bounds__(256) void k_ntt_dif_multi(uint32_t *__restrict__ a,
   const uint32_t *t = tw + (size_t)(blockIdx.y % 3) * half_max;
   uint32_t v[R];
   if (in) {
-    const uint32_t *src = in + (size_t)(blockIdx.y / 3) * in_stride;
+    const uint32_t *src = in + (size_t)(map ? map[blockIdx.y / 3] : blockIdx.y / 3) * in_stride;
 #pragma unroll
     for (int m = 0; m < R; m++) {
       const uint32_t e = s + j + (uint32_t)m * qd;
@@ -146,7 +165,8 @@ __global__ __launch_bounds__(256) void k_ntt_dif_multi(uint32_t *__restrict__ a,
 // K consecutive DIT stages with block lengths len, 2len, ..., len<<(K-1) (inverse twiddles)
 template <int K>
 __global__ __launch_bounds__(256) void k_ntt_dit_multi(uint32_t *__restrict__ a, uint32_t N, uint32_t len, const uint32_t *__restrict__ tw,
-                                                       uint32_t half_max, Primes3 P) {
+                                                       uint32_t half_max, Primes3 P, const uint32_t *__restrict__ need = nullptr) {
+  MF_NEEDED(need, blockIdx.y / 3);
   constexpr int R = 1 << K;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (N >> K)) return;
@@ -215,7 +235,9 @@ __global__ __launch_bounds__(256) void k_ntt_lds(uint32_t *__restrict__ a, uint3
 // forward low stages + pointwise product + inverse low stages of one 2^B block, all in LDS: a <- INTT_low( NTT_low(a) .* rhs ),
 // rhs = NTT_low-transformed b (b == nullptr: a itself, i.e. squaring; b_is_hat: b is already fully transformed, e.g. the cached G^).
 __global__ __launch_bounds__(256) void k_ntt_lds_mul(uint32_t *__restrict__ a, const uint32_t *__restrict__ b, int b_is_hat, uint32_t N, uint32_t B,
-                                                     const uint32_t *__restrict__ tw, const uint32_t *__restrict__ twi, uint32_t half_max, Primes3 P) {
+                                                     const uint32_t *__restrict__ tw, const uint32_t *__restrict__ twi, uint32_t half_max, Primes3 P,
+                                                     const uint32_t *__restrict__ need = nullptr) {
+  MF_NEEDED(need, blockIdx.y / 3);
   __shared__ uint32_t sa[2048];
   __shared__ uint32_t sb[2048];
   const NttPrime q = P.q[blockIdx.y % 3];
@@ -313,7 +335,9 @@ __device__ __forceinline__ void dit_regs(uint32_t *v, uint32_t j, uint32_t qd, u
   }
 }
 __global__ __launch_bounds__(256) void k_ntt_lds_mul8(uint32_t *__restrict__ a, const uint32_t *__restrict__ bhat, uint32_t N,
-                                                      const uint32_t *__restrict__ tw, const uint32_t *__restrict__ twi, uint32_t half_max, Primes3 P) {
+                                                      const uint32_t *__restrict__ tw, const uint32_t *__restrict__ twi, uint32_t half_max, Primes3 P,
+                                                      const uint32_t *__restrict__ need = nullptr) {
+  MF_NEEDED(need, blockIdx.y / 3);
   __shared__ uint32_t sm[2048 + 64];
   // the block's stages use every (half_max / 1024)-th entry of the twiddle tables: 2 x 1024 words, staged in LDS once per workgroup -- the
   // 88 twiddle reads per thread are then LDS gathers instead of global ones (64 different cache lines per wave-load)
@@ -408,7 +432,9 @@ struct Crt {
   uint32_t p1_mod, p1p2_mod;                 // p1 mod p32, p1*p2 mod p32
 };
 // residues (Montgomery, unscaled inverse transform) -> coefficient mod p32, first `count` coefficients
-__global__ void k_crt(const uint32_t *__restrict__ r, uint32_t N, uint32_t count, Primes3 P, Crt C, uint32_t *__restrict__ out, size_t out_stride) {
+__global__ void k_crt(const uint32_t *__restrict__ r, uint32_t N, uint32_t count, Primes3 P, Crt C, uint32_t *__restrict__ out, size_t out_stride,
+                      const uint32_t *__restrict__ need = nullptr) {
+  MF_NEEDED(need, blockIdx.y);
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
   r += (size_t)blockIdx.y * 3 * N;  // grid.y = batch
@@ -429,7 +455,8 @@ __global__ void k_crt(const uint32_t *__restrict__ r, uint32_t N, uint32_t count
 }
 
 __global__ void k_reverse(const uint32_t *__restrict__ in, int64_t top, uint32_t count, uint32_t *__restrict__ out, size_t in_stride = 0,
-                          size_t out_stride = 0) {
+                          size_t out_stride = 0, const uint32_t *__restrict__ need = nullptr) {
+  MF_NEEDED(need, blockIdx.y);
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;  // out[i] = in[top - i] (0 if top - i < 0); grid.y = batch
   if (i >= count) return;
   in += (size_t)blockIdx.y * in_stride;
@@ -444,7 +471,8 @@ __global__ void k_two_minus(uint32_t *__restrict__ e, uint32_t count) {  // e <-
   uint32_t neg = v ? P32 - v : 0u;
   e[i] = i == 0 ? red_p32((uint64_t)neg + 2) : neg;
 }
-__global__ void k_sub_const0(uint32_t *__restrict__ a, uint32_t c, size_t stride = 0) {  // a[0] -= c; grid.x = batch
+__global__ void k_sub_const0(uint32_t *__restrict__ a, uint32_t c, size_t stride = 0, const uint32_t *__restrict__ need = nullptr) {  // a[0] -= c; grid.x = batch
+  MF_NEEDED(need, blockIdx.x);
   if (threadIdx.x == 0) a[(size_t)blockIdx.x * stride] = red_p32((uint64_t)a[(size_t)blockIdx.x * stride] + P32 - c);
 }
 __global__ void k_add_vec(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, uint32_t count, uint32_t *__restrict__ out) {
@@ -453,12 +481,76 @@ __global__ void k_add_vec(const uint32_t *__restrict__ a, const uint32_t *__rest
 }
 // out[i] = q[n-1-i] for i < min(n, d), zero above (quotient reversed back, first d coefficients)
 __global__ void k_unreverse_pad(const uint32_t *__restrict__ qrev, uint32_t n, uint32_t d, uint32_t *__restrict__ out, size_t in_stride = 0,
-                                size_t out_stride = 0) {
+                                size_t out_stride = 0, const uint32_t *__restrict__ need = nullptr, const uint32_t *__restrict__ map = nullptr) {
+  MF_NEEDED(need, blockIdx.y);
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= d) return;
   qrev += (size_t)blockIdx.y * in_stride;
-  out += (size_t)blockIdx.y * out_stride;
+  out += (size_t)(map ? map[blockIdx.y] : blockIdx.y) * out_stride;
   out[i] = i < n ? qrev[n - 1 - i] : 0u;
+}
+
+// ---- the ring F_p[x] / (x^n - 1), n a power of two (the exact-division path) --------------------------------------------------------
+// out(x) = a(-x): an automorphism of the ring for even n
+__global__ void k_conj(const uint32_t *__restrict__ a, uint32_t n, uint32_t *__restrict__ out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (i & 1) && a[i] ? P32 - a[i] : a[i];
+}
+// c: the 2n - 1 coefficients of a linear product of two ring elements.  out[j] = c[j] + c[j + n] (the product in the ring), j < n ...
+__global__ void k_fold(const uint32_t *__restrict__ c, uint32_t n, uint32_t *__restrict__ out) {
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n) out[j] = red_p32((uint64_t)c[j] + (j + n < 2 * n - 1 ? c[j + n] : 0u));
+}
+// ... and its even coefficients only, as an element of the ring of half the length in y = x^2 (the norm a(x) a(-x) has no odd ones): out[i] = c[2i] + c[2i + n], i < n / 2
+__global__ void k_fold_even(const uint32_t *__restrict__ c, uint32_t n, uint32_t *__restrict__ out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n / 2) out[i] = red_p32((uint64_t)c[2 * i] + c[2 * i + n]);
+}
+// out(x) = b(x^2): n / 2 coefficients spread over n
+__global__ void k_spread2(const uint32_t *__restrict__ b, uint32_t n, uint32_t *__restrict__ out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (i & 1) ? 0u : b[i >> 1];
+}
+// the check behind the exact-division path, one workgroup per statement: h(r) t(r) = v(r)^2 - 1 at the four points?  pw[j][i] = r_j^i, t_at[j] = t(r_j).  A statement that
+// fails at one of them appends itself to the list the Euclidean kernels queued behind work through (need[0] = length, need[2 ..] = statements) and counts in need[1].
+__global__ __launch_bounds__(1024) void k_exact_check(const uint32_t *__restrict__ v, const uint32_t *__restrict__ h, uint32_t d, const uint32_t *__restrict__ pw,
+                                                      uint32_t pw_stride, uint4 t_at, uint32_t *__restrict__ need) {
+  __shared__ uint32_t red[16][8];
+  const uint32_t *vk = v + (size_t)blockIdx.x * d, *hk = h + (size_t)blockIdx.x * d;
+  uint64_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // v at the four points, then h
+  for (uint32_t i = threadIdx.x; i < d; i += 1024) {
+    const uint64_t x = vk[i], y = hk[i];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const uint64_t w = pw[(size_t)j * pw_stride + i];
+      acc[j] = red_p32(acc[j] + x * w);  // (2^32 - 1)^2 + 2^32 < 2^64
+      acc[4 + j] = red_p32(acc[4 + j] + y * w);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    uint32_t a = (uint32_t)acc[j];
+#pragma unroll
+    for (int o = 32; o; o >>= 1) a = red_p32((uint64_t)a + __shfl_xor(a, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][j] = a;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t tj[4] = {t_at.x, t_at.y, t_at.z, t_at.w};
+    uint64_t sum[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      sum[j] = 0;
+      for (int w = 0; w < 16; w++) sum[j] = red_p32(sum[j] + red[w][j]);
+    }
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < 4; j++) bad |= red_p32(sum[4 + j] * tj[j]) != red_p32(sum[j] * sum[j] + (P32 - 1));
+    if (bad) {
+      need[2 + atomicAdd(need, 1u)] = blockIdx.x;
+      atomicAdd(need + 1, 1u);
+    }
+  }
 }
 
 inline dim3 g1(uint32_t n) { return dim3((n + 255) / 256); }
@@ -481,8 +573,15 @@ struct PolyState {
   uint32_t *d_G = nullptr;     // n coefficients of rev(t)^-1
   uint32_t *d_Ghat = nullptr;  // [3][N2] forward transform of G
   uint32_t *d_f = nullptr;     // rev(t), dt+1 coefficients
+  // ... and the exact-division path (when deg t = d - 1 and t is a unit modulo x^Nc - 1)
+  bool cyc = false;
+  uint32_t logNc = 0;            // Nc = 2^logNc >= d
+  uint32_t *d_That = nullptr;    // [3][Nc] forward transform of t^-1 mod (x^Nc - 1)
+  uint32_t *d_chk = nullptr;     // [4][Nc] powers of the four check points
+  uint32_t chk_t[4]{};           // t at the check points
+  uint32_t *d_need = nullptr;    // [0] statements of the batch that failed the check, [1] the same since the last reset, [2 ..] which ones (k_exact_check)
   ~PolyState() {
-    for (uint32_t *p : {d_tw, d_twi, d_bufA, d_bufB, d_tmp, d_tmp2, d_G, d_Ghat, d_f})
+    for (uint32_t *p : {d_tw, d_twi, d_bufA, d_bufB, d_tmp, d_tmp2, d_G, d_Ghat, d_f, d_That, d_chk, d_need})
       if (p) hipFree(p);
   }
 };
@@ -491,6 +590,7 @@ namespace {
 
 const uint32_t kPrimes[3] = {2013265921u, 1811939329u, 2113929217u};  // 15*2^27+1, 27*2^26+1, 63*2^25+1
 const uint32_t kRoots[3] = {31u, 13u, 5u};                             // primitive roots (checked at init)
+constexpr uint32_t kMaxBatch = 21845;  // polynomials side by side: 3 per polynomial on grid.y (<= 65535)
 
 uint32_t to_mont(uint64_t x, const NttPrime &q) { return (uint32_t)(((unsigned __int128)(x % q.p) << 32) % q.p); }
 
@@ -577,7 +677,8 @@ uint32_t ceil_log2(size_t x) {
 // the top (register) stages of a forward / inverse transform; the low B = min(logN, 11) stages run in LDS
 // (up to five stages per pass: 32 elements per thread; 2^16 -> one pass of 5, 2^21 -> two.  `in`: the coefficients to load in the first
 // pass instead of a separate k_ntt_load; returns false when there is no register pass to fuse the load into)
-bool forward_top(mfh_ctx *c, uint32_t *buf, uint32_t logN, uint32_t nb = 1, const uint32_t *in = nullptr, uint32_t in_len = 0, size_t in_stride = 0) {
+bool forward_top(mfh_ctx *c, uint32_t *buf, uint32_t logN, uint32_t nb = 1, const uint32_t *in = nullptr, uint32_t in_len = 0, size_t in_stride = 0,
+                 const uint32_t *need = nullptr, const uint32_t *map = nullptr) {
   PolyState *S = c->poly;
   const uint32_t N = 1u << logN, half_max = 1u << (S->logmax - 1);
   uint32_t top = logN - std::min(logN, 11u), len = N;
@@ -586,19 +687,20 @@ bool forward_top(mfh_ctx *c, uint32_t *buf, uint32_t logN, uint32_t nb = 1, cons
     const uint32_t k = top > 5 ? std::min(top - 3, 5u) : top;  // never leave a pass of fewer than three stages behind a full one
     dim3 g(((N >> k) + 255) / 256, 3 * nb);
     switch (k) {
-      case 5: hipLaunchKernelGGL(k_ntt_dif_multi<5>, g, dim3(256), 0, c->stream, buf, N, len, S->d_tw, half_max, S->P, in, in_len, in_stride); break;
-      case 4: hipLaunchKernelGGL(k_ntt_dif_multi<4>, g, dim3(256), 0, c->stream, buf, N, len, S->d_tw, half_max, S->P, in, in_len, in_stride); break;
-      case 3: hipLaunchKernelGGL(k_ntt_dif_multi<3>, g, dim3(256), 0, c->stream, buf, N, len, S->d_tw, half_max, S->P, in, in_len, in_stride); break;
-      case 2: hipLaunchKernelGGL(k_ntt_dif_multi<2>, g, dim3(256), 0, c->stream, buf, N, len, S->d_tw, half_max, S->P, in, in_len, in_stride); break;
-      default: hipLaunchKernelGGL(k_ntt_dif_multi<1>, g, dim3(256), 0, c->stream, buf, N, len, S->d_tw, half_max, S->P, in, in_len, in_stride); break;
+      case 5: hipLaunchKernelGGL(k_ntt_dif_multi<5>, g, dim3(256), 0, c->stream, buf, N, len, S->d_tw, half_max, S->P, in, in_len, in_stride, need, map); break;
+      case 4: hipLaunchKernelGGL(k_ntt_dif_multi<4>, g, dim3(256), 0, c->stream, buf, N, len, S->d_tw, half_max, S->P, in, in_len, in_stride, need, map); break;
+      case 3: hipLaunchKernelGGL(k_ntt_dif_multi<3>, g, dim3(256), 0, c->stream, buf, N, len, S->d_tw, half_max, S->P, in, in_len, in_stride, need, map); break;
+      case 2: hipLaunchKernelGGL(k_ntt_dif_multi<2>, g, dim3(256), 0, c->stream, buf, N, len, S->d_tw, half_max, S->P, in, in_len, in_stride, need, map); break;
+      default: hipLaunchKernelGGL(k_ntt_dif_multi<1>, g, dim3(256), 0, c->stream, buf, N, len, S->d_tw, half_max, S->P, in, in_len, in_stride, need, map); break;
     }
     in = nullptr;
+    map = nullptr;
     len >>= k;
     top -= k;
   }
   return true;
 }
-void inverse_top(mfh_ctx *c, uint32_t *buf, uint32_t logN, uint32_t nb = 1) {
+void inverse_top(mfh_ctx *c, uint32_t *buf, uint32_t logN, uint32_t nb = 1, const uint32_t *need = nullptr) {
   PolyState *S = c->poly;
   const uint32_t N = 1u << logN, half_max = 1u << (S->logmax - 1);
   const uint32_t B = std::min(logN, 11u);
@@ -607,11 +709,11 @@ void inverse_top(mfh_ctx *c, uint32_t *buf, uint32_t logN, uint32_t nb = 1) {
     const uint32_t k = top > 5 ? std::min(top - 3, 5u) : top;
     dim3 g(((N >> k) + 255) / 256, 3 * nb);
     switch (k) {
-      case 5: hipLaunchKernelGGL(k_ntt_dit_multi<5>, g, dim3(256), 0, c->stream, buf, N, len, S->d_twi, half_max, S->P); break;
-      case 4: hipLaunchKernelGGL(k_ntt_dit_multi<4>, g, dim3(256), 0, c->stream, buf, N, len, S->d_twi, half_max, S->P); break;
-      case 3: hipLaunchKernelGGL(k_ntt_dit_multi<3>, g, dim3(256), 0, c->stream, buf, N, len, S->d_twi, half_max, S->P); break;
-      case 2: hipLaunchKernelGGL(k_ntt_dit_multi<2>, g, dim3(256), 0, c->stream, buf, N, len, S->d_twi, half_max, S->P); break;
-      default: hipLaunchKernelGGL(k_ntt_dit_multi<1>, g, dim3(256), 0, c->stream, buf, N, len, S->d_twi, half_max, S->P); break;
+      case 5: hipLaunchKernelGGL(k_ntt_dit_multi<5>, g, dim3(256), 0, c->stream, buf, N, len, S->d_twi, half_max, S->P, need); break;
+      case 4: hipLaunchKernelGGL(k_ntt_dit_multi<4>, g, dim3(256), 0, c->stream, buf, N, len, S->d_twi, half_max, S->P, need); break;
+      case 3: hipLaunchKernelGGL(k_ntt_dit_multi<3>, g, dim3(256), 0, c->stream, buf, N, len, S->d_twi, half_max, S->P, need); break;
+      case 2: hipLaunchKernelGGL(k_ntt_dit_multi<2>, g, dim3(256), 0, c->stream, buf, N, len, S->d_twi, half_max, S->P, need); break;
+      default: hipLaunchKernelGGL(k_ntt_dit_multi<1>, g, dim3(256), 0, c->stream, buf, N, len, S->d_twi, half_max, S->P, need); break;
     }
     len <<= k;
     top -= k;
@@ -637,18 +739,21 @@ Crt make_crt(const PolyState *S, uint32_t logN) {
 
 // c[0..keep) = (a * b)[0..keep) mod p32.  bhat != null: use that precomputed forward transform (size 2^logN) instead of b.
 // nb > 1: nb products side by side, polynomial k at a + k a_stride (and b + k a_stride), result at out + k out_stride.
+// log_cyc != 0: the product in F_p[x] / (x^N - 1), N = 2^log_cyc >= la, lb (the transform of that length IS the cyclic product).  need, a_map (which polynomial at `a`
+// product k reads): see MF_NEEDED.
 int poly_mul(mfh_ctx *c, const uint32_t *a, uint32_t la, const uint32_t *b, uint32_t lb, const uint32_t *bhat, uint32_t logN_hat,
-             uint32_t *out, uint32_t keep, uint32_t nb = 1, size_t a_stride = 0, size_t out_stride = 0) {
+             uint32_t *out, uint32_t keep, uint32_t nb = 1, size_t a_stride = 0, size_t out_stride = 0, const uint32_t *need = nullptr, uint32_t log_cyc = 0,
+             const uint32_t *a_map = nullptr) {
   PolyState *S = c->poly;
-  uint32_t logN = bhat ? logN_hat : ceil_log2((size_t)la + lb - 1);
+  uint32_t logN = log_cyc ? log_cyc : bhat ? logN_hat : ceil_log2((size_t)la + lb - 1);
   if (logN < 1) logN = 1;
-  if (logN > S->logmax || ((size_t)la + lb - 1) > ((size_t)1 << logN)) {
+  if (logN > S->logmax || (log_cyc ? std::max(la, lb) : (size_t)la + lb - 1) > ((size_t)1 << logN) || (bhat && logN != logN_hat)) {
     c->err = "poly_mul: size exceeds the prepared NTT length";
     return MFH_EINVAL;
   }
   const uint32_t N = 1u << logN, half_max = 1u << (S->logmax - 1), B = std::min(logN, 11u);
-  if (!forward_top(c, S->d_bufA, logN, nb, a, la, a_stride)) {  // (no register pass at this size: load on its own)
-    hipLaunchKernelGGL(k_ntt_load, dim3((N + 255) / 256, 3 * nb), dim3(256), 0, c->stream, a, la, N, S->P, S->d_bufA, a_stride);
+  if (!forward_top(c, S->d_bufA, logN, nb, a, la, a_stride, need, a_map)) {  // (no register pass at this size: load on its own)
+    hipLaunchKernelGGL(k_ntt_load, dim3((N + 255) / 256, 3 * nb), dim3(256), 0, c->stream, a, la, N, S->P, S->d_bufA, a_stride, need, a_map);
   }
   const uint32_t *rhs = bhat;  // already fully transformed
   int is_hat = 1;
@@ -657,19 +762,100 @@ int poly_mul(mfh_ctx *c, const uint32_t *a, uint32_t la, const uint32_t *b, uint
     if (b == a && lb == la) {
       rhs = nullptr;  // square
     } else {
-      if (!forward_top(c, S->d_bufB, logN, nb, b, lb, a_stride))
-        hipLaunchKernelGGL(k_ntt_load, dim3((N + 255) / 256, 3 * nb), dim3(256), 0, c->stream, b, lb, N, S->P, S->d_bufB, a_stride);
+      if (!forward_top(c, S->d_bufB, logN, nb, b, lb, a_stride, need))
+        hipLaunchKernelGGL(k_ntt_load, dim3((N + 255) / 256, 3 * nb), dim3(256), 0, c->stream, b, lb, N, S->P, S->d_bufB, a_stride, need, (const uint32_t *)nullptr);
       rhs = S->d_bufB;
     }
   }
   // low forward stages of both operands, pointwise product, low inverse stages: one kernel, the block never leaves LDS
   if (B == 11 && (rhs == nullptr || is_hat))
-    hipLaunchKernelGGL(k_ntt_lds_mul8, dim3(N >> B, 3 * nb), dim3(256), 0, c->stream, S->d_bufA, rhs, N, S->d_tw, S->d_twi, half_max, S->P);
+    hipLaunchKernelGGL(k_ntt_lds_mul8, dim3(N >> B, 3 * nb), dim3(256), 0, c->stream, S->d_bufA, rhs, N, S->d_tw, S->d_twi, half_max, S->P, need);
   else
-    hipLaunchKernelGGL(k_ntt_lds_mul, dim3(N >> B, 3 * nb), dim3(256), 0, c->stream, S->d_bufA, rhs, is_hat, N, B, S->d_tw, S->d_twi, half_max, S->P);
-  inverse_top(c, S->d_bufA, logN, nb);
-  hipLaunchKernelGGL(k_crt, dim3((keep + 255) / 256, nb), dim3(256), 0, c->stream, S->d_bufA, N, keep, S->P, make_crt(S, logN), out, out_stride);
+    hipLaunchKernelGGL(k_ntt_lds_mul, dim3(N >> B, 3 * nb), dim3(256), 0, c->stream, S->d_bufA, rhs, is_hat, N, B, S->d_tw, S->d_twi, half_max, S->P, need);
+  inverse_top(c, S->d_bufA, logN, nb, need);
+  hipLaunchKernelGGL(k_crt, dim3((keep + 255) / 256, nb), dim3(256), 0, c->stream, S->d_bufA, N, keep, S->P, make_crt(S, logN), out, out_stride, need);
   HIP_TRY(c, hipGetLastError());
+  return MFH_OK;
+}
+
+// T' = t^-1 in F_p[x] / (x^Nc - 1) by the norm recursion, its transform, and the check points: everything the exact-division path of mfh_poly_h_multi needs.
+// Leaves S->cyc false (and the Euclidean path in charge) when deg t < d - 1 or t is not a unit of that ring.
+int prepare_exact(mfh_ctx *c, const uint32_t *d_t, const std::vector<uint32_t> &t) {
+  PolyState *S = c->poly;
+  S->cyc = false;
+  for (uint32_t **p : {&S->d_That, &S->d_chk})
+    if (*p) { hipFree(*p); *p = nullptr; }
+  const uint32_t d = S->d;
+  if (S->dt != d - 1 || d < 2) return MFH_OK;
+  const uint32_t logNc = ceil_log2(d), Nc = 1u << logNc;
+  if (logNc + 1 > S->logmax) return MFH_OK;  // (the linear products below have 2 Nc - 1 coefficients)
+  if (!S->d_need) {
+    HIP_TRY(c, hipMalloc(&S->d_need, (size_t)(2 + kMaxBatch) * 4));
+    HIP_TRY(c, hipMemsetAsync(S->d_need, 0, 8, c->stream));
+  }
+  // scratch: the ring elements a_0 = t, a_1, ... of lengths Nc, Nc / 2, ..., 1 (2 Nc words), a(-x), b(x^2) and two inverses (Nc each)
+  uint32_t *scr = nullptr;
+  HIP_TRY(c, hipMalloc(&scr, (size_t)6 * Nc * 4));
+  struct Free { uint32_t *p; ~Free() { hipFree(p); } } guard{scr};
+  uint32_t *lev = scr, *cj = scr + 2 * (size_t)Nc, *sp = cj + Nc, *inv[2] = {sp + Nc, sp + 2 * (size_t)Nc};
+  HIP_TRY(c, hipMemsetAsync(lev, 0, (size_t)Nc * 4, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(lev, d_t, (size_t)d * 4, hipMemcpyDeviceToDevice, c->stream));
+  std::vector<size_t> off{0};
+  int rc;
+  for (uint32_t n = Nc; n > 1; n >>= 1) {  // down: a_{k+1}(x^2) = a_k(x) a_k(-x)
+    uint32_t *a = lev + off.back();
+    hipLaunchKernelGGL(k_conj, g1(n), dim3(256), 0, c->stream, a, n, cj);
+    if ((rc = poly_mul(c, a, n, cj, n, nullptr, 0, S->d_tmp, 2 * n - 1))) return rc;
+    off.push_back(off.back() + n);
+    hipLaunchKernelGGL(k_fold_even, g1(n / 2), dim3(256), 0, c->stream, S->d_tmp, n, lev + off.back());
+  }
+  uint32_t bottom = 0;  // the ring of length 1: a scalar
+  HIP_TRY(c, hipMemcpyAsync(&bottom, lev + off.back(), 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (!bottom) return MFH_OK;  // t shares a factor with x^Nc - 1 (probability about 2 / p for a random t)
+  const uint32_t binv = (uint32_t)h_powmod(bottom, (uint64_t)P32 - 2, P32);
+  HIP_TRY(c, hipMemcpyAsync(inv[0], &binv, 4, hipMemcpyHostToDevice, c->stream));
+  int cur = 0;
+  for (int k = (int)off.size() - 2; k >= 0; k--) {  // up: a_k^-1 = a_k(-x) a_{k+1}^-1(x^2)
+    const uint32_t n = Nc >> k;
+    hipLaunchKernelGGL(k_conj, g1(n), dim3(256), 0, c->stream, lev + off[k], n, cj);
+    hipLaunchKernelGGL(k_spread2, g1(n), dim3(256), 0, c->stream, inv[cur], n, sp);
+    if ((rc = poly_mul(c, cj, n, sp, n, nullptr, 0, S->d_tmp, 2 * n - 1))) return rc;
+    hipLaunchKernelGGL(k_fold, g1(n), dim3(256), 0, c->stream, S->d_tmp, n, inv[cur ^ 1]);
+    cur ^= 1;
+  }
+  // t T' = 1 in the ring?  (checked, not assumed: one more product and Nc words to the host, once per SSP)
+  if ((rc = poly_mul(c, lev, Nc, inv[cur], Nc, nullptr, 0, S->d_tmp, 2 * Nc - 1))) return rc;
+  hipLaunchKernelGGL(k_fold, g1(Nc), dim3(256), 0, c->stream, S->d_tmp, Nc, sp);
+  std::vector<uint32_t> one(Nc);
+  HIP_TRY(c, hipMemcpyAsync(one.data(), sp, (size_t)Nc * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (one[0] != 1 || std::any_of(one.begin() + 1, one.end(), [](uint32_t x) { return x != 0; })) return MFH_OK;
+  HIP_TRY(c, hipMalloc(&S->d_That, (size_t)3 * Nc * 4));
+  hipLaunchKernelGGL(k_ntt_load, dim3((Nc + 255) / 256, 3), dim3(256), 0, c->stream, inv[cur], Nc, Nc, S->P, S->d_That, (size_t)0, (const uint32_t *)nullptr,
+                     (const uint32_t *)nullptr);
+  forward(c, S->d_That, logNc);
+  // the check points: fixed, odd, spread over F_p (splitmix64 of 1..4); their powers and t at them
+  std::vector<uint32_t> pw((size_t)4 * Nc);
+  for (int j = 0; j < 4; j++) {
+    uint64_t z = 0x9e3779b97f4a7c15ull * (uint64_t)(j + 1);
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    const uint64_t r = 2 + (z ^ (z >> 31)) % (P32 - 2);
+    uint64_t x = 1, tv = 0;
+    for (uint32_t i = 0; i < Nc; i++) {
+      pw[(size_t)j * Nc + i] = (uint32_t)x;
+      if (i < d) tv = (tv + x * t[i]) % P32;
+      x = x * r % P32;
+    }
+    S->chk_t[j] = (uint32_t)tv;
+  }
+  HIP_TRY(c, hipMalloc(&S->d_chk, pw.size() * 4));
+  HIP_TRY(c, hipMemcpyAsync(S->d_chk, pw.data(), pw.size() * 4, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  S->logNc = logNc;
+  S->cyc = true;
   return MFH_OK;
 }
 
@@ -739,10 +925,12 @@ int mfh_poly_prepare_t(mfh_ctx *c, const uint32_t *d_t) {
     k = k2;
   }
   // forward transform of G at the size used per proof
-  hipLaunchKernelGGL(k_ntt_load, dim3((N2 + 255) / 256, 3), dim3(256), 0, c->stream, S->d_G, n, N2, S->P, S->d_Ghat, (size_t)0);
+  hipLaunchKernelGGL(k_ntt_load, dim3((N2 + 255) / 256, 3), dim3(256), 0, c->stream, S->d_G, n, N2, S->P, S->d_Ghat, (size_t)0, (const uint32_t *)nullptr,
+                     (const uint32_t *)nullptr);
   forward(c, S->d_Ghat, S->logN2);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if ((rc = prepare_exact(c, d_t, t))) return rc;
   S->have_t = true;
   return MFH_OK;
 }
@@ -750,7 +938,7 @@ int mfh_poly_prepare_t(mfh_ctx *c, const uint32_t *d_t) {
 // h_k = floor((v_k^2 - 1) / t) for nb polynomials side by side (v_k = d_v + k d, h_k = d_h + k d): the same launches as for one, nb times
 // the work each
 int mfh_poly_h_multi(mfh_ctx *c, const uint32_t *d_v, uint32_t *d_h, uint32_t nb) {
-  if (!c || !d_v || !d_h || !nb) return MFH_EINVAL;
+  if (!c || !d_v || !d_h || !nb || nb > kMaxBatch) return MFH_EINVAL;
   PolyState *S = c->poly;
   if (!S || !S->have_t) {
     c->err = "mfh_poly_prepare_t has not been called for this SSP";
@@ -761,18 +949,49 @@ int mfh_poly_h_multi(mfh_ctx *c, const uint32_t *d_v, uint32_t *d_h, uint32_t nb
   if (rc) return rc;
   const uint32_t d = S->d, n = S->n;
   const size_t Nmax = (size_t)1 << S->logmax;
+  // the exact-division path (a batch: for one polynomial the launches below are latency, not work): two cyclic products of length Nc and the check
+  const uint32_t *need = nullptr;
+  if (S->cyc && c->poly_exact && nb >= 4) {
+    const uint32_t Nc = 1u << S->logNc;
+    HIP_TRY(c, hipMemsetAsync(S->d_need, 0, 4, c->stream));
+    rc = poly_mul(c, d_v, d, d_v, d, nullptr, 0, S->d_tmp, Nc, nb, d, Nmax, nullptr, S->logNc);  // v^2 mod x^Nc - 1
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_sub_const0, dim3(nb), dim3(64), 0, c->stream, S->d_tmp, 1u, Nmax, (const uint32_t *)nullptr);
+    rc = poly_mul(c, S->d_tmp, Nc, nullptr, Nc, S->d_That, S->logNc, d_h, d, nb, Nmax, d, nullptr, S->logNc);  // times t^-1 in the ring: h when t | v^2 - 1
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_exact_check, dim3(nb), dim3(1024), 0, c->stream, d_v, d_h, d, S->d_chk, Nc, uint4{S->chk_t[0], S->chk_t[1], S->chk_t[2], S->chk_t[3]},
+                       S->d_need);
+    need = S->d_need;  // the Euclidean kernels below work through the statements that failed the check: none, as a rule
+  }
+  const uint32_t *map = need ? need + 2 : nullptr;
   // A = v^2 - 1 : 2d-1 coefficients (nominal degree 2d-2)
-  rc = poly_mul(c, d_v, d, d_v, d, nullptr, 0, S->d_tmp, 2 * d - 1, nb, d, Nmax);
+  rc = poly_mul(c, d_v, d, d_v, d, nullptr, 0, S->d_tmp, 2 * d - 1, nb, d, Nmax, need, 0, map);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_sub_const0, dim3(nb), dim3(64), 0, c->stream, S->d_tmp, 1u, Nmax);
+  hipLaunchKernelGGL(k_sub_const0, dim3(nb), dim3(64), 0, c->stream, S->d_tmp, 1u, Nmax, need);
   // rev(A)[:n]
-  hipLaunchKernelGGL(k_reverse, dim3((n + 255) / 256, nb), dim3(256), 0, c->stream, S->d_tmp, (int64_t)(2 * d - 2), n, S->d_tmp2, Nmax, Nmax);
+  hipLaunchKernelGGL(k_reverse, dim3((n + 255) / 256, nb), dim3(256), 0, c->stream, S->d_tmp, (int64_t)(2 * d - 2), n, S->d_tmp2, Nmax, Nmax, need);
   // qrev = rev(A)[:n] * G mod x^n
-  rc = poly_mul(c, S->d_tmp2, n, nullptr, n, S->d_Ghat, S->logN2, S->d_tmp, n, nb, Nmax, Nmax);
+  rc = poly_mul(c, S->d_tmp2, n, nullptr, n, S->d_Ghat, S->logN2, S->d_tmp, n, nb, Nmax, Nmax, need);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_unreverse_pad, dim3((d + 255) / 256, nb), dim3(256), 0, c->stream, S->d_tmp, n, d, d_h, Nmax, (size_t)d);
+  hipLaunchKernelGGL(k_unreverse_pad, dim3((d + 255) / 256, nb), dim3(256), 0, c->stream, S->d_tmp, n, d, d_h, Nmax, (size_t)d, need, map);
   HIP_TRY(c, hipGetLastError());
   return MFH_OK;
+}
+int mfh_set_poly_exact(mfh_ctx *c, int on) {
+  if (!c) return MFH_EINVAL;
+  c->poly_exact = on != 0;
+  return MFH_OK;
+}
+// statements whose exact-division result failed the check (and were recomputed by Euclidean division) since the last call; waits for the stream.
+// -1: no SSP prepared / no exact path for this t
+long mfh_poly_exact_fallbacks(mfh_ctx *c) {
+  if (!c || !c->poly || !c->poly->cyc) return -1;
+  HIP_TRY(c, hipSetDevice(c->device));
+  uint32_t w[2] = {0, 0};
+  if (hipMemcpyAsync(w, c->poly->d_need, 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess ||
+      hipMemsetAsync(c->poly->d_need + 1, 0, 4, c->stream) != hipSuccess)
+    return -1;
+  return (long)w[1];
 }
 int mfh_poly_h(mfh_ctx *c, const uint32_t *d_v, uint32_t *d_h) { return mfh_poly_h_multi(c, d_v, d_h, 1); }
 

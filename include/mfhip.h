@@ -180,6 +180,14 @@ int mfh_ssp_prepare(mfh_ctx *ctx, const uint32_t *d_ssp); /* = mfh_poly_prepare_
 int mfh_poly_h(mfh_ctx *ctx, const uint32_t *d_v, uint32_t *d_h);
 /* the same for nb polynomials side by side (v_k at d_v + k d, h_k at d_h + k d): one set of launches for the whole batch */
 int mfh_poly_h_multi(mfh_ctx *ctx, const uint32_t *d_v, uint32_t *d_h, uint32_t nb);
+/* A batch (nb >= 4) takes the exact-division path when the prepared t has degree d - 1 and is a unit modulo x^N - 1 (N = the power of two >= d): a prover with a valid
+ * witness divides exactly (src/ssp.c:37-77), and then h = (v^2 - 1 mod x^N - 1) t^-1 mod x^N - 1 -- two cyclic products of length N instead of two linear ones of
+ * length 2N.  Every result is CHECKED on the device (h(r) t(r) = v(r)^2 - 1 at four points); the statements that fail -- a witness that does not satisfy the SSP
+ * -- are recomputed by the Euclidean division above, by kernels queued behind the check (no host round trip; a batch with k such statements pays that path for k):
+ * the output is nmod_poly_div's in every case.  mfh_set_poly_exact(ctx, 0) keeps every batch on the Euclidean path (A/B, tests); on by default. */
+int mfh_set_poly_exact(mfh_ctx *ctx, int on);
+/* statements that failed that check (and were recomputed) since the last call; waits for the stream.  -1: the prepared t has no exact-division path */
+long mfh_poly_exact_fallbacks(mfh_ctx *ctx);
 
 /* The 2d+m plaintexts setup() encrypts, in stream order: s^i | alpha s^i | beta t(s) | beta v_i(s), i=1..m-1
  * (src/snark.c:73-110; the Horner values nmod_poly_evaluate_nmod are computed as dot products with the powers of s). */

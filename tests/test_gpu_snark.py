@@ -88,6 +88,78 @@ def test_poly_square_and_hat_paths_at_2048_point_blocks(gpu_ctx_factory, oracle,
     assert np.array_equal(got, oracle.poly_h(v, t))
 
 
+@pytest.mark.parametrize("d,m", [(256, 64), (1152, 40), (2048, 24), (4096, 16)])
+def test_exact_division_path_is_checked_and_falls_back(gpu_ctx_factory, oracle, mf, d, m):
+    """A batch of h = (v^2 - 1) / t goes through two CYCLIC products of length N = 2^ceil(log2 d) (the exact quotient of a valid witness is determined modulo x^N - 1),
+    is checked on the device and recomputed by Euclidean division when one statement does not divide (src/snark.c:166-169 computes nmod_poly_div whatever the witness):
+    (i) valid witnesses only: equal to the oracle's quotients, no statement recomputed; (ii) the same batch with two statements whose v does not belong to the SSP:
+    equal to the oracle's (Euclidean) quotients, those two counted; (iii) the same with the path switched off.  d = 1152: N = 2048 > d; 2048 / 4096: the register
+    kernels with one and two passes above the 2048-point blocks."""
+    p = mf.Params(logq=736, d=d, m=m)
+    c = gpu_ctx_factory(p)
+    rng = np.random.default_rng(d)
+    nb = 9
+    tape = rng.integers(0, 256, size=p.m * 8 * p.d, dtype=np.uint8)
+    base_bits = rng.integers(0, 256, size=(p.m + 7) // 8, dtype=np.uint8).tobytes()
+    ssp = oracle.ssp_from_tape(p, tape, base_bits).reshape(p.m + 3, p.d)
+    t = ssp[0].copy()
+
+    def v_of(bits):
+        v = ssp[1].copy()
+        for i in range(1, p.m):
+            if (bits[(i - 1) >> 3] >> ((i - 1) & 7)) & 1:
+                v = (v + ssp[i + 1]) % np.uint64(ol.P)
+        return v
+
+    v_ok = v_of(base_bits)
+    assert oracle.poly_divides(v_ok, t)
+    # valid statements: +- v (the same square), and v with t-multiples added is no longer of degree < d, so vary by sign and by delta t instead: (v + delta t)^2 - 1 = v^2 - 1 + t (...)
+    vs = []
+    for k in range(nb):
+        delta = int(rng.integers(0, ol.P, dtype=np.uint64))
+        vs.append((v_ok.astype(object) + delta * t.astype(object)) % ol.P)
+    V = np.array(vs, dtype=np.uint64)
+    for v in V:
+        assert oracle.poly_divides(v, t)
+    exp = np.stack([oracle.poly_h(v, t) for v in V])
+    c.poly_prepare_t(_u32(c, t))
+    assert c.poly_exact_fallbacks() == 0  # (an exact path exists for this t, nothing has failed)
+    got = c.to_host(c.poly_h_many(_u32(c, V.reshape(-1)), nb), np.uint32).astype(np.uint64).reshape(nb, d)
+    assert np.array_equal(got, exp)
+    assert c.poly_exact_fallbacks() == 0
+    # two statements of the batch do not divide
+    other = bytearray(base_bits)
+    other[0] ^= 0x14
+    V2 = V.copy()
+    V2[2] = v_of(bytes(other))
+    V2[7, d // 2] = (V2[7, d // 2] + np.uint64(1)) % np.uint64(ol.P)
+    assert not oracle.poly_divides(V2[2], t) and not oracle.poly_divides(V2[7], t)
+    exp2 = np.stack([oracle.poly_h(v, t) for v in V2])
+    got2 = c.to_host(c.poly_h_many(_u32(c, V2.reshape(-1)), nb), np.uint32).astype(np.uint64).reshape(nb, d)
+    assert np.array_equal(got2, exp2)
+    assert c.poly_exact_fallbacks() == 2
+    # ... and a valid batch behind it is again exact (the flag is per batch)
+    got = c.to_host(c.poly_h_many(_u32(c, V.reshape(-1)), nb), np.uint32).astype(np.uint64).reshape(nb, d)
+    assert np.array_equal(got, exp) and c.poly_exact_fallbacks() == 0
+    c.set_poly_exact(False)
+    got3 = c.to_host(c.poly_h_many(_u32(c, V2.reshape(-1)), nb), np.uint32).astype(np.uint64).reshape(nb, d)
+    assert np.array_equal(got3, exp2) and c.poly_exact_fallbacks() == 0
+
+
+def test_exact_division_path_is_not_offered_for_a_short_t(gpu_ctx_factory, oracle, mf):
+    """deg t < d - 1: the quotient has more than d coefficients, nothing is determined modulo x^N - 1 -- Euclidean division only"""
+    p = mf.Params(logq=736, d=256, m=64)
+    c = gpu_ctx_factory(p)
+    rng = np.random.default_rng(77)
+    t = rng.integers(0, ol.P, size=p.d, dtype=np.uint64)
+    t[p.d - 3:] = 0
+    V = rng.integers(0, ol.P, size=(6, p.d), dtype=np.uint64)
+    c.poly_prepare_t(_u32(c, t))
+    assert c.poly_exact_fallbacks() == -1
+    got = c.to_host(c.poly_h_many(_u32(c, V.reshape(-1)), 6), np.uint32).astype(np.uint64).reshape(6, p.d)
+    assert np.array_equal(got, np.stack([oracle.poly_h(v, t) for v in V]))
+
+
 def test_poly_prepare_rejects_zero_t(ctx, mf):
     with pytest.raises(mf.MfhError):
         ctx.poly_prepare_t(ctx.zeros(mf.DEBUG.d * 4))

@@ -1,5 +1,5 @@
 """four mfh_prove_batch steps of $BATCH_PROF_NB (default 1020) statements at the default instance, for rocprofv3 --kernel-trace (tools/step_breakdown.py). dev tool.
-usage: python tools/batch_prof.py [merge 0|1]      $MFUOCO_MM_PACK=0: int32 partial products (the round-5 epilogue)"""
+usage: python tools/batch_prof.py [merge 0|1]      $MFUOCO_MM_PACK=0: int32 partial products (the round-5 epilogue); $MFUOCO_POLY_EXACT=0: no exact-division path"""
 import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,6 +16,8 @@ rng = np.random.default_rng(5)
 nb = int(os.environ.get("BATCH_PROF_NB", "1020"))
 if os.environ.get("MFUOCO_MM_PACK") == "0":
     ctx.set_mm_pack(False)
+if os.environ.get("MFUOCO_POLY_EXACT") == "0":
+    ctx.set_poly_exact(False)  # the polynomial step by Euclidean division only (rounds 1 - 5)
 ctx.set_batch_launch(8, bool(int(sys.argv[1])) if len(sys.argv) > 1 else True)
 if os.environ.get("MFUOCO_MM_WAVE1") == "1":
     ctx.set_mm_stream(1, 2, 0, 0)
