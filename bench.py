@@ -274,6 +274,9 @@ def main():
                          "expanded once per group of 31, MAC on the matrix cores), ranks take disjoint statements, no collective; "
                          "single: a step = one prover() call, CRS rows sharded over the ranks + lane all-reduces")
     ap.add_argument("--batch", type=int, default=1020, help="statements per GPU per step in batch mode (4 super-groups of 255)")
+    ap.add_argument("--invalid-every", type=int, default=0,
+                    help="batch mode: every K-th statement of the headline batch carries a random witness instead of the satisfying one (0 = none, the reference's "
+                         "benchmark_snark case; rounds 1 - 5 ran 2).  The mixed batch is always run beside the headline as its own leg")
     ap.add_argument("--no-overlap", action="store_true", help="run the prover on one stream (A/B check of the side-stream overlap)")
     ap.add_argument("--groups-per-launch", type=int, default=8, help="batch mode: groups of 63 / 64 coefficient vectors per streaming launch and region (8 = a super-group's S and AS regions in one launch; 4 = rounds 1-3)")
     ap.add_argument("--no-merge", action="store_true", help="batch mode: S and AS groups of a round as two launches on two streams (A/B check)")
@@ -622,24 +625,29 @@ def main():
         b_delta = [int(x) for x in brng.integers(0, mf.P, size=nb, dtype=np.uint64)]
         b_mags = [brng.integers(0, 256, size=5 * 80, dtype=np.uint8).tobytes() for _ in range(nb)]
         b_signs = [bytes(brng.integers(0, 2, size=5, dtype=np.uint8).tolist()) for _ in range(nb)]
-        # statements: even ones carry the satisfying witness (must be accepted), odd ones a random witness (a complete proof is still
-        # computed; the verifier must reject it) -- so the witness pass sees diverse bit strings, as a prover service would
-        b_valid = [i % 2 == 0 for i in range(nb)]
-        b_bits = [inst["bits"] if b_valid[i] else brng.bytes(len(inst["bits"])) for i in range(nb)]
+        # statements: the satisfying witness under fresh randomness (delta, smudging terms) each -- what the reference's benchmark_snark proves (random_ssp builds
+        # the SSP around ONE witness, src/ssp.c:37-77: a second satisfying bit string does not exist).  Rounds 1 - 5 gave every other statement a random witness (a
+        # complete proof is still computed; the verifier must reject it): that batch is the `mixed_witnesses` leg below, and --invalid-every 2 makes it the headline again.
+        # Before round 6 no kernel's work depended on the witness; now the polynomial step of a statement that divides exactly is cheaper (csrc/poly.hip).
+        b_valid = [not (args.invalid_every and i % args.invalid_every == args.invalid_every - 1) for i in range(nb)]
+        b_random = [brng.bytes(len(inst["bits"])) for _ in range(nb)]
+        b_bits = [inst["bits"] if b_valid[i] else b_random[i] for i in range(nb)]
         d_ssp_b = inst["d_ssp"]
 
-        def run_batch(out=None):
+        def run_batch(out=None, bits=None, steps=None):
             """warm-up + args.steps timed calls of prove_batch; returns (proofs, seconds [max over ranks], per-kind kernel timings)"""
-            out = ctx.prove_batch(d_crs, d_ssp_b, b_bits, b_delta, b_mags, b_signs, out=out)
+            bits = b_bits if bits is None else bits
+            steps = steps or args.steps
+            out = ctx.prove_batch(d_crs, d_ssp_b, bits, b_delta, b_mags, b_signs, out=out)
             for _ in range(max(args.warmup - 1, 0)):
-                ctx.prove_batch(d_crs, d_ssp_b, b_bits, b_delta, b_mags, b_signs, out=out)
+                ctx.prove_batch(d_crs, d_ssp_b, bits, b_delta, b_mags, b_signs, out=out)
             ctx.set_timing(True)
             for k in ("evalmm", "mmstream_rounds", "mmstream_bw", "evalmm_resident", "expandmm"):
                 ctx.timing_drain(k)
             barrier()
             t_ = time.perf_counter()
-            for _ in range(args.steps):
-                ctx.prove_batch(d_crs, d_ssp_b, b_bits, b_delta, b_mags, b_signs, out=out)
+            for _ in range(steps):
+                ctx.prove_batch(d_crs, d_ssp_b, bits, b_delta, b_mags, b_signs, out=out)
             barrier()
             el = time.perf_counter() - t_
             ctx.set_timing(False)
@@ -652,7 +660,9 @@ def main():
             return out, el, kt
 
         # headline: the CRS expanded once per call (= per step) into a transient image, streamed for every super-group of 255 proofs
+        ctx.poly_exact_fallbacks()
         out_b, el_b, kt_b = run_batch()
+        recomputed_b = ctx.poly_exact_fallbacks()  # statements whose polynomial step fell back to Euclidean division, warm-up and timed calls (-1: no exact path for this t)
         ok_b = ctx.to_host(ctx.verify(d_ssp_b, inst["alpha"], inst["beta"], inst["s"], inst["sk"], out_b, nb))
         torch.cuda.synchronize()
         tv = time.perf_counter()
@@ -661,10 +671,31 @@ def main():
         torch.cuda.synchronize()
         verify_per_s = 5 * nb / (time.perf_counter() - tv)
         same_b = True
-        for i in (0, nb - 1):  # a valid and (nb even) an invalid statement against the single-proof path, bit for bit
+        for i in (0, nb - 1):  # the first and the last statement against the single-proof path, bit for bit
             one = ctx.prove(d_crs, d_ssp_b, b_bits[i], b_delta[i], b_mags[i], b_signs[i])
             same_b = same_b and bool(torch.equal(out_b.view(nb, -1)[i], one))
         all_ok = [bool(int(x)) for x in ok_b] == b_valid and same_b
+        # the batch of rounds 1 - 5: every other statement carries a random witness -- its proof is computed all the same (src/snark.c:117-190 does not look at
+        # divisibility), the verifier must reject it, and it must equal the single-proof prover's bit for bit
+        mixed = None
+        if not args.invalid_every and nb >= 2:
+            m_valid = [i % 2 == 0 for i in range(nb)]
+            m_bits = [inst["bits"] if m_valid[i] else b_random[i] for i in range(nb)]
+            msteps = max(2, args.steps // 4)
+            out_m, el_m, _ = run_batch(bits=m_bits, steps=msteps)
+            recomputed_m = ctx.poly_exact_fallbacks()
+            ok_m = ctx.to_host(ctx.verify(d_ssp_b, inst["alpha"], inst["beta"], inst["s"], inst["sk"], out_m, nb))
+            im = nb - 1 if not m_valid[nb - 1] else nb - 2
+            one = ctx.prove(d_crs, d_ssp_b, m_bits[im], b_delta[im], b_mags[im], b_signs[im])
+            same_m = bool(torch.equal(out_m.view(nb, -1)[im], one)) and bool(torch.equal(out_m.view(nb, -1)[0], out_b.view(nb, -1)[0]))
+            mixed_ok = [bool(int(x)) for x in ok_m] == m_valid and same_m
+            all_ok = all_ok and mixed_ok
+            mixed = {"value": world * nb * msteps / el_m, "unit": "proofs/s", "ms_per_step": el_m / msteps * 1e3, "steps": msteps,
+                     "valid_accepted_invalid_rejected_and_identical_to_single_proof_path": mixed_ok,
+                     "statements_recomputed_by_euclidean_division": recomputed_m,
+                     "note": "the headline batch of rounds 1 - 5: every other statement carries a random witness.  Its polynomial step h = (v^2 - 1) / t does not divide exactly: "
+                             "the exact-division path's check fails for it on the device and the Euclidean path recomputes that statement behind it"}
+            del out_m
         if dist is not None:
             all_ok = bool(int(ctl_reduce(1 if all_ok else 0, dist.ReduceOp.MIN)))
         image_bytes = int(ctx.lib.mfh_crs_mm_image_bytes(ctx._h))
@@ -717,6 +748,11 @@ def main():
         used_image = kt_b["evalmm_resident"][0] + kt_b["mmstream_rounds"][0] > 0
         batched = {"value": world * nb * args.steps / el_b, "unit": "proofs/s", "ms_per_step": el_b / args.steps * 1e3, "statements_per_gpu_per_step": nb,
                    "valid_accepted_invalid_rejected_and_identical_to_single_proof_path": all_ok, "resident_crs": resident_b,
+                   "witnesses": ("every statement carries the satisfying witness" if not args.invalid_every else f"every {args.invalid_every}. statement carries a random witness"),
+                   "polynomial_step": {"exact_division_path_offered": recomputed_b >= 0, "statements_recomputed_by_euclidean_division": max(recomputed_b, 0),
+                                       "what": "h = (v^2 - 1 mod x^N - 1) t^-1 in F_p[x] / (x^N - 1), N = 2^15: two cyclic products of half the length, every result checked on "
+                                               "the device at four points, a statement that fails recomputed by Euclidean division behind the check (csrc/poly.hip)"},
+                   "mixed_witnesses": mixed,
                    "regenerate_per_group": regen, "call_of_twice_the_statements": larger, "device_verifier_proofs_per_s": verify_per_s,
                    "transient_image_bytes_per_rank": image_bytes if used_image else 0, "crs_expansion": expand_info(kt_b["expandmm"]),
                    "roofline": mmstream_roofline(kt_b, el_b / args.steps * 1e3) if used_image else evalmm16_roofline(kt_b["evalmm"])}
@@ -939,7 +975,7 @@ def main():
         elif mode == "batch":
             head = {"value": batched["value"], "ms_per_step": batched["ms_per_step"], "scaling": "weak", "roofline": batched["roofline"],
                     "proof_accepted": batched["valid_accepted_invalid_rejected_and_identical_to_single_proof_path"],
-                    "config": {"workload": base_workload + f"; a step = {args.batch} statements per GPU (same circuit and CRS; half with the satisfying witness, half with random ones; own randomness) through "
+                    "config": {"workload": base_workload + f"; a step = {args.batch} statements per GPU (same circuit and CRS, " + ("the satisfying witness of the reference's random_ssp" if not args.invalid_every else f"every {args.invalid_every}. one with a random witness") + ", own delta and smudging terms each) through "
                                            "mfh_prove_batch: every call expands the compressed CRS once (AES on the CU) into a transient image in HBM and streams it for every "
                                            "super-group of 255 proofs (one persistent launch of 8 + 8 groups of 63 / 64 coefficient vectors over the S / AS images per super-group, one launch over BT+BV for b_w of all super-groups), "
                                            "the groups' multiply-accumulate on the matrix cores; every proof is bit-identical to "
@@ -992,6 +1028,9 @@ def main():
             "regenerate_per_group_batch": batched["regenerate_per_group"] if batched else None,
             "resident_crs_batch": batched["resident_crs"] if batched else None,
             "call_of_twice_the_statements": batched["call_of_twice_the_statements"] if batched else None,
+            "witnesses": batched["witnesses"] if batched else None,
+            "polynomial_step": batched["polynomial_step"] if batched else None,
+            "mixed_witnesses": batched["mixed_witnesses"] if batched else None,
             "device_verifier_proofs_per_s": batched["device_verifier_proofs_per_s"] if batched else None,
             "row_sharded_batch": sharded_b,
             "single_proof_row_sharded": single_rows,

@@ -431,18 +431,12 @@ struct Crt {
   uint32_t inv_p1_p2, inv_p1_p3, inv_p2_p3;  // Montgomery form of p1^-1 mod p2, p1^-1 mod p3, p2^-1 mod p3
   uint32_t p1_mod, p1p2_mod;                 // p1 mod p32, p1*p2 mod p32
 };
-// residues (Montgomery, unscaled inverse transform) -> coefficient mod p32, first `count` coefficients
-__global__ void k_crt(const uint32_t *__restrict__ r, uint32_t N, uint32_t count, Primes3 P, Crt C, uint32_t *__restrict__ out, size_t out_stride,
-                      const uint32_t *__restrict__ need = nullptr) {
-  MF_NEEDED(need, blockIdx.y);
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= count) return;
-  r += (size_t)blockIdx.y * 3 * N;  // grid.y = batch
-  out += (size_t)blockIdx.y * out_stride;
+// the three residues of one coefficient (Montgomery form, as an unscaled inverse transform leaves them) -> the coefficient mod p32
+__device__ __forceinline__ uint32_t crt_coeff(uint32_t a1, uint32_t a2, uint32_t a3, const Primes3 &P, const Crt &C) {
   const NttPrime q1 = P.q[0], q2 = P.q[1], q3 = P.q[2];
-  uint32_t x1 = mont_mul(r[i], C.ninv_std[0], q1.p, q1.ninv);
-  uint32_t r2 = mont_mul(r[(size_t)N + i], C.ninv_std[1], q2.p, q2.ninv);
-  uint32_t r3 = mont_mul(r[(size_t)2 * N + i], C.ninv_std[2], q3.p, q3.ninv);
+  uint32_t x1 = mont_mul(a1, C.ninv_std[0], q1.p, q1.ninv);
+  uint32_t r2 = mont_mul(a2, C.ninv_std[1], q2.p, q2.ninv);
+  uint32_t r3 = mont_mul(a3, C.ninv_std[2], q3.p, q3.ninv);
   // Garner: X = x1 + x2 p1 + x3 p1 p2
   uint32_t x1m2 = x1 >= q2.p ? x1 - q2.p : x1;  // x1 < p1 < 2 p2
   uint32_t x2 = mont_mul(sub_mod(r2, x1m2, q2.p), C.inv_p1_p2, q2.p, q2.ninv);
@@ -451,7 +445,64 @@ __global__ void k_crt(const uint32_t *__restrict__ r, uint32_t N, uint32_t count
   uint32_t t3 = mont_mul(sub_mod(r3, x1m3, q3.p), C.inv_p1_p3, q3.p, q3.ninv);
   uint32_t x3 = mont_mul(sub_mod(t3, x2m3, q3.p), C.inv_p2_p3, q3.p, q3.ninv);
   uint64_t acc = (uint64_t)red_p32(x1) + red_p32((uint64_t)x2 * C.p1_mod) + red_p32((uint64_t)x3 * C.p1p2_mod);
-  out[i] = red_p32(acc);
+  return red_p32(acc);
+}
+// residues (Montgomery, unscaled inverse transform) -> coefficient mod p32: out[i] = coefficient i, i < count -- or, rev_top >= 0, coefficient rev_top - i where that
+// lies in [0, nsrc) and zero elsewhere (the reversals of the Euclidean path written by the kernel that produces the coefficients: rev(A)[:n], and the quotient
+// turned back and padded); map: see MF_NEEDED
+__global__ void k_crt(const uint32_t *__restrict__ r, uint32_t N, uint32_t count, Primes3 P, Crt C, uint32_t *__restrict__ out, size_t out_stride,
+                      const uint32_t *__restrict__ need = nullptr, int64_t rev_top = -1, uint32_t nsrc = 0, const uint32_t *__restrict__ map = nullptr) {
+  MF_NEEDED(need, blockIdx.y);
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  r += (size_t)blockIdx.y * 3 * N;  // grid.y = batch
+  out += (size_t)(map ? map[blockIdx.y] : blockIdx.y) * out_stride;
+  if (rev_top < 0) {
+    out[i] = crt_coeff(r[i], r[(size_t)N + i], r[(size_t)2 * N + i], P, C);
+    return;
+  }
+  const int64_t e = rev_top - (int64_t)i;
+  out[i] = e >= 0 && e < (int64_t)nsrc ? crt_coeff(r[e], r[(size_t)N + e], r[(size_t)2 * N + e], P, C) : 0u;
+}
+// ---- the exact-division path's seams, fused (2^12 <= N <= 2^16: one register pass of K = log N - 11 stages above the 2048-point blocks) ------------------------------
+// Between the two cyclic products: the K top inverse stages of the square, the coefficient itself (crt_coeff), "- 1", back to residues, the K top forward stages of
+// the second product -- k_ntt_dit_multi<K>, k_crt, k_sub_const0 and k_ntt_dif_multi<K> work on the SAME 2^K strided points {j + m N / 2^K} per thread, so one
+// thread carries them through all four (three passes over the transform buffer saved).  LAST: the seam behind the second product -- top inverse stages, coefficient,
+// out (the first `keep` of them): k_ntt_dit_multi<K> + k_crt.  grid = (N / 2^K / 256, batch); `a` = [batch][3][N], transformed in place.
+template <int K, bool LAST>
+__global__ __launch_bounds__(256) void k_exact_seam(uint32_t *__restrict__ a, uint32_t N, const uint32_t *__restrict__ tw, const uint32_t *__restrict__ twi,
+                                                    uint32_t half_max, Primes3 P, Crt C, uint32_t *__restrict__ out, uint32_t keep, size_t out_stride) {
+  constexpr int R = 1 << K;
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x, qd = N >> K;  // (one block of length N per polynomial: s = 0)
+  if (j >= qd) return;
+  uint32_t *x = a + (size_t)blockIdx.y * 3 * N + j;
+  uint32_t r[3][R];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+#pragma unroll
+    for (int m = 0; m < R; m++) r[k][m] = x[(size_t)k * N + (size_t)m * qd];
+    dit_regs<K>(r[k], j, qd, 2 * qd, twi + (size_t)k * half_max, half_max, P.q[k]);  // block lengths 2 qd .. N
+  }
+  uint32_t cf[R];
+#pragma unroll
+  for (int m = 0; m < R; m++) cf[m] = crt_coeff(r[0][m], r[1][m], r[2][m], P, C);
+  if (LAST) {
+    out += (size_t)blockIdx.y * out_stride;
+#pragma unroll
+    for (int m = 0; m < R; m++)
+      if (j + (uint32_t)m * qd < keep) out[j + (uint32_t)m * qd] = cf[m];
+    return;
+  }
+  if (j == 0) cf[0] = cf[0] ? cf[0] - 1 : P32 - 1;  // v^2 - 1
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const NttPrime q = P.q[k];
+#pragma unroll
+    for (int m = 0; m < R; m++) r[k][m] = mont_mul(cf[m], q.r2, q.p, q.ninv);
+    dif_regs<K>(r[k], j, qd, N, tw + (size_t)k * half_max, half_max, q);  // block lengths N .. 2 qd
+#pragma unroll
+    for (int m = 0; m < R; m++) x[(size_t)k * N + (size_t)m * qd] = r[k][m];
+  }
 }
 
 __global__ void k_reverse(const uint32_t *__restrict__ in, int64_t top, uint32_t count, uint32_t *__restrict__ out, size_t in_stride = 0,
@@ -513,23 +564,27 @@ __global__ void k_spread2(const uint32_t *__restrict__ b, uint32_t n, uint32_t *
 }
 // the check behind the exact-division path, one workgroup per statement: h(r) t(r) = v(r)^2 - 1 at the four points?  pw[j][i] = r_j^i, t_at[j] = t(r_j).  A statement that
 // fails at one of them appends itself to the list the Euclidean kernels queued behind work through (need[0] = length, need[2 ..] = statements) and counts in need[1].
+// (The dot products are summed as two 32-bit halves per term -- 2^15 terms per lane at most -- and reduced mod p once per lane.)
 __global__ __launch_bounds__(1024) void k_exact_check(const uint32_t *__restrict__ v, const uint32_t *__restrict__ h, uint32_t d, const uint32_t *__restrict__ pw,
                                                       uint32_t pw_stride, uint4 t_at, uint32_t *__restrict__ need) {
   __shared__ uint32_t red[16][8];
   const uint32_t *vk = v + (size_t)blockIdx.x * d, *hk = h + (size_t)blockIdx.x * d;
-  uint64_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // v at the four points, then h
+  uint64_t lo[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hi[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // v at the four points, then h
   for (uint32_t i = threadIdx.x; i < d; i += 1024) {
-    const uint64_t x = vk[i], y = hk[i];
+    const uint32_t x = vk[i], y = hk[i];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      const uint64_t w = pw[(size_t)j * pw_stride + i];
-      acc[j] = red_p32(acc[j] + x * w);  // (2^32 - 1)^2 + 2^32 < 2^64
-      acc[4 + j] = red_p32(acc[4 + j] + y * w);
+      const uint32_t w = pw[(size_t)j * pw_stride + i];
+      const uint64_t a = (uint64_t)x * w, b = (uint64_t)y * w;
+      lo[j] += (uint32_t)a;
+      hi[j] += a >> 32;
+      lo[4 + j] += (uint32_t)b;
+      hi[4 + j] += b >> 32;
     }
   }
 #pragma unroll
   for (int j = 0; j < 8; j++) {
-    uint32_t a = (uint32_t)acc[j];
+    uint32_t a = red_p32((uint64_t)red_p32(hi[j]) * 5u + red_p32(lo[j]));  // 2^32 = 5 (mod p)
 #pragma unroll
     for (int o = 32; o; o >>= 1) a = red_p32((uint64_t)a + __shfl_xor(a, o));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][j] = a;
@@ -740,10 +795,10 @@ Crt make_crt(const PolyState *S, uint32_t logN) {
 // c[0..keep) = (a * b)[0..keep) mod p32.  bhat != null: use that precomputed forward transform (size 2^logN) instead of b.
 // nb > 1: nb products side by side, polynomial k at a + k a_stride (and b + k a_stride), result at out + k out_stride.
 // log_cyc != 0: the product in F_p[x] / (x^N - 1), N = 2^log_cyc >= la, lb (the transform of that length IS the cyclic product).  need, a_map (which polynomial at `a`
-// product k reads): see MF_NEEDED.
+// product k reads): see MF_NEEDED.  rev_top, nsrc, out_map: the output written reversed / into the statements of the batch (k_crt).
 int poly_mul(mfh_ctx *c, const uint32_t *a, uint32_t la, const uint32_t *b, uint32_t lb, const uint32_t *bhat, uint32_t logN_hat,
              uint32_t *out, uint32_t keep, uint32_t nb = 1, size_t a_stride = 0, size_t out_stride = 0, const uint32_t *need = nullptr, uint32_t log_cyc = 0,
-             const uint32_t *a_map = nullptr) {
+             const uint32_t *a_map = nullptr, int64_t rev_top = -1, uint32_t nsrc = 0, const uint32_t *out_map = nullptr) {
   PolyState *S = c->poly;
   uint32_t logN = log_cyc ? log_cyc : bhat ? logN_hat : ceil_log2((size_t)la + lb - 1);
   if (logN < 1) logN = 1;
@@ -773,7 +828,8 @@ int poly_mul(mfh_ctx *c, const uint32_t *a, uint32_t la, const uint32_t *b, uint
   else
     hipLaunchKernelGGL(k_ntt_lds_mul, dim3(N >> B, 3 * nb), dim3(256), 0, c->stream, S->d_bufA, rhs, is_hat, N, B, S->d_tw, S->d_twi, half_max, S->P, need);
   inverse_top(c, S->d_bufA, logN, nb, need);
-  hipLaunchKernelGGL(k_crt, dim3((keep + 255) / 256, nb), dim3(256), 0, c->stream, S->d_bufA, N, keep, S->P, make_crt(S, logN), out, out_stride, need);
+  hipLaunchKernelGGL(k_crt, dim3((keep + 255) / 256, nb), dim3(256), 0, c->stream, S->d_bufA, N, keep, S->P, make_crt(S, logN), out, out_stride, need, rev_top, nsrc,
+                     out_map);
   HIP_TRY(c, hipGetLastError());
   return MFH_OK;
 }
@@ -954,17 +1010,51 @@ int mfh_poly_h_multi(mfh_ctx *c, const uint32_t *d_v, uint32_t *d_h, uint32_t nb
   if (S->cyc && c->poly_exact && nb >= 4) {
     const uint32_t Nc = 1u << S->logNc;
     HIP_TRY(c, hipMemsetAsync(S->d_need, 0, 4, c->stream));
-    rc = poly_mul(c, d_v, d, d_v, d, nullptr, 0, S->d_tmp, Nc, nb, d, Nmax, nullptr, S->logNc);  // v^2 mod x^Nc - 1
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_sub_const0, dim3(nb), dim3(64), 0, c->stream, S->d_tmp, 1u, Nmax, (const uint32_t *)nullptr);
-    rc = poly_mul(c, S->d_tmp, Nc, nullptr, Nc, S->d_That, S->logNc, d_h, d, nb, Nmax, d, nullptr, S->logNc);  // times t^-1 in the ring: h when t | v^2 - 1
-    if (rc) return rc;
+    if (S->logNc >= 12 && S->logNc <= 16) {  // five launches: the seams between and behind the two products are fused (k_exact_seam)
+      const uint32_t half_max = 1u << (S->logmax - 1), K = S->logNc - 11;
+      const Crt C = make_crt(S, S->logNc);
+      const dim3 gs(((Nc >> K) + 255) / 256, nb), gl(Nc >> 11, 3 * nb);
+      forward_top(c, S->d_bufA, S->logNc, nb, d_v, d, d);
+      hipLaunchKernelGGL(k_ntt_lds_mul8, gl, dim3(256), 0, c->stream, S->d_bufA, (const uint32_t *)nullptr, Nc, S->d_tw, S->d_twi, half_max, S->P, (const uint32_t *)nullptr);
+#define MF_SEAM(K_, LAST_, out_, keep_, stride_) \
+  hipLaunchKernelGGL((k_exact_seam<K_, LAST_>), gs, dim3(256), 0, c->stream, S->d_bufA, Nc, S->d_tw, S->d_twi, half_max, S->P, C, out_, keep_, stride_)
+#define MF_SEAM_K(LAST_, out_, keep_, stride_)                  \
+  switch (K) {                                                  \
+    case 1: MF_SEAM(1, LAST_, out_, keep_, stride_); break;     \
+    case 2: MF_SEAM(2, LAST_, out_, keep_, stride_); break;     \
+    case 3: MF_SEAM(3, LAST_, out_, keep_, stride_); break;     \
+    case 4: MF_SEAM(4, LAST_, out_, keep_, stride_); break;     \
+    default: MF_SEAM(5, LAST_, out_, keep_, stride_); break;    \
+  }
+      MF_SEAM_K(false, (uint32_t *)nullptr, 0u, (size_t)0)  // v^2 mod x^Nc - 1, minus 1, on its way into the second transform
+      hipLaunchKernelGGL(k_ntt_lds_mul8, gl, dim3(256), 0, c->stream, S->d_bufA, (const uint32_t *)S->d_That, Nc, S->d_tw, S->d_twi, half_max, S->P, (const uint32_t *)nullptr);
+      MF_SEAM_K(true, d_h, d, (size_t)d)  // times t^-1 in the ring: h when t | v^2 - 1
+#undef MF_SEAM_K
+#undef MF_SEAM
+    } else {
+      rc = poly_mul(c, d_v, d, d_v, d, nullptr, 0, S->d_tmp, Nc, nb, d, Nmax, nullptr, S->logNc);  // v^2 mod x^Nc - 1
+      if (rc) return rc;
+      hipLaunchKernelGGL(k_sub_const0, dim3(nb), dim3(64), 0, c->stream, S->d_tmp, 1u, Nmax, (const uint32_t *)nullptr);
+      rc = poly_mul(c, S->d_tmp, Nc, nullptr, Nc, S->d_That, S->logNc, d_h, d, nb, Nmax, d, nullptr, S->logNc);  // times t^-1 in the ring: h when t | v^2 - 1
+      if (rc) return rc;
+    }
     hipLaunchKernelGGL(k_exact_check, dim3(nb), dim3(1024), 0, c->stream, d_v, d_h, d, S->d_chk, Nc, uint4{S->chk_t[0], S->chk_t[1], S->chk_t[2], S->chk_t[3]},
                        S->d_need);
     need = S->d_need;  // the Euclidean kernels below work through the statements that failed the check: none, as a rule
   }
   const uint32_t *map = need ? need + 2 : nullptr;
-  // A = v^2 - 1 : 2d-1 coefficients (nominal degree 2d-2)
+  if (S->dt >= 1) {
+    // rev(A)[:n], A = v^2 - 1 (2d - 1 coefficients, nominal degree 2d - 2): coefficients dt .. 2d - 2 of the square, written reversed by the kernel that produces them
+    // (the "- 1" sits at coefficient 0, which the quotient does not see when deg t >= 1)
+    rc = poly_mul(c, d_v, d, d_v, d, nullptr, 0, S->d_tmp2, n, nb, d, Nmax, need, 0, map, (int64_t)(2 * d - 2), 2 * d - 1);
+    if (rc) return rc;
+    // qrev = rev(A)[:n] * G mod x^n, turned back: h[i] = qrev[n - 1 - i] for i < min(n, d), zero above
+    rc = poly_mul(c, S->d_tmp2, n, nullptr, n, S->d_Ghat, S->logN2, d_h, d, nb, Nmax, d, need, 0, nullptr, (int64_t)n - 1, n, map);
+    if (rc) return rc;
+    HIP_TRY(c, hipGetLastError());
+    return MFH_OK;
+  }
+  // deg t = 0 (division by a constant): the general sequence
   rc = poly_mul(c, d_v, d, d_v, d, nullptr, 0, S->d_tmp, 2 * d - 1, nb, d, Nmax, need, 0, map);
   if (rc) return rc;
   hipLaunchKernelGGL(k_sub_const0, dim3(nb), dim3(64), 0, c->stream, S->d_tmp, 1u, Nmax, need);
