@@ -750,7 +750,7 @@ def main():
                    "valid_accepted_invalid_rejected_and_identical_to_single_proof_path": all_ok, "resident_crs": resident_b,
                    "witnesses": ("every statement carries the satisfying witness" if not args.invalid_every else f"every {args.invalid_every}. statement carries a random witness"),
                    "polynomial_step": {"exact_division_path_offered": recomputed_b >= 0, "statements_recomputed_by_euclidean_division": max(recomputed_b, 0),
-                                       "what": "h = (v^2 - 1 mod x^N - 1) t^-1 in F_p[x] / (x^N - 1), N = 2^15: two cyclic products of half the length, every result checked on "
+                                       "what": f"h = (v^2 - 1 mod x^N - 1) t^-1 in F_p[x] / (x^N - 1), N = 2^{(p.d - 1).bit_length()}: two cyclic products of half the length, every result checked on "
                                                "the device at four points, a statement that fails recomputed by Euclidean division behind the check (csrc/poly.hip)"},
                    "mixed_witnesses": mixed,
                    "regenerate_per_group": regen, "call_of_twice_the_statements": larger, "device_verifier_proofs_per_s": verify_per_s,
