@@ -684,6 +684,7 @@ def main():
             msteps = max(2, args.steps // 4)
             out_m, el_m, _ = run_batch(bits=m_bits, steps=msteps)
             recomputed_m = ctx.poly_exact_fallbacks()
+            ctx.set_poly_exact(1)  # (forget what this batch has taught the polynomial step: the legs below prove satisfying witnesses again)
             ok_m = ctx.to_host(ctx.verify(d_ssp_b, inst["alpha"], inst["beta"], inst["s"], inst["sk"], out_m, nb))
             im = nb - 1 if not m_valid[nb - 1] else nb - 2
             one = ctx.prove(d_crs, d_ssp_b, m_bits[im], b_delta[im], b_mags[im], b_signs[im])
@@ -694,7 +695,8 @@ def main():
                      "valid_accepted_invalid_rejected_and_identical_to_single_proof_path": mixed_ok,
                      "statements_recomputed_by_euclidean_division": recomputed_m,
                      "note": "the headline batch of rounds 1 - 5: every other statement carries a random witness.  Its polynomial step h = (v^2 - 1) / t does not divide exactly: "
-                             "the exact-division path's check fails for it on the device and the Euclidean path recomputes that statement behind it"}
+                             "the exact-division path's check fails for it on the device and the Euclidean path recomputes that statement behind it -- in the first call(s): "
+                             "once the host has seen a failed check, the next 64 batches of 255 take the Euclidean path alone (mfh_set_poly_exact, mode 1)"}
             del out_m
         if dist is not None:
             all_ok = bool(int(ctl_reduce(1 if all_ok else 0, dist.ReduceOp.MIN)))

@@ -333,9 +333,10 @@ class Context:
         """streaming kernels hand their partial products to the epilogue recombined (default) or as int32 (rounds 1 - 5): same results"""
         self._chk(self.lib.mfh_set_mm_pack(self._h, 1 if on else 0))
 
-    def set_poly_exact(self, on=True):
-        """batches of h = (v^2 - 1) / t try the exact-division path (two cyclic products of half the length, checked on the device) before Euclidean division: same results"""
-        self._chk(self.lib.mfh_set_poly_exact(self._h, 1 if on else 0))
+    def set_poly_exact(self, mode=1):
+        """batches of h = (v^2 - 1) / t try the exact-division path (two cyclic products of half the length, checked on the device) before Euclidean division: same results.
+        0 / False: never; 1 / True: unless a recent batch failed the check (64 batches of Euclidean division alone follow); 2: always"""
+        self._chk(self.lib.mfh_set_poly_exact(self._h, int(mode)))
 
     def poly_exact_fallbacks(self):
         """statements whose exact-division result failed the device check since the last call (they were recomputed by Euclidean division); -1: no exact path for this t"""

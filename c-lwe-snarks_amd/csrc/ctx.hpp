@@ -110,7 +110,7 @@ struct mfh_ctx {
   size_t early_ws_half = 0;        // early chain: distance of the two halves of ws3 = the scratch of the call's first (largest) super-group
   bool batch_early_chain = false;  // mfh_prove_batch: chain of super-group k + 1 and epilogue of k queued BESIDE the streaming launch of k / k + 1 (for the CUs a narrower grid leaves free)
   uint32_t *mm_sync = nullptr;  // 8 x 32 counters of the persistent grid's rendezvous
-  bool poly_exact = true;  // batches of h = (v^2 - 1) / t try the exact-division path first (poly.hip; mfh_set_poly_exact)
+  int poly_exact = 1;  // batches of h = (v^2 - 1) / t try the exact-division path first: 0 never, 1 unless recent batches failed its check, 2 always (poly.hip; mfh_set_poly_exact)
   bool mm_pack = true;  // the streaming kernels hand their partial products to the epilogue recombined (evalmm.hip: mms_store_packed); mfh_set_mm_pack
   uint32_t mm_chunk_rows = 131071;  // rows per row chunk of the matrix-core launches (int32 accumulators: |A'C'| <= 2^14 per row)
   int expand_path = 0;     // mfh_crs_expand_mm*: 0 = k_expand_mm (lane = row, MFMA transposition, no LDS tile), 1 = k_evalmm16<MODE 1> (LDS tile + byte gathers)

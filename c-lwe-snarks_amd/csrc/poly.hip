@@ -563,10 +563,10 @@ __global__ void k_spread2(const uint32_t *__restrict__ b, uint32_t n, uint32_t *
   if (i < n) out[i] = (i & 1) ? 0u : b[i >> 1];
 }
 // the check behind the exact-division path, one workgroup per statement: h(r) t(r) = v(r)^2 - 1 at the four points?  pw[j][i] = r_j^i, t_at[j] = t(r_j).  A statement that
-// fails at one of them appends itself to the list the Euclidean kernels queued behind work through (need[0] = length, need[2 ..] = statements) and counts in need[1].
-// (The dot products are summed as two 32-bit halves per term -- 2^15 terms per lane at most -- and reduced mod p once per lane.)
+// fails at one of them appends itself to the list the Euclidean kernels queued behind work through (need[0] = length, need[2 ..] = statements), counts in need[1] and
+// leaves a mark in host memory (`seen`).  (The dot products are summed as two 32-bit halves per term -- 2^15 terms per lane at most -- and reduced mod p once per lane.)
 __global__ __launch_bounds__(1024) void k_exact_check(const uint32_t *__restrict__ v, const uint32_t *__restrict__ h, uint32_t d, const uint32_t *__restrict__ pw,
-                                                      uint32_t pw_stride, uint4 t_at, uint32_t *__restrict__ need) {
+                                                      uint32_t pw_stride, uint4 t_at, uint32_t *__restrict__ need, uint32_t *__restrict__ seen) {
   __shared__ uint32_t red[16][8];
   const uint32_t *vk = v + (size_t)blockIdx.x * d, *hk = h + (size_t)blockIdx.x * d;
   uint64_t lo[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hi[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // v at the four points, then h
@@ -604,6 +604,7 @@ __global__ __launch_bounds__(1024) void k_exact_check(const uint32_t *__restrict
     if (bad) {
       need[2 + atomicAdd(need, 1u)] = blockIdx.x;
       atomicAdd(need + 1, 1u);
+      *(volatile uint32_t *)seen = 1u;  // (host memory: mfh_poly_h_multi looks at it, some batch later, to decide whether the path pays for this caller)
     }
   }
 }
@@ -635,9 +636,12 @@ struct PolyState {
   uint32_t *d_chk = nullptr;     // [4][Nc] powers of the four check points
   uint32_t chk_t[4]{};           // t at the check points
   uint32_t *d_need = nullptr;    // [0] statements of the batch that failed the check, [1] the same since the last reset, [2 ..] which ones (k_exact_check)
+  uint32_t *h_seen = nullptr;    // pinned host word the check sets when a statement fails: read (never waited for) by later calls
+  uint32_t rest = 0;             // batches left on the Euclidean path alone after such a mark (poly_exact == 1)
   ~PolyState() {
     for (uint32_t *p : {d_tw, d_twi, d_bufA, d_bufB, d_tmp, d_tmp2, d_G, d_Ghat, d_f, d_That, d_chk, d_need})
       if (p) hipFree(p);
+    if (h_seen) hipHostFree(h_seen);
   }
 };
 
@@ -848,7 +852,10 @@ int prepare_exact(mfh_ctx *c, const uint32_t *d_t, const std::vector<uint32_t> &
   if (!S->d_need) {
     HIP_TRY(c, hipMalloc(&S->d_need, (size_t)(2 + kMaxBatch) * 4));
     HIP_TRY(c, hipMemsetAsync(S->d_need, 0, 8, c->stream));
+    HIP_TRY(c, hipHostMalloc(&S->h_seen, 64, hipHostMallocDefault));
   }
+  *S->h_seen = 0;
+  S->rest = 0;
   // scratch: the ring elements a_0 = t, a_1, ... of lengths Nc, Nc / 2, ..., 1 (2 Nc words), a(-x), b(x^2) and two inverses (Nc each)
   uint32_t *scr = nullptr;
   HIP_TRY(c, hipMalloc(&scr, (size_t)6 * Nc * 4));
@@ -1007,7 +1014,20 @@ int mfh_poly_h_multi(mfh_ctx *c, const uint32_t *d_v, uint32_t *d_h, uint32_t nb
   const size_t Nmax = (size_t)1 << S->logmax;
   // the exact-division path (a batch: for one polynomial the launches below are latency, not work): two cyclic products of length Nc and the check
   const uint32_t *need = nullptr;
-  if (S->cyc && c->poly_exact && nb >= 4) {
+  bool exact = S->cyc && c->poly_exact && nb >= 4;
+  if (exact && c->poly_exact == 1) {
+    // a caller whose statements do NOT satisfy the SSP pays the cyclic products on top of the Euclidean division: after a batch in which the check has failed (seen
+    // whenever the device gets there: this is a hint, nothing is waited for) the next 64 batches take the Euclidean path alone, then the exact path is tried again
+    if (*(volatile uint32_t *)S->h_seen) {
+      *(volatile uint32_t *)S->h_seen = 0;
+      S->rest = 64;
+    }
+    if (S->rest) {
+      S->rest--;
+      exact = false;
+    }
+  }
+  if (exact) {
     const uint32_t Nc = 1u << S->logNc;
     HIP_TRY(c, hipMemsetAsync(S->d_need, 0, 4, c->stream));
     if (S->logNc >= 12 && S->logNc <= 16) {  // five launches: the seams between and behind the two products are fused (k_exact_seam)
@@ -1039,7 +1059,7 @@ int mfh_poly_h_multi(mfh_ctx *c, const uint32_t *d_v, uint32_t *d_h, uint32_t nb
       if (rc) return rc;
     }
     hipLaunchKernelGGL(k_exact_check, dim3(nb), dim3(1024), 0, c->stream, d_v, d_h, d, S->d_chk, Nc, uint4{S->chk_t[0], S->chk_t[1], S->chk_t[2], S->chk_t[3]},
-                       S->d_need);
+                       S->d_need, S->h_seen);
     need = S->d_need;  // the Euclidean kernels below work through the statements that failed the check: none, as a rule
   }
   const uint32_t *map = need ? need + 2 : nullptr;
@@ -1067,9 +1087,13 @@ int mfh_poly_h_multi(mfh_ctx *c, const uint32_t *d_v, uint32_t *d_h, uint32_t nb
   HIP_TRY(c, hipGetLastError());
   return MFH_OK;
 }
-int mfh_set_poly_exact(mfh_ctx *c, int on) {
-  if (!c) return MFH_EINVAL;
-  c->poly_exact = on != 0;
+int mfh_set_poly_exact(mfh_ctx *c, int mode) {
+  if (!c || mode < 0 || mode > 2) return MFH_EINVAL;
+  c->poly_exact = mode;
+  if (c->poly && c->poly->h_seen) {  // (what earlier batches have taught is forgotten)
+    *c->poly->h_seen = 0;
+    c->poly->rest = 0;
+  }
   return MFH_OK;
 }
 // statements whose exact-division result failed the check (and were recomputed by Euclidean division) since the last call; waits for the stream.

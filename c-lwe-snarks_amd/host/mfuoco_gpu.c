@@ -253,9 +253,9 @@ static mfh_ctx *gpu(void)
   CK(mfh_set_stream(G.ctx, NULL)); /* default stream: hipMemcpy below is ordered with the kernels */
   {
     /* mfuoco_prover_batch's polynomial step: the exact-division path (include/mfhip.h: mfh_set_poly_exact) pays for itself when the statements' witnesses satisfy the
-     * SSP, which is what a prover is given; $MFUOCO_GPU_POLY_EXACT=0 for a caller that proves mostly unsatisfied statements (same proofs either way) */
+     * SSP, which is what a prover is given, and backs off by itself when they do not; $MFUOCO_GPU_POLY_EXACT=0 / 2: never / always (same proofs either way) */
     const char *e = getenv("MFUOCO_GPU_POLY_EXACT");
-    if (e && *e && !atoi(e)) CK(mfh_set_poly_exact(G.ctx, 0));
+    if (e && *e && atoi(e) >= 0 && atoi(e) <= 2) CK(mfh_set_poly_exact(G.ctx, atoi(e)));
   }
   size_t rows = 2 * (size_t)GAMMA_D + GAMMA_M;
   for (int i = 0; i < 3; i++) HK(hipMalloc((void **)&G.d_ct[i], CTL * 8 + 256)); /* (+ room for a keystream block behind a ciphertext: regev_encrypt2) */

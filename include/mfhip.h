@@ -184,8 +184,11 @@ int mfh_poly_h_multi(mfh_ctx *ctx, const uint32_t *d_v, uint32_t *d_h, uint32_t 
  * witness divides exactly (src/ssp.c:37-77), and then h = (v^2 - 1 mod x^N - 1) t^-1 mod x^N - 1 -- two cyclic products of length N instead of two linear ones of
  * length 2N.  Every result is CHECKED on the device (h(r) t(r) = v(r)^2 - 1 at four points); the statements that fail -- a witness that does not satisfy the SSP
  * -- are recomputed by the Euclidean division above, by kernels queued behind the check (no host round trip; a batch with k such statements pays that path for k):
- * the output is nmod_poly_div's in every case.  mfh_set_poly_exact(ctx, 0) keeps every batch on the Euclidean path (A/B, tests); on by default. */
-int mfh_set_poly_exact(mfh_ctx *ctx, int on);
+ * the output is nmod_poly_div's in every case.  mode 1 (the default): as described, except that after a batch in which the check has failed the next 64 batches take
+ * the Euclidean path alone before the exact path is tried again (a caller whose statements do not satisfy the SSP would pay both; the failure is noticed through a
+ * word in host memory whenever the device gets there -- a hint, nothing is waited for).  mode 2: every batch tries the exact path (A/B, tests).  mode 0: never.
+ * Setting a mode forgets what earlier batches have taught. */
+int mfh_set_poly_exact(mfh_ctx *ctx, int mode);
 /* statements that failed that check (and were recomputed) since the last call; waits for the stream.  -1: the prepared t has no exact-division path */
 long mfh_poly_exact_fallbacks(mfh_ctx *ctx);
 

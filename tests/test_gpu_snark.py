@@ -125,6 +125,7 @@ def test_exact_division_path_is_checked_and_falls_back(gpu_ctx_factory, oracle, 
         assert oracle.poly_divides(v, t)
     exp = np.stack([oracle.poly_h(v, t) for v in V])
     c.poly_prepare_t(_u32(c, t))
+    c.set_poly_exact(2)  # every batch tries the path (the default backs off after a failed check: below)
     assert c.poly_exact_fallbacks() == 0  # (an exact path exists for this t, nothing has failed)
     got = c.to_host(c.poly_h_many(_u32(c, V.reshape(-1)), nb), np.uint32).astype(np.uint64).reshape(nb, d)
     assert np.array_equal(got, exp)
@@ -143,9 +144,22 @@ def test_exact_division_path_is_checked_and_falls_back(gpu_ctx_factory, oracle, 
     # ... and a valid batch behind it is again exact (the flag is per batch)
     got = c.to_host(c.poly_h_many(_u32(c, V.reshape(-1)), nb), np.uint32).astype(np.uint64).reshape(nb, d)
     assert np.array_equal(got, exp) and c.poly_exact_fallbacks() == 0
-    c.set_poly_exact(False)
+    c.set_poly_exact(0)
     got3 = c.to_host(c.poly_h_many(_u32(c, V2.reshape(-1)), nb), np.uint32).astype(np.uint64).reshape(nb, d)
     assert np.array_equal(got3, exp2) and c.poly_exact_fallbacks() == 0
+    # the default mode: a batch in which the check fails sends the batches behind it down the Euclidean path alone (64 of them), so that a caller whose statements
+    # do not satisfy the SSP does not pay for both -- seen here by the check not running at all: the same two statements are no longer counted
+    c.set_poly_exact(1)
+    d_v2 = _u32(c, V2.reshape(-1))
+    for k in range(3):
+        got4 = c.to_host(c.poly_h_many(d_v2, nb), np.uint32).astype(np.uint64).reshape(nb, d)
+        assert np.array_equal(got4, exp2)
+        assert c.poly_exact_fallbacks() == (2 if k == 0 else 0)  # (the call waits for the stream: the next batch finds the mark)
+    got = c.to_host(c.poly_h_many(_u32(c, V.reshape(-1)), nb), np.uint32).astype(np.uint64).reshape(nb, d)
+    assert np.array_equal(got, exp)
+    c.set_poly_exact(1)  # setting a mode forgets the mark
+    got4 = c.to_host(c.poly_h_many(d_v2, nb), np.uint32).astype(np.uint64).reshape(nb, d)
+    assert np.array_equal(got4, exp2) and c.poly_exact_fallbacks() == 2
 
 
 def test_exact_division_path_is_not_offered_for_a_short_t(gpu_ctx_factory, oracle, mf):

@@ -17,7 +17,7 @@ nb = int(os.environ.get("BATCH_PROF_NB", "1020"))
 if os.environ.get("MFUOCO_MM_PACK") == "0":
     ctx.set_mm_pack(False)
 if os.environ.get("MFUOCO_POLY_EXACT") == "0":
-    ctx.set_poly_exact(False)  # the polynomial step by Euclidean division only (rounds 1 - 5)
+    ctx.set_poly_exact(0)  # the polynomial step by Euclidean division only (rounds 1 - 5)
 ctx.set_batch_launch(8, bool(int(sys.argv[1])) if len(sys.argv) > 1 else True)
 if os.environ.get("MFUOCO_MM_WAVE1") == "1":
     ctx.set_mm_stream(1, 2, 0, 0)

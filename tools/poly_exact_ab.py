@@ -7,6 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench
 import c_lwe_snarks_amd as mf
+MODE = int(os.environ.get("EXACT_MODE", "2"))  # 2: every batch tries the exact path; 1: the default (64 batches of Euclidean division alone after a failed check)
 p = mf.DEFAULT
 ctx = mf.Context(p, 0)
 ctx.set_seed(bytes((37 * i + 11) & 0xFF for i in range(40)))
@@ -24,7 +25,7 @@ print("exact path offered:", ctx.poly_exact_fallbacks() >= 0, flush=True)
 outs = {}
 for rnd in range(3):
     for on in (True, False):
-        ctx.set_poly_exact(on)
+        ctx.set_poly_exact(MODE if on else 0)
         out = ctx.prove_batch(d_crs, inst["d_ssp"], bits, deltas, mags, signs)
         torch.cuda.synchronize()
         ctx.poly_exact_fallbacks()

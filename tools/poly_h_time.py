@@ -6,6 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench
 import c_lwe_snarks_amd as mf
+MODE = int(os.environ.get("EXACT_MODE", "2"))  # 2: every batch tries the exact path; 1: the default (64 batches of Euclidean division alone after a failed check)
 p = mf.DEFAULT
 ctx = mf.Context(p, 0)
 inst = bench.build_instance(mf, ctx, torch, p, 20260101)
@@ -20,7 +21,7 @@ v0 = inst["d_ssp"].view(torch.int32).view(p.m + 3, p.d)[1].to(torch.int64) & 0xF
 v = ((w + v0) % mf.P).to(torch.int32).contiguous().view(torch.uint8).view(-1)
 res = {}
 for on in (True, False, True, False):
-    ctx.set_poly_exact(on)
+    ctx.set_poly_exact(MODE if on else 0)
     h = ctx.poly_h_many(v, nb)
     torch.cuda.synchronize()
     ctx.poly_exact_fallbacks()
