@@ -1531,15 +1531,27 @@ __global__ __launch_bounds__(512) void k_witness_mm8q(const v4i *__restrict__ ss
 }
 // bits of nstmt statements (packed, bits_stride bytes apart) -> A fragments: bitfrag[K][t][lane (stmt = 32 t + (l & 31), h)][e] = bit
 // (32 K + 16 h + e) of that statement
+// (one thread per lane's 16 bytes: two bytes of the statement's bit string in, one 16-byte store out)
 __global__ void k_witness_bits(const uint8_t *__restrict__ bits, size_t bits_stride, uint32_t nstmt, uint32_t nrowsel, uint32_t ksteps, uint32_t MT,
                                int8_t *__restrict__ bitfrag) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;  // one output byte
-  if (i >= ksteps * MT * 1024) return;
-  const uint32_t e = i & 15, lane = (i >> 4) & 63, t = (i >> 10) % MT, K = (i >> 10) / MT, stmt = 32 * t + (lane & 31), h = lane >> 5;
-  const uint32_t r = K * 32 + 16 * h + e;
-  int8_t v = 0;
-  if (stmt < nstmt && r < nrowsel) v = (int8_t)((bits[stmt * bits_stride + (r >> 3)] >> (r & 7)) & 1);
-  bitfrag[i] = v;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;  // one lane of one fragment: 16 output bytes
+  if (i >= ksteps * MT * 64) return;
+  const uint32_t lane = i & 63, t = (i >> 6) % MT, K = (i >> 6) / MT, stmt = 32 * t + (lane & 31), h = lane >> 5;
+  const uint32_t r0 = K * 32 + 16 * h;  // rows r0 .. r0 + 15: bits of two consecutive bytes (r0 is a multiple of 16)
+  uint32_t w = 0;
+  if (stmt < nstmt && r0 < nrowsel) {
+    const uint8_t *b = bits + (size_t)stmt * bits_stride + (r0 >> 3);
+    w = b[0];
+    if (r0 + 8 < nrowsel) w |= (uint32_t)b[1] << 8;
+    if (nrowsel - r0 < 16) w &= (1u << (nrowsel - r0)) - 1;  // rows beyond the last selected one contribute nothing
+  }
+  uint32_t o[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const uint32_t n4 = (w >> (4 * q)) & 15;  // four bits -> four bytes of 0 / 1
+    o[q] = (n4 & 1) | ((n4 & 2) << 7) | ((n4 & 4) << 14) | ((n4 & 8) << 21);
+  }
+  reinterpret_cast<uint4 *>(bitfrag)[i] = uint4{o[0], o[1], o[2], o[3]};
 }
 // w_b[k] = delta_b t[k] + sum_i bit_b[i] v_i[k] mod p from the chunk partials: sum_w 256^w (G'_w + 128 cnt_b)
 __global__ void k_witness_mm_finish(const int *__restrict__ part, uint32_t nchunks, const uint32_t *__restrict__ t, const uint32_t *__restrict__ cnt_delta,
@@ -2030,7 +2042,7 @@ int mfh_witness_poly_mm_cols(mfh_ctx *c, const uint32_t *d_ssp, uint32_t nstmt, 
   const uint32_t *d_cd = (const uint32_t *)(dev + packed + ((8 - packed % 8) % 8));
   int8_t *d_frag = (int8_t *)(dev + head_b);
   int *d_part = (int *)(dev + head_b + frag_b);
-  hipLaunchKernelGGL(k_witness_bits, dim3((uint32_t)((frag_b + 255) / 256)), dim3(256), 0, c->stream, dev, bits_stride, nstmt, nrowsel, ksteps, MT, d_frag);
+  hipLaunchKernelGGL(k_witness_bits, dim3((uint32_t)((frag_b / 16 + 255) / 256)), dim3(256), 0, c->stream, dev, bits_stride, nstmt, nrowsel, ksteps, MT, d_frag);
   if (!src.dense) {
     uint32_t *d_rk = (uint32_t *)(dev + head_b + frag_b + part_b);
     const dim3 grid(nc / 128, (ksteps + kpc - 1) / kpc);
