@@ -473,19 +473,42 @@ template <int K, bool LAST>
 __global__ __launch_bounds__(256) void k_exact_seam(uint32_t *__restrict__ a, uint32_t N, const uint32_t *__restrict__ tw, const uint32_t *__restrict__ twi,
                                                     uint32_t half_max, Primes3 P, Crt C, uint32_t *__restrict__ out, uint32_t keep, size_t out_stride) {
   constexpr int R = 1 << K;
-  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x, qd = N >> K;  // (one block of length N per polynomial: s = 0)
-  if (j >= qd) return;
+  constexpr uint32_t qd = 2048;  // = N >> K: the launch is for N = 2^(11 + K) (one block of length N per polynomial: s = 0); a constant, so that the 3 R strided
+                                 // addresses are immediates off one base instead of 3 R register pairs
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= qd || N != (qd << K)) return;
   uint32_t *x = a + (size_t)blockIdx.y * 3 * N + j;
-  uint32_t r[3][R];
+  // prime by prime, Garner's digits as they become available (crt_coeff's arithmetic; x1 and x2 kept instead of the three residues).  K = 4 still takes 190 registers --
+  // the 32 twiddles and 16 points of a prime in flight at once -- i.e. 2 waves per SIMD: 89 us per 255 polynomials against 93 for the three-residue form and 131 for the
+  // four kernels it replaces; a 128-register build spills (444 bytes per lane) and was not kept
+  const NttPrime q1 = P.q[0], q2 = P.q[1], q3 = P.q[2];
+  uint32_t r[R], x1[R], x2[R], cf[R];
 #pragma unroll
-  for (int k = 0; k < 3; k++) {
+  for (int m = 0; m < R; m++) r[m] = x[(size_t)m * qd];
+  dit_regs<K>(r, j, qd, 2 * qd, twi, half_max, q1);  // block lengths 2 qd .. N
 #pragma unroll
-    for (int m = 0; m < R; m++) r[k][m] = x[(size_t)k * N + (size_t)m * qd];
-    dit_regs<K>(r[k], j, qd, 2 * qd, twi + (size_t)k * half_max, half_max, P.q[k]);  // block lengths 2 qd .. N
+  for (int m = 0; m < R; m++) x1[m] = mont_mul(r[m], C.ninv_std[0], q1.p, q1.ninv);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int m = 0; m < R; m++) r[m] = x[(size_t)N + (size_t)m * qd];
+  dit_regs<K>(r, j, qd, 2 * qd, twi + (size_t)half_max, half_max, q2);
+#pragma unroll
+  for (int m = 0; m < R; m++) {
+    const uint32_t r2 = mont_mul(r[m], C.ninv_std[1], q2.p, q2.ninv), x1m2 = x1[m] >= q2.p ? x1[m] - q2.p : x1[m];  // x1 < p1 < 2 p2
+    x2[m] = mont_mul(sub_mod(r2, x1m2, q2.p), C.inv_p1_p2, q2.p, q2.ninv);
   }
-  uint32_t cf[R];
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int m = 0; m < R; m++) cf[m] = crt_coeff(r[0][m], r[1][m], r[2][m], P, C);
+  for (int m = 0; m < R; m++) r[m] = x[(size_t)2 * N + (size_t)m * qd];
+  dit_regs<K>(r, j, qd, 2 * qd, twi + (size_t)2 * half_max, half_max, q3);
+#pragma unroll
+  for (int m = 0; m < R; m++) {
+    const uint32_t r3 = mont_mul(r[m], C.ninv_std[2], q3.p, q3.ninv);
+    const uint32_t x1m3 = x1[m] >= q3.p ? x1[m] - q3.p : x1[m], x2m3 = x2[m] >= q3.p ? x2[m] - q3.p : x2[m];
+    const uint32_t t3 = mont_mul(sub_mod(r3, x1m3, q3.p), C.inv_p1_p3, q3.p, q3.ninv);
+    const uint32_t x3 = mont_mul(sub_mod(t3, x2m3, q3.p), C.inv_p2_p3, q3.p, q3.ninv);
+    cf[m] = red_p32((uint64_t)red_p32(x1[m]) + red_p32((uint64_t)x2[m] * C.p1_mod) + red_p32((uint64_t)x3 * C.p1p2_mod));
+  }
   if (LAST) {
     out += (size_t)blockIdx.y * out_stride;
 #pragma unroll
@@ -498,10 +521,11 @@ __global__ __launch_bounds__(256) void k_exact_seam(uint32_t *__restrict__ a, ui
   for (int k = 0; k < 3; k++) {
     const NttPrime q = P.q[k];
 #pragma unroll
-    for (int m = 0; m < R; m++) r[k][m] = mont_mul(cf[m], q.r2, q.p, q.ninv);
-    dif_regs<K>(r[k], j, qd, N, tw + (size_t)k * half_max, half_max, q);  // block lengths N .. 2 qd
+    for (int m = 0; m < R; m++) r[m] = mont_mul(cf[m], q.r2, q.p, q.ninv);
+    dif_regs<K>(r, j, qd, N, tw + (size_t)k * half_max, half_max, q);  // block lengths N .. 2 qd
 #pragma unroll
-    for (int m = 0; m < R; m++) x[(size_t)k * N + (size_t)m * qd] = r[k][m];
+    for (int m = 0; m < R; m++) x[(size_t)k * N + (size_t)m * qd] = r[m];
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
