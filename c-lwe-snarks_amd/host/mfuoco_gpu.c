@@ -1163,14 +1163,24 @@ static void proofs_drain(proof_t *pis, const uint64_t *d_proofs, size_t count, i
     n[sl] = nk_;                                                                                                               \
     next += nk_;                                                                                                               \
   } while (0)
+  const double t_dr = tnow();
+  double t_wait = 0, t_conv = 0, t_last_arrival = 0;
   DRAIN_ISSUE(0);
   while (n[slot]) {
     if (next < count) DRAIN_ISSUE(slot ^ 1); else n[slot ^ 1] = 0;
+    const double t0 = tnow();
     HK(hipEventSynchronize(DR.ev[slot]));
+    const double t1 = tnow();
     struct conv_arg a = { pis + lo[slot], NULL, DR.pin[slot] };
     parallel_for(n[slot] * 5 * (size_t)(GAMMA_N + 1), proofs_from_limbs, &a);
+    t_wait += t1 - t0;
+    t_conv += tnow() - t1;
+    if (!n[slot ^ 1]) t_last_arrival = t1;
     slot ^= 1;
   }
+  if (tracing() && count > DRAIN_SLAB)
+    fprintf(stderr, "  drain of %zu proofs: %.2f ms waiting for slabs, %.2f converting them (in between); the last slab arrived %.2f ms in, the call left %.2f ms later\n", count,
+            t_wait, t_conv, t_last_arrival - t_dr, tnow() - t_last_arrival);
 #undef DRAIN_ISSUE
 }
 void mfuoco_gpu_proofs_to_host(proof_t *pis, const uint64_t *d_proofs, size_t count)
