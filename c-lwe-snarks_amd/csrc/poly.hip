@@ -873,10 +873,10 @@ int prepare_exact(mfh_ctx *c, const uint32_t *d_t, const std::vector<uint32_t> &
   if (S->dt != d - 1 || d < 2) return MFH_OK;
   const uint32_t logNc = ceil_log2(d), Nc = 1u << logNc;
   if (logNc + 1 > S->logmax) return MFH_OK;  // (the linear products below have 2 Nc - 1 coefficients)
+  if (!S->h_seen) HIP_TRY(c, hipHostMalloc(&S->h_seen, 64, hipHostMallocDefault));
   if (!S->d_need) {
     HIP_TRY(c, hipMalloc(&S->d_need, (size_t)(2 + kMaxBatch) * 4));
     HIP_TRY(c, hipMemsetAsync(S->d_need, 0, 8, c->stream));
-    HIP_TRY(c, hipHostMalloc(&S->h_seen, 64, hipHostMallocDefault));
   }
   *S->h_seen = 0;
   S->rest = 0;
