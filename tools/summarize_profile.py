@@ -24,7 +24,7 @@ if f:
     rows = list(csv.DictReader(open(f)))
     with open(os.path.join(out_dir, f"{tag}_kernel_stats.csv"), "w") as o:
         commit_ = sys.argv[2] if len(sys.argv) > 2 else os.popen("git -C %s rev-parse --short HEAD" % ROOT).read().strip()
-        o.write(f"# commit {commit_}: rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline   (MI355X, 1 GPU; default batch mode: the single-proof path (regenerated and resident), then the headline run, then the regenerate-per-group and resident-image variants of the same batch, then the LWE encryption and decryption batches).  k_mmstream_p = the persistent 16-group S + AS launches, one per super-group of 255 proofs (bench.py's roofline kernel), k_mmstream1 = single-group launches (b_w)\n")
+        o.write(f"# commit {commit_}: rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-drop-in   (MI355X, 1 GPU; default batch mode: the single-proof path (regenerated and resident), then the headline run, then the regenerate-per-group and resident-image variants of the same batch, then the LWE encryption and decryption batches).  k_mmstream_p = the persistent 16-group S + AS launches, one per super-group of 255 proofs (bench.py's roofline kernel), k_mmstream1 = single-group launches (b_w)\n")
         o.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
         for r in rows:
             o.write(",".join(['"' + r["Name"][:110].replace('"', "'") + '"', r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]]) + "\n")
