@@ -2,8 +2,8 @@
 //
 // The prover's only non-streaming step is  h = (v^2 - 1) / t  (reference src/snark.c:166-169, FLINT's
 // nmod_poly_pow / nmod_poly_sub / nmod_poly_div).  p - 1 = 2 * 2147483645 has 2-adicity 1, so there is no NTT mod p;
-// products are computed exactly over the integers with three NTT-friendly 31-bit primes + CRT (coefficients < 2^32,
-// length <= 2^22: every convolution coefficient is < 2^86 < p1*p2*p3 ~ 2^92.6) and reduced mod p afterwards.  Because every
+// products are computed exactly over the integers with three NTT-friendly 30-bit primes + CRT (coefficients < 2^32,
+// length <= 2^22: every convolution coefficient is < 2^86 < p1*p2*p3 ~ 2^89.3) and reduced mod p afterwards.  Because every
 // result is the canonical representative in [0, p), it is bit-identical to FLINT's whatever algorithm FLINT picks.
 // Division is a multiplication by the power-series inverse of rev(t), computed once per SSP by Newton iteration
 // (mfh_poly_prepare_t): q = rev( rev(A)[:n] * rev(t)^-1 mod x^n ), n = deg A - deg t + 1.
@@ -48,6 +48,30 @@ __host__ __device__ __forceinline__ uint32_t add_mod(uint32_t a, uint32_t b, uin
   return s >= p ? s - p : s;
 }
 __host__ __device__ __forceinline__ uint32_t sub_mod(uint32_t a, uint32_t b, uint32_t p) { return a >= b ? a - b : a + p - b; }
+// Lazy forms for the stages a kernel runs in registers (round 6; the primes are below 2^30 for them): values in [0, 2p) between stages, so that the product needs no
+// final subtraction and the difference no comparison -- the three quarter-rate multiplies of a butterfly stay, five of the ten instructions around them go
+// (tools/ntt_lazy_ubench.hip: 15 - 20 % of k_ntt_lds_mul8).  Every kernel still reads and writes CANONICAL residues: lz_canon on the way out.
+__device__ __forceinline__ uint32_t lz_mont(uint32_t a, uint32_t b, uint32_t p, uint32_t ninv) {  // a b < 2^32 p (a < 4p, b < p; or a, b < 2p)  ->  [0, 2p)
+  uint64_t t = (uint64_t)a * b;
+  uint32_t m = (uint32_t)t * ninv;
+  return (uint32_t)((t + (uint64_t)m * p) >> 32);
+}
+__device__ __forceinline__ uint32_t lz_add(uint32_t a, uint32_t b, uint32_t p2) {  // a, b in [0, 2p), p2 = 2p  ->  [0, 2p)   (s - 2p wraps when s < 2p)
+  uint32_t s = a + b;
+  return min(s, s - p2);
+}
+__device__ __forceinline__ uint32_t lz_canon(uint32_t a, uint32_t p) { return min(a, a - p); }  // [0, 2p) -> [0, p)
+// one butterfly of a decimation-in-frequency / decimation-in-time stage on lazy values
+__device__ __forceinline__ void lz_dif(uint32_t &x, uint32_t &y, uint32_t w, uint32_t p, uint32_t ninv) {
+  const uint32_t u = x, z = y;
+  x = lz_add(u, z, 2 * p);
+  y = lz_mont(u - z + 2 * p, w, p, ninv);  // u - z + 2p < 4p < 2^32
+}
+__device__ __forceinline__ void lz_dit(uint32_t &x, uint32_t &y, uint32_t w, uint32_t p, uint32_t ninv) {
+  const uint32_t u = x, z = lz_mont(y, w, p, ninv), d = u - z + 2 * p;
+  x = lz_add(u, z, 2 * p);
+  y = min(d, d - 2 * p);
+}
 
 // x mod (2^32 - 5) for x < 2^64:  2^32 = 5
 __host__ __device__ __forceinline__ uint32_t red_p32(uint64_t x) {
@@ -152,15 +176,12 @@ __global__ __launch_bounds__(256) void k_ntt_dif_multi(uint32_t *__restrict__ a,
     for (int m = 0; m < R; m++) {
       if ((m & h) == 0) {
         const uint32_t pos = j + (uint32_t)(m & (h - 1)) * qd;  // position inside the half block
-        const uint32_t w = t[(size_t)pos * tstep];
-        const uint32_t u = v[m], z = v[m + h];
-        v[m] = add_mod(u, z, q.p);
-        v[m + h] = mont_mul(sub_mod(u, z, q.p), w, q.p, q.ninv);
+        lz_dif(v[m], v[m + h], t[(size_t)pos * tstep], q.p, q.ninv);
       }
     }
   }
 #pragma unroll
-  for (int m = 0; m < R; m++) x[(size_t)m * qd] = v[m];
+  for (int m = 0; m < R; m++) x[(size_t)m * qd] = lz_canon(v[m], q.p);
 }
 // K consecutive DIT stages with block lengths len, 2len, ..., len<<(K-1) (inverse twiddles)
 template <int K>
@@ -188,15 +209,12 @@ __global__ __launch_bounds__(256) void k_ntt_dit_multi(uint32_t *__restrict__ a,
     for (int m = 0; m < R; m++) {
       if ((m & h) == 0) {
         const uint32_t pos = j + (uint32_t)(m & (h - 1)) * qd;
-        const uint32_t w = t[(size_t)pos * tstep];
-        const uint32_t u = v[m], z = mont_mul(v[m + h], w, q.p, q.ninv);
-        v[m] = add_mod(u, z, q.p);
-        v[m + h] = sub_mod(u, z, q.p);
+        lz_dit(v[m], v[m + h], t[(size_t)pos * tstep], q.p, q.ninv);
       }
     }
   }
 #pragma unroll
-  for (int m = 0; m < R; m++) x[(size_t)m * qd] = v[m];
+  for (int m = 0; m < R; m++) x[(size_t)m * qd] = lz_canon(v[m], q.p);
 }
 // the lowest B stages (block lengths 2^B .. 2, or 2 .. 2^B for DIT) of every contiguous 2^B block, in LDS.  B <= 11.
 template <bool DIT>
@@ -288,7 +306,7 @@ __global__ __launch_bounds__(256) void k_ntt_lds_mul(uint32_t *__restrict__ a, c
 // (every pass's 64 lanes then spread over the 32 banks twice, the minimum).  rhs: nullptr = squaring, else a cached full transform
 // (b_is_hat); two fresh operands keep the generic kernel above.
 __device__ __forceinline__ uint32_t lpad(uint32_t i) { return i + (i >> 5); }
-// K DIF stages (block lengths len, len/2, ...) on v[0 .. 2^K): element m sits at position j + m * qd of its block, qd = len >> K
+// K DIF stages (block lengths len, len/2, ...) on v[0 .. 2^K): element m sits at position j + m * qd of its block, qd = len >> K.  LAZY values: in [0, 2p) in and out
 // PAD: the twiddle table lies in LDS at lpad() indices -- the stages read it with power-of-two strides (8, 16, ... entries between neighbouring lanes: 4 - 8 of
 // the 64 banks, PMC round 3: SQ_LDS_BANK_CONFLICT was a quarter of k_ntt_lds_mul8's cycles); one skipped word per 32 spreads every such stride over the banks.
 // (Measured, round 4: the chain of 255 statements takes the same 1.80 ms with and without the padding -- the kernel is bound by its Montgomery multiplies and
@@ -305,10 +323,7 @@ __device__ __forceinline__ void dif_regs(uint32_t *v, uint32_t j, uint32_t qd, u
     for (int m = 0; m < R; m++) {
       if ((m & h) == 0) {
         const uint32_t ti_ = (j + (uint32_t)(m & (h - 1)) * qd) * tstep;
-        const uint32_t w = PAD ? t[ti_ + (ti_ >> 5)] : t[(size_t)ti_];
-        const uint32_t u = v[m], z = v[m + h];
-        v[m] = add_mod(u, z, q.p);
-        v[m + h] = mont_mul(sub_mod(u, z, q.p), w, q.p, q.ninv);
+        lz_dif(v[m], v[m + h], PAD ? t[ti_ + (ti_ >> 5)] : t[(size_t)ti_], q.p, q.ninv);
       }
     }
   }
@@ -326,10 +341,7 @@ __device__ __forceinline__ void dit_regs(uint32_t *v, uint32_t j, uint32_t qd, u
     for (int m = 0; m < R; m++) {
       if ((m & h) == 0) {
         const uint32_t ti_ = (j + (uint32_t)(m & (h - 1)) * qd) * tstep;
-        const uint32_t w = PAD ? t[ti_ + (ti_ >> 5)] : t[(size_t)ti_];
-        const uint32_t u = v[m], z = mont_mul(v[m + h], w, q.p, q.ninv);
-        v[m] = add_mod(u, z, q.p);
-        v[m + h] = sub_mod(u, z, q.p);
+        lz_dit(v[m], v[m + h], PAD ? t[ti_ + (ti_ >> 5)] : t[(size_t)ti_], q.p, q.ninv);
       }
     }
   }
@@ -389,10 +401,10 @@ __global__ __launch_bounds__(256) void k_ntt_lds_mul8(uint32_t *__restrict__ a, 
     const uint4 b0 = bp[0], b1 = bp[1];
     const uint32_t bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
-    for (int m = 0; m < 8; m++) v[m] = mont_mul(v[m], bb[m], q.p, q.ninv);
+    for (int m = 0; m < 8; m++) v[m] = lz_mont(v[m], bb[m], q.p, q.ninv);
   } else {
 #pragma unroll
-    for (int m = 0; m < 8; m++) v[m] = mont_mul(v[m], v[m], q.p, q.ninv);
+    for (int m = 0; m < 8; m++) v[m] = lz_mont(v[m], v[m], q.p, q.ninv);  // (2p)^2 < 2^32 p
   }
   // ---- inverse: block lengths 2 .. 2048
   dit_regs<2, true>(v, 0, 1, 2, ti, half_max, q);
@@ -416,7 +428,7 @@ __global__ __launch_bounds__(256) void k_ntt_lds_mul8(uint32_t *__restrict__ a, 
   for (int m = 0; m < 8; m++) v[m] = sm[lpad(i1 + 256 * m)];
   dit_regs<3, true>(v, tid, 256, 512, ti, half_max, q);
 #pragma unroll
-  for (int m = 0; m < 8; m++) a[base + i1 + 256 * m] = v[m];
+  for (int m = 0; m < 8; m++) a[base + i1 + 256 * m] = lz_canon(v[m], q.p);
 }
 
 __global__ void k_pointwise(uint32_t *__restrict__ a, const uint32_t *__restrict__ b, uint32_t N, Primes3 P) {
@@ -524,7 +536,7 @@ __global__ __launch_bounds__(256) void k_exact_seam(uint32_t *__restrict__ a, ui
     for (int m = 0; m < R; m++) r[m] = mont_mul(cf[m], q.r2, q.p, q.ninv);
     dif_regs<K>(r, j, qd, N, tw + (size_t)k * half_max, half_max, q);  // block lengths N .. 2 qd
 #pragma unroll
-    for (int m = 0; m < R; m++) x[(size_t)k * N + (size_t)m * qd] = r[m];
+    for (int m = 0; m < R; m++) x[(size_t)k * N + (size_t)m * qd] = lz_canon(r[m], q.p);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -671,16 +683,17 @@ struct PolyState {
 
 namespace {
 
-const uint32_t kPrimes[3] = {2013265921u, 1811939329u, 2113929217u};  // 15*2^27+1, 27*2^26+1, 63*2^25+1
-const uint32_t kRoots[3] = {31u, 13u, 5u};                             // primitive roots (checked at init)
+// below 2^30 (the lazy butterflies keep values in [0, 2p) and form u - z + 2p < 4p in 32 bits), 2-adicity 23, product 2^89.35; p1 < 2 p2, p1 < 2 p3, p2 < 2 p3 (k_crt)
+const uint32_t kPrimes[3] = {998244353u, 897581057u, 880803841u};  // 119*2^23+1, 107*2^23+1, 105*2^23+1
+const uint32_t kRoots[3] = {3u, 3u, 26u};                          // primitive roots (checked at init)
 constexpr uint32_t kMaxBatch = 21845;  // polynomials side by side: 3 per polynomial on grid.y (<= 65535)
 
 uint32_t to_mont(uint64_t x, const NttPrime &q) { return (uint32_t)(((unsigned __int128)(x % q.p) << 32) % q.p); }
 
 int poly_init(mfh_ctx *c, uint32_t logmax) {
   if (c->poly && c->poly->logmax >= logmax) return MFH_OK;
-  if (logmax > 24) {
-    c->err = "polynomial too long for the NTT primes (max 2^24)";
+  if (logmax > 23) {
+    c->err = "polynomial too long for the NTT primes (max 2^23)";
     return MFH_EUNSUPPORTED;
   }
   delete c->poly;
